@@ -204,6 +204,22 @@ def cli_case(name: str, spec: dict, argv_tail: list[str], seed_py: int, seed_np:
         }
         if rmt_text is not None:
             (case_dir / "case.rmt").write_text(rmt_text)
+        if code is None:
+            # the settings tree the reference derived for this run (rebuilt; RNG-free)
+            old = sys.argv
+            sys.argv = ["mutation-simulator"] + argv
+            try:
+                with _capture_ref_stderr(io.StringIO()):
+                    a2 = ref.get_args()
+                    f2 = ref_util.load_fasta(a2.infile)
+                    sim2 = (SimulationSettings.from_args(a2, f2, True) if a2.mode == "args"
+                            else SimulationSettings.from_rmt(a2.rmtfile, f2, True))
+                meta["sim"] = dump_sim(sim2)
+                meta["contigs"] = [{"name": f2[k].name, "long_name": f2[k].long_name,
+                                    "length": len(f2[k]), "lenc": f2.faidx.index[k].lenc}
+                                   for k in f2.keys()]
+            finally:
+                sys.argv = old
         if exc is None and code is None:
             fa = out_fa.read_bytes()
             vcf = mask_vcf(out_vcf.read_bytes())
@@ -601,7 +617,7 @@ def make_plan():
             np.random.seed(sn)
             entry = {"name": name, "input_spec": spec, "argv_tail": argv, "seed_py": sp,
                      "seed_np": sn, "mut_block": [[t.name, v] for t, v in sc.sim.mut_block.items()],
-                     "contigs": []}
+                     "sim": dump_sim(sc.sim), "contigs": []}
             for chrom in sc.sim.chromosomes:
                 L = len(sc.fasta[chrom.number])
                 for rng in chrom.range_definitions:
@@ -611,6 +627,7 @@ def make_plan():
                     muts, tls, tlis = sc.mutator._Mutator__get_mutations(rng, L)
                     entry["contigs"].append({
                         "number": chrom.number, "length": L, "start": rng.start, "stop": rng.stop,
+                        "range_index": chrom.range_definitions.index(rng),
                         "n_kept": len(muts),
                         "records": [[m.start, m.type.name, m.stop] for _, m in sorted(muts.items())]
                         if len(muts) <= 2500 else None,
