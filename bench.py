@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mbases mutated / s on a synthetic 3 Gb, 24-contig genome, ARGS SNP rate 0.01,
+titv 2.0 (BASELINE.json configs[1]), bit-compatible RNG streams (seeds 42/42).
+
+A "step" is one pass of the hot path -- PLAN (position/type draw -> record table) + APPLY (HIP
+rewrite kernel) -- over the whole genome, with the genome already resident in HBM as uint8 and the
+results (mutated stream + record table) left in HBM.  The driver contract (flags, barrier + sync
+around exactly K steps, max over ranks, ONE JSON line from rank 0) is kept; torch.distributed is
+used only as rendezvous/barrier plumbing when launched with N > 1, the product path is ctypes ->
+libmsim.so.
+
+    python bench.py                      # 1 GPU, K=3, W=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Extra keys in the JSON line: "roofline" (rewrite kernel vs HBM peak, measured live with HIP events
+on the library's stream) and "cpu_baseline" (the CPU oracle timed on a bounded sample, rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+for p in (ROOT, ROOT / "mutation-simulator_amd", ROOT / "tests", ROOT / "tests" / "golden"):
+    if str(p) not in sys.path:
+        sys.path.insert(0, str(p))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+# GRCh38 primary chromosome lengths (chr1-22, X, Y); scaled so the total is exactly `total`
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636,
+          138394717, 133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345,
+          83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+
+
+def contig_lengths(total: int) -> list[int]:
+    s = sum(GRCH38)
+    out = [int(round(x * total / s)) for x in GRCH38]
+    out[-1] += total - sum(out)
+    return out
+
+
+def lpt_partition(lengths: list[int], n: int) -> list[list[int]]:
+    """Longest-processing-time bin packing of contigs over ranks."""
+    bins = [[] for _ in range(n)]
+    load = [0] * n
+    for idx in sorted(range(len(lengths)), key=lambda i: -lengths[i]):
+        b = load.index(min(load))
+        bins[b].append(idx)
+        load[b] += lengths[idx]
+    return [sorted(b) for b in bins]
+
+
+def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
+    """Settings tree for `args -sn 0.01 -titv 2.0` over the synthetic contigs (host package)."""
+    import mutation_simulator_amd as msa
+
+    class Rec:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    class FakeFasta:     # only contig count + lengths are needed to build settings
+        def __init__(self, ls):
+            self.ls = ls
+
+        def keys(self):
+            return [f"chr{i+1}" for i in range(len(self.ls))]
+
+        def __getitem__(self, k):
+            return Rec(self.ls[k] if isinstance(k, int) else self.ls[int(k[3:]) - 1])
+
+    argv = ["synthetic.fa", "args", "-sn", repr(snp), "-titv", repr(titv)] + list(extra or [])
+    args = msa.get_args(argv)
+    sim = msa.SimulationSettings.from_args(args, FakeFasta(lengths), True)
+    return sim
+
+
+def one_step(eng, sim, cids, my_contigs, plan_all=True):
+    """PLAN every contig in order (the RNG streams chain across contigs), APPLY this rank's."""
+    from mutation_simulator_amd import mutator as mm
+    eng.seed(42, 42)
+    mine = set(my_contigs)
+    for chrom in sim.chromosomes:
+        i = chrom.number
+        eng.plan_contig(cids[i], mm.plan_descriptors(chrom))
+        if i in mine:
+            eng.apply_contig(cids[i])
+    eng.sync()
+
+
+def cpu_baseline(sample_total: int, n_contigs: int = 4):
+    """CPU oracle (single-threaded C restatement of the reference path) on a bounded sample of the
+    same workload: `n_contigs` contigs totalling `sample_total` bases, -sn 0.01 -titv 2.0, 42/42."""
+    from oracle import oracle as orc
+    from test_gpu_parity import synth_host  # same generator as the device kernel
+    from test_host_settings import dump_sim
+    lengths = [sample_total // n_contigs] * n_contigs
+    sim = workload_settings(lengths)
+    contigs = [{"name": f"chr{i+1}", "long_name": f"chr{i+1} synthetic", "lenc": 60,
+                "bases": synth_host(L, 1000 + i)} for i, L in enumerate(lengths)]
+    o = orc.Oracle()
+    o.seed(42, 42)
+    t0 = time.perf_counter()
+    o.run_genome(contigs, dump_sim(sim), "synthetic.fa")
+    dt = time.perf_counter() - t0
+    total = sum(lengths)
+    return {"value": round(total / dt / 1e6, 3), "unit": "Mbases/s", "cores": 1, "kind": "port",
+            "sample": f"{n_contigs} contigs x {lengths[0]/1e6:.0f} Mb, args -sn 0.01 -titv 2.0, seeds 42/42, "
+                      f"Fasta framing + VCF text included ({dt:.1f} s of CPU work)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--total-bases", type=int, default=3_000_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mutation_simulator_amd import _ffi
+    from mutation_simulator_amd import mutator as mm
+
+    lengths = contig_lengths(a.total_bases)
+    sim = workload_settings(lengths)
+    parts = lpt_partition(lengths, world)
+    mine = parts[rank]
+
+    eng = _ffi.Engine(local_rank)
+    eng.set_params(mm.params_descriptor(sim))
+    # genome resident in HBM before the timed region (3 GB; every rank holds every contig so that
+    # contig numbering is global -- 288 GB of HBM make the replica free)
+    cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
+    eng.sync()
+
+    def barrier():
+        eng.sync()
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step(eng, sim, cids, mine)
+    eng.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_step(eng, sim, cids, mine)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    st = eng.stats()
+
+    if rank == 0:
+        total = sum(lengths)
+        ms_per_step = dt / a.steps * 1e3
+        value = total * a.steps / dt / 1e6
+        launches = max(st["apply_launches"], 1)
+        alg_bytes = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
+        k_ms = st["apply_kernel_ms"]
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        line = {
+            "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01",
+            "value": round(value, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "ARGS mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
+                                   "-sn 0.01 -titv 2.0, CPython/NumPy-compatible MT19937 streams seeded 42/42",
+                       "total_bases": total, "contigs": len(lengths),
+                       "parallelism": f"contigs sharded over {world} GPU(s) (LPT), PLAN replicated"},
+            "stages_ms_per_step": {
+                "plan_host": round(st["plan_host_ms"] / a.steps, 3),
+                "plan_gpu": round(st["plan_gpu_ms"] / a.steps, 3),
+                "record_upload": round(st["upload_ms"] / a.steps, 3),
+                "apply_all_kernels": round(st["apply_ms"] / a.steps, 3),
+                "apply_rewrite_kernel": round(k_ms / a.steps, 3)},
+            "records_per_step": st["records"] // a.steps,
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "msim::k_rewrite",
+                         "algorithmic_bytes_per_launch": alg_bytes // launches,
+                         "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_sample)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * msim.h -- C-ABI of libmsim.so: the MI355X-native mutation-injection path.
+ *
+ * The reference (mkpython3/Mutation-Simulator 3.0.2) is pure Python and has NO plugin / FFI /
+ * native boundary of its own: the hot path sits behind the Python class `Mutator`
+ * (mutation_simulator/mutator.py:73-479, called from __main__.py:80-85).  This header is the
+ * boundary a maintainer would bind with ctypes to replace that class's internals; each entry
+ * point cites the reference code whose work it takes over (paths relative to
+ * /root/reference/mutation_simulator/).  INTEGRATION.md shows the ctypes stub.
+ *
+ * Contract: plain C, opaque handle, caller-owned host buffers, int return codes (0 = ok) with
+ * msim_last_error() for the text; one context per process/GPU; like the reference (a single
+ * thread driving two global RNGs) a context is NOT thread-safe.  No Python, torch or HIP types
+ * cross this line.  Everything floating point on the path (rate sums -> k, chances -> cdf, titv ->
+ * p_ti) is evaluated by the caller with the reference's own Python expressions and arrives here
+ * as integers (see msim_range / msim_params), so the device work is integer/byte only.
+ *
+ * Two phases -- possible because RNG use never depends on genome content:
+ *   PLAN   two MT19937 streams -> a position-sorted table of 16-byte mutation records per contig
+ *   APPLY  records + uint8 genome in HBM -> mutated uint8 stream in HBM (HBM-bandwidth bound)
+ */
+#ifndef MSIM_H
+#define MSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSIM_ABI_VERSION 1
+
+/* ---- return codes ---------------------------------------------------------------------------- */
+#define MSIM_OK               0
+#define MSIM_ERR_ARG          1   /* bad argument / call order                                      */
+#define MSIM_ERR_HIP          2   /* HIP runtime failure (no device, OOM, launch error)             */
+#define MSIM_ERR_VALUE        3   /* reference raises ValueError("Sample larger than population or
+                                     is negative") -- util.py:104 via random.sample                */
+#define MSIM_ERR_KEY          4   /* reference raises KeyError(base): transversion of a base outside
+                                     A,G,T,C,N -- mutator.py:449-455; see msim_key_error()         */
+#define MSIM_ERR_UNSUPPORTED  5   /* valid for the reference, outside this build (TL/TLI, >=4 GiB)  */
+#define MSIM_ERR_NOMEM        6
+
+/* ---- mutation types: numerically identical to mut_types.py:6-12 --------------------------------- */
+#define MSIM_SN  1
+#define MSIM_IN  2
+#define MSIM_DE  3
+#define MSIM_DU  4
+#define MSIM_IV  5
+#define MSIM_TL  6
+#define MSIM_TLI 7
+
+/* ---- msim_create flags --------------------------------------------------------------------- */
+#define MSIM_PLAN_AUTO   0u      /* GPU sampler where the stream structure parallelises, else host */
+#define MSIM_PLAN_HOST   1u      /* force the sequential host planner (cross-check / debugging)     */
+#define MSIM_PLAN_GPU    2u      /* force the GPU sampler; MSIM_ERR_UNSUPPORTED where it cannot run  */
+
+typedef struct msim_ctx msim_ctx;
+
+/* One mutation -- the reference's `Mutation` object (mutator.py:26-50) in 16 bytes.
+ * Positions are 0-based inclusive like the reference's.  Tables are sorted by pos and hold only
+ * the mutations __mutate_sequence actually visits (entries swallowed by an earlier DE/IV/DU span,
+ * mutator.py:376/386/398, are dropped: they draw no random numbers and emit nothing).            */
+typedef struct msim_record {
+    uint32_t pos;     /* Mutation.start (dict key)                                               */
+    uint32_t stop;    /* Mutation.stop; for IN: pos + insert_len - 1 (mutator.py:344)            */
+    uint32_t extra;   /* IN: offset of the insert's bases in the contig's insert pool             */
+    uint8_t  type;    /* MSIM_SN .. MSIM_TLI                                                     */
+    uint8_t  aux;     /* SN: 0 = transition, 1/2 = transversion table column 0/1 (mutator.py:428-463) */
+    uint16_t rsv;
+} msim_record;
+
+/* One RangeDefinition that has mutations (rmt.py:166-189 + MutationSettings rmt.py:79-163),
+ * reduced to the integers __get_mutations (mutator.py:144-214) needs.                            */
+typedef struct msim_range {
+    int64_t  start, stop;     /* 0-based inclusive                                                */
+    int64_t  k;               /* int(((stop-start)+1) * sum(rates))           mutator.py:225       */
+    int64_t  setsize;         /* CPython sample(): 21 + 4**ceil(log(3k,4)) if k>5 else 21          */
+    int32_t  n_types;         /* len(mut_chances), dict order                 mutator.py:171-173   */
+    int32_t  types[8];        /* MSIM_* ids in that order                                          */
+    uint64_t cdf_thr[8];      /* ceil(cdf_j * 2^53), cdf = cumsum(p)/cumsum(p)[-1]: the type drawn
+                                 for a 53-bit NumPy sample m is types[#{j: cdf_thr[j] <= m}]       */
+    int64_t  min_len[8];      /* mut_lengs["min"/"max"], indexed by MSIM_* id                      */
+    int64_t  max_len[8];
+} msim_range;
+
+/* SimulationSettings.mut_block / .titv (rmt.py:326-352) */
+typedef struct msim_params {
+    int64_t  block[8];        /* indexed by MSIM_* id; min over ids 1..7 is the sampling distance d */
+    uint64_t ti_lim;          /* floor(p_ti * 2^53) + 1, p_ti = titv*(1/(titv+1)); 0 if p_ti is NaN:
+                                 transition iff the 53-bit sample m < ti_lim  (p <= p_ti,
+                                 mutator.py:436-438)                                               */
+} msim_params;
+
+typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times on the ctx stream */
+    double plan_host_ms;      /* host planner wall time (sequential RNG chain)                      */
+    double plan_gpu_ms;       /* GPU sampler kernels                                                */
+    double upload_ms;         /* record table H2D                                                   */
+    double apply_ms;          /* APPLY kernels (scan + tile index + rewrite)                        */
+    double apply_kernel_ms;   /* the rewrite kernel alone (roofline kernel)                         */
+    uint64_t apply_launches;  /* rewrite-kernel launches accumulated since msim_reset_stats         */
+    uint64_t bytes_in, bytes_out, records;   /* algorithmic traffic of those launches               */
+    uint64_t py_words, np_words;             /* MT19937 words consumed from each stream             */
+} msim_timing;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+int  msim_abi_version(void);
+int  msim_create(int device_id, uint32_t flags, msim_ctx **out);     /* Mutator.__init__ mutator.py:79 */
+void msim_destroy(msim_ctx *ctx);                                     /* Mutator.close    mutator.py:95 */
+const char *msim_last_error(const msim_ctx *ctx);                     /* "" when none; ctx may be NULL  */
+int  msim_device_name(const msim_ctx *ctx, char *dst, int cap);
+int  msim_sync(msim_ctx *ctx);
+
+/* ---- the two global RNGs the reference draws from ---------------------------------------------- */
+/* random.seed(int) == init_by_array(little-endian 32-bit limbs of abs(seed));
+ * numpy.random.seed(int) == init_genrand(seed).  (mutator.py:4,8; util.py:5)                      */
+int msim_seed(msim_ctx *ctx, const uint32_t *py_key, int n_key, uint32_t np_seed);
+/* Hand over / read back raw MT19937 states (random.getstate()[1], numpy.random.get_state()[1:3]) so a
+ * caller that seeded the Python generators itself gets the reference's exact stream, and can put the
+ * advanced state back afterwards.  stream: 0 = CPython `random`, 1 = numpy.random.                 */
+int msim_set_mt_state(msim_ctx *ctx, int stream, const uint32_t mt[624], int pos);
+int msim_get_mt_state(msim_ctx *ctx, int stream, uint32_t mt[624], int *pos);
+
+/* ---- genome in HBM ----------------------------------------------------------------------------- */
+/* Upload one contig (upper-cased bases, what pyfaidx hands the reference: util.py:84-88).
+ * Contigs are numbered in call order like fasta[i].                                                */
+int msim_add_contig(msim_ctx *ctx, const uint8_t *bases_upper, uint64_t len, int *contig);
+/* Synthesize i.i.d. uniform A/C/G/T directly in HBM: base(i) = "ACGT"[mix64(seed + i) >> 62]
+ * (same function in tests/ for cross-checking).  Benchmark input.                  */
+int msim_add_contig_synthetic(msim_ctx *ctx, uint64_t len, uint64_t seed, int *contig);
+int msim_contig_length(msim_ctx *ctx, int contig, uint64_t *len);
+int msim_read_contig(msim_ctx *ctx, int contig, uint64_t offset, uint64_t n, uint8_t *dst);
+int msim_clear(msim_ctx *ctx);            /* drop all contigs and results, keep RNG states          */
+
+/* ---- PLAN: Mutator.__get_mutations + the RNG draws of __mutate_sequence -------------------------- */
+int msim_set_params(msim_ctx *ctx, const msim_params *params);
+/* One iteration of mutate()'s contig loop up to the rewrite (mutator.py:111-131 + the SNP/insert
+ * draws of :334-358 in position order).  Consumes both streams exactly as the reference does and
+ * leaves the contig's record table (+ insert pool) in HBM.  Contigs must be planned in index order
+ * -- the streams are chained across contigs.                                                       */
+int msim_plan_contig(msim_ctx *ctx, int contig, const msim_range *ranges, int n_ranges);
+/* 1 if the last plan of this contig left `muts` empty (warning at mutator.py:125-129).             */
+int msim_plan_was_empty(msim_ctx *ctx, int contig, int *empty);
+
+/* ---- APPLY: Mutator.__mutate_sequence (mutator.py:318-426) -------------------------------------- */
+int msim_apply_contig(msim_ctx *ctx, int contig);
+/* If apply hit the reference's KeyError: the offending (ambiguity-converted) base and position.    */
+int msim_key_error(msim_ctx *ctx, int contig, uint8_t *base, uint64_t *pos);
+
+int msim_result_sizes(msim_ctx *ctx, int contig, uint64_t *out_len, uint64_t *n_records,
+                      uint64_t *insert_pool_len);
+int msim_fetch_sequence(msim_ctx *ctx, int contig, uint64_t offset, uint64_t n, uint8_t *dst);
+int msim_fetch_records(msim_ctx *ctx, int contig, msim_record *dst, uint8_t *insert_pool_dst);
+/* 64-bit FNV-style checksum of the mutated stream computed on the device (parity at full size).   */
+int msim_result_checksum(msim_ctx *ctx, int contig, uint64_t *sum);
+int msim_release_result(msim_ctx *ctx, int contig);
+
+/* ---- VCF text (vcf_writer.py:118-126 + record construction mutator.py:334-399) ------------------ */
+/* Render the record lines of one contig.  Stateless host helper: `bases` is the INPUT contig.
+ * Call with out == NULL to get the size.  Lines whose REF == ALT are suppressed like the reference. */
+int msim_render_vcf(const msim_record *recs, uint64_t n_records, const uint8_t *insert_pool,
+                    const uint8_t *bases, uint64_t len, const char *seq_name,
+                    char *out, uint64_t cap, uint64_t *needed);
+
+/* ---- stats -------------------------------------------------------------------------------------- */
+int msim_stats(msim_ctx *ctx, msim_timing *out);
+int msim_reset_stats(msim_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSIM_H */

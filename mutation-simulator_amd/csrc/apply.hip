@@ -1,0 +1,537 @@
+// APPLY: records + uint8 genome in HBM -> mutated uint8 stream in HBM.   gfx950 (MI355X) only.
+//
+// Takes over Mutator.__mutate_sequence (mutator.py:318-426), i.e. the per-base Python loop that is
+// ~96 % of the reference's wall time, as an output-centric streaming rewrite:
+//
+//   1. k_delta_* : per-record length delta -> exclusive scan -> output offset of every record
+//      (the "wavefront scan for the length delta"; three small kernels, records only).
+//   2. k_tile_index : for every 16 KiB output tile the last record starting at or before it.
+//   3. k_rewrite : one workgroup per output tile.  The tile's record window (offset / end / source /
+//      type) is staged in LDS; every lane owns 16 consecutive OUTPUT bytes per iteration, finds its
+//      governing record by binary search in LDS and
+//        - pure copy run      : one 16-B read at the shifted source, one aligned 16-B store
+//        - copy run with SNPs : same, then patches the SNP bytes in registers through an LDS LUT
+//        - anything else      : byte-exact slow path (insert pool, reverse-complement, duplication)
+//      Stores are always full aligned 16-B vectors of the output stream; loads are dword-aligned
+//      dwordx4 + dword with v_alignbyte for the sub-dword shift.  The kernel is HBM-bound: per
+//      output byte it reads one input byte and writes one output byte (+ 20 B per record).
+//
+// Integer/byte work only -- no MFMA.  Roofline: HBM bandwidth.
+#include <algorithm>
+
+#include "ctx.h"
+
+namespace msim {
+
+namespace {
+
+constexpr int THREADS = 256;
+constexpr int GROUP = 16;                              // output bytes per lane per iteration
+constexpr int ITERS = 4;
+constexpr int TILE = THREADS * GROUP * ITERS;          // 16384 output bytes per workgroup
+constexpr int REC_CAP = 1024;                          // records staged in LDS per tile
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_BLOCK = THREADS * SCAN_ITEMS;
+
+// LUT layout in the 1280-byte table (built on the host, ctx creation):
+//   [0,256)     snp, aux 0 : transition(conv(x))                      mutator.py:77,463
+//   [256,512)   snp, aux 1 : transversion column 0 of conv(x), 0 = KeyError   mutator.py:449-455
+//   [512,768)   snp, aux 2 : transversion column 1
+//   [768,1024)  conv(x)    : non_ambiguous                            mutator.py:75
+//   [1024,1280) comp(conv(x))                                         mutator.py:76,383
+constexpr int LUT_BYTES = 1280;
+
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void rec_lengths(const msim_record &r, uint32_t &outlen, uint32_t &inlen) {
+    const uint32_t len = r.stop - r.pos + 1;
+    switch (r.type) {
+        case MSIM_SN: outlen = 1; inlen = 1; break;
+        case MSIM_IN: outlen = len + 1; inlen = 1; break;          // insert, then the base itself
+        case MSIM_DE: outlen = 0; inlen = len; break;
+        case MSIM_IV: outlen = len; inlen = len; break;
+        case MSIM_DU: outlen = 2 * len; inlen = len; break;
+        default: outlen = 0; inlen = 0; break;
+    }
+}
+
+// ------------------------------------------------------------------ 1. offsets (delta scan)
+__global__ __launch_bounds__(THREADS) void k_delta_reduce(const msim_record *__restrict__ recs, uint32_t n,
+                                                          long long *__restrict__ block_sums) {
+    __shared__ long long red[THREADS / 64];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    long long s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) {
+            uint32_t ol, il;
+            rec_lengths(recs[base + i], ol, il);
+            s += (long long)ol - (long long)il;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < THREADS / 64; w++) t += red[w];
+        block_sums[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of block_sums[0..nb) in place, total to block_sums[nb]; single workgroup
+__global__ __launch_bounds__(1024) void k_scan_sums(long long *__restrict__ block_sums, uint32_t nb) {
+    __shared__ long long buf[1024];
+    __shared__ long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const long long v = i < nb ? block_sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            long long t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const long long incl = buf[threadIdx.x];
+        const long long c = carry;
+        if (i < nb) block_sums[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[nb] = carry;
+}
+
+__global__ __launch_bounds__(THREADS) void k_offsets(const msim_record *__restrict__ recs, uint32_t n,
+                                                     const long long *__restrict__ block_sums,
+                                                     uint32_t *__restrict__ off) {
+    __shared__ long long part[THREADS];
+    const uint32_t base = blockIdx.x * SCAN_BLOCK + threadIdx.x * SCAN_ITEMS;
+    long long d[SCAN_ITEMS];
+    long long s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        d[i] = 0;
+        if (base + i < n) {
+            uint32_t ol, il;
+            rec_lengths(recs[base + i], ol, il);
+            d[i] = (long long)ol - (long long)il;
+        }
+        s += d[i];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < THREADS; o <<= 1) {
+        long long t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    long long run = block_sums[blockIdx.x] + part[threadIdx.x] - s;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) off[base + i] = (uint32_t)((long long)recs[base + i].pos + run);
+        run += d[i];
+    }
+}
+
+// ------------------------------------------------------------------ 2. tile index
+// first[t] = index of the last record whose output offset is <= t*TILE, or -1
+__global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restrict__ off, uint32_t n,
+                                                        int32_t *__restrict__ first, uint32_t n_entries) {
+    const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
+    if (t >= n_entries) return;
+    const uint64_t target = (uint64_t)t * TILE;
+    uint32_t lo = 0, hi = n;                               // upper bound: first index with off > target
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)off[mid] <= target) lo = mid + 1; else hi = mid;
+    }
+    first[t] = (int32_t)lo - 1;
+}
+
+// ------------------------------------------------------------------ 3. rewrite
+__device__ __forceinline__ u32x4 load16_shifted(const uint8_t *__restrict__ in, uint64_t src) {
+    // 16 bytes starting at an arbitrary byte address: dword-aligned dwordx4 + dword, then a funnel
+    // shift per output dword (v_alignbyte_b32).
+    const uint64_t a = src & ~3ull;
+    const uint32_t sh = (uint32_t)(src & 3ull);
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(in + a);
+    const uint32_t w4 = *reinterpret_cast<const uint32_t *>(in + a + 16);
+    u32x4 r;
+    r.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
+    r.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
+    r.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
+    r.w = __builtin_amdgcn_alignbyte(w4, v.w, sh);
+    return r;
+}
+
+__device__ __forceinline__ uint32_t get_byte(const u32x4 &v, uint32_t idx) {
+    const uint32_t w = (idx >> 2) == 0 ? v.x : (idx >> 2) == 1 ? v.y : (idx >> 2) == 2 ? v.z : v.w;
+    return (w >> ((idx & 3) * 8)) & 0xffu;
+}
+__device__ __forceinline__ void set_byte(u32x4 &v, uint32_t idx, uint32_t b) {
+    const uint32_t sh = (idx & 3) * 8;
+    const uint32_t m = ~(0xffu << sh), x = b << sh;
+    const uint32_t wi = idx >> 2;
+    v.x = wi == 0 ? (v.x & m) | x : v.x;
+    v.y = wi == 1 ? (v.y & m) | x : v.y;
+    v.z = wi == 2 ? (v.z & m) | x : v.z;
+    v.w = wi == 3 ? (v.w & m) | x : v.w;
+}
+
+struct RecWin {                 // the tile's record window in LDS
+    uint32_t o[REC_CAP];        // output offset of the record's own bytes
+    uint32_t e[REC_CAP];        // end of the record's own bytes (o + outlen)
+    uint32_t s[REC_CAP];        // input position where the copy run after the record starts
+    uint32_t m[REC_CAP];        // type | aux << 8
+};
+
+template <bool IN_LDS>
+struct RecAccess {
+    const RecWin *win;
+    const msim_record *recs;
+    const uint32_t *off;
+    int32_t r_lo;
+    __device__ __forceinline__ uint32_t O(int32_t j) const { return IN_LDS ? win->o[j - r_lo] : off[j]; }
+    __device__ __forceinline__ void all(int32_t j, uint32_t &o, uint32_t &e, uint32_t &s, uint32_t &m) const {
+        if (IN_LDS) {
+            const int32_t q = j - r_lo;
+            o = win->o[q]; e = win->e[q]; s = win->s[q]; m = win->m[q];
+        } else {
+            const msim_record r = recs[j];
+            uint32_t ol, il;
+            rec_lengths(r, ol, il);
+            o = off[j]; e = o + ol; s = r.pos + il; m = (uint32_t)r.type | ((uint32_t)r.aux << 8);
+        }
+    }
+};
+
+__device__ __forceinline__ void report_key_error(unsigned long long *err, uint64_t pos, uint32_t conv_base) {
+    atomicMin(err, (unsigned long long)((pos << 8) | conv_base));
+}
+
+// byte-exact slow path: output byte at absolute offset P, governed by record j (or none if j < 0)
+__device__ __forceinline__ uint32_t slow_byte(uint64_t P, int32_t j, uint32_t o, uint32_t e, uint32_t s,
+                                              const uint8_t *__restrict__ in, const uint8_t *__restrict__ pool,
+                                              const msim_record *__restrict__ recs, const uint8_t *lut,
+                                              unsigned long long *err) {
+    if (j < 0) return in[P];
+    if (P >= e) return in[(uint64_t)s + (P - e)];
+    const msim_record r = recs[j];
+    const uint32_t t = (uint32_t)(P - o);
+    const uint32_t len = r.stop - r.pos + 1;
+    switch (r.type) {
+        case MSIM_SN: {
+            const uint32_t x = in[r.pos];
+            const uint32_t nb = lut[(uint32_t)r.aux * 256 + x];
+            if (nb == 0 && r.aux != 0) { report_key_error(err, r.pos, lut[768 + x]); return x; }
+            return nb;
+        }
+        case MSIM_IN: return t < len ? pool[(uint64_t)r.extra + t] : in[r.pos];
+        case MSIM_IV: return lut[1024 + in[(uint64_t)r.stop - t]];
+        case MSIM_DU: return in[(uint64_t)r.pos + (t < len ? t : t - len)];
+        default: return 0;
+    }
+}
+
+template <bool IN_LDS>
+__device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t r_hi, bool any_rec,
+                                             const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                             const msim_record *__restrict__ recs,
+                                             const uint8_t *__restrict__ pool, const uint8_t *lut,
+                                             uint64_t tile0, uint64_t L_out, unsigned long long *err) {
+    const int32_t r_lo = A.r_lo;
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) {
+        const uint64_t O = tile0 + (uint64_t)it * (THREADS * GROUP) + (uint64_t)threadIdx.x * GROUP;
+        if (O >= L_out) continue;
+        // b = last record in [r_lo, r_hi] with o <= O, or r_lo-1
+        int32_t b = r_lo - 1;
+        if (any_rec) {
+            int32_t lo = r_lo, hi = r_hi + 1;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if ((uint64_t)A.O(mid) <= O) lo = mid + 1; else hi = mid;
+            }
+            b = lo - 1;
+        }
+        const bool has_b = any_rec && b >= r_lo;
+        uint32_t ob = 0, eb = 0, sb = 0, mb = 0;
+        if (has_b) A.all(b, ob, eb, sb, mb);
+        const int64_t shift = has_b ? (int64_t)sb - (int64_t)eb : 0;      // input = output + shift
+        const int32_t nxt = has_b ? b + 1 : r_lo;
+        const uint64_t next_o = (any_rec && nxt <= r_hi) ? (uint64_t)A.O(nxt) : ~0ull;
+        const bool clear_of_b = !has_b || O >= (uint64_t)eb;
+        u32x4 v;
+        if (clear_of_b && next_o >= O + GROUP) {
+            v = load16_shifted(in, (uint64_t)((int64_t)O + shift));       // pure copy run
+        } else {
+            // does the group only meet SNPs?  (they keep the shift; patch in registers)
+            bool only_sn = clear_of_b || (mb & 0xff) == MSIM_SN;
+            int32_t j = clear_of_b ? nxt : b;
+            const int32_t j0 = j;
+            if (only_sn) {
+                for (int32_t q = nxt; q <= r_hi; q++) {
+                    uint32_t o, e, s, m;
+                    A.all(q, o, e, s, m);
+                    if ((uint64_t)o >= O + GROUP) break;
+                    if ((m & 0xff) != MSIM_SN) { only_sn = false; break; }
+                }
+            }
+            if (only_sn) {
+                v = load16_shifted(in, (uint64_t)((int64_t)O + shift));
+                for (int32_t q = j0; q <= r_hi; q++) {
+                    uint32_t o, e, s, m;
+                    A.all(q, o, e, s, m);
+                    if ((uint64_t)o >= O + GROUP) break;
+                    const uint32_t idx = (uint32_t)((uint64_t)o - O);
+                    const uint32_t x = get_byte(v, idx);
+                    const uint32_t nb = lut[(m >> 8) * 256 + x];
+                    if (nb == 0 && (m >> 8) != 0) report_key_error(err, (uint64_t)s - 1, lut[768 + x]);
+                    else set_byte(v, idx, nb);
+                }
+            } else {
+                // general: walk the records byte by byte (monotone record cursor)
+                uint32_t w[4] = {0, 0, 0, 0};
+                int32_t cj = has_b ? b : -1;
+                uint32_t co = ob, ce = eb, cs = sb, cm = mb;
+                uint64_t cnext = next_o;
+                int32_t cn = nxt;
+#pragma unroll
+                for (int bi = 0; bi < GROUP; bi++) {
+                    const uint64_t P = O + bi;
+                    uint32_t byte = 0;
+                    if (P < L_out) {
+                        while (cnext <= P) {                       // advance to the last record with o <= P
+                            cj = cn;
+                            A.all(cj, co, ce, cs, cm);
+                            cn = cj + 1;
+                            cnext = cn <= r_hi ? (uint64_t)A.O(cn) : ~0ull;
+                        }
+                        byte = slow_byte(P, cj, co, ce, cs, in, pool, recs, lut, err);
+                    }
+                    w[bi >> 2] |= byte << ((bi & 3) * 8);
+                }
+                v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+            }
+        }
+        *reinterpret_cast<u32x4 *>(out + O) = v;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                     const msim_record *__restrict__ recs,
+                                                     const uint32_t *__restrict__ off,
+                                                     const int32_t *__restrict__ first, uint32_t n_rec,
+                                                     uint64_t L_out, const uint8_t *__restrict__ pool,
+                                                     const uint8_t *__restrict__ lut_g,
+                                                     unsigned long long *err) {
+    __shared__ RecWin win;
+    __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
+    const uint32_t t = blockIdx.x;
+    const uint64_t tile0 = (uint64_t)t * TILE;
+    for (int i = threadIdx.x; i < LUT_BYTES / 4; i += THREADS)
+        reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
+    const int32_t f0 = first[t], f1 = first[t + 1];
+    const bool any_rec = f1 >= 0 && n_rec > 0;
+    const int32_t r_lo = f0 < 0 ? 0 : f0;
+    const int32_t r_hi = f1;
+    const int32_t cnt = any_rec ? r_hi - r_lo + 1 : 0;
+    const bool in_lds = cnt <= REC_CAP;
+    if (in_lds) {
+        for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
+            const msim_record r = recs[r_lo + q];
+            uint32_t ol, il;
+            rec_lengths(r, ol, il);
+            const uint32_t o = off[r_lo + q];
+            win.o[q] = o;
+            win.e[q] = o + ol;
+            win.s[q] = r.pos + il;
+            win.m[q] = (uint32_t)r.type | ((uint32_t)r.aux << 8);
+        }
+    }
+    __syncthreads();
+    if (in_lds) {
+        RecAccess<true> A{&win, recs, off, r_lo};
+        rewrite_tile<true>(A, r_hi, any_rec, in, out, recs, pool, lut, tile0, L_out, err);
+    } else {
+        RecAccess<false> A{&win, recs, off, r_lo};
+        rewrite_tile<false>(A, r_hi, any_rec, in, out, recs, pool, lut, tile0, L_out, err);
+    }
+}
+
+// ------------------------------------------------------------------ synthetic genome / checksum
+__device__ __host__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// base(i) = "ACGT"[(mix64(seed + (i >> 5)) >> (2 * (i & 31))) & 3]; one lane makes 32 bases
+__global__ __launch_bounds__(THREADS) void k_synth(uint8_t *__restrict__ dst, uint64_t len, uint64_t seed) {
+    const uint64_t g = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    const uint64_t i0 = g * 32;
+    if (i0 >= len) return;
+    uint64_t bits = mix64(seed + g);
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t code = (uint32_t)(bits & 3);
+            bits >>= 2;
+            x |= (uint32_t)("ACGT"[code]) << (q * 8);
+        }
+        w[k] = x;
+    }
+    if (i0 + 32 <= len) {
+        u32x4 *p = reinterpret_cast<u32x4 *>(dst + i0);
+        u32x4 a, b;
+        a.x = w[0]; a.y = w[1]; a.z = w[2]; a.w = w[3];
+        b.x = w[4]; b.y = w[5]; b.z = w[6]; b.w = w[7];
+        p[0] = a; p[1] = b;
+    } else {
+        for (uint64_t i = i0; i < len; i++) dst[i] = (uint8_t)(w[(i - i0) >> 2] >> (((i - i0) & 3) * 8));
+    }
+}
+
+// checksum = sum_k mix64(word_k + k * GOLD) over the little-endian 8-byte words of the stream
+// (zero padded), wrapping uint64; order sensitive, parallel.  Same function in tests/.
+__global__ __launch_bounds__(THREADS) void k_checksum(const uint8_t *__restrict__ src, uint64_t len,
+                                                      unsigned long long *__restrict__ sum) {
+    const uint64_t nwords = (len + 7) / 8;
+    unsigned long long acc = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x; k < nwords; k += (uint64_t)gridDim.x * THREADS) {
+        uint64_t w;
+        if (k * 8 + 8 <= len) {
+            w = *reinterpret_cast<const uint64_t *>(src + k * 8);
+        } else {
+            w = 0;
+            for (uint64_t i = k * 8; i < len; i++) w |= (uint64_t)src[i] << ((i - k * 8) * 8);
+        }
+        acc += mix64(w + k * 0x9E3779B97F4A7C15ull);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+}  // namespace
+
+int ensure_scratch(Ctx *c, size_t bytes) {
+    if (bytes <= c->scratch_bytes) return MSIM_OK;
+    if (c->d_scratch) MSIM_HIP(c, hipFree(c->d_scratch));
+    c->d_scratch = nullptr;
+    c->scratch_bytes = 0;
+    size_t want = bytes + (bytes >> 2) + 4096;
+    MSIM_HIP(c, hipMalloc(&c->d_scratch, want));
+    c->scratch_bytes = want;
+    return MSIM_OK;
+}
+
+int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed) {
+    if (len == 0) return MSIM_OK;
+    const uint64_t lanes = (len + 31) / 32;
+    const uint32_t blocks = (uint32_t)((lanes + THREADS - 1) / THREADS);
+    hipLaunchKernelGGL(k_synth, dim3(blocks), dim3(THREADS), 0, c->stream, d_dst, len, seed);
+    MSIM_HIP(c, hipGetLastError());
+    return MSIM_OK;
+}
+
+int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum) {
+    int rc = ensure_scratch(c, 64);
+    if (rc) return rc;
+    unsigned long long *d_sum = reinterpret_cast<unsigned long long *>(c->d_scratch);
+    MSIM_HIP(c, hipMemsetAsync(d_sum, 0, 8, c->stream));
+    if (len) {
+        const uint64_t nwords = (len + 7) / 8;
+        uint32_t blocks = (uint32_t)std::min<uint64_t>((nwords + THREADS - 1) / THREADS, 256 * 16);
+        hipLaunchKernelGGL(k_checksum, dim3(blocks), dim3(THREADS), 0, c->stream, d_src, len, d_sum);
+        MSIM_HIP(c, hipGetLastError());
+    }
+    unsigned long long h = 0;
+    MSIM_HIP(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    *sum = h + len * 0x9E3779B97F4A7C15ull;
+    return MSIM_OK;
+}
+
+// LUT upload lives with the ctx (msim_api.hip); declared here
+extern uint8_t *ctx_lut(Ctx *c);
+extern unsigned long long *ctx_err_word(Ctx *c);
+
+int apply_contig_device(Ctx *c, Contig &g) {
+    const uint32_t n = (uint32_t)g.n_rec;
+    MSIM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    // ---- 1. output offsets
+    long long total_delta = 0;
+    const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (g.d_off) { MSIM_HIP(c, hipFree(g.d_off)); g.d_off = nullptr; }
+    if (n) {
+        MSIM_HIP(c, hipMalloc(&g.d_off, (size_t)n * sizeof(uint32_t)));
+        int rc = ensure_scratch(c, (size_t)(nb + 1) * sizeof(long long));
+        if (rc) return rc;
+        long long *d_sums = reinterpret_cast<long long *>(c->d_scratch);
+        hipLaunchKernelGGL(k_delta_reduce, dim3(nb), dim3(THREADS), 0, c->stream, g.d_recs, n, d_sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, d_sums, nb);
+        hipLaunchKernelGGL(k_offsets, dim3(nb), dim3(THREADS), 0, c->stream, g.d_recs, n, d_sums, g.d_off);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipMemcpyAsync(&total_delta, d_sums + nb, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    const long long out_len_ll = (long long)g.len + total_delta;
+    if (out_len_ll < 0 || (uint64_t)out_len_ll >= (1ull << 32))
+        return fail(c, MSIM_ERR_UNSUPPORTED, "mutated contig of 4 GiB or more");
+    g.out_len = (uint64_t)out_len_ll;
+    if (g.d_out) { MSIM_HIP(c, hipFree(g.d_out)); g.d_out = nullptr; }
+    MSIM_HIP(c, hipMalloc(&g.d_out, g.out_len + PAD));
+    // ---- 2. tile index
+    const uint32_t n_tiles = (uint32_t)((g.out_len + TILE - 1) / TILE);
+    int32_t *d_first = nullptr;
+    if (n_tiles) {
+        int rc = ensure_scratch(c, (size_t)(n_tiles + 1) * sizeof(int32_t) + 64);
+        if (rc) return rc;
+        d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
+        hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, c->stream,
+                           g.d_off, n, d_first, n_tiles + 1);
+        MSIM_HIP(c, hipGetLastError());
+    }
+    // ---- 3. rewrite
+    unsigned long long *d_err = ctx_err_word(c);
+    MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
+    MSIM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    if (n_tiles) {
+        hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
+                           g.d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
+        MSIM_HIP(c, hipGetLastError());
+    }
+    MSIM_HIP(c, hipEventRecord(c->ev2, c->stream));
+    unsigned long long h_err = 0;
+    MSIM_HIP(c, hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    float ms_all = 0, ms_k = 0;
+    MSIM_HIP(c, hipEventElapsedTime(&ms_all, c->ev0, c->ev2));
+    MSIM_HIP(c, hipEventElapsedTime(&ms_k, c->ev1, c->ev2));
+    c->t.apply_ms += ms_all;
+    c->t.apply_kernel_ms += ms_k;
+    c->t.apply_launches += n_tiles ? 1 : 0;
+    c->t.bytes_in += g.len;
+    c->t.bytes_out += g.out_len;
+    c->t.records += n;
+    g.key_error = h_err != ~0ull;
+    if (g.key_error) {
+        g.key_pos = h_err >> 8;
+        g.key_base = (uint8_t)(h_err & 0xff);
+    }
+    g.applied = true;
+    return g.key_error ? fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'") : MSIM_OK;
+}
+
+}  // namespace msim

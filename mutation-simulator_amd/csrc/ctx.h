@@ -1,0 +1,80 @@
+// Internal state of a libmsim context (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/msim.h"
+#include "mt19937.h"
+
+namespace msim {
+
+struct Contig {
+    uint64_t len = 0;
+    uint8_t *d_in = nullptr;          // input bases (uint8, upper-cased), padded by PAD bytes
+    // plan result
+    bool planned = false;
+    bool plan_empty = true;
+    uint64_t n_rec = 0, pool_len = 0;
+    msim_record *d_recs = nullptr;    // sorted, visited-only records
+    uint8_t *d_pool = nullptr;        // insert bases
+    // apply result
+    bool applied = false;
+    uint64_t out_len = 0;
+    uint8_t *d_out = nullptr;
+    uint32_t *d_off = nullptr;        // output offset of every record
+    uint8_t key_base = 0;             // KeyError report
+    uint64_t key_pos = 0;
+    bool key_error = false;
+    // host-only context (device_id -1): the record table stays here
+    std::vector<msim_record> h_recs;
+    std::vector<uint8_t> h_pool;
+};
+
+constexpr uint64_t PAD = 64;          // slack after every byte buffer so 16-B vector accesses stay in bounds
+
+struct Ctx {
+    int device = 0;
+    bool host_only = false;           // msim_create(-1): PLAN + text rendering only, no GPU touched
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::string err;
+    std::string devname;
+    HostMT py, np;                    // canonical stream states (host engine)
+    msim_params params{};
+    bool have_params = false;
+    std::vector<Contig> contigs;
+    msim_timing t{};
+    // device scratch
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    uint32_t *d_flags = nullptr;      // [0..1] key error pos (lo/hi via atomicMin on u64), [2] base
+};
+
+int fail(Ctx *c, int code, const std::string &msg);
+int hip_fail(Ctx *c, hipError_t e, const char *what);
+
+#define MSIM_HIP(ctx, call)                                              \
+    do {                                                                 \
+        hipError_t e__ = (call);                                         \
+        if (e__ != hipSuccess) return ::msim::hip_fail((ctx), e__, #call); \
+    } while (0)
+
+// plan_host.cpp
+struct HostPlan {
+    std::vector<msim_record> recs;
+    std::vector<uint8_t> pool;
+    bool empty = true;
+};
+int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out);
+
+// apply.hip
+int apply_contig_device(Ctx *c, Contig &g);
+int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed);
+int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum);
+int ensure_scratch(Ctx *c, size_t bytes);
+
+}  // namespace msim

@@ -1,0 +1,440 @@
+// C-ABI entry points of libmsim.so (include/msim.h).  gfx950 (MI355X) only.
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ctx.h"
+
+namespace msim {
+
+static thread_local std::string g_create_error;
+
+int fail(Ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+int hip_fail(Ctx *c, hipError_t e, const char *what) {
+    return fail(c, MSIM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+struct CtxDev {            // small device-side constants owned by the ctx
+    uint8_t *d_lut = nullptr;
+    unsigned long long *d_err = nullptr;
+};
+static CtxDev *dev_of(Ctx *c);
+uint8_t *ctx_lut(Ctx *c) { return dev_of(c)->d_lut; }
+unsigned long long *ctx_err_word(Ctx *c) { return dev_of(c)->d_err; }
+
+struct CtxFull : Ctx { CtxDev dev; };
+static CtxDev *dev_of(Ctx *c) { return &static_cast<CtxFull *>(c)->dev; }
+
+// Translation tables of mutator.py:75-77 and the transversion dict of mutator.py:449-455.
+static void build_lut(uint8_t *lut) {
+    uint8_t conv[256], comp[256], ti[256];
+    for (int i = 0; i < 256; i++) conv[i] = comp[i] = ti[i] = (uint8_t)i;
+    const char *a = "KSYMWRBDHV-", *b = "GCCAAACAAAN";
+    for (int i = 0; a[i]; i++) conv[(uint8_t)a[i]] = (uint8_t)b[i];
+    a = "ACGTUMRWSYKVHDB"; b = "TGCAAKYWSRMBDHV";
+    for (int i = 0; a[i]; i++) comp[(uint8_t)a[i]] = (uint8_t)b[i];
+    a = "AGTC"; b = "GACT";
+    for (int i = 0; a[i]; i++) ti[(uint8_t)a[i]] = (uint8_t)b[i];
+    for (int x = 0; x < 256; x++) {
+        const uint8_t r = conv[x];
+        lut[x] = ti[r];
+        const char *pair = nullptr;
+        switch (r) {
+            case 'A': pair = "TC"; break;
+            case 'G': pair = "CT"; break;
+            case 'T': pair = "GA"; break;
+            case 'C': pair = "AG"; break;
+            case 'N': pair = "NN"; break;
+            default: break;
+        }
+        lut[256 + x] = pair ? (uint8_t)pair[0] : 0;      // 0 -> the reference raises KeyError(r)
+        lut[512 + x] = pair ? (uint8_t)pair[1] : 0;
+        lut[768 + x] = r;
+        lut[1024 + x] = comp[r];
+    }
+}
+
+static int free_contig(Ctx *c, Contig &g, bool keep_input) {
+    if (g.d_recs) { MSIM_HIP(c, hipFree(g.d_recs)); g.d_recs = nullptr; }
+    if (g.d_pool) { MSIM_HIP(c, hipFree(g.d_pool)); g.d_pool = nullptr; }
+    if (g.d_out) { MSIM_HIP(c, hipFree(g.d_out)); g.d_out = nullptr; }
+    if (g.d_off) { MSIM_HIP(c, hipFree(g.d_off)); g.d_off = nullptr; }
+    g.planned = g.applied = false;
+    g.n_rec = g.pool_len = g.out_len = 0;
+    g.h_recs.clear(); g.h_recs.shrink_to_fit();
+    g.h_pool.clear(); g.h_pool.shrink_to_fit();
+    if (!keep_input && g.d_in) { MSIM_HIP(c, hipFree(g.d_in)); g.d_in = nullptr; }
+    return MSIM_OK;
+}
+
+static Contig *get_contig(Ctx *c, int id) {
+    if (id < 0 || (size_t)id >= c->contigs.size()) { fail(c, MSIM_ERR_ARG, "no such contig"); return nullptr; }
+    return &c->contigs[(size_t)id];
+}
+
+static int new_contig(Ctx *c, uint64_t len, Contig **out) {
+    if (len >= (1ull << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "contig of 4 GiB or more (multi-word getrandbits)");
+    Contig g;
+    g.len = len;
+    if (!c->host_only) {
+        MSIM_HIP(c, hipMalloc(&g.d_in, len + PAD));
+        MSIM_HIP(c, hipMemsetAsync(g.d_in + len, 0, PAD, c->stream));
+    }
+    c->contigs.push_back(g);
+    *out = &c->contigs.back();
+    return MSIM_OK;
+}
+
+}  // namespace msim
+
+using namespace msim;
+
+extern "C" {
+
+int msim_abi_version(void) { return MSIM_ABI_VERSION; }
+
+int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
+    if (!out) return MSIM_ERR_ARG;
+    *out = nullptr;
+    if (device_id == -1) {
+        // Host-only context: the sequential planner and the text renderer work, every entry point
+        // that needs the GPU fails with MSIM_ERR_HIP.  Exists so the planner can be checked against
+        // the oracle on machines without a GPU; it cannot produce a mutated sequence.
+        CtxFull *c = new (std::nothrow) CtxFull();
+        if (!c) return MSIM_ERR_NOMEM;
+        c->device = -1;
+        c->host_only = true;
+        c->flags = flags;
+        c->devname = "host-only (no GPU)";
+        c->py.init_genrand(5489u);
+        c->np.init_genrand(5489u);
+        for (int i = 0; i < 8; i++) c->params.block[i] = 1;
+        c->params.ti_lim = (1ull << 52) + 1;
+        *out = reinterpret_cast<msim_ctx *>(static_cast<Ctx *>(c));
+        return MSIM_OK;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, MSIM_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, MSIM_ERR_ARG, "device_id out of range");
+    CtxFull *c = new (std::nothrow) CtxFull();
+    if (!c) return MSIM_ERR_NOMEM;
+    c->device = device_id;
+    c->flags = flags;
+    c->py.init_genrand(5489u);
+    c->np.init_genrand(5489u);
+    for (int i = 0; i < 8; i++) c->params.block[i] = 1;
+    c->params.ti_lim = (1ull << 52) + 1;
+    auto bail = [&](hipError_t he, const char *what) {
+        int rc = hip_fail(nullptr, he, what);
+        delete c;
+        return rc;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail(e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    hipEvent_t *evs[4] = {&c->ev0, &c->ev1, &c->ev2, &c->ev3};
+    for (auto ev : evs)
+        if ((e = hipEventCreate(ev)) != hipSuccess) return bail(e, "hipEventCreate");
+    uint8_t lut[1280];
+    build_lut(lut);
+    if ((e = hipMalloc(&c->dev.d_lut, sizeof lut)) != hipSuccess) return bail(e, "hipMalloc(lut)");
+    if ((e = hipMemcpy(c->dev.d_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(lut)");
+    if ((e = hipMalloc(&c->dev.d_err, 64)) != hipSuccess) return bail(e, "hipMalloc(err)");
+    *out = reinterpret_cast<msim_ctx *>(static_cast<Ctx *>(c));
+    return MSIM_OK;
+}
+
+static Ctx *C(msim_ctx *p) { return reinterpret_cast<Ctx *>(p); }
+#define NEED_GPU(c) do { if ((c)->host_only) return fail((c), MSIM_ERR_HIP, "host-only context: this call needs the GPU"); } while (0)
+
+void msim_destroy(msim_ctx *p) {
+    if (!p) return;
+    CtxFull *c = static_cast<CtxFull *>(C(p));
+    if (c->host_only) { delete c; return; }
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &g : c->contigs) (void)free_contig(c, g, false);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
+    if (c->dev.d_err) (void)hipFree(c->dev.d_err);
+    hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
+    for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *msim_last_error(const msim_ctx *p) {
+    if (!p) return g_create_error.c_str();
+    return reinterpret_cast<const Ctx *>(p)->err.c_str();
+}
+
+int msim_device_name(const msim_ctx *p, char *dst, int cap) {
+    if (!p || !dst || cap <= 0) return MSIM_ERR_ARG;
+    snprintf(dst, (size_t)cap, "%s", reinterpret_cast<const Ctx *>(p)->devname.c_str());
+    return MSIM_OK;
+}
+
+int msim_sync(msim_ctx *p) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    if (c->host_only) return MSIM_OK;
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    return MSIM_OK;
+}
+
+int msim_seed(msim_ctx *p, const uint32_t *py_key, int n_key, uint32_t np_seed) {
+    Ctx *c = C(p);
+    if (!c || !py_key || n_key < 1) return MSIM_ERR_ARG;
+    c->py.init_by_array(py_key, n_key);
+    c->py.words = 0;
+    c->np.init_genrand(np_seed);
+    c->np.words = 0;
+    return MSIM_OK;
+}
+
+int msim_set_mt_state(msim_ctx *p, int stream, const uint32_t mt[624], int pos) {
+    Ctx *c = C(p);
+    if (!c || !mt || pos < 0 || pos > 624 || stream < 0 || stream > 1) return MSIM_ERR_ARG;
+    HostMT &g = stream ? c->np : c->py;
+    memcpy(g.mt, mt, sizeof g.mt);
+    g.idx = pos;
+    return MSIM_OK;
+}
+
+int msim_get_mt_state(msim_ctx *p, int stream, uint32_t mt[624], int *pos) {
+    Ctx *c = C(p);
+    if (!c || !mt || !pos || stream < 0 || stream > 1) return MSIM_ERR_ARG;
+    HostMT &g = stream ? c->np : c->py;
+    memcpy(mt, g.mt, sizeof g.mt);
+    *pos = g.idx;
+    return MSIM_OK;
+}
+
+int msim_add_contig(msim_ctx *p, const uint8_t *bases, uint64_t len, int *contig) {
+    Ctx *c = C(p);
+    if (!c || (!bases && len) || !contig) return MSIM_ERR_ARG;
+    Contig *g;
+    int rc = new_contig(c, len, &g);
+    if (rc) return rc;
+    if (!c->host_only) {
+        if (len) MSIM_HIP(c, hipMemcpyAsync(g->d_in, bases, len, hipMemcpyHostToDevice, c->stream));
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *contig = (int)c->contigs.size() - 1;
+    return MSIM_OK;
+}
+
+int msim_add_contig_synthetic(msim_ctx *p, uint64_t len, uint64_t seed, int *contig) {
+    Ctx *c = C(p);
+    if (!c || !contig) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    Contig *g;
+    int rc = new_contig(c, len, &g);
+    if (rc) return rc;
+    rc = synth_contig_device(c, g->d_in, len, seed);
+    if (rc) return rc;
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    *contig = (int)c->contigs.size() - 1;
+    return MSIM_OK;
+}
+
+int msim_contig_length(msim_ctx *p, int contig, uint64_t *len) {
+    Ctx *c = C(p);
+    if (!c || !len) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    *len = g->len;
+    return MSIM_OK;
+}
+
+int msim_read_contig(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8_t *dst) {
+    Ctx *c = C(p);
+    if (!c || (!dst && n)) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (offset > g->len || n > g->len - offset) return fail(c, MSIM_ERR_ARG, "read beyond contig end");
+    if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_in + offset, n, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    return MSIM_OK;
+}
+
+int msim_clear(msim_ctx *p) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    if (!c->host_only) MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &g : c->contigs) {
+        int rc = free_contig(c, g, false);
+        if (rc) return rc;
+    }
+    c->contigs.clear();
+    return MSIM_OK;
+}
+
+int msim_set_params(msim_ctx *p, const msim_params *params) {
+    Ctx *c = C(p);
+    if (!c || !params) return MSIM_ERR_ARG;
+    for (int t = 1; t <= 7; t++)
+        if (params->block[t] < 1) return fail(c, MSIM_ERR_ARG, "block values must be >= 1 (rmt.py:326-345)");
+    c->params = *params;
+    c->have_params = true;
+    return MSIM_OK;
+}
+
+int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ranges) {
+    Ctx *c = C(p);
+    if (!c || n_ranges < 0 || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
+    int rc = free_contig(c, *g, true);
+    if (rc) return rc;
+    if (c->flags & MSIM_PLAN_GPU)
+        return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
+    HostPlan hp;
+    const uint64_t w_py = c->py.words, w_np = c->np.words;
+    rc = plan_contig_host(c, g->len, ranges, n_ranges, hp);
+    if (rc) return rc;
+    c->t.py_words += c->py.words - w_py;
+    c->t.np_words += c->np.words - w_np;
+    const auto t0 = std::chrono::steady_clock::now();
+    g->n_rec = hp.recs.size();
+    g->pool_len = hp.pool.size();
+    g->plan_empty = hp.empty;
+    if (c->host_only) {
+        g->h_recs.swap(hp.recs);
+        g->h_pool.swap(hp.pool);
+        g->planned = true;
+        return MSIM_OK;
+    }
+    if (g->n_rec) {
+        MSIM_HIP(c, hipMalloc(&g->d_recs, g->n_rec * sizeof(msim_record)));
+        MSIM_HIP(c, hipMemcpyAsync(g->d_recs, hp.recs.data(), g->n_rec * sizeof(msim_record), hipMemcpyHostToDevice, c->stream));
+    }
+    MSIM_HIP(c, hipMalloc(&g->d_pool, g->pool_len + PAD));
+    if (g->pool_len)
+        MSIM_HIP(c, hipMemcpyAsync(g->d_pool, hp.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    c->t.upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g->planned = true;
+    return MSIM_OK;
+}
+
+int msim_plan_was_empty(msim_ctx *p, int contig, int *empty) {
+    Ctx *c = C(p);
+    if (!c || !empty) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    *empty = g->plan_empty ? 1 : 0;
+    return MSIM_OK;
+}
+
+int msim_apply_contig(msim_ctx *p, int contig) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "msim_apply_contig before msim_plan_contig");
+    return apply_contig_device(c, *g);
+}
+
+int msim_key_error(msim_ctx *p, int contig, uint8_t *base, uint64_t *pos) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->key_error) return fail(c, MSIM_ERR_ARG, "no KeyError recorded for this contig");
+    if (base) *base = g->key_base;
+    if (pos) *pos = g->key_pos;
+    return MSIM_OK;
+}
+
+int msim_result_sizes(msim_ctx *p, int contig, uint64_t *out_len, uint64_t *n_records, uint64_t *pool_len) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    if (out_len) {
+        if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+        *out_len = g->out_len;
+    }
+    if (n_records) *n_records = g->n_rec;
+    if (pool_len) *pool_len = g->pool_len;
+    return MSIM_OK;
+}
+
+int msim_fetch_sequence(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8_t *dst) {
+    Ctx *c = C(p);
+    if (!c || (!dst && n)) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    if (offset > g->out_len || n > g->out_len - offset) return fail(c, MSIM_ERR_ARG, "fetch beyond mutated contig end");
+    if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_out + offset, n, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    return MSIM_OK;
+}
+
+int msim_fetch_records(msim_ctx *p, int contig, msim_record *dst, uint8_t *pool_dst) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    if (c->host_only) {
+        if (dst && g->n_rec) memcpy(dst, g->h_recs.data(), g->n_rec * sizeof(msim_record));
+        if (pool_dst && g->pool_len) memcpy(pool_dst, g->h_pool.data(), g->pool_len);
+        return MSIM_OK;
+    }
+    if (dst && g->n_rec)
+        MSIM_HIP(c, hipMemcpyAsync(dst, g->d_recs, g->n_rec * sizeof(msim_record), hipMemcpyDeviceToHost, c->stream));
+    if (pool_dst && g->pool_len)
+        MSIM_HIP(c, hipMemcpyAsync(pool_dst, g->d_pool, g->pool_len, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    return MSIM_OK;
+}
+
+int msim_result_checksum(msim_ctx *p, int contig, uint64_t *sum) {
+    Ctx *c = C(p);
+    if (!c || !sum) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    return checksum_device(c, g->d_out, g->out_len, sum);
+}
+
+int msim_release_result(msim_ctx *p, int contig) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!c->host_only) MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    return free_contig(c, *g, true);
+}
+
+int msim_stats(msim_ctx *p, msim_timing *out) {
+    Ctx *c = C(p);
+    if (!c || !out) return MSIM_ERR_ARG;
+    *out = c->t;
+    return MSIM_OK;
+}
+
+int msim_reset_stats(msim_ctx *p) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    c->t = msim_timing{};
+    return MSIM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+// Host planner: the exact, sequential walk of the reference's two MT19937 streams for one contig.
+//
+// This is the general PLAN engine: it covers every stream structure the reference can produce
+// (many ranges per contig, CPython's pool-path sample, the boundary pass whose randint draws chain
+// through the kept/dropped decisions -- SURVEY.md 7.3 H2).  The GPU sampler (plan_gpu.hip) takes
+// over where the structure parallelises exactly.  Nothing here touches genome bytes: RNG use is
+// independent of sequence content, which is what makes the PLAN / APPLY split possible.
+//
+// Follows (behaviour, not text): mutator.py:144-265 (__get_mutations, __get_mut_positions,
+// __get_stop_position), util.py:94-109 (sample_with_minimum_distance), CPython Lib/random.py
+// (sample, _randbelow_with_getrandbits, randint, random), NumPy legacy RandomState.choice, and the
+// draw order of mutator.py:318-471 (__mutate_sequence, __get_snp, __get_insert).
+#include <algorithm>
+#include <chrono>
+
+#include "ctx.h"
+
+namespace msim {
+
+namespace {
+
+struct Cand { int64_t pos; int32_t type; int64_t stop; };
+
+inline uint64_t randbelow(HostMT &g, uint64_t n) {      // n < 2^32 on this path
+    if (!n) return 0;
+    const int sh = 32 - bit_length64(n);
+    uint64_t r = g.next() >> sh;
+    while (r >= n) r = g.next() >> sh;
+    return r;
+}
+inline int64_t randint(HostMT &g, int64_t a, int64_t b) { return a + (int64_t)randbelow(g, (uint64_t)(b - a + 1)); }
+
+// sample(range(n), k) as a SORTED list of the selected values.  Only the set matters downstream
+// (util.py:104-109 sorts), but the number of words consumed must be exact.
+int sample_sorted(Ctx *c, HostMT &g, int64_t n, int64_t k, int64_t setsize, std::vector<int64_t> &out) {
+    out.clear();
+    if (n < 0) n = 0;                                   // len(range(a, b)) with b < a
+    if (k < 0 || k > n)
+        return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
+    if (k == 0) return MSIM_OK;
+    if ((uint64_t)n >= (1ull << 32))
+        return fail(c, MSIM_ERR_UNSUPPORTED, "sampling range of 2^32 or more positions (multi-word getrandbits)");
+    out.reserve((size_t)k);
+    if (n <= setsize) {                                 // pool path: partial Fisher-Yates
+        std::vector<int64_t> pool((size_t)n);
+        for (int64_t i = 0; i < n; i++) pool[(size_t)i] = i;
+        for (int64_t i = 0; i < k; i++) {
+            int64_t j = (int64_t)randbelow(g, (uint64_t)(n - i));
+            out.push_back(pool[(size_t)j]);
+            pool[(size_t)j] = pool[(size_t)(n - i - 1)];
+        }
+        std::sort(out.begin(), out.end());
+        return MSIM_OK;
+    }
+    // set path: first k distinct accepted draws.  Dense enough -> bitmap (scan gives sorted order
+    // for free); sparse -> sort + unique rounds.
+    const int sh = 32 - bit_length64((uint64_t)n);
+    if ((uint64_t)n <= 512ull * (uint64_t)k + (1u << 20)) {
+        std::vector<uint64_t> bits(((size_t)n + 63) / 64, 0);
+        int64_t got = 0;
+        while (got < k) {
+            uint64_t v = g.next() >> sh;
+            if (v >= (uint64_t)n) continue;
+            uint64_t &w = bits[v >> 6];
+            const uint64_t m = 1ull << (v & 63);
+            if (!(w & m)) { w |= m; got++; }
+        }
+        for (size_t wi = 0; wi < bits.size(); wi++) {
+            uint64_t w = bits[wi];
+            while (w) { out.push_back((int64_t)(wi * 64 + (size_t)__builtin_ctzll(w))); w &= w - 1; }
+        }
+        return MSIM_OK;
+    }
+    std::vector<int64_t> seen;                          // sorted distinct values so far
+    std::vector<int64_t> fresh;
+    int64_t need = k;
+    while (need > 0) {
+        fresh.clear();
+        // every one of the next `need` accepted draws lies before the cut, duplicate or not
+        while ((int64_t)fresh.size() < need) {
+            uint64_t v = g.next() >> sh;
+            if (v < (uint64_t)n) fresh.push_back((int64_t)v);
+        }
+        std::sort(fresh.begin(), fresh.end());
+        fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+        std::vector<int64_t> merged;
+        merged.reserve(seen.size() + fresh.size());
+        std::set_union(seen.begin(), seen.end(), fresh.begin(), fresh.end(), std::back_inserter(merged));
+        need = k - (int64_t)merged.size();
+        seen.swap(merged);
+    }
+    out.swap(seen);
+    return MSIM_OK;
+}
+
+}  // namespace
+
+int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);       // min(mut_block.values())
+    const int64_t chrom_len = (int64_t)L;
+
+    std::vector<Cand> all;                                           // `muts` of mutator.py:112
+    std::vector<int64_t> pos;
+    bool sorted_concat = true;
+    for (int ri = 0; ri < n_ranges; ri++) {
+        const msim_range &r = ranges[ri];
+        if (r.n_types < 1 || r.n_types > 8) return fail(c, MSIM_ERR_ARG, "msim_range.n_types out of range");
+        const int64_t k = r.k;
+        const int64_t n = (r.stop - (k - 1) * d) - r.start;          // util.py:104
+        int rc = sample_sorted(c, c->py, n, k, r.setsize, pos);
+        if (rc) return rc;
+        if (k == 0) continue;                                        // mutator.py:163-164
+        // types: numpy.random.choice(keys, p=chances, size=k)      mutator.py:170-174
+        const size_t base = all.size();
+        all.resize(base + (size_t)k);
+        for (int64_t i = 0; i < k; i++) {
+            const uint64_t m = c->np.next53();
+            int idx = 0;
+            while (idx < r.n_types && r.cdf_thr[idx] <= m) idx++;
+            if (idx >= r.n_types) idx = r.n_types - 1;               // unreachable: cdf[-1] == 1.0 > u
+            all[base + (size_t)i] = Cand{r.start + pos[(size_t)i] + d * i, r.types[idx], 0};
+        }
+        // boundary pass                                             mutator.py:184-213
+        size_t w = base;
+        int64_t blk_lo = 0, blk_hi = 0;                              // last_mut_range = range(0)
+        for (size_t i = base; i < base + (size_t)k; i++) {
+            Cand m = all[i];
+            if (m.pos >= blk_lo && m.pos < blk_hi) continue;
+            const int t = m.type;
+            if (t == MSIM_SN) {
+                m.stop = m.pos;
+            } else if (t == MSIM_IV) {                               // mutator.py:240-248
+                if (m.pos + r.max_len[MSIM_IV] >= chrom_len - 1) continue;
+                m.stop = randint(c->py, m.pos + r.min_len[t] - 1, m.pos + r.max_len[t] - 1);
+            } else if (t == MSIM_IN) {
+                m.stop = randint(c->py, m.pos + r.min_len[t] - 1, m.pos + r.max_len[t] - 1);
+            } else if (t == MSIM_DU || t == MSIM_DE) {               // mutator.py:253-264
+                m.stop = randint(c->py, m.pos + r.min_len[t] - 1, m.pos + r.max_len[t] - 1);
+                if (m.stop > chrom_len - 1) m.stop = chrom_len - 1;
+            } else {
+                return fail(c, MSIM_ERR_UNSUPPORTED,
+                            "translocations (TL/TLI, mutator.py:267-316) are not part of this build");
+            }
+            blk_lo = m.pos;
+            blk_hi = ((t == MSIM_SN || t == MSIM_IN) ? m.pos : m.stop) + 1 + P.block[t];
+            all[w++] = m;
+        }
+        all.resize(w);
+        if (base > 0 && w > base && all[base].pos <= all[base - 1].pos) sorted_concat = false;
+    }
+    if (!sorted_concat) {
+        // overlapping RMT ranges: dict.update() semantics -- same position, later range wins
+        std::vector<size_t> order(all.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return all[a].pos < all[b].pos; });
+        std::vector<Cand> merged;
+        merged.reserve(all.size());
+        for (size_t i = 0; i < order.size(); i++) {
+            if (i + 1 < order.size() && all[order[i + 1]].pos == all[order[i]].pos) continue;
+            merged.push_back(all[order[i]]);
+        }
+        all.swap(merged);
+    }
+    out.empty = all.empty();
+
+    // Walk in position order like __mutate_sequence (mutator.py:332-425): entries inside a span an
+    // earlier DE/IV/DU consumed are never visited; visited SNPs draw from the CPython stream,
+    // visited inserts from the NumPy stream.
+    out.recs.clear();
+    out.pool.clear();
+    out.recs.reserve(all.size());
+    static const uint8_t ATGC[4] = {'A', 'T', 'G', 'C'};
+    int64_t consumed_to = -1;
+    for (const Cand &m : all) {
+        if (m.pos <= consumed_to) continue;
+        if (m.pos >= chrom_len) continue;                            // `while pos < len(sequence)`
+        if ((uint64_t)m.stop >= (1ull << 32))
+            return fail(c, MSIM_ERR_UNSUPPORTED, "mutation extent beyond 2^32");
+        msim_record rec{};
+        rec.pos = (uint32_t)m.pos;
+        rec.stop = (uint32_t)m.stop;
+        rec.type = (uint8_t)m.type;
+        if (m.type == MSIM_SN) {                                     // mutator.py:436-441, :455
+            const uint64_t u = c->py.next53();
+            rec.aux = (u < P.ti_lim) ? 0 : (uint8_t)(1 + randbelow(c->py, 2));
+        } else if (m.type == MSIM_IN) {                              // mutator.py:344, :471
+            const int64_t len = m.stop + 1 - m.pos;
+            if (out.pool.size() + (uint64_t)len >= (1ull << 32))
+                return fail(c, MSIM_ERR_UNSUPPORTED, "insert pool of 4 GiB or more on one contig");
+            rec.extra = (uint32_t)out.pool.size();
+            for (int64_t i = 0; i < len; i++) out.pool.push_back(ATGC[c->np.next() & 3u]);
+        } else {
+            consumed_to = m.stop;                                    // pos = muts[pos].stop
+        }
+        out.recs.push_back(rec);
+    }
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
+}  // namespace msim

@@ -1,0 +1,70 @@
+"""``mutation-simulator file {args,rmt}`` (reference __main__.py:34-111) on an MI355X."""
+from __future__ import annotations
+
+import json
+import random
+import sys
+from timeit import default_timer as timer
+
+from . import *  # noqa: F401,F403  (same style of namespace as the reference entry point)
+from ._ffi import MsimError, MsimUnsupported
+
+_INIT_ERRORS = (FileNotFoundError, ITNotEnoughAvailChromsError, RatesTooHighError, RatesTooLowError,
+                FastaIndexingError, FastaNotFoundError, ItRateTooHighError, ItRateTooLowError,
+                RMTParseError, MissingLengthError, MinimumLengthTooLowError, TitvTooLowError,
+                ChromNotExistError, RangeDefinitionOutOfBoundsError, FastaDuplicateHeaderError,
+                MinimumLengthHigherThanMaximumError)
+
+
+def initialize(argv=None):
+    args = get_args(argv)
+    try:
+        fasta = load_fasta(args.infile)
+        if args.mode == "args":
+            sim = SimulationSettings.from_args(args, fasta, args.ignore_warnings)
+        elif args.mode == "it":
+            sim = SimulationSettings.from_it(args.interchromosomalrate, fasta, args.ignore_warnings)
+        else:
+            sim = SimulationSettings.from_rmt(args.rmtfile, fasta, args.ignore_warnings)
+    except _INIT_ERRORS as e:
+        exit_with_error(e, args.no_color)
+    if not args.ignore_warnings:
+        warn_user(args, sim)
+    return args, fasta, sim
+
+
+def warn_user(args, sim):
+    if sim.fasta and args.infile.name != sim.fasta:
+        print_warning("Fasta filename does not match RMT", args.no_color)
+    if sim.md5 and get_md5(args.infile) != sim.md5:
+        print_warning("Fasta md5 hash does not match RMT", args.no_color)
+
+
+def main(argv=None):
+    start = timer()
+    args, fasta, sim = initialize(argv)
+    if args.seed is not None:
+        import numpy
+        random.seed(args.seed)
+        numpy.random.seed(args.seed)
+    if sim.has_it:
+        exit_with_error(MsimUnsupported(
+            "interchromosomal translocations (it) are outside the MI355X mutation path; "
+            "run the reference for the IT pass on the *_ms output"), args.no_color)
+    if sim.has_mutations:
+        try:
+            mutator = Mutator(args, fasta, sim)
+            mutator.mutate()
+            mutator.close()
+            fasta.close()
+            if args.bench_json:
+                args.bench_json.write_text(json.dumps(mutator.stats, indent=1) + "\n")
+        except (FastaWriterError, VcfWriterError, MsimError) as e:
+            exit_with_error(e, args.no_color)
+    runtime = round(timer() - start, 4)
+    if not args.quiet:
+        print_success(f"Mutation-Simulator finished in: {runtime}s", args.no_color)
+
+
+if __name__ == "__main__":
+    main()

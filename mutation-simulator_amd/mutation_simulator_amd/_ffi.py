@@ -1,0 +1,298 @@
+"""ctypes binding of libmsim.so (include/msim.h) -- the only way the host package reaches the GPU.
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, ``Engine()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+LIB_CANDIDATES = [PKG_DIR.parent / "lib" / "libmsim.so"]
+
+OK, ERR_ARG, ERR_HIP, ERR_VALUE, ERR_KEY, ERR_UNSUPPORTED, ERR_NOMEM = range(7)
+PLAN_AUTO, PLAN_HOST, PLAN_GPU = 0, 1, 2
+
+
+class MsimError(RuntimeError):
+    """A libmsim call failed (HIP error, bad argument, unsupported input)."""
+
+
+class MsimUnsupported(MsimError):
+    """Valid for the reference, outside this build's scope (translocations, >= 4 GiB contigs)."""
+
+
+class Record(C.Structure):           # msim_record, 16 bytes
+    _fields_ = [("pos", C.c_uint32), ("stop", C.c_uint32), ("extra", C.c_uint32),
+                ("type", C.c_uint8), ("aux", C.c_uint8), ("rsv", C.c_uint16)]
+
+
+RECORD_DTYPE = np.dtype([("pos", "<u4"), ("stop", "<u4"), ("extra", "<u4"), ("type", "u1"),
+                         ("aux", "u1"), ("rsv", "<u2")])
+
+
+class Range(C.Structure):            # msim_range
+    _fields_ = [("start", C.c_int64), ("stop", C.c_int64), ("k", C.c_int64),
+                ("setsize", C.c_int64), ("n_types", C.c_int32), ("types", C.c_int32 * 8),
+                ("cdf_thr", C.c_uint64 * 8), ("min_len", C.c_int64 * 8), ("max_len", C.c_int64 * 8)]
+
+
+class Params(C.Structure):           # msim_params
+    _fields_ = [("block", C.c_int64 * 8), ("ti_lim", C.c_uint64)]
+
+
+class Timing(C.Structure):           # msim_timing
+    _fields_ = [("plan_host_ms", C.c_double), ("plan_gpu_ms", C.c_double),
+                ("upload_ms", C.c_double), ("apply_ms", C.c_double),
+                ("apply_kernel_ms", C.c_double), ("apply_launches", C.c_uint64),
+                ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("records", C.c_uint64),
+                ("py_words", C.c_uint64), ("np_words", C.c_uint64)]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# every symbol include/msim.h declares: (name, restype, argtypes)
+_VP, _U8P, _U64P, _U32P, _IP = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), \
+    C.POINTER(C.c_uint32), C.POINTER(C.c_int)
+SYMBOLS = [
+    ("msim_abi_version", C.c_int, []),
+    ("msim_create", C.c_int, [C.c_int, C.c_uint32, C.POINTER(_VP)]),
+    ("msim_destroy", None, [_VP]),
+    ("msim_last_error", C.c_char_p, [_VP]),
+    ("msim_device_name", C.c_int, [_VP, C.c_char_p, C.c_int]),
+    ("msim_sync", C.c_int, [_VP]),
+    ("msim_seed", C.c_int, [_VP, _U32P, C.c_int, C.c_uint32]),
+    ("msim_set_mt_state", C.c_int, [_VP, C.c_int, _U32P, C.c_int]),
+    ("msim_get_mt_state", C.c_int, [_VP, C.c_int, _U32P, _IP]),
+    ("msim_add_contig", C.c_int, [_VP, _VP, C.c_uint64, _IP]),
+    ("msim_add_contig_synthetic", C.c_int, [_VP, C.c_uint64, C.c_uint64, _IP]),
+    ("msim_contig_length", C.c_int, [_VP, C.c_int, _U64P]),
+    ("msim_read_contig", C.c_int, [_VP, C.c_int, C.c_uint64, C.c_uint64, _VP]),
+    ("msim_clear", C.c_int, [_VP]),
+    ("msim_set_params", C.c_int, [_VP, C.POINTER(Params)]),
+    ("msim_plan_contig", C.c_int, [_VP, C.c_int, C.POINTER(Range), C.c_int]),
+    ("msim_plan_was_empty", C.c_int, [_VP, C.c_int, _IP]),
+    ("msim_apply_contig", C.c_int, [_VP, C.c_int]),
+    ("msim_key_error", C.c_int, [_VP, C.c_int, _U8P, _U64P]),
+    ("msim_result_sizes", C.c_int, [_VP, C.c_int, _U64P, _U64P, _U64P]),
+    ("msim_fetch_sequence", C.c_int, [_VP, C.c_int, C.c_uint64, C.c_uint64, _VP]),
+    ("msim_fetch_records", C.c_int, [_VP, C.c_int, _VP, _VP]),
+    ("msim_result_checksum", C.c_int, [_VP, C.c_int, _U64P]),
+    ("msim_release_result", C.c_int, [_VP, C.c_int]),
+    ("msim_render_vcf", C.c_int, [_VP, C.c_uint64, _VP, _VP, C.c_uint64, C.c_char_p, _VP,
+                                  C.c_uint64, _U64P]),
+    ("msim_stats", C.c_int, [_VP, C.POINTER(Timing)]),
+    ("msim_reset_stats", C.c_int, [_VP]),
+]
+
+_lib = None
+
+
+def library_path() -> Path:
+    env = os.environ.get("MSIM_LIB")
+    if env:
+        return Path(env)
+    for p in LIB_CANDIDATES:
+        if p.exists():
+            return p
+    raise MsimError(
+        f"libmsim.so not found (looked in {[str(p) for p in LIB_CANDIDATES]}); build it with "
+        "`make -C mutation-simulator_amd/csrc` or `python -c 'import __graft_entry__ as g; g.build()'`")
+
+
+def load():
+    """dlopen libmsim.so and declare every prototype.  Never touches the GPU by itself."""
+    global _lib
+    if _lib is None:
+        lib = C.CDLL(str(library_path()))
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.msim_abi_version() != 1:
+            raise MsimError("libmsim ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def _ptr(a: np.ndarray):
+    return C.c_void_p(a.ctypes.data)
+
+
+class Engine:
+    """One libmsim context (one GPU).  Thin, typed wrappers -- no logic lives here."""
+
+    def __init__(self, device: int = 0, flags: int = PLAN_AUTO):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.msim_create(device, flags, C.byref(self.h))
+        if rc != OK:
+            msg = self.lib.msim_last_error(None).decode()
+            self.h = None
+            raise MsimError(f"msim_create failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.msim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------ errors
+    def _check(self, rc: int, contig: int | None = None):
+        if rc == OK:
+            return
+        msg = self.lib.msim_last_error(self.h).decode()
+        if rc == ERR_VALUE:
+            raise ValueError(msg)                      # the reference's own exception (util.py:104)
+        if rc == ERR_KEY:
+            base = C.c_uint8()
+            pos = C.c_uint64()
+            self.lib.msim_key_error(self.h, contig if contig is not None else 0, C.byref(base),
+                                    C.byref(pos))
+            raise KeyError(chr(base.value))            # mutator.py:449-455
+        if rc == ERR_UNSUPPORTED:
+            raise MsimUnsupported(msg)
+        raise MsimError(f"libmsim error {rc}: {msg}")
+
+    # ------------------------------------------------------------------ device / rng
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.msim_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def sync(self):
+        self._check(self.lib.msim_sync(self.h))
+
+    def seed(self, py_seed: int, np_seed: int):
+        n = abs(int(py_seed))
+        key = []
+        while True:
+            key.append(n & 0xFFFFFFFF)
+            n >>= 32
+            if not n:
+                break
+        arr = (C.c_uint32 * len(key))(*key)
+        self._check(self.lib.msim_seed(self.h, arr, len(key), int(np_seed) & 0xFFFFFFFF))
+
+    def set_mt_state(self, stream: int, mt, pos: int):
+        arr = np.ascontiguousarray(mt, dtype=np.uint32)
+        assert arr.shape == (624,)
+        self._check(self.lib.msim_set_mt_state(self.h, stream, arr.ctypes.data_as(_U32P), int(pos)))
+
+    def get_mt_state(self, stream: int):
+        arr = np.zeros(624, dtype=np.uint32)
+        pos = C.c_int()
+        self._check(self.lib.msim_get_mt_state(self.h, stream, arr.ctypes.data_as(_U32P),
+                                               C.byref(pos)))
+        return arr, pos.value
+
+    # ------------------------------------------------------------------ genome
+    def add_contig(self, bases: np.ndarray) -> int:
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        cid = C.c_int()
+        self._check(self.lib.msim_add_contig(self.h, _ptr(bases), bases.shape[0], C.byref(cid)))
+        return cid.value
+
+    def add_contig_synthetic(self, length: int, seed: int) -> int:
+        cid = C.c_int()
+        self._check(self.lib.msim_add_contig_synthetic(self.h, length, seed, C.byref(cid)))
+        return cid.value
+
+    def contig_length(self, contig: int) -> int:
+        n = C.c_uint64()
+        self._check(self.lib.msim_contig_length(self.h, contig, C.byref(n)))
+        return n.value
+
+    def read_contig(self, contig: int, offset: int = 0, n: int | None = None) -> np.ndarray:
+        if n is None:
+            n = self.contig_length(contig) - offset
+        out = np.empty(n, dtype=np.uint8)
+        self._check(self.lib.msim_read_contig(self.h, contig, offset, n, _ptr(out)))
+        return out
+
+    def clear(self):
+        self._check(self.lib.msim_clear(self.h))
+
+    # ------------------------------------------------------------------ plan / apply
+    def set_params(self, params: Params):
+        self._check(self.lib.msim_set_params(self.h, C.byref(params)))
+
+    def plan_contig(self, contig: int, ranges: list):
+        arr = (Range * max(len(ranges), 1))(*ranges)
+        self._check(self.lib.msim_plan_contig(self.h, contig, arr, len(ranges)), contig)
+
+    def plan_was_empty(self, contig: int) -> bool:
+        e = C.c_int()
+        self._check(self.lib.msim_plan_was_empty(self.h, contig, C.byref(e)))
+        return bool(e.value)
+
+    def apply_contig(self, contig: int):
+        self._check(self.lib.msim_apply_contig(self.h, contig), contig)
+
+    def result_sizes(self, contig: int, applied: bool = True):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.msim_result_sizes(self.h, contig, C.byref(a) if applied else None,
+                                               C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def fetch_sequence(self, contig: int, offset: int = 0, n: int | None = None) -> np.ndarray:
+        if n is None:
+            n = self.result_sizes(contig)[0] - offset
+        out = np.empty(n, dtype=np.uint8)
+        self._check(self.lib.msim_fetch_sequence(self.h, contig, offset, n, _ptr(out)))
+        return out
+
+    def fetch_records(self, contig: int):
+        _, n_rec, n_pool = self.result_sizes(contig, applied=False)
+        recs = np.zeros(n_rec, dtype=RECORD_DTYPE)
+        pool = np.zeros(n_pool, dtype=np.uint8)
+        self._check(self.lib.msim_fetch_records(self.h, contig, _ptr(recs), _ptr(pool)))
+        return recs, pool
+
+    def result_checksum(self, contig: int) -> int:
+        s = C.c_uint64()
+        self._check(self.lib.msim_result_checksum(self.h, contig, C.byref(s)))
+        return s.value
+
+    def release_result(self, contig: int):
+        self._check(self.lib.msim_release_result(self.h, contig))
+
+    def stats(self) -> dict:
+        t = Timing()
+        self._check(self.lib.msim_stats(self.h, C.byref(t)))
+        return t.as_dict()
+
+    def reset_stats(self):
+        self._check(self.lib.msim_reset_stats(self.h))
+
+
+def render_vcf(recs: np.ndarray, pool: np.ndarray, bases: np.ndarray, seq_name: str) -> bytes:
+    """Record table -> VCF record lines (host helper; no GPU, no context)."""
+    lib = load()
+    recs = np.ascontiguousarray(recs)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    need = C.c_uint64()
+    name = seq_name.encode("utf-8", "replace")
+    rc = lib.msim_render_vcf(_ptr(recs), recs.shape[0], _ptr(pool), _ptr(bases), bases.shape[0],
+                             name, None, 0, C.byref(need))
+    if rc != OK:
+        raise MsimError(f"msim_render_vcf failed ({rc})")
+    out = np.empty(need.value, dtype=np.uint8)
+    rc = lib.msim_render_vcf(_ptr(recs), recs.shape[0], _ptr(pool), _ptr(bases), bases.shape[0],
+                             name, _ptr(out), need.value, C.byref(need))
+    if rc != OK:
+        raise MsimError(f"msim_render_vcf failed ({rc})")
+    return out.tobytes()

@@ -1,0 +1,189 @@
+"""``Mutator`` -- drop-in for the reference class of the same name (mutator.py:73-479), with the
+per-contig work done on an MI355X through libmsim (include/msim.h).
+
+Same constructor, ``mutate()`` and ``close()``; same output files, warnings and exceptions.  What
+changed is *where* the work happens:
+
+  reference                                   here
+  ---------                                   ----
+  random / numpy.random global generators  -> their MT19937 states are handed to libmsim before the
+                                              pass and put back, advanced, afterwards, so a caller
+                                              that seeded them gets the reference's exact output and
+                                              can keep drawing from them as if the reference had run
+  __get_mutations per range (Python dicts) -> msim_plan_contig: 16-byte records in HBM
+  __mutate_sequence per base               -> msim_apply_contig: HIP rewrite kernel, uint8 stream
+  FastaWriter.write per base               -> FastaWriter.write_array on the fetched stream
+  VcfWriter.write per record               -> msim_render_vcf text, VcfWriter.write_raw
+
+All floating-point expressions of the path are evaluated here with the reference's own formulas
+(``plan_descriptors``); the C-ABI takes integers only.
+"""
+from __future__ import annotations
+
+import random
+import sys
+from math import ceil, log
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from .fasta_writer import FastaWriter
+from .mut_types import MutType
+from .util import format_warning
+from .vcf_writer import VcfWriter
+
+_TWO53 = 1 << 53
+
+
+class Mutation:
+    """One generated mutation; 0-based inclusive positions (reference mutator.py:26-50)."""
+    __slots__ = ("type", "start", "stop", "trans_reverse", "trans_insert_pos")
+
+    def __init__(self, type: MutType, start: int, stop: int = 0, trans_reverse: bool = False,
+                 trans_insert_pos: int = 0):
+        self.type = type
+        self.start = start
+        self.stop = stop
+        self.trans_reverse = trans_reverse
+        self.trans_insert_pos = trans_insert_pos
+
+    def __repr__(self) -> str:
+        return (f"{self.type}, {self.start}, {self.stop}, {self.trans_reverse}, "
+                f"{self.trans_insert_pos}\n")
+
+
+# ---------------------------------------------------------------------- settings -> integers
+def _ceil_scaled(x: float) -> int:
+    """ceil(x * 2**53), exactly."""
+    num, den = float(x).as_integer_ratio()
+    return -((-num * _TWO53) // den)
+
+
+def _floor_scaled(x: float) -> int:
+    num, den = float(x).as_integer_ratio()
+    return (num * _TWO53) // den
+
+
+def sample_setsize(k: int) -> int:
+    """CPython ``random.sample`` pool/set switch (Lib/random.py), same float expression."""
+    setsize = 21
+    if k > 5:
+        setsize += 4 ** ceil(log(k * 3, 4))
+    return setsize
+
+
+def range_descriptor(rd) -> "_ffi.Range":
+    """One ``RangeDefinition`` with mutations -> ``msim_range`` (what mutator.py:157-174 derives)."""
+    ms = rd.mutation_settings
+    rate_sum = sum(ms.mut_rates.values())                         # mutator.py:160
+    r = _ffi.Range()
+    r.start, r.stop = rd.start, rd.stop
+    r.k = int(((rd.stop - rd.start) + 1) * rate_sum)              # mutator.py:225
+    r.setsize = sample_setsize(r.k)
+    chances = list(ms.mut_chances.values())                       # mutator.py:172-173
+    # numpy.random.choice(p=...): cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+    cdf = np.cumsum(np.array(chances, dtype=np.float64))
+    cdf /= cdf[-1]
+    r.n_types = len(chances)
+    for j, t in enumerate(ms.mut_chances):
+        r.types[j] = t.value
+        r.cdf_thr[j] = _ceil_scaled(float(cdf[j]))
+    if ms.mut_lengs:
+        for t, v in ms.mut_lengs["min"].items():
+            r.min_len[t.value] = v
+        for t, v in ms.mut_lengs["max"].items():
+            r.max_len[t.value] = v
+    return r
+
+
+def params_descriptor(sim) -> "_ffi.Params":
+    p = _ffi.Params()
+    for i in range(8):
+        p.block[i] = 1
+    for t, v in sim.mut_block.items():
+        p.block[t.value] = v
+    titv = sim.titv
+    p_ti = titv * (1 / (titv + 1))                                # mutator.py:436
+    p.ti_lim = 0 if p_ti != p_ti else min(_floor_scaled(p_ti) + 1, _TWO53)   # `p <= p_ti`
+    return p
+
+
+def plan_descriptors(chrom) -> list:
+    return [range_descriptor(rd) for rd in chrom.range_definitions
+            if rd.mutation_settings.has_mutations]
+
+
+# ---------------------------------------------------------------------- RNG hand-over
+def export_python_streams(engine: "_ffi.Engine") -> None:
+    """Give libmsim the current states of ``random`` and ``numpy.random``."""
+    st = random.getstate()
+    engine.set_mt_state(0, np.array(st[1][:624], dtype=np.uint32), st[1][624])
+    nst = np.random.get_state()
+    engine.set_mt_state(1, np.asarray(nst[1], dtype=np.uint32), int(nst[2]))
+
+
+def import_python_streams(engine: "_ffi.Engine") -> None:
+    """Put the advanced states back so later draws continue where the reference's would."""
+    mt, pos = engine.get_mt_state(0)
+    st = random.getstate()
+    random.setstate((st[0], tuple(int(x) for x in mt) + (int(pos),), st[2]))
+    mt, pos = engine.get_mt_state(1)
+    nst = np.random.get_state()
+    np.random.set_state((nst[0], mt, int(pos), nst[3], nst[4]))
+
+
+class Mutator:
+    """Runs the mutation pass of one genome on the GPU and writes ``*_ms.fa`` / ``*_ms.vcf``."""
+
+    def __init__(self, args, fasta, sim, engine: Optional["_ffi.Engine"] = None):
+        self._args = args
+        self._fasta = fasta
+        self._sim = sim
+        self._fasta_writer = FastaWriter(args.outfasta)
+        self._vcf_writer = VcfWriter(args.outvcf)
+        self._vcf_writer.write_header(args.infile.name, fasta, sim.assembly_name, sim.species_name,
+                                      sim.sample_name)
+        self._engine = engine
+        self._own_engine = engine is None
+        self.stats: dict = {}
+
+    def close(self):
+        self._fasta_writer.close()
+        self._vcf_writer.close()
+        if self._own_engine and self._engine is not None:
+            self._engine.close()
+            self._engine = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def mutate(self):
+        if self._engine is None:
+            self._engine = _ffi.Engine(getattr(self._args, "device", 0) or 0)
+        eng = self._engine
+        export_python_streams(eng)
+        eng.set_params(params_descriptor(self._sim))
+        eng.reset_stats()
+        try:
+            for chrom in self._sim.chromosomes:
+                rec = self._fasta[chrom.number]
+                cid = eng.add_contig(rec.bases)
+                eng.plan_contig(cid, plan_descriptors(chrom))
+                if eng.plan_was_empty(cid) and not self._args.ignore_warnings:
+                    print(format_warning(
+                        f"No mutations could be generated on sequence {chrom.number+1} "
+                        "(mutation rates too low)", self._args.no_color), file=sys.stderr)
+                self._fasta_writer.set_bpl(self._fasta.faidx.index[rec.name].lenc)
+                self._fasta_writer.write_header(rec.long_name)
+                eng.apply_contig(cid)
+                self._fasta_writer.write_array(eng.fetch_sequence(cid))
+                recs, pool = eng.fetch_records(cid)
+                self._vcf_writer.write_raw(_ffi.render_vcf(recs, pool, rec.bases, rec.name))
+                eng.clear()
+        finally:
+            import_python_streams(eng)
+            self.stats = eng.stats()

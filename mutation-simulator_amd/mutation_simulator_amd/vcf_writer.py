@@ -1,0 +1,84 @@
+"""VCF output (reference vcf_writer.py:16-126): ``VcfRecord`` / ``VcfWriter`` with the same
+fields, header text and line format; ``write_raw`` takes pre-rendered record lines from the C-ABI
+renderer (``msim_render_vcf``) so 30 M records do not go through Python objects."""
+from __future__ import annotations
+
+from datetime import datetime
+
+
+class VcfWriterError(Exception):
+    """Raised when the writer can not write to a file."""
+
+
+class VcfRecord:
+    def __init__(self, svtype: str = "", start: int = 0, end: int = 0, len: int = 0,
+                 ref: str = "", alt: str = ""):
+        self.svtype = svtype
+        self.start = start
+        self.end = end
+        self.len = len
+        self.ref = ref
+        self.alt = alt
+
+    def __repr__(self) -> str:
+        return f"{self.svtype} {self.start} {self.end} {self.len} {self.ref} {self.alt}"
+
+    @property
+    def info(self) -> str:
+        if self.svtype == "sn":
+            return "."
+        return f"SVTYPE={self.svtype};END={self.end};SVLEN={self.len}"
+
+
+_HEADER_TAIL = (
+    '##INFO=<ID=SVTYPE,Number=1,Type=String,Description="Type of structural variant">\n'
+    '##INFO=<ID=END,Number=1,Type=Integer,Description="End position of the variant described in '
+    'this record">\n'
+    '##INFO=<ID=SVLEN,Number=.,Type=Integer,Description="Difference in length between REF and ALT '
+    'alleles">\n'
+    '##ALT=<ID=INS,Description="Insert">\n'
+    '##ALT=<ID=DEL,Description="Deletion">\n'
+    '##ALT=<ID=DUP,Description="Duplication">\n'
+    '##ALT=<ID=INV,Description="Inversion">\n'
+    '##ALT=<ID=DEL:ME,Description="Deletion of mobile element">\n'
+    '##ALT=<ID=INS:ME,Description="Insertion of mobile element">\n'
+    '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">\n')
+
+
+class VcfWriter:
+    def __init__(self, fname):
+        try:
+            self._out = open(fname, "wb")
+        except IOError as e:
+            raise VcfWriterError(f"Cannot write to VCF file {fname} {e}")
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        out = getattr(self, "_out", None)
+        if out is not None:
+            out.close()
+
+    def write_header(self, input_fasta, fasta, assembly_name: str, species_name: str,
+                     sample_name: str):
+        now = datetime.now()
+        lines = ["##fileformat=VCFv4.3\n",
+                 f"##filedate={now.year}{now.month}{now.day}\n",      # unpadded, as the reference
+                 "##source=Mutation-Simulator\n",
+                 f"##reference={input_fasta}\n"]
+        for key in list(fasta.keys()):
+            rec = fasta[key]
+            lines.append(f"##contig=<ID={rec.name},length={len(rec)},assembly={assembly_name},"
+                         f"species=\"{species_name}\">\n")
+        lines.append(_HEADER_TAIL)
+        lines.append(f"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample_name}\n")
+        self._out.write("".join(lines).encode("utf-8", "replace"))
+
+    def write(self, record: VcfRecord, seq_name: str):
+        if record.ref != record.alt:
+            self._out.write(f"{seq_name}\t{record.start}\t.\t{record.ref}\t{record.alt}\t.\t.\t"
+                            f"{record.info}\tGT\t1\n".encode("utf-8", "replace"))
+
+    def write_raw(self, text: bytes):
+        self._out.write(text)

@@ -1,0 +1,216 @@
+"""Parity tests proper: the HIP path, called through the C-ABI, against the reference goldens and
+against the CPU oracle on seeded inputs.  Bar: bit-exact (integer / byte work)."""
+from __future__ import annotations
+
+import contextlib
+import io
+import random
+
+import numpy as np
+import pytest
+
+from helpers import (CASES, all_case_names, case_input_bytes, case_meta, mask_vcf,
+                     parse_fasta_bytes, sha256)
+from mutation_simulator_amd import _ffi
+from oracle import oracle as orc
+from pipeline import run_product_case
+
+pytestmark = pytest.mark.gpu
+
+RUNNABLE = [n for n in all_case_names() if case_meta(n).get("sim") is not None]
+
+
+@pytest.fixture(scope="module")
+def engine():
+    eng = _ffi.Engine(0)
+    yield eng
+    eng.close()
+
+
+def test_device_is_mi355x(engine):
+    assert "gfx950" in engine.device_name()
+
+
+@pytest.mark.parametrize("name", RUNNABLE)
+def test_cli_matches_reference_golden(name, tmp_path):
+    """Whole CLI on the GPU == what the reference wrote for the same argv + seeds."""
+    meta = case_meta(name)
+    res = run_product_case(meta, tmp_path)
+    if name == "readme_mix_tl":
+        assert res["exit_code"] == 1 and "translocations" in res["stderr"]
+        return
+    if meta["exception"] is not None:
+        assert type(res["exception"]).__name__ == meta["exception"]["type"]
+        if meta["exception"]["type"] == "KeyError":
+            assert repr(res["exception"].args[0]) == meta["exception"]["repr_args"][0]
+        else:
+            assert str(res["exception"]) == meta["exception"]["message"]
+        return
+    assert res["exception"] is None and res["exit_code"] is None, (res["exception"], res["stderr"])
+    assert len(res["fasta"]) == meta["fasta_len"] and sha256(res["fasta"]) == meta["fasta_sha256"]
+    assert len(res["vcf"]) == meta["vcf_len"] and sha256(res["vcf"]) == meta["vcf_sha256"]
+    if meta["store"] == "full":
+        assert res["fasta"] == (CASES / name / "expected_ms.fa").read_bytes()
+        assert res["vcf"] == (CASES / name / "expected_ms.vcf").read_bytes()
+    assert res["stderr"] == meta["stderr"]
+    assert [random.getrandbits(32) for _ in range(4)] == meta["py_next_words_after"]
+
+
+# ------------------------------------------------------------------ seeded sweeps vs the oracle
+def _sim_dump_from(sim):
+    from test_host_settings import dump_sim
+    return dump_sim(sim)
+
+
+def _product_vs_oracle(tmp_path, spec, argv_tail, seed_py, seed_np, rmt_text=None):
+    import inputs as gin
+    import mutation_simulator_amd as msa
+    from mutation_simulator_amd import __main__ as msa_main
+    infile = gin.write_input(spec, tmp_path / "in.fa")
+    tail = list(argv_tail)
+    if rmt_text is not None:
+        (tmp_path / "c.rmt").write_text(rmt_text)
+        tail = ["rmt", str(tmp_path / "c.rmt")]
+    argv = ["-q", "-o", str(tmp_path / "out"), str(infile)] + tail
+    random.seed(seed_py)
+    np.random.seed(seed_np)
+    with contextlib.redirect_stderr(io.StringIO()):
+        msa_main.main(argv)
+    got_fa = (tmp_path / "out_ms.fa").read_bytes()
+    got_vcf = mask_vcf((tmp_path / "out_ms.vcf").read_bytes())
+    # oracle on the same settings tree
+    with contextlib.redirect_stderr(io.StringIO()):
+        args = msa.get_args(argv)
+        fasta = msa.load_fasta(args.infile)
+        sim = (msa.SimulationSettings.from_args(args, fasta, True) if args.mode == "args"
+               else msa.SimulationSettings.from_rmt(args.rmtfile, fasta, True))
+    o = orc.Oracle()
+    o.seed(seed_py, seed_np)
+    contigs = parse_fasta_bytes(infile.read_bytes())
+    fa, vcf, _, _ = o.run_genome(contigs, _sim_dump_from(sim), infile.name)
+    assert got_fa == fa
+    assert got_vcf == vcf
+
+
+SWEEP = [
+    ("snp_5mb", [5_000_000], ["args", "-sn", "0.01", "-titv", "2.0"]),
+    ("sv_3mb", [2_000_000, 1_000_003], ["args", "-sn", "0.005", "-in", "0.001", "-inmin", "1", "-inmax", "50",
+                                        "-de", "0.001", "-demin", "1", "-demax", "50", "-du", "0.0005",
+                                        "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50",
+                                        "-ivmax", "500"]),
+    ("dense_snp", [300_000], ["args", "-sn", "0.3", "-titv", "0.7"]),            # > 1024 records / tile
+    ("dense_mix", [200_000, 77], ["args", "-sn", "0.1", "-in", "0.1", "-inmax", "9", "-de", "0.1", "-demax", "7",
+                                  "-du", "0.05", "-dumax", "11", "-iv", "0.05", "-ivmax", "13"]),
+    ("long_sv", [400_000], ["args", "-de", "0.0002", "-demin", "500", "-demax", "40000", "-du", "0.0002",
+                            "-dumin", "300", "-dumax", "30000", "-iv", "0.0002", "-ivmin", "100", "-ivmax",
+                            "20000", "-in", "0.0002", "-inmin", "200", "-inmax", "5000"]),
+    ("tiny", [1, 2, 15, 16, 17, 31, 33, 64, 4095, 4096, 4097, 16383, 16384, 16385],
+     ["args", "-sn", "0.2", "-in", "0.05", "-de", "0.05"]),
+]
+
+
+@pytest.mark.parametrize("name,lengths,argv", SWEEP, ids=[s[0] for s in SWEEP])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_sweep_vs_oracle(name, lengths, argv, seed, tmp_path):
+    spec = {"contigs": [{"defline": f"s{i} d", "length": L, "bpl": 60 + 7 * (i % 3), "seed": 100 * seed + i,
+                         "decorate": (i % 2 == 1) and L > 2000} for i, L in enumerate(lengths)]}
+    _product_vs_oracle(tmp_path, spec, argv, seed, seed + 17)
+
+
+def test_random_parameter_sweep_vs_oracle(tmp_path):
+    """Randomised (fixed-seed) argument sets: rates, length bounds, blocks, titv, odd contig sizes."""
+    rs = np.random.RandomState(2024)
+    for it in range(12):
+        rates = rs.random_sample(5) * rs.choice([0.002, 0.02, 0.08])
+        rates[rs.randint(0, 5)] = 0.0
+        argv = ["args", "-titv", str(round(float(rs.random_sample() * 4), 3))]
+        for flag, r in zip(["sn", "in", "de", "iv", "du"], rates):
+            argv += [f"-{flag}", repr(float(r))]
+            if flag != "sn":
+                lo = int(rs.randint(2 if flag == "iv" else 1, 30))
+                argv += [f"-{flag}min", str(lo), f"-{flag}max", str(lo + int(rs.randint(0, 200)))]
+            argv += [f"-{flag}b", str(int(rs.randint(1, 8)))]
+        lengths = [int(rs.randint(1, 400_000)) for _ in range(int(rs.randint(1, 4)))]
+        spec = {"contigs": [{"defline": f"r{it}_{i}", "length": L, "bpl": int(rs.randint(20, 100)),
+                             "seed": 1000 * it + i, "decorate": bool(rs.randint(0, 2)) and L > 2000}
+                            for i, L in enumerate(lengths)]}
+        d = tmp_path / f"it{it}"
+        d.mkdir()
+        _product_vs_oracle(d, spec, argv, 10 + it, 90 + it)
+
+
+def test_rmt_many_ranges_vs_oracle(tmp_path):
+    rs = np.random.RandomState(7)
+    L = 600_000
+    cuts = sorted(set(int(x) for x in rs.randint(1, L, 120)))
+    rows = []
+    for a, b in zip(cuts[::2], cuts[1::2]):
+        kind = rs.randint(0, 4)
+        if b - a < 3:
+            continue
+        if kind == 0:
+            rows.append(f"{a+1}-{b} None")
+        elif kind == 1:
+            rows.append(f"{a+1}-{b} sn 0.05")
+        elif kind == 2:
+            rows.append(f"{a+1}-{b} sn 0.3 in 0.02 inmin 1 inmax 4")
+        else:
+            rows.append(f"{a+1}-{b} sn 0.001 de 0.002 demin 3 demax 60 iv 0.001 ivmin 5 ivmax 90 du 0.001 dumin 4 dumax 80")
+    text = "titv = 1.7\nsn_block = 2\nstd\nit None\nsn 0.01\nchr 1\n" + "\n".join(rows) + "\n"
+    spec = {"contigs": [{"defline": "big rmt", "length": L, "bpl": 60, "seed": 5},
+                        {"defline": "other", "length": 50_000, "bpl": 60, "seed": 6}]}
+    _product_vs_oracle(tmp_path, spec, [], 3, 4, rmt_text=text)
+
+
+# ------------------------------------------------------------------ device helpers
+def mix64(z):
+    z = (z + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
+    return z ^ (z >> np.uint64(31))
+
+
+def synth_host(length: int, seed: int) -> np.ndarray:
+    """Host twin of msim::k_synth: base(i) = "ACGT"[(mix64(seed + (i >> 5)) >> (2 * (i & 31))) & 3]."""
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = np.empty(length, dtype=np.uint8)
+    lanes = (length + 31) // 32
+    sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
+    step = 1 << 20
+    with np.errstate(over="ignore"):
+        for g0 in range(0, lanes, step):
+            g = np.arange(g0, min(lanes, g0 + step), dtype=np.uint64)
+            bits = mix64(np.uint64(seed) + g)
+            codes = ((bits[:, None] >> sh) & np.uint64(3)).astype(np.uint8).reshape(-1)
+            lo = g0 * 32
+            hi = min(length, lo + codes.shape[0])
+            out[lo:hi] = acgt[codes[:hi - lo]]
+    return out
+
+
+def checksum_host(b: np.ndarray) -> int:
+    n = len(b)
+    pad = (-n) % 8
+    w = np.concatenate([b, np.zeros(pad, np.uint8)]).view("<u8")
+    with np.errstate(over="ignore"):
+        k = np.arange(len(w), dtype=np.uint64)
+        s = int(mix64(w + k * np.uint64(0x9E3779B97F4A7C15)).sum(dtype=np.uint64))
+        return (s + n * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.parametrize("length", [1, 31, 32, 33, 1000, 1 << 20, (1 << 20) + 17])
+def test_synthetic_contig_and_checksum(engine, length):
+    engine.clear()
+    cid = engine.add_contig_synthetic(length, 99)
+    got = engine.read_contig(cid)
+    want = synth_host(length, 99)
+    assert np.array_equal(got, want)
+    p = _ffi.Params()
+    for i in range(8):
+        p.block[i] = 1
+    engine.set_params(p)
+    engine.plan_contig(cid, [])
+    engine.apply_contig(cid)
+    assert np.array_equal(engine.fetch_sequence(cid), want)          # no records: identity
+    assert engine.result_checksum(cid) == checksum_host(want)
+    engine.clear()

@@ -1,0 +1,106 @@
+"""FASTA ingest and the two writers (host side of the drop-in surface)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import mutation_simulator_amd as msa
+from helpers import CASES, all_case_names, case_meta, parse_fasta_bytes
+from mutation_simulator_amd.fasta_io import Fasta
+
+
+def test_loader_basic(tmp_path):
+    p = tmp_path / "a.fa"
+    p.write_bytes(b">c1 first contig\nacgtNN\nACG\n>c2\r\nAAAA\r\nCC\r\n>c3 empty\n>c4\nA")
+    f = Fasta(p)
+    assert list(f.keys()) == ["c1", "c2", "c3", "c4"]
+    assert str(f["c1"]) == "ACGTNNACG" and f[0].long_name == "c1 first contig"
+    assert f.faidx.index["c1"].lenc == 6 and f.faidx.index["c2"].lenc == 4
+    assert str(f[1]) == "AAAACC" and len(f[2]) == 0 and str(f[3]) == "A"
+    assert f[0][2] == "G" and f[0][1:4] == "CGT"
+    assert (tmp_path / "a.fa.fai").read_text().splitlines()[0] == "c1\t9\t17\t6\t7"
+
+
+def test_loader_errors(tmp_path):
+    p = tmp_path / "dup.fa"
+    p.write_bytes(b">x 1\nAC\n>x 2\nGT\n")
+    with pytest.raises(msa.FastaDuplicateHeaderError, match="contains duplicate header"):
+        msa.load_fasta(p)
+    p = tmp_path / "ragged.fa"
+    p.write_bytes(b">x\nACGT\nAC\nACGT\n")
+    with pytest.raises(msa.FastaIndexingError):
+        msa.load_fasta(p)
+    with pytest.raises(msa.FastaNotFoundError):
+        Fasta(tmp_path / "missing.fa")
+
+
+@pytest.mark.parametrize("name", [n for n in all_case_names() if case_meta(n)["store"] == "full"
+                                  and (CASES / n / "expected_ms.fa").exists()])
+def test_fasta_writer_framing_reproduces_reference_files(name, tmp_path):
+    """Feeding the reference's own mutated sequences through our FastaWriter (bulk path, split at
+    awkward places) must give the reference's bytes: wrap at the INPUT contig's line width, newline
+    before a header only after a partial line, no trailing newline after a partial last line."""
+    meta = case_meta(name)
+    want = (CASES / name / "expected_ms.fa").read_bytes()
+    seqs = parse_fasta_bytes(want)
+    out = tmp_path / "o.fa"
+    w = msa.FastaWriter(out)
+    rs = np.random.RandomState(1)
+    for c, g in zip(seqs, meta["contigs"]):
+        w.set_bpl(g["lenc"])
+        w.write_header(g["long_name"])
+        b = c["bases"]
+        cuts = sorted(set(int(x) for x in rs.randint(0, len(b) + 1, 5))) if len(b) else []
+        prev = 0
+        for cut in cuts + [len(b)]:
+            w.write_array(b[prev:cut])
+            prev = cut
+    w.close()
+    assert out.read_bytes() == want
+
+
+def test_fasta_writer_single_base_api(tmp_path):
+    out = tmp_path / "o.fa"
+    w = msa.FastaWriter(out)
+    w.set_bpl(3)
+    w.write_header("h1")
+    for ch in "ACGTA":
+        w.write(ch)
+    w.write_header("h2")
+    w.write_multi("ACG")
+    w.write_header("h3")
+    w.write_multi(["T", "T"])
+    w.close()
+    assert out.read_bytes() == b">h1\nACG\nTA\n>h2\nACG\n>h3\nTT"
+
+
+def test_vcf_writer_header_and_record(tmp_path):
+    name = "snp_titv2_2ctg"
+    meta = case_meta(name)
+    want = (CASES / name / "expected_ms.vcf").read_bytes()
+    inp = tmp_path / meta["infile_name"]
+    inp.write_bytes((CASES / name / "input.fa").read_bytes())
+    fasta = msa.load_fasta(inp)
+    w = msa.VcfWriter(tmp_path / "o.vcf")
+    w.write_header(inp.name, fasta, "Unknown", "Unknown", "Unknown")
+    w.write(msa.VcfRecord("sn", 5, ref="A", alt="A"), "chrA")          # suppressed: REF == ALT
+    w.write(msa.VcfRecord("sn", 7, ref="A", alt="G"), "chrA")
+    w.write(msa.VcfRecord("DEL", 9, 12, 3, "ACGT", "A"), "chrA")
+    w.close()
+    got = (tmp_path / "o.vcf").read_bytes().split(b"\n")
+    header_want = [l for l in want.split(b"\n") if l.startswith(b"#")]
+    header_got = [l for l in got if l.startswith(b"#")]
+    assert [l for l in header_got if not l.startswith(b"##filedate=")] == \
+           [l for l in header_want if not l.startswith(b"##filedate=")]
+    import datetime
+    now = datetime.datetime.now()
+    assert f"##filedate={now.year}{now.month}{now.day}".encode() in header_got
+    assert got[len(header_got):] == [b"chrA\t7\t.\tA\tG\t.\t.\t.\tGT\t1",
+                                     b"chrA\t9\t.\tACGT\tA\t.\t.\tSVTYPE=DEL;END=12;SVLEN=3\tGT\t1", b""]
+
+
+def test_writer_errors(tmp_path):
+    with pytest.raises(msa.FastaWriterError, match="Cannot write to Fasta file"):
+        msa.FastaWriter(tmp_path / "nodir" / "x.fa")
+    with pytest.raises(msa.VcfWriterError, match="Cannot write to VCF file"):
+        msa.VcfWriter(tmp_path / "nodir" / "x.vcf")

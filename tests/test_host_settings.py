@@ -1,0 +1,127 @@
+"""Host logic vs reference goldens: argv / RMT text -> settings tree, output naming, warnings,
+error types + messages (tests/golden/settings.json, cases/err_*)."""
+from __future__ import annotations
+
+import contextlib
+import io
+from pathlib import Path
+
+import pytest
+
+import mutation_simulator_amd as msa
+from helpers import all_case_names, case_meta, load_json
+from pipeline import build_settings, prepare
+
+SETTINGS = load_json("settings.json")
+
+
+def dump_sim(sim) -> dict:
+    """Same neutral form as tests/golden/make_goldens.py:dump_sim, from OUR settings classes."""
+    def ms(m):
+        if m.mut_rates is None:
+            return None
+        return {"rates": [[t.name, r] for t, r in m.mut_rates.items()],
+                "rates_hex": [[t.name, float(r).hex()] for t, r in m.mut_rates.items()],
+                "chances_hex": [[t.name, float(c).hex()] for t, c in m.mut_chances.items()],
+                "rate_sum_hex": float(sum(m.mut_rates.values())).hex(),
+                "min": {t.name: v for t, v in m.mut_lengs["min"].items()} if m.mut_lengs else None,
+                "max": {t.name: v for t, v in m.mut_lengs["max"].items()} if m.mut_lengs else None,
+                "has_mutations": m.has_mutations}
+    return {
+        "mut_block": [[t.name, v] for t, v in sim.mut_block.items()],
+        "titv": sim.titv, "fasta": sim.fasta if sim.fasta is None else str(sim.fasta),
+        "md5": sim.md5, "species_name": sim.species_name, "assembly_name": sim.assembly_name,
+        "sample_name": sim.sample_name, "has_mutations": sim.has_mutations, "has_it": sim.has_it,
+        "chromosomes": [{"number": c.number, "it_rate": c.it_rate,
+                         "ranges": [{"start": r.start, "stop": r.stop,
+                                     "settings": ms(r.mutation_settings)}
+                                    for r in c.range_definitions]} for c in sim.chromosomes],
+    }
+
+
+def _norm_blocks(d):
+    d = dict(d)
+    d["mut_block"] = sorted(d["mut_block"])      # only min() and per-type lookups are observable
+    return d
+
+
+@pytest.mark.parametrize("case", SETTINGS["cases"], ids=lambda c: c["name"])
+def test_settings_tree(case, tmp_path):
+    import inputs as gin
+    infile = gin.write_input(case["input_spec"], tmp_path / "Input.FA")
+    err = io.StringIO()
+    got, exc = None, None
+    try:
+        with contextlib.redirect_stderr(err):
+            if case["kind"] == "rmt":
+                p = tmp_path / f"{case['name']}.rmt"
+                p.write_text(case["rmt_text"])
+                fasta = msa.load_fasta(infile)
+                sim = msa.SimulationSettings.from_rmt(p, fasta, False)
+            else:
+                args = msa.get_args([str(infile)] + case["argv_tail"])
+                fasta = msa.load_fasta(args.infile)
+                sim = msa.SimulationSettings.from_args(args, fasta, args.ignore_warnings)
+        got = dump_sim(sim)
+    except Exception as e:  # noqa: BLE001
+        exc = e
+    if "exception" in case:
+        assert exc is not None and type(exc).__name__ == case["exception"]["type"]
+        assert str(exc).replace(str(tmp_path), "<TMP>") == case["exception"]["message"]
+    else:
+        assert exc is None, exc
+        assert _norm_blocks(got) == _norm_blocks(case["sim"])
+    assert err.getvalue() == case["stderr"]
+
+
+@pytest.mark.parametrize("n", SETTINGS["naming"], ids=lambda n: f"{n['o']}-{n['infile']}")
+def test_output_naming(n):
+    argv = ([] if n["o"] is None else ["-o", n["o"]]) + [n["infile"], "args"]
+    a = msa.get_args(argv)
+    assert (str(a.outbase), str(a.outfasta), str(a.outvcf)) == (n["outbase"], n["outfasta"], n["outvcf"])
+
+
+EXIT_CASES = [n for n in all_case_names() if case_meta(n)["exit_code"] is not None]
+
+
+@pytest.mark.parametrize("name", EXIT_CASES)
+def test_cli_init_errors(name, tmp_path):
+    """Errors the reference funnels into ``ERROR: ...`` + exit(1) (__main__.py:52-59)."""
+    meta = case_meta(name)
+    argv = prepare(meta, tmp_path)
+    from mutation_simulator_amd import __main__ as m
+    err = io.StringIO()
+    with contextlib.redirect_stderr(err), pytest.raises(SystemExit) as ei:
+        m.initialize(argv)
+    assert ei.value.code == meta["exit_code"]
+    assert err.getvalue().replace(str(tmp_path), "<TMP>") == meta["stderr"]
+
+
+@pytest.mark.parametrize("name", [n for n in all_case_names() if case_meta(n).get("sim")])
+def test_cli_case_settings(name, tmp_path):
+    """For every runnable golden case our settings tree equals the reference's."""
+    meta = case_meta(name)
+    with contextlib.redirect_stderr(io.StringIO()):
+        args, fasta, sim = build_settings(prepare(meta, tmp_path))
+    got = dump_sim(sim)
+    want = dict(meta["sim"])
+    # from_rmt keeps meta["fasta"] lower-cased text; compare verbatim
+    assert _norm_blocks(got) == _norm_blocks(want)
+    assert [(fasta[k].name, fasta[k].long_name, len(fasta[k]), fasta.faidx.index[k].lenc)
+            for k in fasta.keys()] == [(c["name"], c["long_name"], c["length"], c["lenc"])
+                                       for c in meta["contigs"]]
+
+
+def test_version_flag(capsys):
+    with pytest.raises(SystemExit):
+        msa.get_args(["-v"])
+    assert capsys.readouterr().out.strip() == "Mutation-Simulator 3.0.2"
+
+
+def test_readme_long_flag_spelling_rejected():
+    """BASELINE.json spells --transitiontransversion; the reference's flag is
+    --transitionstransversions / -titv (argument_parser.py:94-99) and rejects the other."""
+    with pytest.raises(SystemExit):
+        with contextlib.redirect_stderr(io.StringIO()):
+            msa.get_args(["x.fa", "args", "--transitiontransversion", "2.0"])
+    assert msa.get_args(["x.fa", "args", "-titv", "2.0"]).transitionstransversions == 2.0
