@@ -121,6 +121,10 @@ int msim_seed(msim_ctx *ctx, const uint32_t *py_key, int n_key, uint32_t np_seed
 int msim_set_mt_state(msim_ctx *ctx, int stream, const uint32_t mt[624], int pos);
 int msim_get_mt_state(msim_ctx *ctx, int stream, uint32_t mt[624], int *pos);
 
+/* Optional sizing hint for the GPU sampler: how many words of each stream the coming plan calls
+ * will roughly consume, so stream chunks are generated in one batch.  Never changes results.      */
+int msim_reserve_streams(msim_ctx *ctx, uint64_t py_words, uint64_t np_words);
+
 /* ---- genome in HBM ----------------------------------------------------------------------------- */
 /* Upload one contig (upper-cased bases, what pyfaidx hands the reference: util.py:84-88).
  * Contigs are numbered in call order like fasta[i].                                                */

@@ -35,6 +35,8 @@ struct Contig {
 
 constexpr uint64_t PAD = 64;          // slack after every byte buffer so 16-B vector accesses stay in bounds
 
+struct GpuPlan;
+
 struct Ctx {
     int device = 0;
     bool host_only = false;           // msim_create(-1): PLAN + text rendering only, no GPU touched
@@ -43,7 +45,8 @@ struct Ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     std::string err;
     std::string devname;
-    HostMT py, np;                    // canonical stream states (host engine)
+    HostMT py, np;                    // stream states, host representation
+    GpuPlan *gpu = nullptr;           // device representation of the streams + sampler scratch
     msim_params params{};
     bool have_params = false;
     std::vector<Contig> contigs;

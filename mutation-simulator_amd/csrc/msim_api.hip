@@ -5,6 +5,7 @@
 #include <new>
 
 #include "ctx.h"
+#include "plan_gpu.h"
 
 namespace msim {
 
@@ -148,6 +149,7 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     if ((e = hipMalloc(&c->dev.d_lut, sizeof lut)) != hipSuccess) return bail(e, "hipMalloc(lut)");
     if ((e = hipMemcpy(c->dev.d_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(lut)");
     if ((e = hipMalloc(&c->dev.d_err, 64)) != hipSuccess) return bail(e, "hipMalloc(err)");
+    c->gpu = gpu_plan_create();
     *out = reinterpret_cast<msim_ctx *>(static_cast<Ctx *>(c));
     return MSIM_OK;
 }
@@ -165,6 +167,7 @@ void msim_destroy(msim_ctx *p) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
     if (c->dev.d_err) (void)hipFree(c->dev.d_err);
+    gpu_plan_destroy(c->gpu);
     hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -197,24 +200,41 @@ int msim_seed(msim_ctx *p, const uint32_t *py_key, int n_key, uint32_t np_seed) 
     c->py.words = 0;
     c->np.init_genrand(np_seed);
     c->np.words = 0;
+    if (c->gpu) gpu_plan_invalidate(c->gpu);
     return MSIM_OK;
 }
 
 int msim_set_mt_state(msim_ctx *p, int stream, const uint32_t mt[624], int pos) {
     Ctx *c = C(p);
     if (!c || !mt || pos < 0 || pos > 624 || stream < 0 || stream > 1) return MSIM_ERR_ARG;
+    if (c->gpu) {                      // keep the other stream's position before dropping the device copy
+        int rc = gpu_plan_sync_to_host(c, c->gpu);
+        if (rc) return rc;
+    }
     HostMT &g = stream ? c->np : c->py;
     memcpy(g.mt, mt, sizeof g.mt);
     g.idx = pos;
+    if (c->gpu) gpu_plan_invalidate(c->gpu);
     return MSIM_OK;
 }
 
 int msim_get_mt_state(msim_ctx *p, int stream, uint32_t mt[624], int *pos) {
     Ctx *c = C(p);
     if (!c || !mt || !pos || stream < 0 || stream > 1) return MSIM_ERR_ARG;
+    if (c->gpu) {
+        int rc = gpu_plan_sync_to_host(c, c->gpu);
+        if (rc) return rc;
+    }
     HostMT &g = stream ? c->np : c->py;
     memcpy(mt, g.mt, sizeof g.mt);
     *pos = g.idx;
+    return MSIM_OK;
+}
+
+int msim_reserve_streams(msim_ctx *p, uint64_t py_words, uint64_t np_words) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    if (c->gpu) gpu_plan_reserve(c->gpu, py_words, np_words);
     return MSIM_OK;
 }
 
@@ -297,8 +317,14 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
     int rc = free_contig(c, *g, true);
     if (rc) return rc;
-    if (c->flags & MSIM_PLAN_GPU)
+    const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
+    if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok)
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
+    if (gpu_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
+    if (c->gpu) {                      // the host planner continues from wherever the device streams stand
+        rc = gpu_plan_sync_to_host(c, c->gpu);
+        if (rc) return rc;
+    }
     HostPlan hp;
     const uint64_t w_py = c->py.words, w_np = c->np.words;
     rc = plan_contig_host(c, g->len, ranges, n_ranges, hp);

@@ -1,0 +1,20 @@
+// GPU sampler interface (plan_gpu.hip)
+#pragma once
+#include "ctx.h"
+
+namespace msim {
+
+struct GpuPlan;
+GpuPlan *gpu_plan_create();
+void gpu_plan_destroy(GpuPlan *g);
+// host generator states changed (msim_seed / msim_set_mt_state / host planner ran): drop device streams
+void gpu_plan_invalidate(GpuPlan *g);
+// bring the host generators up to the device streams' positions (before the host planner runs or
+// msim_get_mt_state answers)
+int gpu_plan_sync_to_host(Ctx *c, GpuPlan *g);
+// optional sizing hint: generate at least this many words ahead on the first extension
+void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words);
+bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
+int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
+
+}  // namespace msim

@@ -68,6 +68,7 @@ SYMBOLS = [
     ("msim_seed", C.c_int, [_VP, _U32P, C.c_int, C.c_uint32]),
     ("msim_set_mt_state", C.c_int, [_VP, C.c_int, _U32P, C.c_int]),
     ("msim_get_mt_state", C.c_int, [_VP, C.c_int, _U32P, _IP]),
+    ("msim_reserve_streams", C.c_int, [_VP, C.c_uint64, C.c_uint64]),
     ("msim_add_contig", C.c_int, [_VP, _VP, C.c_uint64, _IP]),
     ("msim_add_contig_synthetic", C.c_int, [_VP, C.c_uint64, C.c_uint64, _IP]),
     ("msim_contig_length", C.c_int, [_VP, C.c_int, _U64P]),
@@ -197,6 +198,9 @@ class Engine:
         self._check(self.lib.msim_get_mt_state(self.h, stream, arr.ctypes.data_as(_U32P),
                                                C.byref(pos)))
         return arr, pos.value
+
+    def reserve_streams(self, py_words: int, np_words: int = 0):
+        self._check(self.lib.msim_reserve_streams(self.h, int(py_words), int(np_words)))
 
     # ------------------------------------------------------------------ genome
     def add_contig(self, bases: np.ndarray) -> int:

@@ -1,0 +1,183 @@
+"""GPU sampler (PLAN on the device) vs the sequential host planner and the oracle.
+
+The GPU sampler must land on the same records AND leave both MT19937 streams at the same position
+as a sequential walk of the reference's draws -- including across contigs, where one off-by-one in
+a stream cut would shift every later draw."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from mutation_simulator_amd import _ffi
+from mutation_simulator_amd import mutator as mm
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(blocks=None, titv=1.0):
+    class S:
+        pass
+    from mutation_simulator_amd.mut_types import MutType
+    S.mut_block = {t: 1 for t in MutType}
+    if blocks:
+        for t, v in blocks.items():
+            S.mut_block[MutType[t]] = v
+    S.titv = titv
+    return mm.params_descriptor(S)
+
+
+def _snp_range(start, stop, k, token_order=False):
+    r = _ffi.Range()
+    r.start, r.stop, r.k = start, stop, k
+    r.setsize = mm.sample_setsize(k)
+    if token_order:                         # RMT line "in 0 ... sn x": chances IN 0.0, SN 1.0
+        r.n_types = 2
+        r.types[0], r.types[1] = 2, 1
+        r.cdf_thr[0], r.cdf_thr[1] = 0, 1 << 53
+        r.min_len[2], r.max_len[2] = 1, 2
+    else:                                   # ARGS order SN, IN, DE, IV, DU, TL, TLI with p = 1, 0, ...
+        r.n_types = 7
+        for j, t in enumerate([1, 2, 3, 5, 4, 6, 7]):
+            r.types[j] = t
+            r.cdf_thr[j] = 1 << 53
+        for t in (2, 3, 4, 6):
+            r.min_len[t], r.max_len[t] = 1, 2
+        r.min_len[5], r.max_len[5] = 2, 3
+    return r
+
+
+def _run(flags, contigs, params, seed=(42, 42)):
+    """contigs: list of (length, [ranges]).  Returns per-contig records, final states, stats."""
+    eng = _ffi.Engine(0, flags)
+    eng.seed(*seed)
+    eng.set_params(params)
+    out = []
+    for L, ranges in contigs:
+        cid = eng.add_contig_synthetic(L, 7)
+        eng.plan_contig(cid, ranges)
+        recs, pool = eng.fetch_records(cid)
+        out.append((recs.copy(), eng.plan_was_empty(cid)))
+    st = eng.stats()
+    states = [eng.get_mt_state(0), eng.get_mt_state(1)]
+    eng.close()
+    return out, states, st
+
+
+def _compare(contigs, params, seed=(42, 42)):
+    host, hs, hst = _run(_ffi.PLAN_HOST, contigs, params, seed)
+    gpu, gs, gst = _run(_ffi.PLAN_GPU, contigs, params, seed)
+    for (hr, he), (gr, ge) in zip(host, gpu):
+        assert he == ge
+        assert hr.shape == gr.shape
+        assert np.array_equal(hr["pos"], gr["pos"])
+        assert np.array_equal(hr["aux"], gr["aux"])
+        assert np.array_equal(hr.view(np.uint8), gr.view(np.uint8))
+    assert hst["py_words"] == gst["py_words"] and hst["np_words"] == gst["np_words"]
+    for (hm, hp), (gm, gp) in zip(hs, gs):
+        # same stream position: the next outputs agree (the 624-word windows may be cut differently)
+        assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
+    assert gst["plan_gpu_ms"] > 0 and gst["plan_host_ms"] == 0
+    return gst
+
+
+def _next_words(mt, pos, n):
+    import random
+    r = random.Random()
+    r.setstate((3, tuple(int(x) for x in mt) + (int(pos),), None))
+    return [r.getrandbits(32) for _ in range(n)]
+
+
+def test_c1_shape_matches_survey_known_answer():
+    """1 Mb, k = 10 000: first positions 96, 178, 195 ..., 10 630 sample words."""
+    out, states, st = _run(_ffi.PLAN_GPU, [(1_000_000, [_snp_range(0, 999_999, 10_000)])], _params())
+    recs = out[0][0]
+    assert list(recs["pos"][:6]) == [96, 178, 195, 208, 305, 430] and recs["pos"][-1] == 999_998
+    assert len(recs) == 10_000 and np.all(recs["type"] == 1) and np.array_equal(recs["pos"], recs["stop"])
+
+
+@pytest.mark.parametrize("L,rate,titv", [(1_000_000, 0.01, 1.0), (5_000_000, 0.01, 2.0),
+                                         (3_000_000, 0.05, 0.0), (2_000_000, 0.2, 1e9),
+                                         (4_194_304 + 41_000, 0.01, 0.5), (8_388_608 // 2 + 5, 0.3, 2.0)])
+def test_single_range_vs_host(L, rate, titv):
+    k = int(L * rate)
+    _compare([(L, [_snp_range(0, L - 1, k)])], _params(titv=titv))
+
+
+def test_contig_chain_and_multi_range_vs_host():
+    contigs = [(3_000_000, [_snp_range(0, 2_999_999, 30_000)]),
+               (1_000_000, []),                                            # nothing drawn
+               (2_500_000, [_snp_range(0, 999_999, 10_000), _snp_range(1_000_000, 2_499_999, 120_000, True)]),
+               (700_000, [_snp_range(100_000, 650_000, 5_000)])]
+    _compare(contigs, _params(titv=2.0), seed=(7, 9))
+
+
+def test_min_distance_three_vs_host():
+    blocks = {t: 3 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}
+    _compare([(2_000_000, [_snp_range(0, 1_999_999, 40_000)])], _params(blocks, titv=1.5), seed=(3, 4))
+
+
+def test_ineligible_structures_are_refused_by_forced_gpu_mode():
+    eng = _ffi.Engine(0, _ffi.PLAN_GPU)
+    eng.seed(1, 1)
+    eng.set_params(_params({"SN": 2}))            # SNP block above the sampling distance
+    cid = eng.add_contig_synthetic(1_000_000, 1)
+    with pytest.raises(_ffi.MsimUnsupported):
+        eng.plan_contig(cid, [_snp_range(0, 999_999, 10_000)])
+    eng.set_params(_params())
+    with pytest.raises(_ffi.MsimUnsupported):     # tiny range -> host planner territory
+        eng.plan_contig(cid, [_snp_range(0, 9_999, 100)])
+    eng.close()
+
+
+def test_auto_mode_mixes_engines_along_one_stream():
+    """AUTO: GPU sampler for the big SNP ranges, host planner for the rest -- one continuous stream."""
+    def sv_range(L):
+        r = _snp_range(0, L - 1, int(L * 0.004))
+        for j, thr in enumerate([0.5, 0.75, 1.0, 1.0, 1.0, 1.0, 1.0]):
+            r.cdf_thr[j] = int(thr * (1 << 53))
+        for t in (2, 3, 4):
+            r.min_len[t], r.max_len[t] = 1, 20
+        return r
+    contigs = [(2_000_000, [_snp_range(0, 1_999_999, 20_000)]), (500_000, [sv_range(500_000)]),
+               (1_500_000, [_snp_range(0, 1_499_999, 15_000)]), (300_000, [_snp_range(0, 299_999, 3_000)])]
+    host, hs, hst = _run(_ffi.PLAN_HOST, contigs, _params(titv=2.0))
+    auto, as_, ast = _run(_ffi.PLAN_AUTO, contigs, _params(titv=2.0))
+    for (hr, _), (ar, _) in zip(host, auto):
+        assert np.array_equal(hr.view(np.uint8), ar.view(np.uint8))
+    for (hm, hp), (am, ap) in zip(hs, as_):
+        assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
+    assert ast["plan_gpu_ms"] > 0 and ast["plan_host_ms"] > 0
+
+
+def test_full_size_genome_gpu_sampler_vs_host_planner():
+    """BASELINE config 2 at full size (3 Gb, 24 contigs, 30 M SNPs): every record and both final
+    stream positions equal the sequential host walk (> 200 M MT19937 words, > 1000 stream chunks,
+    i.e. every jump-ahead level in use)."""
+    import bench
+    lengths = bench.contig_lengths(3_000_000_000)
+    sim = bench.workload_settings(lengths)
+    params = mm.params_descriptor(sim)
+
+    def run(flags):
+        eng = _ffi.Engine(0, flags)
+        eng.seed(42, 42)
+        eng.set_params(params)
+        sums = []
+        for chrom in sim.chromosomes:
+            cid = eng.add_contig_synthetic(16, 1)           # PLAN never looks at bases; length comes from the ranges
+            eng.plan_contig(cid, mm.plan_descriptors(chrom))
+            recs, _ = eng.fetch_records(cid)
+            sums.append((len(recs), int(recs["pos"].astype(np.uint64).sum()), int(recs["aux"].astype(np.uint64).sum()),
+                         __import__("hashlib").sha256(recs.tobytes()).hexdigest()))
+            eng.clear()
+        states = [eng.get_mt_state(0), eng.get_mt_state(1)]
+        st = eng.stats()
+        eng.close()
+        return sums, states, st
+
+    hsum, hs, hst = run(_ffi.PLAN_HOST)
+    gsum, gs, gst = run(_ffi.PLAN_GPU)
+    assert hsum == gsum
+    assert hst["py_words"] == gst["py_words"] and hst["np_words"] == gst["np_words"]
+    for (hm, hp), (gm, gp) in zip(hs, gs):
+        assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
