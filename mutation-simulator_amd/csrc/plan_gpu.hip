@@ -670,10 +670,9 @@ bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
     int64_t d = P.block[1];
     for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
     if (P.block[MSIM_SN] != d) return false;              // an SNP could block its successor
-    bool any = false;
     for (int i = 0; i < n_ranges; i++) {
         const msim_range &r = ranges[i];
-        if (r.k == 0) continue;
+        if (r.k == 0) continue;                           // draws nothing (mutator.py:163-164)
         if (r.k < 4096) return false;                     // tiny ranges: the sequential host walk is faster
         const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
         if (r.k < 0 || n < r.k) return false;             // ValueError: let the host planner raise it
@@ -686,9 +685,8 @@ bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
             else if (r.cdf_thr[j] < (1ull << 53)) return false;
         }
         if (zeros >= r.n_types || r.types[zeros] != MSIM_SN) return false;
-        any = true;
     }
-    return any;
+    return true;                                          // (a contig that draws nothing is trivially fine)
 }
 
 int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {

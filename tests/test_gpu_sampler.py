@@ -95,11 +95,15 @@ def test_c1_shape_matches_survey_known_answer():
     assert len(recs) == 10_000 and np.all(recs["type"] == 1) and np.array_equal(recs["pos"], recs["stop"])
 
 
-@pytest.mark.parametrize("L,rate,titv", [(1_000_000, 0.01, 1.0), (5_000_000, 0.01, 2.0),
-                                         (3_000_000, 0.05, 0.0), (2_000_000, 0.2, 1e9),
-                                         (4_194_304 + 41_000, 0.01, 0.5), (8_388_608 // 2 + 5, 0.3, 2.0)])
-def test_single_range_vs_host(L, rate, titv):
-    k = int(L * rate)
+@pytest.mark.parametrize("L,k,titv", [
+    (1_000_000, 10_000, 1.0), (5_000_000, 50_000, 2.0), (3_000_000, 150_000, 0.0),
+    (1_400_000, 300_000, 1e9),            # k/n = 0.27: thousands of duplicate draws, multi-round tail
+    (2_000_000, 340_000, 0.3),
+    (4_194_304 + 41_000, 41_000, 0.5),    # n = 2^22 exactly -> 23-bit draws, accept ratio ~ 0.5
+    (4_194_304 + 40_999, 41_000, 2.0),    # n = 2^22 - 1   -> 22-bit draws, accept ratio ~ 1.0
+])
+def test_single_range_vs_host(L, k, titv):
+    assert (L - k) > mm.sample_setsize(k)       # CPython set path (pool path belongs to the host planner)
     _compare([(L, [_snp_range(0, L - 1, k)])], _params(titv=titv))
 
 
@@ -164,7 +168,7 @@ def test_full_size_genome_gpu_sampler_vs_host_planner():
         eng.set_params(params)
         sums = []
         for chrom in sim.chromosomes:
-            cid = eng.add_contig_synthetic(16, 1)           # PLAN never looks at bases; length comes from the ranges
+            cid = eng.add_contig_synthetic(lengths[chrom.number], 1)
             eng.plan_contig(cid, mm.plan_descriptors(chrom))
             recs, _ = eng.fetch_records(cid)
             sums.append((len(recs), int(recs["pos"].astype(np.uint64).sum()), int(recs["aux"].astype(np.uint64).sum()),
