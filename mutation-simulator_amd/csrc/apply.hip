@@ -142,7 +142,9 @@ __global__ __launch_bounds__(THREADS) void k_offsets(const msim_record *__restri
 
 // ------------------------------------------------------------------ 2. tile index
 // first[t] = index of the last record whose output offset is <= t*TILE, or -1
-__global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restrict__ off, uint32_t n,
+// (off == nullptr: SNP-only table, a record's output offset is its position)
+__global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restrict__ off,
+                                                        const msim_record *__restrict__ recs, uint32_t n,
                                                         int32_t *__restrict__ first, uint32_t n_entries) {
     const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
     if (t >= n_entries) return;
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restri
     uint32_t lo = 0, hi = n;                               // upper bound: first index with off > target
     while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if ((uint64_t)off[mid] <= target) lo = mid + 1; else hi = mid;
+        const uint32_t o = off ? off[mid] : recs[mid].pos;
+        if ((uint64_t)o <= target) lo = mid + 1; else hi = mid;
     }
     first[t] = (int32_t)lo - 1;
 }
@@ -198,7 +201,9 @@ struct RecAccess {
     const msim_record *recs;
     const uint32_t *off;
     int32_t r_lo;
-    __device__ __forceinline__ uint32_t O(int32_t j) const { return IN_LDS ? win->o[j - r_lo] : off[j]; }
+    __device__ __forceinline__ uint32_t O(int32_t j) const {
+        return IN_LDS ? win->o[j - r_lo] : (off ? off[j] : recs[j].pos);
+    }
     __device__ __forceinline__ void all(int32_t j, uint32_t &o, uint32_t &e, uint32_t &s, uint32_t &m) const {
         if (IN_LDS) {
             const int32_t q = j - r_lo;
@@ -207,7 +212,7 @@ struct RecAccess {
             const msim_record r = recs[j];
             uint32_t ol, il;
             rec_lengths(r, ol, il);
-            o = off[j]; e = o + ol; s = r.pos + il; m = (uint32_t)r.type | ((uint32_t)r.aux << 8);
+            o = off ? off[j] : r.pos; e = o + ol; s = r.pos + il; m = (uint32_t)r.type | ((uint32_t)r.aux << 8);
         }
     }
 };
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
             const msim_record r = recs[r_lo + q];
             uint32_t ol, il;
             rec_lengths(r, ol, il);
-            const uint32_t o = off[r_lo + q];
+            const uint32_t o = off ? off[r_lo + q] : r.pos;
             win.o[q] = o;
             win.e[q] = o + ol;
             win.s[q] = r.pos + il;
@@ -364,6 +369,12 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
         RecAccess<false> A{&win, recs, off, r_lo};
         rewrite_tile<false>(A, r_hi, any_rec, in, out, recs, pool, lut, tile0, L_out, err);
     }
+}
+
+// single-lane epilogue: small results go to the pinned host mailbox (no blit-kernel D2H copy)
+__global__ void k_publish_u64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ mailbox) {
+    *mailbox = *src;
+    __threadfence_system();
 }
 
 // ------------------------------------------------------------------ synthetic genome / checksum
@@ -425,6 +436,17 @@ __global__ __launch_bounds__(THREADS) void k_checksum(const uint8_t *__restrict_
 
 }  // namespace
 
+int dev_reserve(Ctx *c, void **p, size_t *cap, size_t want_bytes) {
+    if (*p && *cap >= want_bytes) return MSIM_OK;
+    if (*p) MSIM_HIP(c, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t sz = want_bytes + (want_bytes >> 4) + 256;
+    MSIM_HIP(c, hipMalloc(p, sz));
+    *cap = sz;
+    return MSIM_OK;
+}
+
 int ensure_scratch(Ctx *c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return MSIM_OK;
     if (c->d_scratch) MSIM_HIP(c, hipFree(c->d_scratch));
@@ -470,52 +492,59 @@ extern unsigned long long *ctx_err_word(Ctx *c);
 int apply_contig_device(Ctx *c, Contig &g) {
     const uint32_t n = (uint32_t)g.n_rec;
     MSIM_HIP(c, hipEventRecord(c->ev0, c->stream));
-    // ---- 1. output offsets
+    // ---- 1. output offsets (skipped for an SNP-only table: no length change, offset == position)
     long long total_delta = 0;
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-    if (g.d_off) { MSIM_HIP(c, hipFree(g.d_off)); g.d_off = nullptr; }
-    if (n) {
-        MSIM_HIP(c, hipMalloc(&g.d_off, (size_t)n * sizeof(uint32_t)));
-        int rc = ensure_scratch(c, (size_t)(nb + 1) * sizeof(long long));
+    const uint32_t *d_off = nullptr;
+    if (n && !g.all_snp) {
+        int rc = dev_reserve(c, (void **)&g.d_off, &g.cap_off, (size_t)n * sizeof(uint32_t));
+        if (rc) return rc;
+        rc = ensure_scratch(c, (size_t)(nb + 1) * sizeof(long long));
         if (rc) return rc;
         long long *d_sums = reinterpret_cast<long long *>(c->d_scratch);
         hipLaunchKernelGGL(k_delta_reduce, dim3(nb), dim3(THREADS), 0, c->stream, g.d_recs, n, d_sums);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, d_sums, nb);
         hipLaunchKernelGGL(k_offsets, dim3(nb), dim3(THREADS), 0, c->stream, g.d_recs, n, d_sums, g.d_off);
+        hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, c->stream,
+                           reinterpret_cast<const unsigned long long *>(d_sums + nb), c->h_mail);
         MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipMemcpyAsync(&total_delta, d_sums + nb, sizeof(long long), hipMemcpyDeviceToHost, c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        total_delta = (long long)*c->h_mail;
+        d_off = g.d_off;
     }
     const long long out_len_ll = (long long)g.len + total_delta;
     if (out_len_ll < 0 || (uint64_t)out_len_ll >= (1ull << 32))
         return fail(c, MSIM_ERR_UNSUPPORTED, "mutated contig of 4 GiB or more");
     g.out_len = (uint64_t)out_len_ll;
-    if (g.d_out) { MSIM_HIP(c, hipFree(g.d_out)); g.d_out = nullptr; }
-    MSIM_HIP(c, hipMalloc(&g.d_out, g.out_len + PAD));
+    {
+        int rc = dev_reserve(c, (void **)&g.d_out, &g.cap_out, g.out_len + PAD);
+        if (rc) return rc;
+    }
     // ---- 2. tile index
     const uint32_t n_tiles = (uint32_t)((g.out_len + TILE - 1) / TILE);
     int32_t *d_first = nullptr;
+    unsigned long long *d_err = ctx_err_word(c);
     if (n_tiles) {
         int rc = ensure_scratch(c, (size_t)(n_tiles + 1) * sizeof(int32_t) + 64);
         if (rc) return rc;
         d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
         hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, c->stream,
-                           g.d_off, n, d_first, n_tiles + 1);
+                           d_off, g.d_recs, n, d_first, n_tiles + 1);
         MSIM_HIP(c, hipGetLastError());
     }
     // ---- 3. rewrite
-    unsigned long long *d_err = ctx_err_word(c);
     MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
     MSIM_HIP(c, hipEventRecord(c->ev1, c->stream));
     if (n_tiles) {
         hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
-                           g.d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
+                           d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
         MSIM_HIP(c, hipGetLastError());
     }
     MSIM_HIP(c, hipEventRecord(c->ev2, c->stream));
-    unsigned long long h_err = 0;
-    MSIM_HIP(c, hipMemcpyAsync(&h_err, d_err, 8, hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, c->stream, d_err, c->h_mail);
+    MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    const unsigned long long h_err = *c->h_mail;
     float ms_all = 0, ms_k = 0;
     MSIM_HIP(c, hipEventElapsedTime(&ms_all, c->ev0, c->ev2));
     MSIM_HIP(c, hipEventElapsedTime(&ms_k, c->ev1, c->ev2));

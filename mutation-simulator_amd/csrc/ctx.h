@@ -17,9 +17,11 @@ struct Contig {
     // plan result
     bool planned = false;
     bool plan_empty = true;
+    bool all_snp = false;             // record table holds SNPs only: no length change, offset == pos
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // insert bases
+    size_t cap_recs = 0, cap_pool = 0, cap_out = 0, cap_off = 0;   // bytes kept allocated across plans
     // apply result
     bool applied = false;
     uint64_t out_len = 0;
@@ -54,7 +56,7 @@ struct Ctx {
     // device scratch
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
-    uint32_t *d_flags = nullptr;      // [0..1] key error pos (lo/hi via atomicMin on u64), [2] base
+    unsigned long long *h_mail = nullptr;   // pinned, device-visible mailbox for small results
 };
 
 int fail(Ctx *c, int code, const std::string &msg);
@@ -79,5 +81,7 @@ int apply_contig_device(Ctx *c, Contig &g);
 int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed);
 int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum);
 int ensure_scratch(Ctx *c, size_t bytes);
+// grow-only device buffer (contents are NOT preserved)
+int dev_reserve(Ctx *c, void **p, size_t *cap, size_t want_bytes);
 
 }  // namespace msim

@@ -59,15 +59,21 @@ static void build_lut(uint8_t *lut) {
     }
 }
 
+// forget a contig's plan/apply results; device buffers stay allocated for the next plan of this contig
+static void reset_contig(Contig &g) {
+    g.planned = g.applied = false;
+    g.n_rec = g.pool_len = g.out_len = 0;
+    g.h_recs.clear(); g.h_recs.shrink_to_fit();
+    g.h_pool.clear(); g.h_pool.shrink_to_fit();
+}
+
 static int free_contig(Ctx *c, Contig &g, bool keep_input) {
     if (g.d_recs) { MSIM_HIP(c, hipFree(g.d_recs)); g.d_recs = nullptr; }
     if (g.d_pool) { MSIM_HIP(c, hipFree(g.d_pool)); g.d_pool = nullptr; }
     if (g.d_out) { MSIM_HIP(c, hipFree(g.d_out)); g.d_out = nullptr; }
     if (g.d_off) { MSIM_HIP(c, hipFree(g.d_off)); g.d_off = nullptr; }
-    g.planned = g.applied = false;
-    g.n_rec = g.pool_len = g.out_len = 0;
-    g.h_recs.clear(); g.h_recs.shrink_to_fit();
-    g.h_pool.clear(); g.h_pool.shrink_to_fit();
+    g.cap_recs = g.cap_pool = g.cap_out = g.cap_off = 0;
+    reset_contig(g);
     if (!keep_input && g.d_in) { MSIM_HIP(c, hipFree(g.d_in)); g.d_in = nullptr; }
     return MSIM_OK;
 }
@@ -149,6 +155,7 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     if ((e = hipMalloc(&c->dev.d_lut, sizeof lut)) != hipSuccess) return bail(e, "hipMalloc(lut)");
     if ((e = hipMemcpy(c->dev.d_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(lut)");
     if ((e = hipMalloc(&c->dev.d_err, 64)) != hipSuccess) return bail(e, "hipMalloc(err)");
+    if ((e = hipHostMalloc(&c->h_mail, 64, hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(mailbox)");
     c->gpu = gpu_plan_create();
     *out = reinterpret_cast<msim_ctx *>(static_cast<Ctx *>(c));
     return MSIM_OK;
@@ -168,6 +175,7 @@ void msim_destroy(msim_ctx *p) {
     if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
     if (c->dev.d_err) (void)hipFree(c->dev.d_err);
     gpu_plan_destroy(c->gpu);
+    if (c->h_mail) (void)hipHostFree(c->h_mail);
     hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -315,8 +323,8 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
-    int rc = free_contig(c, *g, true);
-    if (rc) return rc;
+    int rc = MSIM_OK;
+    reset_contig(*g);
     const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
     if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok)
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
@@ -335,6 +343,9 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     g->n_rec = hp.recs.size();
     g->pool_len = hp.pool.size();
     g->plan_empty = hp.empty;
+    g->all_snp = true;
+    for (const msim_record &r : hp.recs)
+        if (r.type != MSIM_SN) { g->all_snp = false; break; }
     if (c->host_only) {
         g->h_recs.swap(hp.recs);
         g->h_pool.swap(hp.pool);
@@ -342,10 +353,12 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
         return MSIM_OK;
     }
     if (g->n_rec) {
-        MSIM_HIP(c, hipMalloc(&g->d_recs, g->n_rec * sizeof(msim_record)));
+        rc = dev_reserve(c, (void **)&g->d_recs, &g->cap_recs, g->n_rec * sizeof(msim_record));
+        if (rc) return rc;
         MSIM_HIP(c, hipMemcpyAsync(g->d_recs, hp.recs.data(), g->n_rec * sizeof(msim_record), hipMemcpyHostToDevice, c->stream));
     }
-    MSIM_HIP(c, hipMalloc(&g->d_pool, g->pool_len + PAD));
+    rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + PAD);
+    if (rc) return rc;
     if (g->pool_len)
         MSIM_HIP(c, hipMemcpyAsync(g->d_pool, hp.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));

@@ -59,57 +59,92 @@ struct PlanState {
 };
 
 // ------------------------------------------------------------------ 1. MT19937 in bulk
-// state' = g(A) state : z = state followed by 19 937 more raw words, out[m] = XOR_{i in g} z[i+m]
-__global__ __launch_bounds__(1024) void k_mt_jump(uint32_t *__restrict__ states, uint32_t n_src,
-                                                  const uint32_t *__restrict__ poly) {
+// state' = g(A) state : z = state followed by 19 937 more raw words, out[m] = XOR_{i in g} z[i+m].
+// One jump is spread over JUMP_SPLIT workgroups (64 outputs each) so the early cascade levels, which
+// have few source states, still fill the chip; inside a workgroup the four waves take every fourth
+// polynomial limb (wave-uniform bit scan on the scalar unit, four LDS reads in flight per lane).
+constexpr int JUMP_OUT = 64;
+constexpr int JUMP_SPLIT = (MT_N + JUMP_OUT - 1) / JUMP_OUT;
+
+constexpr int JUMP_THREADS = 1024;
+constexpr int JUMP_WAVES = JUMP_THREADS / 64;
+
+__global__ __launch_bounds__(JUMP_THREADS) void k_mt_jump(uint32_t *__restrict__ states, uint32_t n_src,
+                                                          const uint32_t *__restrict__ poly) {
     __shared__ uint32_t z[JUMP_Z + 3];
     __shared__ uint32_t g[MT_POLY_WORDS];
+    __shared__ uint32_t red[JUMP_THREADS];
     const uint32_t src = blockIdx.x;
+    const int m0 = blockIdx.y * JUMP_OUT;
     const uint32_t *s = states + (size_t)src * MT_N;
     uint32_t *dst = states + (size_t)(src + n_src) * MT_N;
-    for (int i = threadIdx.x; i < MT_N; i += blockDim.x) z[i] = s[i];
-    for (int i = threadIdx.x; i < MT_POLY_WORDS; i += blockDim.x) g[i] = poly[i];
+    for (int i = threadIdx.x; i < MT_N; i += JUMP_THREADS) z[i] = s[i];
+    for (int i = threadIdx.x; i < MT_POLY_WORDS; i += JUMP_THREADS) g[i] = poly[i];
     __syncthreads();
     for (int base = 0; base < JUMP_Z - MT_N; base += GEN_STEP) {
         const int t = base + (int)threadIdx.x;
         if ((int)threadIdx.x < GEN_STEP && t + MT_N < JUMP_Z) z[t + MT_N] = mt_twist(z[t], z[t + 1], z[t + MT_M]);
         __syncthreads();
     }
-    if (threadIdx.x < MT_N) {
-        const int m = threadIdx.x;
-        uint32_t acc = 0;
-        for (int j = 0; j < MT_POLY_WORDS; j++) {
-            uint32_t bits = g[j];                        // uniform across the workgroup
-            const int base = j * 32 + m;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = m0 + lane;
+    uint32_t acc = 0;
+    if (m < MT_N) {
+        const uint32_t *zl = z + m;
+        for (int j = wave; j < MT_POLY_WORDS; j += JUMP_WAVES) {
+            uint32_t bits = __builtin_amdgcn_readfirstlane(g[j]);
+            const uint32_t *zj = zl + j * 32;
             while (bits) {
-                const int b = __builtin_ctz(bits);
-                bits &= bits - 1;
-                acc ^= z[base + b];
+                uint32_t v0, v1 = 0, v2 = 0, v3 = 0;
+                v0 = zj[__builtin_ctz(bits)]; bits &= bits - 1;
+                if (bits) { v1 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
+                if (bits) { v2 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
+                if (bits) { v3 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
+                acc ^= (v0 ^ v1) ^ (v2 ^ v3);
             }
         }
-        dst[m] = acc;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < JUMP_OUT && m0 + (int)threadIdx.x < MT_N) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int w = 0; w < JUMP_WAVES; w++) r ^= red[threadIdx.x + 64 * w];
+        dst[m0 + threadIdx.x] = r;
     }
 }
 
-// chunk j: raw words x[624 + j*S .. 624 + (j+1)*S) from state_j (the 624 words before the chunk)
-__global__ __launch_bounds__(256) void k_mt_generate(const uint32_t *__restrict__ states,
-                                                     uint32_t *__restrict__ raw, uint32_t first_chunk) {
+// chunk j: raw words x[624 + j*S .. 624 + (j+1)*S) from state_j (the 624 words before the chunk).
+// One wave per chunk: 227 words are mutually independent per step, a step's reads never touch the
+// slots it overwrites, so the only ordering needed is "this step's writes before the next step's
+// reads" -- a single-wave workgroup barrier.
+__global__ __launch_bounds__(64) void k_mt_generate(const uint32_t *__restrict__ states,
+                                                    uint32_t *__restrict__ raw, uint32_t first_chunk) {
     __shared__ uint32_t ring[1024];
     const uint32_t j = first_chunk + blockIdx.x;
     const uint32_t *s = states + (size_t)j * MT_N;
     uint32_t *out = raw + MT_N + (size_t)j * MT_CHUNK_WORDS;
-    for (int i = threadIdx.x; i < MT_N; i += 256) ring[i] = s[i];
+    for (int i = threadIdx.x; i < MT_N; i += 64) ring[i] = s[i];
     __syncthreads();
-    // word t of the chunk (t >= 0) is sequence index 624 + t relative to the state: needs t, t+1, t+397
+    // word t of the chunk is sequence index 624 + t relative to the state: needs t, t+1, t+397
     for (int base = 0; base < MT_CHUNK_WORDS; base += GEN_STEP) {
-        const int t = base + (int)threadIdx.x;
-        uint32_t v = 0;
-        const bool on = (int)threadIdx.x < GEN_STEP && t < MT_CHUNK_WORDS;
-        if (on) v = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
-        __syncthreads();                                 // all reads of the slots being overwritten are done
-        if (on) {
-            ring[(t + MT_N) & 1023] = v;
-            out[t] = v;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            v[q] = 0;
+            if (o < GEN_STEP && t < MT_CHUNK_WORDS)
+                v[q] = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            if (o < GEN_STEP && t < MT_CHUNK_WORDS) {
+                ring[(t + MT_N) & 1023] = v[q];
+                out[t] = v[q];
+            }
         }
         __syncthreads();
     }
@@ -150,10 +185,12 @@ __device__ __forceinline__ bool accepted(const uint32_t *__restrict__ raw, unsig
 }
 
 __global__ __launch_bounds__(ACC_THREADS) void k_accept_count(const uint32_t *__restrict__ raw,
-                                                              const PlanState *__restrict__ ps, uint32_t W,
+                                                              const PlanState *ps, uint32_t W,
                                                               uint32_t shift, uint32_t n,
-                                                              uint32_t *__restrict__ block_cnt) {
+                                                              uint32_t *__restrict__ block_cnt,
+                                                              PlanState *ps_rw) {
     __shared__ uint32_t red[ACC_THREADS / 64];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ps_rw->dups = 0; ps_rw->accepted_used = 0; }   // new range
     const unsigned long long p0 = ps->pos;
     const uint32_t i0 = blockIdx.x * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
     uint32_t c = 0;
@@ -502,14 +539,22 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__rest
     }
 }
 
-__global__ void k_snp_check(const SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K, PlanState *__restrict__ ps) {
-    if (block_maps[nb].c[0] < K) atomicOr(&ps->flags, FLAG_SNP_OVERFLOW);
+// single-lane epilogues: flag an undersized SNP window, then publish the bookkeeping block to the
+// pinned host mailbox (a plain store over PCIe -- no blit-kernel D2H copy on the critical path)
+__global__ void k_snp_check_publish(const SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
+                                    PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
+    if (K && block_maps[nb].c[0] < K) ps->flags |= FLAG_SNP_OVERFLOW;
+    *mailbox = *ps;
+    __threadfence_system();
+}
+__global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
+    *mailbox = *ps;
+    __threadfence_system();
 }
 
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
     ps->pos = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0; ps->rsv = 0;
 }
-__global__ void k_state_clear_dups(PlanState *ps) { ps->dups = 0; ps->accepted_used = 0; }
 
 }  // namespace
 
@@ -522,6 +567,7 @@ struct GpuStream {
     uint32_t n_states = 0;              // valid states (power of two once the cascade ran)
     uint32_t n_chunks = 0;              // chunks generated
     uint64_t pos = 0;                   // next unconsumed index into x (exact, host copy)
+    uint64_t last_session_words = 0;    // words the previous (re)seeded session went through: sizing hint
     bool live = false;                  // device copy is the authoritative stream
 };
 
@@ -529,6 +575,7 @@ struct GpuPlan {
     GpuStream s[2];
     uint32_t *d_poly = nullptr;
     PlanState *d_ps = nullptr;
+    PlanState *h_mail = nullptr;        // pinned, device-visible mailbox
     // scratch
     uint32_t *d_acc = nullptr; size_t acc_cap = 0;
     uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
@@ -554,6 +601,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     for (auto &s : g->s) { if (s.d_raw) (void)hipFree(s.d_raw); if (s.d_states) (void)hipFree(s.d_states); }
     if (g->d_poly) (void)hipFree(g->d_poly);
     if (g->d_ps) (void)hipFree(g->d_ps);
+    if (g->h_mail) (void)hipHostFree(g->h_mail);
     if (g->d_acc) (void)hipFree(g->d_acc);
     if (g->d_cnt) (void)hipFree(g->d_cnt);
     if (g->d_bitmap) (void)hipFree(g->d_bitmap);
@@ -561,7 +609,12 @@ void gpu_plan_destroy(GpuPlan *g) {
     delete g;
 }
 
-void gpu_plan_invalidate(GpuPlan *g) { g->s[0].live = g->s[1].live = false; }
+void gpu_plan_invalidate(GpuPlan *g) {
+    for (auto &s : g->s) {
+        if (s.live) s.last_session_words = std::max<uint64_t>(s.pos, MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS);
+        s.live = false;
+    }
+}
 void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words) { g->reserve_words[0] = py_words; g->reserve_words[1] = np_words; }
 
 // make x[0 .. upto) available on the device for stream `si`
@@ -569,7 +622,9 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
     GpuStream &s = g->s[si];
     const uint64_t have = MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS;
     if (upto <= have) return MSIM_OK;
+    // batch the extension: an explicit hint, or what the previous session on this context needed
     upto = std::max<uint64_t>(upto, s.pos + g->reserve_words[si]);
+    if (si == 0) upto = std::max<uint64_t>(upto, std::min<uint64_t>(s.last_session_words, upto * 64));
     const uint32_t need_chunks = (uint32_t)((upto - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
     uint32_t want_states = 1;
     int levels = 0;
@@ -606,13 +661,13 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
     while (s.n_states < want_states) {
         int r = 0;
         while ((1u << r) < s.n_states) r++;
-        hipLaunchKernelGGL(k_mt_jump, dim3(s.n_states), dim3(1024), 0, c->stream, s.d_states, s.n_states,
+        hipLaunchKernelGGL(k_mt_jump, dim3(s.n_states, JUMP_SPLIT), dim3(JUMP_THREADS), 0, c->stream, s.d_states, s.n_states,
                            g->d_poly + (size_t)r * MT_POLY_WORDS);
         MSIM_HIP(c, hipGetLastError());
         s.n_states <<= 1;
     }
     if (need_chunks > s.n_chunks) {
-        hipLaunchKernelGGL(k_mt_generate, dim3(need_chunks - s.n_chunks), dim3(256), 0, c->stream, s.d_states,
+        hipLaunchKernelGGL(k_mt_generate, dim3(need_chunks - s.n_chunks), dim3(64), 0, c->stream, s.d_states,
                            s.d_raw, s.n_chunks);
         MSIM_HIP(c, hipGetLastError());
         s.n_chunks = need_chunks;
@@ -660,6 +715,7 @@ int gpu_plan_sync_to_host(Ctx *c, GpuPlan *g) {
             h.idx = (int)consumed;
         }
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        s.last_session_words = std::max<uint64_t>(s.pos, MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS);
         s.live = false;
     }
     return MSIM_OK;
@@ -697,14 +753,16 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     if ((rc = stream_to_device(c, g, 0))) return rc;
     if ((rc = stream_to_device(c, g, 1))) return rc;
     if (!g->d_ps) MSIM_HIP(c, hipMalloc(&g->d_ps, sizeof(PlanState)));
+    if (!g->h_mail) MSIM_HIP(c, hipHostMalloc(&g->h_mail, sizeof(PlanState), hipHostMallocMapped));
     uint64_t K = 0;
     for (int i = 0; i < n_ranges; i++) K += (uint64_t)ranges[i].k;
     if (K >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "more than 2^31 mutations on one contig");
     ct.n_rec = K;
     ct.pool_len = 0;
     ct.plan_empty = K == 0;
-    MSIM_HIP(c, hipMalloc(&ct.d_recs, std::max<uint64_t>(K, 1) * sizeof(msim_record)));
-    MSIM_HIP(c, hipMalloc(&ct.d_pool, PAD));
+    ct.all_snp = true;                                    // every record is an SNP: output offset == position
+    if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, std::max<uint64_t>(K, 1) * sizeof(msim_record)))) return rc;
+    if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, PAD))) return rc;
     const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
 
     GpuStream &py = g->s[0];
@@ -735,9 +793,8 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             const size_t bm_words64 = (size_t)((n + 63) / 64);
             if ((rc = grow(c, (void **)&g->d_bitmap, &g->bm_cap, bm_words64 * 8))) return rc;
             MSIM_HIP(c, hipMemsetAsync(g->d_bitmap, 0, bm_words64 * 8, c->stream));
-            hipLaunchKernelGGL(k_state_clear_dups, dim3(1), dim3(1), 0, c->stream, g->d_ps);
             hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, g->d_cnt);
+                               (uint32_t)(32 - bits), (uint32_t)n, g->d_cnt, g->d_ps);
             hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, g->d_cnt, nb);
             hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
                                (uint32_t)(32 - bits), (uint32_t)n, g->d_cnt, g->d_acc);
@@ -770,22 +827,23 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                                (unsigned long long)P.ti_lim, g->d_maps);
             hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, g->d_maps, nb2);
-            hipLaunchKernelGGL(k_snp_check, dim3(1), dim3(1), 0, c->stream, g->d_maps, nb2, (uint32_t)K, g->d_ps);
-            MSIM_HIP(c, hipGetLastError());
         }
+        hipLaunchKernelGGL(k_snp_check_publish, dim3(1), dim3(1), 0, c->stream, g->d_maps, nb2, (uint32_t)K, g->d_ps,
+                           g->h_mail);
+        MSIM_HIP(c, hipGetLastError());
         // the emit pass needs the position the sample phases ended at as a plain argument
-        PlanState h{};
-        MSIM_HIP(c, hipMemcpyAsync(&h, g->d_ps, sizeof h, hipMemcpyDeviceToHost, c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        PlanState h = *g->h_mail;
         if (!(h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) && K) {
             hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps,
                                (unsigned long long)h.pos, W2, (unsigned long long)P.ti_lim, g->d_maps, ct.d_recs,
                                (uint32_t)K);
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
             MSIM_HIP(c, hipGetLastError());
-            MSIM_HIP(c, hipMemcpyAsync(&h, g->d_ps, sizeof h, hipMemcpyDeviceToHost, c->stream));
         }
         MSIM_HIP(c, hipEventRecord(c->ev1, c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        h = *g->h_mail;
         float ms = 0;
         MSIM_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->t.plan_gpu_ms += ms;
