@@ -46,17 +46,6 @@ def contig_lengths(total: int) -> list[int]:
     return out
 
 
-def lpt_partition(lengths: list[int], n: int) -> list[list[int]]:
-    """Longest-processing-time bin packing of contigs over ranks."""
-    bins = [[] for _ in range(n)]
-    load = [0] * n
-    for idx in sorted(range(len(lengths)), key=lambda i: -lengths[i]):
-        b = load.index(min(load))
-        bins[b].append(idx)
-        load[b] += lengths[idx]
-    return [sorted(b) for b in bins]
-
-
 def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
     """Settings tree for `args -sn 0.01 -titv 2.0` over the synthetic contigs (host package)."""
     import mutation_simulator_amd as msa
@@ -84,16 +73,12 @@ def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
     return sim
 
 
-def one_step(eng, sim, cids, my_contigs, plan_all=True):
+def one_step(eng, sim, cids, my_contigs):
     """PLAN every contig in order (the RNG streams chain across contigs), APPLY this rank's."""
     from mutation_simulator_amd import mutator as mm
+    from mutation_simulator_amd.sharding import run_sharded_pass
     eng.seed(42, 42)
-    mine = set(my_contigs)
-    for chrom in sim.chromosomes:
-        i = chrom.number
-        eng.plan_contig(cids[i], mm.plan_descriptors(chrom))
-        if i in mine:
-            eng.apply_contig(cids[i])
+    run_sharded_pass(eng, sim, cids, my_contigs, mm.plan_descriptors)
     eng.sync()
 
 
@@ -143,6 +128,7 @@ def main():
 
     lengths = contig_lengths(a.total_bases)
     sim = workload_settings(lengths)
+    from mutation_simulator_amd.sharding import lpt_partition
     parts = lpt_partition(lengths, world)
     mine = parts[rank]
 
