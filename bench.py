@@ -188,7 +188,7 @@ def main():
             "records_per_step": st["records"] // a.steps,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "msim::k_rewrite",
+                         "kernel": "msim::k_rewrite_snp (SNP-only tables; msim::k_rewrite for SV mixes)",
                          "algorithmic_bytes_per_launch": alg_bytes // launches,
                          "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
         }

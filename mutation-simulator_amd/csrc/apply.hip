@@ -371,6 +371,55 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
     }
 }
 
+// ------------------------------------------------------------------ 3b. rewrite, SNP-only tables
+// No length change: output offset == input position.  The tile is staged in LDS (aligned 16-B loads,
+// ds_write_b128), then ONE LANE PER RECORD patches its byte through the LDS LUT -- no per-lane record
+// search -- and the tile streams out with aligned 16-B stores.  Any number of records per tile.
+__global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                         const msim_record *__restrict__ recs,
+                                                         const int32_t *__restrict__ first, uint32_t n_rec,
+                                                         uint64_t L, const uint8_t *__restrict__ lut_g,
+                                                         unsigned long long *err) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
+    __shared__ __attribute__((aligned(16))) uint8_t lut[1024];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    u32x4 v[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t o = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        v[it] = u32x4{0, 0, 0, 0};
+        if (tile0 + o < L) v[it] = *reinterpret_cast<const u32x4 *>(in + tile0 + o);
+    }
+    reinterpret_cast<uint32_t *>(lut)[threadIdx.x] = reinterpret_cast<const uint32_t *>(lut_g)[threadIdx.x];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t o = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        *reinterpret_cast<u32x4 *>(tile + o) = v[it];
+    }
+    const int32_t f0 = first[blockIdx.x], f1 = first[blockIdx.x + 1];
+    __syncthreads();
+    // records with tile0 <= pos < tile0 + TILE are (f0 or f0+1) .. f1
+    if (f1 >= 0 && n_rec) {
+        const int32_t lo = f0 < 0 ? 0 : f0;
+        for (int32_t j = lo + (int32_t)threadIdx.x; j <= f1; j += THREADS) {
+            const msim_record r = recs[j];
+            const uint64_t p = r.pos;
+            if (p < tile0 || p >= tile0 + TILE) continue;
+            const uint32_t idx = (uint32_t)(p - tile0);
+            const uint32_t x = tile[idx];
+            const uint32_t nb = lut[(uint32_t)r.aux * 256 + x];
+            if (nb == 0 && r.aux != 0) report_key_error(err, p, lut[768 + x]);
+            else tile[idx] = (uint8_t)nb;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t o = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        if (tile0 + o < L) *reinterpret_cast<u32x4 *>(out + tile0 + o) = *reinterpret_cast<const u32x4 *>(tile + o);
+    }
+}
+
 // single-lane epilogue: small results go to the pinned host mailbox (no blit-kernel D2H copy)
 __global__ void k_publish_u64(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ mailbox) {
     *mailbox = *src;
@@ -536,8 +585,12 @@ int apply_contig_device(Ctx *c, Contig &g) {
     MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
     MSIM_HIP(c, hipEventRecord(c->ev1, c->stream));
     if (n_tiles) {
-        hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
-                           d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
+        if (g.all_snp)
+            hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
+                               d_first, n, g.out_len, ctx_lut(c), d_err);
+        else
+            hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
+                               d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
         MSIM_HIP(c, hipGetLastError());
     }
     MSIM_HIP(c, hipEventRecord(c->ev2, c->stream));
