@@ -147,8 +147,14 @@ int msim_plan_contig(msim_ctx *ctx, int contig, const msim_range *ranges, int n_
 int msim_plan_was_empty(msim_ctx *ctx, int contig, int *empty);
 
 /* ---- APPLY: Mutator.__mutate_sequence (mutator.py:318-426) -------------------------------------- */
+/* Execution model: msim_plan_contig (GPU sampler) and msim_apply_contig (SNP-only tables) only ENQUEUE
+ * work -- the chain that fixes stream positions on one HIP stream, record emission and the rewrite
+ * kernel on another, overlapping the next contig's chain.  Deferred outcomes (the reference's
+ * KeyError, an internal window overflow) are reported by the next call that synchronises: msim_sync,
+ * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats.    */
 int msim_apply_contig(msim_ctx *ctx, int contig);
-/* If apply hit the reference's KeyError: the offending (ambiguity-converted) base and position.    */
+/* If apply hit the reference's KeyError: the offending (ambiguity-converted) base and position.
+ * contig == -1: the first contig (in index order) that hit it.                                    */
 int msim_key_error(msim_ctx *ctx, int contig, uint8_t *base, uint64_t *pos);
 
 int msim_result_sizes(msim_ctx *ctx, int contig, uint64_t *out_len, uint64_t *n_records,

@@ -498,6 +498,8 @@ int dev_reserve(Ctx *c, void **p, size_t *cap, size_t want_bytes) {
 
 int ensure_scratch(Ctx *c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return MSIM_OK;
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));          // the old block may still be in use
+    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
     if (c->d_scratch) MSIM_HIP(c, hipFree(c->d_scratch));
     c->d_scratch = nullptr;
     c->scratch_bytes = 0;
@@ -536,11 +538,48 @@ int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum) {
 
 // LUT upload lives with the ctx (msim_api.hip); declared here
 extern uint8_t *ctx_lut(Ctx *c);
-extern unsigned long long *ctx_err_word(Ctx *c);
 
+int apply_finish(Ctx *c) {
+    if (c->pending_apply.empty()) return MSIM_OK;
+    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    std::vector<unsigned long long> errs(c->contigs.size());
+    MSIM_HIP(c, hipMemcpy(errs.data(), c->d_errs, errs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int idx : c->pending_apply) {
+        if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
+        Contig &g = c->contigs[(size_t)idx];
+        if (!g.apply_pending) continue;
+        g.apply_pending = false;
+        float ms_all = 0, ms_k = 0;
+        MSIM_HIP(c, hipEventElapsedTime(&ms_all, g.ea0, g.ea2));
+        MSIM_HIP(c, hipEventElapsedTime(&ms_k, g.ea1, g.ea2));
+        c->t.apply_ms += ms_all;
+        c->t.apply_kernel_ms += ms_k;
+        const unsigned long long h_err = errs[(size_t)idx];
+        g.key_error = h_err != ~0ull;
+        if (g.key_error) { g.key_pos = h_err >> 8; g.key_base = (uint8_t)(h_err & 0xff); g.key_reported = false; }
+    }
+    c->pending_apply.clear();
+    return MSIM_OK;
+}
+
+// SNP-only tables: fully asynchronous (no length change, so nothing has to come back to the host
+// before the kernel can be launched); the KeyError word and the timings are collected by
+// apply_finish at the next synchronising call.  Tables with indels need the scanned total length to
+// size the output, so that path synchronises once.
 int apply_contig_device(Ctx *c, Contig &g) {
     const uint32_t n = (uint32_t)g.n_rec;
-    MSIM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    hipStream_t st = c->emit_stream;
+    if (!g.ea0) {
+        MSIM_HIP(c, hipEventCreate(&g.ea0));
+        MSIM_HIP(c, hipEventCreate(&g.ea1));
+        MSIM_HIP(c, hipEventCreate(&g.ea2));
+    }
+    if (g.apply_pending) {                                 // same contig applied again before collection
+        int rc = apply_finish(c);
+        if (rc) return rc;
+    }
+    unsigned long long *d_err = c->d_errs + g.index;
+    MSIM_HIP(c, hipEventRecord(g.ea0, st));
     // ---- 1. output offsets (skipped for an SNP-only table: no length change, offset == position)
     long long total_delta = 0;
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
@@ -551,13 +590,13 @@ int apply_contig_device(Ctx *c, Contig &g) {
         rc = ensure_scratch(c, (size_t)(nb + 1) * sizeof(long long));
         if (rc) return rc;
         long long *d_sums = reinterpret_cast<long long *>(c->d_scratch);
-        hipLaunchKernelGGL(k_delta_reduce, dim3(nb), dim3(THREADS), 0, c->stream, g.d_recs, n, d_sums);
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, d_sums, nb);
-        hipLaunchKernelGGL(k_offsets, dim3(nb), dim3(THREADS), 0, c->stream, g.d_recs, n, d_sums, g.d_off);
-        hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, c->stream,
+        hipLaunchKernelGGL(k_delta_reduce, dim3(nb), dim3(THREADS), 0, st, g.d_recs, n, d_sums);
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, d_sums, nb);
+        hipLaunchKernelGGL(k_offsets, dim3(nb), dim3(THREADS), 0, st, g.d_recs, n, d_sums, g.d_off);
+        hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, st,
                            reinterpret_cast<const unsigned long long *>(d_sums + nb), c->h_mail);
         MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        MSIM_HIP(c, hipStreamSynchronize(st));
         total_delta = (long long)*c->h_mail;
         d_off = g.d_off;
     }
@@ -565,55 +604,48 @@ int apply_contig_device(Ctx *c, Contig &g) {
     if (out_len_ll < 0 || (uint64_t)out_len_ll >= (1ull << 32))
         return fail(c, MSIM_ERR_UNSUPPORTED, "mutated contig of 4 GiB or more");
     g.out_len = (uint64_t)out_len_ll;
-    {
+    if (g.cap_out < g.out_len + PAD) {                     // replacing a buffer: nothing may be in flight on it
+        MSIM_HIP(c, hipStreamSynchronize(st));
         int rc = dev_reserve(c, (void **)&g.d_out, &g.cap_out, g.out_len + PAD);
         if (rc) return rc;
     }
     // ---- 2. tile index
     const uint32_t n_tiles = (uint32_t)((g.out_len + TILE - 1) / TILE);
     int32_t *d_first = nullptr;
-    unsigned long long *d_err = ctx_err_word(c);
     if (n_tiles) {
         int rc = ensure_scratch(c, (size_t)(n_tiles + 1) * sizeof(int32_t) + 64);
         if (rc) return rc;
         d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
-        hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, c->stream,
+        hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, st,
                            d_off, g.d_recs, n, d_first, n_tiles + 1);
         MSIM_HIP(c, hipGetLastError());
     }
     // ---- 3. rewrite
-    MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, c->stream));
-    MSIM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
+    MSIM_HIP(c, hipEventRecord(g.ea1, st));
     if (n_tiles) {
         if (g.all_snp)
-            hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
+            hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in, g.d_out, g.d_recs,
                                d_first, n, g.out_len, ctx_lut(c), d_err);
         else
-            hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, c->stream, g.d_in, g.d_out, g.d_recs,
+            hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in, g.d_out, g.d_recs,
                                d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
         MSIM_HIP(c, hipGetLastError());
     }
-    MSIM_HIP(c, hipEventRecord(c->ev2, c->stream));
-    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, c->stream, d_err, c->h_mail);
-    MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
-    const unsigned long long h_err = *c->h_mail;
-    float ms_all = 0, ms_k = 0;
-    MSIM_HIP(c, hipEventElapsedTime(&ms_all, c->ev0, c->ev2));
-    MSIM_HIP(c, hipEventElapsedTime(&ms_k, c->ev1, c->ev2));
-    c->t.apply_ms += ms_all;
-    c->t.apply_kernel_ms += ms_k;
+    MSIM_HIP(c, hipEventRecord(g.ea2, st));
     c->t.apply_launches += n_tiles ? 1 : 0;
     c->t.bytes_in += g.len;
     c->t.bytes_out += g.out_len;
     c->t.records += n;
-    g.key_error = h_err != ~0ull;
-    if (g.key_error) {
-        g.key_pos = h_err >> 8;
-        g.key_base = (uint8_t)(h_err & 0xff);
-    }
     g.applied = true;
-    return g.key_error ? fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'") : MSIM_OK;
+    g.apply_pending = true;
+    g.key_error = false;
+    c->pending_apply.push_back(g.index);
+    if (g.all_snp) return MSIM_OK;                         // asynchronous
+    int rc = apply_finish(c);
+    if (rc) return rc;
+    if (g.key_error) { g.key_reported = true; return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'"); }
+    return MSIM_OK;
 }
 
 }  // namespace msim

@@ -30,6 +30,10 @@ struct Contig {
     uint8_t key_base = 0;             // KeyError report
     uint64_t key_pos = 0;
     bool key_error = false;
+    bool key_reported = false;
+    int index = 0;                    // position in Ctx::contigs (selects the error word)
+    bool apply_pending = false;       // APPLY enqueued, result not yet collected
+    hipEvent_t ea0 = nullptr, ea1 = nullptr, ea2 = nullptr;   // APPLY timing (emit stream)
     // host-only context (device_id -1): the record table stays here
     std::vector<msim_record> h_recs;
     std::vector<uint8_t> h_pool;
@@ -43,7 +47,8 @@ struct Ctx {
     int device = 0;
     bool host_only = false;           // msim_create(-1): PLAN + text rendering only, no GPU touched
     uint32_t flags = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;         // plan chain, uploads
+    hipStream_t emit_stream = nullptr;    // record emission + APPLY (overlaps the next contig's chain)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     std::string err;
     std::string devname;
@@ -57,6 +62,8 @@ struct Ctx {
     void *d_scratch = nullptr;
     size_t scratch_bytes = 0;
     unsigned long long *h_mail = nullptr;   // pinned, device-visible mailbox for small results
+    unsigned long long *d_errs = nullptr;   // one KeyError word per contig
+    std::vector<int> pending_apply;
 };
 
 int fail(Ctx *c, int code, const std::string &msg);
@@ -78,6 +85,8 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);
+int apply_finish(Ctx *c);             // collect results of asynchronous APPLYs (timing, KeyError words)
+constexpr int MAX_CONTIGS = 1 << 16;
 int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed);
 int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum);
 int ensure_scratch(Ctx *c, size_t bytes);

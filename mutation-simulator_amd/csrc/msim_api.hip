@@ -21,11 +21,26 @@ int hip_fail(Ctx *c, hipError_t e, const char *what) {
 
 struct CtxDev {            // small device-side constants owned by the ctx
     uint8_t *d_lut = nullptr;
-    unsigned long long *d_err = nullptr;
 };
 static CtxDev *dev_of(Ctx *c);
 uint8_t *ctx_lut(Ctx *c) { return dev_of(c)->d_lut; }
-unsigned long long *ctx_err_word(Ctx *c) { return dev_of(c)->d_err; }
+
+// Everything enqueued has completed and its deferred results are collected: sampler flags + exact
+// stream position, APPLY timings + KeyError words.  Returns the sampler's error, if any.
+static int drain(Ctx *c) {
+    if (c->host_only) return MSIM_OK;
+    int rc = c->gpu ? gpu_plan_finish(c, c->gpu) : MSIM_OK;
+    int rc2 = apply_finish(c);
+    if (rc) return rc;
+    if (rc2) return rc2;
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    return MSIM_OK;
+}
+static int key_error_of(Ctx *c, Contig &g) {
+    g.key_reported = true;
+    return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'");
+}
 
 struct CtxFull : Ctx { CtxDev dev; };
 static CtxDev *dev_of(Ctx *c) { return &static_cast<CtxFull *>(c)->dev; }
@@ -73,6 +88,9 @@ static int free_contig(Ctx *c, Contig &g, bool keep_input) {
     if (g.d_out) { MSIM_HIP(c, hipFree(g.d_out)); g.d_out = nullptr; }
     if (g.d_off) { MSIM_HIP(c, hipFree(g.d_off)); g.d_off = nullptr; }
     g.cap_recs = g.cap_pool = g.cap_out = g.cap_off = 0;
+    if (g.ea0) { (void)hipEventDestroy(g.ea0); (void)hipEventDestroy(g.ea1); (void)hipEventDestroy(g.ea2); g.ea0 = g.ea1 = g.ea2 = nullptr; }
+    g.apply_pending = false;
+    g.key_error = false;
     reset_contig(g);
     if (!keep_input && g.d_in) { MSIM_HIP(c, hipFree(g.d_in)); g.d_in = nullptr; }
     return MSIM_OK;
@@ -85,8 +103,10 @@ static Contig *get_contig(Ctx *c, int id) {
 
 static int new_contig(Ctx *c, uint64_t len, Contig **out) {
     if (len >= (1ull << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "contig of 4 GiB or more (multi-word getrandbits)");
+    if (c->contigs.size() >= (size_t)MAX_CONTIGS) return fail(c, MSIM_ERR_UNSUPPORTED, "more than 65536 contigs in one context");
     Contig g;
     g.len = len;
+    g.index = (int)c->contigs.size();
     if (!c->host_only) {
         MSIM_HIP(c, hipMalloc(&g.d_in, len + PAD));
         MSIM_HIP(c, hipMemsetAsync(g.d_in + len, 0, PAD, c->stream));
@@ -147,6 +167,7 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&c->emit_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     hipEvent_t *evs[4] = {&c->ev0, &c->ev1, &c->ev2, &c->ev3};
     for (auto ev : evs)
         if ((e = hipEventCreate(ev)) != hipSuccess) return bail(e, "hipEventCreate");
@@ -154,7 +175,7 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     build_lut(lut);
     if ((e = hipMalloc(&c->dev.d_lut, sizeof lut)) != hipSuccess) return bail(e, "hipMalloc(lut)");
     if ((e = hipMemcpy(c->dev.d_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(lut)");
-    if ((e = hipMalloc(&c->dev.d_err, 64)) != hipSuccess) return bail(e, "hipMalloc(err)");
+    if ((e = hipMalloc(&c->d_errs, (size_t)MAX_CONTIGS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(errs)");
     if ((e = hipHostMalloc(&c->h_mail, 64, hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(mailbox)");
     c->gpu = gpu_plan_create();
     *out = reinterpret_cast<msim_ctx *>(static_cast<Ctx *>(c));
@@ -170,15 +191,17 @@ void msim_destroy(msim_ctx *p) {
     if (c->host_only) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->emit_stream);
     for (auto &g : c->contigs) (void)free_contig(c, g, false);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
-    if (c->dev.d_err) (void)hipFree(c->dev.d_err);
+    if (c->d_errs) (void)hipFree(c->d_errs);
     gpu_plan_destroy(c->gpu);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->emit_stream) (void)hipStreamDestroy(c->emit_stream);
     delete c;
 }
 
@@ -197,13 +220,20 @@ int msim_sync(msim_ctx *p) {
     Ctx *c = C(p);
     if (!c) return MSIM_ERR_ARG;
     if (c->host_only) return MSIM_OK;
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    int rc = drain(c);
+    if (rc) return rc;
+    for (auto &g : c->contigs)                             // deferred KeyError of an asynchronous APPLY
+        if (g.key_error && !g.key_reported) return key_error_of(c, g);
     return MSIM_OK;
 }
 
 int msim_seed(msim_ctx *p, const uint32_t *py_key, int n_key, uint32_t np_seed) {
     Ctx *c = C(p);
     if (!c || !py_key || n_key < 1) return MSIM_ERR_ARG;
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     c->py.init_by_array(py_key, n_key);
     c->py.words = 0;
     c->np.init_genrand(np_seed);
@@ -298,7 +328,10 @@ int msim_read_contig(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8
 int msim_clear(msim_ctx *p) {
     Ctx *c = C(p);
     if (!c) return MSIM_ERR_ARG;
-    if (!c->host_only) MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     for (auto &g : c->contigs) {
         int rc = free_contig(c, g, false);
         if (rc) return rc;
@@ -331,6 +364,10 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     if (gpu_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
         rc = gpu_plan_sync_to_host(c, c->gpu);
+        if (rc) return rc;
+    }
+    if (!c->host_only) {               // this contig's buffers may still be read by an asynchronous APPLY
+        rc = apply_finish(c);
         if (rc) return rc;
     }
     HostPlan hp;
@@ -390,8 +427,14 @@ int msim_apply_contig(msim_ctx *p, int contig) {
 int msim_key_error(msim_ctx *p, int contig, uint8_t *base, uint64_t *pos) {
     Ctx *c = C(p);
     if (!c) return MSIM_ERR_ARG;
-    Contig *g = get_contig(c, contig);
-    if (!g) return MSIM_ERR_ARG;
+    Contig *g = nullptr;
+    if (contig == -1) {                                    // first contig that hit it
+        for (auto &q : c->contigs) if (q.key_error) { g = &q; break; }
+        if (!g) return fail(c, MSIM_ERR_ARG, "no KeyError recorded");
+    } else {
+        g = get_contig(c, contig);
+        if (!g) return MSIM_ERR_ARG;
+    }
     if (!g->key_error) return fail(c, MSIM_ERR_ARG, "no KeyError recorded for this contig");
     if (base) *base = g->key_base;
     if (pos) *pos = g->key_pos;
@@ -406,6 +449,9 @@ int msim_result_sizes(msim_ctx *p, int contig, uint64_t *out_len, uint64_t *n_re
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
     if (out_len) {
         if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+        int rc = drain(c);
+        if (rc) return rc;
+        if (g->key_error) return key_error_of(c, *g);
         *out_len = g->out_len;
     }
     if (n_records) *n_records = g->n_rec;
@@ -419,6 +465,11 @@ int msim_fetch_sequence(msim_ctx *p, int contig, uint64_t offset, uint64_t n, ui
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+        if (g->key_error) return key_error_of(c, *g);
+    }
     if (offset > g->out_len || n > g->out_len - offset) return fail(c, MSIM_ERR_ARG, "fetch beyond mutated contig end");
     if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_out + offset, n, hipMemcpyDeviceToHost, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
@@ -436,6 +487,10 @@ int msim_fetch_records(msim_ctx *p, int contig, msim_record *dst, uint8_t *pool_
         if (pool_dst && g->pool_len) memcpy(pool_dst, g->h_pool.data(), g->pool_len);
         return MSIM_OK;
     }
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     if (dst && g->n_rec)
         MSIM_HIP(c, hipMemcpyAsync(dst, g->d_recs, g->n_rec * sizeof(msim_record), hipMemcpyDeviceToHost, c->stream));
     if (pool_dst && g->pool_len)
@@ -450,6 +505,11 @@ int msim_result_checksum(msim_ctx *p, int contig, uint64_t *sum) {
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+        if (g->key_error) return key_error_of(c, *g);
+    }
     return checksum_device(c, g->d_out, g->out_len, sum);
 }
 
@@ -458,13 +518,20 @@ int msim_release_result(msim_ctx *p, int contig) {
     if (!c) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
-    if (!c->host_only) MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     return free_contig(c, *g, true);
 }
 
 int msim_stats(msim_ctx *p, msim_timing *out) {
     Ctx *c = C(p);
     if (!c || !out) return MSIM_ERR_ARG;
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     *out = c->t;
     return MSIM_OK;
 }
@@ -472,6 +539,10 @@ int msim_stats(msim_ctx *p, msim_timing *out) {
 int msim_reset_stats(msim_ctx *p) {
     Ctx *c = C(p);
     if (!c) return MSIM_ERR_ARG;
+    {
+        int rc = drain(c);
+        if (rc) return rc;
+    }
     c->t = msim_timing{};
     return MSIM_OK;
 }

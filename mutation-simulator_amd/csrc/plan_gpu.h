@@ -14,6 +14,8 @@ void gpu_plan_invalidate(GpuPlan *g);
 int gpu_plan_sync_to_host(Ctx *c, GpuPlan *g);
 // optional sizing hint: generate at least this many words ahead on the first extension
 void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words);
+// wait for everything enqueued, collect flags + exact stream position (no-op if nothing is pending)
+int gpu_plan_finish(Ctx *c, GpuPlan *g);
 bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 

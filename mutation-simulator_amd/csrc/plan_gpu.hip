@@ -28,6 +28,7 @@
 // i.e. SNP-only ARGS runs such as BASELINE config 2.  Everything else goes through plan_host.cpp.
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "ctx.h"
 #include "mt_jump_table.h"
@@ -43,8 +44,8 @@ constexpr int ACC_THREADS = 256;
 constexpr int ACC_ITEMS = 8;
 constexpr int ACC_BLOCK = ACC_THREADS * ACC_ITEMS;       // 2048 stream words per workgroup
 constexpr int SNP_THREADS = 256;
-constexpr int SNP_ITEMS = 16;
-constexpr int SNP_BLOCK = SNP_THREADS * SNP_ITEMS;       // 4096 stream words per workgroup
+
+
 constexpr int BM_THREADS = 256;
 
 enum : uint32_t { FLAG_SAMPLE_OVERFLOW = 1u, FLAG_SNP_OVERFLOW = 2u };
@@ -52,6 +53,7 @@ enum : uint32_t { FLAG_SAMPLE_OVERFLOW = 1u, FLAG_SNP_OVERFLOW = 2u };
 // device-resident bookkeeping of one plan call
 struct PlanState {
     unsigned long long pos;        // index into the raw word array of the next unconsumed word
+    unsigned long long snp_base;   // pos at which the current contig's SNP draws start (= end of its samples)
     uint32_t flags;
     uint32_t dups;                 // duplicates found by the first-k insert
     uint32_t accepted_used;        // accepted draws consumed by the last sample
@@ -239,13 +241,22 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accept_scatter(const uint32_t *
 // ------------------------------------------------------------------ 3. first-occurrence de-dup
 __global__ __launch_bounds__(256) void k_bitmap_insert(const uint32_t *__restrict__ acc, uint32_t count,
                                                        uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps) {
-    uint32_t d = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
-        const uint32_t v = acc[i];
-        const uint32_t bit = 1u << (v & 31);
-        const uint32_t old = atomicOr(&bitmap[v >> 5], bit);
-        if (old & bit) d++;
+    // every lane issues its four atomics back to back (latency-bound otherwise), then counts
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t old[4], bit[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = base + 256 * q;
+        old[q] = 0; bit[q] = 0;
+        if (i < count) {
+            const uint32_t v = acc[i];
+            bit[q] = 1u << (v & 31);
+            old[q] = atomicOr(&bitmap[v >> 5], bit[q]);
+        }
     }
+    uint32_t d = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) d += (old[q] & bit[q]) ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
     if ((threadIdx.x & 63) == 0 && d) atomicAdd(&ps->dups, d);
 }
@@ -326,6 +337,7 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
     if (excl < want && want <= incl) {
         const uint32_t idx = (f[0] && excl + 1 == want) ? i0 : i0 + 1;
         ps->pos = p0 + idx + 1;
+        ps->snp_base = p0 + idx + 1;
         ps->accepted_used = A;
     }
 }
@@ -388,81 +400,133 @@ __device__ __forceinline__ SnpMap snp_compose(const SnpMap &f, const SnpMap &g) 
 }
 __device__ __forceinline__ SnpMap snp_identity() { SnpMap r; r.c[0] = r.c[1] = r.c[2] = 0; r.e = 0 | (1 << 2) | (2 << 4); return r; }
 
-// one step; returns new state, sets emit/aux
-__device__ __forceinline__ uint32_t snp_step(uint32_t s, uint32_t prev, uint32_t cur, unsigned long long ti_lim,
-                                             bool &emit, uint32_t &aux) {
-    emit = false;
-    if (s == 0) return 1;
-    if (s == 1) {
-        const unsigned long long m = ((unsigned long long)(prev >> 5) << 26) | (cur >> 6);
-        if (m < ti_lim) { emit = true; aux = 0; return 0; }          // p <= p_ti: transition
-        return 2;
-    }
-    if ((cur >> 31) == 0) { emit = true; aux = 1 + ((cur >> 30) & 1); return 0; }   // getrandbits(2) < 2
-    return 2;
+// A lane owns 32 consecutive stream words, reduced to three bitmasks:
+//   A bit i : words (i-1, i) as a uniform(0,1) sample decide "transition"  (p <= p_ti, mutator.py:438)
+//   B bit i : word i ends a randbelow(2) loop (getrandbits(2) < 2, i.e. top bit clear)
+//   T bit i : the transversion column word i would pick (bit 30)
+// With them the transducer walks SNP by SNP (ctz over the masks) instead of word by word.
+struct SnpBits { uint32_t A, B, T; int E; };             // E = valid words (0..32)
+
+__device__ __forceinline__ uint32_t first_bit_from(uint32_t mask, int from, int E) {   // index or 32
+    if (from >= 32) return 32;
+    uint32_t m = mask & (~0u << from);
+    if (E < 32) m &= (1u << E) - 1u;
+    return m ? (uint32_t)__builtin_ctz(m) : 32u;
 }
 
-__device__ __forceinline__ SnpMap snp_thread_map(const uint32_t *u, uint32_t prev, int cnt, unsigned long long ti_lim) {
+// Walk the SNPs of one lane's words from start state s0.  on_emit(word_index, aux) is called for
+// every completed SNP in order.  Returns the end state; count through the reference.
+template <typename F>
+__device__ __forceinline__ uint32_t snp_walk(uint32_t s0, const SnpBits &m, uint32_t &count, F on_emit) {
+    count = 0;
+    const int E = m.E;
+    if (E <= 0) return s0;
+    int p;                                               // word index at which the next SNP's 1st word sits
+    if (s0 == 0) {
+        p = 0;
+    } else {
+        uint32_t j;
+        if (s0 == 1 && (m.A & 1u)) { on_emit(0, 0u); count = 1; p = 1; }
+        else {
+            j = first_bit_from(m.B, s0 == 1 ? 1 : 0, E);
+            if (j >= 32) return 2;
+            on_emit((int)j, 1u + ((m.T >> j) & 1u)); count = 1; p = (int)j + 1;
+        }
+    }
+    while (true) {
+        if (p >= E) return 0;
+        if (p == E - 1) return 1;
+        if ((m.A >> (p + 1)) & 1u) { on_emit(p + 1, 0u); count++; p += 2; }
+        else {
+            const uint32_t j = first_bit_from(m.B, p + 2, E);
+            if (j >= 32) return 2;
+            on_emit((int)j, 1u + ((m.T >> j) & 1u)); count++; p = (int)j + 1;
+        }
+    }
+}
+
+__device__ __forceinline__ SnpMap snp_lane_map(const SnpBits &m) {
     SnpMap r;
     r.e = 0;
 #pragma unroll
-    for (int s0 = 0; s0 < 3; s0++) {
-        uint32_t s = s0, c = 0, p = prev;
-        for (int q = 0; q < cnt; q++) {
-            bool emit; uint32_t aux;
-            s = snp_step(s, p, u[q], ti_lim, emit, aux);
-            c += emit ? 1u : 0u;
-            p = u[q];
-        }
+    for (uint32_t s0 = 0; s0 < 3; s0++) {
+        uint32_t c;
+        const uint32_t e = snp_walk(s0, m, c, [](int, uint32_t) {});
         r.c[s0] = c;
-        r.e |= s << (2 * s0);
+        r.e |= e << (2 * s0);
     }
     return r;
 }
 
-// exclusive scan of per-thread maps inside the workgroup; returns this thread's prefix map and
-// leaves the workgroup aggregate in total
-__device__ __forceinline__ SnpMap snp_block_scan(const SnpMap &mine, SnpMap *lds, SnpMap &total) {
-    lds[threadIdx.x] = mine;
-    __syncthreads();
-    for (int o = 1; o < SNP_THREADS; o <<= 1) {
-        SnpMap t = snp_identity();
-        const bool on = threadIdx.x >= (unsigned)o;
-        if (on) t = lds[threadIdx.x - o];
-        __syncthreads();
-        if (on) lds[threadIdx.x] = snp_compose(t, lds[threadIdx.x]);
-        __syncthreads();
+constexpr int SNP_ITEMS2 = 32;
+constexpr int SNP_BLOCK2 = SNP_THREADS * SNP_ITEMS2;     // 8192 stream words per workgroup
+constexpr int SNP_LDS_WORDS = SNP_BLOCK2 + SNP_BLOCK2 / 32 + 1;
+
+// Coalesced load of the workgroup's 8192 words (tempered) into LDS, row-padded (stride 33) so a
+// lane's 32 consecutive words are conflict-free; then each lane builds its masks.
+__device__ __forceinline__ SnpBits snp_stage(const uint32_t *__restrict__ raw, unsigned long long p0, uint32_t base,
+                                             uint32_t W, unsigned long long ti_lim, uint32_t *sw) {
+    for (int r = 0; r < SNP_ITEMS2; r++) {
+        const uint32_t idx = r * SNP_THREADS + threadIdx.x;
+        uint32_t w = 0;
+        if (base + idx < W) w = mt_temper(raw[p0 + base + idx]);
+        sw[idx + (idx >> 5)] = w;
     }
-    total = lds[SNP_THREADS - 1];
-    SnpMap ex = snp_identity();
-    if (threadIdx.x > 0) ex = lds[threadIdx.x - 1];
+    if (threadIdx.x == 0) sw[SNP_LDS_WORDS - 1] = base > 0 ? mt_temper(raw[p0 + base - 1]) : 0;
     __syncthreads();
-    return ex;
+    SnpBits m;
+    m.A = m.B = m.T = 0;
+    const uint32_t first = base + threadIdx.x * SNP_ITEMS2;
+    m.E = first >= W ? 0 : (int)std::min<uint32_t>(SNP_ITEMS2, W - first);
+    uint32_t prev = threadIdx.x ? sw[(threadIdx.x - 1) * 33 + 31] : sw[SNP_LDS_WORDS - 1];
+    const uint32_t *mine = sw + threadIdx.x * 33;
+#pragma unroll
+    for (int i = 0; i < SNP_ITEMS2; i++) {
+        const uint32_t w = mine[i];
+        const unsigned long long u = ((unsigned long long)(prev >> 5) << 26) | (w >> 6);
+        m.A |= (u < ti_lim ? 1u : 0u) << i;
+        m.B |= ((w >> 31) ^ 1u) << i;
+        m.T |= ((w >> 30) & 1u) << i;
+        prev = w;
+    }
+    return m;
 }
 
-__device__ __forceinline__ int snp_load(const uint32_t *__restrict__ raw, unsigned long long p0, uint32_t i0,
-                                        uint32_t W, uint32_t *u, uint32_t &prev) {
-    int cnt = 0;
+// exclusive prefix of the lanes' maps across the workgroup (shuffles inside a wave, LDS across waves)
+__device__ __forceinline__ SnpMap snp_shfl_up(const SnpMap &v, int o) {
+    SnpMap r;
+    r.c[0] = __shfl_up(v.c[0], o, 64); r.c[1] = __shfl_up(v.c[1], o, 64);
+    r.c[2] = __shfl_up(v.c[2], o, 64); r.e = __shfl_up(v.e, o, 64);
+    return r;
+}
+__device__ __forceinline__ SnpMap snp_block_scan2(const SnpMap &mine, SnpMap *wave_tot, SnpMap &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SnpMap incl = mine;
 #pragma unroll
-    for (int q = 0; q < SNP_ITEMS; q++) {
-        u[q] = 0;
-        if (i0 + q < W) { u[q] = mt_temper(raw[p0 + i0 + q]); cnt = q + 1; }
+    for (int o = 1; o < 64; o <<= 1) {
+        const SnpMap t = snp_shfl_up(incl, o);
+        if (lane >= o) incl = snp_compose(t, incl);
     }
-    prev = i0 > 0 ? mt_temper(raw[p0 + i0 - 1]) : 0;
-    return cnt;
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    SnpMap pre = snp_identity();
+    for (int w = 0; w < wave; w++) pre = snp_compose(pre, wave_tot[w]);
+    total = wave_tot[0];
+    for (int w = 1; w < SNP_THREADS / 64; w++) total = snp_compose(total, wave_tot[w]);
+    SnpMap ex = snp_shfl_up(incl, 1);
+    if (lane == 0) ex = snp_identity();
+    __syncthreads();
+    return snp_compose(pre, ex);
 }
 
 __global__ __launch_bounds__(SNP_THREADS) void k_snp_reduce(const uint32_t *__restrict__ raw,
                                                             const PlanState *__restrict__ ps, uint32_t W,
                                                             unsigned long long ti_lim, SnpMap *__restrict__ block_maps) {
-    __shared__ SnpMap lds[SNP_THREADS];
-    const unsigned long long p0 = ps->pos;
-    const uint32_t i0 = blockIdx.x * SNP_BLOCK + threadIdx.x * SNP_ITEMS;
-    uint32_t u[SNP_ITEMS], prev;
-    const int cnt = snp_load(raw, p0, i0, W, u, prev);
-    const SnpMap mine = snp_thread_map(u, prev, cnt, ti_lim);
+    __shared__ uint32_t sw[SNP_LDS_WORDS];
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    const SnpBits m = snp_stage(raw, ps->snp_base, blockIdx.x * SNP_BLOCK2, W, ti_lim, sw);
     SnpMap total;
-    (void)snp_block_scan(mine, lds, total);
+    (void)snp_block_scan2(snp_lane_map(m), wave_tot, total);
     if (threadIdx.x == 0) block_maps[blockIdx.x] = total;
 }
 
@@ -512,48 +576,78 @@ __global__ __launch_bounds__(1024) void k_snp_scan(SnpMap *__restrict__ block_ma
     }
 }
 
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
-                                                          unsigned long long p0, uint32_t W, unsigned long long ti_lim,
-                                                          const SnpMap *__restrict__ block_maps,
-                                                          msim_record *__restrict__ recs, uint32_t K) {
-    __shared__ SnpMap lds[SNP_THREADS];
-    const uint32_t i0 = blockIdx.x * SNP_BLOCK + threadIdx.x * SNP_ITEMS;
-    uint32_t u[SNP_ITEMS], prev;
-    const int cnt = snp_load(raw, p0, i0, W, u, prev);
-    const SnpMap mine = snp_thread_map(u, prev, cnt, ti_lim);
-    SnpMap total;
-    const SnpMap ex = snp_block_scan(mine, lds, total);
-    const uint32_t bs = block_maps[blockIdx.x].e, bc = block_maps[blockIdx.x].c[0];
-    uint32_t s = (ex.e >> (2 * bs)) & 3;
-    uint32_t idx = bc + ex.c[bs];
-    uint32_t p = prev;
-    for (int q = 0; q < cnt; q++) {
-        bool emit; uint32_t aux;
-        s = snp_step(s, p, u[q], ti_lim, emit, aux);
-        p = u[q];
-        if (emit) {
-            if (idx < K) recs[idx].aux = (uint8_t)aux;
-            idx++;
-            if (idx == K) ps->pos = p0 + i0 + q + 1;      // the K-th SNP completed on this word
+// Exact end of the SNP draws: the workgroup in which the K-th SNP completes is re-walked by one
+// workgroup; the word on which it completes + 1 is the new stream position.  Keeps the (large) emit
+// pass off the stream-position critical path.  Also saves the base for the emit pass.
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_cut(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
+                                                         uint32_t W, unsigned long long ti_lim,
+                                                         const SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
+                                                         unsigned long long *__restrict__ base_out) {
+    __shared__ uint32_t sw[SNP_LDS_WORDS];
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    __shared__ uint32_t s_blk;
+    const unsigned long long p0 = ps->snp_base;
+    if (threadIdx.x == 0) {
+        *base_out = p0;
+        if (block_maps[nb].c[0] < K) { ps->flags |= FLAG_SNP_OVERFLOW; s_blk = 0xffffffffu; }
+        else {
+            uint32_t lo = 0, hi = nb;                     // last block whose count-before is < K
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (block_maps[mid].c[0] < K) lo = mid; else hi = mid;
+            }
+            s_blk = lo;
         }
     }
+    __syncthreads();
+    const uint32_t b = s_blk;
+    if (b == 0xffffffffu) return;
+    const uint32_t base = b * SNP_BLOCK2;
+    const SnpBits m = snp_stage(raw, p0, base, W, ti_lim, sw);
+    SnpMap total;
+    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
+    const uint32_t bs = block_maps[b].e, bc = block_maps[b].c[0];
+    const uint32_t st = (ex.e >> (2 * bs)) & 3;
+    uint32_t idx = bc + ex.c[bs];
+    uint32_t cnt;
+    const unsigned long long w0 = p0 + base + (unsigned long long)threadIdx.x * SNP_ITEMS2;
+    (void)snp_walk(st, m, cnt, [&](int word, uint32_t) {
+        idx++;
+        if (idx == K) ps->pos = w0 + (unsigned long long)word + 1;   // the K-th SNP completed on this word
+    });
 }
 
-// single-lane epilogues: flag an undersized SNP window, then publish the bookkeeping block to the
-// pinned host mailbox (a plain store over PCIe -- no blit-kernel D2H copy on the critical path)
-__global__ void k_snp_check_publish(const SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
-                                    PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
-    if (K && block_maps[nb].c[0] < K) ps->flags |= FLAG_SNP_OVERFLOW;
-    *mailbox = *ps;
-    __threadfence_system();
+// aux of every SNP record (off the critical path; runs on the emit stream)
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__restrict__ raw,
+                                                          const unsigned long long *__restrict__ base_in, uint32_t W,
+                                                          unsigned long long ti_lim,
+                                                          const SnpMap *__restrict__ block_maps,
+                                                          msim_record *__restrict__ recs, uint32_t K) {
+    __shared__ uint32_t sw[SNP_LDS_WORDS];
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    const uint32_t bc = block_maps[blockIdx.x].c[0];
+    if (bc >= K) return;                                  // window slack beyond the last SNP (uniform)
+    const SnpBits m = snp_stage(raw, *base_in, blockIdx.x * SNP_BLOCK2, W, ti_lim, sw);
+    SnpMap total;
+    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
+    const uint32_t bs = block_maps[blockIdx.x].e;
+    const uint32_t st = (ex.e >> (2 * bs)) & 3;
+    uint32_t idx = bc + ex.c[bs];
+    uint32_t cnt;
+    (void)snp_walk(st, m, cnt, [&](int, uint32_t aux) {
+        if (idx < K) recs[idx].aux = (uint8_t)aux;
+        idx++;
+    });
 }
+
+// single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
 __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
     *mailbox = *ps;
     __threadfence_system();
 }
 
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
-    ps->pos = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0; ps->rsv = 0;
+    ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0; ps->rsv = 0;
 }
 
 }  // namespace
@@ -569,23 +663,56 @@ struct GpuStream {
     uint64_t pos = 0;                   // next unconsumed index into x (exact, host copy)
     uint64_t last_session_words = 0;    // words the previous (re)seeded session went through: sizing hint
     bool live = false;                  // device copy is the authoritative stream
+    // generation runs on its own HIP stream; batch b covers chunks [.., ready_hi[b]) and signals ready_ev[b]
+    std::vector<uint32_t> ready_hi;
+    std::vector<hipEvent_t> ready_ev;
+    uint32_t waited_chunks = 0;         // the plan stream already waited for chunks below this
+};
+
+constexpr int N_SETS = 3;                // rotating scratch: chain(u+1) overlaps emit(u)
+
+struct SampleSet {                       // scratch of one sampled range
+    uint32_t *acc = nullptr; size_t acc_cap = 0;          // accepted draws, stream order
+    uint32_t *cnt = nullptr; size_t cnt_cap = 0;          // per-workgroup accept counts / offsets
+    uint32_t *bitmap = nullptr; size_t bm_cap = 0;        // n-bit de-dup bitmap (bytes)
+    uint32_t *cnt2 = nullptr; size_t cnt2_cap = 0;        // per-workgroup popcounts / ranks
+    hipEvent_t emit_done = nullptr;
+    bool pending = false;
+};
+struct SnpSet {                          // scratch of one contig's SNP draws
+    SnpMap *maps = nullptr; size_t cap = 0;
+    unsigned long long *base = nullptr;                   // device word: stream position the draws start at
+    hipEvent_t emit_done = nullptr;
+    bool pending = false;
 };
 
 struct GpuPlan {
     GpuStream s[2];
+    hipStream_t gen_stream = nullptr;   // chunk generation (latency-bound, ~300 us per batch)
+    hipStream_t jump_stream = nullptr;  // jump cascade: never waits for a generation batch
+    std::vector<hipEvent_t> ev_pool;
     uint32_t *d_poly = nullptr;
     PlanState *d_ps = nullptr;
     PlanState *h_mail = nullptr;        // pinned, device-visible mailbox
-    // scratch
-    uint32_t *d_acc = nullptr; size_t acc_cap = 0;
-    uint32_t *d_cnt = nullptr; size_t cnt_cap = 0;
-    uint32_t *d_bitmap = nullptr; size_t bm_cap = 0;     // bytes
-    SnpMap *d_maps = nullptr; size_t maps_cap = 0;
+    SampleSet sample[N_SETS];
+    SnpSet snp[N_SETS];
+    uint32_t unit = 0, snp_unit = 0;    // rotation counters
+    hipEvent_t chain_ev[2 * N_SETS] = {};
+    uint32_t chain_i = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // chain-time span since the last finish
+    bool ps_valid = false;              // device PlanState carries the current session's position
+    bool unverified = false;            // work enqueued since the last finish (flags / exact position unknown)
+    uint64_t verified_pos = 0;          // exact position at the last finish
     uint64_t reserve_words[2] = {0, 0};
 };
 
-static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes) {
+static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
     if (*cap >= want_bytes) return MSIM_OK;
+    if (!*grew) {                         // a buffer is about to be replaced: nothing may be in flight
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        *grew = true;
+    }
     if (*p) MSIM_HIP(c, hipFree(*p));
     *p = nullptr; *cap = 0;
     const size_t sz = want_bytes + want_bytes / 4 + 4096;
@@ -598,14 +725,32 @@ GpuPlan *gpu_plan_create() { return new GpuPlan(); }
 
 void gpu_plan_destroy(GpuPlan *g) {
     if (!g) return;
-    for (auto &s : g->s) { if (s.d_raw) (void)hipFree(s.d_raw); if (s.d_states) (void)hipFree(s.d_states); }
+    if (g->jump_stream) { (void)hipStreamSynchronize(g->jump_stream); (void)hipStreamDestroy(g->jump_stream); }
+    if (g->gen_stream) { (void)hipStreamSynchronize(g->gen_stream); (void)hipStreamDestroy(g->gen_stream); }
+    for (auto &s : g->s) {
+        if (s.d_raw) (void)hipFree(s.d_raw);
+        if (s.d_states) (void)hipFree(s.d_states);
+        for (auto e : s.ready_ev) (void)hipEventDestroy(e);
+    }
+    for (auto e : g->ev_pool) (void)hipEventDestroy(e);
+    for (auto &t : g->sample) {
+        if (t.acc) (void)hipFree(t.acc);
+        if (t.cnt) (void)hipFree(t.cnt);
+        if (t.bitmap) (void)hipFree(t.bitmap);
+        if (t.cnt2) (void)hipFree(t.cnt2);
+        if (t.emit_done) (void)hipEventDestroy(t.emit_done);
+    }
+    for (auto &t : g->snp) {
+        if (t.maps) (void)hipFree(t.maps);
+        if (t.base) (void)hipFree(t.base);
+        if (t.emit_done) (void)hipEventDestroy(t.emit_done);
+    }
+    for (auto e : g->chain_ev) if (e) (void)hipEventDestroy(e);
+    if (g->t0) (void)hipEventDestroy(g->t0);
+    if (g->t1) (void)hipEventDestroy(g->t1);
     if (g->d_poly) (void)hipFree(g->d_poly);
     if (g->d_ps) (void)hipFree(g->d_ps);
     if (g->h_mail) (void)hipHostFree(g->h_mail);
-    if (g->d_acc) (void)hipFree(g->d_acc);
-    if (g->d_cnt) (void)hipFree(g->d_cnt);
-    if (g->d_bitmap) (void)hipFree(g->d_bitmap);
-    if (g->d_maps) (void)hipFree(g->d_maps);
     delete g;
 }
 
@@ -617,60 +762,113 @@ void gpu_plan_invalidate(GpuPlan *g) {
 }
 void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words) { g->reserve_words[0] = py_words; g->reserve_words[1] = np_words; }
 
-// make x[0 .. upto) available on the device for stream `si`
+// Make x[0 .. upto) available to kernels on the PLAN stream.  Jumps and chunk generation are
+// enqueued on the generation stream, level by level (after cascade level r the states of chunks
+// < 2^(r+1) exist and those chunks can be generated), each batch followed by an event; the plan
+// stream only waits for the batch that covers what it is about to read.  With the sizing hint the
+// whole session is enqueued at the first call, so the cascade overlaps the planning of the first
+// contigs instead of preceding it.
 static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
     GpuStream &s = g->s[si];
+    if (!g->gen_stream) {
+        // distinct priorities -> distinct hardware queues (streams of one priority may share a queue and
+        // then serialise): the cascade must not queue behind a 300 us generation batch
+        int lo = 0, hi = 0;
+        MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MSIM_HIP(c, hipStreamCreateWithPriority(&g->gen_stream, hipStreamNonBlocking, lo));
+        MSIM_HIP(c, hipStreamCreateWithPriority(&g->jump_stream, hipStreamNonBlocking, hi));
+    }
     const uint64_t have = MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS;
-    if (upto <= have) return MSIM_OK;
-    // batch the extension: an explicit hint, or what the previous session on this context needed
-    upto = std::max<uint64_t>(upto, s.pos + g->reserve_words[si]);
-    if (si == 0) upto = std::max<uint64_t>(upto, std::min<uint64_t>(s.last_session_words, upto * 64));
-    const uint32_t need_chunks = (uint32_t)((upto - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
-    uint32_t want_states = 1;
-    int levels = 0;
-    while (want_states < need_chunks) { want_states <<= 1; levels++; }
-    if (levels > MT_JUMP_LEVELS) return fail(c, MSIM_ERR_UNSUPPORTED, "random stream longer than the jump table covers");
-    if (!g->d_poly) {
-        MSIM_HIP(c, hipMalloc(&g->d_poly, sizeof(MT_JUMP_POLY)));
-        MSIM_HIP(c, hipMemcpyAsync(g->d_poly, MT_JUMP_POLY, sizeof(MT_JUMP_POLY), hipMemcpyHostToDevice, c->stream));
-    }
-    if (want_states > s.states_cap) {
-        uint32_t *ns = nullptr;
-        MSIM_HIP(c, hipMalloc(&ns, (size_t)want_states * MT_N * sizeof(uint32_t)));
-        if (s.d_states) {
-            MSIM_HIP(c, hipMemcpyAsync(ns, s.d_states, (size_t)s.n_states * MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipFree(s.d_states));
+    if (upto > have) {
+        // batch the extension: an explicit hint, or what the previous session on this context needed
+        uint64_t want = std::max<uint64_t>(upto, s.pos + g->reserve_words[si]);
+        if (si == 0) want = std::max<uint64_t>(want, std::min<uint64_t>(s.last_session_words, want * 64));
+        const uint32_t need_chunks = (uint32_t)((want - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
+        uint32_t want_states = 1;
+        int levels = 0;
+        while (want_states < need_chunks) { want_states <<= 1; levels++; }
+        if (levels > MT_JUMP_LEVELS) return fail(c, MSIM_ERR_UNSUPPORTED, "random stream longer than the jump table covers");
+        if (!g->d_poly) {
+            MSIM_HIP(c, hipMalloc(&g->d_poly, sizeof(MT_JUMP_POLY)));
+            MSIM_HIP(c, hipMemcpy(g->d_poly, MT_JUMP_POLY, sizeof(MT_JUMP_POLY), hipMemcpyHostToDevice));
         }
-        s.d_states = ns;
-        s.states_cap = want_states;
-    }
-    const uint64_t want_cap = MT_N + (uint64_t)need_chunks * MT_CHUNK_WORDS;
-    if (want_cap > s.cap) {
-        uint32_t *nr = nullptr;
-        MSIM_HIP(c, hipMalloc(&nr, want_cap * sizeof(uint32_t)));
-        if (s.d_raw) {
-            MSIM_HIP(c, hipMemcpyAsync(nr, s.d_raw, have * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+        const uint64_t want_cap = MT_N + (uint64_t)need_chunks * MT_CHUNK_WORDS;
+        if (want_states > s.states_cap || want_cap > s.cap) {      // grow (rare): quiesce every stream first
+            MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));
+            MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipFree(s.d_raw));
+            if (want_states > s.states_cap) {
+                uint32_t *ns = nullptr;
+                MSIM_HIP(c, hipMalloc(&ns, (size_t)want_states * MT_N * sizeof(uint32_t)));
+                if (s.d_states) {
+                    MSIM_HIP(c, hipMemcpy(ns, s.d_states, (size_t)s.n_states * MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                    MSIM_HIP(c, hipFree(s.d_states));
+                }
+                s.d_states = ns;
+                s.states_cap = want_states;
+            }
+            if (want_cap > s.cap) {
+                uint32_t *nr = nullptr;
+                MSIM_HIP(c, hipMalloc(&nr, want_cap * sizeof(uint32_t)));
+                if (s.d_raw) {
+                    MSIM_HIP(c, hipMemcpy(nr, s.d_raw, have * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                    MSIM_HIP(c, hipFree(s.d_raw));
+                }
+                s.d_raw = nr;
+                s.cap = want_cap;
+            }
         }
-        s.d_raw = nr;
-        s.cap = want_cap;
+        auto take_event = [&](hipEvent_t &ev) -> int {
+            if (!g->ev_pool.empty()) { ev = g->ev_pool.back(); g->ev_pool.pop_back(); }
+            else MSIM_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            return MSIM_OK;
+        };
+        while (s.n_chunks < need_chunks) {
+            const uint32_t hi = std::min<uint32_t>(need_chunks, s.n_states);
+            // a generation batch costs ~300 us of latency whatever its size and batches queue in order,
+            // so the first few cascade levels (1, 2, 4 ... states) are not worth a batch of their own
+            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, 64u)) {
+                // states [n_chunks, hi) are complete on the jump stream: generate those chunks
+                hipEvent_t st_ev;
+                int rc = take_event(st_ev);
+                if (rc) return rc;
+                MSIM_HIP(c, hipEventRecord(st_ev, g->jump_stream));
+                MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, st_ev, 0));
+                s.ready_ev.push_back(st_ev);                // recycled with the batch events at the next reseed
+                s.ready_hi.push_back(0);
+                hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(64), 0, g->gen_stream, s.d_states,
+                                   s.d_raw, s.n_chunks);
+                MSIM_HIP(c, hipGetLastError());
+                hipEvent_t ev;
+                rc = take_event(ev);
+                if (rc) return rc;
+                MSIM_HIP(c, hipEventRecord(ev, g->gen_stream));
+                s.ready_hi.push_back(hi);
+                s.ready_ev.push_back(ev);
+                s.n_chunks = hi;
+            }
+            if (s.n_chunks < need_chunks) {                // next cascade level: states [0,n) -> [n,2n)
+                int r = 0;
+                while ((1u << r) < s.n_states) r++;
+                hipLaunchKernelGGL(k_mt_jump, dim3(s.n_states, JUMP_SPLIT), dim3(JUMP_THREADS), 0, g->jump_stream,
+                                   s.d_states, s.n_states, g->d_poly + (size_t)r * MT_POLY_WORDS);
+                MSIM_HIP(c, hipGetLastError());
+                s.n_states <<= 1;
+            }
+        }
     }
-    // cascade: level r turns states [0, 2^r) into [2^r, 2^(r+1))
-    while (s.n_states < want_states) {
-        int r = 0;
-        while ((1u << r) < s.n_states) r++;
-        hipLaunchKernelGGL(k_mt_jump, dim3(s.n_states, JUMP_SPLIT), dim3(JUMP_THREADS), 0, c->stream, s.d_states, s.n_states,
-                           g->d_poly + (size_t)r * MT_POLY_WORDS);
-        MSIM_HIP(c, hipGetLastError());
-        s.n_states <<= 1;
-    }
-    if (need_chunks > s.n_chunks) {
-        hipLaunchKernelGGL(k_mt_generate, dim3(need_chunks - s.n_chunks), dim3(64), 0, c->stream, s.d_states,
-                           s.d_raw, s.n_chunks);
-        MSIM_HIP(c, hipGetLastError());
-        s.n_chunks = need_chunks;
+    // the plan stream waits for the batch that covers `upto`
+    if (upto > MT_N) {
+        const uint32_t need = (uint32_t)((upto - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
+        if (need > s.waited_chunks) {
+            for (size_t b = 0; b < s.ready_hi.size(); b++) {
+                if (s.ready_hi[b] >= need) {
+                    MSIM_HIP(c, hipStreamWaitEvent(c->stream, s.ready_ev[b], 0));
+                    s.waited_chunks = s.ready_hi[b];
+                    break;
+                }
+            }
+        }
     }
     return MSIM_OK;
 }
@@ -688,18 +886,27 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
         MSIM_HIP(c, hipMalloc(&s.d_raw, (size_t)MT_N * sizeof(uint32_t)));
         s.cap = MT_N;
     }
+    if (g->jump_stream) MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));  // nothing of the old session in flight
+    if (g->gen_stream) MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
     MSIM_HIP(c, hipMemcpyAsync(s.d_states, h.mt, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
     MSIM_HIP(c, hipMemcpyAsync(s.d_raw, h.mt, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));       // h.mt may change right after
+    for (auto e : s.ready_ev) g->ev_pool.push_back(e);
+    s.ready_ev.clear();
+    s.ready_hi.clear();
+    s.waited_chunks = 0;
     s.n_states = 1;
     s.n_chunks = 0;
     s.pos = (uint64_t)h.idx;
     s.live = true;
+    if (si == 0) { g->ps_valid = false; g->verified_pos = s.pos; }
     return MSIM_OK;
 }
 
 // device stream -> host generator (any 624-word window ending at pos is a valid state)
 int gpu_plan_sync_to_host(Ctx *c, GpuPlan *g) {
+    int frc = gpu_plan_finish(c, g);
+    if (frc) return frc;
     for (int si = 0; si < 2; si++) {
         GpuStream &s = g->s[si];
         if (!s.live) continue;
@@ -745,6 +952,40 @@ bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
     return true;                                          // (a contig that draws nothing is trivially fine)
 }
 
+// Everything enqueued so far has completed: collect the sticky flags and the exact stream position.
+int gpu_plan_finish(Ctx *c, GpuPlan *g) {
+    if (!g->unverified) return MSIM_OK;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    float ms = 0;
+    MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
+    c->t.plan_gpu_ms += ms;
+    g->unverified = false;
+    for (auto &t : g->sample) t.pending = false;
+    for (auto &t : g->snp) t.pending = false;
+    const PlanState h = *g->h_mail;
+    if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
+        g->s[0].live = g->s[1].live = false;
+        return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its 16-sigma margin (results discarded)");
+    }
+    c->t.py_words += h.pos - g->verified_pos;
+    g->verified_pos = h.pos;
+    g->s[0].pos = h.pos;
+    return MSIM_OK;
+}
+
+static hipEvent_t next_chain_event(GpuPlan *g) {
+    hipEvent_t &e = g->chain_ev[g->chain_i++ % (2 * N_SETS)];
+    if (!e) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return e;
+}
+
+// Asynchronous: enqueues the contig's chain (stream positions) on the plan stream and its emit work
+// (records) on the emit stream; nothing is waited for.  Flags and the exact position are collected
+// by gpu_plan_finish at the next synchronising call.
 int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
     const msim_params &P = c->params;
     int64_t d = P.block[1];
@@ -757,105 +998,116 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     uint64_t K = 0;
     for (int i = 0; i < n_ranges; i++) K += (uint64_t)ranges[i].k;
     if (K >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "more than 2^31 mutations on one contig");
+    bool grew = false;
+    {   // the record table may still be read by an earlier apply of this contig
+        const size_t want = std::max<uint64_t>(K, 1) * sizeof(msim_record);
+        if (ct.cap_recs < want || ct.cap_pool < PAD) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        }
+        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, PAD))) return rc;
+    }
     ct.n_rec = K;
     ct.pool_len = 0;
     ct.plan_empty = K == 0;
     ct.all_snp = true;                                    // every record is an SNP: output offset == position
-    if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, std::max<uint64_t>(K, 1) * sizeof(msim_record)))) return rc;
-    if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, PAD))) return rc;
     const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
 
     GpuStream &py = g->s[0];
-    const uint64_t pos_start = py.pos;
-    for (int attempt = 0; attempt < 6; attempt++) {
-        const double slack = (double)(1u << attempt);
-        MSIM_HIP(c, hipEventRecord(c->ev0, c->stream));
-        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)pos_start);
-        uint64_t pos_hi = pos_start;                      // upper bound of the device position
-        uint64_t rec_base = 0;
-        for (int i = 0; i < n_ranges; i++) {
-            const msim_range &r = ranges[i];
-            if (r.k == 0) continue;
-            const uint32_t k = (uint32_t)r.k;
-            const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
-            const int bits = bit_length64(n);
-            const double p_acc = (double)n / (double)(1ull << bits);
-            // accepted draws needed ~ -n ln(1 - k/n) (coupon collector), words = that / p_acc
-            const double need_acc = -(double)n * std::log1p(-(double)k / (double)n);
-            const double target = need_acc + slack * (8.0 * std::sqrt(need_acc) + 2048.0);
-            const double wd = target / p_acc + slack * (8.0 * std::sqrt(target) / p_acc + 4096.0);
-            if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
-            const uint32_t W = (uint32_t)wd;
-            if ((rc = ensure_words(c, g, 0, pos_hi + W + 1))) return rc;
-            const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
-            if ((rc = grow(c, (void **)&g->d_cnt, &g->cnt_cap, (size_t)(std::max<uint64_t>(nb, (n + 63) / 64 / BM_THREADS + 1) + 2) * sizeof(uint32_t)))) return rc;
-            if ((rc = grow(c, (void **)&g->d_acc, &g->acc_cap, (size_t)W * sizeof(uint32_t)))) return rc;
-            const size_t bm_words64 = (size_t)((n + 63) / 64);
-            if ((rc = grow(c, (void **)&g->d_bitmap, &g->bm_cap, bm_words64 * 8))) return rc;
-            MSIM_HIP(c, hipMemsetAsync(g->d_bitmap, 0, bm_words64 * 8, c->stream));
-            hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, g->d_cnt, g->d_ps);
-            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, g->d_cnt, nb);
-            hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, g->d_cnt, g->d_acc);
-            hipLaunchKernelGGL(k_bitmap_insert, dim3(std::min<uint32_t>((k + 255) / 256, 256 * 8)), dim3(256), 0, c->stream,
-                               g->d_acc, k, g->d_bitmap, g->d_ps);
-            hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, g->d_acc, g->d_cnt, nb, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, k, g->d_bitmap, g->d_ps);
-            // sorted positions straight into the record table
-            const uint32_t bmw = (uint32_t)bm_words64;
-            const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
-            hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->stream,
-                               reinterpret_cast<const uint64_t *>(g->d_bitmap), bmw, g->d_cnt);
-            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, g->d_cnt, bnb);
-            hipLaunchKernelGGL(k_bitmap_expand, dim3(bnb), dim3(BM_THREADS), 0, c->stream,
-                               reinterpret_cast<const uint64_t *>(g->d_bitmap), bmw, g->d_cnt, (uint32_t)r.start,
-                               (uint32_t)d, ct.d_recs + rec_base);
-            MSIM_HIP(c, hipGetLastError());
-            pos_hi += W;
-            rec_base += k;
-        }
-        // SNP draws of the whole contig, in position order
-        uint32_t W2 = 0, nb2 = 0;
-        if (K) {
-            const double w2 = (double)K * (2.0 + 2.0 * p_tv) + slack * (8.0 * std::sqrt(4.0 * (double)K) + 8192.0);
-            if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
-            W2 = (uint32_t)w2;
-            if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
-            nb2 = (W2 + SNP_BLOCK - 1) / SNP_BLOCK;
-            if ((rc = grow(c, (void **)&g->d_maps, &g->maps_cap, (size_t)(nb2 + 1) * sizeof(SnpMap)))) return rc;
-            hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                               (unsigned long long)P.ti_lim, g->d_maps);
-            hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, g->d_maps, nb2);
-        }
-        hipLaunchKernelGGL(k_snp_check_publish, dim3(1), dim3(1), 0, c->stream, g->d_maps, nb2, (uint32_t)K, g->d_ps,
-                           g->h_mail);
-        MSIM_HIP(c, hipGetLastError());
-        // the emit pass needs the position the sample phases ended at as a plain argument
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
-        PlanState h = *g->h_mail;
-        if (!(h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) && K) {
-            hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps,
-                               (unsigned long long)h.pos, W2, (unsigned long long)P.ti_lim, g->d_maps, ct.d_recs,
-                               (uint32_t)K);
-            hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
-            MSIM_HIP(c, hipGetLastError());
-        }
-        MSIM_HIP(c, hipEventRecord(c->ev1, c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
-        h = *g->h_mail;
-        float ms = 0;
-        MSIM_HIP(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->t.plan_gpu_ms += ms;
-        if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) continue;   // rare: widen the windows and redo
-        c->t.py_words += h.pos - pos_start;
-        c->t.np_words += 2 * K;
-        py.pos = h.pos;
-        g->s[1].pos += 2 * K;                             // numpy.random.choice(size=k): 2 words per candidate
-        ct.planned = true;
-        return MSIM_OK;
+    if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
+    if (!g->unverified) MSIM_HIP(c, hipEventRecord(g->t0, c->stream));
+    if (!g->ps_valid) {
+        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)py.pos);
+        g->ps_valid = true;
     }
-    return fail(c, MSIM_ERR_HIP, "GPU sampler: stream window overflow persisted after 6 attempts");
+    uint64_t pos_hi = py.pos;                             // upper bound of the device position
+    uint64_t rec_base = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;
+        const uint32_t k = (uint32_t)r.k;
+        const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
+        const int bits = bit_length64(n);
+        const double p_acc = (double)n / (double)(1ull << bits);
+        // accepted draws needed ~ -n ln(1 - k/n) (coupon collector); window = that / p_acc, 16-sigma margins
+        const double need_acc = -(double)n * std::log1p(-(double)k / (double)n);
+        const double target = need_acc + 16.0 * std::sqrt(need_acc) + 4096.0;
+        const double wd = target / p_acc + 16.0 * std::sqrt(target) / p_acc + 8192.0;
+        if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
+        const uint32_t W = (uint32_t)wd;
+        SampleSet &S = g->sample[g->unit++ % N_SETS];
+        if (S.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, S.emit_done, 0));   // its last emit still reads it
+        const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
+        const size_t bm_words64 = (size_t)((n + 63) / 64);
+        const uint32_t bmw = (uint32_t)bm_words64;
+        const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
+        if ((rc = grow(c, (void **)&S.cnt, &S.cnt_cap, (size_t)(nb + 2) * sizeof(uint32_t), &grew))) return rc;
+        if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
+        if ((rc = grow(c, (void **)&S.acc, &S.acc_cap, (size_t)W * sizeof(uint32_t), &grew))) return rc;
+        if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, bm_words64 * 8, &grew))) return rc;
+        if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
+        if ((rc = ensure_words(c, g, 0, pos_hi + W + 1))) return rc;
+        // ---- chain (plan stream): where does this sample end?
+        MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
+        hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, S.cnt, g->d_ps);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
+        hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, S.cnt, S.acc);
+        hipLaunchKernelGGL(k_bitmap_insert, dim3((k + 1023) / 1024), dim3(256), 0, c->stream, S.acc, k, S.bitmap, g->d_ps);
+        hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, S.cnt, nb, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
+        MSIM_HIP(c, hipGetLastError());
+        hipEvent_t ce = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce, c->stream));
+        // ---- emit (emit stream): the bitmap is the sorted sample -> records
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+        hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                           reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, S.cnt2, bnb);
+        hipLaunchKernelGGL(k_bitmap_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                           reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
+                           ct.d_recs + rec_base);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
+        S.pending = true;
+        pos_hi += W;
+        rec_base += k;
+    }
+    if (K) {                                               // SNP draws of the whole contig, in position order
+        const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
+        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
+        const uint32_t W2 = (uint32_t)w2;
+        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
+        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
+        if (T.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, T.emit_done, 0));
+        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
+        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
+        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
+        if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
+        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps);
+        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2);
+        hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
+        MSIM_HIP(c, hipGetLastError());
+        hipEvent_t ce = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
+                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+        T.pending = true;
+        pos_hi += W2;
+    }
+    py.pos = pos_hi;                                       // bound until gpu_plan_finish reads the exact value
+    g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k): 2 words per candidate
+    c->t.np_words += 2 * K;
+    g->unverified = true;
+    ct.planned = true;
+    return MSIM_OK;
 }
 
 }  // namespace msim

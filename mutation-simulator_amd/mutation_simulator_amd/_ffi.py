@@ -160,7 +160,7 @@ class Engine:
         if rc == ERR_KEY:
             base = C.c_uint8()
             pos = C.c_uint64()
-            self.lib.msim_key_error(self.h, contig if contig is not None else 0, C.byref(base),
+            self.lib.msim_key_error(self.h, -1, C.byref(base),
                                     C.byref(pos))
             raise KeyError(chr(base.value))            # mutator.py:449-455
         if rc == ERR_UNSUPPORTED:
