@@ -166,7 +166,13 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
     c->devname = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    {   // the plan chain is the critical path of a step: give its stream the highest priority (and with it
+        // a hardware queue of its own), so its small kernels are dispatched ahead of the bulk work that
+        // runs beside it (jump cascade, chunk generation, record emission, rewrite)
+        int lo = 0, hi = 0;
+        if ((e = hipDeviceGetStreamPriorityRange(&lo, &hi)) != hipSuccess) return bail(e, "hipDeviceGetStreamPriorityRange");
+        if ((e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi)) != hipSuccess) return bail(e, "hipStreamCreate");
+    }
     if ((e = hipStreamCreateWithFlags(&c->emit_stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     hipEvent_t *evs[4] = {&c->ev0, &c->ev1, &c->ev2, &c->ev3};
     for (auto ev : evs)

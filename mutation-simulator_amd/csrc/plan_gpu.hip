@@ -261,13 +261,173 @@ __global__ __launch_bounds__(256) void k_bitmap_insert(const uint32_t *__restric
     if ((threadIdx.x & 63) == 0 && d) atomicAdd(&ps->dups, d);
 }
 
+// ---- locality-friendly de-dup: bins of 2^20 values, each de-duplicated in a 128 KB LDS bitmap ----
+constexpr int BIN_SHIFT = 20;
+constexpr int BIN_VALUES = 1 << BIN_SHIFT;
+constexpr int BIN_WORDS = BIN_VALUES / 32;               // 32768 x u32 = 128 KB
+constexpr int MAX_BINS = 1024;                           // n <= 2^30; larger ranges use the global-atomic path
+constexpr int BIN_SUBS = 16;                             // sub-cursors per bin: workgroup b fills sub-list b % 16,
+                                                         // so a cursor sees 1/16 of the same-address atomics
+constexpr int SPL_ITEMS = 32;
+constexpr int SPL_BLOCK = ACC_THREADS * SPL_ITEMS;       // 8192 stream words per workgroup (= 4 count blocks)
+constexpr int SPL_LDS = SPL_BLOCK + SPL_BLOCK / 32;
+
+// Ordered accept (as k_accept_scatter) but the first k accepted draws go to their value bin (order
+// inside a bin is irrelevant: only the SET of the first k matters), later ones to the ordered tail
+// list.  A workgroup stages its 8192 words through row-padded LDS (coalesced loads, conflict-free
+// per-lane runs), counting-sorts its accepted values by bin in LDS, reserves bin space with one
+// atomicAdd per non-empty bin and writes every bin's run out contiguously.
+__global__ __launch_bounds__(ACC_THREADS) void k_bin_scatter(const uint32_t *__restrict__ raw, const PlanState *ps,
+                                                             uint32_t W, uint32_t shift, uint32_t n, uint32_t k,
+                                                             const uint32_t *__restrict__ block_off, uint32_t n_bins,
+                                                             uint32_t bin_cap, uint32_t *__restrict__ cursors,
+                                                             uint32_t *__restrict__ bins, uint32_t *__restrict__ tail,
+                                                             PlanState *ps_rw) {
+    __shared__ uint32_t stage[SPL_LDS];
+    __shared__ uint32_t part[ACC_THREADS];
+    __shared__ uint32_t lhist[MAX_BINS];
+    __shared__ uint32_t lbase[MAX_BINS + 1];
+    __shared__ uint32_t gbase[MAX_BINS];
+    for (uint32_t b = threadIdx.x; b < n_bins; b += ACC_THREADS) lhist[b] = 0;
+    const unsigned long long p0 = ps->pos;
+    const uint32_t base = blockIdx.x * SPL_BLOCK;
+    {
+        uint32_t w[SPL_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SPL_ITEMS; r++) {
+            const uint32_t idx = r * ACC_THREADS + threadIdx.x;
+            w[r] = base + idx < W ? raw[p0 + base + idx] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < SPL_ITEMS; r++) {
+            const uint32_t idx = r * ACC_THREADS + threadIdx.x;
+            uint32_t v = 0xffffffffu;                    // rejected / out of window
+            if (base + idx < W) { v = mt_temper(w[r]) >> shift; if (v >= n) v = 0xffffffffu; }
+            stage[idx + (idx >> 5)] = v;
+        }
+    }
+    __syncthreads();
+    uint32_t vals[SPL_ITEMS];
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++) {
+        vals[q] = stage[threadIdx.x * 33 + q];
+        c += vals[q] != 0xffffffffu ? 1u : 0u;
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < ACC_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t a = block_off[blockIdx.x * (SPL_BLOCK / ACC_BLOCK)] + part[threadIdx.x] - c;   // accepted index
+    uint32_t slot[SPL_ITEMS];
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++) {
+        slot[q] = 0xffffffffu;
+        if (vals[q] != 0xffffffffu) {
+            if (a < k) slot[q] = atomicAdd(&lhist[vals[q] >> BIN_SHIFT], 1u);
+            else tail[a - k] = vals[q];
+            a++;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the local histogram (<= 1024 bins: 4 per lane) + global space reservation
+    {
+        uint32_t h[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            h[q] = b < n_bins ? lhist[b] : 0;
+            sum += h[q];
+        }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 1; o < ACC_THREADS; o <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            if (b < n_bins) {
+                lbase[b] = run;
+                gbase[b] = h[q] ? atomicAdd(&cursors[b * BIN_SUBS + (blockIdx.x & (BIN_SUBS - 1))], h[q]) : 0;
+            }
+            run += h[q];
+        }
+        if (threadIdx.x == ACC_THREADS - 1) lbase[MAX_BINS] = part[ACC_THREADS - 1];   // total placed
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++)
+        if (slot[q] != 0xffffffffu) stage[lbase[vals[q] >> BIN_SHIFT] + slot[q]] = vals[q];
+    __syncthreads();
+    const uint32_t total = lbase[MAX_BINS];
+    bool over = false;
+    for (uint32_t i = threadIdx.x; i < total; i += ACC_THREADS) {
+        const uint32_t v = stage[i];
+        const uint32_t b = v >> BIN_SHIFT;
+        const uint32_t at = gbase[b] + (i - lbase[b]);
+        if (at < bin_cap) bins[((size_t)b * BIN_SUBS + (blockIdx.x & (BIN_SUBS - 1))) * bin_cap + at] = v;
+        else over = true;
+    }
+    if (over) atomicOr(&ps_rw->flags, FLAG_SAMPLE_OVERFLOW);
+}
+
+// One workgroup per bin: LDS bitmap, LDS atomics, duplicate count, then the bitmap slice is written
+// out with coalesced 16-B stores (so the global bitmap needs no memset).
+__global__ __launch_bounds__(512) void k_bin_dedupe(const uint32_t *__restrict__ bins, const uint32_t *__restrict__ cursors,
+                                                    uint32_t bin_cap, uint32_t *__restrict__ bitmap,
+                                                    PlanState *__restrict__ ps) {
+    __shared__ __attribute__((aligned(16))) uint32_t lbm[BIN_WORDS];
+    __shared__ uint32_t red[8];
+    const uint32_t b = blockIdx.x;
+    uint4 *l4 = reinterpret_cast<uint4 *>(lbm);
+    for (int i = threadIdx.x; i < BIN_WORDS / 4; i += 512) l4[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    uint32_t d = 0;
+    for (int sub = 0; sub < BIN_SUBS; sub++) {
+        const uint32_t cnt = min(cursors[b * BIN_SUBS + sub], bin_cap);
+        const uint32_t *mine = bins + ((size_t)b * BIN_SUBS + sub) * bin_cap;
+        for (uint32_t i = threadIdx.x; i < cnt; i += 512) {
+            const uint32_t v = mine[i] & (BIN_VALUES - 1);
+            const uint32_t bit = 1u << (v & 31);
+            const uint32_t old = atomicOr(&lbm[v >> 5], bit);
+            d += (old & bit) ? 1u : 0u;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 8; w++) t += red[w];
+        if (t) atomicAdd(&ps->dups, t);
+    }
+    uint4 *g4 = reinterpret_cast<uint4 *>(bitmap + (size_t)b * BIN_WORDS);
+    for (int i = threadIdx.x; i < BIN_WORDS / 4; i += 512) g4[i] = l4[i];
+}
+
 // Tail rounds + exact cut.  One workgroup.  `total_acc` = accepted draws available in the window.
+// `acc` holds the accepted draws from accepted-index `acc_first` on (0: the whole list, k: tail only).
+constexpr int TAIL_LDS_OFFS = 8192;
 __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict__ raw, const uint32_t *__restrict__ acc,
+                                                      uint32_t acc_first,
                                                       const uint32_t *__restrict__ block_off, uint32_t n_blocks,
                                                       uint32_t W, uint32_t shift, uint32_t n, uint32_t k,
                                                       uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps) {
     __shared__ uint32_t red[16];
     __shared__ uint32_t s_need, s_pos, s_blk;
+    __shared__ uint32_t loff[TAIL_LDS_OFFS + 1];
+    const bool offs_in_lds = n_blocks <= TAIL_LDS_OFFS;
+    if (offs_in_lds)
+        for (uint32_t i = threadIdx.x; i <= n_blocks; i += 1024) loff[i] = block_off[i];
     const uint32_t total_acc = block_off[n_blocks];
     if (threadIdx.x == 0) { s_pos = k; s_need = ps->dups; }
     __syncthreads();
@@ -284,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
         }
         uint32_t d = 0;
         for (uint32_t i = threadIdx.x; i < need; i += 1024) {
-            const uint32_t v = acc[pos + i];
+            const uint32_t v = acc[pos - acc_first + i];
             const uint32_t bit = 1u << (v & 31);
             const uint32_t old = atomicOr(&bitmap[v >> 5], bit);
             if (old & bit) d++;
@@ -307,13 +467,13 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
         uint32_t lo = 0, hi = n_blocks;                   // last block with block_off[b] < A
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (block_off[mid] < A) lo = mid; else hi = mid;
+            if ((offs_in_lds ? loff[mid] : block_off[mid]) < A) lo = mid; else hi = mid;
         }
         s_blk = lo;
     }
     __syncthreads();
     const uint32_t b = s_blk;
-    const uint32_t want = A - block_off[b];               // 1-based rank inside block b
+    const uint32_t want = A - (offs_in_lds ? loff[b] : block_off[b]);   // 1-based rank inside block b
     const unsigned long long p0 = ps->pos;
     // 1024 threads x 2 words cover the block's 2048 words in stream order
     uint32_t f[2], v;
@@ -466,11 +626,16 @@ constexpr int SNP_LDS_WORDS = SNP_BLOCK2 + SNP_BLOCK2 / 32 + 1;
 // lane's 32 consecutive words are conflict-free; then each lane builds its masks.
 __device__ __forceinline__ SnpBits snp_stage(const uint32_t *__restrict__ raw, unsigned long long p0, uint32_t base,
                                              uint32_t W, unsigned long long ti_lim, uint32_t *sw) {
+    uint32_t w[SNP_ITEMS2];
+#pragma unroll
+    for (int r = 0; r < SNP_ITEMS2; r++) {               // all 32 loads in flight before the first use
+        const uint32_t idx = r * SNP_THREADS + threadIdx.x;
+        w[r] = base + idx < W ? raw[p0 + base + idx] : 0u;
+    }
+#pragma unroll
     for (int r = 0; r < SNP_ITEMS2; r++) {
         const uint32_t idx = r * SNP_THREADS + threadIdx.x;
-        uint32_t w = 0;
-        if (base + idx < W) w = mt_temper(raw[p0 + base + idx]);
-        sw[idx + (idx >> 5)] = w;
+        sw[idx + (idx >> 5)] = base + idx < W ? mt_temper(w[r]) : 0u;
     }
     if (threadIdx.x == 0) sw[SNP_LDS_WORDS - 1] = base > 0 ? mt_temper(raw[p0 + base - 1]) : 0;
     __syncthreads();
@@ -532,7 +697,7 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_reduce(const uint32_t *__re
 
 // sequential-in-chunks scan of the workgroup maps; afterwards block_maps[b] = (state, count) at the
 // start of block b when the stream starts in state 0: c[0] = count, e = state
-__global__ __launch_bounds__(1024) void k_snp_scan(SnpMap *__restrict__ block_maps, uint32_t nb) {
+__global__ __launch_bounds__(1024) void k_snp_scan(SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K) {
     __shared__ SnpMap buf[1024];
     __shared__ uint32_t c_state, c_count;
     if (threadIdx.x == 0) { c_state = 0; c_count = 0; }
@@ -562,6 +727,9 @@ __global__ __launch_bounds__(1024) void k_snp_scan(SnpMap *__restrict__ block_ma
             r.c[1] = r.c[2] = 0;
             r.e = (ex.e >> (2 * s0)) & 3;
             block_maps[i] = r;
+            // the workgroup in which the K-th SNP completes: count-before < K <= count-after
+            const uint32_t after = n0 + buf[threadIdx.x].c[s0];
+            if (r.c[0] < K && K <= after) block_maps[nb].c[1] = i;
         }
         if (threadIdx.x == 0) {
             c_count = n0 + last.c[s0];
@@ -569,10 +737,9 @@ __global__ __launch_bounds__(1024) void k_snp_scan(SnpMap *__restrict__ block_ma
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {                               // totals after the whole window
-        SnpMap r;
-        r.c[0] = c_count; r.c[1] = r.c[2] = 0; r.e = c_state;
-        block_maps[nb] = r;
+    if (threadIdx.x == 0) {                               // totals after the whole window (c[1] set above)
+        block_maps[nb].c[0] = c_count;
+        block_maps[nb].e = c_state;
     }
 }
 
@@ -590,14 +757,7 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_cut(const uint32_t *__restr
     if (threadIdx.x == 0) {
         *base_out = p0;
         if (block_maps[nb].c[0] < K) { ps->flags |= FLAG_SNP_OVERFLOW; s_blk = 0xffffffffu; }
-        else {
-            uint32_t lo = 0, hi = nb;                     // last block whose count-before is < K
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (block_maps[mid].c[0] < K) lo = mid; else hi = mid;
-            }
-            s_blk = lo;
-        }
+        else s_blk = block_maps[nb].c[1];                 // found by k_snp_scan
     }
     __syncthreads();
     const uint32_t b = s_blk;
@@ -676,6 +836,8 @@ struct SampleSet {                       // scratch of one sampled range
     uint32_t *cnt = nullptr; size_t cnt_cap = 0;          // per-workgroup accept counts / offsets
     uint32_t *bitmap = nullptr; size_t bm_cap = 0;        // n-bit de-dup bitmap (bytes)
     uint32_t *cnt2 = nullptr; size_t cnt2_cap = 0;        // per-workgroup popcounts / ranks
+    uint32_t *bins = nullptr; size_t bins_cap = 0;        // first-k draws grouped by value bin
+    uint32_t *cursors = nullptr; size_t cursors_cap = 0;  // per-bin fill counters
     hipEvent_t emit_done = nullptr;
     bool pending = false;
 };
@@ -738,6 +900,8 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (t.cnt) (void)hipFree(t.cnt);
         if (t.bitmap) (void)hipFree(t.bitmap);
         if (t.cnt2) (void)hipFree(t.cnt2);
+        if (t.bins) (void)hipFree(t.bins);
+        if (t.cursors) (void)hipFree(t.cursors);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
     for (auto &t : g->snp) {
@@ -775,8 +939,9 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
         // then serialise): the cascade must not queue behind a 300 us generation batch
         int lo = 0, hi = 0;
         MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        MSIM_HIP(c, hipStreamCreateWithPriority(&g->gen_stream, hipStreamNonBlocking, lo));
-        MSIM_HIP(c, hipStreamCreateWithPriority(&g->jump_stream, hipStreamNonBlocking, hi));
+        (void)lo; (void)hi;
+        MSIM_HIP(c, hipStreamCreateWithFlags(&g->gen_stream, hipStreamNonBlocking));
+        MSIM_HIP(c, hipStreamCreateWithFlags(&g->jump_stream, hipStreamNonBlocking));
     }
     const uint64_t have = MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS;
     if (upto > have) {
@@ -1049,15 +1214,39 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
         if ((rc = ensure_words(c, g, 0, pos_hi + W + 1))) return rc;
         // ---- chain (plan stream): where does this sample end?
-        MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
+        const uint32_t n_bins = (uint32_t)((n + BIN_VALUES - 1) >> BIN_SHIFT);
+        const bool binned = n_bins <= (uint32_t)MAX_BINS;
         hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
                            (uint32_t)(32 - bits), (uint32_t)n, S.cnt, g->d_ps);
         hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
-        hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                           (uint32_t)(32 - bits), (uint32_t)n, S.cnt, S.acc);
-        hipLaunchKernelGGL(k_bitmap_insert, dim3((k + 1023) / 1024), dim3(256), 0, c->stream, S.acc, k, S.bitmap, g->d_ps);
-        hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, S.cnt, nb, W,
-                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
+        if (binned) {
+            // expected k/n_bins per bin (the last bin is partial), 16-sigma + slack capacity
+            // sub-list s of a bin is filled by the scatter workgroups with index == s (mod 16).  Only the
+            // workgroups up to the one holding the k-th accepted draw contribute (the window has slack
+            // behind it), each at most 8192 * p_acc draws, of which the bin's share is min(1, 2^20 / n).
+            const uint32_t nbk = (uint32_t)((double)k / p_acc / SPL_BLOCK) + 3;
+            const double mean = (double)((nbk + BIN_SUBS - 1) / BIN_SUBS) * SPL_BLOCK * p_acc *
+                                std::min(1.0, (double)BIN_VALUES / (double)n);
+            const uint32_t bin_cap = (uint32_t)std::min<double>((double)k + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
+            if ((rc = grow(c, (void **)&S.bins, &S.bins_cap, (size_t)n_bins * BIN_SUBS * bin_cap * sizeof(uint32_t), &grew))) return rc;
+            if ((rc = grow(c, (void **)&S.cursors, &S.cursors_cap, (size_t)MAX_BINS * BIN_SUBS * sizeof(uint32_t), &grew))) return rc;
+            if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, (size_t)n_bins * BIN_WORDS * 4, &grew))) return rc;
+            MSIM_HIP(c, hipMemsetAsync(S.cursors, 0, (size_t)n_bins * BIN_SUBS * sizeof(uint32_t), c->stream));
+            hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                               (uint32_t)(32 - bits), (uint32_t)n, k, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc,
+                               g->d_ps);
+            hipLaunchKernelGGL(k_bin_dedupe, dim3(n_bins), dim3(512), 0, c->stream, S.bins, S.cursors, bin_cap, S.bitmap,
+                               g->d_ps);
+            hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, k, S.cnt, nb, W,
+                               (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
+        } else {
+            MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
+            hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                               (uint32_t)(32 - bits), (uint32_t)n, S.cnt, S.acc);
+            hipLaunchKernelGGL(k_bitmap_insert, dim3((k + 1023) / 1024), dim3(256), 0, c->stream, S.acc, k, S.bitmap, g->d_ps);
+            hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, 0u, S.cnt, nb, W,
+                               (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
+        }
         MSIM_HIP(c, hipGetLastError());
         hipEvent_t ce = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(ce, c->stream));
@@ -1088,7 +1277,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
         hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2);
+        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2, (uint32_t)K);
         hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
         MSIM_HIP(c, hipGetLastError());
