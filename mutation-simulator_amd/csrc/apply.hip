@@ -188,10 +188,29 @@ __device__ __forceinline__ void set_byte(u32x4 &v, uint32_t idx, uint32_t b) {
     v.w = wi == 3 ? (v.w & m) | x : v.w;
 }
 
+// How a record shapes the output stream: at most ONE special segment [o, e) followed by a plain copy
+// run out[e + t] = in[s + t] that lasts until the next record's o.
+//   SN : no segment (e = o), run continues at in[pos]; the byte at o is patched      mutator.py:334-341
+//   IN : segment = insert pool bytes, run continues at in[pos]                       mutator.py:343-358
+//   DE : no segment, run continues at in[stop + 1]                                   mutator.py:360-377
+//   IV : segment = reverse complement of in[pos..stop], run continues at in[stop+1]  mutator.py:379-387
+//   DU : segment = in[pos..stop] (first copy); the second copy simply IS the run, which restarts at
+//        in[pos]                                                                      mutator.py:389-399
+__device__ __forceinline__ void rec_view(const msim_record &r, uint32_t o, uint32_t &e, uint32_t &s) {
+    const uint32_t len = r.stop - r.pos + 1;
+    switch (r.type) {
+        case MSIM_IN: e = o + len; s = r.pos; break;
+        case MSIM_DE: e = o; s = r.stop + 1; break;
+        case MSIM_IV: e = o + len; s = r.stop + 1; break;
+        case MSIM_DU: e = o + len; s = r.pos; break;
+        default: e = o; s = r.pos; break;                 // SN
+    }
+}
+
 struct RecWin {                 // the tile's record window in LDS
-    uint32_t o[REC_CAP];        // output offset of the record's own bytes
-    uint32_t e[REC_CAP];        // end of the record's own bytes (o + outlen)
-    uint32_t s[REC_CAP];        // input position where the copy run after the record starts
+    uint32_t o[REC_CAP];        // output offset of the record's segment
+    uint32_t e[REC_CAP];        // end of the segment
+    uint32_t s[REC_CAP];        // input position where the copy run after the segment starts
     uint32_t m[REC_CAP];        // type | aux << 8
 };
 
@@ -210,9 +229,9 @@ struct RecAccess {
             o = win->o[q]; e = win->e[q]; s = win->s[q]; m = win->m[q];
         } else {
             const msim_record r = recs[j];
-            uint32_t ol, il;
-            rec_lengths(r, ol, il);
-            o = off ? off[j] : r.pos; e = o + ol; s = r.pos + il; m = (uint32_t)r.type | ((uint32_t)r.aux << 8);
+            o = off ? off[j] : r.pos;
+            rec_view(r, o, e, s);
+            m = (uint32_t)r.type | ((uint32_t)r.aux << 8);
         }
     }
 };
@@ -221,28 +240,31 @@ __device__ __forceinline__ void report_key_error(unsigned long long *err, uint64
     atomicMin(err, (unsigned long long)((pos << 8) | conv_base));
 }
 
-// byte-exact slow path: output byte at absolute offset P, governed by record j (or none if j < 0)
-__device__ __forceinline__ uint32_t slow_byte(uint64_t P, int32_t j, uint32_t o, uint32_t e, uint32_t s,
-                                              const uint8_t *__restrict__ in, const uint8_t *__restrict__ pool,
-                                              const msim_record *__restrict__ recs, const uint8_t *lut,
-                                              unsigned long long *err) {
-    if (j < 0) return in[P];
-    if (P >= e) return in[(uint64_t)s + (P - e)];
-    const msim_record r = recs[j];
-    const uint32_t t = (uint32_t)(P - o);
-    const uint32_t len = r.stop - r.pos + 1;
-    switch (r.type) {
-        case MSIM_SN: {
-            const uint32_t x = in[r.pos];
-            const uint32_t nb = lut[(uint32_t)r.aux * 256 + x];
-            if (nb == 0 && r.aux != 0) { report_key_error(err, r.pos, lut[768 + x]); return x; }
-            return nb;
-        }
-        case MSIM_IN: return t < len ? pool[(uint64_t)r.extra + t] : in[r.pos];
-        case MSIM_IV: return lut[1024 + in[(uint64_t)r.stop - t]];
-        case MSIM_DU: return in[(uint64_t)r.pos + (t < len ? t : t - len)];
-        default: return 0;
+// bytes [lo, hi) of pv replace those of v (0 <= lo < hi <= 16)
+__device__ __forceinline__ void merge_bytes(u32x4 &v, const u32x4 &pv, uint32_t lo, uint32_t hi) {
+    if (lo == 0 && hi == 16) { v = pv; return; }
+    uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+    const uint32_t pp[4] = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int l = max(0, min(4, (int)lo - 4 * d)), h = max(0, min(4, (int)hi - 4 * d));
+        const uint32_t mh = h >= 4 ? 0xffffffffu : ((1u << (8 * h)) - 1u);
+        const uint32_t ml = l >= 4 ? 0xffffffffu : ((1u << (8 * l)) - 1u);
+        const uint32_t m = mh & ~ml;
+        vv[d] = (vv[d] & ~m) | (pp[d] & m);
     }
+    v.x = vv[0]; v.y = vv[1]; v.z = vv[2]; v.w = vv[3];
+}
+
+// complement(convert(x)) of four bases at once.  A/C/G/T have distinct (x >> 1) & 3 codes (0,1,3,2):
+// v_perm_b32 turns codes back into letters (check: all four bytes plain ACGT) or into complements;
+// anything else (N, IUPAC, U ...) takes the 256-entry LDS table of mutator.py:75-76.
+__device__ __forceinline__ uint32_t revcomp4(uint32_t x, const uint8_t *lut) {
+    const uint32_t codes = (x >> 1) & 0x03030303u;
+    if (__builtin_amdgcn_perm(0u, 0x47544341u, codes) == x)            // "ACTG"[code] == byte ?
+        return __builtin_amdgcn_perm(0u, 0x43414754u, codes);          // "TGAC"[code]
+    return (uint32_t)lut[1024 + (x & 0xff)] | ((uint32_t)lut[1024 + ((x >> 8) & 0xff)] << 8) |
+           ((uint32_t)lut[1024 + ((x >> 16) & 0xff)] << 16) | ((uint32_t)lut[1024 + (x >> 24)] << 24);
 }
 
 template <bool IN_LDS>
@@ -256,74 +278,68 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
     for (int it = 0; it < ITERS; it++) {
         const uint64_t O = tile0 + (uint64_t)it * (THREADS * GROUP) + (uint64_t)threadIdx.x * GROUP;
         if (O >= L_out) continue;
-        // b = last record in [r_lo, r_hi] with o <= O, or r_lo-1
-        int32_t b = r_lo - 1;
+        // j = last record in [r_lo, r_hi] with o <= O (none: has = false)
+        int32_t j = r_lo - 1;
         if (any_rec) {
             int32_t lo = r_lo, hi = r_hi + 1;
             while (lo < hi) {
                 const int32_t mid = (lo + hi) >> 1;
                 if ((uint64_t)A.O(mid) <= O) lo = mid + 1; else hi = mid;
             }
-            b = lo - 1;
+            j = lo - 1;
         }
-        const bool has_b = any_rec && b >= r_lo;
-        uint32_t ob = 0, eb = 0, sb = 0, mb = 0;
-        if (has_b) A.all(b, ob, eb, sb, mb);
-        const int64_t shift = has_b ? (int64_t)sb - (int64_t)eb : 0;      // input = output + shift
-        const int32_t nxt = has_b ? b + 1 : r_lo;
-        const uint64_t next_o = (any_rec && nxt <= r_hi) ? (uint64_t)A.O(nxt) : ~0ull;
-        const bool clear_of_b = !has_b || O >= (uint64_t)eb;
-        u32x4 v;
-        if (clear_of_b && next_o >= O + GROUP) {
-            v = load16_shifted(in, (uint64_t)((int64_t)O + shift));       // pure copy run
-        } else {
-            // does the group only meet SNPs?  (they keep the shift; patch in registers)
-            bool only_sn = clear_of_b || (mb & 0xff) == MSIM_SN;
-            int32_t j = clear_of_b ? nxt : b;
-            const int32_t j0 = j;
-            if (only_sn) {
-                for (int32_t q = nxt; q <= r_hi; q++) {
-                    uint32_t o, e, s, m;
-                    A.all(q, o, e, s, m);
-                    if ((uint64_t)o >= O + GROUP) break;
-                    if ((m & 0xff) != MSIM_SN) { only_sn = false; break; }
+        bool has = any_rec && j >= r_lo;
+        uint32_t oj = 0, ej = 0, sj = 0, mj = 0;
+        if (has) A.all(j, oj, ej, sj, mj);
+        int32_t jn = has ? j + 1 : r_lo;
+        uint64_t next_o = (any_rec && jn <= r_hi) ? (uint64_t)A.O(jn) : ~0ull;
+        const uint64_t gend = O + GROUP;
+        u32x4 v = u32x4{0, 0, 0, 0};
+        uint64_t cur = O;
+        while (true) {
+            uint64_t pend;
+            if (has && cur < (uint64_t)ej) {                 // inside record j's segment
+                pend = min((uint64_t)ej, gend);
+                const int64_t rel = (int64_t)O - (int64_t)oj;    // segment offset of the group's first byte
+                const uint32_t type = mj & 0xff;
+                u32x4 pv;
+                if (type == MSIM_DU) {
+                    pv = load16_shifted(in, (uint64_t)((int64_t)sj + rel));
+                } else if (type == MSIM_IN) {
+                    pv = load16_shifted(pool, (uint64_t)((int64_t)recs[j].extra + rel));
+                } else {                                     // MSIM_IV: out[P] = rc(in[stop - (P - o)])
+                    const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)sj - 1 - rel - 15));
+                    pv.x = revcomp4(__builtin_bswap32(w.w), lut);
+                    pv.y = revcomp4(__builtin_bswap32(w.z), lut);
+                    pv.z = revcomp4(__builtin_bswap32(w.y), lut);
+                    pv.w = revcomp4(__builtin_bswap32(w.x), lut);
+                }
+                merge_bytes(v, pv, (uint32_t)(cur - O), (uint32_t)(pend - O));
+            } else {                                         // copy run after record j (or before the first)
+                pend = min(next_o, gend);
+                if (pend > cur) {
+                    const int64_t src = has ? (int64_t)sj + ((int64_t)O - (int64_t)ej) : (int64_t)O;
+                    u32x4 pv = load16_shifted(in, (uint64_t)src);
+                    if (has && (mj & 0xff) == MSIM_SN && (uint64_t)oj == cur) {   // the run starts on the SNP byte
+                        const uint32_t idx = (uint32_t)(cur - O);
+                        const uint32_t x = get_byte(pv, idx);
+                        const uint32_t nb = lut[(mj >> 8) * 256 + x];
+                        if (nb == 0 && (mj >> 8) != 0) report_key_error(err, (uint64_t)sj, lut[768 + x]);
+                        else set_byte(pv, idx, nb);
+                    }
+                    merge_bytes(v, pv, (uint32_t)(cur - O), (uint32_t)(pend - O));
                 }
             }
-            if (only_sn) {
-                v = load16_shifted(in, (uint64_t)((int64_t)O + shift));
-                for (int32_t q = j0; q <= r_hi; q++) {
-                    uint32_t o, e, s, m;
-                    A.all(q, o, e, s, m);
-                    if ((uint64_t)o >= O + GROUP) break;
-                    const uint32_t idx = (uint32_t)((uint64_t)o - O);
-                    const uint32_t x = get_byte(v, idx);
-                    const uint32_t nb = lut[(m >> 8) * 256 + x];
-                    if (nb == 0 && (m >> 8) != 0) report_key_error(err, (uint64_t)s - 1, lut[768 + x]);
-                    else set_byte(v, idx, nb);
+            cur = pend;
+            if (cur >= gend) break;
+            if (!(has && cur < (uint64_t)ej)) {              // segment (if any) finished and the run hit the next record
+                if (cur >= next_o) {
+                    j = jn;
+                    has = true;
+                    A.all(j, oj, ej, sj, mj);
+                    jn = j + 1;
+                    next_o = jn <= r_hi ? (uint64_t)A.O(jn) : ~0ull;
                 }
-            } else {
-                // general: walk the records byte by byte (monotone record cursor)
-                uint32_t w[4] = {0, 0, 0, 0};
-                int32_t cj = has_b ? b : -1;
-                uint32_t co = ob, ce = eb, cs = sb, cm = mb;
-                uint64_t cnext = next_o;
-                int32_t cn = nxt;
-#pragma unroll
-                for (int bi = 0; bi < GROUP; bi++) {
-                    const uint64_t P = O + bi;
-                    uint32_t byte = 0;
-                    if (P < L_out) {
-                        while (cnext <= P) {                       // advance to the last record with o <= P
-                            cj = cn;
-                            A.all(cj, co, ce, cs, cm);
-                            cn = cj + 1;
-                            cnext = cn <= r_hi ? (uint64_t)A.O(cn) : ~0ull;
-                        }
-                        byte = slow_byte(P, cj, co, ce, cs, in, pool, recs, lut, err);
-                    }
-                    w[bi >> 2] |= byte << ((bi & 3) * 8);
-                }
-                v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
             }
         }
         *reinterpret_cast<u32x4 *>(out + O) = v;
@@ -352,12 +368,12 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
     if (in_lds) {
         for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
             const msim_record r = recs[r_lo + q];
-            uint32_t ol, il;
-            rec_lengths(r, ol, il);
             const uint32_t o = off ? off[r_lo + q] : r.pos;
+            uint32_t e, s;
+            rec_view(r, o, e, s);
             win.o[q] = o;
-            win.e[q] = o + ol;
-            win.s[q] = r.pos + il;
+            win.e[q] = e;
+            win.s[q] = s;
             win.m[q] = (uint32_t)r.type | ((uint32_t)r.aux << 8);
         }
     }
@@ -625,11 +641,11 @@ int apply_contig_device(Ctx *c, Contig &g) {
     MSIM_HIP(c, hipEventRecord(g.ea1, st));
     if (n_tiles) {
         if (g.all_snp)
-            hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in, g.d_out, g.d_recs,
+            hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
                                d_first, n, g.out_len, ctx_lut(c), d_err);
         else
-            hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in, g.d_out, g.d_recs,
-                               d_off, d_first, n, g.out_len, g.d_pool, ctx_lut(c), d_err);
+            hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
+                               d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err);
         MSIM_HIP(c, hipGetLastError());
     }
     MSIM_HIP(c, hipEventRecord(g.ea2, st));

@@ -13,14 +13,14 @@ namespace msim {
 
 struct Contig {
     uint64_t len = 0;
-    uint8_t *d_in = nullptr;          // input bases (uint8, upper-cased), padded by PAD bytes
+    uint8_t *d_in = nullptr;          // allocation; the bases (uint8, upper-cased) start at d_in + PAD
     // plan result
     bool planned = false;
     bool plan_empty = true;
     bool all_snp = false;             // record table holds SNPs only: no length change, offset == pos
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
-    uint8_t *d_pool = nullptr;        // insert bases
+    uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD
     size_t cap_recs = 0, cap_pool = 0, cap_out = 0, cap_off = 0;   // bytes kept allocated across plans
     // apply result
     bool applied = false;

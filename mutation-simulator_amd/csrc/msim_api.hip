@@ -108,8 +108,10 @@ static int new_contig(Ctx *c, uint64_t len, Contig **out) {
     g.len = len;
     g.index = (int)c->contigs.size();
     if (!c->host_only) {
-        MSIM_HIP(c, hipMalloc(&g.d_in, len + PAD));
-        MSIM_HIP(c, hipMemsetAsync(g.d_in + len, 0, PAD, c->stream));
+        // PAD bytes of zero slack on BOTH sides: shifted 16-B reads may start before / end after the data
+        MSIM_HIP(c, hipMalloc(&g.d_in, len + 2 * PAD));
+        MSIM_HIP(c, hipMemsetAsync(g.d_in, 0, PAD, c->stream));
+        MSIM_HIP(c, hipMemsetAsync(g.d_in + PAD + len, 0, PAD, c->stream));
     }
     c->contigs.push_back(g);
     *out = &c->contigs.back();
@@ -289,7 +291,7 @@ int msim_add_contig(msim_ctx *p, const uint8_t *bases, uint64_t len, int *contig
     int rc = new_contig(c, len, &g);
     if (rc) return rc;
     if (!c->host_only) {
-        if (len) MSIM_HIP(c, hipMemcpyAsync(g->d_in, bases, len, hipMemcpyHostToDevice, c->stream));
+        if (len) MSIM_HIP(c, hipMemcpyAsync(g->d_in + PAD, bases, len, hipMemcpyHostToDevice, c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
     }
     *contig = (int)c->contigs.size() - 1;
@@ -303,7 +305,7 @@ int msim_add_contig_synthetic(msim_ctx *p, uint64_t len, uint64_t seed, int *con
     Contig *g;
     int rc = new_contig(c, len, &g);
     if (rc) return rc;
-    rc = synth_contig_device(c, g->d_in, len, seed);
+    rc = synth_contig_device(c, g->d_in + PAD, len, seed);
     if (rc) return rc;
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
     *contig = (int)c->contigs.size() - 1;
@@ -326,7 +328,7 @@ int msim_read_contig(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (offset > g->len || n > g->len - offset) return fail(c, MSIM_ERR_ARG, "read beyond contig end");
-    if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_in + offset, n, hipMemcpyDeviceToHost, c->stream));
+    if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_in + PAD + offset, n, hipMemcpyDeviceToHost, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
     return MSIM_OK;
 }
@@ -400,10 +402,10 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
         if (rc) return rc;
         MSIM_HIP(c, hipMemcpyAsync(g->d_recs, hp.recs.data(), g->n_rec * sizeof(msim_record), hipMemcpyHostToDevice, c->stream));
     }
-    rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + PAD);
+    rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + 2 * PAD);
     if (rc) return rc;
     if (g->pool_len)
-        MSIM_HIP(c, hipMemcpyAsync(g->d_pool, hp.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
+        MSIM_HIP(c, hipMemcpyAsync(g->d_pool + PAD, hp.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
     c->t.upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     g->planned = true;
@@ -500,7 +502,7 @@ int msim_fetch_records(msim_ctx *p, int contig, msim_record *dst, uint8_t *pool_
     if (dst && g->n_rec)
         MSIM_HIP(c, hipMemcpyAsync(dst, g->d_recs, g->n_rec * sizeof(msim_record), hipMemcpyDeviceToHost, c->stream));
     if (pool_dst && g->pool_len)
-        MSIM_HIP(c, hipMemcpyAsync(pool_dst, g->d_pool, g->pool_len, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipMemcpyAsync(pool_dst, g->d_pool + PAD, g->pool_len, hipMemcpyDeviceToHost, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
     return MSIM_OK;
 }

@@ -1166,12 +1166,12 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     bool grew = false;
     {   // the record table may still be read by an earlier apply of this contig
         const size_t want = std::max<uint64_t>(K, 1) * sizeof(msim_record);
-        if (ct.cap_recs < want || ct.cap_pool < PAD) {
+        if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
             MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
         }
         if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
-        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, PAD))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
     }
     ct.n_rec = K;
     ct.pool_len = 0;
