@@ -164,8 +164,9 @@ __device__ __forceinline__ u32x4 load16_shifted(const uint8_t *__restrict__ in, 
     // shift per output dword (v_alignbyte_b32).
     const uint64_t a = src & ~3ull;
     const uint32_t sh = (uint32_t)(src & 3ull);
-    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4 *>(in + a);
-    const uint32_t w4 = *reinterpret_cast<const uint32_t *>(in + a + 16);
+    // streamed once: nontemporal (keeps L2 / MALL for the record tables)
+    const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(in + a));
+    const uint32_t w4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(in + a + 16));
     u32x4 r;
     r.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
     r.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
@@ -342,7 +343,7 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
                 }
             }
         }
-        *reinterpret_cast<u32x4 *>(out + O) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + O));
     }
 }
 
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restri
     for (int it = 0; it < ITERS; it++) {
         const uint32_t o = it * (THREADS * GROUP) + threadIdx.x * GROUP;
         v[it] = u32x4{0, 0, 0, 0};
-        if (tile0 + o < L) v[it] = *reinterpret_cast<const u32x4 *>(in + tile0 + o);
+        if (tile0 + o < L) v[it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(in + tile0 + o));
     }
     reinterpret_cast<uint32_t *>(lut)[threadIdx.x] = reinterpret_cast<const uint32_t *>(lut_g)[threadIdx.x];
 #pragma unroll
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restri
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const uint32_t o = it * (THREADS * GROUP) + threadIdx.x * GROUP;
-        if (tile0 + o < L) *reinterpret_cast<u32x4 *>(out + tile0 + o) = *reinterpret_cast<const u32x4 *>(tile + o);
+        if (tile0 + o < L)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(tile + o), reinterpret_cast<u32x4 *>(out + tile0 + o));
     }
 }
 
