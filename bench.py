@@ -170,6 +170,13 @@ def main():
         alg_bytes = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
         k_ms = st["apply_kernel_ms"]
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes, if present
+        tf = ROOT / "profiles" / "r01_traffic.json"
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text())["traffic_bytes_per_launch"]
+            except Exception:  # noqa: BLE001
+                traffic = None
         line = {
             "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01",
             "value": round(value, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
@@ -187,7 +194,7 @@ def main():
                 "apply_rewrite_kernel": round(k_ms / a.steps, 3)},
             "records_per_step": st["records"] // a.steps,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "msim::k_rewrite_snp (SNP-only tables; msim::k_rewrite for SV mixes)",
                          "algorithmic_bytes_per_launch": alg_bytes // launches,
                          "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
