@@ -111,13 +111,17 @@ def main():
     ap.add_argument("--total-bases", type=int, default=3_000_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="also gather every mutated contig to rank 0 over RCCL inside the timed step")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
+        # launched by torch.distributed.run: one rank per GPU, rendezvous over RCCL (backend "nccl").
+        # torch is imported BEFORE libmsim so both share one HIP runtime (tools/share_hip_runtime.py).
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -146,13 +150,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    def step():
         one_step(eng, sim, cids, mine)
+        if a.gather:
+            import torch
+            from mutation_simulator_amd.gather import gather_to_root
+            got = gather_to_root(eng, cids, parts, lengths, rank, world, torch.device("cuda", local_rank))
+            torch.cuda.synchronize()
+            del got
+
+    if a.gather:
+        import torch
+        torch.cuda.set_device(local_rank)
+    for _ in range(a.warmup):
+        step()
     eng.reset_stats()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        one_step(eng, sim, cids, mine)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -185,7 +201,8 @@ def main():
             "config": {"workload": "ARGS mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
                                    "-sn 0.01 -titv 2.0, CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
-                       "parallelism": f"contigs sharded over {world} GPU(s) (LPT), PLAN replicated"},
+                       "parallelism": f"contigs sharded over {world} GPU(s) (LPT), PLAN replicated"
+                                      + (", RCCL gather to rank 0 included" if a.gather else ", results left in HBM")},
             "stages_ms_per_step": {
                 "plan_host": round(st["plan_host_ms"] / a.steps, 3),
                 "plan_gpu": round(st["plan_gpu_ms"] / a.steps, 3),

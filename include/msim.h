@@ -164,6 +164,10 @@ int msim_fetch_records(msim_ctx *ctx, int contig, msim_record *dst, uint8_t *ins
 /* 64-bit FNV-style checksum of the mutated stream computed on the device (parity at full size).   */
 int msim_result_checksum(msim_ctx *ctx, int contig, uint64_t *sum);
 int msim_release_result(msim_ctx *ctx, int contig);
+/* Device address of the mutated stream (valid until the contig is re-applied / released / cleared), for
+ * communication layers that move results GPU-to-GPU (RCCL gather of sharded contigs).
+ * Synchronises like msim_fetch_sequence.                                                            */
+int msim_result_device_ptr(msim_ctx *ctx, int contig, uint64_t *device_address, uint64_t *len);
 
 /* ---- VCF text (vcf_writer.py:118-126 + record construction mutator.py:334-399) ------------------ */
 /* Render the record lines of one contig.  Stateless host helper: `bases` is the INPUT contig.

@@ -521,6 +521,21 @@ int msim_result_checksum(msim_ctx *p, int contig, uint64_t *sum) {
     return checksum_device(c, g->d_out, g->out_len, sum);
 }
 
+int msim_result_device_ptr(msim_ctx *p, int contig, uint64_t *device_address, uint64_t *len) {
+    Ctx *c = C(p);
+    if (!c || !device_address || !len) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    int rc = drain(c);
+    if (rc) return rc;
+    if (g->key_error) return key_error_of(c, *g);
+    *device_address = (uint64_t)(uintptr_t)g->d_out;
+    *len = g->out_len;
+    return MSIM_OK;
+}
+
 int msim_release_result(msim_ctx *p, int contig) {
     Ctx *c = C(p);
     if (!c) return MSIM_ERR_ARG;

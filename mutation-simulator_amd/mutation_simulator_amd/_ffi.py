@@ -84,6 +84,7 @@ SYMBOLS = [
     ("msim_fetch_records", C.c_int, [_VP, C.c_int, _VP, _VP]),
     ("msim_result_checksum", C.c_int, [_VP, C.c_int, _U64P]),
     ("msim_release_result", C.c_int, [_VP, C.c_int]),
+    ("msim_result_device_ptr", C.c_int, [_VP, C.c_int, _U64P, _U64P]),
     ("msim_render_vcf", C.c_int, [_VP, C.c_uint64, _VP, _VP, C.c_uint64, C.c_char_p, _VP,
                                   C.c_uint64, _U64P]),
     ("msim_stats", C.c_int, [_VP, C.POINTER(Timing)]),
@@ -269,6 +270,12 @@ class Engine:
         s = C.c_uint64()
         self._check(self.lib.msim_result_checksum(self.h, contig, C.byref(s)))
         return s.value
+
+    def result_device_ptr(self, contig: int):
+        """(device address, length) of the mutated stream, for GPU-to-GPU transports."""
+        a, n = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.msim_result_device_ptr(self.h, contig, C.byref(a), C.byref(n)), contig)
+        return a.value, n.value
 
     def release_result(self, contig: int):
         self._check(self.lib.msim_release_result(self.h, contig))

@@ -214,3 +214,30 @@ def test_synthetic_contig_and_checksum(engine, length):
     assert np.array_equal(engine.fetch_sequence(cid), want)          # no records: identity
     assert engine.result_checksum(cid) == checksum_host(want)
     engine.clear()
+
+
+def test_result_device_pointer_and_gather_single_rank(engine):
+    """The device pointer libmsim exposes wraps zero-copy as a tensor (what the RCCL gather moves)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    from mutation_simulator_amd.gather import gather_to_root
+    engine.clear()
+    engine.seed(5, 6)
+    p = _ffi.Params()
+    for i in range(8):
+        p.block[i] = 1
+    p.ti_lim = (1 << 52) + 1
+    engine.set_params(p)
+    cid = engine.add_contig_synthetic(3_000_001, 4)
+    r = _ffi.Range()
+    r.start, r.stop, r.k, r.setsize, r.n_types = 0, 3_000_000, 30_000, 262165, 1
+    r.types[0] = 1
+    r.cdf_thr[0] = 1 << 53
+    engine.plan_contig(cid, [r])
+    engine.apply_contig(cid)
+    want = engine.fetch_sequence(cid)
+    got = gather_to_root(engine, [cid], [[0]], [len(want)], 0, 1, torch.device("cuda", 0))
+    assert list(got) == [0]
+    assert np.array_equal(got[0].cpu().numpy(), want)
+    engine.clear()
