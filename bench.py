@@ -73,11 +73,11 @@ def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
     return sim
 
 
-def one_step(eng, sim, cids, my_contigs):
+def one_step(eng, sim, cids, my_contigs, seed=42):
     """PLAN every contig in order (the RNG streams chain across contigs), APPLY this rank's."""
     from mutation_simulator_amd import mutator as mm
     from mutation_simulator_amd.sharding import run_sharded_pass
-    eng.seed(42, 42)
+    eng.seed(seed, seed)
     run_sharded_pass(eng, sim, cids, my_contigs, mm.plan_descriptors)
     eng.sync()
 
@@ -111,6 +111,10 @@ def main():
     ap.add_argument("--total-bases", type=int, default=3_000_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: 'weak' = N independent replicas, one whole genome per GPU with its own seeded "
+                         "streams (PLAN cannot shard in bit-compatible mode: the streams chain across contigs); "
+                         "'strong' = one genome, PLAN replayed on every rank, contigs' APPLY sharded (LPT)")
     ap.add_argument("--gather", action="store_true",
                     help="also gather every mutated contig to rank 0 over RCCL inside the timed step")
     a = ap.parse_args()
@@ -133,8 +137,10 @@ def main():
     lengths = contig_lengths(a.total_bases)
     sim = workload_settings(lengths)
     from mutation_simulator_amd.sharding import lpt_partition
-    parts = lpt_partition(lengths, world)
+    strong = a.scaling == "strong" and world > 1
+    parts = lpt_partition(lengths, world) if strong else [list(range(len(lengths)))] * world
     mine = parts[rank]
+    seed = 42 if strong else 42 + rank       # replicas: every GPU mutates its own genome
 
     eng = _ffi.Engine(local_rank)
     eng.set_params(mm.params_descriptor(sim))
@@ -151,8 +157,8 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        one_step(eng, sim, cids, mine)
-        if a.gather:
+        one_step(eng, sim, cids, mine, seed)
+        if a.gather and strong or a.gather and world == 1:
             import torch
             from mutation_simulator_amd.gather import gather_to_root
             got = gather_to_root(eng, cids, parts, lengths, rank, world, torch.device("cuda", local_rank))
@@ -179,7 +185,7 @@ def main():
     st = eng.stats()
 
     if rank == 0:
-        total = sum(lengths)
+        total = sum(lengths) * (1 if strong else world)      # weak: every rank mutated a whole genome
         ms_per_step = dt / a.steps * 1e3
         value = total * a.steps / dt / 1e6
         launches = max(st["apply_launches"], 1)
@@ -197,11 +203,13 @@ def main():
             "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01",
             "value": round(value, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "ARGS mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
                                    "-sn 0.01 -titv 2.0, CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
-                       "parallelism": f"contigs sharded over {world} GPU(s) (LPT), PLAN replicated"
+                       "parallelism": (f"one genome, contigs' APPLY sharded over {world} GPUs (LPT), PLAN replayed per rank"
+                                       if strong else f"{world} independent replica(s): one whole genome per GPU, "
+                                       f"streams seeded 42+rank")
                                       + (", RCCL gather to rank 0 included" if a.gather else ", results left in HBM")},
             "stages_ms_per_step": {
                 "plan_host": round(st["plan_host_ms"] / a.steps, 3),
