@@ -38,7 +38,7 @@ extern "C" {
                                      is negative") -- util.py:104 via random.sample                */
 #define MSIM_ERR_KEY          4   /* reference raises KeyError(base): transversion of a base outside
                                      A,G,T,C,N -- mutator.py:449-455; see msim_key_error()         */
-#define MSIM_ERR_UNSUPPORTED  5   /* valid for the reference, outside this build (TL/TLI, >=4 GiB)  */
+#define MSIM_ERR_UNSUPPORTED  5   /* valid for the reference, outside this build (contigs >= 4 GiB)  */
 #define MSIM_ERR_NOMEM        6
 
 /* ---- mutation types: numerically identical to mut_types.py:6-12 --------------------------------- */
@@ -64,9 +64,11 @@ typedef struct msim_ctx msim_ctx;
 typedef struct msim_record {
     uint32_t pos;     /* Mutation.start (dict key)                                               */
     uint32_t stop;    /* Mutation.stop; for IN: pos + insert_len - 1 (mutator.py:344)            */
-    uint32_t extra;   /* IN: offset of the insert's bases in the contig's insert pool             */
+    uint32_t extra;   /* IN: offset of the insert's bases in the contig's insert pool;
+                         TLI: Mutation.start of the linked TL span (stop = its Mutation.stop)        */
     uint8_t  type;    /* MSIM_SN .. MSIM_TLI                                                     */
-    uint8_t  aux;     /* SN: 0 = transition, 1/2 = transversion table column 0/1 (mutator.py:428-463) */
+    uint8_t  aux;     /* SN: 0 = transition, 1/2 = transversion table column 0/1 (mutator.py:428-463);
+                         TLI: bit 0 = trans_reverse, bit 1 = trans_insert_pos > 0 (mutator.py:281-284) */
     uint16_t rsv;
 } msim_record;
 

@@ -52,6 +52,11 @@ __device__ __forceinline__ void rec_lengths(const msim_record &r, uint32_t &outl
         case MSIM_DE: outlen = 0; inlen = len; break;
         case MSIM_IV: outlen = len; inlen = len; break;
         case MSIM_DU: outlen = 2 * len; inlen = len; break;
+        case MSIM_TL: outlen = 0; inlen = len; break;               // excised like a deletion
+        case MSIM_TLI: {                                            // seq[start : stop+1], then the base itself
+            const uint32_t ilen = r.stop + 1 > r.extra ? r.stop + 1 - r.extra : 0;
+            outlen = ilen + 1; inlen = 1; break;
+        }
         default: outlen = 0; inlen = 0; break;
     }
 }
@@ -204,6 +209,10 @@ __device__ __forceinline__ void rec_view(const msim_record &r, uint32_t o, uint3
         case MSIM_DE: e = o; s = r.stop + 1; break;
         case MSIM_IV: e = o + len; s = r.stop + 1; break;
         case MSIM_DU: e = o + len; s = r.pos; break;
+        case MSIM_TL: e = o; s = r.stop + 1; break;       // DEL:ME, excised span         mutator.py:360-377
+        case MSIM_TLI:                                    // INS:ME: (converted / rev-comp) copy of the linked
+            e = o + (r.stop + 1 > r.extra ? r.stop + 1 - r.extra : 0);   // TL span, then in[pos]   :401-421
+            s = r.pos; break;
         default: e = o; s = r.pos; break;                 // SN
     }
 }
@@ -257,6 +266,14 @@ __device__ __forceinline__ void merge_bytes(u32x4 &v, const u32x4 &pv, uint32_t 
     v.x = vv[0]; v.y = vv[1]; v.z = vv[2]; v.w = vv[3];
 }
 
+// convert(x) (ambiguity codes -> bases, mutator.py:75) of four bases at once; plain ACGT is a no-op
+__device__ __forceinline__ uint32_t conv4(uint32_t x, const uint8_t *lut) {
+    const uint32_t codes = (x >> 1) & 0x03030303u;
+    if (__builtin_amdgcn_perm(0u, 0x47544341u, codes) == x) return x;
+    return (uint32_t)lut[768 + (x & 0xff)] | ((uint32_t)lut[768 + ((x >> 8) & 0xff)] << 8) |
+           ((uint32_t)lut[768 + ((x >> 16) & 0xff)] << 16) | ((uint32_t)lut[768 + (x >> 24)] << 24);
+}
+
 // complement(convert(x)) of four bases at once.  A/C/G/T have distinct (x >> 1) & 3 codes (0,1,3,2):
 // v_perm_b32 turns codes back into letters (check: all four bytes plain ACGT) or into complements;
 // anything else (N, IUPAC, U ...) takes the 256-entry LDS table of mutator.py:75-76.
@@ -308,6 +325,18 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
                     pv = load16_shifted(in, (uint64_t)((int64_t)sj + rel));
                 } else if (type == MSIM_IN) {
                     pv = load16_shifted(pool, (uint64_t)((int64_t)recs[j].extra + rel));
+                } else if (type == MSIM_TLI) {               // copy of the linked TL span in[extra .. stop]
+                    const msim_record r = recs[j];
+                    if (r.aux & 1) {                         // trans_reverse: reverse complement
+                        const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)r.stop - rel - 15));
+                        pv.x = revcomp4(__builtin_bswap32(w.w), lut);
+                        pv.y = revcomp4(__builtin_bswap32(w.z), lut);
+                        pv.z = revcomp4(__builtin_bswap32(w.y), lut);
+                        pv.w = revcomp4(__builtin_bswap32(w.x), lut);
+                    } else {
+                        const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)r.extra + rel));
+                        pv.x = conv4(w.x, lut); pv.y = conv4(w.y, lut); pv.z = conv4(w.z, lut); pv.w = conv4(w.w, lut);
+                    }
                 } else {                                     // MSIM_IV: out[P] = rc(in[stop - (P - o)])
                     const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)sj - 1 - rel - 15));
                     pv.x = revcomp4(__builtin_bswap32(w.w), lut);

@@ -19,7 +19,7 @@ namespace msim {
 
 namespace {
 
-struct Cand { int64_t pos; int32_t type; int64_t stop; };
+struct Cand { int64_t pos; int32_t type; int64_t stop; int64_t src = 0; bool rev = false, linked = false; };
 
 inline uint64_t randbelow(HostMT &g, uint64_t n) {      // n < 2^32 on this path
     if (!n) return 0;
@@ -104,6 +104,7 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
 
     std::vector<Cand> all;                                           // `muts` of mutator.py:112
     std::vector<int64_t> pos;
+    std::vector<int64_t> tls, tlis;                                  // mutator.py:113-114
     bool sorted_concat = true;
     for (int ri = 0; ri < n_ranges; ri++) {
         const msim_range &r = ranges[ri];
@@ -121,7 +122,11 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
             int idx = 0;
             while (idx < r.n_types && r.cdf_thr[idx] <= m) idx++;
             if (idx >= r.n_types) idx = r.n_types - 1;               // unreachable: cdf[-1] == 1.0 > u
-            all[base + (size_t)i] = Cand{r.start + pos[(size_t)i] + d * i, r.types[idx], 0};
+            Cand cnd;
+            cnd.pos = r.start + pos[(size_t)i] + d * i;
+            cnd.type = r.types[idx];
+            cnd.stop = 0;
+            all[base + (size_t)i] = cnd;
         }
         // boundary pass                                             mutator.py:184-213
         size_t w = base;
@@ -137,15 +142,16 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
                 m.stop = randint(c->py, m.pos + r.min_len[t] - 1, m.pos + r.max_len[t] - 1);
             } else if (t == MSIM_IN) {
                 m.stop = randint(c->py, m.pos + r.min_len[t] - 1, m.pos + r.max_len[t] - 1);
-            } else if (t == MSIM_DU || t == MSIM_DE) {               // mutator.py:253-264
+            } else if (t == MSIM_DU || t == MSIM_DE || t == MSIM_TL) {   // mutator.py:253-264
                 m.stop = randint(c->py, m.pos + r.min_len[t] - 1, m.pos + r.max_len[t] - 1);
                 if (m.stop > chrom_len - 1) m.stop = chrom_len - 1;
-            } else {
-                return fail(c, MSIM_ERR_UNSUPPORTED,
-                            "translocations (TL/TLI, mutator.py:267-316) are not part of this build");
-            }
+            } else if (t != MSIM_TLI) {
+                return fail(c, MSIM_ERR_ARG, "unknown mutation type in msim_range.types");
+            }   // TLI: no branch of __get_stop_position matches, stop stays 0 (mutator.py:238-265)
             blk_lo = m.pos;
             blk_hi = ((t == MSIM_SN || t == MSIM_IN) ? m.pos : m.stop) + 1 + P.block[t];
+            if (t == MSIM_TL) tls.push_back(m.pos);                  // mutator.py:210-213
+            if (t == MSIM_TLI) tlis.push_back(m.pos);
             all[w++] = m;
         }
         all.resize(w);
@@ -165,6 +171,42 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
         all.swap(merged);
     }
     out.empty = all.empty();
+
+    // Translocations: pair every TL (excised span) with a TLI (insert site)   mutator.py:130-131, 267-316
+    if (!tls.empty()) {
+        auto find = [&](int64_t p) -> Cand * {
+            auto it = std::lower_bound(all.begin(), all.end(), p, [](const Cand &a, int64_t v) { return a.pos < v; });
+            return (it != all.end() && it->pos == p) ? &*it : nullptr;
+        };
+        // __fix_tl_amount: drop random surplus entries (a dropped entry leaves `muts`: type 0 = tombstone)
+        while (tls.size() < tlis.size()) {
+            const size_t idx = (size_t)randint(c->py, 0, (int64_t)tlis.size() - 1);
+            if (Cand *q = find(tlis[idx])) q->type = 0;
+            tlis.erase(tlis.begin() + (long)idx);
+        }
+        while (tls.size() > tlis.size()) {
+            const size_t idx = (size_t)randint(c->py, 0, (int64_t)tls.size() - 1);
+            if (Cand *q = find(tls[idx])) q->type = 0;
+            tls.erase(tls.begin() + (long)idx);
+        }
+        for (size_t i = tls.size(); i-- > 1;) {                      // random.shuffle(tls)
+            const size_t j = (size_t)randbelow(c->py, (uint64_t)i + 1);
+            std::swap(tls[i], tls[j]);
+        }
+        for (size_t i = 0; i < tls.size(); i++) {
+            Cand *tl = find(tls[i]), *tli = find(tlis[i]);
+            if (!tl || !tli) continue;                               // overwritten by an overlapping range
+            const int64_t tlen = tl->stop + 1 - tl->pos;
+            const bool rev = !(randint(c->py, 0, 1) == 0 || tlen < 2);   // __transloc_invert (draws first)
+            // muts[tli_pos] = Mutation(TLI, tl_pos, muts[tl_pos].stop, rev, tli_pos)
+            tli->type = MSIM_TLI;
+            tli->src = tl->pos;
+            tli->stop = tl->stop;
+            tli->rev = rev;
+            tli->linked = true;
+        }
+        all.erase(std::remove_if(all.begin(), all.end(), [](const Cand &a) { return a.type == 0; }), all.end());
+    }
 
     // Walk in position order like __mutate_sequence (mutator.py:332-425): entries inside a span an
     // earlier DE/IV/DU consumed are never visited; visited SNPs draw from the CPython stream,
@@ -192,8 +234,13 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
                 return fail(c, MSIM_ERR_UNSUPPORTED, "insert pool of 4 GiB or more on one contig");
             rec.extra = (uint32_t)out.pool.size();
             for (int64_t i = 0; i < len; i++) out.pool.push_back(ATGC[c->np.next() & 3u]);
+        } else if (m.type == MSIM_TLI) {                             // mutator.py:401-421, draws nothing
+            // Mutation.start / stop of the linked TL span; an unlinked TLI keeps start = pos, stop = 0
+            const int64_t src = m.linked ? m.src : m.pos;
+            rec.extra = (uint32_t)src;
+            rec.aux = (uint8_t)((m.rev ? 1 : 0) | ((m.linked && m.pos > 0) ? 2 : 0));   // bit 1: trans_insert_pos > 0
         } else {
-            consumed_to = m.stop;                                    // pos = muts[pos].stop
+            consumed_to = m.stop;                                    // pos = muts[pos].stop  (DE, TL, IV, DU)
         }
         out.recs.push_back(rec);
     }

@@ -86,6 +86,25 @@ uint64_t render(const msim_record *recs, uint64_t n, const uint8_t *pool, const 
                 }
                 break;
             }
+            case MSIM_TLI: {                                         // mutator.py:401-421
+                // insert = conv(seq[start : stop+1]) (Python slice: empty when stop+1 <= start)
+                const uint64_t src = r.extra;
+                const uint64_t hi = stop + 1 < L ? stop + 1 : L;
+                const uint64_t ilen = hi > src ? hi - src : 0;
+                const bool rev = r.aux & 1, after = r.aux & 2;
+                if (ilen == 0) break;                                // REF == ALT: suppressed
+                const uint64_t start = after ? pos : pos + 1;
+                const char ref = (char)T.conv[in[after ? pos - 1 : pos]];
+                line_head(s, name, name_len, start);
+                s.put(ref); s.put('\t');
+                if (after) s.put(ref);
+                if (rev) for (uint64_t q = 0; q < ilen; q++) s.put((char)T.comp[T.conv[in[hi - 1 - q]]]);
+                else for (uint64_t q = 0; q < ilen; q++) s.put((char)T.conv[in[src + q]]);
+                if (!after) s.put(ref);
+                line_tail(s, "INS:ME", start, ilen);
+                break;
+            }
+            case MSIM_TL:
             case MSIM_DE: {                                          // mutator.py:360-377
                 uint64_t start = pos, end = stop + 1, lo = pos - 1;
                 if (pos == 0) { start = 1; end = stop + 2; lo = 0; }
@@ -94,7 +113,7 @@ uint64_t render(const msim_record *recs, uint64_t n, const uint8_t *pool, const 
                 for (uint64_t q = lo; q < hi; q++) s.put((char)T.conv[in[q]]);
                 s.put('\t');
                 s.put((char)T.conv[in[pos > 0 ? lo : hi - 1]]);      // REF[0] / REF[-1]
-                line_tail(s, "DEL", end, stop - pos + 1);
+                line_tail(s, r.type == MSIM_DE ? "DEL" : "DEL:ME", end, stop - pos + 1);
                 break;
             }
             case MSIM_IV: {                                          // mutator.py:379-387

@@ -363,6 +363,19 @@ def make_cli_cases():
     cli_case("warn_rmt_meta", rmt_in, [], 4, 4,
              rmt_text="fasta = other.fa\nmd5 = 00ff\ntl_block = -3\nstd\nit None\nsn 0.002\n",
              notes="meta mismatch warnings + block clamp warning; values are lower-cased")
+    tl_in = {"contigs": [
+        {"defline": "tl1 translocations", "length": 90_000, "bpl": 60, "seed": 81, "decorate": True},
+        {"defline": "tl2", "length": 151, "bpl": 50, "seed": 82},
+        {"defline": "tl3", "length": 30_000, "bpl": 70, "seed": 83}]}
+    cli_case("tl_heavy", tl_in,
+             ["args", "-tl", "0.03", "-tlmin", "5", "-tlmax", "60", "-tlb", "3", "-sn", "0.01", "-in", "0.002",
+              "-inmax", "5", "-de", "0.002", "-demax", "9", "-iv", "0.002", "-ivmax", "30", "-titv", "1.3"], 12, 13,
+             notes="translocation-heavy mix: linked TL/TLI pairs, reversed and forward copies, IUPAC inside spans, "
+                   "a tiny contig where TL/TLI counts differ (fix_tl_amount) or TLIs stay unlinked")
+    cli_case("tl_rmt", tl_in, [], 21, 22,
+             rmt_text="tl_block = 2\nstd\nit None\ntl 0.01 tlmin 2 tlmax 40\nchr 1\n1-30000 sn 0.02 tl 0.04 tlmin 10 tlmax 200\n"
+                      "50001-60000 None\nchr 2\n1-151 tl 0.2 tlmin 1 tlmax 3\n",
+             notes="RMT with translocations: token-order chances, TL pairs linked across ranges of one contig")
     cli_case("rmt_quiet_none_std", rmt_in, [], 4, 4,
              rmt_text="std\nit None\nNone\nchr 2\n11-5000 sn 0.01 IN 0.002 INMIN 1 INMAX 4\n",
              notes="std None: only the listed range mutates; upper-case keywords")

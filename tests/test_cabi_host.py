@@ -122,10 +122,6 @@ def test_host_planner_vcf_matches_reference(name, tmp_path):
         return
     if meta["exception"] is not None:
         pytest.skip("KeyError surfaces in APPLY (GPU test)")
-    if name == "readme_mix_tl":
-        with pytest.raises(_ffi.MsimUnsupported):
-            plan_only_vcf(meta, tmp_path)
-        return
     vcf, empty, eng = plan_only_vcf(meta, tmp_path)
     assert len(vcf) == meta["vcf_len"] and sha256(vcf) == meta["vcf_sha256"]
     if meta["store"] == "full":

@@ -36,9 +36,6 @@ def test_cli_matches_reference_golden(name, tmp_path):
     """Whole CLI on the GPU == what the reference wrote for the same argv + seeds."""
     meta = case_meta(name)
     res = run_product_case(meta, tmp_path)
-    if name == "readme_mix_tl":
-        assert res["exit_code"] == 1 and "translocations" in res["stderr"]
-        return
     if meta["exception"] is not None:
         assert type(res["exception"]).__name__ == meta["exception"]["type"]
         if meta["exception"]["type"] == "KeyError":
@@ -104,6 +101,9 @@ SWEEP = [
     ("long_sv", [400_000], ["args", "-de", "0.0002", "-demin", "500", "-demax", "40000", "-du", "0.0002",
                             "-dumin", "300", "-dumax", "30000", "-iv", "0.0002", "-ivmin", "100", "-ivmax",
                             "20000", "-in", "0.0002", "-inmin", "200", "-inmax", "5000"]),
+    ("tl_mix", [300_000, 5_000, 40], ["args", "-tl", "0.02", "-tlmin", "1", "-tlmax", "300", "-tlb", "2", "-sn", "0.01",
+                                      "-in", "0.003", "-inmax", "7", "-du", "0.002", "-dumax", "50", "-iv", "0.002",
+                                      "-ivmax", "40", "-de", "0.002", "-demax", "30"]),
     ("tiny", [1, 2, 15, 16, 17, 31, 33, 64, 4095, 4096, 4097, 16383, 16384, 16385],
      ["args", "-sn", "0.2", "-in", "0.05", "-de", "0.05"]),
 ]
