@@ -164,34 +164,9 @@ __global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restri
 }
 
 // ------------------------------------------------------------------ 3. rewrite
-__device__ __forceinline__ u32x4 load16_shifted(const uint8_t *__restrict__ in, uint64_t src) {
-    // 16 bytes starting at an arbitrary byte address: dword-aligned dwordx4 + dword, then a funnel
-    // shift per output dword (v_alignbyte_b32).
-    const uint64_t a = src & ~3ull;
-    const uint32_t sh = (uint32_t)(src & 3ull);
-    // streamed once: nontemporal (keeps L2 / MALL for the record tables)
-    const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(in + a));
-    const uint32_t w4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(in + a + 16));
-    u32x4 r;
-    r.x = __builtin_amdgcn_alignbyte(v.y, v.x, sh);
-    r.y = __builtin_amdgcn_alignbyte(v.z, v.y, sh);
-    r.z = __builtin_amdgcn_alignbyte(v.w, v.z, sh);
-    r.w = __builtin_amdgcn_alignbyte(w4, v.w, sh);
-    return r;
-}
-
 __device__ __forceinline__ uint32_t get_byte(const u32x4 &v, uint32_t idx) {
     const uint32_t w = (idx >> 2) == 0 ? v.x : (idx >> 2) == 1 ? v.y : (idx >> 2) == 2 ? v.z : v.w;
     return (w >> ((idx & 3) * 8)) & 0xffu;
-}
-__device__ __forceinline__ void set_byte(u32x4 &v, uint32_t idx, uint32_t b) {
-    const uint32_t sh = (idx & 3) * 8;
-    const uint32_t m = ~(0xffu << sh), x = b << sh;
-    const uint32_t wi = idx >> 2;
-    v.x = wi == 0 ? (v.x & m) | x : v.x;
-    v.y = wi == 1 ? (v.y & m) | x : v.y;
-    v.z = wi == 2 ? (v.z & m) | x : v.z;
-    v.w = wi == 3 ? (v.w & m) | x : v.w;
 }
 
 // How a record shapes the output stream: at most ONE special segment [o, e) followed by a plain copy
@@ -250,129 +225,207 @@ __device__ __forceinline__ void report_key_error(unsigned long long *err, uint64
     atomicMin(err, (unsigned long long)((pos << 8) | conv_base));
 }
 
-// bytes [lo, hi) of pv replace those of v (0 <= lo < hi <= 16)
-__device__ __forceinline__ void merge_bytes(u32x4 &v, const u32x4 &pv, uint32_t lo, uint32_t hi) {
-    if (lo == 0 && hi == 16) { v = pv; return; }
-    uint32_t vv[4] = {v.x, v.y, v.z, v.w};
-    const uint32_t pp[4] = {pv.x, pv.y, pv.z, pv.w};
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-        const int l = max(0, min(4, (int)lo - 4 * d)), h = max(0, min(4, (int)hi - 4 * d));
-        const uint32_t mh = h >= 4 ? 0xffffffffu : ((1u << (8 * h)) - 1u);
-        const uint32_t ml = l >= 4 ? 0xffffffffu : ((1u << (8 * l)) - 1u);
-        const uint32_t m = mh & ~ml;
-        vv[d] = (vv[d] & ~m) | (pp[d] & m);
-    }
-    v.x = vv[0]; v.y = vv[1]; v.z = vv[2]; v.w = vv[3];
-}
-
-// convert(x) (ambiguity codes -> bases, mutator.py:75) of four bases at once; plain ACGT is a no-op
-__device__ __forceinline__ uint32_t conv4(uint32_t x, const uint8_t *lut) {
-    const uint32_t codes = (x >> 1) & 0x03030303u;
-    if (__builtin_amdgcn_perm(0u, 0x47544341u, codes) == x) return x;
-    return (uint32_t)lut[768 + (x & 0xff)] | ((uint32_t)lut[768 + ((x >> 8) & 0xff)] << 8) |
-           ((uint32_t)lut[768 + ((x >> 16) & 0xff)] << 16) | ((uint32_t)lut[768 + (x >> 24)] << 24);
-}
-
-// complement(convert(x)) of four bases at once.  A/C/G/T have distinct (x >> 1) & 3 codes (0,1,3,2):
-// v_perm_b32 turns codes back into letters (check: all four bytes plain ACGT) or into complements;
-// anything else (N, IUPAC, U ...) takes the 256-entry LDS table of mutator.py:75-76.
-__device__ __forceinline__ uint32_t revcomp4(uint32_t x, const uint8_t *lut) {
+// Four bases through one of the reference's translation tables (mutator.py:75-76):
+//   mode 1: convert(x) (ambiguity codes -> bases), mode 2: complement(convert(x)).
+// A/C/G/T have distinct (x >> 1) & 3 codes (0,1,3,2): v_perm_b32 turns codes back into letters (check:
+// all four bytes plain ACGT -> convert is the identity) or into complements; anything else (N, IUPAC,
+// U ...) takes the 256-entry LDS table.
+__device__ __forceinline__ uint32_t map4(uint32_t x, uint32_t mode, const uint8_t *lut) {
     const uint32_t codes = (x >> 1) & 0x03030303u;
     if (__builtin_amdgcn_perm(0u, 0x47544341u, codes) == x)            // "ACTG"[code] == byte ?
-        return __builtin_amdgcn_perm(0u, 0x43414754u, codes);          // "TGAC"[code]
-    return (uint32_t)lut[1024 + (x & 0xff)] | ((uint32_t)lut[1024 + ((x >> 8) & 0xff)] << 8) |
-           ((uint32_t)lut[1024 + ((x >> 16) & 0xff)] << 16) | ((uint32_t)lut[1024 + (x >> 24)] << 24);
+        return mode == 2 ? __builtin_amdgcn_perm(0u, 0x43414754u, codes) : x;   // "TGAC"[code]
+    const uint8_t *t = lut + (mode == 2 ? 1024 : 768);
+    return (uint32_t)t[x & 0xff] | ((uint32_t)t[(x >> 8) & 0xff] << 8) | ((uint32_t)t[(x >> 16) & 0xff] << 16) |
+           ((uint32_t)t[x >> 24] << 24);
+}
+
+// Where the 16 output bytes of the group starting at absolute offset G come from, as produced by ONE
+// piece of record j: its segment (in_seg) or the copy run after it (has = false: the run before the
+// first record).  Bytes outside the piece are garbage the caller masks or overwrites.  All output
+// offsets are < 2^32 (checked on the host), so the bookkeeping is 32-bit; only sources are 64-bit.
+struct PieceSrc {
+    const uint8_t *ptr;      // source byte address of the group's first byte (may be unaligned)
+    uint32_t mode;           // 0 raw, 1 convert, 2 complement(convert); bit 8: reversed
+};
+
+__device__ __forceinline__ PieceSrc piece_src(uint32_t G, bool has, bool in_seg, int32_t j, uint32_t oj, uint32_t ej,
+                                              uint32_t sj, uint32_t mj, const uint8_t *__restrict__ in,
+                                              const uint8_t *__restrict__ pool,
+                                              const msim_record *__restrict__ recs) {
+    PieceSrc p;
+    p.mode = 0;
+    const uint8_t *sp = in;
+    int64_t so;
+    if (in_seg) {
+        const uint32_t type = mj & 0xff;
+        const int64_t rel = (int64_t)G - (int64_t)oj;    // segment offset of the group's first byte
+        if (type == MSIM_DU) {
+            so = (int64_t)sj + rel;
+        } else if (type == MSIM_IN) {
+            sp = pool;
+            so = (int64_t)recs[j].extra + rel;
+        } else if (type == MSIM_IV) {                    // out[P] = rc(in[stop - (P - o)]), stop = s - 1
+            so = (int64_t)sj - 16 - rel;
+            p.mode = 2 | 256;
+        } else {                                         // MSIM_TLI: copy of the linked TL span in[extra .. stop]
+            const msim_record r = recs[j];
+            if (r.aux & 1) { so = (int64_t)r.stop - 15 - rel; p.mode = 2 | 256; }
+            else { so = (int64_t)r.extra + rel; p.mode = 1; }
+        }
+    } else {
+        so = has ? (int64_t)sj + ((int64_t)G - (int64_t)ej) : (int64_t)G;
+    }
+    p.ptr = sp + so;
+    return p;
+}
+
+// five dwords covering the 16 bytes at an arbitrary byte address (dword-aligned dwordx4 + dword)
+struct Raw5 { u32x4_a4 v; uint32_t w4; uint32_t sh; };
+__device__ __forceinline__ Raw5 piece_load(const PieceSrc &p) {
+    Raw5 r;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p.ptr);
+    const uint8_t *al = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3);
+    r.sh = (uint32_t)(a & 3);
+    r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(al));
+    r.w4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(al + 16));
+    return r;
+}
+__device__ __forceinline__ u32x4 piece_finish(const Raw5 &r, uint32_t mode, const uint8_t *lut) {
+    u32x4 pv;
+    pv.x = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh);
+    pv.y = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh);
+    pv.z = __builtin_amdgcn_alignbyte(r.v.w, r.v.z, r.sh);
+    pv.w = __builtin_amdgcn_alignbyte(r.w4, r.v.w, r.sh);
+    if (mode & 256) {
+        const u32x4 w = pv;
+        pv.x = __builtin_bswap32(w.w); pv.y = __builtin_bswap32(w.z);
+        pv.z = __builtin_bswap32(w.y); pv.w = __builtin_bswap32(w.x);
+    }
+    if (mode & 3) {
+        pv.x = map4(pv.x, mode & 3, lut); pv.y = map4(pv.y, mode & 3, lut);
+        pv.z = map4(pv.z, mode & 3, lut); pv.w = map4(pv.w, mode & 3, lut);
+    }
+    return pv;
+}
+__device__ __forceinline__ u32x4 piece_bytes(uint32_t G, bool has, bool in_seg, int32_t j, uint32_t oj, uint32_t ej,
+                                             uint32_t sj, uint32_t mj, const uint8_t *__restrict__ in,
+                                             const uint8_t *__restrict__ pool, const msim_record *__restrict__ recs,
+                                             const uint8_t *lut) {
+    const PieceSrc p = piece_src(G, has, in_seg, j, oj, ej, sj, mj, in, pool, recs);
+    return piece_finish(piece_load(p), p.mode, lut);
+}
+
+__device__ __forceinline__ uint32_t snp_patch(uint32_t x, uint32_t mj, uint32_t pos, const uint8_t *lut,
+                                              unsigned long long *err) {
+    const uint32_t nb = lut[(mj >> 8) * 256 + x];
+    if (nb == 0 && (mj >> 8) != 0) { report_key_error(err, (uint64_t)pos, lut[768 + x]); return x; }
+    return nb;
+}
+
+// Pass B helper: bytes [p, q) (same 16-B group) of one piece -> LDS tile, byte by byte
+__device__ __forceinline__ void fix_bytes(uint8_t *tile, uint32_t tile0, uint32_t p, uint32_t q, const u32x4 &pv,
+                                          int patch_idx, uint32_t patch_val) {
+    const uint32_t G = p & ~15u;
+    for (uint32_t b = p; b < q; b++) {
+        uint32_t x = get_byte(pv, b - G);
+        if ((int)(b - G) == patch_idx) x = patch_val;
+        tile[b - tile0] = (uint8_t)x;
+    }
 }
 
 template <bool IN_LDS>
-__device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t r_hi, bool any_rec,
-                                             const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                             const msim_record *__restrict__ recs,
-                                             const uint8_t *__restrict__ pool, const uint8_t *lut,
-                                             uint64_t tile0, uint64_t L_out, unsigned long long *err) {
+__device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t r_hi, bool any_rec, int32_t cnt,
+                                             uint8_t *tile, const uint8_t *__restrict__ in,
+                                             uint8_t *__restrict__ out, const msim_record *__restrict__ recs,
+                                             uint32_t n_rec, const uint8_t *__restrict__ pool, const uint8_t *lut,
+                                             uint64_t tile0_64, uint64_t L_out, unsigned long long *err) {
     const int32_t r_lo = A.r_lo;
-#pragma unroll 1
+    const uint32_t INF = 0xffffffffu;
+    const uint32_t tile0 = (uint32_t)tile0_64;
+    const uint32_t tile_end = (uint32_t)min<uint64_t>(tile0_64 + TILE, L_out);
+    // ---- pass A: every group from the piece that covers its first byte.  Three phases so that all
+    // four groups' loads are in flight together: resolve sources (LDS searches), load, transform.
+    PieceSrc src[ITERS];
+    uint32_t patch[ITERS];                               // SNP on the group's first byte: mj | pos handled below
+    uint32_t ppos[ITERS];
+    bool live[ITERS];
+#pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const uint64_t O = tile0 + (uint64_t)it * (THREADS * GROUP) + (uint64_t)threadIdx.x * GROUP;
-        if (O >= L_out) continue;
-        // j = last record in [r_lo, r_hi] with o <= O (none: has = false)
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        const uint32_t O = tile0 + g;
+        live[it] = O < tile_end;
+        patch[it] = 0;
+        ppos[it] = 0;
+        src[it].ptr = in;
+        src[it].mode = 0;
+        if (!live[it]) continue;
         int32_t j = r_lo - 1;
         if (any_rec) {
             int32_t lo = r_lo, hi = r_hi + 1;
             while (lo < hi) {
                 const int32_t mid = (lo + hi) >> 1;
-                if ((uint64_t)A.O(mid) <= O) lo = mid + 1; else hi = mid;
+                if (A.O(mid) <= O) lo = mid + 1; else hi = mid;
             }
             j = lo - 1;
         }
-        bool has = any_rec && j >= r_lo;
+        const bool has = any_rec && j >= r_lo;
         uint32_t oj = 0, ej = 0, sj = 0, mj = 0;
         if (has) A.all(j, oj, ej, sj, mj);
-        int32_t jn = has ? j + 1 : r_lo;
-        uint64_t next_o = (any_rec && jn <= r_hi) ? (uint64_t)A.O(jn) : ~0ull;
-        const uint64_t gend = O + GROUP;
-        u32x4 v = u32x4{0, 0, 0, 0};
-        uint64_t cur = O;
-        while (true) {
-            uint64_t pend;
-            if (has && cur < (uint64_t)ej) {                 // inside record j's segment
-                pend = min((uint64_t)ej, gend);
-                const int64_t rel = (int64_t)O - (int64_t)oj;    // segment offset of the group's first byte
-                const uint32_t type = mj & 0xff;
-                u32x4 pv;
-                if (type == MSIM_DU) {
-                    pv = load16_shifted(in, (uint64_t)((int64_t)sj + rel));
-                } else if (type == MSIM_IN) {
-                    pv = load16_shifted(pool, (uint64_t)((int64_t)recs[j].extra + rel));
-                } else if (type == MSIM_TLI) {               // copy of the linked TL span in[extra .. stop]
-                    const msim_record r = recs[j];
-                    if (r.aux & 1) {                         // trans_reverse: reverse complement
-                        const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)r.stop - rel - 15));
-                        pv.x = revcomp4(__builtin_bswap32(w.w), lut);
-                        pv.y = revcomp4(__builtin_bswap32(w.z), lut);
-                        pv.z = revcomp4(__builtin_bswap32(w.y), lut);
-                        pv.w = revcomp4(__builtin_bswap32(w.x), lut);
-                    } else {
-                        const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)r.extra + rel));
-                        pv.x = conv4(w.x, lut); pv.y = conv4(w.y, lut); pv.z = conv4(w.z, lut); pv.w = conv4(w.w, lut);
-                    }
-                } else {                                     // MSIM_IV: out[P] = rc(in[stop - (P - o)])
-                    const u32x4 w = load16_shifted(in, (uint64_t)((int64_t)sj - 1 - rel - 15));
-                    pv.x = revcomp4(__builtin_bswap32(w.w), lut);
-                    pv.y = revcomp4(__builtin_bswap32(w.z), lut);
-                    pv.z = revcomp4(__builtin_bswap32(w.y), lut);
-                    pv.w = revcomp4(__builtin_bswap32(w.x), lut);
-                }
-                merge_bytes(v, pv, (uint32_t)(cur - O), (uint32_t)(pend - O));
-            } else {                                         // copy run after record j (or before the first)
-                pend = min(next_o, gend);
-                if (pend > cur) {
-                    const int64_t src = has ? (int64_t)sj + ((int64_t)O - (int64_t)ej) : (int64_t)O;
-                    u32x4 pv = load16_shifted(in, (uint64_t)src);
-                    if (has && (mj & 0xff) == MSIM_SN && (uint64_t)oj == cur) {   // the run starts on the SNP byte
-                        const uint32_t idx = (uint32_t)(cur - O);
-                        const uint32_t x = get_byte(pv, idx);
-                        const uint32_t nb = lut[(mj >> 8) * 256 + x];
-                        if (nb == 0 && (mj >> 8) != 0) report_key_error(err, (uint64_t)sj, lut[768 + x]);
-                        else set_byte(pv, idx, nb);
-                    }
-                    merge_bytes(v, pv, (uint32_t)(cur - O), (uint32_t)(pend - O));
-                }
-            }
-            cur = pend;
-            if (cur >= gend) break;
-            if (!(has && cur < (uint64_t)ej)) {              // segment (if any) finished and the run hit the next record
-                if (cur >= next_o) {
-                    j = jn;
-                    has = true;
-                    A.all(j, oj, ej, sj, mj);
-                    jn = j + 1;
-                    next_o = jn <= r_hi ? (uint64_t)A.O(jn) : ~0ull;
-                }
-            }
+        const bool in_seg = has && O < ej;
+        src[it] = piece_src(O, has, in_seg, j, oj, ej, sj, mj, in, pool, recs);
+        if (!in_seg && has && (mj & 0xff) == MSIM_SN && oj == O) { patch[it] = mj | 0x80000000u; ppos[it] = sj; }
+    }
+    Raw5 raw[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) raw[it] = piece_load(src[it]);
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        if (!live[it]) continue;
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        u32x4 pv = piece_finish(raw[it], src[it].mode, lut);
+        if (patch[it])                                   // the group starts on an SNP byte
+            pv.x = (pv.x & ~0xffu) | snp_patch(pv.x & 0xff, patch[it] & 0x7fffffffu, ppos[it], lut, err);
+        *reinterpret_cast<u32x4 *>(tile + g) = pv;
+    }
+    __syncthreads();
+    // ---- pass B: one lane per PIECE (2 per record: segment, copy run) fixes the bytes from the piece
+    // start to the end of its 16-B group
+    for (int32_t q2 = threadIdx.x; q2 < 2 * cnt; q2 += THREADS) {
+        const int32_t q = q2 >> 1;
+        const bool run = q2 & 1;
+        const int32_t j = r_lo + q;
+        uint32_t oj, ej, sj, mj;
+        A.all(j, oj, ej, sj, mj);
+        uint32_t p, end;
+        if (!run) {                                       // segment piece [o, e)
+            p = oj;
+            end = ej;
+        } else {                                          // copy run piece [e, next o)
+            uint32_t next_o = INF;
+            if (q + 1 < cnt) next_o = A.O(j + 1);
+            else if ((uint32_t)(j + 1) < n_rec) next_o = A.off ? A.off[j + 1] : recs[j + 1].pos;
+            p = ej;
+            end = next_o;
         }
-        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(out + O));
+        if (end <= p || p < tile0 || p >= tile_end || !(p & 15u)) continue;
+        end = min(min(end, (p | 15u) + 1u), tile_end);
+        const u32x4 pv = piece_bytes(p & ~15u, true, !run, j, oj, ej, sj, mj, in, pool, recs, lut);
+        int pidx = -1;
+        uint32_t pval = 0;
+        if (run && (mj & 0xff) == MSIM_SN) {              // the run starts on the SNP byte
+            pidx = (int)(p & 15u);
+            pval = snp_patch(get_byte(pv, (uint32_t)pidx), mj, sj, lut, err);
+        }
+        fix_bytes(tile, tile0, p, end, pv, pidx, pval);
+    }
+    __syncthreads();
+    // ---- pass C: stream the tile out
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        if (tile0 + g < tile_end)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(tile + g),
+                                        reinterpret_cast<u32x4 *>(out + tile0_64 + g));
     }
 }
 
@@ -384,6 +437,7 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
                                                      const uint8_t *__restrict__ lut_g,
                                                      unsigned long long *err) {
     __shared__ RecWin win;
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
     const uint32_t t = blockIdx.x;
     const uint64_t tile0 = (uint64_t)t * TILE;
@@ -410,10 +464,10 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
     __syncthreads();
     if (in_lds) {
         RecAccess<true> A{&win, recs, off, r_lo};
-        rewrite_tile<true>(A, r_hi, any_rec, in, out, recs, pool, lut, tile0, L_out, err);
+        rewrite_tile<true>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
     } else {
         RecAccess<false> A{&win, recs, off, r_lo};
-        rewrite_tile<false>(A, r_hi, any_rec, in, out, recs, pool, lut, tile0, L_out, err);
+        rewrite_tile<false>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
     }
 }
 
