@@ -106,6 +106,7 @@ typedef struct {
 } orc_t;
 
 static int buf_put(buf_t *b, const void *src, size_t n) {
+    if (n == 0) return ORC_OK;               /* memcpy(NULL, ..., 0) is undefined */
     if (b->n + n > b->cap) {
         size_t nc = b->cap ? b->cap * 2 : 1 << 16;
         while (nc < b->n + n) nc *= 2;
@@ -247,7 +248,7 @@ int orc_sample_min_dist(orc_t *o, int64_t start, int64_t stop, int64_t k, int64_
     int64_t n = (stop - (k - 1) * d) - start;
     int rc = orc_sample(o, n, k, out);
     if (rc) return rc;
-    qsort(out, (size_t)k, sizeof(int64_t), cmp_i64);
+    if (k) qsort(out, (size_t)k, sizeof(int64_t), cmp_i64);
     for (int64_t i = 0; i < k; i++) out[i] = start + out[i] + d * i;
     return ORC_OK;
 }
@@ -573,14 +574,16 @@ int orc_mutate_contig(orc_t *o, const unsigned char *seq, int64_t L, const char 
         if (n_all + nr > cap) { cap = (n_all + nr) * 2 + 16; all = (rec_t *)realloc(all, (size_t)cap * sizeof(rec_t)); }
         for (int64_t i = 0; i < nr; i++) { all[n_all] = rr[i]; all[n_all].ins_pos = n_all; /* temp: insertion order */ n_all++; }
         tls = (int64_t *)realloc(tls, (size_t)(n_tls + na + 1) * sizeof(int64_t));
-        memcpy(tls + n_tls, a, (size_t)na * sizeof(int64_t)); n_tls += na;
+        if (na) memcpy(tls + n_tls, a, (size_t)na * sizeof(int64_t));
+        n_tls += na;
         tlis = (int64_t *)realloc(tlis, (size_t)(n_tlis + nb + 1) * sizeof(int64_t));
-        memcpy(tlis + n_tlis, b, (size_t)nb * sizeof(int64_t)); n_tlis += nb;
+        if (nb) memcpy(tlis + n_tlis, b, (size_t)nb * sizeof(int64_t));
+        n_tlis += nb;
         free(rr); free(a); free(b);
     }
     if (rc) { free(all); free(tls); free(tlis); return rc; }
     /* muts.update(rng_muts): key = pos, later ranges win (mutator.py:121) */
-    qsort(all, (size_t)n_all, sizeof(rec_t), cmp_rec);
+    if (n_all) qsort(all, (size_t)n_all, sizeof(rec_t), cmp_rec);
     int64_t w = 0;
     for (int64_t i = 0; i < n_all; i++) {
         if (i + 1 < n_all && all[i + 1].pos == all[i].pos) continue;

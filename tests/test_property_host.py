@@ -1,0 +1,116 @@
+"""Property tests (hypothesis) on the CPU tier: for random ARGS parameter sets the product's host
+planner + VCF renderer (host-only libmsim context) must produce the oracle's VCF and leave both
+MT19937 streams where the oracle leaves them; record tables must satisfy the path's invariants."""
+from __future__ import annotations
+
+import contextlib
+import io
+import random
+
+import numpy as np
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+import mutation_simulator_amd as msa
+from mutation_simulator_amd import _ffi
+from mutation_simulator_amd import mutator as mm
+from oracle import oracle as orc
+from test_host_settings import dump_sim
+
+rate = st.sampled_from([0.0, 0.0005, 0.003, 0.02, 0.07])
+
+
+@st.composite
+def workloads(draw):
+    rates = {t: draw(rate) for t in ("sn", "in", "de", "iv", "du", "tl")}
+    if sum(rates.values()) <= 0:
+        rates["sn"] = 0.01
+    if sum(rates.values()) > 0.5:
+        rates = {k: v / 4 for k, v in rates.items()}
+    argv = ["args", "-titv", str(draw(st.sampled_from([0.0, 0.5, 1.0, 2.0, 7.5])))]
+    for t, r in rates.items():
+        argv += [f"-{t}", repr(r)]
+        if t != "sn":
+            lo = draw(st.integers(2 if t == "iv" else 1, 12))
+            argv += [f"-{t}min", str(lo), f"-{t}max", str(lo + draw(st.integers(0, 90)))]
+        argv += [f"-{t}b", str(draw(st.integers(1, 6)))]
+    lengths = draw(st.lists(st.integers(1, 60_000), min_size=1, max_size=3))
+    return argv, lengths, draw(st.integers(0, 2**32 - 1)), draw(st.integers(0, 2**32 - 1))
+
+
+class _Rec:
+    def __init__(self, name, bases):
+        self.name, self.long_name, self.bases = name, name + " synthetic", bases
+
+    def __len__(self):
+        return len(self.bases)
+
+
+class _Fasta:
+    def __init__(self, recs):
+        self.recs = recs
+
+    def keys(self):
+        return [r.name for r in self.recs]
+
+    def __getitem__(self, k):
+        return self.recs[k] if isinstance(k, int) else next(r for r in self.recs if r.name == k)
+
+
+@settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+@given(workloads())
+def test_host_planner_matches_oracle(w):
+    argv, lengths, seed_py, seed_np = w
+    rs = np.random.RandomState(seed_np % 1000)
+    recs = [_Rec(f"c{i}", np.frombuffer(b"ACGTNRY", dtype=np.uint8)[rs.randint(0, 7, L)].copy())
+            for i, L in enumerate(lengths)]
+    fasta = _Fasta(recs)
+    with contextlib.redirect_stderr(io.StringIO()):
+        args = msa.get_args(["x.fa"] + argv)
+        sim = msa.SimulationSettings.from_args(args, fasta, True)
+    # oracle
+    o = orc.Oracle()
+    o.seed(seed_py, seed_np)
+    contigs = [{"name": r.name, "long_name": r.long_name, "lenc": 60, "bases": r.bases} for r in recs]
+    try:
+        _, want_vcf, _, _ = o.run_genome(contigs, dump_sim(sim), "x.fa")
+        want_exc = None
+    except (ValueError, KeyError) as e:
+        want_vcf, want_exc = None, type(e)
+    # product (host-only context)
+    eng = _ffi.Engine(device=-1)
+    eng.seed(seed_py, seed_np)
+    eng.set_params(mm.params_descriptor(sim))
+    body = []
+    got_exc = None
+    try:
+        for chrom in sim.chromosomes:
+            r = recs[chrom.number]
+            cid = eng.add_contig(r.bases)
+            eng.plan_contig(cid, mm.plan_descriptors(chrom))
+            tab, pool = eng.fetch_records(cid)
+            # invariants: sorted, in range, spans of visited records never overlap
+            pos = tab["pos"].astype(np.int64)
+            assert np.all(np.diff(pos) > 0) and (len(pos) == 0 or pos[-1] < len(r))
+            span = np.isin(tab["type"], (3, 4, 5, 6))
+            end = np.where(span, tab["stop"].astype(np.int64), pos)
+            assert np.all(pos[1:] > end[:-1])
+            body.append(_ffi.render_vcf(tab, pool, r.bases, r.name))
+            eng.clear()
+    except ValueError as e:
+        got_exc = ValueError
+    if want_exc is ValueError:
+        assert got_exc is ValueError
+        return
+    assert got_exc is None
+    if want_exc is KeyError:
+        return                                   # surfaces in APPLY (GPU); the plan itself is valid
+    want_body = b"".join(l + b"\n" for l in want_vcf.split(b"\n") if l and not l.startswith(b"#"))
+    assert b"".join(body) == want_body
+    for stream in (0, 1):
+        mt, idx = eng.get_mt_state(stream)
+        ost, oidx = o.get_state(stream)
+        ref = random.Random()
+        ref.setstate((3, tuple(int(x) for x in mt) + (int(idx),), None))
+        ref2 = random.Random()
+        ref2.setstate((3, tuple(int(x) for x in ost) + (int(oidx),), None))
+        assert [ref.getrandbits(32) for _ in range(4)] == [ref2.getrandbits(32) for _ in range(4)]
