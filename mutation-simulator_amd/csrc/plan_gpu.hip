@@ -567,55 +567,54 @@ __device__ __forceinline__ SnpMap snp_identity() { SnpMap r; r.c[0] = r.c[1] = r
 // With them the transducer walks SNP by SNP (ctz over the masks) instead of word by word.
 struct SnpBits { uint32_t A, B, T; int E; };             // E = valid words (0..32)
 
-__device__ __forceinline__ uint32_t first_bit_from(uint32_t mask, int from, int E) {   // index or 32
-    if (from >= 32) return 32;
-    uint32_t m = mask & (~0u << from);
-    if (E < 32) m &= (1u << E) - 1u;
-    return m ? (uint32_t)__builtin_ctz(m) : 32u;
-}
-
-// Walk the SNPs of one lane's words from start state s0.  on_emit(word_index, aux) is called for
-// every completed SNP in order.  Returns the end state; count through the reference.
-template <typename F>
-__device__ __forceinline__ uint32_t snp_walk(uint32_t s0, const SnpBits &m, uint32_t &count, F on_emit) {
-    count = 0;
-    const int E = m.E;
-    if (E <= 0) return s0;
-    int p;                                               // word index at which the next SNP's 1st word sits
-    if (s0 == 0) {
-        p = 0;
-    } else {
-        uint32_t j;
-        if (s0 == 1 && (m.A & 1u)) { on_emit(0, 0u); count = 1; p = 1; }
-        else {
-            j = first_bit_from(m.B, s0 == 1 ? 1 : 0, E);
-            if (j >= 32) return 2;
-            on_emit((int)j, 1u + ((m.T >> j) & 1u)); count = 1; p = (int)j + 1;
-        }
-    }
-    while (true) {
-        if (p >= E) return 0;
-        if (p == E - 1) return 1;
-        if ((m.A >> (p + 1)) & 1u) { on_emit(p + 1, 0u); count++; p += 2; }
-        else {
-            const uint32_t j = first_bit_from(m.B, p + 2, E);
-            if (j >= 32) return 2;
-            on_emit((int)j, 1u + ((m.T >> j) & 1u)); count++; p = (int)j + 1;
-        }
-    }
-}
-
+// Branch-free, bit-sliced transducer over one lane's <= 32 words.  Bit k (k = 0..2) of s0/s1/s2 says
+// whether the simulation that STARTED in state k is currently in state 0/1/2, so all three start
+// states advance together with a fixed sequence of bitwise ops per word (no divergence):
+//   word i:  emit = (s1 & a_i) | (s2 & b_i);  s0' = emit;  s1' = s0;  s2' = (s1 & ~a_i) | (s2 & ~b_i)
+// Emit counts are packed byte counters (<= 32 each).
 __device__ __forceinline__ SnpMap snp_lane_map(const SnpBits &m) {
+    uint32_t s0 = 1u, s1 = 2u, s2 = 4u, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint32_t live = i < m.E ? 7u : 0u;         // words beyond the window leave the state alone
+        const uint32_t a = (0u - ((m.A >> i) & 1u)) & live;
+        const uint32_t b = (0u - ((m.B >> i) & 1u)) & live;
+        const uint32_t emit = (s1 & a) | (s2 & b);
+        const uint32_t n2 = (s1 & ~a & live) | (s2 & ~b & live) | (s2 & ~live);
+        const uint32_t n1 = (s0 & live) | (s1 & ~live);
+        const uint32_t n0 = emit | (s0 & ~live);
+        cnt += (emit | (emit << 7) | (emit << 14)) & 0x00010101u;
+        s0 = n0; s1 = n1; s2 = n2;
+    }
     SnpMap r;
+    r.c[0] = cnt & 0xff; r.c[1] = (cnt >> 8) & 0xff; r.c[2] = (cnt >> 16) & 0xff;
     r.e = 0;
 #pragma unroll
-    for (uint32_t s0 = 0; s0 < 3; s0++) {
-        uint32_t c;
-        const uint32_t e = snp_walk(s0, m, c, [](int, uint32_t) {});
-        r.c[s0] = c;
-        r.e |= e << (2 * s0);
+    for (int k = 0; k < 3; k++) {
+        const uint32_t e = ((s0 >> k) & 1u) ? 0u : ((s1 >> k) & 1u) ? 1u : 2u;
+        r.e |= e << (2 * k);
     }
     return r;
+}
+
+// One simulation (true start state st): emit mask (bit i: an SNP completes on word i) and the mask of
+// emits that came out of the randbelow(2) loop (transversions).  Returns the end state.
+__device__ __forceinline__ uint32_t snp_lane_emits(uint32_t st, const SnpBits &m, uint32_t &emits, uint32_t &from2) {
+    uint32_t s0 = st == 0, s1 = st == 1, s2 = st == 2;
+    emits = 0; from2 = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint32_t live = i < m.E ? 1u : 0u;
+        const uint32_t a = (m.A >> i) & live, b = (m.B >> i) & live;
+        const uint32_t e1 = s1 & a, e2 = s2 & b;
+        const uint32_t n2 = (s1 & ~a & live) | (s2 & ~b & live) | (s2 & ~live & 1u);
+        const uint32_t n1 = (s0 & live) | (s1 & ~live & 1u);
+        const uint32_t n0 = e1 | e2 | (s0 & ~live & 1u);
+        emits |= (e1 | e2) << i;
+        from2 |= e2 << i;
+        s0 = n0; s1 = n1; s2 = n2;
+    }
+    return s0 ? 0u : s1 ? 1u : 2u;
 }
 
 constexpr int SNP_ITEMS2 = 32;
@@ -768,13 +767,16 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_cut(const uint32_t *__restr
     const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
     const uint32_t bs = block_maps[b].e, bc = block_maps[b].c[0];
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
-    uint32_t idx = bc + ex.c[bs];
-    uint32_t cnt;
-    const unsigned long long w0 = p0 + base + (unsigned long long)threadIdx.x * SNP_ITEMS2;
-    (void)snp_walk(st, m, cnt, [&](int word, uint32_t) {
-        idx++;
-        if (idx == K) ps->pos = w0 + (unsigned long long)word + 1;   // the K-th SNP completed on this word
-    });
+    const uint32_t idx = bc + ex.c[bs];                   // SNPs completed before this lane's words
+    uint32_t emits, from2;
+    (void)snp_lane_emits(st, m, emits, from2);
+    const uint32_t mine = (uint32_t)__popc(emits);
+    if (idx < K && K <= idx + mine) {                     // the K-th SNP completes in this lane: on which word?
+        uint32_t e = emits;
+        for (uint32_t q = idx + 1; q < K; q++) e &= e - 1; // drop the first K - idx - 1 emits
+        const unsigned long long w0 = p0 + base + (unsigned long long)threadIdx.x * SNP_ITEMS2;
+        ps->pos = w0 + (unsigned long long)__builtin_ctz(e) + 1;
+    }
 }
 
 // aux of every SNP record (off the critical path; runs on the emit stream)
@@ -793,11 +795,13 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__rest
     const uint32_t bs = block_maps[blockIdx.x].e;
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
     uint32_t idx = bc + ex.c[bs];
-    uint32_t cnt;
-    (void)snp_walk(st, m, cnt, [&](int, uint32_t aux) {
-        if (idx < K) recs[idx].aux = (uint8_t)aux;
-        idx++;
-    });
+    uint32_t emits, from2;
+    (void)snp_lane_emits(st, m, emits, from2);
+    while (emits && idx < K) {                            // aux: 0 transition, 1/2 transversion column (bit 30)
+        const uint32_t i = (uint32_t)__builtin_ctz(emits);
+        emits &= emits - 1;
+        recs[idx++].aux = (uint8_t)(((from2 >> i) & 1u) ? 1u + ((m.T >> i) & 1u) : 0u);
+    }
 }
 
 // single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
