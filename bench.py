@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--total-bases", type=int, default=3_000_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+                    help="c2 = BASELINE configs[1] (headline: -sn 0.01 -titv 2.0); c3 = configs[2], the full SV mix "
+                         "(-sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500) -- secondary number")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: 'weak' = N independent replicas, one whole genome per GPU with its own seeded "
                          "streams (PLAN cannot shard in bit-compatible mode: the streams chain across contigs); "
@@ -135,7 +138,9 @@ def main():
     from mutation_simulator_amd import mutator as mm
 
     lengths = contig_lengths(a.total_bases)
-    sim = workload_settings(lengths)
+    C3 = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
+          "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
+    sim = workload_settings(lengths) if a.workload == "c2" else workload_settings(lengths, snp=0.005, titv=1.0, extra=C3)
     from mutation_simulator_amd.sharding import lpt_partition
     strong = a.scaling == "strong" and world > 1
     parts = lpt_partition(lengths, world) if strong else [list(range(len(lengths)))] * world
@@ -194,7 +199,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes, if present
         tf = ROOT / "profiles" / "r01_traffic.json"
-        if tf.exists():
+        if tf.exists() and a.workload == "c2":
             try:
                 traffic = json.loads(tf.read_text())["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
@@ -205,7 +210,8 @@ def main():
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "ARGS mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
-                                   "-sn 0.01 -titv 2.0, CPython/NumPy-compatible MT19937 streams seeded 42/42",
+                                   + ("-sn 0.01 -titv 2.0" if a.workload == "c2" else "full SV mix (BASELINE configs[2])")
+                                   + ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
                        "parallelism": (f"one genome, contigs' APPLY sharded over {world} GPUs (LPT), PLAN replayed per rank"
                                        if strong else f"{world} independent replica(s): one whole genome per GPU, "
@@ -220,11 +226,11 @@ def main():
             "records_per_step": st["records"] // a.steps,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "msim::k_rewrite_snp (SNP-only tables; msim::k_rewrite for SV mixes)",
+                         "kernel": "msim::k_rewrite_snp" if a.workload == "c2" else "msim::k_rewrite",
                          "algorithmic_bytes_per_launch": alg_bytes // launches,
                          "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         print(json.dumps(line), flush=True)
     eng.close()

@@ -260,6 +260,7 @@ int msim_set_mt_state(msim_ctx *p, int stream, const uint32_t mt[624], int pos) 
     HostMT &g = stream ? c->np : c->py;
     memcpy(g.mt, mt, sizeof g.mt);
     g.idx = pos;
+    g.state_changed();
     if (c->gpu) gpu_plan_invalidate(c->gpu);
     return MSIM_OK;
 }

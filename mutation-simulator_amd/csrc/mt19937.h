@@ -33,8 +33,11 @@ MSIM_HD uint32_t mt_twist(uint32_t xk, uint32_t xk1, uint32_t xk397) {
 }
 
 // Sequential host generator.  `words` counts outputs drawn (stream position bookkeeping).
+// A regeneration produces the next 624 raw words in three dependency-free loops and tempers them all
+// at once into `out`, so both loops vectorise (an AVX2 clone is selected at load time where available).
 struct HostMT {
-    uint32_t mt[MT_N];
+    uint32_t mt[MT_N];                 // raw state (what random.getstate() / numpy get_state() hold)
+    uint32_t out[MT_N];                // tempered outputs of the current block
     int idx = MT_N;
     uint64_t words = 0;
 
@@ -58,17 +61,25 @@ struct HostMT {
         mt[0] = 0x80000000u;
         idx = MT_N;
     }
-    void regenerate() {
-        int k = 0;
-        for (; k < MT_N - MT_M; k++) mt[k] = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]);
-        for (; k < MT_N - 1; k++) mt[k] = mt_twist(mt[k], mt[k + 1], mt[k + MT_M - MT_N]);
-        mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
-        idx = 0;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __attribute__((target_clones("avx2", "default")))
+#endif
+    void block(bool advance) {
+        if (advance) {
+            int k = 0;
+            for (; k < MT_N - MT_M; k++) mt[k] = mt_twist(mt[k], mt[k + 1], mt[k + MT_M]);
+            for (; k < MT_N - 1; k++) mt[k] = mt_twist(mt[k], mt[k + 1], mt[k + MT_M - MT_N]);
+            mt[MT_N - 1] = mt_twist(mt[MT_N - 1], mt[0], mt[MT_M - 1]);
+        }
+        for (int k = 0; k < MT_N; k++) out[k] = mt_temper(mt[k]);
     }
+    void regenerate() { block(true); idx = 0; }
+    // the raw state was set from outside (msim_set_mt_state, device window): refresh the tempered block
+    void state_changed() { block(false); }
     inline uint32_t next() {
         if (idx >= MT_N) regenerate();
         words++;
-        return mt_temper(mt[idx++]);
+        return out[idx++];
     }
     // 53-bit sample shared by random.random() and NumPy's random_sample(): (a>>5)*2^26 + (b>>6)
     inline uint64_t next53() {

@@ -1091,6 +1091,7 @@ int gpu_plan_sync_to_host(Ctx *c, GpuPlan *g) {
             h.idx = (int)consumed;
         }
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        h.state_changed();
         s.last_session_words = std::max<uint64_t>(s.pos, MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS);
         s.live = false;
     }

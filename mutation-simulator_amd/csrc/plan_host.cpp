@@ -58,12 +58,27 @@ int sample_sorted(Ctx *c, HostMT &g, int64_t n, int64_t k, int64_t setsize, std:
     if ((uint64_t)n <= 512ull * (uint64_t)k + (1u << 20)) {
         std::vector<uint64_t> bits(((size_t)n + 63) / 64, 0);
         int64_t got = 0;
+        // The bitmap is far larger than the caches, so the test-and-set is a random DRAM access.  Draw the
+        // accepted values in batches and prefetch their words first.  A batch never exceeds k - got: that
+        // many more accepted draws are consumed in any case (each adds at most one distinct value), so the
+        // stream position stays exact.
+        uint32_t batch[64];
         while (got < k) {
-            uint64_t v = g.next() >> sh;
-            if (v >= (uint64_t)n) continue;
-            uint64_t &w = bits[v >> 6];
-            const uint64_t m = 1ull << (v & 63);
-            if (!(w & m)) { w |= m; got++; }
+            const int want = (int)std::min<int64_t>(64, k - got);
+            int nb = 0;
+            while (nb < want) {
+                const uint64_t v = g.next() >> sh;
+                if (v < (uint64_t)n) {
+                    batch[nb++] = (uint32_t)v;
+                    __builtin_prefetch(&bits[v >> 6], 1, 0);
+                }
+            }
+            for (int i = 0; i < nb; i++) {
+                const uint32_t v = batch[i];
+                uint64_t &w = bits[v >> 6];
+                const uint64_t m = 1ull << (v & 63);
+                if (!(w & m)) { w |= m; got++; }
+            }
         }
         for (size_t wi = 0; wi < bits.size(); wi++) {
             uint64_t w = bits[wi];
@@ -233,7 +248,10 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
             if (out.pool.size() + (uint64_t)len >= (1ull << 32))
                 return fail(c, MSIM_ERR_UNSUPPORTED, "insert pool of 4 GiB or more on one contig");
             rec.extra = (uint32_t)out.pool.size();
-            for (int64_t i = 0; i < len; i++) out.pool.push_back(ATGC[c->np.next() & 3u]);
+            const size_t at = out.pool.size();
+            out.pool.resize(at + (size_t)len);
+            uint8_t *dst = out.pool.data() + at;
+            for (int64_t i = 0; i < len; i++) dst[i] = ATGC[c->np.next() & 3u];
         } else if (m.type == MSIM_TLI) {                             // mutator.py:401-421, draws nothing
             // Mutation.start / stop of the linked TL span; an unlinked TLI keeps start = pos, stop = 0
             const int64_t src = m.linked ? m.src : m.pos;
