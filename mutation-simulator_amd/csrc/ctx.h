@@ -82,6 +82,14 @@ struct HostPlan {
     bool empty = true;
 };
 int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out);
+// The boundary pass (mutator.py:184-265) of ONE range restricted to its non-SNP candidates -- the only
+// stage of an SV-mix plan that is a true sequential chain.  pos/type: the candidates in
+// position order; words: tempered CPython-stream words from the current position on.  stop[j] receives
+// Mutation.stop, or CHAIN_DROPPED for a candidate that is blocked / dropped.  Valid when
+// block[SN] == min(block): an SNP then never blocks a successor, so SNPs cannot influence the chain.
+constexpr uint32_t CHAIN_DROPPED = 0xffffffffu;
+int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
+                        const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept);
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);

@@ -18,5 +18,9 @@ void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words);
 int gpu_plan_finish(Ctx *c, GpuPlan *g);
 bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
+// SV mixes (SNPs + IN/DE/DU/IV on one large range): sample, type draw, filter, records, insert pool and SNP
+// draws on the device; only the boundary chain over the non-SNP candidates runs on the host
+bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
+int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 
 }  // namespace msim

@@ -57,7 +57,9 @@ struct PlanState {
     uint32_t flags;
     uint32_t dups;                 // duplicates found by the first-k insert
     uint32_t accepted_used;        // accepted draws consumed by the last sample
-    uint32_t rsv;
+    uint32_t n_nsn;                // SV mixes: non-SNP candidates of the current range
+    uint32_t n_rec, n_sn;          // SV mixes: kept mutations / kept SNPs of the current contig
+    uint32_t pool_len;             // SV mixes: insert bases of the current contig
 };
 
 // ------------------------------------------------------------------ 1. MT19937 in bulk
@@ -784,7 +786,8 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__rest
                                                           const unsigned long long *__restrict__ base_in, uint32_t W,
                                                           unsigned long long ti_lim,
                                                           const SnpMap *__restrict__ block_maps,
-                                                          msim_record *__restrict__ recs, uint32_t K) {
+                                                          msim_record *__restrict__ recs, uint32_t K,
+                                                          const uint32_t *__restrict__ sn_index) {
     __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     const uint32_t bc = block_maps[blockIdx.x].c[0];
@@ -800,9 +803,347 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__rest
     while (emits && idx < K) {                            // aux: 0 transition, 1/2 transversion column (bit 30)
         const uint32_t i = (uint32_t)__builtin_ctz(emits);
         emits &= emits - 1;
-        recs[idx++].aux = (uint8_t)(((from2 >> i) & 1u) ? 1u + ((m.T >> i) & 1u) : 0u);
+        recs[sn_index ? sn_index[idx] : idx].aux = (uint8_t)(((from2 >> i) & 1u) ? 1u + ((m.T >> i) & 1u) : 0u);
+        idx++;
     }
 }
+
+// ------------------------------------------------------------------ 6. SV mixes: candidates, types, filter
+// A range whose type draw is not deterministic (insertions, deletions, duplications, inversions beside
+// SNPs) still samples its positions as above; what changes is everything after the bitmap:
+//   a. every candidate gets its type from the NumPy stream (2 words each, no rejection: parallel)
+//   b. the NON-SNP candidates are compacted and handed to the host, which runs the boundary pass over
+//      them -- the one stage that is a true sequential chain (plan_host.cpp: chain_boundary_host)
+//   c. back on the device: an SNP is kept iff it lies outside the blocked range of the last kept
+//      non-SNP before it (running maximum of the blocked-range ends), kept candidates are compacted
+//      into the record table, insert bases come from the NumPy stream by prefix sum of the insert
+//      lengths, and the kept SNPs' draws run through the transducer of section 5.
+constexpr int CB_THREADS = 256;
+constexpr int CB_ITEMS = 8;
+constexpr int CB_BLOCK = CB_THREADS * CB_ITEMS;          // 2048 candidates per workgroup
+constexpr uint8_t KEEP_BIT = 0x80;
+
+struct TypeTable { unsigned long long thr[8]; uint32_t n; uint8_t type[8]; };   // msim_range.cdf_thr / .types
+struct BlockTable { uint32_t p1[8]; };                   // block[t] + 1 (saturated), indexed by MSIM_* id
+
+// exclusive prefix over the workgroup (sum / max); wsum: one word per wave
+__device__ __forceinline__ uint32_t block_scan_add(uint32_t v, uint32_t *wsum, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    total = 0;
+    for (int w = 0; w < CB_THREADS / 64; w++) {
+        if (w < wave) pre += wsum[w];
+        total += wsum[w];
+    }
+    __syncthreads();
+    return pre + incl - v;
+}
+__device__ __forceinline__ uint32_t block_scan_max(uint32_t v, uint32_t *wsum, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl = max(incl, t);
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    total = 0;
+    for (int w = 0; w < CB_THREADS / 64; w++) {
+        if (w < wave) pre = max(pre, wsum[w]);
+        total = max(total, wsum[w]);
+    }
+    uint32_t ex = __shfl_up(incl, 1, 64);
+    if (lane == 0) ex = 0;
+    __syncthreads();
+    return max(pre, ex);
+}
+
+// bitmap -> candidate i of the range: pos = start + value + d * rank (util.py:104-109), type from
+// numpy.random.choice(p=...) = searchsorted(cdf, u, 'right') on the 53-bit sample of words 2i, 2i+1
+// (mutator.py:170-174)
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand_cand(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                                   const uint32_t *__restrict__ block_off,
+                                                                   uint32_t start, uint32_t d,
+                                                                   const uint32_t *__restrict__ np_raw,
+                                                                   unsigned long long np_base, TypeTable tt,
+                                                                   uint32_t *__restrict__ cand_pos,
+                                                                   uint8_t *__restrict__ cand_type) {
+    __shared__ uint32_t part[BM_THREADS];
+    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+    uint64_t w = i < n_words ? bm[i] : 0;
+    const uint32_t c = (uint32_t)__popcll(w);
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < BM_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t rank = block_off[blockIdx.x] + part[threadIdx.x] - c;
+    while (w) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+        w &= w - 1;
+        const uint32_t a = mt_temper(np_raw[np_base + 2ull * rank]);
+        const uint32_t b = mt_temper(np_raw[np_base + 2ull * rank + 1]);
+        const unsigned long long m = ((unsigned long long)(a >> 5) << 26) | (b >> 6);
+        uint32_t idx = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) idx += ((uint32_t)j < tt.n && tt.thr[j] <= m) ? 1u : 0u;
+        if (idx >= tt.n) idx = tt.n - 1;                 // unreachable: cdf[-1] == 1.0 > u
+        cand_pos[rank] = start + (i * 64 + bit) + d * rank;
+        cand_type[rank] = tt.type[idx];
+        rank++;
+    }
+}
+
+__global__ __launch_bounds__(CB_THREADS) void k_nsn_count(const uint8_t *__restrict__ cand_type, uint32_t k,
+                                                          uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++)
+        if (i0 + q < k && cand_type[i0 + q] != MSIM_SN) c++;
+    uint32_t total;
+    (void)block_scan_add(c, wsum, total);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CB_THREADS) void k_nsn_scatter(const uint32_t *__restrict__ cand_pos,
+                                                            const uint8_t *__restrict__ cand_type, uint32_t k,
+                                                            const uint32_t *__restrict__ off, uint32_t n_blocks,
+                                                            uint32_t *__restrict__ nsn_pos, uint8_t *__restrict__ nsn_type,
+                                                            uint32_t *__restrict__ nsn_rank, PlanState *__restrict__ ps) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint8_t t[CB_ITEMS];
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)MSIM_SN;
+        c += t[q] != MSIM_SN ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t j = off[blockIdx.x] + block_scan_add(c, wsum, total);
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (t[q] != MSIM_SN) {
+            nsn_pos[j] = cand_pos[i0 + q];
+            nsn_type[j] = t[q];
+            nsn_rank[j] = i0 + q;
+            j++;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps->n_nsn = off[n_blocks];
+}
+
+// tempered words of the window the boundary chain may consume (D2H staging)
+__global__ __launch_bounds__(256) void k_temper_window(const uint32_t *__restrict__ raw, unsigned long long p0,
+                                                       uint32_t n, uint32_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = mt_temper(raw[p0 + i]);
+}
+
+__global__ __launch_bounds__(256) void k_stop_scatter(const uint32_t *__restrict__ nsn_rank,
+                                                      const uint32_t *__restrict__ nsn_stop, uint32_t n_nsn,
+                                                      uint32_t *__restrict__ cand_stop) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_nsn) cand_stop[nsn_rank[j]] = nsn_stop[j];
+}
+
+// end (exclusive) of the blocked range a kept non-SNP opens: [pos, stop + block] resp. [pos, pos + block]
+// for an insertion (mutator.py:204-209); 0 for everything else
+__device__ __forceinline__ uint32_t blocked_end(uint32_t pos, uint8_t type, uint32_t stop, const BlockTable &bt) {
+    if (type == MSIM_SN || stop == CHAIN_DROPPED) return 0;
+    const unsigned long long e = (unsigned long long)(type == MSIM_IN ? pos : stop) + bt.p1[type & 7];
+    return e > 0xffffffffull ? 0xffffffffu : (uint32_t)e;
+}
+
+__global__ __launch_bounds__(CB_THREADS) void k_blk_reduce(const uint32_t *__restrict__ cand_pos,
+                                                           const uint8_t *__restrict__ cand_type,
+                                                           const uint32_t *__restrict__ cand_stop, uint32_t k,
+                                                           BlockTable bt, uint32_t *__restrict__ bmax) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (i0 + q < k) {
+            const uint8_t t = cand_type[i0 + q];
+            if (t != MSIM_SN) m = max(m, blocked_end(cand_pos[i0 + q], t, cand_stop[i0 + q], bt));
+        }
+    }
+    uint32_t total;
+    (void)block_scan_max(m, wsum, total);
+    if (threadIdx.x == 0) bmax[blockIdx.x] = total;
+}
+
+// exclusive running maximum of a[0..n) in place; single workgroup
+__global__ __launch_bounds__(1024) void k_scan_max_u32(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? a[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] = max(buf[threadIdx.x], t);
+            __syncthreads();
+        }
+        const uint32_t ex = threadIdx.x ? buf[threadIdx.x - 1] : 0;
+        const uint32_t c = carry, last = buf[1023];
+        if (i < n) a[i] = max(c, ex);
+        __syncthreads();
+        if (threadIdx.x == 0) carry = max(c, last);
+        __syncthreads();
+    }
+}
+
+// keep flags (KEEP_BIT in cand_type) + per-workgroup counts of kept mutations, kept SNPs, insert bases
+__global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__restrict__ cand_pos,
+                                                           uint8_t *__restrict__ cand_type,
+                                                           const uint32_t *__restrict__ cand_stop, uint32_t k,
+                                                           BlockTable bt, const uint32_t *__restrict__ bmax,
+                                                           uint32_t *__restrict__ cnt_keep, uint32_t *__restrict__ cnt_sn,
+                                                           uint32_t *__restrict__ cnt_ins) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint32_t pos[CB_ITEMS], stop[CB_ITEMS], before[CB_ITEMS];
+    uint8_t t[CB_ITEMS];
+    uint32_t run = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        const bool in = i0 + q < k;
+        pos[q] = in ? cand_pos[i0 + q] : 0;
+        t[q] = in ? cand_type[i0 + q] : (uint8_t)0;
+        stop[q] = (in && t[q] != MSIM_SN) ? cand_stop[i0 + q] : CHAIN_DROPPED;
+        before[q] = run;
+        if (in) run = max(run, blocked_end(pos[q], t[q], stop[q], bt));
+    }
+    uint32_t total;
+    const uint32_t pre = max(bmax[blockIdx.x], block_scan_max(run, wsum, total));
+    uint32_t nk = 0, ns = 0, ni = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (i0 + q >= k) continue;
+        bool keep;
+        if (t[q] == MSIM_SN) { keep = pos[q] >= max(pre, before[q]); ns += keep ? 1u : 0u; }   // mutator.py:190-196
+        else { keep = stop[q] != CHAIN_DROPPED; if (keep && t[q] == MSIM_IN) ni += stop[q] - pos[q] + 1; }
+        nk += keep ? 1u : 0u;
+        if (keep) cand_type[i0 + q] = t[q] | KEEP_BIT;
+    }
+    uint32_t tk, ts, ti;
+    (void)block_scan_add(nk, wsum, tk);
+    (void)block_scan_add(ns, wsum, ts);
+    (void)block_scan_add(ni, wsum, ti);
+    if (threadIdx.x == 0) { cnt_keep[blockIdx.x] = tk; cnt_sn[blockIdx.x] = ts; cnt_ins[blockIdx.x] = ti; }
+}
+
+// three exclusive scans in one launch (blockIdx.x selects the array), totals to a[n]; publishes them
+__global__ __launch_bounds__(1024) void k_scan3_u32(uint32_t *__restrict__ a0, uint32_t *__restrict__ a1,
+                                                    uint32_t *__restrict__ a2, uint32_t n, PlanState *__restrict__ ps) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    uint32_t *a = blockIdx.x == 0 ? a0 : blockIdx.x == 1 ? a1 : a2;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? a[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[threadIdx.x], c = carry;
+        if (i < n) a[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a[n] = carry;
+        if (blockIdx.x == 0) ps->n_rec = carry; else if (blockIdx.x == 1) ps->n_sn = carry; else ps->pool_len = carry;
+    }
+}
+
+// kept candidates -> record table (position order), SNP ordinal -> record index, insert pool offsets
+__global__ __launch_bounds__(CB_THREADS) void k_emit_records(const uint32_t *__restrict__ cand_pos,
+                                                             const uint8_t *__restrict__ cand_type,
+                                                             const uint32_t *__restrict__ cand_stop, uint32_t k,
+                                                             const uint32_t *__restrict__ off_keep,
+                                                             const uint32_t *__restrict__ off_sn,
+                                                             const uint32_t *__restrict__ off_ins,
+                                                             msim_record *__restrict__ recs,
+                                                             uint32_t *__restrict__ sn_index) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint8_t t[CB_ITEMS];
+    uint32_t pos[CB_ITEMS], stop[CB_ITEMS];
+    uint32_t nk = 0, ns = 0, ni = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)0;
+        pos[q] = 0; stop[q] = 0;
+        if (t[q] & KEEP_BIT) {
+            pos[q] = cand_pos[i0 + q];
+            const uint8_t ty = t[q] & 7;
+            stop[q] = ty == MSIM_SN ? pos[q] : cand_stop[i0 + q];
+            nk++;
+            if (ty == MSIM_SN) ns++;
+            if (ty == MSIM_IN) ni += stop[q] - pos[q] + 1;
+        }
+    }
+    uint32_t tot;
+    uint32_t r = off_keep[blockIdx.x] + block_scan_add(nk, wsum, tot);
+    uint32_t s = off_sn[blockIdx.x] + block_scan_add(ns, wsum, tot);
+    uint32_t p = off_ins[blockIdx.x] + block_scan_add(ni, wsum, tot);
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (!(t[q] & KEEP_BIT)) continue;
+        const uint8_t ty = t[q] & 7;
+        msim_record rec;
+        rec.pos = pos[q]; rec.stop = stop[q]; rec.extra = 0; rec.type = ty; rec.aux = 0; rec.rsv = 0;
+        if (ty == MSIM_SN) sn_index[s++] = r;
+        if (ty == MSIM_IN) { rec.extra = p; p += stop[q] - pos[q] + 1; }
+        recs[r++] = rec;
+    }
+}
+
+// insert bases: "ATGC"[word & 3], one NumPy-stream word per base, in position order (mutator.py:465-471)
+__global__ __launch_bounds__(256) void k_pool_fill(const uint32_t *__restrict__ np_raw, unsigned long long np_base,
+                                                   uint32_t pool_len, uint8_t *__restrict__ pool) {
+    const uint32_t g = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (g >= pool_len) return;
+    uint32_t x = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t w = g + q < pool_len ? mt_temper(np_raw[np_base + g + q]) : 0u;
+        x |= (uint32_t)("ATGC"[w & 3u]) << (8 * q);
+    }
+    *reinterpret_cast<uint32_t *>(pool + g) = x;         // the pool buffer is padded: whole dwords are in bounds
+}
+
+__global__ void k_set_pos(PlanState *ps, unsigned long long pos) { ps->pos = pos; ps->snp_base = pos; }
 
 // single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
 __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
@@ -811,7 +1152,8 @@ __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restric
 }
 
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
-    ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0; ps->rsv = 0;
+    ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0;
+    ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;
 }
 
 }  // namespace
@@ -852,8 +1194,29 @@ struct SnpSet {                          // scratch of one contig's SNP draws
     bool pending = false;
 };
 
+struct MixedSet {                        // scratch of one SV-mix range (section 6)
+    uint32_t *cand_pos = nullptr; size_t cap_pos = 0;     // candidates in position order
+    uint8_t *cand_type = nullptr; size_t cap_type = 0;    // MSIM_* id | KEEP_BIT
+    uint32_t *cand_stop = nullptr; size_t cap_stop = 0;   // non-SNP candidates: stop from the host chain
+    uint32_t *nsn_pos = nullptr; size_t cap_npos = 0;     // compacted non-SNP candidates
+    uint8_t *nsn_type = nullptr; size_t cap_ntype = 0;
+    uint32_t *nsn_rank = nullptr; size_t cap_nrank = 0;   // their candidate index
+    uint32_t *nsn_stop = nullptr; size_t cap_nstop = 0;
+    uint32_t *sn_index = nullptr; size_t cap_snidx = 0;   // kept-SNP ordinal -> record index
+    uint32_t *cnt = nullptr; size_t cap_cnt = 0;          // five per-workgroup counter arrays
+    uint32_t *words = nullptr; size_t cap_words = 0;      // tempered word window for the host chain
+    hipEvent_t emit_done = nullptr;
+    bool pending = false;
+};
+
 struct GpuPlan {
     GpuStream s[2];
+    MixedSet mixed[N_SETS];
+    uint32_t mixed_unit = 0;
+    uint32_t *h_words = nullptr; size_t cap_h_words = 0;  // pinned host staging of the boundary chain
+    uint32_t *h_npos = nullptr; size_t cap_h_npos = 0;
+    uint8_t *h_ntype = nullptr; size_t cap_h_ntype = 0;
+    uint32_t *h_nstop = nullptr; size_t cap_h_nstop = 0;
     hipStream_t gen_stream = nullptr;   // chunk generation (latency-bound, ~300 us per batch)
     hipStream_t jump_stream = nullptr;  // jump cascade: never waits for a generation batch
     std::vector<hipEvent_t> ev_pool;
@@ -913,6 +1276,14 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (t.base) (void)hipFree(t.base);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
+    for (auto &t : g->mixed) {
+        void *bufs[] = {t.cand_pos, t.cand_type, t.cand_stop, t.nsn_pos, t.nsn_type, t.nsn_rank, t.nsn_stop, t.sn_index,
+                        t.cnt, t.words};
+        for (void *b : bufs) if (b) (void)hipFree(b);
+        if (t.emit_done) (void)hipEventDestroy(t.emit_done);
+    }
+    void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop};
+    for (void *b : hb) if (b) (void)hipHostFree(b);
     for (auto e : g->chain_ev) if (e) (void)hipEventDestroy(e);
     if (g->t0) (void)hipEventDestroy(g->t0);
     if (g->t1) (void)hipEventDestroy(g->t1);
@@ -966,6 +1337,7 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
             MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));
             MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));     // record emission reads the word arrays too
             if (want_states > s.states_cap) {
                 uint32_t *ns = nullptr;
                 MSIM_HIP(c, hipMalloc(&ns, (size_t)want_states * MT_N * sizeof(uint32_t)));
@@ -1136,6 +1508,7 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
     g->unverified = false;
     for (auto &t : g->sample) t.pending = false;
     for (auto &t : g->snp) t.pending = false;
+    for (auto &t : g->mixed) t.pending = false;
     const PlanState h = *g->h_mail;
     if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
         g->s[0].live = g->s[1].live = false;
@@ -1151,6 +1524,74 @@ static hipEvent_t next_chain_event(GpuPlan *g) {
     hipEvent_t &e = g->chain_ev[g->chain_i++ % (2 * N_SETS)];
     if (!e) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
     return e;
+}
+
+// Enqueue the chain of one sampled range on the plan stream: where does random.sample() end (exact stream
+// cut in the device PlanState) and which values did it draw (the set, as a bitmap in S.bitmap).
+struct SampleLaunch { SampleSet *S; uint32_t W, bmw, bnb; };
+static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t d, uint64_t pos_hi, bool &grew,
+                                SampleLaunch &out) {
+    GpuStream &py = g->s[0];
+    int rc;
+    const uint32_t k = (uint32_t)r.k;
+    const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
+    const int bits = bit_length64(n);
+    const double p_acc = (double)n / (double)(1ull << bits);
+    // accepted draws needed ~ -n ln(1 - k/n) (coupon collector); window = that / p_acc, 16-sigma margins
+    const double need_acc = -(double)n * std::log1p(-(double)k / (double)n);
+    const double target = need_acc + 16.0 * std::sqrt(need_acc) + 4096.0;
+    const double wd = target / p_acc + 16.0 * std::sqrt(target) / p_acc + 8192.0;
+    if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
+    const uint32_t W = (uint32_t)wd;
+    SampleSet &S = g->sample[g->unit++ % N_SETS];
+    if (S.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, S.emit_done, 0));   // its last emit still reads it
+    const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
+    const size_t bm_words64 = (size_t)((n + 63) / 64);
+    const uint32_t bmw = (uint32_t)bm_words64;
+    const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
+    if ((rc = grow(c, (void **)&S.cnt, &S.cnt_cap, (size_t)(nb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.acc, &S.acc_cap, (size_t)W * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, bm_words64 * 8, &grew))) return rc;
+    if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
+    if ((rc = ensure_words(c, g, 0, pos_hi + W + 1))) return rc;
+    // ---- chain (plan stream): where does this sample end?
+    const uint32_t n_bins = (uint32_t)((n + BIN_VALUES - 1) >> BIN_SHIFT);
+    const bool binned = n_bins <= (uint32_t)MAX_BINS;
+    hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                       (uint32_t)(32 - bits), (uint32_t)n, S.cnt, g->d_ps);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
+    if (binned) {
+        // expected k/n_bins per bin (the last bin is partial), 16-sigma + slack capacity
+        // sub-list s of a bin is filled by the scatter workgroups with index == s (mod 16).  Only the
+        // workgroups up to the one holding the k-th accepted draw contribute (the window has slack
+        // behind it), each at most 8192 * p_acc draws, of which the bin's share is min(1, 2^20 / n).
+        const uint32_t nbk = (uint32_t)((double)k / p_acc / SPL_BLOCK) + 3;
+        const double mean = (double)((nbk + BIN_SUBS - 1) / BIN_SUBS) * SPL_BLOCK * p_acc *
+                            std::min(1.0, (double)BIN_VALUES / (double)n);
+        const uint32_t bin_cap = (uint32_t)std::min<double>((double)k + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
+        if ((rc = grow(c, (void **)&S.bins, &S.bins_cap, (size_t)n_bins * BIN_SUBS * bin_cap * sizeof(uint32_t), &grew))) return rc;
+        if ((rc = grow(c, (void **)&S.cursors, &S.cursors_cap, (size_t)MAX_BINS * BIN_SUBS * sizeof(uint32_t), &grew))) return rc;
+        if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, (size_t)n_bins * BIN_WORDS * 4, &grew))) return rc;
+        MSIM_HIP(c, hipMemsetAsync(S.cursors, 0, (size_t)n_bins * BIN_SUBS * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc,
+                           g->d_ps);
+        hipLaunchKernelGGL(k_bin_dedupe, dim3(n_bins), dim3(512), 0, c->stream, S.bins, S.cursors, bin_cap, S.bitmap,
+                           g->d_ps);
+        hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, k, S.cnt, nb, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
+    } else {
+        MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
+        hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, S.cnt, S.acc);
+        hipLaunchKernelGGL(k_bitmap_insert, dim3((k + 1023) / 1024), dim3(256), 0, c->stream, S.acc, k, S.bitmap, g->d_ps);
+        hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, 0u, S.cnt, nb, W,
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
+    }
+    MSIM_HIP(c, hipGetLastError());
+    out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
+    return MSIM_OK;
 }
 
 // Asynchronous: enqueues the contig's chain (stream positions) on the plan stream and its emit work
@@ -1197,62 +1638,10 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         const msim_range &r = ranges[i];
         if (r.k == 0) continue;
         const uint32_t k = (uint32_t)r.k;
-        const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
-        const int bits = bit_length64(n);
-        const double p_acc = (double)n / (double)(1ull << bits);
-        // accepted draws needed ~ -n ln(1 - k/n) (coupon collector); window = that / p_acc, 16-sigma margins
-        const double need_acc = -(double)n * std::log1p(-(double)k / (double)n);
-        const double target = need_acc + 16.0 * std::sqrt(need_acc) + 4096.0;
-        const double wd = target / p_acc + 16.0 * std::sqrt(target) / p_acc + 8192.0;
-        if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
-        const uint32_t W = (uint32_t)wd;
-        SampleSet &S = g->sample[g->unit++ % N_SETS];
-        if (S.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, S.emit_done, 0));   // its last emit still reads it
-        const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
-        const size_t bm_words64 = (size_t)((n + 63) / 64);
-        const uint32_t bmw = (uint32_t)bm_words64;
-        const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
-        if ((rc = grow(c, (void **)&S.cnt, &S.cnt_cap, (size_t)(nb + 2) * sizeof(uint32_t), &grew))) return rc;
-        if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
-        if ((rc = grow(c, (void **)&S.acc, &S.acc_cap, (size_t)W * sizeof(uint32_t), &grew))) return rc;
-        if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, bm_words64 * 8, &grew))) return rc;
-        if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
-        if ((rc = ensure_words(c, g, 0, pos_hi + W + 1))) return rc;
-        // ---- chain (plan stream): where does this sample end?
-        const uint32_t n_bins = (uint32_t)((n + BIN_VALUES - 1) >> BIN_SHIFT);
-        const bool binned = n_bins <= (uint32_t)MAX_BINS;
-        hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                           (uint32_t)(32 - bits), (uint32_t)n, S.cnt, g->d_ps);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
-        if (binned) {
-            // expected k/n_bins per bin (the last bin is partial), 16-sigma + slack capacity
-            // sub-list s of a bin is filled by the scatter workgroups with index == s (mod 16).  Only the
-            // workgroups up to the one holding the k-th accepted draw contribute (the window has slack
-            // behind it), each at most 8192 * p_acc draws, of which the bin's share is min(1, 2^20 / n).
-            const uint32_t nbk = (uint32_t)((double)k / p_acc / SPL_BLOCK) + 3;
-            const double mean = (double)((nbk + BIN_SUBS - 1) / BIN_SUBS) * SPL_BLOCK * p_acc *
-                                std::min(1.0, (double)BIN_VALUES / (double)n);
-            const uint32_t bin_cap = (uint32_t)std::min<double>((double)k + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
-            if ((rc = grow(c, (void **)&S.bins, &S.bins_cap, (size_t)n_bins * BIN_SUBS * bin_cap * sizeof(uint32_t), &grew))) return rc;
-            if ((rc = grow(c, (void **)&S.cursors, &S.cursors_cap, (size_t)MAX_BINS * BIN_SUBS * sizeof(uint32_t), &grew))) return rc;
-            if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, (size_t)n_bins * BIN_WORDS * 4, &grew))) return rc;
-            MSIM_HIP(c, hipMemsetAsync(S.cursors, 0, (size_t)n_bins * BIN_SUBS * sizeof(uint32_t), c->stream));
-            hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, k, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc,
-                               g->d_ps);
-            hipLaunchKernelGGL(k_bin_dedupe, dim3(n_bins), dim3(512), 0, c->stream, S.bins, S.cursors, bin_cap, S.bitmap,
-                               g->d_ps);
-            hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, k, S.cnt, nb, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
-        } else {
-            MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
-            hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, S.cnt, S.acc);
-            hipLaunchKernelGGL(k_bitmap_insert, dim3((k + 1023) / 1024), dim3(256), 0, c->stream, S.acc, k, S.bitmap, g->d_ps);
-            hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, py.d_raw, S.acc, 0u, S.cnt, nb, W,
-                               (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, g->d_ps);
-        }
-        MSIM_HIP(c, hipGetLastError());
+        SampleLaunch sl;
+        if ((rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl))) return rc;
+        SampleSet &S = *sl.S;
+        const uint32_t W = sl.W, bmw = sl.bmw, bnb = sl.bnb;
         hipEvent_t ce = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(ce, c->stream));
         // ---- emit (emit stream): the bitmap is the sorted sample -> records
@@ -1290,7 +1679,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         MSIM_HIP(c, hipEventRecord(ce, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
         hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K);
+                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K, (const uint32_t *)nullptr);
         MSIM_HIP(c, hipGetLastError());
         MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
         T.pending = true;
@@ -1299,6 +1688,253 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     py.pos = pos_hi;                                       // bound until gpu_plan_finish reads the exact value
     g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k): 2 words per candidate
     c->t.np_words += 2 * K;
+    g->unverified = true;
+    ct.planned = true;
+    return MSIM_OK;
+}
+
+// ====================================================================== SV mixes (section 6 kernels)
+static int grow_host(Ctx *c, void **p, size_t *cap, size_t want_bytes) {
+    if (*cap >= want_bytes) return MSIM_OK;
+    if (*p) MSIM_HIP(c, hipHostFree(*p));
+    *p = nullptr; *cap = 0;
+    const size_t sz = want_bytes + want_bytes / 4 + 4096;
+    MSIM_HIP(c, hipHostMalloc(p, sz, hipHostMallocDefault));
+    *cap = sz;
+    return MSIM_OK;
+}
+
+// Which non-SNP types can the type draw of this range produce?  (thresholds are cumulative: entry j is
+// drawn iff thr[j-1] < thr[j], with thr[-1] = 0, and only below 2^53)
+static bool range_type_drawable(const msim_range &r, int j) {
+    const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+    return r.cdf_thr[j] > lo && lo < (1ull << 53);
+}
+
+// SV mix on one large set-path range (ARGS mode: one range per contig): SNPs plus any of IN/DE/DU/IV.
+bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    if (P.block[MSIM_SN] != d) return false;              // an SNP could block its successor: the chain needs all candidates
+    const msim_range *one = nullptr;
+    for (int i = 0; i < n_ranges; i++) {
+        if (ranges[i].k == 0) continue;
+        if (one) return false;                            // several drawing ranges: host planner
+        one = &ranges[i];
+    }
+    if (!one) return false;
+    const msim_range &r = *one;
+    if (r.k < 4096 || r.k >= (1ll << 31)) return false;
+    const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+    if (n < r.k || n <= r.setsize || n >= (1ll << 32)) return false;
+    if (r.start < 0 || r.stop >= (1ll << 32)) return false;
+    if (r.n_types < 1 || r.n_types > 8) return false;
+    for (int j = 0; j < r.n_types; j++) {
+        if (!range_type_drawable(r, j)) continue;
+        const int t = r.types[j];
+        if (t == MSIM_SN) continue;
+        if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return false;   // TL / TLI: host planner
+        const int64_t w = r.max_len[t] - r.min_len[t] + 1;
+        if (r.min_len[t] < 1 || w < 1 || w >= (1ll << 32)) return false;
+        if (t == MSIM_IN && (double)r.k * (double)r.max_len[t] >= 4.0e9) return false;     // insert pool offsets are 32-bit
+    }
+    for (int t = 1; t <= 7; t++)
+        if (P.block[t] >= (1ll << 32)) return false;
+    return true;
+}
+
+// plan stream drained: exact stream position + counts from the mailbox, chain time accounted
+static int mixed_sync(Ctx *c, GpuPlan *g, PlanState &h) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
+    c->t.plan_gpu_ms += ms;
+    h = *g->h_mail;
+    if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
+        g->s[0].live = g->s[1].live = false;
+        g->unverified = false;
+        return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its 16-sigma margin (results discarded)");
+    }
+    c->t.py_words += h.pos - g->verified_pos;
+    g->verified_pos = h.pos;
+    g->s[0].pos = h.pos;
+    MSIM_HIP(c, hipEventRecord(g->t0, c->stream));        // the next span starts here
+    return MSIM_OK;
+}
+
+int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    const msim_range *rp = nullptr;
+    for (int i = 0; i < n_ranges; i++) if (ranges[i].k) rp = &ranges[i];
+    const msim_range &r = *rp;
+    const uint32_t k = (uint32_t)r.k;
+    int rc;
+    if ((rc = stream_to_device(c, g, 0))) return rc;
+    if ((rc = stream_to_device(c, g, 1))) return rc;
+    if (!g->d_ps) MSIM_HIP(c, hipMalloc(&g->d_ps, sizeof(PlanState)));
+    if (!g->h_mail) MSIM_HIP(c, hipHostMalloc(&g->h_mail, sizeof(PlanState), hipHostMallocMapped));
+    GpuStream &py = g->s[0], &np = g->s[1];
+    if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
+    if (!g->unverified) MSIM_HIP(c, hipEventRecord(g->t0, c->stream));
+    if (!g->ps_valid) {
+        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)py.pos);
+        g->ps_valid = true;
+    }
+    g->unverified = true;
+    bool grew = false;
+    MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
+    if (M.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, M.emit_done, 0));   // its last emit still reads it
+    if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
+    const uint32_t nbk = (k + CB_BLOCK - 1) / CB_BLOCK;
+    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)k * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cand_type, &M.cap_type, (size_t)k + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cand_stop, &M.cap_stop, (size_t)k * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_pos, &M.cap_npos, (size_t)k * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_type, &M.cap_ntype, (size_t)k + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_rank, &M.cap_nrank, (size_t)k * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)k * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)k * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, (size_t)5 * (nbk + 2) * 4, &grew))) return rc;
+    uint32_t *cnt_nsn = M.cnt, *bmax = M.cnt + (nbk + 2), *cnt_keep = M.cnt + 2 * (nbk + 2),
+             *cnt_sn = M.cnt + 3 * (nbk + 2), *cnt_ins = M.cnt + 4 * (nbk + 2);
+
+    // ---- 1. sample -> bitmap; bitmap -> candidates with types; non-SNP candidates compacted
+    SampleLaunch sl;
+    if ((rc = enqueue_sample_chain(c, g, r, d, py.pos, grew, sl))) return rc;
+    SampleSet &S = *sl.S;
+    const uint64_t np_base = np.pos;                       // exact: the NumPy stream never rejects
+    if ((rc = ensure_words(c, g, 1, np_base + 2ull * k + 1))) return rc;
+    TypeTable tt{};
+    tt.n = (uint32_t)r.n_types;
+    for (int j = 0; j < r.n_types; j++) { tt.thr[j] = r.cdf_thr[j]; tt.type[j] = (uint8_t)r.types[j]; }
+    hipLaunchKernelGGL(k_bitmap_count, dim3(sl.bnb), dim3(BM_THREADS), 0, c->stream,
+                       reinterpret_cast<const uint64_t *>(S.bitmap), sl.bmw, S.cnt2);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt2, sl.bnb);
+    hipLaunchKernelGGL(k_bitmap_expand_cand, dim3(sl.bnb), dim3(BM_THREADS), 0, c->stream,
+                       reinterpret_cast<const uint64_t *>(S.bitmap), sl.bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
+                       np.d_raw, (unsigned long long)np_base, tt, M.cand_pos, M.cand_type);
+    hipLaunchKernelGGL(k_nsn_count, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_type, k, cnt_nsn);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, cnt_nsn, nbk);
+    hipLaunchKernelGGL(k_nsn_scatter, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, k, cnt_nsn, nbk,
+                       M.nsn_pos, M.nsn_type, M.nsn_rank, g->d_ps);
+    MSIM_HIP(c, hipGetLastError());
+    S.pending = false;                                     // consumed on the plan stream itself
+    PlanState h;
+    if ((rc = mixed_sync(c, g, h))) return rc;
+    const uint32_t n_nsn = h.n_nsn;
+    const uint64_t p_b = h.pos;                            // the boundary pass draws from here
+    np.pos = np_base + 2ull * k;
+    c->t.np_words += 2ull * k;
+
+    // ---- 2. the sequential chain over the non-SNP candidates, on the host
+    size_t consumed = 0, kept_nsn = 0;
+    if (n_nsn) {
+        double acc_min = 1.0;
+        for (int t = 1; t <= 7; t++) {
+            const int64_t w = r.max_len[t] - r.min_len[t] + 1;
+            if (w >= 1 && w < (1ll << 32)) acc_min = std::min(acc_min, (double)w / (double)(1ull << bit_length64((uint64_t)w)));
+        }
+        const double wb = (double)n_nsn / acc_min + 16.0 * std::sqrt((double)n_nsn) / acc_min + 4096.0;
+        if (wb >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "boundary window beyond 2^32 words");
+        const uint32_t Wb = (uint32_t)wb;
+        if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)Wb * 4, &grew))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)Wb * 4))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)n_nsn * 4))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_ntype, &g->cap_h_ntype, (size_t)n_nsn))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_nstop, &g->cap_h_nstop, (size_t)n_nsn * 4))) return rc;
+        if ((rc = ensure_words(c, g, 0, p_b + Wb + 1))) return rc;
+        hipLaunchKernelGGL(k_temper_window, dim3((Wb + 255) / 256), dim3(256), 0, c->stream, py.d_raw,
+                           (unsigned long long)p_b, Wb, M.words);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipMemcpyAsync(g->h_npos, M.nsn_pos, (size_t)n_nsn * 4, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_nsn, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)Wb * 4, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop, &consumed, &kept_nsn);
+        if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
+        MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_nsn * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_stop_scatter, dim3((n_nsn + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_stop, n_nsn,
+                           M.cand_stop);
+    }
+    const uint64_t p_s = p_b + consumed;                   // the SNP draws of __mutate_sequence start here
+    hipLaunchKernelGGL(k_set_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)p_s);
+
+    // ---- 3. keep flags, counts
+    BlockTable bt{};
+    for (int t = 1; t <= 7; t++) bt.p1[t] = (uint32_t)std::min<int64_t>(P.block[t] + 1, 0xffffffffll);
+    hipLaunchKernelGGL(k_blk_reduce, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt, bmax);
+    hipLaunchKernelGGL(k_scan_max_u32, dim3(1), dim3(1024), 0, c->stream, bmax, nbk);
+    hipLaunchKernelGGL(k_keep_flags, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt,
+                       bmax, cnt_keep, cnt_sn, cnt_ins);
+    hipLaunchKernelGGL(k_scan3_u32, dim3(3), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, nbk, g->d_ps);
+    MSIM_HIP(c, hipGetLastError());
+    if ((rc = mixed_sync(c, g, h))) return rc;
+    const uint32_t n_rec = h.n_rec, n_sn = h.n_sn, pool_len = h.pool_len;
+
+    // ---- 4. records, insert pool, SNP draws
+    {   // the record table / pool may still be read by an earlier apply of this contig
+        const size_t want = std::max<uint64_t>(n_rec, 1) * sizeof(msim_record);
+        if (ct.cap_recs < want || ct.cap_pool < pool_len + 2 * PAD) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        }
+        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, pool_len + 2 * PAD))) return rc;
+    }
+    ct.n_rec = n_rec;
+    ct.pool_len = pool_len;
+    ct.plan_empty = n_rec == 0;
+    ct.all_snp = kept_nsn == 0;
+    if (pool_len && (rc = ensure_words(c, g, 1, np.pos + pool_len + 1))) return rc;
+    uint64_t pos_hi = p_s;
+    hipEvent_t ce = next_chain_event(g);
+    MSIM_HIP(c, hipEventRecord(ce, c->stream));
+    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+    hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
+                       cnt_keep, cnt_sn, cnt_ins, ct.d_recs, M.sn_index);
+    if (pool_len)
+        hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
+                           (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
+    MSIM_HIP(c, hipGetLastError());
+    np.pos += pool_len;
+    c->t.np_words += pool_len;
+    if (n_sn) {                                            // SNP draws of the kept SNPs, in position order
+        const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
+        const double w2 = (double)n_sn * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)n_sn) + 16384.0;
+        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
+        const uint32_t W2 = (uint32_t)w2;
+        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
+        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
+        if (T.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, T.emit_done, 0));
+        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
+        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
+        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
+        if ((rc = ensure_words(c, g, 0, p_s + W2 + 1))) return rc;
+        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps);
+        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2, n_sn);
+        hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps, nb2, n_sn, T.base);
+        MSIM_HIP(c, hipGetLastError());
+        hipEvent_t ce2 = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce2, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce2, 0));
+        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
+                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, n_sn, (const uint32_t *)M.sn_index);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+        T.pending = true;
+        pos_hi += W2;
+    }
+    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
+    M.pending = true;
+    py.pos = pos_hi;                                       // bound until the next sync reads the exact value
     g->unverified = true;
     ct.planned = true;
     return MSIM_OK;

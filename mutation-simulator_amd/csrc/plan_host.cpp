@@ -110,6 +110,53 @@ int sample_sorted(Ctx *c, HostMT &g, int64_t n, int64_t k, int64_t setsize, std:
 
 }  // namespace
 
+int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
+                        const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const msim_params &P = c->params;
+    const int64_t last = (int64_t)L - 1;
+    // per type: getrandbits shift + width of randint(pos+min-1, pos+max-1), offset, extent rules
+    int sh[8] = {0};
+    uint64_t width[8] = {0};
+    int64_t add[8] = {0}, blk1[8] = {0};
+    for (int t = 1; t <= 7; t++) {
+        const int64_t w = r.max_len[t] - r.min_len[t] + 1;
+        if (w < 0 || w >= (1ll << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "randint range of 2^32 or more values");
+        width[t] = (uint64_t)w;
+        sh[t] = 32 - bit_length64((uint64_t)w);
+        add[t] = r.min_len[t] - 1;
+        blk1[t] = 1 + P.block[t];
+    }
+    const int64_t iv_reach = r.max_len[MSIM_IV];
+    size_t w = 0, nk = 0;
+    int64_t blk_hi = 0;                                              // last_mut_range = range(0)
+    for (size_t j = 0; j < n; j++) {
+        const int64_t p = pos[j];
+        if (p < blk_hi) { stop[j] = CHAIN_DROPPED; continue; }       // mutator.py:190-191
+        const int t = type[j];
+        if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV)
+            return fail(c, MSIM_ERR_ARG, "chain_boundary_host: type outside IN/DE/DU/IV");
+        if (t == MSIM_IV && p + iv_reach >= last) { stop[j] = CHAIN_DROPPED; continue; }   // mutator.py:240-245
+        uint64_t v = 0;
+        if (width[t]) {                                              // _randbelow_with_getrandbits
+            do {
+                if (w >= n_words) return fail(c, MSIM_ERR_HIP, "boundary chain: word window overflowed its margin");
+                v = words[w++] >> sh[t];
+            } while (v >= width[t]);
+        }
+        int64_t s = p + add[t] + (int64_t)v;
+        if ((t == MSIM_DU || t == MSIM_DE) && s > last) s = last;    // mutator.py:253-264
+        if (s < 0 || s >= (int64_t)CHAIN_DROPPED) return fail(c, MSIM_ERR_UNSUPPORTED, "mutation extent beyond 2^32");
+        stop[j] = (uint32_t)s;
+        blk_hi = (t == MSIM_IN ? p : s) + blk1[t];
+        nk++;
+    }
+    *consumed = w;
+    *kept = nk;
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
 int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out) {
     const auto t0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;

@@ -56,27 +56,30 @@ def _run(flags, contigs, params, seed=(42, 42)):
         cid = eng.add_contig_synthetic(L, 7)
         eng.plan_contig(cid, ranges)
         recs, pool = eng.fetch_records(cid)
-        out.append((recs.copy(), eng.plan_was_empty(cid)))
+        out.append((recs.copy(), eng.plan_was_empty(cid), pool.copy()))
     st = eng.stats()
     states = [eng.get_mt_state(0), eng.get_mt_state(1)]
     eng.close()
     return out, states, st
 
 
-def _compare(contigs, params, seed=(42, 42)):
+def _compare(contigs, params, seed=(42, 42), host_chain=False):
     host, hs, hst = _run(_ffi.PLAN_HOST, contigs, params, seed)
     gpu, gs, gst = _run(_ffi.PLAN_GPU, contigs, params, seed)
-    for (hr, he), (gr, ge) in zip(host, gpu):
+    for (hr, he, hpool), (gr, ge, gpool) in zip(host, gpu):
         assert he == ge
         assert hr.shape == gr.shape
         assert np.array_equal(hr["pos"], gr["pos"])
+        assert np.array_equal(hr["type"], gr["type"])
+        assert np.array_equal(hr["stop"], gr["stop"])
         assert np.array_equal(hr["aux"], gr["aux"])
         assert np.array_equal(hr.view(np.uint8), gr.view(np.uint8))
+        assert np.array_equal(hpool, gpool)
     assert hst["py_words"] == gst["py_words"] and hst["np_words"] == gst["np_words"]
     for (hm, hp), (gm, gp) in zip(hs, gs):
         # same stream position: the next outputs agree (the 624-word windows may be cut differently)
         assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
-    assert gst["plan_gpu_ms"] > 0 and gst["plan_host_ms"] == 0
+    assert gst["plan_gpu_ms"] > 0 and (host_chain or gst["plan_host_ms"] == 0)
     return gst
 
 
@@ -146,11 +149,112 @@ def test_auto_mode_mixes_engines_along_one_stream():
                (1_500_000, [_snp_range(0, 1_499_999, 15_000)]), (300_000, [_snp_range(0, 299_999, 3_000)])]
     host, hs, hst = _run(_ffi.PLAN_HOST, contigs, _params(titv=2.0))
     auto, as_, ast = _run(_ffi.PLAN_AUTO, contigs, _params(titv=2.0))
-    for (hr, _), (ar, _) in zip(host, auto):
+    for (hr, _, hpool), (ar, _, apool) in zip(host, auto):
         assert np.array_equal(hr.view(np.uint8), ar.view(np.uint8))
+        assert np.array_equal(hpool, apool)
     for (hm, hp), (am, ap) in zip(hs, as_):
         assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
     assert ast["plan_gpu_ms"] > 0 and ast["plan_host_ms"] > 0
+
+
+# ---------------------------------------------------------------------- SV mixes on the device
+# (sample, type draw, SNP filter, records, insert pool and SNP draws on the GPU; only the boundary chain
+#  over the non-SNP candidates on the host)
+ARGS_ORDER = [1, 2, 3, 5, 4, 6, 7]          # SN, IN, DE, IV, DU, TL, TLI  (rmt.py:443-450)
+
+
+def _sv_range(start, stop, k, chances, lens, order=ARGS_ORDER):
+    """chances: {type id: p}; lens: {type id: (min, max)} -- thresholds built like mutator.range_descriptor."""
+    r = _ffi.Range()
+    r.start, r.stop, r.k = start, stop, k
+    r.setsize = mm.sample_setsize(k)
+    p = np.array([chances.get(t, 0.0) for t in order], dtype=np.float64)
+    cdf = np.cumsum(p / p.sum())
+    cdf /= cdf[-1]
+    r.n_types = len(order)
+    for j, t in enumerate(order):
+        r.types[j] = t
+        r.cdf_thr[j] = mm._ceil_scaled(float(cdf[j]))
+    for t in (2, 3, 4, 6):
+        r.min_len[t], r.max_len[t] = lens.get(t, (1, 2))
+    r.min_len[5], r.max_len[5] = lens.get(5, (2, 3))
+    return r
+
+
+C3_CHANCES = {1: 0.005, 2: 0.001, 3: 0.001, 4: 0.0005, 5: 0.0005}
+C3_LENS = {2: (1, 50), 3: (1, 50), 4: (50, 500), 5: (50, 500)}
+
+
+@pytest.mark.parametrize("L,rate,chances,lens,blocks,titv", [
+    (3_000_000, 0.008, C3_CHANCES, C3_LENS, None, 1.0),                   # BASELINE configs[2] shape
+    (1_000_000, 0.05, C3_CHANCES, C3_LENS, None, 2.0),                    # dense: most candidates blocked
+    (2_000_000, 0.01, {2: 1.0}, {2: (1, 1)}, None, 1.0),                  # insertions only, width-1 randint
+    (2_000_000, 0.01, {3: 0.5, 1: 0.5}, {3: (1, 3000)}, None, 0.0),       # long deletions swallow many candidates
+    (2_500_000, 0.006, {1: 0.2, 4: 0.4, 5: 0.4}, {4: (2, 2000), 5: (2, 2000)}, {"DU": 40, "IV": 7}, 1e9),
+    (2_000_000, 0.02, C3_CHANCES, C3_LENS, {t: 3 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}, 0.5),
+    (600_000, 0.01, {1: 0.1, 5: 0.9}, {5: (2, 400_000)}, None, 1.0),      # IV reach beyond the contig end: dropped undrawn
+    (600_000, 0.01, {1: 0.5, 3: 0.25, 4: 0.25}, {3: (1, 500_000), 4: (1, 500_000)}, None, 1.0),   # DE/DU clamped at the end
+])
+def test_sv_mix_vs_host(L, rate, chances, lens, blocks, titv):
+    k = int(L * rate)
+    _compare([(L, [_sv_range(0, L - 1, k, chances, lens)])], _params(blocks, titv=titv), host_chain=True)
+
+
+def test_sv_mix_rmt_token_order_and_inner_range():
+    """RMT-style chance order (DU, SN, IN) on a range that does not start at 0 nor end at the contig end."""
+    r = _sv_range(200_000, 1_799_999, 16_000, {4: 0.1, 1: 0.6, 2: 0.3}, {4: (5, 90), 2: (1, 12)}, order=[4, 1, 2])
+    _compare([(2_000_000, [r])], _params(titv=2.0), seed=(11, 5), host_chain=True)
+
+
+def test_sv_mix_contig_chain():
+    """SNP-only sampler, SV-mix path and host planner alternate along one pair of streams."""
+    sv = lambda L, rate: _sv_range(0, L - 1, int(L * rate), C3_CHANCES, C3_LENS)
+    contigs = [(2_000_000, [_snp_range(0, 1_999_999, 20_000)]), (3_000_000, [sv(3_000_000, 0.008)]),
+               (1_000_000, [sv(1_000_000, 0.02)]), (300_000, [sv(300_000, 0.008)]),      # k < 4096: host planner
+               (1_500_000, [_snp_range(0, 1_499_999, 15_000)]), (2_000_000, [sv(2_000_000, 0.004)])]
+    host, hs, hst = _run(_ffi.PLAN_HOST, contigs, _params(titv=2.0), (5, 6))
+    auto, as_, ast = _run(_ffi.PLAN_AUTO, contigs, _params(titv=2.0), (5, 6))
+    for (hr, he, hpool), (ar, ae, apool) in zip(host, auto):
+        assert he == ae and np.array_equal(hr.view(np.uint8), ar.view(np.uint8)) and np.array_equal(hpool, apool)
+    assert hst["py_words"] == ast["py_words"] and hst["np_words"] == ast["np_words"]
+    for (hm, hp), (am, ap) in zip(hs, as_):
+        assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
+
+
+def test_full_size_sv_mix_gpu_vs_host_planner():
+    """BASELINE config 3 at full size (3 Gb, 24 contigs, 24 M candidates): records, insert pools and both
+    final stream positions equal the sequential host planner's."""
+    import hashlib
+
+    import bench
+    from test_gpu_fullsize import C3
+    lengths = bench.contig_lengths(3_000_000_000)
+    sim = bench.workload_settings(lengths, snp=0.005, titv=1.0, extra=C3)
+    params = mm.params_descriptor(sim)
+
+    def run(flags):
+        eng = _ffi.Engine(0, flags)
+        eng.seed(42, 42)
+        eng.set_params(params)
+        sums = []
+        for chrom in sim.chromosomes:
+            cid = eng.add_contig_synthetic(lengths[chrom.number], 1)
+            eng.plan_contig(cid, mm.plan_descriptors(chrom))
+            recs, pool = eng.fetch_records(cid)
+            sums.append((len(recs), len(pool), hashlib.sha256(recs.tobytes()).hexdigest(),
+                         hashlib.sha256(pool.tobytes()).hexdigest()))
+            eng.clear()
+        states = [eng.get_mt_state(0), eng.get_mt_state(1)]
+        st = eng.stats()
+        eng.close()
+        return sums, states, st
+
+    hsum, hs, hst = run(_ffi.PLAN_HOST)
+    gsum, gs, gst = run(_ffi.PLAN_GPU)
+    assert hsum == gsum
+    assert hst["py_words"] == gst["py_words"] and hst["np_words"] == gst["np_words"]
+    for (hm, hp), (gm, gp) in zip(hs, gs):
+        assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
 
 
 def test_full_size_genome_gpu_sampler_vs_host_planner():
