@@ -1321,8 +1321,11 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
     const uint64_t have = MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS;
     if (upto > have) {
         // batch the extension: an explicit hint, or what the previous session on this context needed
+        // A generation batch costs ~300 us of latency whatever its size, so never extend piecemeal: take
+        // what the previous session on this context went through, else at least double the stream.
         uint64_t want = std::max<uint64_t>(upto, s.pos + g->reserve_words[si]);
-        if (si == 0) want = std::max<uint64_t>(want, std::min<uint64_t>(s.last_session_words, want * 64));
+        want = std::max<uint64_t>(want, std::min<uint64_t>(s.last_session_words, want * 64));
+        if (s.n_chunks) want = std::max<uint64_t>(want, std::min<uint64_t>(2 * have, (uint64_t)MT_N + (1ull << MT_JUMP_LEVELS) * MT_CHUNK_WORDS));
         const uint32_t need_chunks = (uint32_t)((want - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
         uint32_t want_states = 1;
         int levels = 0;
