@@ -643,8 +643,10 @@ extern uint8_t *ctx_lut(Ctx *c);
 int apply_finish(Ctx *c) {
     if (c->pending_apply.empty()) return MSIM_OK;
     MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-    std::vector<unsigned long long> errs(c->contigs.size());
+    std::vector<unsigned long long> errs(c->contigs.size()), deltas(c->contigs.size());
     MSIM_HIP(c, hipMemcpy(errs.data(), c->d_errs, errs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    MSIM_HIP(c, hipMemcpy(deltas.data(), c->d_errs + MAX_CONTIGS, deltas.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    bool delta_mismatch = false;
     for (int idx : c->pending_apply) {
         if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
         Contig &g = c->contigs[(size_t)idx];
@@ -658,8 +660,10 @@ int apply_finish(Ctx *c) {
         const unsigned long long h_err = errs[(size_t)idx];
         g.key_error = h_err != ~0ull;
         if (g.key_error) { g.key_pos = h_err >> 8; g.key_base = (uint8_t)(h_err & 0xff); g.key_reported = false; }
+        if (g.delta_known && !g.all_snp && g.n_rec && (long long)deltas[(size_t)idx] != g.known_delta) delta_mismatch = true;
     }
     c->pending_apply.clear();
+    if (delta_mismatch) return fail(c, MSIM_ERR_HIP, "internal: planner and device disagree on the mutated length");
     return MSIM_OK;
 }
 
@@ -694,11 +698,22 @@ int apply_contig_device(Ctx *c, Contig &g) {
         hipLaunchKernelGGL(k_delta_reduce, dim3(nb), dim3(THREADS), 0, st, g.d_recs, n, d_sums);
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, d_sums, nb);
         hipLaunchKernelGGL(k_offsets, dim3(nb), dim3(THREADS), 0, st, g.d_recs, n, d_sums, g.d_off);
-        hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, st,
-                           reinterpret_cast<const unsigned long long *>(d_sums + nb), c->h_mail);
         MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipStreamSynchronize(st));
-        total_delta = (long long)*c->h_mail;
+        if (g.delta_known) {
+            // the planner summed the length changes while it ran the boundary chain: no round trip.  The
+            // device total goes to this contig's check word and is compared when the APPLY is collected.
+            total_delta = g.known_delta;
+            hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, st,
+                               reinterpret_cast<const unsigned long long *>(d_sums + nb),
+                               c->d_errs + MAX_CONTIGS + g.index);
+            MSIM_HIP(c, hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, st,
+                               reinterpret_cast<const unsigned long long *>(d_sums + nb), c->h_mail);
+            MSIM_HIP(c, hipGetLastError());
+            MSIM_HIP(c, hipStreamSynchronize(st));
+            total_delta = (long long)*c->h_mail;
+        }
         d_off = g.d_off;
     }
     const long long out_len_ll = (long long)g.len + total_delta;
@@ -742,7 +757,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
     g.apply_pending = true;
     g.key_error = false;
     c->pending_apply.push_back(g.index);
-    if (g.all_snp) return MSIM_OK;                         // asynchronous
+    if (g.all_snp || g.delta_known) return MSIM_OK;        // asynchronous
     int rc = apply_finish(c);
     if (rc) return rc;
     if (g.key_error) { g.key_reported = true; return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'"); }

@@ -18,6 +18,8 @@ struct Contig {
     bool planned = false;
     bool plan_empty = true;
     bool all_snp = false;             // record table holds SNPs only: no length change, offset == pos
+    bool delta_known = false;         // the planner already knows out_len - len (SV mixes planned on the device):
+    long long known_delta = 0;        //   APPLY needs no round trip for the output size
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD
@@ -89,7 +91,8 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
 // block[SN] == min(block): an SNP then never blocks a successor, so SNPs cannot influence the chain.
 constexpr uint32_t CHAIN_DROPPED = 0xffffffffu;
 int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
-                        const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept);
+                        const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept,
+                        long long *len_delta);
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);

@@ -77,6 +77,8 @@ static void build_lut(uint8_t *lut) {
 // forget a contig's plan/apply results; device buffers stay allocated for the next plan of this contig
 static void reset_contig(Contig &g) {
     g.planned = g.applied = false;
+    g.delta_known = false;
+    g.known_delta = 0;
     g.n_rec = g.pool_len = g.out_len = 0;
     g.h_recs.clear(); g.h_recs.shrink_to_fit();
     g.h_pool.clear(); g.h_pool.shrink_to_fit();
@@ -183,7 +185,7 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     build_lut(lut);
     if ((e = hipMalloc(&c->dev.d_lut, sizeof lut)) != hipSuccess) return bail(e, "hipMalloc(lut)");
     if ((e = hipMemcpy(c->dev.d_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(lut)");
-    if ((e = hipMalloc(&c->d_errs, (size_t)MAX_CONTIGS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(errs)");
+    if ((e = hipMalloc(&c->d_errs, (size_t)2 * MAX_CONTIGS * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(errs)");   // KeyError words + length-check words
     if ((e = hipHostMalloc(&c->h_mail, 64, hipHostMallocMapped)) != hipSuccess) return bail(e, "hipHostMalloc(mailbox)");
     c->gpu = gpu_plan_create();
     *out = reinterpret_cast<msim_ctx *>(static_cast<Ctx *>(c));
@@ -373,8 +375,10 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
     if (gpu_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
     if (mixed_ok && !(c->flags & MSIM_PLAN_HOST)) {
-        rc = apply_finish(c);                              // this contig's buffers may still be read by an APPLY
-        if (rc) return rc;
+        if (g->apply_pending) {                            // this contig's buffers may still be read by its last APPLY
+            rc = apply_finish(c);
+            if (rc) return rc;
+        }
         return plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
     }
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand

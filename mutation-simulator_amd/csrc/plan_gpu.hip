@@ -1837,6 +1837,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
 
     // ---- 2. the sequential chain over the non-SNP candidates, on the host
     size_t consumed = 0, kept_nsn = 0;
+    long long len_delta = 0;
     if (n_nsn) {
         double acc_min = 1.0;
         for (int t = 1; t <= 7; t++) {
@@ -1859,7 +1860,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_nsn, hipMemcpyDeviceToHost, c->stream));
         MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)Wb * 4, hipMemcpyDeviceToHost, c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
-        rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop, &consumed, &kept_nsn);
+        rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop, &consumed, &kept_nsn, &len_delta);
         if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
         MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_nsn * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_stop_scatter, dim3((n_nsn + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_stop, n_nsn,
@@ -1894,6 +1895,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     ct.pool_len = pool_len;
     ct.plan_empty = n_rec == 0;
     ct.all_snp = kept_nsn == 0;
+    ct.delta_known = true;
+    ct.known_delta = len_delta;
     if (pool_len && (rc = ensure_words(c, g, 1, np.pos + pool_len + 1))) return rc;
     uint64_t pos_hi = p_s;
     hipEvent_t ce = next_chain_event(g);

@@ -111,7 +111,8 @@ int sample_sorted(Ctx *c, HostMT &g, int64_t n, int64_t k, int64_t setsize, std:
 }  // namespace
 
 int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
-                        const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept) {
+                        const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept,
+                        long long *len_delta) {
     const auto t0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;
     const int64_t last = (int64_t)L - 1;
@@ -129,6 +130,10 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
     }
     const int64_t iv_reach = r.max_len[MSIM_IV];
     size_t w = 0, nk = 0;
+    // output length change per kept mutation: IN +len, DE -len, DU +len, IV 0   (mutator.py:343-399)
+    int64_t dsign[8] = {0};
+    dsign[MSIM_IN] = 1; dsign[MSIM_DE] = -1; dsign[MSIM_DU] = 1;
+    int64_t delta = 0;
     int64_t blk_hi = 0;                                              // last_mut_range = range(0)
     for (size_t j = 0; j < n; j++) {
         const int64_t p = pos[j];
@@ -149,10 +154,12 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
         if (s < 0 || s >= (int64_t)CHAIN_DROPPED) return fail(c, MSIM_ERR_UNSUPPORTED, "mutation extent beyond 2^32");
         stop[j] = (uint32_t)s;
         blk_hi = (t == MSIM_IN ? p : s) + blk1[t];
+        delta += dsign[t] * (s - p + 1);
         nk++;
     }
     *consumed = w;
     *kept = nk;
+    *len_delta = delta;
     c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSIM_OK;
 }
