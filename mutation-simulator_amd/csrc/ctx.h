@@ -94,6 +94,14 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
                         const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept,
                         long long *len_delta);
 
+// random.sample() of every drawing range of a contig (util.py:94-109), reading tempered CPython-stream words
+// from `words` instead of generating them: set path and pool path, exact word consumption.  Writes the
+// candidate positions (start + value + d * rank, ascending per range) to pos_out.  For contigs with many
+// small ranges (RMT mode), where a chain of thousands of data-dependent stream cuts leaves nothing to
+// parallelise -- the device still generates the words and does all per-record work.
+int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
+                       size_t n_words, uint32_t *pos_out, size_t *consumed);
+
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);
 int apply_finish(Ctx *c);             // collect results of asynchronous APPLYs (timing, KeyError words)

@@ -371,7 +371,8 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     reset_contig(*g);
     const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
     const bool mixed_ok = !gpu_ok && !c->host_only && c->gpu && gpu_plan_mixed_eligible(c, ranges, n_ranges);
-    if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok && !mixed_ok)
+    const bool hs_ok = !gpu_ok && !mixed_ok && !c->host_only && c->gpu && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
+    if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok && !mixed_ok && !hs_ok)
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
     if (gpu_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
     if (mixed_ok && !(c->flags & MSIM_PLAN_HOST)) {
@@ -381,6 +382,7 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
         }
         return plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
     }
+    if (hs_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
         rc = gpu_plan_sync_to_host(c, c->gpu);
         if (rc) return rc;

@@ -22,5 +22,9 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
 // draws on the device; only the boundary chain over the non-SNP candidates runs on the host
 bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
+// deterministic-SNP ranges of any size and number (RMT mode): the host walks the chain of samples over words the
+// device generated; records, SNP draws and APPLY stay on the device
+bool gpu_plan_hostsample_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
+int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 
 }  // namespace msim

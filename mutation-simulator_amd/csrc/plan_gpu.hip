@@ -1145,6 +1145,24 @@ __global__ __launch_bounds__(256) void k_pool_fill(const uint32_t *__restrict__ 
 
 __global__ void k_set_pos(PlanState *ps, unsigned long long pos) { ps->pos = pos; ps->snp_base = pos; }
 
+// ---- host-sampled contigs (many small ranges): the device still owns the streams
+// tempered words from the CURRENT device position on (the host needs no round trip to learn it)
+__global__ __launch_bounds__(256) void k_temper_window_ps(const uint32_t *__restrict__ raw, const PlanState *__restrict__ ps,
+                                                          uint32_t n, uint32_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = mt_temper(raw[ps->pos + i]);
+}
+__global__ void k_advance_pos(PlanState *ps, unsigned long long words) { ps->pos += words; ps->snp_base = ps->pos; }
+// candidate positions -> SNP records (stop = pos, mutator.py:199-200)
+__global__ __launch_bounds__(256) void k_records_from_pos(const uint32_t *__restrict__ pos, uint32_t n,
+                                                          msim_record *__restrict__ recs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    msim_record r;
+    r.pos = pos[i]; r.stop = r.pos; r.extra = 0; r.type = MSIM_SN; r.aux = 0; r.rsv = 0;
+    recs[i] = r;
+}
+
 // single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
 __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
     *mailbox = *ps;
@@ -1942,6 +1960,154 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     M.pending = true;
     py.pos = pos_hi;                                       // bound until the next sync reads the exact value
     g->unverified = true;
+    ct.planned = true;
+    return MSIM_OK;
+}
+
+
+// ====================================================================== host-sampled contigs
+// Deterministic-SNP ranges of any size and number (RMT gene-blocking files: thousands of small ranges per
+// contig, pool-path hot spots): the stream cuts form a chain of thousands of tiny data-dependent samples,
+// so the host walks them (plan_host.cpp: sample_ranges_host) -- but over words the DEVICE generated, and
+// everything per record (records, the SNP transducer of section 5, APPLY) stays on the device.
+static bool range_is_deterministic_sn(const msim_range &r) {
+    if (r.n_types < 1 || r.n_types > 8) return false;
+    int zeros = 0;
+    for (int j = 0; j < r.n_types; j++) {
+        if (r.cdf_thr[j] == 0) zeros++;
+        else if (r.cdf_thr[j] < (1ull << 53)) return false;
+    }
+    return zeros < r.n_types && r.types[zeros] == MSIM_SN;
+}
+
+bool gpu_plan_hostsample_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    if (P.block[MSIM_SN] != d) return false;
+    int64_t prev_stop = -1;
+    uint64_t K = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;
+        const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+        if (r.k < 0 || n < r.k || n >= (1ll << 32)) return false;        // ValueError / multi-word: host planner decides
+        if (r.start <= prev_stop || r.stop >= (1ll << 32)) return false; // overlapping or unsorted ranges: dict semantics
+        if (!range_is_deterministic_sn(r)) return false;
+        prev_stop = r.stop;
+        K += (uint64_t)r.k;
+    }
+    return K > 0 && K < (1ull << 31);
+}
+
+int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    int rc;
+    if ((rc = stream_to_device(c, g, 0))) return rc;
+    if ((rc = stream_to_device(c, g, 1))) return rc;
+    if (!g->d_ps) MSIM_HIP(c, hipMalloc(&g->d_ps, sizeof(PlanState)));
+    if (!g->h_mail) MSIM_HIP(c, hipHostMalloc(&g->h_mail, sizeof(PlanState), hipHostMallocMapped));
+    GpuStream &py = g->s[0];
+    if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
+    if (!g->unverified) MSIM_HIP(c, hipEventRecord(g->t0, c->stream));
+    if (!g->ps_valid) {
+        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)py.pos);
+        g->ps_valid = true;
+    }
+    g->unverified = true;
+    // word window: expected consumption of every sample + 16 sigma of the total
+    uint64_t K = 0;
+    double e_words = 0, var = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;
+        const double k = (double)r.k, n = (double)((r.stop - (r.k - 1) * d) - r.start);
+        K += (uint64_t)r.k;
+        if (n <= (double)r.setsize) { e_words += 2.0 * k; var += 2.0 * k; continue; }   // pool path: < 2 words per draw
+        const double p_acc = n / (double)(1ull << bit_length64((uint64_t)n));
+        const double need = k >= n ? 64.0 * k : -n * std::log1p(-k / n);                // coupon collector
+        e_words += need / p_acc;
+        var += need * (1.0 - p_acc) / (p_acc * p_acc) + 4.0 * (need - k) / (p_acc * p_acc) + need / p_acc;
+    }
+    const double wd = e_words + 16.0 * std::sqrt(var) + 65536.0;
+    if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
+    const uint32_t W = (uint32_t)wd;
+    bool grew = false;
+    MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
+    if (M.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, M.emit_done, 0));
+    if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
+    if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;
+    if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)W * 4))) return rc;
+    if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)K * 4))) return rc;
+    {   // the record table may still be read by an earlier apply of this contig
+        const size_t want = (size_t)K * sizeof(msim_record);
+        if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        }
+        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
+    }
+    if ((rc = ensure_words(c, g, 0, py.pos + W + 1))) return rc;
+    hipLaunchKernelGGL(k_temper_window_ps, dim3((W + 255) / 256), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W, M.words);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    size_t consumed = 0;
+    rc = sample_ranges_host(c, ranges, n_ranges, d, g->h_words, W, g->h_npos, &consumed);
+    if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
+    MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_advance_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)consumed);
+    MSIM_HIP(c, hipGetLastError());
+    {   // records on the emit stream: ordered after any earlier APPLY that still reads this contig's table
+        hipEvent_t ce0 = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce0, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce0, 0));
+        hipLaunchKernelGGL(k_records_from_pos, dim3(((uint32_t)K + 255) / 256), dim3(256), 0, c->emit_stream, M.cand_pos,
+                           (uint32_t)K, ct.d_recs);
+        MSIM_HIP(c, hipGetLastError());
+    }
+    ct.n_rec = K;
+    ct.pool_len = 0;
+    ct.plan_empty = false;
+    ct.all_snp = true;
+    uint64_t pos_hi = py.pos + consumed;
+    {   // SNP draws of the whole contig, in position order (as in plan_contig_gpu)
+        const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
+        const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
+        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
+        const uint32_t W2 = (uint32_t)w2;
+        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
+        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
+        if (T.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, T.emit_done, 0));
+        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
+        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
+        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
+        if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
+        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps);
+        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2, (uint32_t)K);
+        hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
+        MSIM_HIP(c, hipGetLastError());
+        hipEvent_t ce = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
+                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K, (const uint32_t *)nullptr);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+        T.pending = true;
+        pos_hi += W2;
+    }
+    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
+    M.pending = true;
+    py.pos = pos_hi;
+    g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k) per drawing range
+    c->t.np_words += 2 * K;
     ct.planned = true;
     return MSIM_OK;
 }

@@ -164,6 +164,88 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
     return MSIM_OK;
 }
 
+int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
+                       size_t n_words, uint32_t *pos_out, size_t *consumed) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t w = 0, at = 0;
+    static thread_local std::vector<uint64_t> bits;                 // cleared while it is scanned
+    std::vector<uint32_t> pool, picked;
+    auto overflow = [&]() {
+        std::fill(bits.begin(), bits.end(), 0);                       // keep the scratch bitmap clean for the next call
+        return fail(c, MSIM_ERR_HIP, "host sampler: word window overflowed its margin");
+    };
+    for (int ri = 0; ri < n_ranges; ri++) {
+        const msim_range &r = ranges[ri];
+        const int64_t k = r.k;
+        if (k == 0) continue;
+        const int64_t n = (r.stop - (k - 1) * d) - r.start;          // util.py:104
+        if (k < 0 || k > n) return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
+        if (n >= (1ll << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "sampling range of 2^32 or more positions");
+        const uint32_t base = (uint32_t)r.start, dd = (uint32_t)d;
+        if (n <= r.setsize) {                                        // pool path: partial Fisher-Yates
+            pool.resize((size_t)n);
+            for (int64_t i = 0; i < n; i++) pool[(size_t)i] = (uint32_t)i;
+            picked.clear();
+            for (int64_t i = 0; i < k; i++) {
+                const uint64_t m = (uint64_t)(n - i);
+                const int sh = 32 - bit_length64(m);
+                uint64_t v;
+                do { if (w >= n_words) return overflow(); v = words[w++] >> sh; } while (v >= m);
+                picked.push_back(pool[(size_t)v]);
+                pool[(size_t)v] = pool[(size_t)(n - i - 1)];
+            }
+            std::sort(picked.begin(), picked.end());
+            for (int64_t i = 0; i < k; i++) pos_out[at++] = base + picked[(size_t)i] + dd * (uint32_t)i;
+            continue;
+        }
+        const int sh = 32 - bit_length64((uint64_t)n);
+        const size_t nw = ((size_t)n + 63) / 64;
+        if (bits.size() < nw) bits.resize(nw, 0);
+        int64_t got = 0;
+        if (nw <= 4096) {                                            // bitmap stays in L1/L2: plain test-and-set
+            while (got < k) {
+                if (w >= n_words) return overflow();
+                const uint64_t v = words[w++] >> sh;
+                if (v >= (uint64_t)n) continue;
+                uint64_t &x = bits[v >> 6];
+                const uint64_t m = 1ull << (v & 63);
+                got += (x & m) ? 0 : 1;
+                x |= m;
+            }
+        } else {                                                     // large bitmap: batch + prefetch (see sample_sorted)
+            uint32_t batch[64];
+            while (got < k) {
+                const int want = (int)std::min<int64_t>(64, k - got);
+                int nb = 0;
+                while (nb < want) {
+                    if (w >= n_words) return overflow();
+                    const uint64_t v = words[w++] >> sh;
+                    if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&bits[v >> 6], 1, 0); }
+                }
+                for (int i = 0; i < nb; i++) {
+                    uint64_t &x = bits[batch[i] >> 6];
+                    const uint64_t m = 1ull << (batch[i] & 63);
+                    if (!(x & m)) { x |= m; got++; }
+                }
+            }
+        }
+        uint32_t rank = 0;
+        for (size_t wi = 0; wi < nw; wi++) {
+            uint64_t x = bits[wi];
+            if (!x) continue;
+            bits[wi] = 0;
+            while (x) {
+                pos_out[at++] = base + (uint32_t)(wi * 64 + (size_t)__builtin_ctzll(x)) + dd * rank;
+                rank++;
+                x &= x - 1;
+            }
+        }
+    }
+    *consumed = w;
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
 int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out) {
     const auto t0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;

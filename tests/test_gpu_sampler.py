@@ -131,8 +131,10 @@ def test_ineligible_structures_are_refused_by_forced_gpu_mode():
     with pytest.raises(_ffi.MsimUnsupported):
         eng.plan_contig(cid, [_snp_range(0, 999_999, 10_000)])
     eng.set_params(_params())
-    with pytest.raises(_ffi.MsimUnsupported):     # tiny range -> host planner territory
-        eng.plan_contig(cid, [_snp_range(0, 9_999, 100)])
+    with pytest.raises(_ffi.MsimUnsupported):     # translocations -> host planner territory
+        eng.plan_contig(cid, [_sv_range(0, 999_999, 8_000, {1: 0.5, 6: 0.5}, {6: (1, 20)})])
+    with pytest.raises(_ffi.MsimUnsupported):     # SV mix on a tiny range -> host planner territory
+        eng.plan_contig(cid, [_sv_range(0, 9_999, 100, C3_CHANCES, C3_LENS)])
     eng.close()
 
 
@@ -155,6 +157,63 @@ def test_auto_mode_mixes_engines_along_one_stream():
     for (hm, hp), (am, ap) in zip(hs, as_):
         assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
     assert ast["plan_gpu_ms"] > 0 and ast["plan_host_ms"] > 0
+
+
+# ---------------------------------------------------------------------- host-sampled contigs (RMT shape)
+def _rmt_like_ranges(L, rng, n_blocks, hot=(), token_order=True):
+    """Gene-blocking layout: `n_blocks` blocked stretches, std `sn 0.01` in the gaps, optional hot spots
+    (start, stop, rate).  Returns drawing ranges in position order."""
+    cuts = np.sort(rng.choice(np.arange(1, L - 1), size=2 * n_blocks, replace=False))
+    ranges, at = [], 0
+    for a, b in zip(cuts[0::2], cuts[1::2]):          # [at, a-1] drawing, [a, b] blocked
+        if a - 1 > at:
+            ranges.append((at, int(a) - 1, 0.01))
+        at = int(b) + 1
+    if at < L - 1:
+        ranges.append((at, L - 1, 0.01))
+    out = []
+    for s, e, rate in sorted(list(ranges) + list(hot)):
+        k = int(((e - s) + 1) * rate)
+        if k:
+            out.append(_snp_range(s, e, k, token_order))
+    return out
+
+
+@pytest.mark.parametrize("L,n_blocks,seed", [(3_000_000, 60, 1), (2_000_000, 400, 2), (5_000_000, 1500, 3)])
+def test_many_small_ranges_vs_host(L, n_blocks, seed):
+    rng = np.random.RandomState(seed)
+    ranges = _rmt_like_ranges(L, rng, n_blocks)
+    assert len(ranges) > n_blocks // 2
+    _compare([(L, ranges)], _params(titv=2.0), seed=(seed, seed + 1), host_chain=True)
+
+
+def test_pool_path_hot_spots_and_tiny_ranges_vs_host():
+    """Hot spots whose sample takes CPython's pool path (n <= setsize), k <= 5 (setsize 21), k = 1, and a
+    range that fills its whole population (k == n)."""
+    ranges = [_snp_range(0, 99_999, 1_000), _snp_range(100_000, 100_999, 211),       # 1 kb at 0.211: pool path
+              _snp_range(101_000, 101_024, 5), _snp_range(101_100, 101_120, 1), _snp_range(101_200, 101_209, 5),
+              _snp_range(102_000, 901_999, 8_000, True), _snp_range(902_000, 902_099, 40)]
+    for r in ranges[1:5]:
+        d = 1
+        assert (r.stop - (r.k - 1) * d) - r.start <= r.setsize                   # really the pool path
+    _compare([(1_000_000, ranges)], _params(titv=0.7), seed=(8, 8), host_chain=True)
+    blocks = {t: 2 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}
+    _compare([(1_000_000, ranges[:2] + ranges[5:6])], _params(blocks, titv=1.0), seed=(9, 1), host_chain=True)   # d = 2
+
+
+def test_host_sampled_chain_with_other_engines():
+    rng = np.random.RandomState(5)
+    sv = lambda L, rate: _sv_range(0, L - 1, int(L * rate), C3_CHANCES, C3_LENS)
+    contigs = [(2_000_000, _rmt_like_ranges(2_000_000, rng, 100)), (2_000_000, [_snp_range(0, 1_999_999, 20_000)]),
+               (1_500_000, [sv(1_500_000, 0.008)]), (1_000_000, _rmt_like_ranges(1_000_000, rng, 300, token_order=False)),
+               (400_000, [sv(400_000, 0.005)]), (700_000, _rmt_like_ranges(700_000, rng, 20))]
+    host, hs, hst = _run(_ffi.PLAN_HOST, contigs, _params(titv=2.0), (2, 3))
+    auto, as_, ast = _run(_ffi.PLAN_AUTO, contigs, _params(titv=2.0), (2, 3))
+    for (hr, he, hpool), (ar, ae, apool) in zip(host, auto):
+        assert he == ae and np.array_equal(hr.view(np.uint8), ar.view(np.uint8)) and np.array_equal(hpool, apool)
+    assert hst["py_words"] == ast["py_words"] and hst["np_words"] == ast["np_words"]
+    for (hm, hp), (am, ap) in zip(hs, as_):
+        assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
 
 
 # ---------------------------------------------------------------------- SV mixes on the device
