@@ -73,12 +73,76 @@ def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
     return sim
 
 
-def one_step(eng, sim, cids, my_contigs, seed=42):
+def c4_rmt_text(lengths, seed=4) -> str:
+    """BASELINE configs[3]: a NON-overlapping gene-blocking RMT in the style of the reference's example files
+    (`data/Example RMT files/Homo_sapiens.rmt`: std `sn 0.01`, ~60 k `a-b None` blocks, median 3.6 kb, mean
+    33 kb -- as shipped they overlap and crash the reference), plus hot (`sn 0.05`) and
+    cold (`sn 0.001`) ranges and a few 1 kb `sn 0.2` hot spots that take CPython's pool-path sample.
+    Own deterministic generator (NumPy legacy RandomState); nothing is taken from the reference's files."""
+    rs = np.random.RandomState(seed)
+    out = ["std", "it None", "sn 0.01", ""]
+    for ci, L in enumerate(lengths):
+        out.append(f"chr {ci + 1}")
+        n_blocks = max(1, int(L / 75_000))
+        block_len = np.minimum(np.exp(rs.normal(np.log(3600.0), 2.09, n_blocks)).astype(np.int64) + 50, 2_000_000)
+        kinds = rs.choice(4, size=n_blocks, p=[0.96, 0.015, 0.015, 0.01])      # None / hot / cold / pool-path hot spot
+        block_len[kinds == 3] = 1000
+        block_len[kinds == 1] = rs.randint(1_000, 100_000, int((kinds == 1).sum()))
+        block_len[kinds == 2] = rs.randint(100_000, 1_000_000, int((kinds == 2).sum()))
+        free = L - int(block_len.sum()) - 2 * n_blocks - 1000
+        while free < L // 4:                                                     # keep at least a quarter unblocked
+            block_len = np.maximum(block_len // 2, 50)
+            free = L - int(block_len.sum()) - 2 * n_blocks - 1000
+        gaps = rs.dirichlet(np.ones(n_blocks + 1)) * free
+        at = 1                                                                   # RMT positions are 1-based inclusive
+        for b in range(n_blocks):
+            at += int(gaps[b]) + 2
+            a, e = at, at + int(block_len[b]) - 1
+            what = ("None", "sn 0.05", "sn 0.001", "sn 0.2")[kinds[b]]
+            out.append(f"{a}-{e} {what}")
+            at = e + 1
+        assert at < L
+    return "\n".join(out) + "\n"
+
+
+def workload_settings_rmt(lengths, rmt_text: str):
+    """Settings tree of an RMT file over the synthetic contigs, through the package's own RMT parser."""
+    import tempfile
+
+    import mutation_simulator_amd as msa
+
+    class Rec:
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    class FakeFasta:
+        def __init__(self, ls):
+            self.ls = ls
+
+        def keys(self):
+            return [f"chr{i+1}" for i in range(len(self.ls))]
+
+        def __getitem__(self, k):
+            return Rec(self.ls[k] if isinstance(k, int) else self.ls[int(k[3:]) - 1])
+
+    with tempfile.NamedTemporaryFile("w", suffix=".rmt", delete=False) as f:
+        f.write(rmt_text)
+        path = f.name
+    try:
+        return msa.SimulationSettings.from_rmt(Path(path), FakeFasta(lengths), True)
+    finally:
+        os.unlink(path)
+
+
+def one_step(eng, sim, cids, my_contigs, seed=42, plan_descriptors=None):
     """PLAN every contig in order (the RNG streams chain across contigs), APPLY this rank's."""
     from mutation_simulator_amd import mutator as mm
     from mutation_simulator_amd.sharding import run_sharded_pass
     eng.seed(seed, seed)
-    run_sharded_pass(eng, sim, cids, my_contigs, mm.plan_descriptors)
+    run_sharded_pass(eng, sim, cids, my_contigs, plan_descriptors or mm.plan_descriptors)
     eng.sync()
 
 
@@ -111,9 +175,10 @@ def main():
     ap.add_argument("--total-bases", type=int, default=3_000_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["c2", "c3"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2 = BASELINE configs[1] (headline: -sn 0.01 -titv 2.0); c3 = configs[2], the full SV mix "
-                         "(-sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500) -- secondary number")
+                         "(-sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500); c4 = configs[3], RMT mode with ~40 k blocked "
+                         "ranges + hot/cold spots (c4_rmt_text) -- secondary numbers")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: 'weak' = N independent replicas, one whole genome per GPU with its own seeded "
                          "streams (PLAN cannot shard in bit-compatible mode: the streams chain across contigs); "
@@ -140,7 +205,18 @@ def main():
     lengths = contig_lengths(a.total_bases)
     C3 = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
           "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
-    sim = workload_settings(lengths) if a.workload == "c2" else workload_settings(lengths, snp=0.005, titv=1.0, extra=C3)
+    if a.workload == "c2":
+        sim = workload_settings(lengths)
+    elif a.workload == "c3":
+        sim = workload_settings(lengths, snp=0.005, titv=1.0, extra=C3)
+    else:
+        sim = workload_settings_rmt(lengths, c4_rmt_text(lengths))
+    descs = {}                       # msim_range descriptors per contig: settings -> integers once, outside the timed steps
+
+    def plan_descs(chrom):
+        if chrom.number not in descs:
+            descs[chrom.number] = mm.plan_descriptors(chrom)
+        return descs[chrom.number]
     from mutation_simulator_amd.sharding import lpt_partition
     strong = a.scaling == "strong" and world > 1
     parts = lpt_partition(lengths, world) if strong else [list(range(len(lengths)))] * world
@@ -162,7 +238,7 @@ def main():
             torch.cuda.synchronize()
 
     def step():
-        one_step(eng, sim, cids, mine, seed)
+        one_step(eng, sim, cids, mine, seed, plan_descs)
         if a.gather and strong or a.gather and world == 1:
             import torch
             from mutation_simulator_amd.gather import gather_to_root
@@ -209,8 +285,9 @@ def main():
             "value": round(value, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "ARGS mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
-                                   + ("-sn 0.01 -titv 2.0" if a.workload == "c2" else "full SV mix (BASELINE configs[2])")
+            "config": {"workload": ("RMT" if a.workload == "c4" else "ARGS") + " mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
+                                   + {"c2": "-sn 0.01 -titv 2.0", "c3": "full SV mix (BASELINE configs[2])",
+                                      "c4": "RMT mode, synthetic gene-blocking file with hot/cold spots (BASELINE configs[3])"}[a.workload]
                                    + ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
                        "parallelism": (f"one genome, contigs' APPLY sharded over {world} GPUs (LPT), PLAN replayed per rank"
@@ -226,7 +303,7 @@ def main():
             "records_per_step": st["records"] // a.steps,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "msim::k_rewrite_snp" if a.workload == "c2" else "msim::k_rewrite",
+                         "kernel": "msim::k_rewrite" if a.workload == "c3" else "msim::k_rewrite_snp",
                          "algorithmic_bytes_per_launch": alg_bytes // launches,
                          "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
         }

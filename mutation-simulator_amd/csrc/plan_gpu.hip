@@ -2041,7 +2041,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;
     if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)W * 4))) return rc;
-    if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)K * 4))) return rc;
+    if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)K * 4 + 64))) return rc;   // the sampler writes up to 2 slots ahead
     {   // the record table may still be read by an earlier apply of this contig
         const size_t want = (size_t)K * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {

@@ -168,7 +168,7 @@ int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d
                        size_t n_words, uint32_t *pos_out, size_t *consumed) {
     const auto t0 = std::chrono::steady_clock::now();
     size_t w = 0, at = 0;
-    static thread_local std::vector<uint64_t> bits;                 // cleared while it is scanned
+    static thread_local std::vector<uint64_t> bits, summ;           // cleared while they are scanned
     std::vector<uint32_t> pool, picked;
     auto overflow = [&]() {
         std::fill(bits.begin(), bits.end(), 0);                       // keep the scratch bitmap clean for the next call
@@ -200,19 +200,58 @@ int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d
         }
         const int sh = 32 - bit_length64((uint64_t)n);
         const size_t nw = ((size_t)n + 63) / 64;
-        if (bits.size() < nw) bits.resize(nw, 0);
+        if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
+        uint64_t *B = bits.data();
         int64_t got = 0;
-        if (nw <= 4096) {                                            // bitmap stays in L1/L2: plain test-and-set
+        if (nw <= 4096) {
+            // Bitmap in L1/L2.  Both data-dependent branches of the obvious loop (draw rejected? word of the
+            // bitmap empty?) mispredict about every second time, so: rejected draws are OR-ed into a dummy word
+            // instead of skipped, a summary bitmap (one bit per bitmap word) is kept while inserting, and the
+            // extraction visits only the non-empty words, writing three slots unconditionally.
+            const size_t ns = (nw + 63) / 64, dummy = nw;
+            if (summ.size() < ns + 1) summ.resize(ns + 1, 0);
+            uint64_t *S = summ.data();
+            const uint32_t nn = (uint32_t)n;
             while (got < k) {
-                if (w >= n_words) return overflow();
-                const uint64_t v = words[w++] >> sh;
-                if (v >= (uint64_t)n) continue;
-                uint64_t &x = bits[v >> 6];
-                const uint64_t m = 1ull << (v & 63);
-                got += (x & m) ? 0 : 1;
-                x |= m;
+                if (w >= n_words) { std::fill(summ.begin(), summ.end(), 0); return overflow(); }
+                const uint32_t v = words[w++] >> sh;
+                const bool ok = v < nn;
+                const size_t wi = ok ? (size_t)(v >> 6) : dummy;
+                const uint64_t m = (uint64_t)ok << (v & 63);
+                const uint64_t x = B[wi];
+                got += (int64_t)(ok & !(x & m));
+                B[wi] = x | m;
+                S[wi >> 6] |= 1ull << (wi & 63);
             }
-        } else {                                                     // large bitmap: batch + prefetch (see sample_sorted)
+            B[dummy] = 0;
+            uint32_t rank = 0;
+            for (size_t si = 0; si <= ns; si++) {                     // (the dummy's summary bit may sit in word ns)
+                uint64_t sm = S[si];
+                if (!sm) continue;
+                S[si] = 0;
+                do {
+                    const size_t wi = si * 64 + (size_t)__builtin_ctzll(sm);
+                    sm &= sm - 1;
+                    uint64_t x = B[wi];
+                    B[wi] = 0;
+                    const uint32_t cn = (uint32_t)__builtin_popcountll(x);
+                    const uint32_t p0 = base + (uint32_t)(wi * 64) + dd * rank;
+                    if (__builtin_expect(cn <= 3, 1)) {               // slots beyond cn are overwritten by the next word
+                        const uint64_t x1 = x & (x - 1), x2 = x1 & (x1 - 1), top = 1ull << 63;
+                        pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x | top);
+                        pos_out[at + 1] = p0 + dd + (uint32_t)__builtin_ctzll(x1 | top);
+                        pos_out[at + 2] = p0 + 2 * dd + (uint32_t)__builtin_ctzll(x2 | top);
+                    } else {
+                        uint32_t q = 0;
+                        while (x) { pos_out[at + q] = p0 + dd * q + (uint32_t)__builtin_ctzll(x); q++; x &= x - 1; }
+                    }
+                    at += cn;
+                    rank += cn;
+                } while (sm);
+            }
+            continue;
+        }
+        {                                                            // large bitmap: batch + prefetch (see sample_sorted)
             uint32_t batch[64];
             while (got < k) {
                 const int want = (int)std::min<int64_t>(64, k - got);
@@ -220,10 +259,10 @@ int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d
                 while (nb < want) {
                     if (w >= n_words) return overflow();
                     const uint64_t v = words[w++] >> sh;
-                    if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&bits[v >> 6], 1, 0); }
+                    if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&B[v >> 6], 1, 0); }
                 }
                 for (int i = 0; i < nb; i++) {
-                    uint64_t &x = bits[batch[i] >> 6];
+                    uint64_t &x = B[batch[i] >> 6];
                     const uint64_t m = 1ull << (batch[i] & 63);
                     if (!(x & m)) { x |= m; got++; }
                 }
@@ -231,9 +270,9 @@ int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d
         }
         uint32_t rank = 0;
         for (size_t wi = 0; wi < nw; wi++) {
-            uint64_t x = bits[wi];
+            uint64_t x = B[wi];
             if (!x) continue;
-            bits[wi] = 0;
+            B[wi] = 0;
             while (x) {
                 pos_out[at++] = base + (uint32_t)(wi * 64 + (size_t)__builtin_ctzll(x)) + dd * rank;
                 rank++;

@@ -316,6 +316,42 @@ def test_full_size_sv_mix_gpu_vs_host_planner():
         assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
 
 
+def test_full_size_rmt_host_sampled_vs_host_planner():
+    """BASELINE config 4 at full size (3 Gb, 24 contigs, ~41 k drawing ranges incl. pool-path hot spots,
+    17.8 M SNPs): records and both final stream positions equal the sequential host planner's."""
+    import hashlib
+
+    import bench
+    lengths = bench.contig_lengths(3_000_000_000)
+    sim = bench.workload_settings_rmt(lengths, bench.c4_rmt_text(lengths))
+    params = mm.params_descriptor(sim)
+    descs = [mm.plan_descriptors(ch) for ch in sim.chromosomes]
+    assert sum(len(d) for d in descs) > 30_000
+
+    def run(flags):
+        eng = _ffi.Engine(0, flags)
+        eng.seed(42, 42)
+        eng.set_params(params)
+        sums = []
+        for chrom in sim.chromosomes:
+            cid = eng.add_contig_synthetic(lengths[chrom.number], 1)
+            eng.plan_contig(cid, descs[chrom.number])
+            recs, pool = eng.fetch_records(cid)
+            sums.append((len(recs), len(pool), hashlib.sha256(recs.tobytes()).hexdigest()))
+            eng.clear()
+        states = [eng.get_mt_state(0), eng.get_mt_state(1)]
+        st = eng.stats()
+        eng.close()
+        return sums, states, st
+
+    hsum, hs, hst = run(_ffi.PLAN_HOST)
+    gsum, gs, gst = run(_ffi.PLAN_GPU)
+    assert hsum == gsum
+    assert hst["py_words"] == gst["py_words"] and hst["np_words"] == gst["np_words"]
+    for (hm, hp), (gm, gp) in zip(hs, gs):
+        assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
+
+
 def test_full_size_genome_gpu_sampler_vs_host_planner():
     """BASELINE config 2 at full size (3 Gb, 24 contigs, 30 M SNPs): every record and both final
     stream positions equal the sequential host walk (> 200 M MT19937 words, > 1000 stream chunks,
