@@ -178,6 +178,25 @@ int msim_render_vcf(const msim_record *recs, uint64_t n_records, const uint8_t *
                     const uint8_t *bases, uint64_t len, const char *seq_name,
                     char *out, uint64_t cap, uint64_t *needed);
 
+/* ---- text on the device ------------------------------------------------ */
+/* The same record lines as msim_render_vcf, rendered by HIP kernels from the record table, insert pool and
+ * input contig already in HBM (mutator.py:334-421 + vcf_writer.py:44-52,118-126).  Two-call protocol:
+ * out == NULL renders into a device buffer and reports the size in *needed; a following call for the same
+ * contig with out != NULL (cap >= *needed) copies the text to the host.                               */
+int msim_render_vcf_device(msim_ctx *ctx, int contig, const char *seq_name, char *out, uint64_t cap,
+                           uint64_t *needed);
+/* The mutated contig as FASTA body text: '\n' after every `bpl` bases, none after a partial last line --
+ * what FastaWriter.write emits between two headers (fasta_writer.py:40-58).  *needed = L + L / bpl.
+ * Same two-call protocol.                                                                             */
+int msim_fetch_sequence_framed(msim_ctx *ctx, int contig, uint32_t bpl, uint8_t *out, uint64_t cap,
+                               uint64_t *needed);
+/* Ingest one FASTA record straight from file text: `body` = the bytes after the header line, n_bases bases
+ * in lines of `lenc` bases every `lenb` bytes (the .fai columns; uniform line width is what pyfaidx
+ * requires, util.py:77-91).  Line terminators are skipped and a-z upper-cased on the device
+ * (sequence_always_upper=True, util.py:84-88).  Replaces msim_add_contig + host-side parsing.           */
+int msim_add_contig_text(msim_ctx *ctx, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases,
+                         uint32_t lenc, uint32_t lenb, int *contig);
+
 /* ---- stats -------------------------------------------------------------------------------------- */
 int msim_stats(msim_ctx *ctx, msim_timing *out);
 int msim_reset_stats(msim_ctx *ctx);

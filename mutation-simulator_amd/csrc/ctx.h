@@ -66,6 +66,14 @@ struct Ctx {
     unsigned long long *h_mail = nullptr;   // pinned, device-visible mailbox for small results
     unsigned long long *d_errs = nullptr;   // one KeyError word per contig
     std::vector<int> pending_apply;
+    // text on the device (text_gpu.hip): rendered VCF lines / framed FASTA body / raw FASTA body staging
+    uint8_t *d_text = nullptr;
+    size_t cap_text = 0;
+    uint64_t text_len = 0;
+    int text_contig = -1, text_kind = 0;  // what d_text currently holds: 1 VCF lines, 2 framed FASTA body
+    uint32_t text_bpl = 0;
+    uint8_t *d_text_scratch = nullptr;
+    size_t cap_text_scratch = 0;
 };
 
 int fail(Ctx *c, int code, const std::string &msg);
@@ -101,6 +109,12 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
 // parallelise -- the device still generates the words and does all per-record work.
 int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
                        size_t n_words, uint32_t *pos_out, size_t *consumed);
+
+// text_gpu.hip
+int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);
+int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes);
+int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
+                        uint32_t lenb, uint8_t *d_dst);
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);

@@ -75,7 +75,7 @@ static void build_lut(uint8_t *lut) {
 }
 
 // forget a contig's plan/apply results; device buffers stay allocated for the next plan of this contig
-static void reset_contig(Contig &g) {
+static void reset_contig(Contig &g) {   // (callers also drop the context's text cache: see text_kind)
     g.planned = g.applied = false;
     g.delta_known = false;
     g.known_delta = 0;
@@ -206,6 +206,8 @@ void msim_destroy(msim_ctx *p) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
     if (c->d_errs) (void)hipFree(c->d_errs);
+    if (c->d_text) (void)hipFree(c->d_text);
+    if (c->d_text_scratch) (void)hipFree(c->d_text_scratch);
     gpu_plan_destroy(c->gpu);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
@@ -348,6 +350,7 @@ int msim_clear(msim_ctx *p) {
         if (rc) return rc;
     }
     c->contigs.clear();
+    c->text_kind = 0;
     return MSIM_OK;
 }
 
@@ -369,6 +372,7 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
     int rc = MSIM_OK;
     reset_contig(*g);
+    c->text_kind = 0;
     const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
     const bool mixed_ok = !gpu_ok && !c->host_only && c->gpu && gpu_plan_mixed_eligible(c, ranges, n_ranges);
     const bool hs_ok = !gpu_ok && !mixed_ok && !c->host_only && c->gpu && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
@@ -442,6 +446,7 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     if (!g) return MSIM_ERR_ARG;
     NEED_GPU(c);
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "msim_apply_contig before msim_plan_contig");
+    c->text_kind = 0;
     return apply_contig_device(c, *g);
 }
 
@@ -559,6 +564,78 @@ int msim_release_result(msim_ctx *p, int contig) {
         if (rc) return rc;
     }
     return free_contig(c, *g, true);
+}
+
+// ---- text on the device -------------------------------------------------
+static int text_copy_out(Ctx *c, uint8_t *out, uint64_t cap, uint64_t *needed) {
+    *needed = c->text_len;
+    if (!out) return MSIM_OK;
+    if (cap < c->text_len) return fail(c, MSIM_ERR_ARG, "text buffer too small (see *needed)");
+    if (c->text_len) MSIM_HIP(c, hipMemcpyAsync(out, c->d_text, c->text_len, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    return MSIM_OK;
+}
+
+int msim_render_vcf_device(msim_ctx *p, int contig, const char *seq_name, char *out, uint64_t cap, uint64_t *needed) {
+    Ctx *c = C(p);
+    if (!c || !seq_name || !needed) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    if (!(out && c->text_kind == 1 && c->text_contig == contig)) {      // not cached by a preceding size call
+        int rc = drain(c);                                               // record aux bytes come from the emit stream
+        if (rc) return rc;
+        c->text_kind = 0;
+        uint64_t bytes = 0;
+        rc = vcf_render_device(c, *g, seq_name, &bytes);
+        if (rc) return rc;
+        c->text_kind = 1;
+        c->text_contig = contig;
+    }
+    return text_copy_out(c, reinterpret_cast<uint8_t *>(out), cap, needed);
+}
+
+int msim_fetch_sequence_framed(msim_ctx *p, int contig, uint32_t bpl, uint8_t *out, uint64_t cap, uint64_t *needed) {
+    Ctx *c = C(p);
+    if (!c || !needed || bpl == 0) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    if (!(out && c->text_kind == 2 && c->text_contig == contig && c->text_bpl == bpl)) {
+        int rc = drain(c);
+        if (rc) return rc;
+        if (g->key_error) return key_error_of(c, *g);
+        c->text_kind = 0;
+        uint64_t bytes = 0;
+        rc = fasta_frame_device(c, *g, bpl, &bytes);
+        if (rc) return rc;
+        c->text_kind = 2;
+        c->text_contig = contig;
+        c->text_bpl = bpl;
+    }
+    return text_copy_out(c, out, cap, needed);
+}
+
+int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
+                         uint32_t lenb, int *contig) {
+    Ctx *c = C(p);
+    if (!c || !contig || (!body && n_bases)) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    if (n_bases) {
+        if (lenc == 0 || lenb < lenc) return fail(c, MSIM_ERR_ARG, "line width / line stride of the FASTA body are inconsistent");
+        const uint64_t last = (n_bases - 1) / lenc * lenb + (n_bases - 1) % lenc;    // offset of the last base
+        if (last >= body_bytes) return fail(c, MSIM_ERR_ARG, "FASTA body shorter than n_bases at this line width");
+    }
+    Contig *g;
+    int rc = new_contig(c, n_bases, &g);
+    if (rc) return rc;
+    c->text_kind = 0;                                                    // the staging buffer is about to be reused
+    rc = fasta_gather_device(c, body, body_bytes, n_bases, lenc, lenb, g->d_in + PAD);
+    if (rc) return rc;
+    *contig = (int)c->contigs.size() - 1;
+    return MSIM_OK;
 }
 
 int msim_stats(msim_ctx *p, msim_timing *out) {

@@ -1,0 +1,409 @@
+// Text on the device: VCF record lines, FASTA line framing (egress) and FASTA body gathering (ingest).
+// gfx950 (MI355X) only.                                                   SURVEY.md section 8(f) rows 1-2.
+//
+// The record table and the mutated stream live in HBM; for an SV mix the VCF text is as large as the
+// genome, so rendering it on the host means one core pushing gigabytes through a
+// byte-wise formatter.  Here:
+//   VCF    k_vcf_lines<false> : one wave per record -> length of its line (0 = suppressed, REF == ALT)
+//          k_len_* / k_scan_u64: exclusive u64 scan -> byte offset of every line
+//          k_vcf_lines<true>  : same walk, writing: lane 0 emits the scalar fields, all 64 lanes copy
+//                               REF / ALT (raw, ambiguity-converted, or reverse-complemented) coalesced
+//          follows mutator.py:334-421 (record construction) and vcf_writer.py:44-52,118-126 (the line)
+//   FASTA  k_frame  : mutated stream -> text with '\n' after every `bpl` bases (fasta_writer.py:40-58)
+//          k_gather : FASTA body text (uniform line width, as pyfaidx requires) -> upper-cased uint8 bases
+//                     (what pyfaidx hands the reference with sequence_always_upper=True, util.py:84-88)
+// Byte/integer work, HBM-bound; no MFMA.
+#include <cstring>
+
+#include "ctx.h"
+
+namespace msim {
+
+uint8_t *ctx_lut(Ctx *c);             // msim_api.hip: 1280-byte translation table (layout in apply.hip)
+
+namespace {
+
+constexpr int TX_THREADS = 256;
+constexpr int TX_WAVES = TX_THREADS / 64;
+
+__device__ __forceinline__ int ndigits(unsigned long long v) {
+    int k = 1;
+    unsigned long long p = 10;
+    while (v >= p && k < 20) { p *= 10; k++; }
+    return k;
+}
+
+// Wave-uniform sink: every lane carries the same offset n; small fields are written by the low lanes,
+// bulk copies by all 64.
+template <bool WRITE>
+struct WSink {
+    char *p;
+    unsigned long long n;
+    uint32_t lane;
+    __device__ __forceinline__ void put(char c) {
+        if (WRITE && lane == 0) p[n] = c;
+        n++;
+    }
+    template <int N>
+    __device__ __forceinline__ void lit(const char (&s)[N]) {            // N - 1 characters
+        if (WRITE && lane < (uint32_t)(N - 1)) p[n + lane] = s[lane];
+        n += N - 1;
+    }
+    __device__ __forceinline__ void num(unsigned long long v) {
+        const int k = ndigits(v);
+        if (WRITE && lane < (uint32_t)k) {
+            unsigned long long q = v;
+            for (int i = 0; i < k - 1 - (int)lane; i++) q /= 10;
+            p[n + lane] = (char)('0' + (int)(q % 10));
+        }
+        n += (unsigned)k;
+    }
+    // mode 0 raw, 1 conv(x), 2 comp(conv(x)) read BACKWARDS from src (src points at the LAST source byte)
+    __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode,
+                                         const uint8_t *lut) {
+        if (WRITE) {
+            for (unsigned long long i = lane; i < len; i += 64) {
+                uint8_t c;
+                if (mode == 0) c = src[i];
+                else if (mode == 1) c = lut[768 + src[i]];
+                else c = lut[1024 + *(src - i)];
+                p[n + i] = (char)c;
+            }
+        }
+        n += len;
+    }
+};
+
+template <bool WRITE>
+__device__ __forceinline__ void line_head(WSink<WRITE> &s, const uint8_t *name, uint32_t name_len, unsigned long long start) {
+    s.bulk(name, name_len, 0, nullptr);
+    s.put('\t');
+    s.num(start);
+    s.lit("\t.\t");
+}
+// svtype: 0 none (SNP), 1 INS, 2 DEL, 3 INV, 4 DUP, 5 INS:ME, 6 DEL:ME
+template <bool WRITE>
+__device__ __forceinline__ void line_tail(WSink<WRITE> &s, int svtype, unsigned long long end, unsigned long long len) {
+    s.lit("\t.\t.\t");
+    if (svtype) {
+        s.lit("SVTYPE=");
+        switch (svtype) {
+            case 1: s.lit("INS"); break;
+            case 2: s.lit("DEL"); break;
+            case 3: s.lit("INV"); break;
+            case 4: s.lit("DUP"); break;
+            case 5: s.lit("INS:ME"); break;
+            default: s.lit("DEL:ME"); break;
+        }
+        s.lit(";END=");
+        s.num(end);
+        s.lit(";SVLEN=");
+        s.num(len);
+    } else {
+        s.put('.');
+    }
+    s.lit("\tGT\t1\n");
+}
+
+template <bool WRITE>
+__global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
+                                                          const uint8_t *__restrict__ pool,
+                                                          const uint8_t *__restrict__ in, unsigned long long L,
+                                                          const uint8_t *__restrict__ name, uint32_t name_len,
+                                                          const uint8_t *__restrict__ lut_g,
+                                                          uint32_t *__restrict__ len_out,
+                                                          const unsigned long long *__restrict__ off,
+                                                          char *__restrict__ text) {
+    __shared__ uint8_t lut[1280];
+    for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
+        reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * TX_WAVES + (threadIdx.x >> 6);
+    if (i >= n_rec) return;
+    const msim_record r = recs[i];
+    WSink<WRITE> s;
+    s.lane = threadIdx.x & 63;
+    s.n = 0;
+    s.p = WRITE ? text + off[i] : nullptr;
+    const unsigned long long pos = r.pos, stop = r.stop;
+    switch (r.type) {
+        case MSIM_SN: {                                                  // mutator.py:334-341
+            const uint8_t x = in[pos];
+            const uint8_t ref = lut[768 + x];
+            const uint8_t alt = lut[(uint32_t)r.aux * 256 + x];          // ti / tv column of conv(x)
+            if (ref == alt) break;                                       // vcf_writer.py:123
+            line_head(s, name, name_len, pos + 1);
+            s.put((char)ref); s.put('\t'); s.put((char)alt);
+            line_tail(s, 0, 0, 0);
+            break;
+        }
+        case MSIM_IN: {                                                  // mutator.py:343-358
+            const unsigned long long len = stop + 1 - pos;
+            const uint8_t *ins = pool + r.extra;
+            if (pos > 0) {
+                const char ref = (char)lut[768 + in[pos - 1]];
+                line_head(s, name, name_len, pos);
+                s.put(ref); s.put('\t'); s.put(ref); s.bulk(ins, len, 0, lut);
+                line_tail(s, 1, pos, len);
+            } else {
+                const char ref = (char)lut[768 + in[0]];
+                line_head(s, name, name_len, 1);
+                s.put(ref); s.put('\t'); s.bulk(ins, len, 0, lut); s.put(ref);
+                line_tail(s, 1, 1, len);
+            }
+            break;
+        }
+        case MSIM_TLI: {                                                 // mutator.py:401-421
+            const unsigned long long src = r.extra;
+            const unsigned long long hi = stop + 1 < L ? stop + 1 : L;
+            const unsigned long long ilen = hi > src ? hi - src : 0;
+            const bool rev = r.aux & 1, after = r.aux & 2;
+            if (ilen == 0) break;                                        // REF == ALT: suppressed
+            const unsigned long long start = after ? pos : pos + 1;
+            const char ref = (char)lut[768 + in[after ? pos - 1 : pos]];
+            line_head(s, name, name_len, start);
+            s.put(ref); s.put('\t');
+            if (after) s.put(ref);
+            if (rev) s.bulk(in + hi - 1, ilen, 2, lut);
+            else s.bulk(in + src, ilen, 1, lut);
+            if (!after) s.put(ref);
+            line_tail(s, 5, start, ilen);
+            break;
+        }
+        case MSIM_TL:
+        case MSIM_DE: {                                                  // mutator.py:360-377
+            unsigned long long start = pos, end = stop + 1, lo = pos - 1;
+            if (pos == 0) { start = 1; end = stop + 2; lo = 0; }
+            const unsigned long long hi = end < L ? end : L;             // slice clamps at len(sequence)
+            line_head(s, name, name_len, start);
+            s.bulk(in + lo, hi - lo, 1, lut);
+            s.put('\t');
+            s.put((char)lut[768 + in[pos > 0 ? lo : hi - 1]]);           // REF[0] / REF[-1]
+            line_tail(s, r.type == MSIM_DE ? 2 : 6, end, stop - pos + 1);
+            break;
+        }
+        case MSIM_IV: {                                                  // mutator.py:379-387
+            const unsigned long long len = stop - pos + 1;
+            bool diff = false;                                           // REF == ALT (palindrome): suppressed
+            for (unsigned long long q = s.lane; q < len; q += 64)
+                diff |= lut[768 + in[pos + q]] != lut[1024 + in[stop - q]];
+            if (__ballot(diff) == 0ull) break;
+            line_head(s, name, name_len, pos + 1);
+            s.bulk(in + pos, len, 1, lut);
+            s.put('\t');
+            s.bulk(in + stop, len, 2, lut);
+            line_tail(s, 3, stop + 1, 0);
+            break;
+        }
+        case MSIM_DU: {                                                  // mutator.py:389-399 (REF not converted)
+            const unsigned long long len = stop - pos + 1;
+            line_head(s, name, name_len, pos + 1);
+            s.bulk(in + pos, len, 0, lut); s.put('\t');
+            s.bulk(in + pos, len, 0, lut); s.bulk(in + pos, len, 0, lut);
+            line_tail(s, 4, pos + len, len);
+            break;
+        }
+        default: break;
+    }
+    if (!WRITE && s.lane == 0) len_out[i] = (uint32_t)s.n;
+}
+
+// ---- exclusive u64 scan of u32 lengths (2048 per workgroup)
+constexpr int LS_ITEMS = 8;
+constexpr int LS_BLOCK = TX_THREADS * LS_ITEMS;
+
+__global__ __launch_bounds__(TX_THREADS) void k_len_reduce(const uint32_t *__restrict__ len, uint32_t n,
+                                                           unsigned long long *__restrict__ sums) {
+    __shared__ unsigned long long red[TX_WAVES];
+    const uint32_t i0 = blockIdx.x * LS_BLOCK + threadIdx.x * LS_ITEMS;
+    unsigned long long s = 0;
+#pragma unroll
+    for (int q = 0; q < LS_ITEMS; q++) if (i0 + q < n) s += len[i0 + q];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_u64(unsigned long long *__restrict__ a, uint32_t n,
+                                                   unsigned long long *__restrict__ mailbox) {
+    __shared__ unsigned long long buf[1024];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = i < n ? a[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const unsigned long long t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const unsigned long long incl = buf[threadIdx.x], c = carry;
+        if (i < n) a[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { a[n] = carry; *mailbox = carry; __threadfence_system(); }
+}
+
+__global__ __launch_bounds__(TX_THREADS) void k_len_offsets(const uint32_t *__restrict__ len, uint32_t n,
+                                                            const unsigned long long *__restrict__ sums,
+                                                            unsigned long long *__restrict__ off) {
+    __shared__ unsigned long long wsum[TX_WAVES];
+    const uint32_t i0 = blockIdx.x * LS_BLOCK + threadIdx.x * LS_ITEMS;
+    uint32_t l[LS_ITEMS];
+    unsigned long long s = 0;
+#pragma unroll
+    for (int q = 0; q < LS_ITEMS; q++) { l[q] = i0 + q < n ? len[i0 + q] : 0; s += l[q]; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long run = sums[blockIdx.x] + incl - s;
+    for (int w = 0; w < wave; w++) run += wsum[w];
+#pragma unroll
+    for (int q = 0; q < LS_ITEMS; q++) {
+        if (i0 + q < n) off[i0 + q] = run;
+        run += l[q];
+    }
+}
+
+// ---- FASTA egress: '\n' after every bpl bases (no newline after a partial last line)
+__global__ __launch_bounds__(TX_THREADS) void k_frame(const uint8_t *__restrict__ seq, unsigned long long L,
+                                                      uint32_t bpl, unsigned long long text_len,
+                                                      uint8_t *__restrict__ text) {
+    const unsigned long long t0 = ((unsigned long long)blockIdx.x * TX_THREADS + threadIdx.x) * 16;
+    if (t0 >= text_len) return;
+    const uint32_t stride = bpl + 1;
+    unsigned long long line = t0 / stride;
+    uint32_t col = (uint32_t)(t0 % stride);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        uint8_t c = 0;
+        if (t0 + q < text_len) c = col == bpl ? (uint8_t)'\n' : seq[line * bpl + col];
+        w[q >> 2] |= (uint32_t)c << ((q & 3) * 8);
+        if (++col == stride) { col = 0; line++; }
+    }
+    if (t0 + 16 <= text_len) {
+        uint4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        *reinterpret_cast<uint4 *>(text + t0) = v;
+    } else {
+        for (int q = 0; t0 + q < text_len; q++) text[t0 + q] = (uint8_t)(w[q >> 2] >> ((q & 3) * 8));
+    }
+}
+
+// ---- FASTA ingest: base i of the record sits at body[(i / lenc) * lenb + i % lenc]; a-z -> A-Z
+__global__ __launch_bounds__(TX_THREADS) void k_gather(const uint8_t *__restrict__ body, unsigned long long n_bases,
+                                                       uint32_t lenc, uint32_t lenb, uint8_t *__restrict__ dst) {
+    const unsigned long long i0 = ((unsigned long long)blockIdx.x * TX_THREADS + threadIdx.x) * 16;
+    if (i0 >= n_bases) return;
+    unsigned long long line = i0 / lenc;
+    uint32_t col = (uint32_t)(i0 % lenc);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        uint8_t c = 0;
+        if (i0 + q < n_bases) {
+            c = body[line * lenb + col];
+            if (c >= 'a' && c <= 'z') c -= 32;
+        }
+        w[q >> 2] |= (uint32_t)c << ((q & 3) * 8);
+        if (++col == lenc) { col = 0; line++; }
+    }
+    if (i0 + 16 <= n_bases) {
+        uint4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        *reinterpret_cast<uint4 *>(dst + i0) = v;
+    } else {
+        for (int q = 0; i0 + q < n_bases; q++) dst[i0 + q] = (uint8_t)(w[q >> 2] >> ((q & 3) * 8));
+    }
+}
+
+}  // namespace
+
+// VCF text of one contig into the context's text buffer; returns its size.
+int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes) {
+    const uint32_t n = (uint32_t)g.n_rec;
+    *bytes = 0;
+    if (!n) { c->text_len = 0; return MSIM_OK; }
+    hipStream_t st = c->stream;
+    const size_t name_len = strlen(seq_name);
+    const uint32_t nb = (n + LS_BLOCK - 1) / LS_BLOCK;
+    // scratch: name | lens u32[n] | sums u64[nb+1] | off u64[n]
+    const size_t o_len = (name_len + 255) & ~(size_t)255;
+    const size_t o_sums = o_len + (((size_t)n * 4 + 255) & ~(size_t)255);
+    const size_t o_off = o_sums + (((size_t)(nb + 1) * 8 + 255) & ~(size_t)255);
+    int rc = dev_reserve(c, (void **)&c->d_text_scratch, &c->cap_text_scratch, o_off + (size_t)n * 8);
+    if (rc) return rc;
+    uint8_t *base = c->d_text_scratch;
+    uint8_t *d_name = base;
+    uint32_t *d_len = reinterpret_cast<uint32_t *>(base + o_len);
+    unsigned long long *d_sums = reinterpret_cast<unsigned long long *>(base + o_sums);
+    unsigned long long *d_off = reinterpret_cast<unsigned long long *>(base + o_off);
+    MSIM_HIP(c, hipMemcpyAsync(d_name, seq_name, name_len, hipMemcpyHostToDevice, st));
+    const uint8_t *in = g.d_in + PAD;
+    const uint8_t *pool = g.d_pool ? g.d_pool + PAD : nullptr;
+    const dim3 grid((n + TX_WAVES - 1) / TX_WAVES);
+    hipLaunchKernelGGL(k_vcf_lines<false>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
+                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, (const unsigned long long *)nullptr, (char *)nullptr);
+    hipLaunchKernelGGL(k_len_reduce, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, d_sums, nb, c->h_mail);
+    hipLaunchKernelGGL(k_len_offsets, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums, d_off);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipStreamSynchronize(st));
+    const uint64_t total = *c->h_mail;
+    rc = dev_reserve(c, (void **)&c->d_text, &c->cap_text, total + 64);
+    if (rc) return rc;
+    if (total) {
+        hipLaunchKernelGGL(k_vcf_lines<true>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
+                           d_name, (uint32_t)name_len, ctx_lut(c), (uint32_t *)nullptr, d_off, reinterpret_cast<char *>(c->d_text));
+        MSIM_HIP(c, hipGetLastError());
+    }
+    c->text_len = total;
+    *bytes = total;
+    return MSIM_OK;
+}
+
+// Mutated stream of one contig as FASTA body text into the context's text buffer.
+int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes) {
+    const uint64_t L = g.out_len;
+    const uint64_t total = L + L / bpl;
+    *bytes = total;
+    c->text_len = total;
+    if (!total) return MSIM_OK;
+    int rc = dev_reserve(c, (void **)&c->d_text, &c->cap_text, total + 64);
+    if (rc) return rc;
+    const uint64_t groups = (total + 15) / 16;
+    hipLaunchKernelGGL(k_frame, dim3((uint32_t)((groups + TX_THREADS - 1) / TX_THREADS)), dim3(TX_THREADS), 0, c->stream,
+                       g.d_out, (unsigned long long)L, bpl, (unsigned long long)total, c->d_text);
+    MSIM_HIP(c, hipGetLastError());
+    return MSIM_OK;
+}
+
+// FASTA body text (host memory) -> upper-cased bases of a new contig's input buffer.
+int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
+                        uint32_t lenb, uint8_t *d_dst) {
+    if (!n_bases) return MSIM_OK;
+    int rc = dev_reserve(c, (void **)&c->d_text, &c->cap_text, body_bytes + 64);
+    if (rc) return rc;
+    MSIM_HIP(c, hipMemcpyAsync(c->d_text, body, body_bytes, hipMemcpyHostToDevice, c->stream));
+    const uint64_t groups = (n_bases + 15) / 16;
+    hipLaunchKernelGGL(k_gather, dim3((uint32_t)((groups + TX_THREADS - 1) / TX_THREADS)), dim3(TX_THREADS), 0, c->stream,
+                       c->d_text, (unsigned long long)n_bases, lenc, lenb, d_dst);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    c->text_len = 0;
+    return MSIM_OK;
+}
+
+}  // namespace msim

@@ -87,6 +87,9 @@ SYMBOLS = [
     ("msim_result_device_ptr", C.c_int, [_VP, C.c_int, _U64P, _U64P]),
     ("msim_render_vcf", C.c_int, [_VP, C.c_uint64, _VP, _VP, C.c_uint64, C.c_char_p, _VP,
                                   C.c_uint64, _U64P]),
+    ("msim_render_vcf_device", C.c_int, [_VP, C.c_int, C.c_char_p, _VP, C.c_uint64, _U64P]),
+    ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
+    ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
     ("msim_stats", C.c_int, [_VP, C.POINTER(Timing)]),
     ("msim_reset_stats", C.c_int, [_VP]),
 ]
@@ -210,6 +213,14 @@ class Engine:
         self._check(self.lib.msim_add_contig(self.h, _ptr(bases), bases.shape[0], C.byref(cid)))
         return cid.value
 
+    def add_contig_text(self, body: np.ndarray, n_bases: int, lenc: int, lenb: int) -> int:
+        """One FASTA record straight from file text (bytes after the header line); the device skips the
+        line terminators and upper-cases."""
+        body = np.ascontiguousarray(body, dtype=np.uint8)
+        cid = C.c_int()
+        self._check(self.lib.msim_add_contig_text(self.h, _ptr(body), body.shape[0], n_bases, lenc, lenb, C.byref(cid)))
+        return cid.value
+
     def add_contig_synthetic(self, length: int, seed: int) -> int:
         cid = C.c_int()
         self._check(self.lib.msim_add_contig_synthetic(self.h, length, seed, C.byref(cid)))
@@ -265,6 +276,25 @@ class Engine:
         pool = np.zeros(n_pool, dtype=np.uint8)
         self._check(self.lib.msim_fetch_records(self.h, contig, _ptr(recs), _ptr(pool)))
         return recs, pool
+
+    def render_vcf_device(self, contig: int, seq_name: str) -> np.ndarray:
+        """VCF record lines of the contig rendered on the device (uint8 array of text)."""
+        need = C.c_uint64()
+        name = seq_name.encode("utf-8", "replace")
+        self._check(self.lib.msim_render_vcf_device(self.h, contig, name, None, 0, C.byref(need)), contig)
+        out = np.empty(need.value, dtype=np.uint8)
+        if need.value:
+            self._check(self.lib.msim_render_vcf_device(self.h, contig, name, _ptr(out), need.value, C.byref(need)), contig)
+        return out
+
+    def fetch_sequence_framed(self, contig: int, bpl: int) -> np.ndarray:
+        """The mutated contig as FASTA body text (newline after every ``bpl`` bases)."""
+        need = C.c_uint64()
+        self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, None, 0, C.byref(need)), contig)
+        out = np.empty(need.value, dtype=np.uint8)
+        if need.value:
+            self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, _ptr(out), need.value, C.byref(need)), contig)
+        return out
 
     def result_checksum(self, contig: int) -> int:
         s = C.c_uint64()

@@ -13,8 +13,9 @@ vectorised NumPy passes and exposes the small part of the pyfaidx surface the pa
     fasta.faidx.index[name].lenc       bases per line of that record
     fasta.close()
 
-plus ``record.bases`` (np.uint8) for the device upload.  Like pyfaidx it leaves a samtools-style
-``<infile>.fai`` next to the input when it can.
+plus ``record.body`` (the record's file text, for ingest on the device: the HIP gather kernel skips the
+line terminators and upper-cases) and ``record.bases`` (np.uint8, materialised lazily on the host).  Like
+pyfaidx it leaves a samtools-style ``<infile>.fai`` next to the input when it can.
 """
 from __future__ import annotations
 
@@ -33,19 +34,34 @@ class FastaNotFoundError(Exception):
 
 
 class FastaRecord:
-    __slots__ = ("name", "long_name", "bases", "lenc", "lenb", "offset")
+    """One record of the index.  ``body`` is the record's file text (a view of the loaded file: the bytes
+    after the header line); the upper-cased base array is only materialised on the host if someone asks for
+    ``bases`` -- the device path ingests ``body`` directly (``Engine.add_contig_text``)."""
+    __slots__ = ("name", "long_name", "body", "n_bases", "lenc", "lenb", "offset", "uniform", "_bases")
 
-    def __init__(self, name: str, long_name: str, bases: np.ndarray, lenc: int, lenb: int,
-                 offset: int):
+    def __init__(self, name: str, long_name: str, body: np.ndarray, n_bases: int, lenc: int, lenb: int,
+                 offset: int, uniform: bool):
         self.name = name
         self.long_name = long_name
-        self.bases = bases
+        self.body = body
+        self.n_bases = n_bases
         self.lenc = lenc
         self.lenb = lenb
         self.offset = offset
+        self.uniform = uniform        # every line of `lenc` bases is `lenb` bytes long: bases sit at fixed strides
+        self._bases = None
+
+    @property
+    def bases(self) -> np.ndarray:
+        if self._bases is None:
+            seg = self.body
+            b = seg[(seg != 10) & (seg != 13)]
+            _upper_inplace(b)
+            self._bases = b
+        return self._bases
 
     def __len__(self) -> int:
-        return int(self.bases.shape[0])
+        return self.n_bases
 
     def __getitem__(self, key) -> str:
         if isinstance(key, slice):
@@ -107,12 +123,9 @@ class Fasta:
             if name in self._records:
                 raise ValueError(f"Duplicate key \"{name}\"")
             if lo >= hi:
-                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, int(ends[li]) + 1)
+                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, 0, int(ends[li]) + 1, True)
             else:
                 b0, b1 = int(starts[lo]), int(ends[hi - 1])
-                seg = raw[b0:b1]
-                bases = seg[(seg != 10) & (seg != 13)]
-                _upper_inplace(bases)
                 l_end = ends[lo:hi].astype(np.int64)
                 l_start = starts[lo:hi].astype(np.int64)
                 cr = (l_end > l_start) & (raw[np.maximum(l_end - 1, 0)] == 13)
@@ -126,7 +139,9 @@ class Fasta:
                     if np.any(body != lenc) or llen[nz[-1]] > lenc:
                         raise FastaIndexingError(
                             f"Line length of fasta file is not consistent in {name}")
-                rec = FastaRecord(name, long_name, bases, lenc, lenb, b0)
+                # fixed stride: every full line has the first line's terminator ('\n' or '\r\n')
+                uniform = bool(nz.size == 0 or np.all(cr[:nz[-1]] == cr[0]))
+                rec = FastaRecord(name, long_name, raw[b0:b1], int(llen.sum()), lenc, lenb, b0, uniform)
             self._records[name] = rec
             self._order.append(rec)
 

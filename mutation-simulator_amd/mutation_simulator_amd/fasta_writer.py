@@ -48,6 +48,15 @@ class FastaWriter:
             bases = "".join(bases)
         self.write_array(np.frombuffer(bases.encode("latin-1"), dtype=np.uint8))
 
+    def write_framed(self, text: np.ndarray, n_bases: int):
+        """Append a record body that is already wrapped at the current line width (framed on the device,
+        ``Engine.fetch_sequence_framed``); must start a line, i.e. directly follow ``write_header``."""
+        if self._written != 0:
+            raise FastaWriterError("write_framed needs to start at the beginning of a line")
+        if n_bases:
+            self._out.write(memoryview(np.ascontiguousarray(text)))
+            self._written = n_bases % self._bpl
+
     def write_array(self, bases: np.ndarray):
         """Append ``bases`` (uint8) wrapped at the current line width."""
         n = int(bases.shape[0])

@@ -12,8 +12,9 @@ changed is *where* the work happens:
                                               can keep drawing from them as if the reference had run
   __get_mutations per range (Python dicts) -> msim_plan_contig: 16-byte records in HBM
   __mutate_sequence per base               -> msim_apply_contig: HIP rewrite kernel, uint8 stream
-  FastaWriter.write per base               -> FastaWriter.write_array on the fetched stream
-  VcfWriter.write per record               -> msim_render_vcf text, VcfWriter.write_raw
+  pyfaidx per-base reads                   -> msim_add_contig_text: file text to HBM, stripped + upper-cased there
+  FastaWriter.write per base               -> msim_fetch_sequence_framed: line-wrapped on the device, one write
+  VcfWriter.write per record               -> msim_render_vcf_device: record lines rendered on the device
 
 All floating-point expressions of the path are evaluated here with the reference's own formulas
 (``plan_descriptors``); the C-ABI takes integers only.
@@ -171,7 +172,10 @@ class Mutator:
         try:
             for chrom in self._sim.chromosomes:
                 rec = self._fasta[chrom.number]
-                cid = eng.add_contig(rec.bases)
+                if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
+                    cid = eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
+                else:
+                    cid = eng.add_contig(rec.bases)
                 eng.plan_contig(cid, plan_descriptors(chrom))
                 if eng.plan_was_empty(cid) and not self._args.ignore_warnings:
                     print(format_warning(
@@ -180,9 +184,13 @@ class Mutator:
                 self._fasta_writer.set_bpl(self._fasta.faidx.index[rec.name].lenc)
                 self._fasta_writer.write_header(rec.long_name)
                 eng.apply_contig(cid)
-                self._fasta_writer.write_array(eng.fetch_sequence(cid))
-                recs, pool = eng.fetch_records(cid)
-                self._vcf_writer.write_raw(_ffi.render_vcf(recs, pool, rec.bases, rec.name))
+                bpl = self._fasta.faidx.index[rec.name].lenc
+                if bpl > 0:                                    # line framing and VCF text rendered on the device
+                    out_len, _, _ = eng.result_sizes(cid)
+                    self._fasta_writer.write_framed(eng.fetch_sequence_framed(cid, bpl), out_len)
+                else:
+                    self._fasta_writer.write_array(eng.fetch_sequence(cid))
+                self._vcf_writer.write_raw(eng.render_vcf_device(cid, rec.name))
                 eng.clear()
         finally:
             import_python_streams(eng)

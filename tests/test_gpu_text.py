@@ -1,0 +1,154 @@
+"""Text on the device: VCF record lines, FASTA line framing and FASTA ingest done
+by HIP kernels must be byte-identical to the host restatements (msim_render_vcf / FastaWriter / the host
+FASTA parser), which in turn are pinned to the reference's goldens by the CLI tests."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from inputs import decorate, random_bases
+from mutation_simulator_amd import _ffi
+from mutation_simulator_amd import mutator as mm
+from test_gpu_sampler import ARGS_ORDER, _params, _sv_range
+
+pytestmark = pytest.mark.gpu
+
+ALL_SV = {1: 0.3, 2: 0.15, 3: 0.15, 4: 0.1, 5: 0.1, 6: 0.1, 7: 0.1}
+LENS = {2: (1, 9), 3: (1, 12), 4: (2, 30), 5: (2, 25), 6: (1, 15)}
+
+
+def _wrap(seq: np.ndarray, bpl: int) -> bytes:
+    """fasta_writer.py:40-58 for one record body: newline after every full line, none after a partial one."""
+    raw = seq.tobytes()
+    out = bytearray()
+    for i in range(0, len(raw), bpl):
+        out += raw[i:i + bpl]
+        if i + bpl <= len(raw):
+            out += b"\n"
+    return bytes(out)
+
+
+def _plan_apply(eng, bases, ranges):
+    cid = eng.add_contig(bases)
+    eng.plan_contig(cid, ranges)
+    eng.apply_contig(cid)
+    return cid
+
+
+@pytest.mark.parametrize("L,rate,seed,deco", [(200_000, 0.02, 1, True), (1_500_000, 0.008, 2, False),
+                                               (50_000, 0.05, 3, True)])
+def test_vcf_device_equals_host_renderer(L, rate, seed, deco):
+    bases = random_bases(L, seed)
+    if deco:
+        bases = decorate(bases, seed + 1, n_runs=6, iupac=400, lower=0)
+        bases[bases == ord("U")] = ord("A")
+    eng = _ffi.Engine(0)
+    eng.seed(seed, seed + 10)
+    eng.set_params(_params(titv=1.0))
+    r = _sv_range(0, L - 1, int(L * rate), ALL_SV, LENS)
+    try:
+        cid = _plan_apply(eng, bases, [r])
+    except KeyError:
+        pytest.skip("transversion drawn on an ambiguity code: the reference raises KeyError here")
+    recs, pool = eng.fetch_records(cid)
+    assert {1, 2, 3, 4, 5}.issubset(set(np.unique(recs["type"]).tolist()))
+    want = _ffi.render_vcf(recs, pool, bases, "chrT some name")
+    got = eng.render_vcf_device(cid, "chrT some name").tobytes()
+    assert got == want
+    eng.close()
+
+
+def test_vcf_device_tiny_contigs_cover_position_zero_and_contig_end():
+    """Thousands of 12-40 base contigs under a dense SV + translocation mix: mutations at position 0
+    (IN / DE / TLI special cases, mutator.py:346-358, 362-371, 404-413), deletions clamped at the end."""
+    rs = np.random.RandomState(11)
+    eng = _ffi.Engine(0, _ffi.PLAN_HOST)
+    eng.seed(5, 6)
+    eng.set_params(_params(titv=0.8))
+    seen_pos0 = set()
+    total = 0
+    for i in range(1500):
+        L = int(rs.randint(12, 41))
+        bases = random_bases(L, 1000 + i)
+        r = _sv_range(0, L - 1, max(1, int(L * 0.25)), ALL_SV, {2: (1, 4), 3: (1, 6), 4: (2, 5), 5: (2, 5), 6: (1, 5)})
+        cid = _plan_apply(eng, bases, [r])
+        recs, pool = eng.fetch_records(cid)
+        for t in recs["type"][recs["pos"] == 0]:
+            seen_pos0.add(int(t))
+        want = _ffi.render_vcf(recs, pool, bases, f"c{i}")
+        got = eng.render_vcf_device(cid, f"c{i}").tobytes()
+        assert got == want, (i, recs)
+        total += len(want)
+        eng.clear()
+    assert {2, 3}.issubset(seen_pos0) and total > 100_000
+    eng.close()
+
+
+def test_vcf_device_snp_only_table_from_gpu_sampler():
+    L = 3_000_000
+    eng = _ffi.Engine(0)
+    eng.seed(42, 42)
+    eng.set_params(_params(titv=2.0))
+    bases = random_bases(L, 9)
+    bases[1000:1200] = ord("N")                          # SNPs on N: REF == ALT, line suppressed
+    cid = _plan_apply(eng, bases, [_sv_range(0, L - 1, 30_000, {1: 1.0}, {})])
+    recs, pool = eng.fetch_records(cid)
+    want = _ffi.render_vcf(recs, pool, bases, "chr1")
+    assert eng.render_vcf_device(cid, "chr1").tobytes() == want
+    assert want.count(b"\n") <= len(recs)
+    eng.close()
+
+
+@pytest.mark.parametrize("bpl", [1, 7, 60, 61, 4096])
+def test_framed_fetch_equals_fasta_writer_rule(bpl):
+    L = 123_457
+    eng = _ffi.Engine(0)
+    eng.seed(3, 3)
+    eng.set_params(_params())
+    bases = random_bases(L, 4)
+    cid = _plan_apply(eng, bases, [_sv_range(0, L - 1, 1200, ALL_SV, LENS)])
+    seq = eng.fetch_sequence(cid)
+    assert eng.fetch_sequence_framed(cid, bpl).tobytes() == _wrap(seq, bpl)
+    # exact multiple of the line width: the last line is full and keeps its newline
+    cid2 = _plan_apply(eng, random_bases(bpl * 5, 1), [])
+    assert eng.fetch_sequence_framed(cid2, bpl).tobytes() == _wrap(eng.fetch_sequence(cid2), bpl)
+    eng.close()
+
+
+def test_framed_fetch_through_the_real_writer(tmp_path):
+    """Device-framed bodies written with FastaWriter.write_framed give the same file as write_array."""
+    import mutation_simulator_amd as msa
+    eng = _ffi.Engine(0)
+    eng.seed(1, 2)
+    eng.set_params(_params())
+    a, b = msa.FastaWriter(tmp_path / "a.fa"), msa.FastaWriter(tmp_path / "b.fa")
+    for i, (L, bpl) in enumerate([(1000, 60), (60, 60), (61, 60), (5, 70), (0, 60), (777, 11)]):
+        bases = random_bases(L, 20 + i)
+        cid = _plan_apply(eng, bases, [])
+        for w in (a, b):
+            w.set_bpl(bpl)
+            w.write_header(f"rec{i} x")
+        a.write_array(eng.fetch_sequence(cid))
+        b.write_framed(eng.fetch_sequence_framed(cid, bpl), L)
+    a.close()
+    b.close()
+    assert (tmp_path / "a.fa").read_bytes() == (tmp_path / "b.fa").read_bytes()
+    eng.close()
+
+
+@pytest.mark.parametrize("lenc,eol", [(60, b"\n"), (60, b"\r\n"), (1, b"\n"), (113, b"\n")])
+def test_ingest_from_text_equals_host_parse(lenc, eol):
+    L = 250_003
+    bases = decorate(random_bases(L, 8), 9, lower=12)                      # lower-case stretches included
+    raw = bases.tobytes()
+    body = eol.join(raw[i:i + lenc] for i in range(0, L, lenc)) + eol
+    eng = _ffi.Engine(0)
+    cid = eng.add_contig_text(np.frombuffer(body, dtype=np.uint8), L, lenc, lenc + len(eol))
+    want = np.frombuffer(raw.upper(), dtype=np.uint8)
+    assert np.array_equal(eng.read_contig(cid), want)
+    # no trailing newline / body shorter than claimed
+    cid2 = eng.add_contig_text(np.frombuffer(body[:-len(eol)], dtype=np.uint8), L, lenc, lenc + len(eol))
+    assert np.array_equal(eng.read_contig(cid2), want)
+    with pytest.raises(_ffi.MsimError):
+        eng.add_contig_text(np.frombuffer(body[:1000], dtype=np.uint8), L, lenc, lenc + len(eol))
+    eng.close()
