@@ -29,7 +29,8 @@ constexpr int THREADS = 256;
 constexpr int GROUP = 16;                              // output bytes per lane per iteration
 constexpr int ITERS = 4;
 constexpr int TILE = THREADS * GROUP * ITERS;          // 16384 output bytes per workgroup
-constexpr int REC_CAP = 1024;                          // records staged in LDS per tile
+constexpr int REC_CAP = 1024;                          // records staged in LDS per tile (dense tables)
+constexpr int REC_CAP_SMALL = 256;                     // sparse tables: 12 KB less LDS -> 7 instead of 4 tiles per CU
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = THREADS * SCAN_ITEMS;
 
@@ -192,16 +193,18 @@ __device__ __forceinline__ void rec_view(const msim_record &r, uint32_t o, uint3
     }
 }
 
+template <int CAP>
 struct RecWin {                 // the tile's record window in LDS
-    uint32_t o[REC_CAP];        // output offset of the record's segment
-    uint32_t e[REC_CAP];        // end of the segment
-    uint32_t s[REC_CAP];        // input position where the copy run after the segment starts
-    uint32_t m[REC_CAP];        // type | aux << 8
-};
+    uint32_t o[CAP];            // output offset of the record's segment
+    uint32_t e[CAP];            // end of the segment
+    uint32_t s[CAP];            // input position where the copy run after the segment starts
+    uint32_t m[CAP];            // type | aux << 8
+    uint32_t x[CAP];            // segment source: record.extra (insert pool offset, TLI span start), or
+};                              //   record.stop for a reversed TLI (its span is read backwards)
 
-template <bool IN_LDS>
+template <bool IN_LDS, int CAP>
 struct RecAccess {
-    const RecWin *win;
+    const RecWin<CAP> *win;
     const msim_record *recs;
     const uint32_t *off;
     int32_t r_lo;
@@ -218,6 +221,12 @@ struct RecAccess {
             rec_view(r, o, e, s);
             m = (uint32_t)r.type | ((uint32_t)r.aux << 8);
         }
+    }
+    // segment source (see RecWin::x) without a global round trip
+    __device__ __forceinline__ uint32_t ext(int32_t j) const {
+        if (IN_LDS) return win->x[j - r_lo];
+        const msim_record r = recs[j];
+        return (r.type == MSIM_TLI && (r.aux & 1)) ? r.stop : r.extra;
     }
 };
 
@@ -248,10 +257,9 @@ struct PieceSrc {
     uint32_t mode;           // 0 raw, 1 convert, 2 complement(convert); bit 8: reversed
 };
 
-__device__ __forceinline__ PieceSrc piece_src(uint32_t G, bool has, bool in_seg, int32_t j, uint32_t oj, uint32_t ej,
-                                              uint32_t sj, uint32_t mj, const uint8_t *__restrict__ in,
-                                              const uint8_t *__restrict__ pool,
-                                              const msim_record *__restrict__ recs) {
+__device__ __forceinline__ PieceSrc piece_src(uint32_t G, bool has, bool in_seg, uint32_t oj, uint32_t ej,
+                                              uint32_t sj, uint32_t mj, uint32_t xj,
+                                              const uint8_t *__restrict__ in, const uint8_t *__restrict__ pool) {
     PieceSrc p;
     p.mode = 0;
     const uint8_t *sp = in;
@@ -263,14 +271,13 @@ __device__ __forceinline__ PieceSrc piece_src(uint32_t G, bool has, bool in_seg,
             so = (int64_t)sj + rel;
         } else if (type == MSIM_IN) {
             sp = pool;
-            so = (int64_t)recs[j].extra + rel;
+            so = (int64_t)xj + rel;
         } else if (type == MSIM_IV) {                    // out[P] = rc(in[stop - (P - o)]), stop = s - 1
             so = (int64_t)sj - 16 - rel;
             p.mode = 2 | 256;
         } else {                                         // MSIM_TLI: copy of the linked TL span in[extra .. stop]
-            const msim_record r = recs[j];
-            if (r.aux & 1) { so = (int64_t)r.stop - 15 - rel; p.mode = 2 | 256; }
-            else { so = (int64_t)r.extra + rel; p.mode = 1; }
+            if ((mj >> 8) & 1) { so = (int64_t)xj - 15 - rel; p.mode = 2 | 256; }
+            else { so = (int64_t)xj + rel; p.mode = 1; }
         }
     } else {
         so = has ? (int64_t)sj + ((int64_t)G - (int64_t)ej) : (int64_t)G;
@@ -307,14 +314,6 @@ __device__ __forceinline__ u32x4 piece_finish(const Raw5 &r, uint32_t mode, cons
     }
     return pv;
 }
-__device__ __forceinline__ u32x4 piece_bytes(uint32_t G, bool has, bool in_seg, int32_t j, uint32_t oj, uint32_t ej,
-                                             uint32_t sj, uint32_t mj, const uint8_t *__restrict__ in,
-                                             const uint8_t *__restrict__ pool, const msim_record *__restrict__ recs,
-                                             const uint8_t *lut) {
-    const PieceSrc p = piece_src(G, has, in_seg, j, oj, ej, sj, mj, in, pool, recs);
-    return piece_finish(piece_load(p), p.mode, lut);
-}
-
 __device__ __forceinline__ uint32_t snp_patch(uint32_t x, uint32_t mj, uint32_t pos, const uint8_t *lut,
                                               unsigned long long *err) {
     const uint32_t nb = lut[(mj >> 8) * 256 + x];
@@ -333,8 +332,8 @@ __device__ __forceinline__ void fix_bytes(uint8_t *tile, uint32_t tile0, uint32_
     }
 }
 
-template <bool IN_LDS>
-__device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t r_hi, bool any_rec, int32_t cnt,
+template <bool IN_LDS, int CAP>
+__device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS, CAP> &A, int32_t r_hi, bool any_rec, int32_t cnt,
                                              uint8_t *tile, const uint8_t *__restrict__ in,
                                              uint8_t *__restrict__ out, const msim_record *__restrict__ recs,
                                              uint32_t n_rec, const uint8_t *__restrict__ pool, const uint8_t *lut,
@@ -343,8 +342,10 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
     const uint32_t INF = 0xffffffffu;
     const uint32_t tile0 = (uint32_t)tile0_64;
     const uint32_t tile_end = (uint32_t)min<uint64_t>(tile0_64 + TILE, L_out);
-    // ---- pass A: every group from the piece that covers its first byte.  Three phases so that all
-    // four groups' loads are in flight together: resolve sources (LDS searches), load, transform.
+    // ---- resolve: (A) every group from the piece that covers its first byte; (B) one lane per PIECE (2 per
+    // record: segment, copy run) owns the bytes from the piece start to the end of its 16-B group.  All sources
+    // are resolved first (LDS searches), then ALL loads are issued together -- the fix-up loads do not wait for
+    // a second HBM round trip behind a barrier.
     PieceSrc src[ITERS];
     uint32_t patch[ITERS];                               // SNP on the group's first byte: mj | pos handled below
     uint32_t ppos[ITERS];
@@ -369,28 +370,20 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
             j = lo - 1;
         }
         const bool has = any_rec && j >= r_lo;
-        uint32_t oj = 0, ej = 0, sj = 0, mj = 0;
+        uint32_t oj = 0, ej = 0, sj = 0, mj = 0, xj = 0;
         if (has) A.all(j, oj, ej, sj, mj);
         const bool in_seg = has && O < ej;
-        src[it] = piece_src(O, has, in_seg, j, oj, ej, sj, mj, in, pool, recs);
+        if (in_seg) xj = A.ext(j);
+        src[it] = piece_src(O, has, in_seg, oj, ej, sj, mj, xj, in, pool);
         if (!in_seg && has && (mj & 0xff) == MSIM_SN && oj == O) { patch[it] = mj | 0x80000000u; ppos[it] = sj; }
     }
-    Raw5 raw[ITERS];
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) raw[it] = piece_load(src[it]);
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        if (!live[it]) continue;
-        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
-        u32x4 pv = piece_finish(raw[it], src[it].mode, lut);
-        if (patch[it])                                   // the group starts on an SNP byte
-            pv.x = (pv.x & ~0xffu) | snp_patch(pv.x & 0xff, patch[it] & 0x7fffffffu, ppos[it], lut, err);
-        *reinterpret_cast<u32x4 *>(tile + g) = pv;
-    }
-    __syncthreads();
-    // ---- pass B: one lane per PIECE (2 per record: segment, copy run) fixes the bytes from the piece
-    // start to the end of its 16-B group
-    for (int32_t q2 = threadIdx.x; q2 < 2 * cnt; q2 += THREADS) {
+    // (B) fix-up pieces owned by this lane: FIX per pass over the piece list (one pass unless the tile is dense)
+    constexpr int FIX = 2;
+    struct Fix { PieceSrc ps; uint32_t p, end, mj, sj; bool on; };
+    auto resolve_fix = [&](int32_t q2, Fix &f) {
+        f.on = false;
+        f.ps.ptr = in; f.ps.mode = 0; f.p = f.end = f.mj = f.sj = 0;
+        if (q2 >= 2 * cnt) return;
         const int32_t q = q2 >> 1;
         const bool run = q2 & 1;
         const int32_t j = r_lo + q;
@@ -407,16 +400,52 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
             p = ej;
             end = next_o;
         }
-        if (end <= p || p < tile0 || p >= tile_end || !(p & 15u)) continue;
-        end = min(min(end, (p | 15u) + 1u), tile_end);
-        const u32x4 pv = piece_bytes(p & ~15u, true, !run, j, oj, ej, sj, mj, in, pool, recs, lut);
+        if (end <= p || p < tile0 || p >= tile_end || !(p & 15u)) return;
+        const uint32_t xj = run ? 0u : A.ext(j);
+        f.on = true;
+        f.p = p;
+        f.end = min(min(end, (p | 15u) + 1u), tile_end);
+        f.mj = run ? mj : 0u;                             // only a copy run can start on an SNP byte
+        f.sj = sj;
+        f.ps = piece_src(p & ~15u, true, !run, oj, ej, sj, mj, xj, in, pool);
+    };
+    auto apply_fix = [&](const Fix &f, const Raw5 &raw) {
+        if (!f.on) return;
+        const u32x4 pv = piece_finish(raw, f.ps.mode, lut);
         int pidx = -1;
         uint32_t pval = 0;
-        if (run && (mj & 0xff) == MSIM_SN) {              // the run starts on the SNP byte
-            pidx = (int)(p & 15u);
-            pval = snp_patch(get_byte(pv, (uint32_t)pidx), mj, sj, lut, err);
+        if ((f.mj & 0xff) == MSIM_SN) {                   // the run starts on the SNP byte
+            pidx = (int)(f.p & 15u);
+            pval = snp_patch(get_byte(pv, (uint32_t)pidx), f.mj, f.sj, lut, err);
         }
-        fix_bytes(tile, tile0, p, end, pv, pidx, pval);
+        fix_bytes(tile, tile0, f.p, f.end, pv, pidx, pval);
+    };
+    Fix fx[FIX];
+#pragma unroll
+    for (int u = 0; u < FIX; u++) resolve_fix((int32_t)threadIdx.x + u * THREADS, fx[u]);
+    // ---- all loads in flight together
+    Raw5 raw[ITERS], fraw[FIX];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) raw[it] = piece_load(src[it]);
+#pragma unroll
+    for (int u = 0; u < FIX; u++) fraw[u] = piece_load(fx[u].ps);
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        if (!live[it]) continue;
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        u32x4 pv = piece_finish(raw[it], src[it].mode, lut);
+        if (patch[it])                                   // the group starts on an SNP byte
+            pv.x = (pv.x & ~0xffu) | snp_patch(pv.x & 0xff, patch[it] & 0x7fffffffu, ppos[it], lut, err);
+        *reinterpret_cast<u32x4 *>(tile + g) = pv;
+    }
+    __syncthreads();
+    // ---- pass B: piece starts inside a group overwrite the bytes up to the group's end
+#pragma unroll
+    for (int u = 0; u < FIX; u++) apply_fix(fx[u], fraw[u]);
+    for (int32_t q2 = (int32_t)threadIdx.x + FIX * THREADS; q2 < 2 * cnt; q2 += THREADS) {   // dense tiles
+        Fix f;
+        resolve_fix(q2, f);
+        if (f.on) apply_fix(f, piece_load(f.ps));
     }
     __syncthreads();
     // ---- pass C: stream the tile out
@@ -429,6 +458,159 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS> &A, int32_t
     }
 }
 
+
+// ---- LDS path (the tile's records fit the window) --------------------------------------------------------
+// k_rewrite is VALU-issue bound on SV mixes (PMC: ~1000 VALU instructions per wave, VALU pipes ~70 % busy
+// with the first version of this routine), so everything here is about instruction count:
+//   * governing record of every 16-B group from an INDEX TABLE (one LDS atomicMax per record + a max-scan,
+//     aliased onto the tile buffer) instead of a binary search per group
+//   * SNPs do not break a copy run (the run after an SNP continues the same source stream), so only the
+//     STRUCTURAL records (everything but SNPs; compacted in order while the window is filled) own pieces and
+//     boundary fix-ups; SNP bytes are patched afterwards, one lane per record, like k_rewrite_snp does
+//   * fix-up bytes are merged with masked dword LDS atomics, not byte loops
+__device__ __forceinline__ void fix_merge(uint8_t *tile, uint32_t tile0, uint32_t p, uint32_t end, const u32x4 &pv) {
+    const uint32_t G = p & ~15u;
+    const int a = (int)(p - G), b = (int)(end - G);       // bytes [a, b) of the group, 0 < a < b <= 16
+    uint32_t *grp = reinterpret_cast<uint32_t *>(tile + (G - tile0));
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const int lo = max(a - 4 * d, 0), hi = min(b - 4 * d, 4);
+        if (hi > lo) {
+            const uint32_t w = d == 0 ? pv.x : d == 1 ? pv.y : d == 2 ? pv.z : pv.w;
+            if (hi - lo == 4) {
+                grp[d] = w;
+            } else {
+                const uint32_t mask = ((1u << (8 * (hi - lo))) - 1u) << (8 * lo);
+                atomicAnd(&grp[d], ~mask);                // other lanes own the other bytes of this dword
+                atomicOr(&grp[d], w & mask);
+            }
+        }
+    }
+}
+
+template <int CAP>
+__device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t cnt, int32_t n_struct, uint8_t *tile,
+                                                 uint32_t *wtmp, const uint8_t *__restrict__ in,
+                                                 uint8_t *__restrict__ out, const uint8_t *__restrict__ pool,
+                                                 const uint8_t *lut, uint64_t tile0_64, uint64_t L_out,
+                                                 unsigned long long *err) {
+    const uint32_t INF = 0xffffffffu;
+    const uint32_t tile0 = (uint32_t)tile0_64;
+    const uint32_t tile_end = (uint32_t)min<uint64_t>(tile0_64 + TILE, L_out);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- index table: idx[g] = 1 + window index of the last record whose output offset is <= the start of
+    // group g (0: none).  Aliases the tile buffer, which is not written before the barrier below.
+    uint32_t *idx = reinterpret_cast<uint32_t *>(tile);
+    *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x) = u32x4{0, 0, 0, 0};
+    __syncthreads();
+    for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
+        const uint32_t o = win.o[q];
+        const uint32_t g = o <= tile0 ? 0u : (o - tile0 + 15u) >> 4;
+        if (g < (uint32_t)(TILE / GROUP)) atomicMax(&idx[g], (uint32_t)q + 1u);
+    }
+    __syncthreads();
+    {
+        u32x4 v = *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x);
+        v.y = max(v.y, v.x); v.z = max(v.z, v.y); v.w = max(v.w, v.z);
+        uint32_t incl = v.w;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl = max(incl, t);
+        }
+        uint32_t ex = __shfl_up(incl, 1, 64);
+        if (lane == 0) ex = 0;
+        if (lane == 63) wtmp[wave] = incl;
+        __syncthreads();
+        for (int w = 0; w < wave; w++) ex = max(ex, wtmp[w]);
+        v.x = max(v.x, ex); v.y = max(v.y, ex); v.z = max(v.z, ex); v.w = max(v.w, ex);
+        *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x) = v;
+        __syncthreads();
+    }
+    // ---- resolve: (A) every group from the piece that covers its first byte
+    PieceSrc src[ITERS];
+    bool live[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        const uint32_t O = tile0 + g;
+        live[it] = O < tile_end;
+        const uint32_t j1 = idx[it * THREADS + threadIdx.x];
+        const bool has = j1 != 0;
+        const uint32_t q = has ? j1 - 1u : 0u;
+        const uint32_t oj = win.o[q], ej = win.e[q], sj = win.s[q], mj = win.m[q] & 0xffffu;
+        const bool in_seg = has && O < ej;
+        const uint32_t xj = win.x[q];
+        src[it] = piece_src(O, has, in_seg, oj, ej, sj, mj, xj, in, pool);
+        if (!live[it]) { src[it].ptr = in; src[it].mode = 0; }
+    }
+    // ---- resolve: (B) a structural piece that starts inside a group owns the bytes up to the group's end.
+    // piece u: record sidx[u >> 1]; even = its segment [o, e), odd = its copy run [e, next structural o)
+    struct Fix { PieceSrc ps; uint32_t p, end; bool on; };
+    auto resolve_fix = [&](int32_t u, Fix &f) {
+        f.on = false;
+        f.ps.ptr = in; f.ps.mode = 0; f.p = f.end = 0;
+        if (u >= 2 * n_struct) return;
+        const int32_t k = u >> 1;
+        const bool run = u & 1;
+        const uint32_t q = win.m[k] >> 16;
+        const uint32_t oj = win.o[q], ej = win.e[q], sj = win.s[q], mj = win.m[q] & 0xffffu;
+        uint32_t p = oj, end = ej;
+        if (run) {
+            p = ej;
+            end = k + 1 < n_struct ? win.o[win.m[k + 1] >> 16] : INF;   // later records start beyond this tile
+        }
+        if (end <= p || p < tile0 || p >= tile_end || !(p & 15u)) return;
+        f.on = true;
+        f.p = p;
+        f.end = min(min(end, (p | 15u) + 1u), tile_end);
+        f.ps = piece_src(p & ~15u, true, !run, oj, ej, sj, mj, win.x[q], in, pool);
+    };
+    Fix fx;
+    resolve_fix((int32_t)threadIdx.x, fx);
+    // ---- all loads in flight together; the index table is dead from here on
+    Raw5 raw[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) raw[it] = piece_load(src[it]);
+    const Raw5 fraw = piece_load(fx.ps);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        if (!live[it]) continue;
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        *reinterpret_cast<u32x4 *>(tile + g) = piece_finish(raw[it], src[it].mode, lut);
+    }
+    __syncthreads();
+    // ---- pass B: structural boundaries
+    if (fx.on) fix_merge(tile, tile0, fx.p, fx.end, piece_finish(fraw, fx.ps.mode, lut));
+    for (int32_t u = (int32_t)threadIdx.x + THREADS; u < 2 * n_struct; u += THREADS) {   // dense tiles
+        Fix f;
+        resolve_fix(u, f);
+        if (f.on) fix_merge(tile, tile0, f.p, f.end, piece_finish(piece_load(f.ps), f.ps.mode, lut));
+    }
+    __syncthreads();
+    // ---- pass B2: SNP bytes, one lane per record (mutator.py:334-341, 428-463)
+    for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
+        const uint32_t mj = win.m[q] & 0xffffu;
+        const uint32_t o = win.o[q];
+        if ((mj & 0xff) != MSIM_SN || o < tile0 || o >= tile_end) continue;
+        const uint32_t x = tile[o - tile0];
+        const uint32_t nb = lut[(mj >> 8) * 256 + x];
+        if (nb == 0 && (mj >> 8) != 0) report_key_error(err, (uint64_t)win.s[q], lut[768 + x]);
+        else tile[o - tile0] = (uint8_t)nb;
+    }
+    __syncthreads();
+    // ---- pass C: stream the tile out
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
+        if (tile0 + g < tile_end)
+            __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(tile + g),
+                                        reinterpret_cast<u32x4 *>(out + tile0_64 + g));
+    }
+}
+
+template <int CAP>
 __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const msim_record *__restrict__ recs,
                                                      const uint32_t *__restrict__ off,
@@ -436,7 +618,7 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
                                                      uint64_t L_out, const uint8_t *__restrict__ pool,
                                                      const uint8_t *__restrict__ lut_g,
                                                      unsigned long long *err) {
-    __shared__ RecWin win;
+    __shared__ RecWin<CAP> win;
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
     const uint32_t t = blockIdx.x;
@@ -448,26 +630,44 @@ __global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__
     const int32_t r_lo = f0 < 0 ? 0 : f0;
     const int32_t r_hi = f1;
     const int32_t cnt = any_rec ? r_hi - r_lo + 1 : 0;
-    const bool in_lds = cnt <= REC_CAP;
+    const bool in_lds = cnt <= CAP;
+    __shared__ uint32_t wtmp[THREADS / 64];
+    int32_t n_struct = 0;
     if (in_lds) {
-        for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
-            const msim_record r = recs[r_lo + q];
-            const uint32_t o = off ? off[r_lo + q] : r.pos;
-            uint32_t e, s;
-            rec_view(r, o, e, s);
-            win.o[q] = o;
-            win.e[q] = e;
-            win.s[q] = s;
-            win.m[q] = (uint32_t)r.type | ((uint32_t)r.aux << 8);
+        // window fill + ORDERED list of the structural (non-SNP) records: sidx lives in the upper halves of win.m
+        uint16_t *m16 = reinterpret_cast<uint16_t *>(win.m);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int32_t q0 = 0; q0 < cnt; q0 += THREADS) {
+            const int32_t q = q0 + (int32_t)threadIdx.x;
+            bool is_struct = false;
+            if (q < cnt) {
+                const msim_record r = recs[r_lo + q];
+                const uint32_t o = off ? off[r_lo + q] : r.pos;
+                uint32_t e, s;
+                rec_view(r, o, e, s);
+                win.o[q] = o;
+                win.e[q] = e;
+                win.s[q] = s;
+                m16[2 * q] = (uint16_t)((uint32_t)r.type | ((uint32_t)r.aux << 8));
+                win.x[q] = (r.type == MSIM_TLI && (r.aux & 1)) ? r.stop : r.extra;
+                is_struct = r.type != MSIM_SN;
+            }
+            const unsigned long long bal = __ballot(is_struct);
+            if (lane == 0) wtmp[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t base = 0, total = 0;
+            for (int w = 0; w < THREADS / 64; w++) { if (w < wave) base += wtmp[w]; total += wtmp[w]; }
+            if (is_struct) m16[2 * (n_struct + (int32_t)base + __popcll(bal & ((1ull << lane) - 1ull))) + 1] = (uint16_t)q;
+            __syncthreads();
+            n_struct += (int32_t)total;
         }
     }
     __syncthreads();
     if (in_lds) {
-        RecAccess<true> A{&win, recs, off, r_lo};
-        rewrite_tile<true>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
+        rewrite_tile_lds<CAP>(win, cnt, n_struct, tile, wtmp, in, out, pool, lut, tile0, L_out, err);
     } else {
-        RecAccess<false> A{&win, recs, off, r_lo};
-        rewrite_tile<false>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
+        RecAccess<false, CAP> A{&win, recs, off, r_lo};
+        rewrite_tile<false, CAP>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
     }
 }
 
@@ -743,8 +943,11 @@ int apply_contig_device(Ctx *c, Contig &g) {
         if (g.all_snp)
             hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
                                d_first, n, g.out_len, ctx_lut(c), d_err);
+        else if ((uint64_t)n * 2 + 64 < (uint64_t)n_tiles * REC_CAP_SMALL)   // mean records per tile < half the small window
+            hipLaunchKernelGGL(k_rewrite<REC_CAP_SMALL>, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
+                               d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err);
         else
-            hipLaunchKernelGGL(k_rewrite, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
+            hipLaunchKernelGGL(k_rewrite<REC_CAP>, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
                                d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err);
         MSIM_HIP(c, hipGetLastError());
     }
