@@ -275,9 +275,9 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes, if present
         tf = ROOT / "profiles" / "r01_traffic.json"
-        if tf.exists() and a.workload == "c2":
+        if tf.exists():
             try:
-                traffic = json.loads(tf.read_text())["traffic_bytes_per_launch"]
+                traffic = json.loads(tf.read_text())[a.workload]["traffic_bytes_per_launch"]
             except Exception:  # noqa: BLE001
                 traffic = None
         line = {
