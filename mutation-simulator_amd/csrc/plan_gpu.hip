@@ -21,7 +21,7 @@
 //   5. the SNP draws are a 3-state transducer over the following words (expect word 1 / expect
 //      word 2 / inside randbelow(2)); its state maps compose associatively, so a scan over
 //      per-thread maps gives every thread its true start state and record index
-//      (k_snp_reduce / k_snp_scan / k_snp_emit)
+//      (k_snp_reduce / k_snp_scan_cut / k_snp_emit)
 //
 // Eligible: ranges whose sample takes CPython's set path, whose type draw is deterministic SN and
 // whose SNP block equals the sampling distance (nothing is ever blocked, no randint is drawn) --
@@ -73,23 +73,65 @@ constexpr int JUMP_SPLIT = (MT_N + JUMP_OUT - 1) / JUMP_OUT;
 constexpr int JUMP_THREADS = 1024;
 constexpr int JUMP_WAVES = JUMP_THREADS / 64;
 
-__global__ __launch_bounds__(JUMP_THREADS) void k_mt_jump(uint32_t *__restrict__ states, uint32_t n_src,
-                                                          const uint32_t *__restrict__ poly) {
+// A jump needs z = the source state followed by 19 937 more raw words.  That extension is a sequential
+// recurrence (227 independent words per step, 88 steps) and used to be redone by every workgroup of every jump
+// from the same source -- 10 output splits x up to 15 multipliers -- which made it ~90 % of the cascade's GPU
+// time.  It is now computed ONCE per source state by one wave (k_mt_extend, same scheme as chunk generation)
+// into a z buffer, and the jump itself (k_mt_jump) only streams z into LDS and convolves.
+constexpr int JUMP_ZP = (JUMP_Z + 63) & ~63;             // z row pitch in words
+
+__global__ __launch_bounds__(64) void k_mt_extend(const uint32_t *__restrict__ states, uint32_t *__restrict__ zbuf) {
+    __shared__ uint32_t ring[1024];
+    const uint32_t j = blockIdx.x;
+    const uint32_t *s = states + (size_t)j * MT_N;
+    uint32_t *out = zbuf + (size_t)j * JUMP_ZP;
+    for (int i = threadIdx.x; i < MT_N; i += 64) { const uint32_t v = s[i]; ring[i] = v; out[i] = v; }
+    __syncthreads();
+    // word t beyond the state is sequence index 624 + t: needs t, t+1, t+397 (ring of 1024 >= 624 + 227 live words)
+    for (int base = 0; base < JUMP_Z - MT_N; base += GEN_STEP) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            v[q] = 0;
+            if (o < GEN_STEP && t + MT_N < JUMP_Z)
+                v[q] = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            if (o < GEN_STEP && t + MT_N < JUMP_Z) {
+                ring[(t + MT_N) & 1023] = v[q];
+                out[t + MT_N] = v[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One cascade level: every source state j < n_src is advanced by mult * n_src chunks for mult = m_first,
+// m_first + 1, ... (blockIdx.x / n_src selects the multiplier and with it the polynomial), giving the states of
+// chunks j + mult * n_src.  All multipliers of a level are independent, hence one launch per level.
+// state' = g(A) state : out[m] = XOR_{i in g} z[i+m].  One jump is spread over JUMP_SPLIT workgroups (64 outputs
+// each); inside a workgroup the 16 waves take every 16th polynomial limb (wave-uniform bit scan on the scalar
+// unit, four LDS reads in flight per lane).
+__global__ __launch_bounds__(JUMP_THREADS) void k_mt_jump(uint32_t *__restrict__ states, const uint32_t *__restrict__ zbuf,
+                                                          uint32_t n_src, const uint32_t *__restrict__ poly_level,
+                                                          uint32_t m_first) {
     __shared__ uint32_t z[JUMP_Z + 3];
     __shared__ uint32_t g[MT_POLY_WORDS];
     __shared__ uint32_t red[JUMP_THREADS];
-    const uint32_t src = blockIdx.x;
+    const uint32_t src = blockIdx.x % n_src;
+    const uint32_t mult = m_first + blockIdx.x / n_src;
+    const uint32_t *poly = poly_level + (size_t)(mult - 1) * MT_POLY_WORDS;
     const int m0 = blockIdx.y * JUMP_OUT;
-    const uint32_t *s = states + (size_t)src * MT_N;
-    uint32_t *dst = states + (size_t)(src + n_src) * MT_N;
-    for (int i = threadIdx.x; i < MT_N; i += JUMP_THREADS) z[i] = s[i];
+    const uint32_t *zs = zbuf + (size_t)src * JUMP_ZP;
+    uint32_t *dst = states + ((size_t)src + (size_t)mult * n_src) * MT_N;
+    for (int i = threadIdx.x; i < JUMP_Z; i += JUMP_THREADS) z[i] = zs[i];
     for (int i = threadIdx.x; i < MT_POLY_WORDS; i += JUMP_THREADS) g[i] = poly[i];
     __syncthreads();
-    for (int base = 0; base < JUMP_Z - MT_N; base += GEN_STEP) {
-        const int t = base + (int)threadIdx.x;
-        if ((int)threadIdx.x < GEN_STEP && t + MT_N < JUMP_Z) z[t + MT_N] = mt_twist(z[t], z[t + 1], z[t + MT_M]);
-        __syncthreads();
-    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int m = m0 + lane;
     uint32_t acc = 0;
@@ -155,27 +197,40 @@ __global__ __launch_bounds__(64) void k_mt_generate(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------ generic u32 exclusive scan
-// in place over a[0..n), total to a[n]; single workgroup (n up to a few million is fine)
+// in place over a[0..n), total to a[n]; single workgroup (these scans sit on the stream-position critical
+// path, so: 4 items per lane, wave scan by shuffles, two barriers per 4096 items)
 __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
-    __shared__ uint32_t buf[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? a[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const uint32_t t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
+    __shared__ uint32_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = i0 + q < n ? a[i0 + q] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
         }
-        const uint32_t incl = buf[threadIdx.x], c = carry;
-        if (i < n) a[i] = c + incl - v;
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
+        uint32_t pre = carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wsum[w];
+            if (w < wave) pre += t;
+            total += t;
+        }
+        uint32_t run = pre + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i0 + q < n) a[i0 + q] = run;
+            run += v[q];
+        }
+        carry += total;
         __syncthreads();
     }
     if (threadIdx.x == 0) a[n] = carry;
@@ -192,9 +247,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_accept_count(const uint32_t *__
                                                               const PlanState *ps, uint32_t W,
                                                               uint32_t shift, uint32_t n,
                                                               uint32_t *__restrict__ block_cnt,
-                                                              PlanState *ps_rw) {
+                                                              PlanState *ps_rw, uint32_t *__restrict__ cursors,
+                                                              uint32_t n_cursors) {
     __shared__ uint32_t red[ACC_THREADS / 64];
     if (blockIdx.x == 0 && threadIdx.x == 0) { ps_rw->dups = 0; ps_rw->accepted_used = 0; }   // new range
+    // bin cursors of the scatter that follows (saves a fill-buffer dispatch on the critical path)
+    for (uint32_t i = blockIdx.x * ACC_THREADS + threadIdx.x; i < n_cursors; i += gridDim.x * ACC_THREADS) cursors[i] = 0;
     const unsigned long long p0 = ps->pos;
     const uint32_t i0 = blockIdx.x * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
     uint32_t c = 0;
@@ -696,78 +754,75 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_reduce(const uint32_t *__re
     if (threadIdx.x == 0) block_maps[blockIdx.x] = total;
 }
 
-// sequential-in-chunks scan of the workgroup maps; afterwards block_maps[b] = (state, count) at the
-// start of block b when the stream starts in state 0: c[0] = count, e = state
-__global__ __launch_bounds__(1024) void k_snp_scan(SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K) {
-    __shared__ SnpMap buf[1024];
-    __shared__ uint32_t c_state, c_count;
-    if (threadIdx.x == 0) { c_state = 0; c_count = 0; }
-    __syncthreads();
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        const uint32_t i = base + threadIdx.x;
-        SnpMap v = snp_identity();
-        if (i < nb) v = block_maps[i];
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            SnpMap t = snp_identity();
-            const bool on = threadIdx.x >= (unsigned)o;
-            if (on) t = buf[threadIdx.x - o];
-            __syncthreads();
-            if (on) buf[threadIdx.x] = snp_compose(t, buf[threadIdx.x]);
-            __syncthreads();
-        }
-        SnpMap ex = snp_identity();
-        if (threadIdx.x > 0) ex = buf[threadIdx.x - 1];
-        const uint32_t s0 = c_state, n0 = c_count;
-        const SnpMap last = buf[1023];
-        __syncthreads();
-        if (i < nb) {
-            SnpMap r;
-            r.c[0] = n0 + ex.c[s0];
-            r.c[1] = r.c[2] = 0;
-            r.e = (ex.e >> (2 * s0)) & 3;
-            block_maps[i] = r;
-            // the workgroup in which the K-th SNP completes: count-before < K <= count-after
-            const uint32_t after = n0 + buf[threadIdx.x].c[s0];
-            if (r.c[0] < K && K <= after) block_maps[nb].c[1] = i;
-        }
-        if (threadIdx.x == 0) {
-            c_count = n0 + last.c[s0];
-            c_state = (last.e >> (2 * s0)) & 3;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {                               // totals after the whole window (c[1] set above)
-        block_maps[nb].c[0] = c_count;
-        block_maps[nb].e = c_state;
-    }
-}
-
-// Exact end of the SNP draws: the workgroup in which the K-th SNP completes is re-walked by one
-// workgroup; the word on which it completes + 1 is the new stream position.  Keeps the (large) emit
-// pass off the stream-position critical path.  Also saves the base for the emit pass.
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_cut(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
-                                                         uint32_t W, unsigned long long ti_lim,
-                                                         const SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
-                                                         unsigned long long *__restrict__ base_out) {
+// Scan of the workgroup maps + exact end of the SNP draws, ONE workgroup (both steps sit on the stream-position
+// critical path, so they share a launch).  Afterwards block_maps[b] = (state, count) at the start of block b
+// when the stream starts in state 0 (c[0] = count, e = state) -- what k_snp_emit needs -- and the workgroup in
+// which the K-th SNP completes has been re-walked: the word on which it completes + 1 is the new stream
+// position.  Keeps the (large) emit pass off the critical path; also saves the base for the emit pass.
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
+                                                              uint32_t W, unsigned long long ti_lim,
+                                                              SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
+                                                              unsigned long long *__restrict__ base_out) {
     __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
-    __shared__ uint32_t s_blk;
+    __shared__ uint32_t s_blk, s_bs, s_bc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long p0 = ps->snp_base;
-    if (threadIdx.x == 0) {
-        *base_out = p0;
-        if (block_maps[nb].c[0] < K) { ps->flags |= FLAG_SNP_OVERFLOW; s_blk = 0xffffffffu; }
-        else s_blk = block_maps[nb].c[1];                 // found by k_snp_scan
-    }
+    if (threadIdx.x == 0) { s_blk = 0xffffffffu; *base_out = p0; }
+    uint32_t c_state = 0, c_count = 0;                    // carried across chunks, identical in every lane
     __syncthreads();
-    const uint32_t b = s_blk;
-    if (b == 0xffffffffu) return;
-    const uint32_t base = b * SNP_BLOCK2;
-    const SnpBits m = snp_stage(raw, p0, base, W, ti_lim, sw);
-    SnpMap total;
-    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
-    const uint32_t bs = block_maps[b].e, bc = block_maps[b].c[0];
+    for (uint32_t base = 0; base < nb; base += 4 * SNP_THREADS) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        SnpMap v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = i0 + q < nb ? block_maps[i0 + q] : snp_identity();
+        SnpMap incl = snp_compose(snp_compose(v[0], v[1]), snp_compose(v[2], v[3]));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const SnpMap t = snp_shfl_up(incl, o);
+            if (lane >= o) incl = snp_compose(t, incl);
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        SnpMap run = snp_identity();                      // all blocks of this chunk before i0
+        for (int w = 0; w < wave; w++) run = snp_compose(run, wave_tot[w]);
+        SnpMap total = wave_tot[0];
+        for (int w = 1; w < SNP_THREADS / 64; w++) total = snp_compose(total, wave_tot[w]);
+        SnpMap ex = snp_shfl_up(incl, 1);
+        if (lane == 0) ex = snp_identity();
+        run = snp_compose(run, ex);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const SnpMap nxt = snp_compose(run, v[q]);
+            if (i0 + q < nb) {
+                SnpMap r;
+                r.c[0] = c_count + run.c[c_state];
+                r.c[1] = r.c[2] = 0;
+                r.e = (run.e >> (2 * c_state)) & 3;
+                block_maps[i0 + q] = r;
+                // the workgroup in which the K-th SNP completes: count-before < K <= count-after
+                const uint32_t after = c_count + nxt.c[c_state];
+                if (r.c[0] < K && K <= after) { s_blk = i0 + q; s_bs = r.e; s_bc = r.c[0]; }
+            }
+            run = nxt;
+        }
+        const uint32_t n_count = c_count + total.c[c_state], n_state = (total.e >> (2 * c_state)) & 3;
+        __syncthreads();
+        c_count = n_count;
+        c_state = n_state;
+    }
+    if (threadIdx.x == 0) {                               // totals after the whole window
+        block_maps[nb].c[0] = c_count;
+        block_maps[nb].c[1] = s_blk;
+        block_maps[nb].e = c_state;
+        if (c_count < K) ps->flags |= FLAG_SNP_OVERFLOW;
+    }
+    if (c_count < K) return;                              // uniform
+    const uint32_t b = s_blk, bs = s_bs, bc = s_bc;
+    const uint32_t wbase = b * SNP_BLOCK2;
+    const SnpBits m = snp_stage(raw, p0, wbase, W, ti_lim, sw);
+    SnpMap tot2;
+    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, tot2);
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
     const uint32_t idx = bc + ex.c[bs];                   // SNPs completed before this lane's words
     uint32_t emits, from2;
@@ -776,7 +831,7 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_cut(const uint32_t *__restr
     if (idx < K && K <= idx + mine) {                     // the K-th SNP completes in this lane: on which word?
         uint32_t e = emits;
         for (uint32_t q = idx + 1; q < K; q++) e &= e - 1; // drop the first K - idx - 1 emits
-        const unsigned long long w0 = p0 + base + (unsigned long long)threadIdx.x * SNP_ITEMS2;
+        const unsigned long long w0 = p0 + wbase + (unsigned long long)threadIdx.x * SNP_ITEMS2;
         ps->pos = w0 + (unsigned long long)__builtin_ctz(e) + 1;
     }
 }
@@ -1182,7 +1237,11 @@ struct GpuStream {
     uint64_t cap = 0;
     uint32_t *d_states = nullptr;       // chunk start states
     uint32_t states_cap = 0;            // allocated states
-    uint32_t n_states = 0;              // valid states (power of two once the cascade ran)
+    uint32_t n_states = 0;              // valid states = n_src * (m_done + 1)
+    uint32_t lvl = 0, n_src = 1, m_done = 0;   // cascade position: level, states at its start, multipliers done
+    uint32_t *d_z = nullptr;            // extensions of the current level's source states (k_mt_extend)
+    size_t z_cap = 0;                   // in source states
+    int z_lvl = -1;                     // level whose sources d_z holds
     uint32_t n_chunks = 0;              // chunks generated
     uint64_t pos = 0;                   // next unconsumed index into x (exact, host copy)
     uint64_t last_session_words = 0;    // words the previous (re)seeded session went through: sizing hint
@@ -1193,7 +1252,9 @@ struct GpuStream {
     uint32_t waited_chunks = 0;         // the plan stream already waited for chunks below this
 };
 
-constexpr int N_SETS = 3;                // rotating scratch: chain(u+1) overlaps emit(u)
+constexpr int N_SETS = 32;               // scratch sets: one per in-flight contig, so the plan stream does not have to
+                                         // wait for the emit stream (a cross-stream wait costs tens of us of idle
+                                         // queue even when it is about to be satisfied); 288 GB of HBM make this free
 
 struct SampleSet {                       // scratch of one sampled range
     uint32_t *acc = nullptr; size_t acc_cap = 0;          // accepted draws, stream order
@@ -1277,6 +1338,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     for (auto &s : g->s) {
         if (s.d_raw) (void)hipFree(s.d_raw);
         if (s.d_states) (void)hipFree(s.d_states);
+        if (s.d_z) (void)hipFree(s.d_z);
         for (auto e : s.ready_ev) (void)hipEventDestroy(e);
     }
     for (auto e : g->ev_pool) (void)hipEventDestroy(e);
@@ -1312,6 +1374,7 @@ void gpu_plan_destroy(GpuPlan *g) {
 }
 
 void gpu_plan_invalidate(GpuPlan *g) {
+    g->unit = g->snp_unit = g->mixed_unit = 0;            // a new pass: contig i meets scratch set i again (sizes fit)
     for (auto &s : g->s) {
         if (s.live) s.last_session_words = std::max<uint64_t>(s.pos, MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS);
         s.live = false;
@@ -1343,12 +1406,16 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
         // what the previous session on this context went through, else at least double the stream.
         uint64_t want = std::max<uint64_t>(upto, s.pos + g->reserve_words[si]);
         want = std::max<uint64_t>(want, std::min<uint64_t>(s.last_session_words, want * 64));
-        if (s.n_chunks) want = std::max<uint64_t>(want, std::min<uint64_t>(2 * have, (uint64_t)MT_N + (1ull << MT_JUMP_LEVELS) * MT_CHUNK_WORDS));
+        if (s.n_chunks) want = std::max<uint64_t>(want, std::min<uint64_t>(2 * have, (uint64_t)MT_N + (uint64_t)MT_JUMP_MAX_CHUNKS * MT_CHUNK_WORDS));
         const uint32_t need_chunks = (uint32_t)((want - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
+        if (need_chunks > (uint32_t)MT_JUMP_MAX_CHUNKS) return fail(c, MSIM_ERR_UNSUPPORTED, "random stream longer than the jump table covers");
+        // states the cascade will hold once it covers need_chunks: whole levels, then part of one
         uint32_t want_states = 1;
-        int levels = 0;
-        while (want_states < need_chunks) { want_states <<= 1; levels++; }
-        if (levels > MT_JUMP_LEVELS) return fail(c, MSIM_ERR_UNSUPPORTED, "random stream longer than the jump table covers");
+        for (int l = 0; l < MT_JUMP_LEVELS && want_states < need_chunks; l++) {
+            const uint32_t R = (uint32_t)MT_JUMP_RADIX[l];
+            if ((uint64_t)want_states * R >= need_chunks) { want_states *= (need_chunks + want_states - 1) / want_states; break; }
+            want_states *= R;
+        }
         if (!g->d_poly) {
             MSIM_HIP(c, hipMalloc(&g->d_poly, sizeof(MT_JUMP_POLY)));
             MSIM_HIP(c, hipMemcpy(g->d_poly, MT_JUMP_POLY, sizeof(MT_JUMP_POLY), hipMemcpyHostToDevice));
@@ -1387,9 +1454,9 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
         };
         while (s.n_chunks < need_chunks) {
             const uint32_t hi = std::min<uint32_t>(need_chunks, s.n_states);
-            // a generation batch costs ~300 us of latency whatever its size and batches queue in order,
-            // so the first few cascade levels (1, 2, 4 ... states) are not worth a batch of their own
-            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, 64u)) {
+            // a generation batch costs ~300 us of latency whatever its size and batches queue in order, so the
+            // single state before the first cascade level is not worth a batch of its own
+            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, (uint32_t)MT_JUMP_RADIX[0])) {
                 // states [n_chunks, hi) are complete on the jump stream: generate those chunks
                 hipEvent_t st_ev;
                 int rc = take_event(st_ev);
@@ -1409,13 +1476,34 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                 s.ready_ev.push_back(ev);
                 s.n_chunks = hi;
             }
-            if (s.n_chunks < need_chunks) {                // next cascade level: states [0,n) -> [n,2n)
-                int r = 0;
-                while ((1u << r) < s.n_states) r++;
-                hipLaunchKernelGGL(k_mt_jump, dim3(s.n_states, JUMP_SPLIT), dim3(JUMP_THREADS), 0, g->jump_stream,
-                                   s.d_states, s.n_states, g->d_poly + (size_t)r * MT_POLY_WORDS);
+            if (s.n_chunks < need_chunks) {                // extend the cascade (mixed radix, one launch per level)
+                if (s.m_done == (uint32_t)MT_JUMP_RADIX[s.lvl] - 1) {       // level complete: the next one starts
+                    s.lvl++;
+                    s.n_src = s.n_states;
+                    s.m_done = 0;
+                }
+                const uint32_t R = (uint32_t)MT_JUMP_RADIX[s.lvl];
+                const uint32_t m_need = std::min<uint32_t>(R - 1, (need_chunks + s.n_src - 1) / s.n_src - 1);
+                uint32_t level_base = 0;
+                for (uint32_t l = 0; l < s.lvl; l++) level_base += (uint32_t)MT_JUMP_RADIX[l] - 1;
+                if (s.z_lvl != (int)s.lvl) {               // extend this level's source states once
+                    if (s.z_cap < s.n_src) {
+                        MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));   // the old buffer may still be read
+                        if (s.d_z) MSIM_HIP(c, hipFree(s.d_z));
+                        s.d_z = nullptr; s.z_cap = 0;
+                        MSIM_HIP(c, hipMalloc(&s.d_z, (size_t)s.n_src * JUMP_ZP * sizeof(uint32_t)));
+                        s.z_cap = s.n_src;
+                    }
+                    hipLaunchKernelGGL(k_mt_extend, dim3(s.n_src), dim3(64), 0, g->jump_stream, s.d_states, s.d_z);
+                    MSIM_HIP(c, hipGetLastError());
+                    s.z_lvl = (int)s.lvl;
+                }
+                hipLaunchKernelGGL(k_mt_jump, dim3(s.n_src * (m_need - s.m_done), JUMP_SPLIT), dim3(JUMP_THREADS), 0,
+                                   g->jump_stream, s.d_states, s.d_z, s.n_src,
+                                   g->d_poly + (size_t)level_base * MT_POLY_WORDS, s.m_done + 1);
                 MSIM_HIP(c, hipGetLastError());
-                s.n_states <<= 1;
+                s.m_done = m_need;
+                s.n_states = s.n_src * (s.m_done + 1);
             }
         }
     }
@@ -1458,6 +1546,8 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     s.ready_hi.clear();
     s.waited_chunks = 0;
     s.n_states = 1;
+    s.lvl = 0; s.n_src = 1; s.m_done = 0;
+    s.z_lvl = -1;
     s.n_chunks = 0;
     s.pos = (uint64_t)h.idx;
     s.live = true;
@@ -1547,6 +1637,16 @@ static hipEvent_t next_chain_event(GpuPlan *g) {
     return e;
 }
 
+// A scratch set may still be read by the emit work of its previous user.  Skip the cross-stream wait when that
+// work is known to have finished.
+static int wait_if_pending(Ctx *c, bool &pending, hipEvent_t ev) {
+    if (!pending) return MSIM_OK;
+    if (hipEventQuery(ev) == hipSuccess) { pending = false; return MSIM_OK; }
+    (void)hipGetLastError();                               // hipErrorNotReady is not an error
+    MSIM_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));
+    return MSIM_OK;
+}
+
 // Enqueue the chain of one sampled range on the plan stream: where does random.sample() end (exact stream
 // cut in the device PlanState) and which values did it draw (the set, as a bitmap in S.bitmap).
 struct SampleLaunch { SampleSet *S; uint32_t W, bmw, bnb; };
@@ -1565,7 +1665,7 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
     const uint32_t W = (uint32_t)wd;
     SampleSet &S = g->sample[g->unit++ % N_SETS];
-    if (S.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, S.emit_done, 0));   // its last emit still reads it
+    if ((rc = wait_if_pending(c, S.pending, S.emit_done))) return rc;          // its last emit may still read it
     const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
     const size_t bm_words64 = (size_t)((n + 63) / 64);
     const uint32_t bmw = (uint32_t)bm_words64;
@@ -1579,10 +1679,9 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     // ---- chain (plan stream): where does this sample end?
     const uint32_t n_bins = (uint32_t)((n + BIN_VALUES - 1) >> BIN_SHIFT);
     const bool binned = n_bins <= (uint32_t)MAX_BINS;
-    hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
-                       (uint32_t)(32 - bits), (uint32_t)n, S.cnt, g->d_ps);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
+    uint32_t bin_cap = 0;
     if (binned) {
+
         // expected k/n_bins per bin (the last bin is partial), 16-sigma + slack capacity
         // sub-list s of a bin is filled by the scatter workgroups with index == s (mod 16).  Only the
         // workgroups up to the one holding the k-th accepted draw contribute (the window has slack
@@ -1590,11 +1689,16 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
         const uint32_t nbk = (uint32_t)((double)k / p_acc / SPL_BLOCK) + 3;
         const double mean = (double)((nbk + BIN_SUBS - 1) / BIN_SUBS) * SPL_BLOCK * p_acc *
                             std::min(1.0, (double)BIN_VALUES / (double)n);
-        const uint32_t bin_cap = (uint32_t)std::min<double>((double)k + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
+        bin_cap = (uint32_t)std::min<double>((double)k + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
         if ((rc = grow(c, (void **)&S.bins, &S.bins_cap, (size_t)n_bins * BIN_SUBS * bin_cap * sizeof(uint32_t), &grew))) return rc;
         if ((rc = grow(c, (void **)&S.cursors, &S.cursors_cap, (size_t)MAX_BINS * BIN_SUBS * sizeof(uint32_t), &grew))) return rc;
         if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, (size_t)n_bins * BIN_WORDS * 4, &grew))) return rc;
-        MSIM_HIP(c, hipMemsetAsync(S.cursors, 0, (size_t)n_bins * BIN_SUBS * sizeof(uint32_t), c->stream));
+    }
+    hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
+                       (uint32_t)(32 - bits), (uint32_t)n, S.cnt, g->d_ps, binned ? S.cursors : nullptr,
+                       binned ? n_bins * BIN_SUBS : 0u);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
+    if (binned) {
         hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, c->stream, py.d_raw, g->d_ps, W,
                            (uint32_t)(32 - bits), (uint32_t)n, k, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc,
                            g->d_ps);
@@ -1685,15 +1789,14 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         const uint32_t W2 = (uint32_t)w2;
         const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
         SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if (T.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, T.emit_done, 0));
+        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
         if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
         if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
         if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
         if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
         hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2, (uint32_t)K);
-        hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
         MSIM_HIP(c, hipGetLastError());
         hipEvent_t ce = next_chain_event(g);
@@ -1810,7 +1913,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     g->unverified = true;
     bool grew = false;
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
-    if (M.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, M.emit_done, 0));   // its last emit still reads it
+    if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;          // its last emit may still read it
     if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
     const uint32_t nbk = (k + CB_BLOCK - 1) / CB_BLOCK;
     if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)k * 4 + 64, &grew))) return rc;
@@ -1935,15 +2038,14 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         const uint32_t W2 = (uint32_t)w2;
         const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
         SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if (T.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, T.emit_done, 0));
+        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
         if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
         if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
         if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
         if ((rc = ensure_words(c, g, 0, p_s + W2 + 1))) return rc;
         hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2, n_sn);
-        hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps, nb2, n_sn, T.base);
         MSIM_HIP(c, hipGetLastError());
         hipEvent_t ce2 = next_chain_event(g);
@@ -2036,7 +2138,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     const uint32_t W = (uint32_t)wd;
     bool grew = false;
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
-    if (M.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, M.emit_done, 0));
+    if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;
     if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
     if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;
@@ -2082,15 +2184,14 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
         const uint32_t W2 = (uint32_t)w2;
         const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
         SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if (T.pending) MSIM_HIP(c, hipStreamWaitEvent(c->stream, T.emit_done, 0));
+        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
         if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
         if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
         if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
         if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
         hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan, dim3(1), dim3(1024), 0, c->stream, T.maps, nb2, (uint32_t)K);
-        hipLaunchKernelGGL(k_snp_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                            (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
         MSIM_HIP(c, hipGetLastError());
         hipEvent_t ce = next_chain_event(g);

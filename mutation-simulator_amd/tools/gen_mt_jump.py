@@ -11,9 +11,13 @@ With the raw output sequence x[t] this reads, word for word,
     x[J + m] = XOR over { i : coefficient i of g_J is 1 } of x[i + m]
 
 so a jump is a GF(2) convolution of ~20 k freshly generated raw words with the polynomial -- a good
-GPU job.  This script computes phi (Berlekamp-Massey on one output bit), then g_r = x^(CHUNK * 2^r)
-mod phi for r = 0..LEVELS-1 by repeated squaring, checks each against plain sequential generation,
-and writes them as a C table.  Pure integer arithmetic on Python ints; runs in well under a minute.
+GPU job.  This script computes phi (Berlekamp-Massey on one output bit), then the polynomials of a
+MIXED-RADIX cascade: level l turns n_l = prod(RADIX[:l]) chunk-start states into n_l * RADIX[l] by applying,
+to every one of them, the jumps m * n_l * CHUNK for m = 1 .. RADIX[l]-1 -- all of one level in a single
+kernel launch, so the cascade is len(RADIX) dependent launches deep (a radix-2 doubling cascade with the
+same reach was 13 deep, and every small level costs ~250 us of latency on the critical path of a step).
+g_{l,m} = x^(m * n_l * CHUNK) mod phi; each is checked against plain sequential generation or against
+the composition of two smaller jumps.  Pure integer arithmetic on Python ints; runs in about a minute.
 """
 from __future__ import annotations
 
@@ -24,7 +28,7 @@ N, M = 624, 397
 DEG = 19937
 CHUNK_BLOCKS = 256                 # one stream chunk = 256 regenerations = 159 744 words
 CHUNK = N * CHUNK_BLOCKS
-LEVELS = 13                        # doubling levels: up to 2^13 chunks = 1.3 G words per cascade
+RADIX = [16, 16, 16, 2]             # 8192 chunks = 1.3 G words per cascade, 4 dependent launches
 
 
 def twist(a, b, c):
@@ -123,36 +127,70 @@ def main():
         assert acc == 0, "characteristic polynomial check failed"
     print(f"phi: degree {DEG}, weight {len(supp)}", file=sys.stderr)
 
-    polys = []
-    g = poly_powx(CHUNK, phi, DEG)
-    for r in range(LEVELS):
-        polys.append(g)
-        g = poly_mod(poly_square(g), phi, DEG)
-    # verify level 0 and 1 against sequential generation (level r>1 follow by the same squaring)
-    long_seq = raw_sequence(state, 2 * CHUNK + DEG + 2 * N)
-    for r in (0, 1):
-        J = CHUNK << r
-        got = apply_jump(polys[r], long_seq)
+    polys = []                                             # level-major: level l holds RADIX[l]-1 polynomials
+    stride = 1
+    by_mult = {}                                           # multiple of CHUNK -> polynomial
+    for radix in RADIX:
+        for m in range(1, radix):
+            g = poly_powx(CHUNK * m * stride, phi, DEG)
+            polys.append(g)
+            by_mult[m * stride] = g
+        stride *= radix
+    # verify the smallest jumps against sequential generation
+    long_seq = raw_sequence(state, 3 * CHUNK + DEG + 2 * N)
+    for mult in (1, 2, 3):
+        J = CHUNK * mult
+        got = apply_jump(by_mult[mult], long_seq)
         want = long_seq[J:J + N]
-        assert got[1:] == want[1:] and (got[0] ^ want[0]) & 0x80000000 == 0, f"jump level {r} mismatch"
-    # composition check for the top level: g_top == g_{top-1}^2 is by construction; check x^J identity
-    # on a cheaper relation: g_2 applied == g_1 applied twice (spot check first 8 words)
-    w1 = apply_jump(polys[1], long_seq)                     # window at 2*CHUNK
-    assert w1[1:9] == long_seq[2 * CHUNK + 1:2 * CHUNK + 9]
-    print("jump polynomials verified against sequential generation", file=sys.stderr)
+        assert got[1:] == want[1:] and (got[0] ^ want[0]) & 0x80000000 == 0, f"jump x{mult} mismatch"
+    # every other polynomial: x^(a+b) = x^a * x^b mod phi, checked as "jump by a, then by b" == "jump by a+b"
+    # on the first words of the window (apply_jump needs DEG + N words after the start: regenerate from the window)
+    def jump_window(g, window):
+        seq2 = raw_sequence(window, DEG + 2 * N)
+        idx = [i for i in range(g.bit_length()) if (g >> i) & 1]
+        out = []
+        for m_ in range(8):
+            acc = 0
+            for i in idx:
+                acc ^= seq2[i + m_]
+            out.append(acc)
+        return out
+    def full_window(g, window):
+        seq2 = raw_sequence(window, DEG + 2 * N)
+        return apply_jump(g, seq2)
+    mults = sorted(by_mult)
+    for mult in mults:
+        if mult <= 3:
+            continue
+        # split into two known multiples
+        a_ = max(x for x in mults if x < mult and (mult - x) in by_mult)
+        b_ = mult - a_
+        mid = full_window(by_mult[a_], state)
+        mid[0] = (mid[0] & 0x80000000) | (mid[0] & 0x7FFFFFFF)
+        got = jump_window(by_mult[b_], mid)
+        want = jump_window(by_mult[mult], state)
+        assert got[1:] == want[1:], f"composition check failed for x{mult} = x{a_} + x{b_}"
+    print(f"{len(polys)} jump polynomials verified (sequential generation / composition)", file=sys.stderr)
 
     words_per_poly = (DEG + 31) // 32
     with open(out_path, "w") as fh:
         fh.write("// GENERATED by tools/gen_mt_jump.py -- do not edit.\n")
-        fh.write("// MT19937 jump-ahead polynomials g_r(x) = x^(CHUNK * 2^r) mod phi(x), little-endian\n")
+        fh.write("// MT19937 jump-ahead polynomials of a mixed-radix cascade: level l (n_l = product of the radices below it)\n")
+        fh.write("// holds g_{l,m}(x) = x^(m * n_l * CHUNK) mod phi(x) for m = 1 .. RADIX[l]-1, level-major; little-endian\n")
         fh.write("// 32-bit limbs (bit i of limb j = coefficient of x^(32 j + i)).\n")
         fh.write("#pragma once\n#include <stdint.h>\n\nnamespace msim {\n")
         fh.write(f"constexpr int MT_CHUNK_BLOCKS = {CHUNK_BLOCKS};\n")
         fh.write(f"constexpr int MT_CHUNK_WORDS = {CHUNK};\n")
-        fh.write(f"constexpr int MT_JUMP_LEVELS = {LEVELS};\n")
+        fh.write(f"constexpr int MT_JUMP_LEVELS = {len(RADIX)};\n")
+        fh.write("constexpr int MT_JUMP_RADIX[MT_JUMP_LEVELS] = {" + ", ".join(str(r) for r in RADIX) + "};\n")
+        fh.write(f"constexpr int MT_JUMP_POLYS = {len(polys)};\n")
+        total = 1
+        for r in RADIX:
+            total *= r
+        fh.write(f"constexpr int MT_JUMP_MAX_CHUNKS = {total};\n")
         fh.write(f"constexpr int MT_POLY_WORDS = {words_per_poly};\n")
         fh.write(f"constexpr int MT_POLY_DEG = {DEG};\n")
-        fh.write("static const uint32_t MT_JUMP_POLY[MT_JUMP_LEVELS][MT_POLY_WORDS] = {\n")
+        fh.write("static const uint32_t MT_JUMP_POLY[MT_JUMP_POLYS][MT_POLY_WORDS] = {\n")
         for g in polys:
             limbs = [(g >> (32 * j)) & 0xFFFFFFFF for j in range(words_per_poly)]
             fh.write("  {")
@@ -162,7 +200,7 @@ def main():
                 fh.write(f"0x{w:08x}u,")
             fh.write("\n  },\n")
         fh.write("};\n}  // namespace msim\n")
-    print(f"wrote {out_path} ({LEVELS} polynomials, weights "
+    print(f"wrote {out_path} ({len(polys)} polynomials, weights "
           f"{[bin(g).count('1') for g in polys[:4]]}...)", file=sys.stderr)
 
 
