@@ -1395,9 +1395,11 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
         // then serialise): the cascade must not queue behind a 300 us generation batch
         int lo = 0, hi = 0;
         MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        (void)lo; (void)hi;
-        MSIM_HIP(c, hipStreamCreateWithFlags(&g->gen_stream, hipStreamNonBlocking));
-        MSIM_HIP(c, hipStreamCreateWithFlags(&g->jump_stream, hipStreamNonBlocking));
+        (void)hi;
+        // bulk side work at the LOWEST priority: its workgroups (88 KB of LDS each for a jump) must not crowd out
+        // the chain kernels of the first contigs, which already wait for nothing but free CU resources
+        MSIM_HIP(c, hipStreamCreateWithPriority(&g->gen_stream, hipStreamNonBlocking, lo));
+        MSIM_HIP(c, hipStreamCreateWithPriority(&g->jump_stream, hipStreamNonBlocking, lo));
     }
     const uint64_t have = MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS;
     if (upto > have) {
