@@ -1,4 +1,5 @@
 // C-ABI entry points of libmsim.so (include/msim.h).  gfx950 (MI355X) only.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -636,6 +637,33 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
     if (rc) return rc;
     *contig = (int)c->contigs.size() - 1;
     return MSIM_OK;
+}
+
+// ---- test hooks: NOT part of the ABI (absent from include/msim.h).  They expose the two host-side chains of the
+// device PLAN engines (plan_host.cpp) so that the CPU test tier can pin them against CPython's own random.sample /
+// random.randint and run them under ASan/UBSan without a GPU (tests/test_cabi_host.py).
+int msim_dbg_sample_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, const uint32_t *words, uint64_t n_words,
+                           uint32_t *pos_out, uint64_t *consumed) {
+    Ctx *c = C(p);
+    if (!c || !consumed || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    int64_t d = c->params.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, c->params.block[t]);
+    size_t used = 0;
+    const int rc = sample_ranges_host(c, ranges, n_ranges, d, words, (size_t)n_words, pos_out, &used);
+    *consumed = used;
+    return rc;
+}
+
+int msim_dbg_chain_boundary(msim_ctx *p, const msim_range *r, uint64_t L, const uint32_t *pos, const uint8_t *type,
+                            uint64_t n, const uint32_t *words, uint64_t n_words, uint32_t *stop, uint64_t *consumed,
+                            uint64_t *kept, int64_t *len_delta) {
+    Ctx *c = C(p);
+    if (!c || !r || !consumed || !kept || !len_delta) return MSIM_ERR_ARG;
+    size_t used = 0, nk = 0;
+    long long delta = 0;
+    const int rc = chain_boundary_host(c, *r, L, pos, type, (size_t)n, words, (size_t)n_words, stop, &used, &nk, &delta);
+    *consumed = used; *kept = nk; *len_delta = delta;
+    return rc;
 }
 
 int msim_stats(msim_ctx *p, msim_timing *out) {

@@ -133,3 +133,137 @@ def test_host_planner_vcf_matches_reference(name, tmp_path):
     assert [random.getrandbits(32) for _ in range(4)] == meta["py_next_words_after"]
     assert [int(x) for x in np.random.randint(0, 4294967296, size=4, dtype=np.uint32)] == \
         meta["np_next_words_after"]
+
+
+# ---------------------------------------------------------------------- host chains of the device engines
+# sample_ranges_host / chain_boundary_host (plan_host.cpp) run on the host but read words the DEVICE generated,
+# so the GPU tests exercise them only on a GPU box.  The debug exports let this tier pin them directly against
+# CPython's own random.sample / random.randint, word for word.
+def _dbg(lib):
+    import ctypes as C
+    vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    lib.msim_dbg_sample_ranges.restype = C.c_int
+    lib.msim_dbg_sample_ranges.argtypes = [vp, C.POINTER(_ffi.Range), C.c_int, vp, C.c_uint64, vp, u64p]
+    lib.msim_dbg_chain_boundary.restype = C.c_int
+    lib.msim_dbg_chain_boundary.argtypes = [vp, C.POINTER(_ffi.Range), C.c_uint64, vp, vp, C.c_uint64, vp, C.c_uint64,
+                                            vp, u64p, u64p, C.POINTER(C.c_int64)]
+    return lib
+
+
+def _host_engine(blocks=None):
+    eng = _ffi.Engine(device=-1)
+    p = _ffi.Params()
+    for i in range(8):
+        p.block[i] = 1
+    for t, v in (blocks or {}).items():
+        p.block[t] = v
+    p.ti_lim = (1 << 52) + 1
+    eng.set_params(p)
+    return eng
+
+
+def _snp_only_range(start, stop, k):
+    r = _ffi.Range()
+    r.start, r.stop, r.k = start, stop, k
+    r.setsize = mm.sample_setsize(k)
+    r.n_types = 1
+    r.types[0] = 1
+    r.cdf_thr[0] = 1 << 53
+    return r
+
+
+@pytest.mark.parametrize("seed,d", [(1, 1), (2, 1), (3, 3), (4, 2)])
+def test_host_range_sampler_equals_cpython_sample(seed, d):
+    """Chains of random.sample() calls over set-path and pool-path ranges of very different sizes, minimum
+    distance d: positions and the exact number of words consumed equal CPython's."""
+    import ctypes as C
+    rs = np.random.RandomState(seed)
+    ranges, at = [], 0
+    for i in range(300):
+        length = int(rs.choice([12, 40, 300, 1000, 5000, 60_000, 700_000]))
+        rate = float(rs.choice([0.001, 0.01, 0.05, 0.2, 0.3]))
+        k = int(length * rate)
+        n = (at + length - 1 - (k - 1) * d) - at
+        if k > 0 and n >= k:
+            ranges.append(_snp_only_range(at, at + length - 1, k))
+        at += length + int(rs.randint(1, 500))
+    assert any((r.stop - (r.k - 1) * d) - r.start <= r.setsize for r in ranges)      # pool path present
+    assert any((r.stop - (r.k - 1) * d) - r.start > 4096 * 64 for r in ranges)       # large-bitmap path present
+    K = sum(r.k for r in ranges)
+    ref = random.Random(seed)
+    clone = random.Random(seed)
+    words = np.array([clone.getrandbits(32) for _ in range(3 * K + 100_000)], dtype=np.uint32)
+    want = []
+    for r in ranges:
+        n = (r.stop - (r.k - 1) * d) - r.start
+        vals = sorted(ref.sample(range(n), r.k))                                       # util.py:104-109
+        want += [r.start + v + d * i for i, v in enumerate(vals)]
+    nxt = ref.getrandbits(32)
+    eng = _host_engine({t: d for t in range(1, 8)})
+    lib = _dbg(eng.lib)
+    got = np.zeros(K + 8, dtype=np.uint32)
+    used = C.c_uint64()
+    arr = (_ffi.Range * len(ranges))(*ranges)
+    rc = lib.msim_dbg_sample_ranges(eng.h, arr, len(ranges), C.c_void_p(words.ctypes.data), len(words),
+                                    C.c_void_p(got.ctypes.data), C.byref(used))
+    assert rc == 0
+    assert got[:K].tolist() == want
+    assert int(words[used.value]) == nxt                    # exactly as many words consumed as CPython drew
+    # a window that is too short is reported, never silently truncated
+    rc = lib.msim_dbg_sample_ranges(eng.h, arr, len(ranges), C.c_void_p(words.ctypes.data), used.value - 1,
+                                    C.c_void_p(got.ctypes.data), C.byref(used))
+    assert rc != 0
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
+def test_host_boundary_chain_equals_cpython_randint(seed):
+    """The boundary pass over non-SNP candidates (mutator.py:184-265) restated with CPython's randint:
+    same stops, same drops (blocked / inversion reaching the contig end), same words consumed, same length delta."""
+    import ctypes as C
+    rs = np.random.RandomState(seed)
+    L = 400_000
+    n = 20_000
+    pos = np.sort(rs.choice(np.arange(0, L - 1), size=n, replace=False)).astype(np.uint32)
+    types = rs.choice([2, 3, 4, 5], size=n).astype(np.uint8)                 # IN, DE, DU, IV
+    lens = {2: (1, int(rs.randint(1, 40))), 3: (1, int(rs.randint(1, 300))), 4: (2, int(rs.randint(2, 90))),
+            5: (2, int(rs.randint(2, 500)))}
+    if seed == 5:
+        lens[2] = (7, 7)                                                        # width-1 randint burns words until a 0 bit
+    block = {1: 1, 2: int(rs.randint(1, 4)), 3: int(rs.randint(1, 30)), 4: 1, 5: int(rs.randint(1, 9)), 6: 1, 7: 1}
+    r = _ffi.Range()
+    r.start, r.stop, r.k = 0, L - 1, n
+    for t, (a, b) in lens.items():
+        r.min_len[t], r.max_len[t] = a, b
+    ref = random.Random(seed)
+    clone = random.Random(seed)
+    words = np.array([clone.getrandbits(32) for _ in range(4 * n + 1000)], dtype=np.uint32)
+    want, blk_hi, delta, kept = [], 0, 0, 0
+    for p, t in zip(pos.tolist(), types.tolist()):
+        if p < blk_hi:
+            want.append(0xFFFFFFFF)
+            continue
+        if t == 5 and p + lens[5][1] >= L - 1:                                  # mutator.py:240-245
+            want.append(0xFFFFFFFF)
+            continue
+        s = ref.randint(p + lens[t][0] - 1, p + lens[t][1] - 1)
+        if t in (3, 4) and s > L - 1:
+            s = L - 1
+        want.append(s)
+        blk_hi = (p if t == 2 else s) + 1 + block[t]
+        delta += {2: 1, 3: -1, 4: 1, 5: 0}[t] * (s - p + 1)
+        kept += 1
+    nxt = ref.getrandbits(32)
+    eng = _host_engine(block)
+    lib = _dbg(eng.lib)
+    stop = np.zeros(n, dtype=np.uint32)
+    used, nk, dl = C.c_uint64(), C.c_uint64(), C.c_int64()
+    rc = lib.msim_dbg_chain_boundary(eng.h, C.byref(r), L, C.c_void_p(pos.ctypes.data), C.c_void_p(types.ctypes.data), n,
+                                     C.c_void_p(words.ctypes.data), len(words), C.c_void_p(stop.ctypes.data),
+                                     C.byref(used), C.byref(nk), C.byref(dl))
+    assert rc == 0
+    assert stop.tolist() == want
+    assert nk.value == kept and dl.value == delta
+    assert int(words[used.value]) == nxt
+    assert 0xFFFFFFFF in want and kept > 1000
+    eng.close()
