@@ -1,0 +1,1214 @@
+// Device kernels of the PLAN engines (included once, by plan_gpu.hip).            gfx950 (MI355X) only.
+//
+//   1. MT19937 in bulk: jump-ahead cascade (k_mt_extend / k_mt_jump) and chunk generation (k_mt_generate)
+//   2. accepted draws of random.sample() in stream order (k_accept_* / k_bin_scatter)
+//   3. first-occurrence de-duplication and the exact stream cut (k_bin_dedupe / k_sample_tail)
+//   4. bitmap -> sorted positions (k_bitmap_count / k_bitmap_expand[_cand])
+//   5. the SNP ti/tv transducer (k_snp_reduce / k_snp_scan_cut / k_snp_emit)
+//   6. SV mixes: type draw, non-SNP compaction, keep flags, record compaction, insert pool
+//      host-sampled contigs: word window, records from positions
+// See plan_gpu.hip for what each engine enqueues and DESIGN.md section 3 for the reasoning.
+#pragma once
+#include <algorithm>
+
+#include "ctx.h"
+#include "mt_jump_table.h"
+
+namespace msim {
+
+namespace {
+
+constexpr int GEN_STEP = MT_N - MT_M;                    // 227 words are independent per step
+constexpr int JUMP_Z = MT_POLY_DEG + MT_N;               // raw words a jump convolves: 20561
+constexpr int ACC_THREADS = 256;
+constexpr int ACC_ITEMS = 8;
+constexpr int ACC_BLOCK = ACC_THREADS * ACC_ITEMS;       // 2048 stream words per workgroup
+constexpr int SNP_THREADS = 256;
+
+
+constexpr int BM_THREADS = 256;
+
+enum : uint32_t { FLAG_SAMPLE_OVERFLOW = 1u, FLAG_SNP_OVERFLOW = 2u };
+
+// device-resident bookkeeping of one plan call
+struct PlanState {
+    unsigned long long pos;        // index into the raw word array of the next unconsumed word
+    unsigned long long snp_base;   // pos at which the current contig's SNP draws start (= end of its samples)
+    uint32_t flags;
+    uint32_t dups;                 // duplicates found by the first-k insert
+    uint32_t accepted_used;        // accepted draws consumed by the last sample
+    uint32_t n_nsn;                // SV mixes: non-SNP candidates of the current range
+    uint32_t n_rec, n_sn;          // SV mixes: kept mutations / kept SNPs of the current contig
+    uint32_t pool_len;             // SV mixes: insert bases of the current contig
+};
+
+// ------------------------------------------------------------------ 1. MT19937 in bulk
+// state' = g(A) state : z = state followed by 19 937 more raw words, out[m] = XOR_{i in g} z[i+m].
+// One jump is spread over JUMP_SPLIT workgroups (64 outputs each) so the early cascade levels, which
+// have few source states, still fill the chip; inside a workgroup the four waves take every fourth
+// polynomial limb (wave-uniform bit scan on the scalar unit, four LDS reads in flight per lane).
+constexpr int JUMP_OUT = 64;
+constexpr int JUMP_SPLIT = (MT_N + JUMP_OUT - 1) / JUMP_OUT;
+
+constexpr int JUMP_THREADS = 1024;
+constexpr int JUMP_WAVES = JUMP_THREADS / 64;
+
+// A jump needs z = the source state followed by 19 937 more raw words.  That extension is a sequential
+// recurrence (227 independent words per step, 88 steps) and used to be redone by every workgroup of every jump
+// from the same source -- 10 output splits x up to 15 multipliers -- which made it ~90 % of the cascade's GPU
+// time.  It is now computed ONCE per source state by one wave (k_mt_extend, same scheme as chunk generation)
+// into a z buffer, and the jump itself (k_mt_jump) only streams z into LDS and convolves.
+constexpr int JUMP_ZP = (JUMP_Z + 63) & ~63;             // z row pitch in words
+
+__global__ __launch_bounds__(64) void k_mt_extend(const uint32_t *__restrict__ states, uint32_t *__restrict__ zbuf) {
+    __shared__ uint32_t ring[1024];
+    const uint32_t j = blockIdx.x;
+    const uint32_t *s = states + (size_t)j * MT_N;
+    uint32_t *out = zbuf + (size_t)j * JUMP_ZP;
+    for (int i = threadIdx.x; i < MT_N; i += 64) { const uint32_t v = s[i]; ring[i] = v; out[i] = v; }
+    __syncthreads();
+    // word t beyond the state is sequence index 624 + t: needs t, t+1, t+397 (ring of 1024 >= 624 + 227 live words)
+    for (int base = 0; base < JUMP_Z - MT_N; base += GEN_STEP) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            v[q] = 0;
+            if (o < GEN_STEP && t + MT_N < JUMP_Z)
+                v[q] = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            if (o < GEN_STEP && t + MT_N < JUMP_Z) {
+                ring[(t + MT_N) & 1023] = v[q];
+                out[t + MT_N] = v[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One cascade level: every source state j < n_src is advanced by mult * n_src chunks for mult = m_first,
+// m_first + 1, ... (blockIdx.x / n_src selects the multiplier and with it the polynomial), giving the states of
+// chunks j + mult * n_src.  All multipliers of a level are independent, hence one launch per level.
+// state' = g(A) state : out[m] = XOR_{i in g} z[i+m].  One jump is spread over JUMP_SPLIT workgroups (64 outputs
+// each); inside a workgroup the 16 waves take every 16th polynomial limb (wave-uniform bit scan on the scalar
+// unit, four LDS reads in flight per lane).
+__global__ __launch_bounds__(JUMP_THREADS) void k_mt_jump(uint32_t *__restrict__ states, const uint32_t *__restrict__ zbuf,
+                                                          uint32_t n_src, const uint32_t *__restrict__ poly_level,
+                                                          uint32_t m_first) {
+    __shared__ uint32_t z[JUMP_Z + 3];
+    __shared__ uint32_t g[MT_POLY_WORDS];
+    __shared__ uint32_t red[JUMP_THREADS];
+    const uint32_t src = blockIdx.x % n_src;
+    const uint32_t mult = m_first + blockIdx.x / n_src;
+    const uint32_t *poly = poly_level + (size_t)(mult - 1) * MT_POLY_WORDS;
+    const int m0 = blockIdx.y * JUMP_OUT;
+    const uint32_t *zs = zbuf + (size_t)src * JUMP_ZP;
+    uint32_t *dst = states + ((size_t)src + (size_t)mult * n_src) * MT_N;
+    for (int i = threadIdx.x; i < JUMP_Z; i += JUMP_THREADS) z[i] = zs[i];
+    for (int i = threadIdx.x; i < MT_POLY_WORDS; i += JUMP_THREADS) g[i] = poly[i];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = m0 + lane;
+    uint32_t acc = 0;
+    if (m < MT_N) {
+        const uint32_t *zl = z + m;
+        for (int j = wave; j < MT_POLY_WORDS; j += JUMP_WAVES) {
+            uint32_t bits = __builtin_amdgcn_readfirstlane(g[j]);
+            const uint32_t *zj = zl + j * 32;
+            while (bits) {
+                uint32_t v0, v1 = 0, v2 = 0, v3 = 0;
+                v0 = zj[__builtin_ctz(bits)]; bits &= bits - 1;
+                if (bits) { v1 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
+                if (bits) { v2 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
+                if (bits) { v3 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
+                acc ^= (v0 ^ v1) ^ (v2 ^ v3);
+            }
+        }
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < JUMP_OUT && m0 + (int)threadIdx.x < MT_N) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int w = 0; w < JUMP_WAVES; w++) r ^= red[threadIdx.x + 64 * w];
+        dst[m0 + threadIdx.x] = r;
+    }
+}
+
+// chunk j: raw words x[624 + j*S .. 624 + (j+1)*S) from state_j (the 624 words before the chunk).
+// One wave per chunk: 227 words are mutually independent per step, a step's reads never touch the
+// slots it overwrites, so the only ordering needed is "this step's writes before the next step's
+// reads" -- a single-wave workgroup barrier.
+__global__ __launch_bounds__(64) void k_mt_generate(const uint32_t *__restrict__ states,
+                                                    uint32_t *__restrict__ raw, uint32_t first_chunk) {
+    __shared__ uint32_t ring[1024];
+    const uint32_t j = first_chunk + blockIdx.x;
+    const uint32_t *s = states + (size_t)j * MT_N;
+    uint32_t *out = raw + MT_N + (size_t)j * MT_CHUNK_WORDS;
+    for (int i = threadIdx.x; i < MT_N; i += 64) ring[i] = s[i];
+    __syncthreads();
+    // word t of the chunk is sequence index 624 + t relative to the state: needs t, t+1, t+397
+    for (int base = 0; base < MT_CHUNK_WORDS; base += GEN_STEP) {
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            v[q] = 0;
+            if (o < GEN_STEP && t < MT_CHUNK_WORDS)
+                v[q] = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int o = (int)threadIdx.x + 64 * q;
+            const int t = base + o;
+            if (o < GEN_STEP && t < MT_CHUNK_WORDS) {
+                ring[(t + MT_N) & 1023] = v[q];
+                out[t] = v[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ generic u32 exclusive scan
+// in place over a[0..n), total to a[n]; single workgroup (these scans sit on the stream-position critical
+// path, so: 4 items per lane, wave scan by shuffles, two barriers per 4096 items)
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t wsum[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = i0 + q < n ? a[i0 + q] : 0;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t pre = carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const uint32_t t = wsum[w];
+            if (w < wave) pre += t;
+            total += t;
+        }
+        uint32_t run = pre + incl - mine;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i0 + q < n) a[i0 + q] = run;
+            run += v[q];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a[n] = carry;
+}
+
+// ------------------------------------------------------------------ 2. accepted draws, in order
+__device__ __forceinline__ bool accepted(const uint32_t *__restrict__ raw, unsigned long long p,
+                                         uint32_t shift, uint32_t n, uint32_t &v) {
+    v = mt_temper(raw[p]) >> shift;                      // getrandbits(bits)
+    return v < n;                                        // _randbelow: retry while r >= n
+}
+
+__global__ __launch_bounds__(ACC_THREADS) void k_accept_count(const uint32_t *__restrict__ raw,
+                                                              const PlanState *ps, uint32_t W,
+                                                              uint32_t shift, uint32_t n,
+                                                              uint32_t *__restrict__ block_cnt,
+                                                              PlanState *ps_rw, uint32_t *__restrict__ cursors,
+                                                              uint32_t n_cursors) {
+    __shared__ uint32_t red[ACC_THREADS / 64];
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ps_rw->dups = 0; ps_rw->accepted_used = 0; }   // new range
+    // bin cursors of the scatter that follows (saves a fill-buffer dispatch on the critical path)
+    for (uint32_t i = blockIdx.x * ACC_THREADS + threadIdx.x; i < n_cursors; i += gridDim.x * ACC_THREADS) cursors[i] = 0;
+    const unsigned long long p0 = ps->pos;
+    const uint32_t i0 = blockIdx.x * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; q++) {
+        uint32_t v;
+        if (i0 + q < W && accepted(raw, p0 + i0 + q, shift, n, v)) c++;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(ACC_THREADS) void k_accept_scatter(const uint32_t *__restrict__ raw,
+                                                                const PlanState *__restrict__ ps, uint32_t W,
+                                                                uint32_t shift, uint32_t n,
+                                                                const uint32_t *__restrict__ block_off,
+                                                                uint32_t *__restrict__ acc) {
+    __shared__ uint32_t part[ACC_THREADS];
+    const unsigned long long p0 = ps->pos;
+    const uint32_t i0 = blockIdx.x * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
+    uint32_t vals[ACC_ITEMS];
+    uint32_t mask = 0, c = 0;
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; q++) {
+        uint32_t v = 0;
+        const bool ok = i0 + q < W && accepted(raw, p0 + i0 + q, shift, n, v);
+        vals[q] = v;
+        if (ok) { mask |= 1u << q; c++; }
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < ACC_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t w = block_off[blockIdx.x] + part[threadIdx.x] - c;
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; q++)
+        if (mask & (1u << q)) acc[w++] = vals[q];
+}
+
+// ------------------------------------------------------------------ 3. first-occurrence de-dup
+__global__ __launch_bounds__(256) void k_bitmap_insert(const uint32_t *__restrict__ acc, uint32_t count,
+                                                       uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps) {
+    // every lane issues its four atomics back to back (latency-bound otherwise), then counts
+    const uint32_t base = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t old[4], bit[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t i = base + 256 * q;
+        old[q] = 0; bit[q] = 0;
+        if (i < count) {
+            const uint32_t v = acc[i];
+            bit[q] = 1u << (v & 31);
+            old[q] = atomicOr(&bitmap[v >> 5], bit[q]);
+        }
+    }
+    uint32_t d = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) d += (old[q] & bit[q]) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(&ps->dups, d);
+}
+
+// ---- locality-friendly de-dup: bins of 2^20 values, each de-duplicated in a 128 KB LDS bitmap ----
+constexpr int BIN_SHIFT = 20;
+constexpr int BIN_VALUES = 1 << BIN_SHIFT;
+constexpr int BIN_WORDS = BIN_VALUES / 32;               // 32768 x u32 = 128 KB
+constexpr int MAX_BINS = 1024;                           // n <= 2^30; larger ranges use the global-atomic path
+constexpr int BIN_SUBS = 16;                             // sub-cursors per bin: workgroup b fills sub-list b % 16,
+                                                         // so a cursor sees 1/16 of the same-address atomics
+constexpr int SPL_ITEMS = 32;
+constexpr int SPL_BLOCK = ACC_THREADS * SPL_ITEMS;       // 8192 stream words per workgroup (= 4 count blocks)
+constexpr int SPL_LDS = SPL_BLOCK + SPL_BLOCK / 32;
+
+// Ordered accept (as k_accept_scatter) but the first k accepted draws go to their value bin (order
+// inside a bin is irrelevant: only the SET of the first k matters), later ones to the ordered tail
+// list.  A workgroup stages its 8192 words through row-padded LDS (coalesced loads, conflict-free
+// per-lane runs), counting-sorts its accepted values by bin in LDS, reserves bin space with one
+// atomicAdd per non-empty bin and writes every bin's run out contiguously.
+__global__ __launch_bounds__(ACC_THREADS) void k_bin_scatter(const uint32_t *__restrict__ raw, const PlanState *ps,
+                                                             uint32_t W, uint32_t shift, uint32_t n, uint32_t k,
+                                                             const uint32_t *__restrict__ block_off, uint32_t n_bins,
+                                                             uint32_t bin_cap, uint32_t *__restrict__ cursors,
+                                                             uint32_t *__restrict__ bins, uint32_t *__restrict__ tail,
+                                                             PlanState *ps_rw) {
+    __shared__ uint32_t stage[SPL_LDS];
+    __shared__ uint32_t part[ACC_THREADS];
+    __shared__ uint32_t lhist[MAX_BINS];
+    __shared__ uint32_t lbase[MAX_BINS + 1];
+    __shared__ uint32_t gbase[MAX_BINS];
+    for (uint32_t b = threadIdx.x; b < n_bins; b += ACC_THREADS) lhist[b] = 0;
+    const unsigned long long p0 = ps->pos;
+    const uint32_t base = blockIdx.x * SPL_BLOCK;
+    {
+        uint32_t w[SPL_ITEMS];
+#pragma unroll
+        for (int r = 0; r < SPL_ITEMS; r++) {
+            const uint32_t idx = r * ACC_THREADS + threadIdx.x;
+            w[r] = base + idx < W ? raw[p0 + base + idx] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < SPL_ITEMS; r++) {
+            const uint32_t idx = r * ACC_THREADS + threadIdx.x;
+            uint32_t v = 0xffffffffu;                    // rejected / out of window
+            if (base + idx < W) { v = mt_temper(w[r]) >> shift; if (v >= n) v = 0xffffffffu; }
+            stage[idx + (idx >> 5)] = v;
+        }
+    }
+    __syncthreads();
+    uint32_t vals[SPL_ITEMS];
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++) {
+        vals[q] = stage[threadIdx.x * 33 + q];
+        c += vals[q] != 0xffffffffu ? 1u : 0u;
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < ACC_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t a = block_off[blockIdx.x * (SPL_BLOCK / ACC_BLOCK)] + part[threadIdx.x] - c;   // accepted index
+    uint32_t slot[SPL_ITEMS];
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++) {
+        slot[q] = 0xffffffffu;
+        if (vals[q] != 0xffffffffu) {
+            if (a < k) slot[q] = atomicAdd(&lhist[vals[q] >> BIN_SHIFT], 1u);
+            else tail[a - k] = vals[q];
+            a++;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the local histogram (<= 1024 bins: 4 per lane) + global space reservation
+    {
+        uint32_t h[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            h[q] = b < n_bins ? lhist[b] : 0;
+            sum += h[q];
+        }
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 1; o < ACC_THREADS; o <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            if (b < n_bins) {
+                lbase[b] = run;
+                gbase[b] = h[q] ? atomicAdd(&cursors[b * BIN_SUBS + (blockIdx.x & (BIN_SUBS - 1))], h[q]) : 0;
+            }
+            run += h[q];
+        }
+        if (threadIdx.x == ACC_THREADS - 1) lbase[MAX_BINS] = part[ACC_THREADS - 1];   // total placed
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++)
+        if (slot[q] != 0xffffffffu) stage[lbase[vals[q] >> BIN_SHIFT] + slot[q]] = vals[q];
+    __syncthreads();
+    const uint32_t total = lbase[MAX_BINS];
+    bool over = false;
+    for (uint32_t i = threadIdx.x; i < total; i += ACC_THREADS) {
+        const uint32_t v = stage[i];
+        const uint32_t b = v >> BIN_SHIFT;
+        const uint32_t at = gbase[b] + (i - lbase[b]);
+        if (at < bin_cap) bins[((size_t)b * BIN_SUBS + (blockIdx.x & (BIN_SUBS - 1))) * bin_cap + at] = v;
+        else over = true;
+    }
+    if (over) atomicOr(&ps_rw->flags, FLAG_SAMPLE_OVERFLOW);
+}
+
+// One workgroup per bin: LDS bitmap, LDS atomics, duplicate count, then the bitmap slice is written
+// out with coalesced 16-B stores (so the global bitmap needs no memset).
+__global__ __launch_bounds__(512) void k_bin_dedupe(const uint32_t *__restrict__ bins, const uint32_t *__restrict__ cursors,
+                                                    uint32_t bin_cap, uint32_t *__restrict__ bitmap,
+                                                    PlanState *__restrict__ ps) {
+    __shared__ __attribute__((aligned(16))) uint32_t lbm[BIN_WORDS];
+    __shared__ uint32_t red[8];
+    const uint32_t b = blockIdx.x;
+    uint4 *l4 = reinterpret_cast<uint4 *>(lbm);
+    for (int i = threadIdx.x; i < BIN_WORDS / 4; i += 512) l4[i] = uint4{0, 0, 0, 0};
+    __syncthreads();
+    uint32_t d = 0;
+    for (int sub = 0; sub < BIN_SUBS; sub++) {
+        const uint32_t cnt = min(cursors[b * BIN_SUBS + sub], bin_cap);
+        const uint32_t *mine = bins + ((size_t)b * BIN_SUBS + sub) * bin_cap;
+        for (uint32_t i = threadIdx.x; i < cnt; i += 512) {
+            const uint32_t v = mine[i] & (BIN_VALUES - 1);
+            const uint32_t bit = 1u << (v & 31);
+            const uint32_t old = atomicOr(&lbm[v >> 5], bit);
+            d += (old & bit) ? 1u : 0u;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 8; w++) t += red[w];
+        if (t) atomicAdd(&ps->dups, t);
+    }
+    uint4 *g4 = reinterpret_cast<uint4 *>(bitmap + (size_t)b * BIN_WORDS);
+    for (int i = threadIdx.x; i < BIN_WORDS / 4; i += 512) g4[i] = l4[i];
+}
+
+// Tail rounds + exact cut.  One workgroup.  `total_acc` = accepted draws available in the window.
+// `acc` holds the accepted draws from accepted-index `acc_first` on (0: the whole list, k: tail only).
+constexpr int TAIL_LDS_OFFS = 8192;
+__global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict__ raw, const uint32_t *__restrict__ acc,
+                                                      uint32_t acc_first,
+                                                      const uint32_t *__restrict__ block_off, uint32_t n_blocks,
+                                                      uint32_t W, uint32_t shift, uint32_t n, uint32_t k,
+                                                      uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps) {
+    __shared__ uint32_t red[16];
+    __shared__ uint32_t s_need, s_pos, s_blk;
+    __shared__ uint32_t loff[TAIL_LDS_OFFS + 1];
+    const bool offs_in_lds = n_blocks <= TAIL_LDS_OFFS;
+    if (offs_in_lds)
+        for (uint32_t i = threadIdx.x; i <= n_blocks; i += 1024) loff[i] = block_off[i];
+    const uint32_t total_acc = block_off[n_blocks];
+    if (threadIdx.x == 0) { s_pos = k; s_need = ps->dups; }
+    __syncthreads();
+    if (total_acc < k) {                                  // window too small even for the first k
+        if (threadIdx.x == 0) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
+        return;
+    }
+    while (true) {
+        const uint32_t need = s_need, pos = s_pos;
+        if (need == 0) break;
+        if (pos + need > total_acc) {
+            if (threadIdx.x == 0) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
+            return;
+        }
+        uint32_t d = 0;
+        for (uint32_t i = threadIdx.x; i < need; i += 1024) {
+            const uint32_t v = acc[pos - acc_first + i];
+            const uint32_t bit = 1u << (v & 31);
+            const uint32_t old = atomicOr(&bitmap[v >> 5], bit);
+            if (old & bit) d++;
+        }
+        for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+        __syncthreads();                                  // everyone has read s_need / s_pos
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < 16; w++) t += red[w];
+            s_pos = pos + need;
+            s_need = t;
+        }
+        __syncthreads();
+    }
+    // A accepted draws were consumed; the stream cut is one past the word holding the A-th of them
+    const uint32_t A = s_pos;
+    if (threadIdx.x == 0) {
+        uint32_t lo = 0, hi = n_blocks;                   // last block with block_off[b] < A
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((offs_in_lds ? loff[mid] : block_off[mid]) < A) lo = mid; else hi = mid;
+        }
+        s_blk = lo;
+    }
+    __syncthreads();
+    const uint32_t b = s_blk;
+    const uint32_t want = A - (offs_in_lds ? loff[b] : block_off[b]);   // 1-based rank inside block b
+    const unsigned long long p0 = ps->pos;
+    // 1024 threads x 2 words cover the block's 2048 words in stream order
+    uint32_t f[2], v;
+    const uint32_t i0 = b * ACC_BLOCK + threadIdx.x * 2;
+    f[0] = (i0 < W && accepted(raw, p0 + i0, shift, n, v)) ? 1u : 0u;
+    f[1] = (i0 + 1 < W && accepted(raw, p0 + i0 + 1, shift, n, v)) ? 1u : 0u;
+    const uint32_t mine = f[0] + f[1];
+    // inclusive scan over the workgroup: ballot-free, via shuffles + LDS
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= (unsigned)o) incl += t;
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) red[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) wave_off += red[w];
+    incl += wave_off;
+    const uint32_t excl = incl - mine;
+    if (excl < want && want <= incl) {
+        const uint32_t idx = (f[0] && excl + 1 == want) ? i0 : i0 + 1;
+        ps->pos = p0 + idx + 1;
+        ps->snp_base = p0 + idx + 1;
+        ps->accepted_used = A;
+    }
+}
+
+// ------------------------------------------------------------------ 4. bitmap -> sorted positions
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_count(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                             uint32_t *__restrict__ block_cnt) {
+    __shared__ uint32_t red[BM_THREADS / 64];
+    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+    uint32_t c = i < n_words ? (uint32_t)__popcll(bm[i]) : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// record i of the range: pos = start + value + d * rank (util.py:104-109), type SN, stop = pos
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                              const uint32_t *__restrict__ block_off,
+                                                              uint32_t start, uint32_t d,
+                                                              msim_record *__restrict__ recs) {
+    __shared__ uint32_t part[BM_THREADS];
+    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+    uint64_t w = i < n_words ? bm[i] : 0;
+    const uint32_t c = (uint32_t)__popcll(w);
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < BM_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t rank = block_off[blockIdx.x] + part[threadIdx.x] - c;
+    while (w) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+        w &= w - 1;
+        const uint32_t pos = start + (i * 64 + bit) + d * rank;
+        msim_record r;
+        r.pos = pos; r.stop = pos; r.extra = 0; r.type = MSIM_SN; r.aux = 0; r.rsv = 0;
+        recs[rank] = r;
+        rank++;
+    }
+}
+
+// ------------------------------------------------------------------ 5. SNP ti/tv transducer
+// states: 0 expect 1st uniform word, 1 expect 2nd (decides ti / tv), 2 inside randbelow(2)
+struct SnpMap { uint32_t c[3]; uint32_t e; };            // per start state: emitted count, end state (2 bits each)
+
+__device__ __forceinline__ SnpMap snp_compose(const SnpMap &f, const SnpMap &g) {   // f first, then g
+    SnpMap r;
+    r.e = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        const uint32_t mid = (f.e >> (2 * s)) & 3;
+        r.c[s] = f.c[s] + g.c[mid];
+        r.e |= ((g.e >> (2 * mid)) & 3) << (2 * s);
+    }
+    return r;
+}
+__device__ __forceinline__ SnpMap snp_identity() { SnpMap r; r.c[0] = r.c[1] = r.c[2] = 0; r.e = 0 | (1 << 2) | (2 << 4); return r; }
+
+// A lane owns 32 consecutive stream words, reduced to three bitmasks:
+//   A bit i : words (i-1, i) as a uniform(0,1) sample decide "transition"  (p <= p_ti, mutator.py:438)
+//   B bit i : word i ends a randbelow(2) loop (getrandbits(2) < 2, i.e. top bit clear)
+//   T bit i : the transversion column word i would pick (bit 30)
+// With them the transducer walks SNP by SNP (ctz over the masks) instead of word by word.
+struct SnpBits { uint32_t A, B, T; int E; };             // E = valid words (0..32)
+
+// Branch-free, bit-sliced transducer over one lane's <= 32 words.  Bit k (k = 0..2) of s0/s1/s2 says
+// whether the simulation that STARTED in state k is currently in state 0/1/2, so all three start
+// states advance together with a fixed sequence of bitwise ops per word (no divergence):
+//   word i:  emit = (s1 & a_i) | (s2 & b_i);  s0' = emit;  s1' = s0;  s2' = (s1 & ~a_i) | (s2 & ~b_i)
+// Emit counts are packed byte counters (<= 32 each).
+__device__ __forceinline__ SnpMap snp_lane_map(const SnpBits &m) {
+    uint32_t s0 = 1u, s1 = 2u, s2 = 4u, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint32_t live = i < m.E ? 7u : 0u;         // words beyond the window leave the state alone
+        const uint32_t a = (0u - ((m.A >> i) & 1u)) & live;
+        const uint32_t b = (0u - ((m.B >> i) & 1u)) & live;
+        const uint32_t emit = (s1 & a) | (s2 & b);
+        const uint32_t n2 = (s1 & ~a & live) | (s2 & ~b & live) | (s2 & ~live);
+        const uint32_t n1 = (s0 & live) | (s1 & ~live);
+        const uint32_t n0 = emit | (s0 & ~live);
+        cnt += (emit | (emit << 7) | (emit << 14)) & 0x00010101u;
+        s0 = n0; s1 = n1; s2 = n2;
+    }
+    SnpMap r;
+    r.c[0] = cnt & 0xff; r.c[1] = (cnt >> 8) & 0xff; r.c[2] = (cnt >> 16) & 0xff;
+    r.e = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t e = ((s0 >> k) & 1u) ? 0u : ((s1 >> k) & 1u) ? 1u : 2u;
+        r.e |= e << (2 * k);
+    }
+    return r;
+}
+
+// One simulation (true start state st): emit mask (bit i: an SNP completes on word i) and the mask of
+// emits that came out of the randbelow(2) loop (transversions).  Returns the end state.
+__device__ __forceinline__ uint32_t snp_lane_emits(uint32_t st, const SnpBits &m, uint32_t &emits, uint32_t &from2) {
+    uint32_t s0 = st == 0, s1 = st == 1, s2 = st == 2;
+    emits = 0; from2 = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const uint32_t live = i < m.E ? 1u : 0u;
+        const uint32_t a = (m.A >> i) & live, b = (m.B >> i) & live;
+        const uint32_t e1 = s1 & a, e2 = s2 & b;
+        const uint32_t n2 = (s1 & ~a & live) | (s2 & ~b & live) | (s2 & ~live & 1u);
+        const uint32_t n1 = (s0 & live) | (s1 & ~live & 1u);
+        const uint32_t n0 = e1 | e2 | (s0 & ~live & 1u);
+        emits |= (e1 | e2) << i;
+        from2 |= e2 << i;
+        s0 = n0; s1 = n1; s2 = n2;
+    }
+    return s0 ? 0u : s1 ? 1u : 2u;
+}
+
+constexpr int SNP_ITEMS2 = 32;
+constexpr int SNP_BLOCK2 = SNP_THREADS * SNP_ITEMS2;     // 8192 stream words per workgroup
+constexpr int SNP_LDS_WORDS = SNP_BLOCK2 + SNP_BLOCK2 / 32 + 1;
+
+// Coalesced load of the workgroup's 8192 words (tempered) into LDS, row-padded (stride 33) so a
+// lane's 32 consecutive words are conflict-free; then each lane builds its masks.
+__device__ __forceinline__ SnpBits snp_stage(const uint32_t *__restrict__ raw, unsigned long long p0, uint32_t base,
+                                             uint32_t W, unsigned long long ti_lim, uint32_t *sw) {
+    uint32_t w[SNP_ITEMS2];
+#pragma unroll
+    for (int r = 0; r < SNP_ITEMS2; r++) {               // all 32 loads in flight before the first use
+        const uint32_t idx = r * SNP_THREADS + threadIdx.x;
+        w[r] = base + idx < W ? raw[p0 + base + idx] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < SNP_ITEMS2; r++) {
+        const uint32_t idx = r * SNP_THREADS + threadIdx.x;
+        sw[idx + (idx >> 5)] = base + idx < W ? mt_temper(w[r]) : 0u;
+    }
+    if (threadIdx.x == 0) sw[SNP_LDS_WORDS - 1] = base > 0 ? mt_temper(raw[p0 + base - 1]) : 0;
+    __syncthreads();
+    SnpBits m;
+    m.A = m.B = m.T = 0;
+    const uint32_t first = base + threadIdx.x * SNP_ITEMS2;
+    m.E = first >= W ? 0 : (int)std::min<uint32_t>(SNP_ITEMS2, W - first);
+    uint32_t prev = threadIdx.x ? sw[(threadIdx.x - 1) * 33 + 31] : sw[SNP_LDS_WORDS - 1];
+    const uint32_t *mine = sw + threadIdx.x * 33;
+#pragma unroll
+    for (int i = 0; i < SNP_ITEMS2; i++) {
+        const uint32_t w = mine[i];
+        const unsigned long long u = ((unsigned long long)(prev >> 5) << 26) | (w >> 6);
+        m.A |= (u < ti_lim ? 1u : 0u) << i;
+        m.B |= ((w >> 31) ^ 1u) << i;
+        m.T |= ((w >> 30) & 1u) << i;
+        prev = w;
+    }
+    return m;
+}
+
+// exclusive prefix of the lanes' maps across the workgroup (shuffles inside a wave, LDS across waves)
+__device__ __forceinline__ SnpMap snp_shfl_up(const SnpMap &v, int o) {
+    SnpMap r;
+    r.c[0] = __shfl_up(v.c[0], o, 64); r.c[1] = __shfl_up(v.c[1], o, 64);
+    r.c[2] = __shfl_up(v.c[2], o, 64); r.e = __shfl_up(v.e, o, 64);
+    return r;
+}
+__device__ __forceinline__ SnpMap snp_block_scan2(const SnpMap &mine, SnpMap *wave_tot, SnpMap &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    SnpMap incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const SnpMap t = snp_shfl_up(incl, o);
+        if (lane >= o) incl = snp_compose(t, incl);
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    SnpMap pre = snp_identity();
+    for (int w = 0; w < wave; w++) pre = snp_compose(pre, wave_tot[w]);
+    total = wave_tot[0];
+    for (int w = 1; w < SNP_THREADS / 64; w++) total = snp_compose(total, wave_tot[w]);
+    SnpMap ex = snp_shfl_up(incl, 1);
+    if (lane == 0) ex = snp_identity();
+    __syncthreads();
+    return snp_compose(pre, ex);
+}
+
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_reduce(const uint32_t *__restrict__ raw,
+                                                            const PlanState *__restrict__ ps, uint32_t W,
+                                                            unsigned long long ti_lim, SnpMap *__restrict__ block_maps) {
+    __shared__ uint32_t sw[SNP_LDS_WORDS];
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    const SnpBits m = snp_stage(raw, ps->snp_base, blockIdx.x * SNP_BLOCK2, W, ti_lim, sw);
+    SnpMap total;
+    (void)snp_block_scan2(snp_lane_map(m), wave_tot, total);
+    if (threadIdx.x == 0) block_maps[blockIdx.x] = total;
+}
+
+// Scan of the workgroup maps + exact end of the SNP draws, ONE workgroup (both steps sit on the stream-position
+// critical path, so they share a launch).  Afterwards block_maps[b] = (state, count) at the start of block b
+// when the stream starts in state 0 (c[0] = count, e = state) -- what k_snp_emit needs -- and the workgroup in
+// which the K-th SNP completes has been re-walked: the word on which it completes + 1 is the new stream
+// position.  Keeps the (large) emit pass off the critical path; also saves the base for the emit pass.
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
+                                                              uint32_t W, unsigned long long ti_lim,
+                                                              SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
+                                                              unsigned long long *__restrict__ base_out) {
+    __shared__ uint32_t sw[SNP_LDS_WORDS];
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    __shared__ uint32_t s_blk, s_bs, s_bc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long p0 = ps->snp_base;
+    if (threadIdx.x == 0) { s_blk = 0xffffffffu; *base_out = p0; }
+    uint32_t c_state = 0, c_count = 0;                    // carried across chunks, identical in every lane
+    __syncthreads();
+    for (uint32_t base = 0; base < nb; base += 4 * SNP_THREADS) {
+        const uint32_t i0 = base + threadIdx.x * 4;
+        SnpMap v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = i0 + q < nb ? block_maps[i0 + q] : snp_identity();
+        SnpMap incl = snp_compose(snp_compose(v[0], v[1]), snp_compose(v[2], v[3]));
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const SnpMap t = snp_shfl_up(incl, o);
+            if (lane >= o) incl = snp_compose(t, incl);
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        SnpMap run = snp_identity();                      // all blocks of this chunk before i0
+        for (int w = 0; w < wave; w++) run = snp_compose(run, wave_tot[w]);
+        SnpMap total = wave_tot[0];
+        for (int w = 1; w < SNP_THREADS / 64; w++) total = snp_compose(total, wave_tot[w]);
+        SnpMap ex = snp_shfl_up(incl, 1);
+        if (lane == 0) ex = snp_identity();
+        run = snp_compose(run, ex);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const SnpMap nxt = snp_compose(run, v[q]);
+            if (i0 + q < nb) {
+                SnpMap r;
+                r.c[0] = c_count + run.c[c_state];
+                r.c[1] = r.c[2] = 0;
+                r.e = (run.e >> (2 * c_state)) & 3;
+                block_maps[i0 + q] = r;
+                // the workgroup in which the K-th SNP completes: count-before < K <= count-after
+                const uint32_t after = c_count + nxt.c[c_state];
+                if (r.c[0] < K && K <= after) { s_blk = i0 + q; s_bs = r.e; s_bc = r.c[0]; }
+            }
+            run = nxt;
+        }
+        const uint32_t n_count = c_count + total.c[c_state], n_state = (total.e >> (2 * c_state)) & 3;
+        __syncthreads();
+        c_count = n_count;
+        c_state = n_state;
+    }
+    if (threadIdx.x == 0) {                               // totals after the whole window
+        block_maps[nb].c[0] = c_count;
+        block_maps[nb].c[1] = s_blk;
+        block_maps[nb].e = c_state;
+        if (c_count < K) ps->flags |= FLAG_SNP_OVERFLOW;
+    }
+    if (c_count < K) return;                              // uniform
+    const uint32_t b = s_blk, bs = s_bs, bc = s_bc;
+    const uint32_t wbase = b * SNP_BLOCK2;
+    const SnpBits m = snp_stage(raw, p0, wbase, W, ti_lim, sw);
+    SnpMap tot2;
+    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, tot2);
+    const uint32_t st = (ex.e >> (2 * bs)) & 3;
+    const uint32_t idx = bc + ex.c[bs];                   // SNPs completed before this lane's words
+    uint32_t emits, from2;
+    (void)snp_lane_emits(st, m, emits, from2);
+    const uint32_t mine = (uint32_t)__popc(emits);
+    if (idx < K && K <= idx + mine) {                     // the K-th SNP completes in this lane: on which word?
+        uint32_t e = emits;
+        for (uint32_t q = idx + 1; q < K; q++) e &= e - 1; // drop the first K - idx - 1 emits
+        const unsigned long long w0 = p0 + wbase + (unsigned long long)threadIdx.x * SNP_ITEMS2;
+        ps->pos = w0 + (unsigned long long)__builtin_ctz(e) + 1;
+    }
+}
+
+// aux of every SNP record (off the critical path; runs on the emit stream)
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__restrict__ raw,
+                                                          const unsigned long long *__restrict__ base_in, uint32_t W,
+                                                          unsigned long long ti_lim,
+                                                          const SnpMap *__restrict__ block_maps,
+                                                          msim_record *__restrict__ recs, uint32_t K,
+                                                          const uint32_t *__restrict__ sn_index) {
+    __shared__ uint32_t sw[SNP_LDS_WORDS];
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    const uint32_t bc = block_maps[blockIdx.x].c[0];
+    if (bc >= K) return;                                  // window slack beyond the last SNP (uniform)
+    const SnpBits m = snp_stage(raw, *base_in, blockIdx.x * SNP_BLOCK2, W, ti_lim, sw);
+    SnpMap total;
+    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
+    const uint32_t bs = block_maps[blockIdx.x].e;
+    const uint32_t st = (ex.e >> (2 * bs)) & 3;
+    uint32_t idx = bc + ex.c[bs];
+    uint32_t emits, from2;
+    (void)snp_lane_emits(st, m, emits, from2);
+    while (emits && idx < K) {                            // aux: 0 transition, 1/2 transversion column (bit 30)
+        const uint32_t i = (uint32_t)__builtin_ctz(emits);
+        emits &= emits - 1;
+        recs[sn_index ? sn_index[idx] : idx].aux = (uint8_t)(((from2 >> i) & 1u) ? 1u + ((m.T >> i) & 1u) : 0u);
+        idx++;
+    }
+}
+
+// ------------------------------------------------------------------ 6. SV mixes: candidates, types, filter
+// A range whose type draw is not deterministic (insertions, deletions, duplications, inversions beside
+// SNPs) still samples its positions as above; what changes is everything after the bitmap:
+//   a. every candidate gets its type from the NumPy stream (2 words each, no rejection: parallel)
+//   b. the NON-SNP candidates are compacted and handed to the host, which runs the boundary pass over
+//      them -- the one stage that is a true sequential chain (plan_host.cpp: chain_boundary_host)
+//   c. back on the device: an SNP is kept iff it lies outside the blocked range of the last kept
+//      non-SNP before it (running maximum of the blocked-range ends), kept candidates are compacted
+//      into the record table, insert bases come from the NumPy stream by prefix sum of the insert
+//      lengths, and the kept SNPs' draws run through the transducer of section 5.
+constexpr int CB_THREADS = 256;
+constexpr int CB_ITEMS = 8;
+constexpr int CB_BLOCK = CB_THREADS * CB_ITEMS;          // 2048 candidates per workgroup
+constexpr uint8_t KEEP_BIT = 0x80;
+
+struct TypeTable { unsigned long long thr[8]; uint32_t n; uint8_t type[8]; };   // msim_range.cdf_thr / .types
+struct BlockTable { uint32_t p1[8]; };                   // block[t] + 1 (saturated), indexed by MSIM_* id
+
+// exclusive prefix over the workgroup (sum / max); wsum: one word per wave
+__device__ __forceinline__ uint32_t block_scan_add(uint32_t v, uint32_t *wsum, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    total = 0;
+    for (int w = 0; w < CB_THREADS / 64; w++) {
+        if (w < wave) pre += wsum[w];
+        total += wsum[w];
+    }
+    __syncthreads();
+    return pre + incl - v;
+}
+__device__ __forceinline__ uint32_t block_scan_max(uint32_t v, uint32_t *wsum, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl = max(incl, t);
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t pre = 0;
+    total = 0;
+    for (int w = 0; w < CB_THREADS / 64; w++) {
+        if (w < wave) pre = max(pre, wsum[w]);
+        total = max(total, wsum[w]);
+    }
+    uint32_t ex = __shfl_up(incl, 1, 64);
+    if (lane == 0) ex = 0;
+    __syncthreads();
+    return max(pre, ex);
+}
+
+// bitmap -> candidate i of the range: pos = start + value + d * rank (util.py:104-109), type from
+// numpy.random.choice(p=...) = searchsorted(cdf, u, 'right') on the 53-bit sample of words 2i, 2i+1
+// (mutator.py:170-174)
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand_cand(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                                   const uint32_t *__restrict__ block_off,
+                                                                   uint32_t start, uint32_t d,
+                                                                   const uint32_t *__restrict__ np_raw,
+                                                                   unsigned long long np_base, TypeTable tt,
+                                                                   uint32_t *__restrict__ cand_pos,
+                                                                   uint8_t *__restrict__ cand_type) {
+    __shared__ uint32_t part[BM_THREADS];
+    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+    uint64_t w = i < n_words ? bm[i] : 0;
+    const uint32_t c = (uint32_t)__popcll(w);
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < BM_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t rank = block_off[blockIdx.x] + part[threadIdx.x] - c;
+    while (w) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+        w &= w - 1;
+        const uint32_t a = mt_temper(np_raw[np_base + 2ull * rank]);
+        const uint32_t b = mt_temper(np_raw[np_base + 2ull * rank + 1]);
+        const unsigned long long m = ((unsigned long long)(a >> 5) << 26) | (b >> 6);
+        uint32_t idx = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) idx += ((uint32_t)j < tt.n && tt.thr[j] <= m) ? 1u : 0u;
+        if (idx >= tt.n) idx = tt.n - 1;                 // unreachable: cdf[-1] == 1.0 > u
+        cand_pos[rank] = start + (i * 64 + bit) + d * rank;
+        cand_type[rank] = tt.type[idx];
+        rank++;
+    }
+}
+
+__global__ __launch_bounds__(CB_THREADS) void k_nsn_count(const uint8_t *__restrict__ cand_type, uint32_t k,
+                                                          uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++)
+        if (i0 + q < k && cand_type[i0 + q] != MSIM_SN) c++;
+    uint32_t total;
+    (void)block_scan_add(c, wsum, total);
+    if (threadIdx.x == 0) cnt[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(CB_THREADS) void k_nsn_scatter(const uint32_t *__restrict__ cand_pos,
+                                                            const uint8_t *__restrict__ cand_type, uint32_t k,
+                                                            const uint32_t *__restrict__ off, uint32_t n_blocks,
+                                                            uint32_t *__restrict__ nsn_pos, uint8_t *__restrict__ nsn_type,
+                                                            uint32_t *__restrict__ nsn_rank, PlanState *__restrict__ ps) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint8_t t[CB_ITEMS];
+    uint32_t c = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)MSIM_SN;
+        c += t[q] != MSIM_SN ? 1u : 0u;
+    }
+    uint32_t total;
+    uint32_t j = off[blockIdx.x] + block_scan_add(c, wsum, total);
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (t[q] != MSIM_SN) {
+            nsn_pos[j] = cand_pos[i0 + q];
+            nsn_type[j] = t[q];
+            nsn_rank[j] = i0 + q;
+            j++;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ps->n_nsn = off[n_blocks];
+}
+
+// tempered words of the window the boundary chain may consume (D2H staging)
+__global__ __launch_bounds__(256) void k_temper_window(const uint32_t *__restrict__ raw, unsigned long long p0,
+                                                       uint32_t n, uint32_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = mt_temper(raw[p0 + i]);
+}
+
+__global__ __launch_bounds__(256) void k_stop_scatter(const uint32_t *__restrict__ nsn_rank,
+                                                      const uint32_t *__restrict__ nsn_stop, uint32_t n_nsn,
+                                                      uint32_t *__restrict__ cand_stop) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_nsn) cand_stop[nsn_rank[j]] = nsn_stop[j];
+}
+
+// end (exclusive) of the blocked range a kept non-SNP opens: [pos, stop + block] resp. [pos, pos + block]
+// for an insertion (mutator.py:204-209); 0 for everything else
+__device__ __forceinline__ uint32_t blocked_end(uint32_t pos, uint8_t type, uint32_t stop, const BlockTable &bt) {
+    if (type == MSIM_SN || stop == CHAIN_DROPPED) return 0;
+    const unsigned long long e = (unsigned long long)(type == MSIM_IN ? pos : stop) + bt.p1[type & 7];
+    return e > 0xffffffffull ? 0xffffffffu : (uint32_t)e;
+}
+
+__global__ __launch_bounds__(CB_THREADS) void k_blk_reduce(const uint32_t *__restrict__ cand_pos,
+                                                           const uint8_t *__restrict__ cand_type,
+                                                           const uint32_t *__restrict__ cand_stop, uint32_t k,
+                                                           BlockTable bt, uint32_t *__restrict__ bmax) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (i0 + q < k) {
+            const uint8_t t = cand_type[i0 + q];
+            if (t != MSIM_SN) m = max(m, blocked_end(cand_pos[i0 + q], t, cand_stop[i0 + q], bt));
+        }
+    }
+    uint32_t total;
+    (void)block_scan_max(m, wsum, total);
+    if (threadIdx.x == 0) bmax[blockIdx.x] = total;
+}
+
+// exclusive running maximum of a[0..n) in place; single workgroup
+__global__ __launch_bounds__(1024) void k_scan_max_u32(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? a[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] = max(buf[threadIdx.x], t);
+            __syncthreads();
+        }
+        const uint32_t ex = threadIdx.x ? buf[threadIdx.x - 1] : 0;
+        const uint32_t c = carry, last = buf[1023];
+        if (i < n) a[i] = max(c, ex);
+        __syncthreads();
+        if (threadIdx.x == 0) carry = max(c, last);
+        __syncthreads();
+    }
+}
+
+// keep flags (KEEP_BIT in cand_type) + per-workgroup counts of kept mutations, kept SNPs, insert bases
+__global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__restrict__ cand_pos,
+                                                           uint8_t *__restrict__ cand_type,
+                                                           const uint32_t *__restrict__ cand_stop, uint32_t k,
+                                                           BlockTable bt, const uint32_t *__restrict__ bmax,
+                                                           uint32_t *__restrict__ cnt_keep, uint32_t *__restrict__ cnt_sn,
+                                                           uint32_t *__restrict__ cnt_ins) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint32_t pos[CB_ITEMS], stop[CB_ITEMS], before[CB_ITEMS];
+    uint8_t t[CB_ITEMS];
+    uint32_t run = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        const bool in = i0 + q < k;
+        pos[q] = in ? cand_pos[i0 + q] : 0;
+        t[q] = in ? cand_type[i0 + q] : (uint8_t)0;
+        stop[q] = (in && t[q] != MSIM_SN) ? cand_stop[i0 + q] : CHAIN_DROPPED;
+        before[q] = run;
+        if (in) run = max(run, blocked_end(pos[q], t[q], stop[q], bt));
+    }
+    uint32_t total;
+    const uint32_t pre = max(bmax[blockIdx.x], block_scan_max(run, wsum, total));
+    uint32_t nk = 0, ns = 0, ni = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (i0 + q >= k) continue;
+        bool keep;
+        if (t[q] == MSIM_SN) { keep = pos[q] >= max(pre, before[q]); ns += keep ? 1u : 0u; }   // mutator.py:190-196
+        else { keep = stop[q] != CHAIN_DROPPED; if (keep && t[q] == MSIM_IN) ni += stop[q] - pos[q] + 1; }
+        nk += keep ? 1u : 0u;
+        if (keep) cand_type[i0 + q] = t[q] | KEEP_BIT;
+    }
+    uint32_t tk, ts, ti;
+    (void)block_scan_add(nk, wsum, tk);
+    (void)block_scan_add(ns, wsum, ts);
+    (void)block_scan_add(ni, wsum, ti);
+    if (threadIdx.x == 0) { cnt_keep[blockIdx.x] = tk; cnt_sn[blockIdx.x] = ts; cnt_ins[blockIdx.x] = ti; }
+}
+
+// three exclusive scans in one launch (blockIdx.x selects the array), totals to a[n]; publishes them
+__global__ __launch_bounds__(1024) void k_scan3_u32(uint32_t *__restrict__ a0, uint32_t *__restrict__ a1,
+                                                    uint32_t *__restrict__ a2, uint32_t n, PlanState *__restrict__ ps) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    uint32_t *a = blockIdx.x == 0 ? a0 : blockIdx.x == 1 ? a1 : a2;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < n ? a[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[threadIdx.x], c = carry;
+        if (i < n) a[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a[n] = carry;
+        if (blockIdx.x == 0) ps->n_rec = carry; else if (blockIdx.x == 1) ps->n_sn = carry; else ps->pool_len = carry;
+    }
+}
+
+// kept candidates -> record table (position order), SNP ordinal -> record index, insert pool offsets
+__global__ __launch_bounds__(CB_THREADS) void k_emit_records(const uint32_t *__restrict__ cand_pos,
+                                                             const uint8_t *__restrict__ cand_type,
+                                                             const uint32_t *__restrict__ cand_stop, uint32_t k,
+                                                             const uint32_t *__restrict__ off_keep,
+                                                             const uint32_t *__restrict__ off_sn,
+                                                             const uint32_t *__restrict__ off_ins,
+                                                             msim_record *__restrict__ recs,
+                                                             uint32_t *__restrict__ sn_index) {
+    __shared__ uint32_t wsum[CB_THREADS / 64];
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    uint8_t t[CB_ITEMS];
+    uint32_t pos[CB_ITEMS], stop[CB_ITEMS];
+    uint32_t nk = 0, ns = 0, ni = 0;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)0;
+        pos[q] = 0; stop[q] = 0;
+        if (t[q] & KEEP_BIT) {
+            pos[q] = cand_pos[i0 + q];
+            const uint8_t ty = t[q] & 7;
+            stop[q] = ty == MSIM_SN ? pos[q] : cand_stop[i0 + q];
+            nk++;
+            if (ty == MSIM_SN) ns++;
+            if (ty == MSIM_IN) ni += stop[q] - pos[q] + 1;
+        }
+    }
+    uint32_t tot;
+    uint32_t r = off_keep[blockIdx.x] + block_scan_add(nk, wsum, tot);
+    uint32_t s = off_sn[blockIdx.x] + block_scan_add(ns, wsum, tot);
+    uint32_t p = off_ins[blockIdx.x] + block_scan_add(ni, wsum, tot);
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        if (!(t[q] & KEEP_BIT)) continue;
+        const uint8_t ty = t[q] & 7;
+        msim_record rec;
+        rec.pos = pos[q]; rec.stop = stop[q]; rec.extra = 0; rec.type = ty; rec.aux = 0; rec.rsv = 0;
+        if (ty == MSIM_SN) sn_index[s++] = r;
+        if (ty == MSIM_IN) { rec.extra = p; p += stop[q] - pos[q] + 1; }
+        recs[r++] = rec;
+    }
+}
+
+// insert bases: "ATGC"[word & 3], one NumPy-stream word per base, in position order (mutator.py:465-471)
+__global__ __launch_bounds__(256) void k_pool_fill(const uint32_t *__restrict__ np_raw, unsigned long long np_base,
+                                                   uint32_t pool_len, uint8_t *__restrict__ pool) {
+    const uint32_t g = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (g >= pool_len) return;
+    uint32_t x = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t w = g + q < pool_len ? mt_temper(np_raw[np_base + g + q]) : 0u;
+        x |= (uint32_t)("ATGC"[w & 3u]) << (8 * q);
+    }
+    *reinterpret_cast<uint32_t *>(pool + g) = x;         // the pool buffer is padded: whole dwords are in bounds
+}
+
+__global__ void k_set_pos(PlanState *ps, unsigned long long pos) { ps->pos = pos; ps->snp_base = pos; }
+
+// ---- host-sampled contigs (many small ranges): the device still owns the streams
+// tempered words from the CURRENT device position on (the host needs no round trip to learn it)
+__global__ __launch_bounds__(256) void k_temper_window_ps(const uint32_t *__restrict__ raw, const PlanState *__restrict__ ps,
+                                                          uint32_t n, uint32_t *__restrict__ dst) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = mt_temper(raw[ps->pos + i]);
+}
+__global__ void k_advance_pos(PlanState *ps, unsigned long long words) { ps->pos += words; ps->snp_base = ps->pos; }
+// candidate positions -> SNP records (stop = pos, mutator.py:199-200)
+__global__ __launch_bounds__(256) void k_records_from_pos(const uint32_t *__restrict__ pos, uint32_t n,
+                                                          msim_record *__restrict__ recs) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    msim_record r;
+    r.pos = pos[i]; r.stop = r.pos; r.extra = 0; r.type = MSIM_SN; r.aux = 0; r.rsv = 0;
+    recs[i] = r;
+}
+
+// single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
+__global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
+    *mailbox = *ps;
+    __threadfence_system();
+}
+
+__global__ void k_state_init(PlanState *ps, unsigned long long pos) {
+    ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0;
+    ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;
+}
+
+}  // namespace
+
+}  // namespace msim
