@@ -259,6 +259,58 @@ def test_sv_mix_vs_host(L, rate, chances, lens, blocks, titv):
     _compare([(L, [_sv_range(0, L - 1, k, chances, lens)])], _params(blocks, titv=titv), host_chain=True)
 
 
+@pytest.mark.parametrize("case", range(16))
+def test_sv_mix_random_sweep_vs_host(case):
+    """Seeded random SV-mix settings (type subset and chances, length ranges, blocks, minimum distance, range placement,
+    titv): the device engine must reproduce the host planner's records, insert pool and stream positions."""
+    rs = np.random.RandomState(1000 + case)
+    L = int(rs.randint(700_000, 2_500_000))
+    start = int(rs.choice([0, rs.randint(1, L // 4)]))
+    stop = int(rs.choice([L - 1, L - 1 - rs.randint(1, L // 4)]))
+    types = [1] + [t for t in (2, 3, 4, 5) if rs.rand() < 0.7]
+    if len(types) == 1:
+        types.append(int(rs.choice([2, 3, 4, 5])))
+    chances = {t: float(rs.uniform(0.05, 1.0)) for t in types}
+    lens = {}
+    for t in (2, 3, 4):
+        a = int(rs.randint(1, 40))
+        lens[t] = (a, a + int(rs.choice([0, 1, 7, 60, 700, 5000])))
+    a = int(rs.randint(2, 40))
+    lens[5] = (a, a + int(rs.choice([0, 1, 7, 60, 700, 5000])))
+    dmin = int(rs.choice([1, 1, 2, 4]))
+    blocks = {name: dmin + int(rs.choice([0, 0, 1, 5, 50])) for name in ("IN", "DE", "IV", "DU", "TL", "TLI")}
+    blocks["SN"] = dmin                                      # SNP block == sampling distance (device engines' precondition)
+    blocks[str(rs.choice(["IN", "DE", "IV", "DU"]))] = dmin  # make sure the minimum is dmin
+    rate = float(rs.choice([0.006, 0.01, 0.02, 0.04]))
+    k = int((stop - start + 1) * rate)
+    order = list(ARGS_ORDER) if rs.rand() < 0.5 else [int(x) for x in rs.permutation(types)]
+    r = _sv_range(start, stop, k, chances, lens, order=order)
+    _compare([(L, [r])], _params(blocks, titv=float(rs.choice([0.0, 0.5, 1.0, 2.0, 1e9]))), seed=(case, 2 * case + 1),
+             host_chain=True)
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_host_sampled_random_sweep_vs_host(case):
+    """Seeded random range layouts (counts, sizes from a handful of bases to megabases, rates up to pool-path density,
+    minimum distance) for the host-sampled engine."""
+    rs = np.random.RandomState(2000 + case)
+    L = int(rs.randint(500_000, 4_000_000))
+    d = int(rs.choice([1, 1, 2, 5]))
+    ranges, at = [], int(rs.randint(0, 1000))
+    while at < L - 50:
+        length = int(min(L - at, rs.choice([8, 30, 200, 2000, 20_000, 300_000, 1_500_000])))
+        rate = float(rs.choice([0.0005, 0.01, 0.03, 0.1, 0.2]))
+        k = int(length * rate)
+        n = (at + length - 1 - (k - 1) * d) - at
+        if k > 0 and n >= k:
+            ranges.append(_snp_range(at, at + length - 1, k, bool(rs.rand() < 0.5)))
+        at += length + int(rs.choice([1, 1, 50, 5000]))
+    assert ranges
+    blocks = {t: d for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}
+    _compare([(L, ranges)], _params(blocks, titv=float(rs.choice([0.0, 1.0, 2.0]))), seed=(case + 7, case + 9),
+             host_chain=True)
+
+
 def test_sv_mix_rmt_token_order_and_inner_range():
     """RMT-style chance order (DU, SN, IN) on a range that does not start at 0 nor end at the contig end."""
     r = _sv_range(200_000, 1_799_999, 16_000, {4: 0.1, 1: 0.6, 2: 0.3}, {4: (5, 90), 2: (1, 12)}, order=[4, 1, 2])
