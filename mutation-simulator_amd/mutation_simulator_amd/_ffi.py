@@ -277,20 +277,41 @@ class Engine:
         self._check(self.lib.msim_fetch_records(self.h, contig, _ptr(recs), _ptr(pool)))
         return recs, pool
 
-    def render_vcf_device(self, contig: int, seq_name: str) -> np.ndarray:
-        """VCF record lines of the contig rendered on the device (uint8 array of text)."""
+    def render_vcf_device(self, contig: int, seq_name: str, guess: int = 0) -> np.ndarray:
+        """VCF record lines of the contig rendered on the device (uint8 array of text).  With a size ``guess`` the
+        text comes back in ONE synchronising call when it fits (the library keeps the rendered text, so a second
+        call with the right size only copies)."""
         need = C.c_uint64()
         name = seq_name.encode("utf-8", "replace")
-        self._check(self.lib.msim_render_vcf_device(self.h, contig, name, None, 0, C.byref(need)), contig)
+        if guess > 0:
+            out = np.empty(guess, dtype=np.uint8)
+            rc = self.lib.msim_render_vcf_device(self.h, contig, name, _ptr(out), guess, C.byref(need))
+            if rc == OK:
+                return out[:need.value]
+            if rc != ERR_ARG or need.value <= guess:
+                self._check(rc, contig)
+        else:
+            self._check(self.lib.msim_render_vcf_device(self.h, contig, name, None, 0, C.byref(need)), contig)
         out = np.empty(need.value, dtype=np.uint8)
         if need.value:
             self._check(self.lib.msim_render_vcf_device(self.h, contig, name, _ptr(out), need.value, C.byref(need)), contig)
         return out
 
-    def fetch_sequence_framed(self, contig: int, bpl: int) -> np.ndarray:
-        """The mutated contig as FASTA body text (newline after every ``bpl`` bases)."""
+    def fetch_sequence_framed(self, contig: int, bpl: int, guess_len: int | None = None) -> np.ndarray:
+        """The mutated contig as FASTA body text (newline after every ``bpl`` bases).  With ``guess_len`` (e.g. the
+        input length: an SNP-only table never changes it) the text comes back in ONE synchronising call when it
+        fits; the library keeps the framed text, so a retry with the exact size only copies."""
         need = C.c_uint64()
-        self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, None, 0, C.byref(need)), contig)
+        if guess_len is not None:
+            cap = guess_len + guess_len // bpl + guess_len // 8 + 64
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, _ptr(out), cap, C.byref(need))
+            if rc == OK:
+                return out[:need.value]
+            if rc != ERR_ARG or need.value <= cap:
+                self._check(rc, contig)
+        else:
+            self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, None, 0, C.byref(need)), contig)
         out = np.empty(need.value, dtype=np.uint8)
         if need.value:
             self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, _ptr(out), need.value, C.byref(need)), contig)

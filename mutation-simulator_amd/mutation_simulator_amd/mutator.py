@@ -186,11 +186,13 @@ class Mutator:
                 eng.apply_contig(cid)
                 bpl = self._fasta.faidx.index[rec.name].lenc
                 if bpl > 0:                                    # line framing and VCF text rendered on the device
-                    out_len, _, _ = eng.result_sizes(cid)
-                    self._fasta_writer.write_framed(eng.fetch_sequence_framed(cid, bpl), out_len)
+                    text = eng.fetch_sequence_framed(cid, bpl, guess_len=len(rec))
+                    q, r = divmod(int(text.shape[0]), bpl + 1)  # text = L + L // bpl bytes  ->  L
+                    self._fasta_writer.write_framed(text, q * bpl + r)
                 else:
                     self._fasta_writer.write_array(eng.fetch_sequence(cid))
-                self._vcf_writer.write_raw(eng.render_vcf_device(cid, rec.name))
+                _, n_rec, _ = eng.result_sizes(cid, applied=False)     # (host-side bookkeeping, no round trip)
+                self._vcf_writer.write_raw(eng.render_vcf_device(cid, rec.name, guess=n_rec * (len(rec.name) + 40) + 256))
                 eng.clear()
         finally:
             import_python_streams(eng)
