@@ -146,14 +146,19 @@ def one_step(eng, sim, cids, my_contigs, seed=42, plan_descriptors=None):
     eng.sync()
 
 
-def cpu_baseline(sample_total: int, n_contigs: int = 4):
-    """CPU oracle (single-threaded C restatement of the reference path) on a bounded sample of the
-    same workload: `n_contigs` contigs totalling `sample_total` bases, -sn 0.01 -titv 2.0, 42/42."""
+def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4):
+    """CPU oracle (single-threaded C restatement of the reference path) on a bounded sample of the same
+    workload: `n_contigs` contigs totalling `sample_total` bases with the workload's settings, seeds 42/42."""
     from oracle import oracle as orc
     from test_gpu_parity import synth_host  # same generator as the device kernel
     from test_host_settings import dump_sim
     lengths = [sample_total // n_contigs] * n_contigs
-    sim = workload_settings(lengths)
+    if workload == "c2":
+        sim, what = workload_settings(lengths), "args -sn 0.01 -titv 2.0"
+    elif workload == "c3":
+        sim, what = workload_settings(lengths, snp=0.005, titv=1.0, extra=C3_FLAGS), "args, full SV mix (configs[2])"
+    else:
+        sim, what = workload_settings_rmt(lengths, c4_rmt_text(lengths)), "rmt, synthetic gene-blocking file (configs[3])"
     contigs = [{"name": f"chr{i+1}", "long_name": f"chr{i+1} synthetic", "lenc": 60,
                 "bases": synth_host(L, 1000 + i)} for i, L in enumerate(lengths)]
     o = orc.Oracle()
@@ -163,8 +168,12 @@ def cpu_baseline(sample_total: int, n_contigs: int = 4):
     dt = time.perf_counter() - t0
     total = sum(lengths)
     return {"value": round(total / dt / 1e6, 3), "unit": "Mbases/s", "cores": 1, "kind": "port",
-            "sample": f"{n_contigs} contigs x {lengths[0]/1e6:.0f} Mb, args -sn 0.01 -titv 2.0, seeds 42/42, "
+            "sample": f"{n_contigs} contigs x {lengths[0]/1e6:.0f} Mb, {what}, seeds 42/42, "
                       f"Fasta framing + VCF text included ({dt:.1f} s of CPU work)"}
+
+
+C3_FLAGS = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
+            "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
 
 
 def main():
@@ -203,8 +212,7 @@ def main():
     from mutation_simulator_amd import mutator as mm
 
     lengths = contig_lengths(a.total_bases)
-    C3 = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
-          "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
+    C3 = C3_FLAGS
     if a.workload == "c2":
         sim = workload_settings(lengths)
     elif a.workload == "c3":
@@ -307,8 +315,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes // launches,
                          "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
         }
-        if world == 1 and not a.no_cpu_baseline and a.workload == "c2":
-            line["cpu_baseline"] = cpu_baseline(a.cpu_sample)
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload)      # bounded sample: ~6-10 s of CPU work
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:
