@@ -708,9 +708,70 @@ def make_apply():
     (HERE / "apply.json").write_text(json.dumps(out, indent=1) + "\n")
 
 
+def _rmt_gene_blocking(lengths, seed):
+    """A non-overlapping gene-blocking RMT (std `sn 0.01`, `None` blocks, hot / cold ranges, 1 kb `sn 0.2`
+    hot spots whose sample takes CPython's pool path) from this file's own deterministic generator."""
+    rs = np.random.RandomState(seed)
+    out = ["titv = 2.0", "", "std", "it None", "sn 0.01", ""]
+    for ci, L in enumerate(lengths):
+        if L is None:
+            continue                                   # unlisted contig: std only
+        out.append(f"chr {ci + 1}")
+        n_blocks = max(4, L // 20_000)
+        kinds = rs.choice(4, size=n_blocks, p=[0.85, 0.06, 0.05, 0.04])
+        blen = np.minimum(np.exp(rs.normal(np.log(2500.0), 1.3, n_blocks)).astype(np.int64) + 30, 60_000)
+        blen[kinds == 3] = 1000
+        blen[kinds == 2] = rs.randint(20_000, 120_000, int((kinds == 2).sum()))
+        free = L - int(blen.sum()) - 2 * n_blocks - 500
+        while free < L // 3:
+            blen = np.maximum(blen // 2, 30)
+            free = L - int(blen.sum()) - 2 * n_blocks - 500
+        gaps = rs.dirichlet(np.ones(n_blocks + 1)) * free
+        at = 1
+        for b in range(n_blocks):
+            at += int(gaps[b]) + 2
+            a, e = at, at + int(blen[b]) - 1
+            out.append(f"{a}-{e} " + ("None", "sn 0.05", "sn 0.001", "sn 0.2")[kinds[b]])
+            at = e + 1
+        assert at < L
+    return "\n".join(out) + "\n"
+
+
+RMT_SV_STD = """\
+# SV mix on every contig through the std line (one range per contig), non-default blocks
+titv = 2.0
+du_block = 20
+iv_block = 5
+de_block = 3
+
+std
+it None
+sn 0.004 in 0.001 inmin 1 inmax 30 de 0.001 demin 1 demax 80 du 0.0005 dumin 20 dumax 300 iv 0.0005 ivmin 20 ivmax 300
+"""
+
+
+def make_cli_cases_engines():
+    """Mid-size cases that reach the device PLAN engines in AUTO mode (k >= 4096 on one range, or many
+    deterministic-SNP ranges): the reference's own output pins them, not only the host planner."""
+    print("CLI cases (device engines)")
+    spec = {"contigs": [{"defline": "g1 gene blocking 3Mb", "length": 3_000_000, "bpl": 60, "seed": 71},
+                        {"defline": "g2 std only", "length": 1_200_000, "bpl": 80, "seed": 72},
+                        {"defline": "g3 dense blocks", "length": 400_000, "bpl": 60, "seed": 73}]}
+    cli_case("rmt_blocks_3mb", spec, [], 42, 43, store="hash",
+             rmt_text=_rmt_gene_blocking([3_000_000, None, 400_000], 5),
+             notes="RMT gene blocking: ~170 drawing ranges incl. pool-path hot spots (host-sampled engine), an unlisted "
+                   "contig (SNP sampler), titv 2")
+    spec = {"contigs": [{"defline": "s1 3Mb", "length": 3_000_000, "bpl": 60, "seed": 81},
+                        {"defline": "s2", "length": 700_011, "bpl": 70, "seed": 82}]}
+    cli_case("rmt_svmix_blocks_3mb", spec, [], 11, 12, store="hash", rmt_text=RMT_SV_STD,
+             notes="SV mix via the RMT std line, du/iv/de blocks 20/5/3 (SV-mix engine, 21 k + 4.9 k candidates)")
+
+
 def main():
     os.chdir(HERE)
-    which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli"}
+    which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli", "engines"}
+    if "engines" in which:
+        make_cli_cases_engines()
     if "rng" in which:
         make_rng_kat()
     if "settings" in which:
