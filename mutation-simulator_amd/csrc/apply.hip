@@ -30,7 +30,7 @@ constexpr int GROUP = 16;                              // output bytes per lane 
 constexpr int ITERS = 4;
 constexpr int TILE = THREADS * GROUP * ITERS;          // 16384 output bytes per workgroup
 constexpr int REC_CAP = 1024;                          // records staged in LDS per tile (dense tables)
-constexpr int REC_CAP_SMALL = 256;                     // sparse tables: 12 KB less LDS -> 7 instead of 4 tiles per CU
+constexpr int REC_CAP_SMALL = 140;                     // sparse tables: window + tile + LUT = 20 KB of LDS -> 8 tiles per CU
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = THREADS * SCAN_ITEMS;
 
@@ -611,7 +611,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
 }
 
 template <int CAP>
-__global__ __launch_bounds__(THREADS) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? 8 : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const msim_record *__restrict__ recs,
                                                      const uint32_t *__restrict__ off,
                                                      const int32_t *__restrict__ first, uint32_t n_rec,
@@ -943,7 +943,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
         if (g.all_snp)
             hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
                                d_first, n, g.out_len, ctx_lut(c), d_err);
-        else if ((uint64_t)n * 2 + 64 < (uint64_t)n_tiles * REC_CAP_SMALL)   // mean records per tile < half the small window
+        else if ((uint64_t)n * 5 + 64 * 4 < (uint64_t)n_tiles * REC_CAP_SMALL * 4)   // mean records per tile < 80 % of the small window
             hipLaunchKernelGGL(k_rewrite<REC_CAP_SMALL>, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
                                d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err);
         else
