@@ -689,6 +689,15 @@ static int mixed_sync(Ctx *c, GpuPlan *g, PlanState &h) {
     return MSIM_OK;
 }
 
+// The plan stream is about to idle while the host walks a chain: close the timed GPU span (t1 must have been
+// recorded before the synchronisation that just returned) and reopen it when device work is enqueued again.
+static int span_close(Ctx *c, GpuPlan *g) {
+    float ms = 0;
+    MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
+    c->t.plan_gpu_ms += ms;
+    return MSIM_OK;
+}
+
 int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
     const msim_params &P = c->params;
     int64_t d = P.block[1];
@@ -779,9 +788,12 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         MSIM_HIP(c, hipMemcpyAsync(g->h_npos, M.nsn_pos, (size_t)n_nsn * 4, hipMemcpyDeviceToHost, c->stream));
         MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_nsn, hipMemcpyDeviceToHost, c->stream));
         MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)Wb * 4, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        if ((rc = span_close(c, g))) return rc;
         rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop, &consumed, &kept_nsn, &len_delta);
         if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
+        MSIM_HIP(c, hipEventRecord(g->t0, c->stream));    // the host chain is not GPU time
         MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_nsn * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_stop_scatter, dim3((n_nsn + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_stop, n_nsn,
                            M.cand_stop);
@@ -956,10 +968,13 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     hipLaunchKernelGGL(k_temper_window_ps, dim3((W + 255) / 256), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W, M.words);
     MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
+    MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    if ((rc = span_close(c, g))) return rc;
     size_t consumed = 0;
     rc = sample_ranges_host(c, ranges, n_ranges, d, g->h_words, W, g->h_npos, &consumed);
     if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
+    MSIM_HIP(c, hipEventRecord(g->t0, c->stream));        // the host chain is not GPU time
     MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_advance_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)consumed);
     MSIM_HIP(c, hipGetLastError());
