@@ -51,9 +51,13 @@ extern "C" {
 #define MSIM_TLI 7
 
 /* ---- msim_create flags --------------------------------------------------------------------- */
-#define MSIM_PLAN_AUTO   0u      /* GPU sampler where the stream structure parallelises, else host */
-#define MSIM_PLAN_HOST   1u      /* force the sequential host planner (cross-check / debugging)     */
-#define MSIM_PLAN_GPU    2u      /* force the GPU sampler; MSIM_ERR_UNSUPPORTED where it cannot run  */
+#define MSIM_PLAN_AUTO   0u      /* per contig: a device PLAN engine where one applies, else the host planner */
+#define MSIM_PLAN_HOST   1u      /* force the sequential host planner (cross-check / debugging)               */
+#define MSIM_PLAN_GPU    2u      /* force a device engine; MSIM_ERR_UNSUPPORTED where none can run             */
+/* Device PLAN engines: the device owns both MT19937 streams and does all per-record work;
+ * SNP-only large ranges need nothing from the host, SV mixes hand the boundary chain over their non-SNP
+ * candidates to the host, contigs with many small SNP ranges hand it the chain of sample() calls -- in both
+ * cases over words the device generated.  Results are bit-identical whichever engine runs.                    */
 
 typedef struct msim_ctx msim_ctx;
 
@@ -149,11 +153,12 @@ int msim_plan_contig(msim_ctx *ctx, int contig, const msim_range *ranges, int n_
 int msim_plan_was_empty(msim_ctx *ctx, int contig, int *empty);
 
 /* ---- APPLY: Mutator.__mutate_sequence (mutator.py:318-426) -------------------------------------- */
-/* Execution model: msim_plan_contig (GPU sampler) and msim_apply_contig (SNP-only tables) only ENQUEUE
- * work -- the chain that fixes stream positions on one HIP stream, record emission and the rewrite
- * kernel on another, overlapping the next contig's chain.  Deferred outcomes (the reference's
- * KeyError, an internal window overflow) are reported by the next call that synchronises: msim_sync,
- * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats.    */
+/* Execution model: msim_plan_contig (SNP sampler engine) and msim_apply_contig (device-planned tables) only
+ * ENQUEUE work -- the chain that fixes stream positions on one HIP stream, record emission and the rewrite
+ * kernel on another, overlapping the next contig's chain.  (The SV-mix and host-sampled engines synchronise
+ * inside msim_plan_contig, where the host walks its chain.)  Deferred outcomes (the reference's KeyError, an
+ * internal window overflow) are reported by the next call that synchronises: msim_sync,
+ * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats, the text calls. */
 int msim_apply_contig(msim_ctx *ctx, int contig);
 /* If apply hit the reference's KeyError: the offending (ambiguity-converted) base and position.
  * contig == -1: the first contig (in index order) that hit it.                                    */
