@@ -21,6 +21,14 @@
 
 #include "ctx.h"
 
+// Timing-only ablations of k_rewrite (tools/apply_ablation.py; `make ablate`).  0 in every shipped build: any other
+// value produces WRONG bytes and exists only to attribute the kernel's time to its parts on the GPU.
+//   1 aligned loads (no byte shift, no fifth dword)   2 no structural fix-ups (pass B)   4 no SNP pass (B2)
+//   8 no index table (every group = plain copy)      16 XCD-contiguous tile order
+#ifndef MSIM_ABL
+#define MSIM_ABL 0
+#endif
+
 namespace msim {
 
 namespace {
@@ -291,6 +299,12 @@ struct Raw5 { u32x4_a4 v; uint32_t w4; uint32_t sh; };
 __device__ __forceinline__ Raw5 piece_load(const PieceSrc &p) {
     Raw5 r;
     const uintptr_t a = reinterpret_cast<uintptr_t>(p.ptr);
+    if (MSIM_ABL & 1) {
+        r.sh = 0;
+        r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(a & ~(uintptr_t)15));
+        r.w4 = 0;
+        return r;
+    }
     const uint8_t *al = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3);
     r.sh = (uint32_t)(a & 3);
     r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(al));
@@ -535,7 +549,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
         const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
         const uint32_t O = tile0 + g;
         live[it] = O < tile_end;
-        const uint32_t j1 = idx[it * THREADS + threadIdx.x];
+        const uint32_t j1 = (MSIM_ABL & 8) ? 0u : idx[it * THREADS + threadIdx.x];
         const bool has = j1 != 0;
         const uint32_t q = has ? j1 - 1u : 0u;
         const uint32_t oj = win.o[q], ej = win.e[q], sj = win.s[q], mj = win.m[q] & 0xffffu;
@@ -550,7 +564,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
     auto resolve_fix = [&](int32_t u, Fix &f) {
         f.on = false;
         f.ps.ptr = in; f.ps.mode = 0; f.p = f.end = 0;
-        if (u >= 2 * n_struct) return;
+        if (u >= 2 * n_struct || (MSIM_ABL & 2)) return;
         const int32_t k = u >> 1;
         const bool run = u & 1;
         const uint32_t q = win.m[k] >> 16;
@@ -590,7 +604,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
     }
     __syncthreads();
     // ---- pass B2: SNP bytes, one lane per record (mutator.py:334-341, 428-463)
-    for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
+    for (int32_t q = threadIdx.x; q < ((MSIM_ABL & 4) ? 0 : cnt); q += THREADS) {
         const uint32_t mj = win.m[q] & 0xffffu;
         const uint32_t o = win.o[q];
         if ((mj & 0xff) != MSIM_SN || o < tile0 || o >= tile_end) continue;
@@ -621,7 +635,11 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 
     __shared__ RecWin<CAP> win;
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
-    const uint32_t t = blockIdx.x;
+    uint32_t t = blockIdx.x;
+    if (MSIM_ABL & 16) {                                   // XCD x gets a contiguous range of tiles (bijective for any grid)
+        const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = t % 8, k8 = t / 8;
+        t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    }
     const uint64_t tile0 = (uint64_t)t * TILE;
     for (int i = threadIdx.x; i < LUT_BYTES / 4; i += THREADS)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];

@@ -253,9 +253,10 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
         };
         while (s.n_chunks < need_chunks) {
             const uint32_t hi = std::min<uint32_t>(need_chunks, s.n_states);
-            // a generation batch costs ~300 us of latency whatever its size and batches queue in order, so the
-            // single state before the first cascade level is not worth a batch of its own
-            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, (uint32_t)MT_JUMP_RADIX[0])) {
+            // a generation batch costs ~80 us of latency whatever its size and batches queue in order, while a
+            // cascade level is ~10-30 us: the first batch waits for the second level (256 chunks) instead of
+            // going out with the 16 states of the first
+            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, (uint32_t)(MT_JUMP_RADIX[0] * MT_JUMP_RADIX[1]))) {
                 // states [n_chunks, hi) are complete on the jump stream: generate those chunks
                 hipEvent_t st_ev;
                 int rc = take_event(st_ev);
@@ -264,7 +265,7 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                 MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, st_ev, 0));
                 s.ready_ev.push_back(st_ev);                // recycled with the batch events at the next reseed
                 s.ready_hi.push_back(0);
-                hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(64), 0, g->gen_stream, s.d_states,
+                hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(GEN_THREADS), 0, g->gen_stream, s.d_states,
                                    s.d_raw, s.n_chunks);
                 MSIM_HIP(c, hipGetLastError());
                 hipEvent_t ev;
@@ -293,11 +294,11 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                         MSIM_HIP(c, hipMalloc(&s.d_z, (size_t)s.n_src * JUMP_ZP * sizeof(uint32_t)));
                         s.z_cap = s.n_src;
                     }
-                    hipLaunchKernelGGL(k_mt_extend, dim3(s.n_src), dim3(64), 0, g->jump_stream, s.d_states, s.d_z);
+                    hipLaunchKernelGGL(k_mt_extend, dim3(s.n_src), dim3(GEN_THREADS), 0, g->jump_stream, s.d_states, s.d_z);
                     MSIM_HIP(c, hipGetLastError());
                     s.z_lvl = (int)s.lvl;
                 }
-                hipLaunchKernelGGL(k_mt_jump, dim3(s.n_src * (m_need - s.m_done), JUMP_SPLIT), dim3(JUMP_THREADS), 0,
+                hipLaunchKernelGGL(k_mt_jump, dim3(s.n_src * (m_need - s.m_done)), dim3(JUMP_THREADS), 0,
                                    g->jump_stream, s.d_states, s.d_z, s.n_src,
                                    g->d_poly + (size_t)level_base * MT_POLY_WORDS, s.m_done + 1);
                 MSIM_HIP(c, hipGetLastError());
@@ -385,10 +386,15 @@ bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
     int64_t d = P.block[1];
     for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
     if (P.block[MSIM_SN] != d) return false;              // an SNP could block its successor
+    int64_t prev_stop = -1;
     for (int i = 0; i < n_ranges; i++) {
         const msim_range &r = ranges[i];
         if (r.k == 0) continue;                           // draws nothing (mutator.py:163-164)
         if (r.k < 4096) return false;                     // tiny ranges: the sequential host walk is faster
+        // overlapping or unsorted drawing ranges: the reference merges the per-range dicts with update()
+        // (mutator.py:121, later range wins) -- only the host planner reproduces that
+        if (r.start <= prev_stop) return false;
+        prev_stop = r.stop;
         const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
         if (r.k < 0 || n < r.k) return false;             // ValueError: let the host planner raise it
         if (n <= r.setsize || n >= (1ll << 32)) return false;   // pool path / multi-word getrandbits

@@ -43,49 +43,48 @@ struct PlanState {
 };
 
 // ------------------------------------------------------------------ 1. MT19937 in bulk
-// state' = g(A) state : z = state followed by 19 937 more raw words, out[m] = XOR_{i in g} z[i+m].
-// One jump is spread over JUMP_SPLIT workgroups (64 outputs each) so the early cascade levels, which
-// have few source states, still fill the chip; inside a workgroup the four waves take every fourth
-// polynomial limb (wave-uniform bit scan on the scalar unit, four LDS reads in flight per lane).
-constexpr int JUMP_OUT = 64;
-constexpr int JUMP_SPLIT = (MT_N + JUMP_OUT - 1) / JUMP_OUT;
-
+// Jump-ahead: state' = g(A) state.  With z = the source state followed by 19 937 more raw words,
+// out[m] = XOR_{i in g} z[i + m], m = 0..623 -- a GF(2) correlation of the 19 937-bit polynomial with z:
+// 624 x ~9 970 word XORs per jump, ~1000 jumps per 3 Gb genome.
+//
+// The first version read one LDS word per (set bit, output) and spent ~16 instructions on each; it cost 1.75 ms of
+// GPU time per genome and, worse, its 88 KB / 1024-thread workgroups blocked the chip for the first 2 ms of a step
+// (rocprofv3 timeline, round 2).  This version is bound by the XORs themselves: a lane owns JUMP_OPL consecutive
+// outputs and, per 32-bit polynomial limb, loads the window z[32 j + 10 l .. + 41] into REGISTERS once
+// (21 ds_read_b64); every set bit b of the limb (wave-uniform: scalar branch) then costs JUMP_OPL register XORs
+// acc[q] ^= W[b + q] -- one VALU instruction per (set bit, output) and 1/8 of the LDS traffic.  One workgroup per
+// jump (z is staged once, not once per output split); its 16 waves take every 16th limb and are XOR-reduced
+// through LDS.
 constexpr int JUMP_THREADS = 1024;
 constexpr int JUMP_WAVES = JUMP_THREADS / 64;
+constexpr int JUMP_OPL = 10;                             // outputs per lane: 63 lanes x 10 cover the 624 outputs
+constexpr int JUMP_WIN2 = (32 + JUMP_OPL) / 2;           // window of a limb, in 8-byte reads: 42 words >= 32 + 10 - 1
+constexpr int JUMP_OUT_PAD = 64 * JUMP_OPL;              // 640
+constexpr int JUMP_ZL = 32 * (MT_POLY_WORDS - 1) + JUMP_OUT_PAD + 2 * JUMP_WIN2 - JUMP_OPL;   // highest index read + 1
+static_assert(MT_POLY_WORDS % JUMP_WAVES == 0, "limbs are dealt to the waves in whole rounds");
+static_assert(MT_POLY_WORDS / JUMP_WAVES <= 64, "a wave keeps its limbs one per lane");
 
 // A jump needs z = the source state followed by 19 937 more raw words.  That extension is a sequential
-// recurrence (227 independent words per step, 88 steps) and used to be redone by every workgroup of every jump
-// from the same source -- 10 output splits x up to 15 multipliers -- which made it ~90 % of the cascade's GPU
-// time.  It is now computed ONCE per source state by one wave (k_mt_extend, same scheme as chunk generation)
-// into a z buffer, and the jump itself (k_mt_jump) only streams z into LDS and convolves.
+// recurrence (227 independent words per step, 88 steps); it is computed ONCE per source state (k_mt_extend,
+// same scheme as chunk generation) into a z buffer which every jump from that source reads.
 constexpr int JUMP_ZP = (JUMP_Z + 63) & ~63;             // z row pitch in words
+constexpr int GEN_THREADS = 256;                         // one word per lane and step (227 of them active)
 
-__global__ __launch_bounds__(64) void k_mt_extend(const uint32_t *__restrict__ states, uint32_t *__restrict__ zbuf) {
+__global__ __launch_bounds__(GEN_THREADS) void k_mt_extend(const uint32_t *__restrict__ states, uint32_t *__restrict__ zbuf) {
     __shared__ uint32_t ring[1024];
     const uint32_t j = blockIdx.x;
     const uint32_t *s = states + (size_t)j * MT_N;
     uint32_t *out = zbuf + (size_t)j * JUMP_ZP;
-    for (int i = threadIdx.x; i < MT_N; i += 64) { const uint32_t v = s[i]; ring[i] = v; out[i] = v; }
+    for (int i = threadIdx.x; i < MT_N; i += GEN_THREADS) { const uint32_t v = s[i]; ring[i] = v; out[i] = v; }
     __syncthreads();
-    // word t beyond the state is sequence index 624 + t: needs t, t+1, t+397 (ring of 1024 >= 624 + 227 live words)
+    // word t beyond the state is sequence index 624 + t: needs t, t+1, t+397 (ring of 1024 >= 624 + 227 live words).
+    // A step's writes [t+624] never touch the slots it reads, so one barrier per step orders everything.
     for (int base = 0; base < JUMP_Z - MT_N; base += GEN_STEP) {
-        uint32_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int o = (int)threadIdx.x + 64 * q;
-            const int t = base + o;
-            v[q] = 0;
-            if (o < GEN_STEP && t + MT_N < JUMP_Z)
-                v[q] = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int o = (int)threadIdx.x + 64 * q;
-            const int t = base + o;
-            if (o < GEN_STEP && t + MT_N < JUMP_Z) {
-                ring[(t + MT_N) & 1023] = v[q];
-                out[t + MT_N] = v[q];
-            }
+        const int t = base + (int)threadIdx.x;
+        if ((int)threadIdx.x < GEN_STEP && t + MT_N < JUMP_Z) {
+            const uint32_t v = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
+            ring[(t + MT_N) & 1023] = v;
+            out[t + MT_N] = v;
         }
         __syncthreads();
     }
@@ -94,83 +93,72 @@ __global__ __launch_bounds__(64) void k_mt_extend(const uint32_t *__restrict__ s
 // One cascade level: every source state j < n_src is advanced by mult * n_src chunks for mult = m_first,
 // m_first + 1, ... (blockIdx.x / n_src selects the multiplier and with it the polynomial), giving the states of
 // chunks j + mult * n_src.  All multipliers of a level are independent, hence one launch per level.
-// state' = g(A) state : out[m] = XOR_{i in g} z[i+m].  One jump is spread over JUMP_SPLIT workgroups (64 outputs
-// each); inside a workgroup the 16 waves take every 16th polynomial limb (wave-uniform bit scan on the scalar
-// unit, four LDS reads in flight per lane).
 __global__ __launch_bounds__(JUMP_THREADS) void k_mt_jump(uint32_t *__restrict__ states, const uint32_t *__restrict__ zbuf,
                                                           uint32_t n_src, const uint32_t *__restrict__ poly_level,
                                                           uint32_t m_first) {
-    __shared__ uint32_t z[JUMP_Z + 3];
-    __shared__ uint32_t g[MT_POLY_WORDS];
-    __shared__ uint32_t red[JUMP_THREADS];
+    __shared__ __attribute__((aligned(16))) uint32_t z[JUMP_ZL];
+    __shared__ uint32_t red[JUMP_WAVES][JUMP_OUT_PAD];
     const uint32_t src = blockIdx.x % n_src;
     const uint32_t mult = m_first + blockIdx.x / n_src;
     const uint32_t *poly = poly_level + (size_t)(mult - 1) * MT_POLY_WORDS;
-    const int m0 = blockIdx.y * JUMP_OUT;
     const uint32_t *zs = zbuf + (size_t)src * JUMP_ZP;
     uint32_t *dst = states + ((size_t)src + (size_t)mult * n_src) * MT_N;
-    for (int i = threadIdx.x; i < JUMP_Z; i += JUMP_THREADS) z[i] = zs[i];
-    for (int i = threadIdx.x; i < MT_POLY_WORDS; i += JUMP_THREADS) g[i] = poly[i];
-    __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m = m0 + lane;
-    uint32_t acc = 0;
-    if (m < MT_N) {
-        const uint32_t *zl = z + m;
-        for (int j = wave; j < MT_POLY_WORDS; j += JUMP_WAVES) {
-            uint32_t bits = __builtin_amdgcn_readfirstlane(g[j]);
-            const uint32_t *zj = zl + j * 32;
-            while (bits) {
-                uint32_t v0, v1 = 0, v2 = 0, v3 = 0;
-                v0 = zj[__builtin_ctz(bits)]; bits &= bits - 1;
-                if (bits) { v1 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
-                if (bits) { v2 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
-                if (bits) { v3 = zj[__builtin_ctz(bits)]; bits &= bits - 1; }
-                acc ^= (v0 ^ v1) ^ (v2 ^ v3);
+    // this wave's limbs, one per lane: limb index wave + 16 * lane
+    const uint32_t my_limb = lane < MT_POLY_WORDS / JUMP_WAVES ? poly[wave + JUMP_WAVES * lane] : 0u;
+    for (int i = threadIdx.x; i < JUMP_ZL; i += JUMP_THREADS) z[i] = i < JUMP_Z ? zs[i] : 0u;
+    __syncthreads();
+    uint32_t acc[JUMP_OPL];
+#pragma unroll
+    for (int q = 0; q < JUMP_OPL; q++) acc[q] = 0;
+    for (int it = 0; it < MT_POLY_WORDS / JUMP_WAVES; it++) {
+        const uint32_t bits = __builtin_amdgcn_readlane(my_limb, it);        // wave-uniform
+        if (bits == 0) continue;
+        const int j = wave + JUMP_WAVES * it;
+        const uint2 *wp = reinterpret_cast<const uint2 *>(z + 32 * j + JUMP_OPL * lane);   // 8-byte aligned
+        uint32_t W[2 * JUMP_WIN2];
+#pragma unroll
+        for (int r = 0; r < JUMP_WIN2; r++) { const uint2 t = wp[r]; W[2 * r] = t.x; W[2 * r + 1] = t.y; }
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            if (bits & (1u << b)) {                                           // scalar branch
+#pragma unroll
+                for (int q = 0; q < JUMP_OPL; q++) acc[q] ^= W[b + q];
             }
         }
     }
-    red[threadIdx.x] = acc;
+#pragma unroll
+    for (int q = 0; q < JUMP_OPL; q++) red[wave][JUMP_OPL * lane + q] = acc[q];
     __syncthreads();
-    if (threadIdx.x < JUMP_OUT && m0 + (int)threadIdx.x < MT_N) {
+    if (threadIdx.x < MT_N) {
         uint32_t r = 0;
 #pragma unroll
-        for (int w = 0; w < JUMP_WAVES; w++) r ^= red[threadIdx.x + 64 * w];
-        dst[m0 + threadIdx.x] = r;
+        for (int w = 0; w < JUMP_WAVES; w++) r ^= red[w][threadIdx.x];
+        dst[threadIdx.x] = r;
     }
 }
 
 // chunk j: raw words x[624 + j*S .. 624 + (j+1)*S) from state_j (the 624 words before the chunk).
-// One wave per chunk: 227 words are mutually independent per step, a step's reads never touch the
-// slots it overwrites, so the only ordering needed is "this step's writes before the next step's
-// reads" -- a single-wave workgroup barrier.
-__global__ __launch_bounds__(64) void k_mt_generate(const uint32_t *__restrict__ states,
-                                                    uint32_t *__restrict__ raw, uint32_t first_chunk) {
+// One workgroup per chunk, one word per lane and step: 227 words are mutually independent per step and a
+// step's reads never touch the slots it overwrites, so the only ordering needed is "this step's writes before
+// the next step's reads" -- one barrier.  (The first version gave a chunk to a single wave, four words per
+// lane and step: 312 us per batch whatever its size, the latency that decided when a step's first contig could
+// start.  Four waves take a quarter of that.)
+__global__ __launch_bounds__(GEN_THREADS) void k_mt_generate(const uint32_t *__restrict__ states,
+                                                             uint32_t *__restrict__ raw, uint32_t first_chunk) {
     __shared__ uint32_t ring[1024];
     const uint32_t j = first_chunk + blockIdx.x;
     const uint32_t *s = states + (size_t)j * MT_N;
     uint32_t *out = raw + MT_N + (size_t)j * MT_CHUNK_WORDS;
-    for (int i = threadIdx.x; i < MT_N; i += 64) ring[i] = s[i];
+    for (int i = threadIdx.x; i < MT_N; i += GEN_THREADS) ring[i] = s[i];
     __syncthreads();
     // word t of the chunk is sequence index 624 + t relative to the state: needs t, t+1, t+397
     for (int base = 0; base < MT_CHUNK_WORDS; base += GEN_STEP) {
-        uint32_t v[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int o = (int)threadIdx.x + 64 * q;
-            const int t = base + o;
-            v[q] = 0;
-            if (o < GEN_STEP && t < MT_CHUNK_WORDS)
-                v[q] = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int o = (int)threadIdx.x + 64 * q;
-            const int t = base + o;
-            if (o < GEN_STEP && t < MT_CHUNK_WORDS) {
-                ring[(t + MT_N) & 1023] = v[q];
-                out[t] = v[q];
-            }
+        const int t = base + (int)threadIdx.x;
+        if ((int)threadIdx.x < GEN_STEP && t < MT_CHUNK_WORDS) {
+            const uint32_t v = mt_twist(ring[t & 1023], ring[(t + 1) & 1023], ring[(t + MT_M) & 1023]);
+            ring[(t + MT_N) & 1023] = v;
+            out[t] = v;
         }
         __syncthreads();
     }

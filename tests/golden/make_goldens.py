@@ -767,9 +767,44 @@ def make_cli_cases_engines():
              notes="SV mix via the RMT std line, du/iv/de blocks 20/5/3 (SV-mix engine, 21 k + 4.9 k candidates)")
 
 
+def make_reference_timing():
+    """Wall time of the REAL reference CLI (file in -> Fasta + VCF out, one core) in THIS container, on the
+    BASELINE config-1 shape (1 Mb, -sn 0.01) and on 10 Mb of the headline settings (-sn 0.01 -titv 2.0).
+    bench.py carries the result in `cpu_baseline.reference_survey_mbases_s` (the reference itself never travels
+    to the GPU box).  Opt-in (`make_goldens.py timing`): wall-clock numbers are not reproducible fixtures.
+    Caveat: sequence access goes through the in-memory pyfaidx stand-in, which is faster than real pyfaidx."""
+    import time
+    print("reference timing")
+    cpu = "unknown"
+    for line in Path("/proc/cpuinfo").read_text().splitlines():
+        if line.startswith("model name"):
+            cpu = line.split(":", 1)[1].strip()
+            break
+    runs = []
+    for name, length, tail in [("c1_1mb_sn0.01", 1_000_000, ["args", "-sn", "0.01"]),
+                               ("10mb_sn0.01_titv2", 10_000_000, ["args", "-sn", "0.01", "-titv", "2.0"]),
+                               ("1mb_c3_svmix", 1_000_000, ["args"] + C3_FLAGS)]:
+        with tempfile.TemporaryDirectory() as td:
+            spec = {"contigs": [{"defline": "contig1 synthetic", "length": length, "bpl": 60, "seed": 1234}]}
+            infile = gin.write_input(spec, Path(td) / "in.fa")
+            t0 = time.perf_counter()
+            code, _, err, exc = run_reference_cli(["-q", "-o", str(Path(td) / "out"), str(infile)] + tail, 42, 42)
+            dt = time.perf_counter() - t0
+            assert code is None and exc is None, (code, err, exc)
+        runs.append({"name": name, "bases": length, "argv": tail, "seconds": round(dt, 3),
+                     "mbases_per_s": round(length / dt / 1e6, 4)})
+        print(f"  {name}: {dt:.2f} s = {length / dt / 1e6:.3f} Mbases/s")
+    out = {"_env": ENV, "cpu_model": cpu, "cores_used": 1, "host_cores": os.cpu_count(),
+           "what": "mutation_simulator.__main__.main() of the real reference, whole CLI incl. file I/O, seeds 42/42",
+           "published_readme_mbases_s": 0.19, "runs": runs}
+    (HERE / "reference_timing.json").write_text(json.dumps(out, indent=1) + "\n")
+
+
 def main():
     os.chdir(HERE)
     which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli", "engines"}
+    if "timing" in which:
+        make_reference_timing()
     if "engines" in which:
         make_cli_cases_engines()
     if "rng" in which:

@@ -241,3 +241,13 @@ def test_result_device_pointer_and_gather_single_rank(engine):
     assert list(got) == [0]
     assert np.array_equal(got[0].cpu().numpy(), want)
     engine.clear()
+
+
+def test_rmt_overlapping_large_snp_ranges_vs_oracle(tmp_path):
+    """Two overlapping SN-only ranges, each large enough for the device SNP sampler (k >= 4096), std None:
+    the reference does not raise (the negative-length filler has no mutations) and merges the two per-range
+    dicts with update() -- later range wins (mutator.py:121).  Only the host planner reproduces that, so the
+    device engines must decline the contig (round-1 advisor finding: they did not)."""
+    text = "std\nit None\nNone\nchr 1\n1-600000 sn 0.02\n400001-1000000 sn 0.02\n"
+    spec = {"contigs": [{"defline": "ovl big", "length": 1_200_000, "bpl": 60, "seed": 11}]}
+    _product_vs_oracle(tmp_path, spec, [], 8, 9, rmt_text=text)
