@@ -294,29 +294,54 @@ __device__ __forceinline__ PieceSrc piece_src(uint32_t G, bool has, bool in_seg,
     return p;
 }
 
-// five dwords covering the 16 bytes at an arbitrary byte address (dword-aligned dwordx4 + dword)
-struct Raw5 { u32x4_a4 v; uint32_t w4; uint32_t sh; };
+// The 16 bytes at an arbitrary byte address.  MSIM_LOAD 1 (default): TWO ALIGNED dwordx4 loads (the 32 bytes
+// around them; the second is the next lane's first, an L1 hit) and a byte funnel -- round-2 ablation: the round-1
+// form (MSIM_LOAD 0: dwordx4 at a 4-byte aligned address + one more dword) cost 23 % of the kernel, a dwordx4 that
+// is not 16-byte aligned being split by the texture addresser.  `s` = byte offset of the wanted bytes in d[].
+#ifndef MSIM_LOAD
+#define MSIM_LOAD 1
+#endif
+#ifndef MSIM_WPE
+#define MSIM_WPE 8                                     // waves per SIMD k_rewrite<140> is compiled for (register budget 512 / WPE)
+#endif
+struct Raw5 { u32x4 a, b; uint32_t s; };              // 32 (or 20) bytes around the wanted 16; s = their byte offset in a|b
 __device__ __forceinline__ Raw5 piece_load(const PieceSrc &p) {
     Raw5 r;
     const uintptr_t a = reinterpret_cast<uintptr_t>(p.ptr);
+    r.b = u32x4{0, 0, 0, 0};
     if (MSIM_ABL & 1) {
-        r.sh = 0;
-        r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(a & ~(uintptr_t)15));
-        r.w4 = 0;
+        r.a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(a & ~(uintptr_t)15));
+        r.s = 0;
+        return r;
+    }
+    if (MSIM_LOAD == 1) {
+        const u32x4 *al = reinterpret_cast<const u32x4 *>(a & ~(uintptr_t)15);
+        r.a = al[0];
+        r.b = al[1];
+        r.s = (uint32_t)(a & 15);
         return r;
     }
     const uint8_t *al = reinterpret_cast<const uint8_t *>(a & ~(uintptr_t)3);
-    r.sh = (uint32_t)(a & 3);
-    r.v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(al));
-    r.w4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(al + 16));
+    const u32x4_a4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4 *>(al));
+    r.a.x = v.x; r.a.y = v.y; r.a.z = v.z; r.a.w = v.w;
+    r.b.x = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(al + 16));
+    r.s = (uint32_t)(a & 3);
     return r;
 }
 __device__ __forceinline__ u32x4 piece_finish(const Raw5 &r, uint32_t mode, const uint8_t *lut) {
+    uint32_t f0 = r.a.x, f1 = r.a.y, f2 = r.a.z, f3 = r.a.w, f4 = r.b.x;
+    if (MSIM_LOAD == 1 && !(MSIM_ABL & 1)) {             // dword part of the shift: two select stages over the 8 dwords
+        const bool q2 = r.s & 8, q1 = r.s & 4;
+        const uint32_t e0 = q2 ? r.a.z : r.a.x, e1 = q2 ? r.a.w : r.a.y, e2 = q2 ? r.b.x : r.a.z, e3 = q2 ? r.b.y : r.a.w,
+                       e4 = q2 ? r.b.z : r.b.x, e5 = q2 ? r.b.w : r.b.y;
+        f0 = q1 ? e1 : e0; f1 = q1 ? e2 : e1; f2 = q1 ? e3 : e2; f3 = q1 ? e4 : e3; f4 = q1 ? e5 : e4;
+    }
+    const uint32_t sh = r.s & 3;
     u32x4 pv;
-    pv.x = __builtin_amdgcn_alignbyte(r.v.y, r.v.x, r.sh);
-    pv.y = __builtin_amdgcn_alignbyte(r.v.z, r.v.y, r.sh);
-    pv.z = __builtin_amdgcn_alignbyte(r.v.w, r.v.z, r.sh);
-    pv.w = __builtin_amdgcn_alignbyte(r.w4, r.v.w, r.sh);
+    pv.x = __builtin_amdgcn_alignbyte(f1, f0, sh);
+    pv.y = __builtin_amdgcn_alignbyte(f2, f1, sh);
+    pv.z = __builtin_amdgcn_alignbyte(f3, f2, sh);
+    pv.w = __builtin_amdgcn_alignbyte(f4, f3, sh);
     if (mode & 256) {
         const u32x4 w = pv;
         pv.x = __builtin_bswap32(w.w); pv.y = __builtin_bswap32(w.z);
@@ -625,7 +650,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
 }
 
 template <int CAP>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? 8 : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? MSIM_WPE : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const msim_record *__restrict__ recs,
                                                      const uint32_t *__restrict__ off,
                                                      const int32_t *__restrict__ first, uint32_t n_rec,

@@ -34,17 +34,23 @@ ms = st["apply_kernel_ms"] / reps
 print(f"k_rewrite {ms*1e3:8.1f} us  {alg/reps/ms/1e6:8.1f} GB/s")
 '''
 
-NAMES = {"": "production", "abl1": "aligned loads", "abl2": "no structural fix-ups", "abl4": "no SNP pass",
-         "abl8": "no index table (plain copy)", "abl16": "XCD-contiguous tiles (still correct)",
-         "abl15": "1+2+4+8: skeleton", "abl31": "skeleton + XCD order"}
+# (sub-directory of lib/, MSIM_REWRITE, label)
+RUNS = [("ld0", "old", "k_rewrite, round-1 byte-shifted 20-B loads, 8 waves/SIMD"),
+        ("ld0w6", "old", "  same, compiled for 6 waves/SIMD"),
+        ("ld0w4", "old", "  same, compiled for 4 waves/SIMD"),
+        ("ld1w8", "old", "k_rewrite, two aligned 16-B loads per group, 8 waves/SIMD"),
+        ("ld1w6", "old", "  same, 6 waves/SIMD"),
+        ("ld1w5", "old", "  same, 5 waves/SIMD"),
+        ("ld1w4", "old", "  same, 4 waves/SIMD"),
+        ("ld1w4", "span", "k_rewrite_span (input span staged in LDS), 4 workgroups/CU")]
 
 if __name__ == "__main__":
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-    for sub, what in NAMES.items():
+    for sub, mode, what in RUNS:
         lib = LIB / sub / "libmsim.so"
         if not lib.exists():
             continue
-        env = dict(os.environ, MSIM_LIB=str(lib))
+        env = dict(os.environ, MSIM_LIB=str(lib), MSIM_REWRITE=mode)
         r = subprocess.run([sys.executable, "-c", CHILD % {"root": str(ROOT), "reps": reps}], env=env,
                            capture_output=True, text=True)
-        print(f"{what:40s} {r.stdout.strip() or r.stderr.strip()[-300:]}", flush=True)
+        print(f"{what:52s} {r.stdout.strip() or r.stderr.strip()[-300:]}", flush=True)
