@@ -146,19 +146,49 @@ def one_step(eng, sim, cids, my_contigs, seed=42, plan_descriptors=None):
     eng.sync()
 
 
+C3_FLAGS = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
+            "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
+
+WORKLOADS = {
+    "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp",
+           "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01"},
+    "c3": {"mode": "ARGS", "what": "full SV mix (BASELINE configs[2]): -sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500",
+           "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},
+    "c4": {"mode": "RMT", "what": "RMT mode, gene-blocking file with hot/cold spots (BASELINE configs[3])",
+           "kernel": "msim::k_rewrite_snp", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT hot/cold/blocked ranges"},
+}
+
+
+def build_settings(workload: str, lengths):
+    if workload == "c2":
+        return workload_settings(lengths)
+    if workload == "c3":
+        return workload_settings(lengths, snp=0.005, titv=1.0, extra=C3_FLAGS)
+    return workload_settings_rmt(lengths, c4_rmt_text(lengths))
+
+
+def host_info():
+    model = "unknown"
+    try:
+        for line in Path("/proc/cpuinfo").read_text().splitlines():
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
 def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4):
     """CPU oracle (single-threaded C restatement of the reference path) on a bounded sample of the same
-    workload: `n_contigs` contigs totalling `sample_total` bases with the workload's settings, seeds 42/42."""
+    workload: `n_contigs` contigs totalling `sample_total` bases with the workload's settings, seeds 42/42.
+    The reference itself cannot travel to the GPU box; its wall time measured in the build container
+    (tests/golden/reference_timing.json, written by `make_goldens.py timing`) is carried along."""
     from oracle import oracle as orc
     from test_gpu_parity import synth_host  # same generator as the device kernel
     from test_host_settings import dump_sim
     lengths = [sample_total // n_contigs] * n_contigs
-    if workload == "c2":
-        sim, what = workload_settings(lengths), "args -sn 0.01 -titv 2.0"
-    elif workload == "c3":
-        sim, what = workload_settings(lengths, snp=0.005, titv=1.0, extra=C3_FLAGS), "args, full SV mix (configs[2])"
-    else:
-        sim, what = workload_settings_rmt(lengths, c4_rmt_text(lengths)), "rmt, synthetic gene-blocking file (configs[3])"
+    sim = build_settings(workload, lengths)
     contigs = [{"name": f"chr{i+1}", "long_name": f"chr{i+1} synthetic", "lenc": 60,
                 "bases": synth_host(L, 1000 + i)} for i, L in enumerate(lengths)]
     o = orc.Oracle()
@@ -167,13 +197,48 @@ def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4):
     o.run_genome(contigs, dump_sim(sim), "synthetic.fa")
     dt = time.perf_counter() - t0
     total = sum(lengths)
-    return {"value": round(total / dt / 1e6, 3), "unit": "Mbases/s", "cores": 1, "kind": "port",
-            "sample": f"{n_contigs} contigs x {lengths[0]/1e6:.0f} Mb, {what}, seeds 42/42, "
-                      f"Fasta framing + VCF text included ({dt:.1f} s of CPU work)"}
+    model, cores = host_info()
+    out = {"value": round(total / dt / 1e6, 3), "unit": "Mbases/s", "cores": 1, "kind": "port",
+           "cpu_model": model, "node_cores": cores,
+           "sample": f"{n_contigs} contigs x {lengths[0]/1e6:.0f} Mb, {WORKLOADS[workload]['what']}, seeds 42/42, "
+                     f"Fasta framing + VCF text included ({dt:.1f} s of CPU work)"}
+    rt = ROOT / "tests" / "golden" / "reference_timing.json"
+    if rt.exists():
+        try:
+            ref = json.loads(rt.read_text())
+            out["reference_survey_mbases_s"] = {r["name"]: r["mbases_per_s"] for r in ref["runs"]}
+            out["reference_survey_note"] = (f"real reference CLI, 1 core of {ref['cpu_model']} in the build container, "
+                                            f"in-memory pyfaidx stand-in; README publishes {ref['published_readme_mbases_s']} Mbases/s")
+        except Exception:  # noqa: BLE001
+            pass
+    return out
 
 
-C3_FLAGS = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
-            "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
+def roofline_of(st, workload, steps):
+    launches = max(st["apply_launches"], 1)
+    alg_bytes = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
+    k_ms = st["apply_kernel_ms"]
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, source = None, None   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        tf = ROOT / "profiles" / name
+        if tf.exists():
+            try:
+                traffic = json.loads(tf.read_text())[workload]["traffic_bytes_per_launch"]
+                source = f"profiles/{name} (rocprofv3 --pmc TCC counters of an earlier run of this command, not this run)"
+                break
+            except Exception:  # noqa: BLE001
+                traffic = None
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+            "kernel": WORKLOADS[workload]["kernel"], "algorithmic_bytes_per_launch": alg_bytes // launches,
+            "avg_launch_ms": round(k_ms / launches, 4), "launches": launches}
+
+
+def stages_of(st, steps):
+    return {"plan_host": round(st["plan_host_ms"] / steps, 3), "plan_gpu": round(st["plan_gpu_ms"] / steps, 3),
+            "record_upload": round(st["upload_ms"] / steps, 3), "apply_all_kernels": round(st["apply_ms"] / steps, 3),
+            "apply_rewrite_kernel": round(st["apply_kernel_ms"] / steps, 3)}
 
 
 def main():
@@ -184,16 +249,15 @@ def main():
     ap.add_argument("--total-bases", type=int, default=3_000_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 / config-4 secondary measurements")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
-                    help="c2 = BASELINE configs[1] (headline: -sn 0.01 -titv 2.0); c3 = configs[2], the full SV mix "
-                         "(-sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500); c4 = configs[3], RMT mode with ~40 k blocked "
-                         "ranges + hot/cold spots (c4_rmt_text) -- secondary numbers")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: 'weak' = N independent replicas, one whole genome per GPU with its own seeded "
-                         "streams (PLAN cannot shard in bit-compatible mode: the streams chain across contigs); "
-                         "'strong' = one genome, PLAN replayed on every rank, contigs' APPLY sharded (LPT)")
-    ap.add_argument("--gather", action="store_true",
-                    help="also gather every mutated contig to rank 0 over RCCL inside the timed step")
+                    help="c2 = BASELINE configs[1] (headline: -sn 0.01 -titv 2.0); c3 = configs[2], the full SV mix; "
+                         "c4 = configs[3], RMT mode with ~40 k blocked ranges + hot/cold spots")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="N > 1: 'strong' (default) = BASELINE configs[4]'s shape: ONE genome, PLAN replayed on every rank "
+                         "(the MT19937 streams chain across contigs), contigs' APPLY sharded (LPT), RCCL gather to rank 0; "
+                         "'weak' = N independent replicas, one whole genome per GPU with its own seeded streams")
+    ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is always measured for N > 1, strong)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,123 +265,116 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
-        # launched by torch.distributed.run: one rank per GPU, rendezvous over RCCL (backend "nccl").
-        # torch is imported BEFORE libmsim so both share one HIP runtime (tools/share_hip_runtime.py).
-        import torch
+        # launched by torch.distributed.run: one rank per GPU.  torch.distributed (gloo, CPU) is the CONTROL plane
+        # only -- rendezvous, barriers, max-over-ranks; the data plane is libmsim's own RCCL communicator
+        # (msim_comm_*: ncclSend/ncclRecv over xGMI), no torch tensor ever holds genome bytes.
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     from mutation_simulator_amd import _ffi
     from mutation_simulator_amd import mutator as mm
+    from mutation_simulator_amd.sharding import lpt_partition
 
     lengths = contig_lengths(a.total_bases)
-    C3 = C3_FLAGS
-    if a.workload == "c2":
-        sim = workload_settings(lengths)
-    elif a.workload == "c3":
-        sim = workload_settings(lengths, snp=0.005, titv=1.0, extra=C3)
-    else:
-        sim = workload_settings_rmt(lengths, c4_rmt_text(lengths))
-    descs = {}                       # msim_range descriptors per contig: settings -> integers once, outside the timed steps
-
-    def plan_descs(chrom):
-        if chrom.number not in descs:
-            descs[chrom.number] = mm.plan_descriptors(chrom)
-        return descs[chrom.number]
-    from mutation_simulator_amd.sharding import lpt_partition
-    strong = a.scaling == "strong" and world > 1
+    scaling = a.scaling or ("strong" if world > 1 else "weak")
+    strong = scaling == "strong" and world > 1
     parts = lpt_partition(lengths, world) if strong else [list(range(len(lengths)))] * world
     mine = parts[rank]
     seed = 42 if strong else 42 + rank       # replicas: every GPU mutates its own genome
 
     eng = _ffi.Engine(local_rank)
-    eng.set_params(mm.params_descriptor(sim))
     # genome resident in HBM before the timed region (3 GB; every rank holds every contig so that
     # contig numbering is global -- 288 GB of HBM make the replica free)
     cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
     eng.sync()
+    comm = None
+    if strong:
+        from mutation_simulator_amd.gather import Communicator
+        comm = Communicator(eng, rank, world, dist)
 
     def barrier():
         eng.sync()
         if dist is not None:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
 
-    def step():
-        one_step(eng, sim, cids, mine, seed, plan_descs)
-        if a.gather and strong or a.gather and world == 1:
-            import torch
-            from mutation_simulator_amd.gather import gather_to_root
-            got = gather_to_root(eng, cids, parts, lengths, rank, world, torch.device("cuda", local_rank))
-            torch.cuda.synchronize()
-            del got
-
-    if a.gather:
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
         import torch
-        torch.cuda.set_device(local_rank)
-    for _ in range(a.warmup):
-        step()
-    eng.reset_stats()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    st = eng.stats()
+        return float(t.item())
 
+    def measure(workload, steps, warmup, gather=False):
+        sim = build_settings(workload, lengths)
+        descs = {}                   # msim_range descriptors per contig: settings -> integers once, outside the timed steps
+
+        def plan_descs(chrom):
+            if chrom.number not in descs:
+                descs[chrom.number] = mm.plan_descriptors(chrom)
+            return descs[chrom.number]
+        eng.set_params(mm.params_descriptor(sim))
+
+        def step():
+            one_step(eng, sim, cids, mine, seed, plan_descs)
+            if gather:
+                comm.gather_to_root(cids, parts)
+
+        for _ in range(warmup):
+            step()
+        eng.reset_stats()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        return dt, eng.stats()
+
+    dt, st = measure(a.workload, a.steps, a.warmup)
+    line = None
     if rank == 0:
         total = sum(lengths) * (1 if strong else world)      # weak: every rank mutated a whole genome
-        ms_per_step = dt / a.steps * 1e3
-        value = total * a.steps / dt / 1e6
-        launches = max(st["apply_launches"], 1)
-        alg_bytes = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
-        k_ms = st["apply_kernel_ms"]
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 --pmc passes, if present
-        tf = ROOT / "profiles" / "r01_traffic.json"
-        if tf.exists():
-            try:
-                traffic = json.loads(tf.read_text())[a.workload]["traffic_bytes_per_launch"]
-            except Exception:  # noqa: BLE001
-                traffic = None
+        W = WORKLOADS[a.workload]
         line = {
-            "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01",
-            "value": round(value, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "metric": W["metric"],
+            "value": round(total * a.steps / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("RMT" if a.workload == "c4" else "ARGS") + " mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), "
-                                   + {"c2": "-sn 0.01 -titv 2.0", "c3": "full SV mix (BASELINE configs[2])",
-                                      "c4": "RMT mode, synthetic gene-blocking file with hot/cold spots (BASELINE configs[3])"}[a.workload]
-                                   + ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
+            "config": {"workload": f"{W['mode']} mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), {W['what']}"
+                                   ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
-                       "parallelism": (f"one genome, contigs' APPLY sharded over {world} GPUs (LPT), PLAN replayed per rank"
+                       "parallelism": (f"one genome, contigs' APPLY sharded over {world} GPUs (LPT), PLAN replayed per rank, "
+                                       "results left in HBM on the owning GPU ('with_gather' adds the RCCL gather to rank 0)"
                                        if strong else f"{world} independent replica(s): one whole genome per GPU, "
-                                       f"streams seeded 42+rank")
-                                      + (", RCCL gather to rank 0 included" if a.gather else ", results left in HBM")},
-            "stages_ms_per_step": {
-                "plan_host": round(st["plan_host_ms"] / a.steps, 3),
-                "plan_gpu": round(st["plan_gpu_ms"] / a.steps, 3),
-                "record_upload": round(st["upload_ms"] / a.steps, 3),
-                "apply_all_kernels": round(st["apply_ms"] / a.steps, 3),
-                "apply_rewrite_kernel": round(k_ms / a.steps, 3)},
+                                       f"streams seeded 42+rank, results left in HBM")},
+            "stages_ms_per_step": stages_of(st, a.steps),
             "records_per_step": st["records"] // a.steps,
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "msim::k_rewrite" if a.workload == "c3" else "msim::k_rewrite_snp",
-                         "algorithmic_bytes_per_launch": alg_bytes // launches,
-                         "avg_launch_ms": round(k_ms / launches, 4), "launches": launches},
+            "roofline": roofline_of(st, a.workload, a.steps),
         }
+    if strong:
+        # the exchange step north_star names: every peer sends its mutated contigs to rank 0 over its own xGMI link
+        dtg, _ = measure(a.workload, a.steps, 1, gather=True)
+        if rank == 0:
+            line["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
+                                   "ms_per_step": round(dtg / a.steps * 1e3, 3),
+                                   "transport": comm.describe()}
+    if world == 1 and not a.no_secondary and a.workload == "c2":
+        # BASELINE configs[2] and [3] on the same resident genome: 3 steps each, same definition of a step
+        sec = {}
+        for w in ("c3", "c4"):
+            dts, sts = measure(w, 3, 1)
+            sec[w] = {"metric": WORKLOADS[w]["metric"], "value": round(sum(lengths) * 3 / dts / 1e6, 3), "unit": "Mbases/s",
+                      "ms_per_step": round(dts / 3 * 1e3, 3), "steps": 3, "warmup": 1,
+                      "stages_ms_per_step": stages_of(sts, 3), "records_per_step": sts["records"] // 3,
+                      "roofline": roofline_of(sts, w, 3)}
+        line["secondary"] = sec
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload)      # bounded sample: ~6-10 s of CPU work
         print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -202,6 +202,28 @@ int msim_fetch_sequence_framed(msim_ctx *ctx, int contig, uint32_t bpl, uint8_t 
 int msim_add_contig_text(msim_ctx *ctx, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases,
                          uint32_t lenc, uint32_t lenb, int *contig);
 
+/* ---- multi-GPU: one process per GPU, contigs' APPLY sharded, gather over RCCL ------------------ */
+/* mutate()'s contig loop (mutator.py:111-141) is the unit of sharding: PLAN is replayed on every rank (the two
+ * MT19937 streams chain across contigs), each rank APPLYs the contigs it owns, and the one exchange step is the
+ * gather of the mutated contigs to `root` -- grouped ncclSend / ncclRecv, every peer over its own xGMI link.
+ * librccl is dlopen()ed by msim_comm_init; the 128-byte ncclUniqueId travels over the caller's control plane. */
+#define MSIM_COMM_ID_BYTES 128
+int msim_comm_unique_id(uint8_t id[MSIM_COMM_ID_BYTES]);                       /* on one rank; broadcast the bytes */
+int msim_comm_init(msim_ctx *ctx, const uint8_t id[MSIM_COMM_ID_BYTES], int rank, int world);   /* collective   */
+int msim_comm_destroy(msim_ctx *ctx);
+/* Mutated length of a planned contig where PLAN alone fixes it (SNP-only tables, SV mixes planned on the device):
+ * every rank then knows every contig's size without an exchange.  *known = 0: only the applying rank knows it. */
+int msim_planned_out_len(msim_ctx *ctx, int contig, uint64_t *out_len, int *known);
+/* Slot i = contig contig_ids[i] (this context's id), applied by rank owner[i], out_len[i] bytes.  Synchronises, then
+ * moves every slot to `root`.  device_addrs[i] (optional) = where slot i now lives on this rank: the contig's own
+ * buffer (owner), a receive buffer of the context (root), 0 elsewhere.  Valid until the next gather / clear.   */
+int msim_gather_to_root(msim_ctx *ctx, int n, const int *contig_ids, const int *owner, const uint64_t *out_len,
+                        int root, uint64_t *device_addrs);
+/* The transfers `rank` posts for that gather, without touching a GPU: ops[4k..] = kind (0 send, 1 recv, 2 already
+ * local), slot, peer, bytes -- in posting order (slot order on both sides of every pair).                       */
+int msim_gather_plan(int n, const int *owner, const uint64_t *out_len, int rank, int world, int root,
+                     int64_t *ops, int *n_ops);
+
 /* ---- stats -------------------------------------------------------------------------------------- */
 int msim_stats(msim_ctx *ctx, msim_timing *out);
 int msim_reset_stats(msim_ctx *ctx);

@@ -44,6 +44,7 @@ struct Contig {
 constexpr uint64_t PAD = 64;          // slack after every byte buffer so 16-B vector accesses stay in bounds
 
 struct GpuPlan;
+struct Comm;                          // comm.cpp: RCCL communicator + receive buffers of the gather
 
 struct Ctx {
     int device = 0;
@@ -56,6 +57,7 @@ struct Ctx {
     std::string devname;
     HostMT py, np;                    // stream states, host representation
     GpuPlan *gpu = nullptr;           // device representation of the streams + sampler scratch
+    Comm *comm = nullptr;             // multi-GPU: set by msim_comm_init
     msim_params params{};
     bool have_params = false;
     std::vector<Contig> contigs;
@@ -115,6 +117,9 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);
 int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes);
 int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
                         uint32_t lenb, uint8_t *d_dst);
+
+// comm.cpp
+void comm_destroy(Ctx *c);
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);

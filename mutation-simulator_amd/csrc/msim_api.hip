@@ -209,6 +209,7 @@ void msim_destroy(msim_ctx *p) {
     if (c->d_errs) (void)hipFree(c->d_errs);
     if (c->d_text) (void)hipFree(c->d_text);
     if (c->d_text_scratch) (void)hipFree(c->d_text_scratch);
+    comm_destroy(c);
     gpu_plan_destroy(c->gpu);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
@@ -552,6 +553,19 @@ int msim_result_device_ptr(msim_ctx *p, int contig, uint64_t *device_address, ui
     if (g->key_error) return key_error_of(c, *g);
     *device_address = (uint64_t)(uintptr_t)g->d_out;
     *len = g->out_len;
+    return MSIM_OK;
+}
+
+int msim_planned_out_len(msim_ctx *p, int contig, uint64_t *out_len, int *known) {
+    Ctx *c = C(p);
+    if (!c || !out_len || !known) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    *known = 0;
+    *out_len = 0;
+    if (g->all_snp || g->n_rec == 0) { *known = 1; *out_len = g->len; }
+    else if (g->delta_known) { *known = 1; *out_len = (uint64_t)((long long)g->len + g->known_delta); }
     return MSIM_OK;
 }
 

@@ -90,6 +90,12 @@ SYMBOLS = [
     ("msim_render_vcf_device", C.c_int, [_VP, C.c_int, C.c_char_p, _VP, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
+    ("msim_comm_unique_id", C.c_int, [_VP]),
+    ("msim_comm_init", C.c_int, [_VP, _VP, C.c_int, C.c_int]),
+    ("msim_comm_destroy", C.c_int, [_VP]),
+    ("msim_planned_out_len", C.c_int, [_VP, C.c_int, _U64P, _IP]),
+    ("msim_gather_to_root", C.c_int, [_VP, C.c_int, _IP, _IP, _U64P, C.c_int, _U64P]),
+    ("msim_gather_plan", C.c_int, [C.c_int, _IP, _U64P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _IP]),
     ("msim_stats", C.c_int, [_VP, C.POINTER(Timing)]),
     ("msim_reset_stats", C.c_int, [_VP]),
 ]
@@ -328,6 +334,30 @@ class Engine:
         self._check(self.lib.msim_result_device_ptr(self.h, contig, C.byref(a), C.byref(n)), contig)
         return a.value, n.value
 
+    # ------------------------------------------------------------------ multi-GPU (csrc/comm.cpp)
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.msim_comm_init(self.h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._check(self.lib.msim_comm_destroy(self.h))
+
+    def planned_out_len(self, contig: int):
+        """(mutated length, known): known = PLAN alone fixes the length (every rank can compute it)."""
+        n, k = C.c_uint64(), C.c_int()
+        self._check(self.lib.msim_planned_out_len(self.h, contig, C.byref(n), C.byref(k)))
+        return n.value, bool(k.value)
+
+    def gather_to_root(self, contig_ids, owner, out_len, root: int = 0):
+        """Moves every slot to ``root`` over RCCL; returns the device address of every slot on this rank."""
+        n = len(contig_ids)
+        ids = (C.c_int * max(n, 1))(*contig_ids)
+        own = (C.c_int * max(n, 1))(*owner)
+        lens = (C.c_uint64 * max(n, 1))(*out_len)
+        addrs = (C.c_uint64 * max(n, 1))()
+        self._check(self.lib.msim_gather_to_root(self.h, n, ids, own, lens, root, addrs))
+        return list(addrs)[:n]
+
     def release_result(self, contig: int):
         self._check(self.lib.msim_release_result(self.h, contig))
 
@@ -338,6 +368,30 @@ class Engine:
 
     def reset_stats(self):
         self._check(self.lib.msim_reset_stats(self.h))
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId as 128 opaque bytes (call on one rank, broadcast over the control plane)."""
+    lib = load()
+    buf = (C.c_uint8 * 128)()
+    rc = lib.msim_comm_unique_id(buf)
+    if rc != OK:
+        raise MsimError(f"msim_comm_unique_id failed ({rc}): {lib.msim_last_error(None).decode()}")
+    return bytes(buf)
+
+
+def gather_plan(owner, out_len, rank: int, world: int, root: int = 0):
+    """The transfers ``rank`` posts for a gather: list of (kind, slot, peer, bytes); kind 0 send, 1 recv, 2 local."""
+    lib = load()
+    n = len(owner)
+    own = (C.c_int * max(n, 1))(*owner)
+    lens = (C.c_uint64 * max(n, 1))(*out_len)
+    ops = (C.c_int64 * (4 * max(n, 1)))()
+    k = C.c_int()
+    rc = lib.msim_gather_plan(n, own, lens, rank, world, root, ops, C.byref(k))
+    if rc != OK:
+        raise MsimError(f"msim_gather_plan failed ({rc})")
+    return [tuple(int(ops[4 * i + j]) for j in range(4)) for i in range(k.value)]
 
 
 def render_vcf(recs: np.ndarray, pool: np.ndarray, bases: np.ndarray, seq_name: str) -> bytes:

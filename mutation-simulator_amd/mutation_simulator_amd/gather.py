@@ -1,65 +1,103 @@
-"""Final gather of sharded results to rank 0 over RCCL (xGMI inside a node).
+"""Final gather of sharded results to rank 0: control plane in Python, data plane in libmsim.
 
-Contigs are applied on the rank that owns them (``sharding.lpt_partition``); a consumer that wants the
-whole mutated genome on one GPU gathers them with point-to-point transfers: every peer sends its
-contigs straight to rank 0 over its own direct link (a ring collective would be bound by one link;
-sizes differ per rank anyway).  The transport is ``torch.distributed`` with backend ``nccl`` -- which
-is RCCL on ROCm -- used purely as plumbing: libmsim's device buffers are wrapped zero-copy through
-``__cuda_array_interface__``; nothing here touches the bytes.
+Contigs are applied on the rank that owns them (``sharding.lpt_partition``); a consumer that wants the whole
+mutated genome on one GPU gathers them with point-to-point transfers -- every peer sends its contigs straight to
+the root over its own direct xGMI link (a ring collective would be bound by one link; sizes differ per rank).
 
-This module is the only place the package imports torch, and only when a gather is requested.
+* data plane: ``msim_gather_to_root`` (csrc/comm.cpp) -- libmsim's own RCCL communicator, grouped
+  ``ncclSend`` / ``ncclRecv`` on its device buffers.  No torch tensor ever holds genome bytes.
+* control plane: whatever process group the launcher provides (``torch.distributed`` with the CPU backend
+  ``gloo`` under ``torch.distributed.run``): it carries the 128-byte ``ncclUniqueId`` once and, only for contigs
+  whose mutated length PLAN does not fix (host-planned tables), their lengths.
+
+``HostTransport`` executes the same transfer list (``msim_gather_plan``) over the control plane's CPU send / recv:
+the stand-in used by the multi-process CPU tests, where no GPU exists.
 """
 from __future__ import annotations
 
+import numpy as np
 
-class _DeviceBytes:
-    """Minimal ``__cuda_array_interface__`` view of ``n`` bytes at device address ``addr``."""
-
-    def __init__(self, addr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (addr, False),
-                                         "version": 2, "strides": None}
+from . import _ffi
 
 
-def as_tensor(addr: int, n: int, device):
-    import torch
-    if n == 0:
-        return torch.empty(0, dtype=torch.uint8, device=device)
-    return torch.as_tensor(_DeviceBytes(addr, n), device=device)
+def owners_of(parts, n_contigs: int):
+    owner = [0] * n_contigs
+    for r, p in enumerate(parts):
+        for i in p:
+            owner[i] = r
+    return owner
 
 
-def gather_to_root(engine, contig_ids, parts, lengths_out, rank: int, world: int, device, root: int = 0):
-    """Move every applied contig's mutated stream to ``root``.
+class Communicator:
+    """One per rank.  ``dist`` = an initialised ``torch.distributed`` module (any backend) or None for world 1."""
 
-    ``parts[r]`` = contig indices owned by rank r, ``lengths_out[i]`` = mutated length of contig i
-    (known on every rank: PLAN is replicated).  Returns, on root, a dict contig -> uint8 tensor on
-    ``device`` (own contigs are views of libmsim's buffers, received ones are fresh tensors); on other
-    ranks an empty dict.  All transfers are posted before any is waited for.
-    """
-    import torch
-    import torch.distributed as dist
-    out = {}
-    if world == 1:
-        for i in parts[0]:
-            addr, n = engine.result_device_ptr(contig_ids[i])
-            out[i] = as_tensor(addr, n, device)
-        return out
-    ops, recv = [], {}
-    if rank == root:
-        for r in range(world):
-            for i in parts[r]:
-                if r == root:
-                    addr, n = engine.result_device_ptr(contig_ids[i])
-                    out[i] = as_tensor(addr, n, device)
-                else:
-                    buf = torch.empty(lengths_out[i], dtype=torch.uint8, device=device)
-                    recv[i] = buf
-                    ops.append(dist.P2POp(dist.irecv, buf, r))
-    else:
-        for i in parts[rank]:
-            addr, n = engine.result_device_ptr(contig_ids[i])
-            ops.append(dist.P2POp(dist.isend, as_tensor(addr, n, device), root))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    out.update(recv)
-    return out
+    def __init__(self, engine, rank: int, world: int, dist=None):
+        self.eng, self.rank, self.world, self.dist = engine, rank, world, dist
+        self.live = False
+        if world > 1:
+            box = [_ffi.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            engine.comm_init(box[0], rank, world)
+            self.live = True
+
+    def describe(self) -> str:
+        return ("libmsim RCCL communicator (dlopen librccl): grouped ncclSend/ncclRecv, every peer -> rank 0 over its own "
+                "xGMI link; ncclUniqueId bootstrapped over the gloo control plane")
+
+    def lengths(self, contig_ids, parts):
+        """Mutated length of every contig, on every rank.  PLAN is replayed everywhere, so lengths it fixes are
+        local knowledge; the rest is exchanged over the control plane by the owning rank."""
+        owner = owners_of(parts, len(contig_ids))
+        lens, missing = [], []
+        for i, cid in enumerate(contig_ids):
+            n, known = self.eng.planned_out_len(cid)
+            if not known:
+                missing.append(i)
+                n = self.eng.result_sizes(cid)[0] if owner[i] == self.rank else 0
+            lens.append(n)
+        if missing and self.world > 1:
+            mine = {i: lens[i] for i in missing if owner[i] == self.rank}
+            every = [None] * self.world
+            self.dist.all_gather_object(every, mine)
+            for d in every:
+                for i, n in d.items():
+                    lens[i] = n
+        return owner, lens
+
+    def gather_to_root(self, contig_ids, parts, root: int = 0):
+        owner, lens = self.lengths(contig_ids, parts)
+        return self.eng.gather_to_root(contig_ids, owner, lens, root), lens
+
+    def close(self):
+        if self.live:
+            self.eng.comm_destroy()
+            self.live = False
+
+
+class HostTransport:
+    """Executes ``msim_gather_plan`` with CPU buffers over ``torch.distributed`` send / recv (gloo): the same
+    bookkeeping as the RCCL path -- who sends what, sizes, posting order -- without a GPU."""
+
+    def __init__(self, rank: int, world: int, dist):
+        self.rank, self.world, self.dist = rank, world, dist
+
+    def gather_to_root(self, payload: dict, owner, out_len, root: int = 0):
+        """payload: slot -> uint8 numpy array for the slots this rank owns.  Returns slot -> array on root."""
+        import torch
+        ops = _ffi.gather_plan(owner, out_len, self.rank, self.world, root)
+        out, reqs, keep = {}, [], []
+        for kind, slot, peer, nbytes in ops:
+            if kind == 2:
+                out[slot] = payload[slot]
+            elif kind == 0:
+                t = torch.from_numpy(np.ascontiguousarray(payload[slot]))
+                assert t.numel() == nbytes
+                keep.append(t)
+                reqs.append(self.dist.isend(t, peer, tag=slot))
+            else:
+                t = torch.empty(nbytes, dtype=torch.uint8)
+                out[slot] = t
+                reqs.append(self.dist.irecv(t, peer, tag=slot))
+        for r in reqs:
+            r.wait()
+        return {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in out.items()}

@@ -216,14 +216,9 @@ def test_synthetic_contig_and_checksum(engine, length):
     engine.clear()
 
 
-def test_result_device_pointer_and_gather_single_rank(engine):
-    """The device pointer libmsim exposes wraps zero-copy as a tensor (what the RCCL gather moves)."""
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    from mutation_simulator_amd.gather import gather_to_root
+def _plan_apply_snp_contig(engine, seed=5):
     engine.clear()
-    engine.seed(5, 6)
+    engine.seed(seed, seed + 1)
     p = _ffi.Params()
     for i in range(8):
         p.block[i] = 1
@@ -236,11 +231,98 @@ def test_result_device_pointer_and_gather_single_rank(engine):
     r.cdf_thr[0] = 1 << 53
     engine.plan_contig(cid, [r])
     engine.apply_contig(cid)
+    return cid
+
+
+def test_gather_single_rank_and_rccl_loopback(engine):
+    """World 1: the gather is the identity (device address of the contig's own buffer).  Then libmsim's RCCL path
+    for real: librccl dlopen()ed, a 1-rank communicator, and the mutated contig sent to and received from rank 0
+    itself (grouped ncclSend + ncclRecv) -- the bytes that come back must be the mutated contig."""
+    import ctypes as C
+    from mutation_simulator_amd.gather import Communicator
+    cid = _plan_apply_snp_contig(engine)
     want = engine.fetch_sequence(cid)
-    got = gather_to_root(engine, [cid], [[0]], [len(want)], 0, 1, torch.device("cuda", 0))
-    assert list(got) == [0]
-    assert np.array_equal(got[0].cpu().numpy(), want)
+    comm = Communicator(engine, 0, 1, None)
+    addrs, lens = comm.gather_to_root([cid], [[0]])
+    assert lens == [len(want)] and addrs[0] == engine.result_device_ptr(cid)[0]
+    engine.comm_init(_ffi.comm_unique_id(), 0, 1)
+    lib = _ffi.load()
+    lib.msim_dbg_comm_loopback.restype = C.c_int
+    lib.msim_dbg_comm_loopback.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    s = C.c_uint64()
+    rc = lib.msim_dbg_comm_loopback(engine.h, cid, C.byref(s))
+    assert rc == 0, lib.msim_last_error(engine.h).decode()
+    assert s.value == checksum_host(want) == engine.result_checksum(cid)
+    engine.comm_destroy()
     engine.clear()
+
+
+def _two_gpu_worker(rank, world, port, out_dir):
+    import json
+    import os
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for q in (root, root / "mutation-simulator_amd", root / "tests", root / "tests" / "golden"):
+        if str(q) not in sys.path:
+            sys.path.insert(0, str(q))
+    import torch.distributed as dist
+    import bench
+    from mutation_simulator_amd import _ffi as ffi
+    from mutation_simulator_amd import mutator as mm
+    from mutation_simulator_amd.gather import Communicator
+    from mutation_simulator_amd.sharding import lpt_partition
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lengths = bench.contig_lengths(60_000_000)
+        sim = bench.workload_settings(lengths, snp=0.005, titv=1.0, extra=bench.C3_FLAGS)
+        parts = lpt_partition(lengths, world)
+        eng = ffi.Engine(rank)
+        eng.set_params(mm.params_descriptor(sim))
+        cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
+        comm = Communicator(eng, rank, world, dist)
+        bench.one_step(eng, sim, cids, parts[rank], 42)
+        addrs, lens = comm.gather_to_root(cids, parts)
+        if rank == 0:
+            sums = []
+            lib = ffi.load()
+            import ctypes as C
+            lib.msim_dbg_checksum_device.restype = C.c_int
+            lib.msim_dbg_checksum_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+            for a, n in zip(addrs, lens):
+                s = C.c_uint64()
+                assert lib.msim_dbg_checksum_device(eng.h, a, n, C.byref(s)) == 0
+                sums.append(s.value)
+            # the 1-GPU answer: apply everything here
+            bench.one_step(eng, sim, cids, list(range(len(lengths))), 42)
+            want = [eng.result_checksum(c) for c in cids]
+            Path(out_dir, "two_gpu.json").write_text(json.dumps({"ok": sums == want, "n": len(sums)}))
+        dist.barrier()
+        comm.close()
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_gpu_sharded_apply_and_rccl_gather(tmp_path):
+    """BASELINE configs[4]'s shape on two GPUs: PLAN replayed per rank, contigs' APPLY LPT-sharded, RCCL gather to
+    rank 0; the gathered genome must equal the 1-GPU result contig by contig.  Needs two visible GPUs."""
+    import ctypes as C
+    import json
+    import socket
+    hip = C.CDLL("libamdhip64.so")
+    n = C.c_int()
+    if hip.hipGetDeviceCount(C.byref(n)) != 0 or n.value < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_two_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = json.loads((tmp_path / "two_gpu.json").read_text())
+    assert res["ok"] and res["n"] == 24
 
 
 def test_rmt_overlapping_large_snp_ranges_vs_oracle(tmp_path):

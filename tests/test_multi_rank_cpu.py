@@ -2,7 +2,8 @@
 run to be correct by construction: (1) the LPT partition covers every contig exactly once and is
 balanced, (2) every rank's replicated PLAN lands on identical records and identical stream
 positions (so any rank may apply any contig), (3) the union of the per-rank apply sets is the
-genome.  PLAN runs through libmsim's host-only context (no GPU here); APPLY itself is covered by the
+genome, (4) the gather's bookkeeping (libmsim's msim_gather_plan) delivers every contig to rank 0
+when driven by a host-memory transport over gloo.  PLAN runs through libmsim's host-only context (no GPU here); APPLY itself is covered by the
 single-GPU parity tests -- contigs are independent, sharding does not change a contig's result."""
 from __future__ import annotations
 
@@ -52,8 +53,26 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
             recs, pool = eng.fetch_records(cid)
             digests.append(hashlib.sha256(recs.tobytes() + pool.tobytes()).hexdigest())
         state = [(hashlib.sha256(eng.get_mt_state(s)[0].tobytes()).hexdigest(), eng.get_mt_state(s)[1]) for s in (0, 1)]
+        # ---- the gather's bookkeeping (msim_gather_plan: who sends what, sizes, posting order), driven end to end
+        # with a host-memory transport: every rank "applies" its contigs (deterministic stand-in bytes whose LENGTH
+        # differs from the input length, like a mutated contig's), rank 0 must end up with every contig intact
+        from mutation_simulator_amd.gather import HostTransport, owners_of
+        owner = owners_of(parts, len(lengths))
+        out_len = [L + (i * 37) % 101 - 50 for i, L in enumerate(lengths)]
+
+        def stand_in(i):
+            return np.random.RandomState(1000 + i).randint(0, 256, out_len[i], dtype=np.uint8)
+        payload = {i: stand_in(i) for i in parts[rank]}
+        got = HostTransport(rank, world, dist).gather_to_root(payload, owner, out_len, root=0)
+        gather_ok = None
+        if rank == 0:
+            gather_ok = sorted(got) == list(range(len(lengths))) and all(np.array_equal(got[i], stand_in(i)) for i in got)
+        else:
+            assert got == {}
+        ops = _ffi.gather_plan(owner, out_len, rank, world, 0)
         gathered = [None] * world
-        dist.all_gather_object(gathered, {"rank": rank, "owned": parts[rank], "digests": digests, "state": state})
+        dist.all_gather_object(gathered, {"rank": rank, "owned": parts[rank], "digests": digests, "state": state,
+                                          "gather_ok": gather_ok, "ops": ops})
         if rank == 0:
             import json
             Path(out_dir, "result.json").write_text(json.dumps({"parts": parts, "gathered": gathered,
@@ -76,6 +95,13 @@ def test_two_ranks_over_gloo(tmp_path):
     assert owned == list(range(res["n_contigs"]))                 # every contig applied exactly once
     assert g[0]["digests"] == g[1]["digests"]                     # replicated PLAN is identical ...
     assert g[0]["state"] == g[1]["state"]                         # ... and so are both stream positions
+    by_rank = {x["rank"]: x for x in g}
+    assert by_rank[0]["gather_ok"] is True                        # root holds every contig, byte for byte
+    sends = [tuple(o) for o in by_rank[1]["ops"]]
+    recvs = [tuple(o) for o in by_rank[0]["ops"] if o[0] == 1]
+    assert [o[0] for o in sends] == [0] * len(sends) and sorted(o[1] for o in sends) == by_rank[1]["owned"]
+    # every send of rank 1 meets a receive of rank 0 for the same slot and size, in the same order
+    assert [(o[1], o[3]) for o in sends] == [(o[1], o[3]) for o in recvs] and all(o[2] == 1 for o in recvs)
 
 
 @pytest.mark.parametrize("world", [1, 2, 4, 8])
