@@ -388,7 +388,10 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
         }
         return plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
     }
-    if (hs_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
+    if (hs_ok && !(c->flags & MSIM_PLAN_HOST)) {
+        if (gpu_plan_walk_eligible(c, ranges, n_ranges)) return plan_contig_gpu_walk(c, c->gpu, *g, ranges, n_ranges);
+        return plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
+    }
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
         rc = gpu_plan_sync_to_host(c, c->gpu);
         if (rc) return rc;

@@ -19,6 +19,8 @@
 // DESIGN.md section 3 has the reasoning and the measurements.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "ctx.h"
@@ -81,6 +83,11 @@ struct MixedSet {                        // scratch of one SV-mix range (section
     uint32_t *sn_index = nullptr; size_t cap_snidx = 0;   // kept-SNP ordinal -> record index
     uint32_t *cnt = nullptr; size_t cap_cnt = 0;          // five per-workgroup counter arrays
     uint32_t *words = nullptr; size_t cap_words = 0;      // tempered word window for the host chain
+    WalkRange *walk_d = nullptr; size_t cap_walk_d = 0;   // device-walked contigs: range table
+    WalkRange *walk_h = nullptr; size_t cap_walk_h = 0;   //   its pinned staging (one per set: the copy is asynchronous)
+    uint32_t *wbits = nullptr; size_t cap_wbits = 0;      //   contig-wide bitmap of sampled positions (zero between uses)
+    bool wbits_dirty = false;                             //   a failed pass may have left bits behind
+    uint32_t *wcnt = nullptr; size_t cap_wcnt = 0;        //   per-workgroup popcounts / ranks of its expansion
     hipEvent_t emit_done = nullptr;
     bool pending = false;
 };
@@ -93,6 +100,7 @@ struct GpuPlan {
     uint32_t *h_npos = nullptr; size_t cap_h_npos = 0;
     uint8_t *h_ntype = nullptr; size_t cap_h_ntype = 0;
     uint32_t *h_nstop = nullptr; size_t cap_h_nstop = 0;
+    uint32_t *walk_gbm = nullptr; size_t cap_walk_gbm = 0; // k_sample_walk: zeroed bitmap for ranges beyond its LDS bitmap
     hipStream_t gen_stream = nullptr;   // chunk generation (latency-bound, ~300 us per batch)
     hipStream_t jump_stream = nullptr;  // jump cascade: never waits for a generation batch
     std::vector<hipEvent_t> ev_pool;
@@ -155,8 +163,9 @@ void gpu_plan_destroy(GpuPlan *g) {
     }
     for (auto &t : g->mixed) {
         void *bufs[] = {t.cand_pos, t.cand_type, t.cand_stop, t.nsn_pos, t.nsn_type, t.nsn_rank, t.nsn_stop, t.sn_index,
-                        t.cnt, t.words};
+                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt};
         for (void *b : bufs) if (b) (void)hipFree(b);
+        if (t.walk_h) (void)hipHostFree(t.walk_h);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
     void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop};
@@ -164,6 +173,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     for (auto e : g->chain_ev) if (e) (void)hipEventDestroy(e);
     if (g->t0) (void)hipEventDestroy(g->t0);
     if (g->t1) (void)hipEventDestroy(g->t1);
+    if (g->walk_gbm) (void)hipFree(g->walk_gbm);
     if (g->d_poly) (void)hipFree(g->d_poly);
     if (g->d_ps) (void)hipFree(g->d_ps);
     if (g->h_mail) (void)hipHostFree(g->h_mail);
@@ -428,6 +438,7 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
     const PlanState h = *g->h_mail;
     if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
         g->s[0].live = g->s[1].live = false;
+        for (auto &t : g->mixed) t.wbits_dirty = true;
         return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its 16-sigma margin (results discarded)");
     }
     c->t.py_words += h.pos - g->verified_pos;
@@ -1027,6 +1038,213 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
     M.pending = true;
     py.pos = pos_hi;
+    g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k) per drawing range
+    c->t.np_words += 2 * K;
+    ct.planned = true;
+    return MSIM_OK;
+}
+
+
+// ====================================================================== device-walked contigs
+// The same contigs as the host-sampled engine above (deterministic-SNP ranges of any size and number), but the chain
+// of samples is walked by ONE workgroup on the device (k_sample_walk): no word window goes to the host, nothing
+// synchronises -- the contig is enqueued like an SNP-sampler contig.  Pool-path ranges beyond the kernel's LDS pool
+// keep the contig on the host-sampled engine.
+// MSIM_WALK_PROF builds: phase counters of k_sample_walk, printed at exit
+static unsigned long long *walk_prof() {
+#ifdef MSIM_WALK_PROF
+    static unsigned long long *d = nullptr;
+    if (!d) {
+        (void)hipMalloc(&d, 16 * 8);
+        (void)hipMemset(d, 0, 16 * 8);
+        atexit([]() {
+            unsigned long long h[16];
+            (void)hipDeviceSynchronize();
+            if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "walk prof: cycles %llu wall100MHz %llu pool %llu set %llu batches %llu refills %llu refill_cyc %llu inner %llu ranges %llu | per-batch phases: flags+exchange %llu, insert rounds %llu, append %llu, cut %llu\n",
+                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]);
+        });
+    }
+    return d;
+#else
+    return nullptr;
+#endif
+}
+
+bool gpu_plan_walk_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
+    // Opt-in (MSIM_WALK=1): bit-exact and fully asynchronous, but measured SLOWER than the host walk in round 2 --
+    // a link of the chain costs ~12 dependent LDS / barrier phases of 400-1200 cycles each on the device (5 700 cycles =
+    // 2.4 us per range, 106 ms per 3 Gb config-4 genome) against 1.8 us on one host core (75 ms); DESIGN.md section 3.3.
+    static const bool enabled = []() { const char *e = getenv("MSIM_WALK"); return e && e[0] == '1'; }();
+    if (!enabled || !gpu_plan_hostsample_eligible(c, ranges, n_ranges)) return false;
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    if (d >= (1ll << 32)) return false;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;
+        const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+        if (n <= r.setsize && n > (int64_t)WK_POOL_MAX) return false;
+    }
+    return true;
+}
+
+int plan_contig_gpu_walk(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    int rc;
+    if ((rc = stream_to_device(c, g, 0))) return rc;
+    if ((rc = stream_to_device(c, g, 1))) return rc;
+    if (!g->d_ps) MSIM_HIP(c, hipMalloc(&g->d_ps, sizeof(PlanState)));
+    if (!g->h_mail) MSIM_HIP(c, hipHostMalloc(&g->h_mail, sizeof(PlanState), hipHostMallocMapped));
+    GpuStream &py = g->s[0];
+    if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
+    if (!g->unverified) MSIM_HIP(c, hipEventRecord(g->t0, c->stream));
+    if (!g->ps_valid) {
+        hipLaunchKernelGGL(k_state_init, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)py.pos);
+        g->ps_valid = true;
+    }
+    g->unverified = true;
+    // word window: expected consumption of every sample + 16 sigma of the total (as for the host-sampled engine)
+    uint64_t K = 0, max_g = 0;
+    uint32_t n_draw = 0;
+    double e_words = 0, var = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;
+        n_draw++;
+        const double k = (double)r.k, n = (double)((r.stop - (r.k - 1) * d) - r.start);
+        K += (uint64_t)r.k;
+        if (n <= (double)r.setsize) { e_words += 2.0 * k; var += 2.0 * k; continue; }   // pool path: < 2 words per draw
+        if (n > (double)WK_LDS_BITS) max_g = std::max<uint64_t>(max_g, (uint64_t)n);
+        const double p_acc = n / (double)(1ull << bit_length64((uint64_t)n));
+        const double need = k >= n ? 64.0 * k : -n * std::log1p(-k / n);                // coupon collector
+        e_words += need / p_acc;
+        var += need * (1.0 - p_acc) / (p_acc * p_acc) + 4.0 * (need - k) / (p_acc * p_acc) + need / p_acc;
+    }
+    const double wd = e_words + 16.0 * std::sqrt(var) + 65536.0;
+    if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
+    const uint32_t W = (uint32_t)wd;
+    bool grew = false;
+    MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
+    if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;
+    if (M.pending) {                                       // the pinned range table of this set may still be in flight
+        MSIM_HIP(c, hipEventSynchronize(M.emit_done));
+        M.pending = false;
+    }
+    if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
+    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;   // unordered position list
+    if ((rc = grow(c, (void **)&M.walk_d, &M.cap_walk_d, (size_t)n_draw * sizeof(WalkRange) + 64, &grew))) return rc;
+    if ((rc = grow_host(c, (void **)&M.walk_h, &M.cap_walk_h, (size_t)n_draw * sizeof(WalkRange) + 64))) return rc;
+    const uint32_t bmw = (uint32_t)((ct.len + 63) / 64);  // contig-wide bitmap, 64-bit words
+    const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
+    {
+        const size_t want = (size_t)bmw * 8 + 64;
+        if (M.cap_wbits < want) {
+            const size_t before = M.cap_wbits;
+            if ((rc = grow(c, (void **)&M.wbits, &M.cap_wbits, want, &grew))) return rc;
+            if (M.cap_wbits != before) MSIM_HIP(c, hipMemset(M.wbits, 0, M.cap_wbits));   // k_walk_expand leaves it zeroed
+        }
+        if (M.wbits_dirty) {
+            MSIM_HIP(c, hipMemsetAsync(M.wbits, 0, M.cap_wbits, c->stream));
+            M.wbits_dirty = false;
+        }
+    }
+    if ((rc = grow(c, (void **)&M.wcnt, &M.cap_wcnt, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if (max_g) {
+        const size_t want = (size_t)((max_g + 31) / 32) * 4 + 64;
+        if (g->cap_walk_gbm < want) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            if (g->walk_gbm) MSIM_HIP(c, hipFree(g->walk_gbm));
+            g->walk_gbm = nullptr; g->cap_walk_gbm = 0;
+            MSIM_HIP(c, hipMalloc(&g->walk_gbm, want + want / 4));
+            MSIM_HIP(c, hipMemset(g->walk_gbm, 0, want + want / 4));      // the kernel leaves it zeroed
+            g->cap_walk_gbm = want + want / 4;
+        }
+    }
+    {   // the record table may still be read by an earlier apply of this contig
+        const size_t want = (size_t)K * sizeof(msim_record);
+        if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        }
+        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
+    }
+    {
+        uint32_t at = 0, base = 0;
+        for (int i = 0; i < n_ranges; i++) {
+            const msim_range &r = ranges[i];
+            if (r.k == 0) continue;
+            const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+            WalkRange w;
+            w.start = (uint32_t)r.start; w.k = (uint32_t)r.k; w.n = (uint32_t)n; w.rec_base = base;
+            w.pool = n <= r.setsize ? 1u : 0u;
+            M.walk_h[at++] = w;
+            base += (uint32_t)r.k;
+        }
+    }
+    const uint64_t pos_lo = py.pos;
+    if ((rc = ensure_words(c, g, 0, pos_lo + W + 1))) return rc;
+    MSIM_HIP(c, hipMemcpyAsync(M.walk_d, M.walk_h, (size_t)n_draw * sizeof(WalkRange), hipMemcpyHostToDevice, c->stream));
+    if (max_g)
+        hipLaunchKernelGGL(k_sample_walk<true>, dim3(1), dim3(WK_THREADS), 0, c->stream, py.d_raw, g->d_ps, W, M.walk_d, n_draw,
+                           M.cand_pos, g->walk_gbm, walk_prof());
+    else
+        hipLaunchKernelGGL(k_sample_walk<false>, dim3(1), dim3(WK_THREADS), 0, c->stream, py.d_raw, g->d_ps, W, M.walk_d, n_draw,
+                           M.cand_pos, g->walk_gbm, walk_prof());
+    MSIM_HIP(c, hipGetLastError());
+    {   // records on the emit stream (ordered after any earlier APPLY that still reads this contig's table): the
+        // contig-wide bitmap is the sorted sample
+        hipEvent_t ce0 = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce0, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce0, 0));
+        hipLaunchKernelGGL(k_list_to_bits, dim3(((uint32_t)K + 255) / 256), dim3(256), 0, c->emit_stream, M.cand_pos,
+                           (uint32_t)K, M.wbits);
+        hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                           reinterpret_cast<const uint64_t *>(M.wbits), bmw, M.wcnt);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, M.wcnt, bnb);
+        hipLaunchKernelGGL(k_walk_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                           reinterpret_cast<uint64_t *>(M.wbits), bmw, M.wcnt, M.walk_d, n_draw, (uint32_t)d, ct.d_recs);
+        MSIM_HIP(c, hipGetLastError());
+    }
+    ct.n_rec = K;
+    ct.pool_len = 0;
+    ct.plan_empty = false;
+    ct.all_snp = true;
+    uint64_t pos_hi = pos_lo + W;
+    {   // SNP draws of the whole contig, in position order (as in plan_contig_gpu)
+        const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
+        const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
+        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
+        const uint32_t W2 = (uint32_t)w2;
+        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
+        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
+        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
+        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
+        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
+        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
+        if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
+        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps);
+        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                           (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
+        MSIM_HIP(c, hipGetLastError());
+        hipEvent_t ce = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
+                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K, (const uint32_t *)nullptr);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+        T.pending = true;
+        pos_hi += W2;
+    }
+    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
+    M.pending = true;
+    py.pos = pos_hi;                                       // bound until gpu_plan_finish reads the exact value
     g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k) per drawing range
     c->t.np_words += 2 * K;
     ct.planned = true;

@@ -1186,6 +1186,420 @@ __global__ __launch_bounds__(256) void k_records_from_pos(const uint32_t *__rest
     recs[i] = r;
 }
 
+// ------------------------------------------------------------------ 7. chains of small samples on the device
+// An RMT file in the style of the reference's examples leaves thousands of drawing ranges per contig, a few hundred
+// SNPs each.  Every random.sample() starts at the word where the previous one stopped and the stops are data
+// dependent, so the ranges form a chain -- but each link is short, and nothing in it needs the host: ONE workgroup
+// walks the contig's ranges in order, with the next stream words always staged in an LDS ring (refilled from
+// registers that were loaded a whole refill earlier, so the chain never waits for global memory) and the range's
+// de-dup bitmap in LDS.  Round 1 did this walk on the host over a D2H copy of the words (74 ms per 3 Gb genome,
+// with a synchronisation per contig).  Only what decides the next stream position is on the walk's critical path:
+//   set path  (Lib/random.py sample(), n > setsize): accepted draws in stream order are numbered by ballots; the
+//     first A = k of them are OR-ed into the LDS bitmap, every duplicate found raises A by one (the rule of
+//     k_sample_tail: distinct(first A) = A - dups(A) must reach k), until a round finds none; the cut is one past
+//     the word holding the A-th accepted draw.
+//   pool path (n <= setsize): the partial Fisher-Yates shuffle is a chain inside the chain; one lane walks it.
+// A lane that inserted a NEW value also sets bit (range start + value) of a contig-wide bitmap in global memory
+// (fire and forget).  Sorting, ranks and records happen afterwards, in bulk, off the chain (k_walk_expand):
+// pos = start + value + d * rank-inside-the-range (util.py:104-109).
+struct WalkRange { uint32_t start, k, n, rec_base, pool; };    // pool = 1: n <= setsize (pool path)
+
+constexpr int WK_THREADS = 1024;                          // 16 waves, 4 per SIMD: the walk is bound by instruction latency, and
+constexpr int WK_WAVES = WK_THREADS / 64;                 //   four waves per SIMD interleave where one would idle between issues
+constexpr int WK_ITEMS = 1;
+constexpr int WK_BATCH = WK_THREADS * WK_ITEMS;           // stream words examined per round (1024): wave w owns words [64 w, 64 w + 64)
+constexpr int WK_RG = 256;                                // range descriptors staged in LDS at a time
+constexpr int WK_RING = 8192;                             // LDS ring of tempered words: four quarters (power of two)
+constexpr int WK_Q = WK_RING / 4;                         // three quarters resident, the fourth being loaded (direct-to-LDS)
+constexpr int WK_BM_WORDS = 16384;                        // 64 KB LDS bitmap: ranges of up to 524 288 positions
+constexpr uint32_t WK_LDS_BITS = (uint32_t)WK_BM_WORDS * 32u;
+constexpr uint32_t WK_POOL_MAX = WK_BM_WORDS;             // largest pool-path range handled here (the pool aliases the bitmap)
+constexpr int WK_LIST = 8192;                             // LDS staging of sampled positions between two flushes
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access
+// (vmcnt(0)) -- here that would stall the chain on its own prefetch loads and list stores at every step.
+#define WK_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
+// index (0..63) of the (r+1)-th set bit of m (r < popcount(m))
+__device__ __forceinline__ uint32_t wk_nth_bit(unsigned long long m, uint32_t r) {
+    uint32_t pos = 0;
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+        const uint32_t c = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
+        if (r >= c) { r -= c; m >>= sh; pos += sh; }
+    }
+    return pos;
+}
+
+template <bool HAS_BIG>                                   // some range needs the de-dup bitmap in global memory
+__global__ __launch_bounds__(WK_THREADS) void k_sample_walk(const uint32_t *__restrict__ raw, PlanState *ps, uint32_t W,
+                                                            const WalkRange *__restrict__ ranges, uint32_t n_ranges,
+                                                            uint32_t *__restrict__ out_list /* K positions, any order */,
+                                                            uint32_t *gbm /* de-dup bitmap for n > WK_LDS_BITS, zeroed */,
+                                                            unsigned long long *prof) {
+#ifdef MSIM_WALK_PROF
+    unsigned long long pr_t0 = __builtin_readcyclecounter(), pr_w0 = wall_clock64(), pr_pool = 0, pr_set = 0, pr_batches = 0,
+                       pr_inner = 0, pr_ref = 0, pr_nref = 0, pr_p1 = 0, pr_p2 = 0, pr_p3 = 0, pr_p4 = 0, pr_p0 = 0;
+#define PR_NOW() __builtin_readcyclecounter()
+#define WK_PROF_REF0 const unsigned long long pr_r0 = PR_NOW();
+#define WK_PROF_REF1 pr_ref += PR_NOW() - pr_r0; pr_nref++;
+#else
+#define WK_PROF_REF0
+#define WK_PROF_REF1
+#endif
+    __shared__ uint32_t ring[WK_RING];
+    __shared__ uint32_t bm[WK_BM_WORDS];
+    __shared__ uint32_t list[WK_LIST];
+    __shared__ WalkRange rg[WK_RG];
+    __shared__ uint32_t wtot[2][WK_WAVES];                // accepted draws per wave of the batch (double-buffered)
+    __shared__ uint32_t dcnt[2][WK_WAVES];
+    __shared__ uint32_t s_w, s_done, s_over, s_lcnt, s_cut;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long p0 = ps->pos;
+    // ring: words [base, base + 3 Q) resident and tempered, [base + 3 Q, base + 4 Q) in flight -- loaded straight into
+    // LDS (global_load_lds), so that no register and no compiler-inserted vmcnt wait ties the chain to global memory
+    typedef __attribute__((address_space(1))) const void wk_gmem;
+    typedef __attribute__((address_space(3))) void wk_lmem;
+    // (issued from inline asm: hipcc guards every LDS access that follows a global_load_lds it knows about with
+    // vmcnt(0), which would turn the prefetch into a blocking load; the chain waits for it by hand, a refill later)
+#define WK_LOAD_QUARTER(first)                                                                     \
+    do {                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < WK_Q / WK_THREADS; i_++) {                         \
+            const uint32_t row_ = (first) + (uint32_t)(i_ * WK_THREADS) + wave * 64;               \
+            const uint32_t lds_ = __builtin_amdgcn_readfirstlane(                                  \
+                (uint32_t)(size_t)(wk_lmem *)(ring + (row_ & (WK_RING - 1))));                     \
+            const uint32_t *src_ = raw + p0 + row_ + lane;                                         \
+            if (row_ + lane < W)                                                                   \
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"        \
+                             :: "s"(lds_), "v"(src_) : "memory");                            \
+        }                                                                                          \
+    } while (0)
+    for (uint32_t i = tid; i < (uint32_t)(3 * WK_Q); i += WK_THREADS) ring[i] = i < W ? mt_temper(raw[p0 + i]) : 0u;
+    for (uint32_t i = tid; i < (uint32_t)WK_BM_WORDS; i += WK_THREADS) bm[i] = 0;
+    uint32_t base = 0;
+    if (tid == 0) { s_over = 0; s_lcnt = 0; }
+    __syncthreads();
+    WK_LOAD_QUARTER(3 * WK_Q);
+    uint32_t w = 0;                                       // words consumed so far (identical in every lane)
+    uint32_t dpar = 0;                                    // which dcnt buffer the next round uses
+    uint32_t flushed = 0;                                 // positions already written to out_list
+    uint32_t lbound = 0;                                  // upper bound of the staged positions (no LDS read needed)
+    bool over = false;
+    // sampled positions go to global memory in bursts, right after the chain had to wait for its prefetch anyway
+#define WK_FLUSH()                                                                                 \
+    do {                                                                                           \
+        const uint32_t n_ = s_lcnt;                                                                \
+        for (uint32_t i_ = tid; i_ < n_; i_ += WK_THREADS) out_list[flushed + i_] = list[i_];      \
+        flushed += n_;                                                                             \
+        lbound = 0;                                                                                \
+        WK_BARRIER();                                                                              \
+        if (tid == 0) s_lcnt = 0;                                                                  \
+        WK_BARRIER();                                                                              \
+    } while (0)
+    // advance the ring until word `at` lies in its first quarter: then [at, at + 2 Q) is resident
+#define WK_REFILL(at)                                                                              \
+    while ((at) >= base + WK_Q) {                                                                  \
+        WK_PROF_REF0                                                                               \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the quarter requested a refill ago */ \
+        WK_BARRIER();                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < WK_Q / WK_THREADS; i_++) {                         \
+            const uint32_t s_ = (base + 3 * WK_Q + (uint32_t)(i_ * WK_THREADS) + tid) & (WK_RING - 1); \
+            ring[s_] = mt_temper(ring[s_]);                                                        \
+        }                                                                                          \
+        base += WK_Q;                                                                              \
+        WK_BARRIER();                                                                              \
+        WK_FLUSH();                                                                                \
+        WK_LOAD_QUARTER(base + 3 * WK_Q);                                                          \
+        WK_PROF_REF1                                                                               \
+    }
+    for (uint32_t r0 = 0; r0 < n_ranges && !over; r0 += WK_RG) {
+        WK_BARRIER();
+        if (tid < (uint32_t)WK_RG && r0 + tid < n_ranges) rg[tid] = ranges[r0 + tid];
+        __syncthreads();
+        const uint32_t in_chunk = min((uint32_t)WK_RG, n_ranges - r0);
+        for (uint32_t rr = 0; rr < in_chunk && !over; rr++) {
+            const WalkRange R = rg[rr];
+            const uint32_t n = R.n, k = R.k;
+            if (k == 0) continue;
+#ifdef MSIM_WALK_PROF
+            const unsigned long long pr_a = PR_NOW();
+#endif
+            if (R.pool) {
+                // ---- pool path: pool[j] = j; k times: j = randbelow(n - i), take pool[j], pool[j] = pool[n - i - 1].
+                // A chain inside the chain: wave 0 walks it in lockstep -- 64 stream words at a time in registers,
+                // picked out with v_readlane, every decision on the scalar unit.
+                uint32_t *pool = bm;                      // (the bitmap is all zero between ranges)
+                for (uint32_t i = tid; i < n; i += WK_THREADS) pool[i] = i;
+                WK_BARRIER();
+                uint32_t i = 0, wl = w;                   // draws done / next word (wave 0, uniform)
+                while (true) {
+                    WK_REFILL(w)
+                    if (lbound + WK_BATCH > (uint32_t)WK_LIST) { WK_BARRIER(); WK_FLUSH(); }
+                    if (wave == 0) {
+                        uint32_t cnt = 0, lc = s_lcnt;
+                        bool ov = false;
+                        while (i < k && cnt < (uint32_t)WK_BATCH && !ov) {
+                            const uint32_t wreg = ring[(wl + lane) & (WK_RING - 1)];
+                            const uint32_t have = min(64u, W > wl ? W - wl : 0u);
+                            if (have == 0) { ov = true; break; }
+                            uint32_t j = 0;
+                            while (j < have && i < k) {
+                                const uint32_t m = n - i;
+                                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)wreg, (int)j) >> __builtin_clz(m);
+                                j++;
+                                if (v < m) {
+                                    const uint32_t pick = pool[v], last = pool[m - 1];
+                                    if (lane == 0) { pool[v] = last; list[lc] = R.start + pick; }
+                                    lc++; i++;
+                                }
+                            }
+                            wl += j; cnt += j;
+                        }
+                        if (lane == 0) {
+                            s_lcnt = lc;
+                            s_w = wl;
+                            s_done = (i == k || ov) ? 1u : 0u;
+                            if (ov) s_over = 1;
+                        }
+                    }
+                    lbound += WK_BATCH + 64;
+                    WK_BARRIER();
+                    w = s_w;
+                    const bool dn = s_done != 0;
+                    over = s_over != 0;
+                    WK_BARRIER();
+                    if (dn) break;
+                }
+                for (uint32_t i2 = tid; i2 < n; i2 += WK_THREADS) pool[i2] = 0;     // the area is bitmap again
+                WK_BARRIER();
+#ifdef MSIM_WALK_PROF
+                pr_pool += PR_NOW() - pr_a;
+#endif
+                continue;
+            }
+            // ---- set path
+            const bool use_g = HAS_BIG && n > WK_LDS_BITS;
+            const uint32_t sh = (uint32_t)__builtin_clz(n);                         // 32 - bit_length(n), n >= 1
+            uint32_t A = k, inserted = 0, acc_before = 0, wb = w;
+            bool first_batch = true, done = false;
+            while (!done) {
+                WK_REFILL(wb)
+#ifdef MSIM_WALK_PROF
+                pr_batches++;
+                const unsigned long long pr_b0 = PR_NOW();
+#endif
+                if (wb + WK_BATCH > W) { over = true; break; }                       // (window slack is far larger)
+                if (lbound + WK_BATCH > (uint32_t)WK_LIST) { WK_BARRIER(); WK_FLUSH(); }
+                uint32_t v[WK_ITEMS], myidx[WK_ITEMS];
+                unsigned long long bal[WK_ITEMS];         // wave-uniform accept ballots of this wave's four rows
+                uint32_t okm = 0, mine = 0;               // bit q: item q accepted / put a NEW value into the bitmap
+                uint32_t wsum_mine = 0;                   // accepted draws in this wave's segment
+#pragma unroll
+                for (int q = 0; q < WK_ITEMS; q++) v[q] = ring[(wb + wave * (64 * WK_ITEMS) + q * 64 + lane) & (WK_RING - 1)] >> sh;
+#pragma unroll
+                for (int q = 0; q < WK_ITEMS; q++) {
+                    const bool ok = v[q] < n;
+                    okm |= (ok ? 1u : 0u) << q;
+                    bal[q] = __ballot(ok);
+                    myidx[q] = wsum_mine + (uint32_t)__popcll(bal[q] & ((1ull << lane) - 1ull));
+                    wsum_mine += (uint32_t)__popcll(bal[q]);
+                }
+                if (lane == 0) wtot[dpar][wave] = wsum_mine;
+                WK_BARRIER();
+                // rank of every accepted draw in stream order: wave-major (a wave owns a contiguous segment)
+#ifdef MSIM_WALK_PROF
+                const unsigned long long pr_b1 = PR_NOW();
+#endif
+                uint32_t mybase = acc_before, avail = acc_before;                   // avail: accepted draws up to the end of this batch
+#pragma unroll
+                for (int ww = 0; ww < WK_WAVES; ww++) {
+                    const uint32_t t = wtot[dpar][ww];
+                    if ((uint32_t)ww < wave) mybase += t;
+                    avail += t;
+                }
+#pragma unroll
+                for (int q = 0; q < WK_ITEMS; q++) myidx[q] += mybase;
+                while (true) {
+                    const uint32_t lim = min(A, avail);
+#ifdef MSIM_WALK_PROF
+                    pr_inner++;
+#endif
+                    uint32_t old[WK_ITEMS];
+                    uint32_t act = 0;
+#pragma unroll
+                    for (int q = 0; q < WK_ITEMS; q++) {                            // all atomics in flight together
+                        old[q] = 0;
+                        if (((okm >> q) & 1u) && myidx[q] >= inserted && myidx[q] < lim) {
+                            act |= 1u << q;
+                            // (two address spaces, two instructions: a generic pointer would make this a FLAT atomic,
+                            // which goes through the vector-memory path even when it lands in LDS)
+                            if (HAS_BIG && use_g) old[q] = atomicOr(&gbm[v[q] >> 5], 1u << (v[q] & 31));
+                            else old[q] = atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
+                        }
+                    }
+                    uint32_t dl = 0;
+#pragma unroll
+                    for (int q = 0; q < WK_ITEMS; q++) {
+                        const bool dup = ((act >> q) & 1u) && ((old[q] >> (v[q] & 31)) & 1u);
+                        if (((act >> q) & 1u) && !dup) mine |= 1u << q;
+                        dl += (uint32_t)__popcll(__ballot(dup));                    // wave-uniform
+                    }
+                    if (lane == 0) dcnt[dpar][wave] = dl;
+                    WK_BARRIER();
+                    uint32_t dsum = 0;
+#pragma unroll
+                    for (int ww = 0; ww < WK_WAVES; ww++) dsum += dcnt[dpar][ww];
+                    dpar ^= 1;
+                    inserted = lim;
+                    A += dsum;
+                    if (dsum == 0 || inserted >= avail) break;
+                }
+#ifdef MSIM_WALK_PROF
+                const unsigned long long pr_b2 = PR_NOW();
+#endif
+                // the new values of this batch: range start + value, appended to the staging list (order is irrelevant;
+                // one LDS atomic per wave)
+                {
+                    uint32_t cntq[WK_ITEMS], tot = 0;
+                    unsigned long long nb[WK_ITEMS];
+#pragma unroll
+                    for (int q = 0; q < WK_ITEMS; q++) {
+                        nb[q] = __ballot((mine >> q) & 1u);
+                        cntq[q] = (uint32_t)__popcll(nb[q]);
+                        tot += cntq[q];
+                    }
+                    uint32_t at = 0;
+                    if (lane == 0 && tot) at = atomicAdd(&s_lcnt, tot);
+                    at = __builtin_amdgcn_readfirstlane(at);
+#pragma unroll
+                    for (int q = 0; q < WK_ITEMS; q++) {
+                        if ((mine >> q) & 1u) list[at + (uint32_t)__popcll(nb[q] & ((1ull << lane) - 1ull))] = R.start + v[q];
+                        at += cntq[q];
+                    }
+                    lbound += WK_BATCH;
+                }
+#ifdef MSIM_WALK_PROF
+                const unsigned long long pr_b3 = PR_NOW();
+                pr_p1 += pr_b1 - pr_b0; pr_p2 += pr_b2 - pr_b1; pr_p3 += pr_b3 - pr_b2;
+#endif
+                if (inserted == A) {                                                // distinct(first A) == k: the sample is complete
+                    // the word holding the A-th accepted draw: only the wave whose segment holds it looks
+                    const uint32_t tgt = A - 1;
+                    const uint32_t lo = mybase;
+                    if (tgt >= lo && tgt < lo + wsum_mine) {                        // wave-uniform
+                        uint32_t rem = tgt - lo, cut = 0;
+                        bool found = false;
+#pragma unroll
+                        for (int q = 0; q < WK_ITEMS; q++) {
+                            const uint32_t c = (uint32_t)__popcll(bal[q]);
+                            if (!found && rem < c) {
+                                cut = wb + wave * (64 * WK_ITEMS) + q * 64 + wk_nth_bit(bal[q], rem) + 1;
+                                found = true;
+                            }
+                            if (!found) rem -= c;
+                        }
+                        if (lane == 0) s_cut = cut;
+                    }
+                    if (first_batch && !use_g) {                                    // one batch: every lane clears what it set
+#pragma unroll
+                        for (int q = 0; q < WK_ITEMS; q++)
+                            if (mine & (1u << q)) bm[v[q] >> 5] = 0;
+                    }
+                    WK_BARRIER();
+                    w = s_cut;
+                    done = true;
+#ifdef MSIM_WALK_PROF
+                    pr_p4 += PR_NOW() - pr_b3;
+#endif
+                } else {
+                    acc_before = avail;
+                    wb += WK_BATCH;
+                    first_batch = false;
+                }
+            }
+            if (over) break;
+            if (!first_batch || use_g) {                                            // several batches: clear the whole bitmap
+                const uint32_t nwords = (n + 31) >> 5;
+                if (HAS_BIG && use_g) { for (uint32_t i = tid; i < nwords; i += WK_THREADS) gbm[i] = 0; __syncthreads(); }
+                else for (uint32_t i = tid; i < nwords; i += WK_THREADS) bm[i] = 0;
+            }
+            WK_BARRIER();                                                           // clears / appends before the next range touches them
+#ifdef MSIM_WALK_PROF
+            pr_set += PR_NOW() - pr_a;
+#endif
+        }
+    }
+    WK_BARRIER();
+    WK_FLUSH();
+#ifdef MSIM_WALK_PROF
+    if (tid == 0 && prof) {
+        atomicAdd(&prof[0], PR_NOW() - pr_t0); atomicAdd(&prof[1], wall_clock64() - pr_w0); atomicAdd(&prof[2], pr_pool);
+        atomicAdd(&prof[3], pr_set); atomicAdd(&prof[4], pr_batches); atomicAdd(&prof[5], pr_nref); atomicAdd(&prof[6], pr_ref);
+        atomicAdd(&prof[7], pr_inner); atomicAdd(&prof[8], (unsigned long long)n_ranges);
+        atomicAdd(&prof[9], pr_p1); atomicAdd(&prof[10], pr_p2); atomicAdd(&prof[11], pr_p3); atomicAdd(&prof[12], pr_p4);
+    }
+#endif
+#undef WK_REFILL
+#undef WK_FLUSH
+#undef WK_LOAD_QUARTER
+    if (tid == 0) {
+        if (over || s_over) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
+        ps->pos = p0 + w;
+        ps->snp_base = p0 + w;
+    }
+}
+
+// unordered list of sampled positions -> bits of the contig-wide bitmap (bulk, off the chain)
+__global__ __launch_bounds__(256) void k_list_to_bits(const uint32_t *__restrict__ list, uint32_t n, uint32_t *__restrict__ bits) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = list[i];
+    atomicOr(&bits[b >> 5], 1u << (b & 31));
+}
+
+// Contig-wide bitmap of (range start + value) -> records, in bulk: global rank by popcount prefix (k_bitmap_count +
+// k_scan_u32 as for the SNP sampler), range of a bit by binary search in the range table, rank inside the range =
+// global rank - rec_base of the range.  Leaves the bitmap zeroed for the next contig that uses this scratch set.
+__global__ __launch_bounds__(BM_THREADS) void k_walk_expand(uint64_t *__restrict__ bm, uint32_t n_words,
+                                                            const uint32_t *__restrict__ block_off,
+                                                            const WalkRange *__restrict__ ranges, uint32_t n_ranges,
+                                                            uint32_t d, msim_record *__restrict__ recs) {
+    __shared__ uint32_t part[BM_THREADS];
+    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+    uint64_t w = i < n_words ? bm[i] : 0;
+    if (w) bm[i] = 0;
+    const uint32_t c = (uint32_t)__popcll(w);
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < BM_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t rank = block_off[blockIdx.x] + part[threadIdx.x] - c;
+    uint32_t r = 0;
+    bool have = false;
+    while (w) {
+        const uint32_t bit = i * 64 + (uint32_t)__builtin_ctzll(w);
+        w &= w - 1;
+        if (!have || (r + 1 < n_ranges && ranges[r + 1].start <= bit)) {            // last range with start <= bit
+            uint32_t lo = 0, hi = n_ranges;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ranges[mid].start <= bit) lo = mid; else hi = mid;
+            }
+            r = lo;
+            have = true;
+        }
+        const uint32_t pos = bit + d * (rank - ranges[r].rec_base);
+        msim_record rec;
+        rec.pos = pos; rec.stop = pos; rec.extra = 0; rec.type = MSIM_SN; rec.aux = 0; rec.rsv = 0;
+        recs[rank] = rec;
+        rank++;
+    }
+}
+
 // single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
 __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
     *mailbox = *ps;

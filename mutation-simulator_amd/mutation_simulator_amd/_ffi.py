@@ -373,6 +373,10 @@ class Engine:
 def comm_unique_id() -> bytes:
     """ncclGetUniqueId as 128 opaque bytes (call on one rank, broadcast over the control plane)."""
     lib = load()
+    # RCCL's bootstrap looks for a network interface; on a box without one (or without name resolution) that can
+    # take a minute.  Inside one node the loopback interface is all it needs.
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
     buf = (C.c_uint8 * 128)()
     rc = lib.msim_comm_unique_id(buf)
     if rc != OK:
