@@ -64,10 +64,10 @@ def test_config2_full_genome_apply_properties():
     eng.close()
 
 
-def _engine_vs_oracle(lengths, extra, tmp_path, seeds=(42, 42)):
+def _engine_vs_oracle(lengths, extra, tmp_path, seeds=(42, 42), sim=None):
     """PLAN + APPLY + text through libmsim vs the oracle's complete Fasta / VCF bytes."""
     import mutation_simulator_amd as msa
-    sim = bench.workload_settings(lengths, extra=extra)
+    sim = sim or bench.workload_settings(lengths, extra=extra)
     contigs = [{"name": f"chr{i+1}", "long_name": f"chr{i+1} synthetic", "lenc": 60,
                 "bases": synth_host(L, 1000 + i)} for i, L in enumerate(lengths)]
     o = orc.Oracle()
@@ -102,6 +102,14 @@ def test_config2_500mb_vs_oracle(tmp_path):
 
 def test_config3_sv_mix_200mb_vs_oracle(tmp_path):
     _engine_vs_oracle([150_000_000, 50_000_000], C3 + ["-sn", "0.005"], tmp_path)
+
+
+def test_config4_rmt_240mb_vs_oracle(tmp_path):
+    """BASELINE configs[3] shape (gene-blocking RMT: ~3 300 drawing ranges incl. hot / cold ranges and pool-path hot
+    spots) at 240 Mb, straight against the ORACLE -- not the host planner: complete Fasta + VCF bytes."""
+    lengths = [150_000_000, 90_000_000]
+    sim = bench.workload_settings_rmt(lengths, bench.c4_rmt_text(lengths))
+    _engine_vs_oracle(lengths, None, tmp_path, sim=sim)
 
 
 def test_config3_full_genome_length_identity():
