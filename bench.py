@@ -73,12 +73,29 @@ def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
     return sim
 
 
+C4_FIXTURE = ROOT / "tests" / "golden" / "c4_blocks.npz"
+
+
 def c4_rmt_text(lengths, seed=4) -> str:
-    """BASELINE configs[3]: a NON-overlapping gene-blocking RMT in the style of the reference's example files
-    (`data/Example RMT files/Homo_sapiens.rmt`: std `sn 0.01`, ~60 k `a-b None` blocks, median 3.6 kb, mean
-    33 kb -- as shipped they overlap and crash the reference), plus hot (`sn 0.05`) and
-    cold (`sn 0.001`) ranges and a few 1 kb `sn 0.2` hot spots that take CPython's pool-path sample.
-    Own deterministic generator (NumPy legacy RandomState); nothing is taken from the reference's files."""
+    """BASELINE configs[3]: a NON-overlapping gene-blocking RMT (std `sn 0.01`, `a-b None` blocks) plus hot (`sn 0.05`)
+    and cold (`sn 0.001`) ranges and 1 kb `sn 0.2` hot spots that take CPython's pool-path sample.
+
+    For the bench genome (lengths == contig_lengths(3e9)) the blocks are the reference's own example after
+    interval-merging (`data/Example RMT files/Homo_sapiens.rmt` as shipped overlaps and crashes the reference,
+    SURVEY.md section 2): the data fixture tests/golden/c4_blocks.npz written by tests/golden/make_c4_blocks.py in the
+    build container (33.9 k ranges, 43-67 % of a contig blocked).  For any other genome (the scaled-down test
+    genomes) or without the fixture: a synthetic file in the same style from this function's own deterministic
+    generator (log-normal block lengths, median 3.6 kb)."""
+    if C4_FIXTURE.exists():
+        z = np.load(C4_FIXTURE)
+        if list(z["lengths"]) == list(lengths):
+            what = ("None", "sn 0.05", "sn 0.001", "sn 0.2")
+            out = ["std", "it None", "sn 0.01", ""]
+            for ci in range(len(lengths)):
+                out.append(f"chr {ci + 1}")
+                for a, e, k in zip(z[f"s{ci}"].tolist(), z[f"e{ci}"].tolist(), z[f"k{ci}"].tolist()):
+                    out.append(f"{a}-{e} {what[k]}")
+            return "\n".join(out) + "\n"
     rs = np.random.RandomState(seed)
     out = ["std", "it None", "sn 0.01", ""]
     for ci, L in enumerate(lengths):

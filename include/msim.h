@@ -135,8 +135,9 @@ int msim_reserve_streams(msim_ctx *ctx, uint64_t py_words, uint64_t np_words);
 /* Upload one contig (upper-cased bases, what pyfaidx hands the reference: util.py:84-88).
  * Contigs are numbered in call order like fasta[i].                                                */
 int msim_add_contig(msim_ctx *ctx, const uint8_t *bases_upper, uint64_t len, int *contig);
-/* Synthesize i.i.d. uniform A/C/G/T directly in HBM: base(i) = "ACGT"[mix64(seed + i) >> 62]
- * (same function in tests/ for cross-checking).  Benchmark input.                  */
+/* Synthesize i.i.d. uniform A/C/G/T directly in HBM, 32 bases per 64-bit hash:
+ *   base(i) = "ACGT"[(mix64(seed + (i >> 5)) >> (2 * (i & 31))) & 3],   mix64 = the splitmix64 finaliser
+ * (k_synth in csrc/apply.hip; host twin synth_host in tests/test_gpu_parity.py).  Benchmark input.          */
 int msim_add_contig_synthetic(msim_ctx *ctx, uint64_t len, uint64_t seed, int *contig);
 int msim_contig_length(msim_ctx *ctx, int contig, uint64_t *len);
 int msim_read_contig(msim_ctx *ctx, int contig, uint64_t offset, uint64_t n, uint8_t *dst);

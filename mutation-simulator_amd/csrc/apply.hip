@@ -6,15 +6,18 @@
 //   1. k_delta_* : per-record length delta -> exclusive scan -> output offset of every record
 //      (the "wavefront scan for the length delta"; three small kernels, records only).
 //   2. k_tile_index : for every 16 KiB output tile the last record starting at or before it.
-//   3. k_rewrite : one workgroup per output tile.  The tile's record window (offset / end / source /
-//      type) is staged in LDS; every lane owns 16 consecutive OUTPUT bytes per iteration, finds its
-//      governing record by binary search in LDS and
-//        - pure copy run      : one 16-B read at the shifted source, one aligned 16-B store
-//        - copy run with SNPs : same, then patches the SNP bytes in registers through an LDS LUT
-//        - anything else      : byte-exact slow path (insert pool, reverse-complement, duplication)
-//      Stores are always full aligned 16-B vectors of the output stream; loads are dword-aligned
-//      dwordx4 + dword with v_alignbyte for the sub-dword shift.  The kernel is HBM-bound: per
-//      output byte it reads one input byte and writes one output byte (+ 20 B per record).
+//   3. k_rewrite<CAP> / k_rewrite_snp : one workgroup per output tile, the tile assembled in LDS and streamed out
+//      with aligned nontemporal 16-B stores.
+//        - k_rewrite_snp (SNP-only tables, offset == position): aligned 16-B loads into the LDS tile, ONE LANE PER
+//          RECORD patches its byte through an LDS LUT.
+//        - k_rewrite<CAP> (indels / SVs): the tile's record window (offset / segment end / run source / type /
+//          segment source, 20 B per record) in LDS; an index table (LDS atomicMax + max-scan) gives every 16-byte
+//          group its governing record; structural (non-SNP) records own pieces -- a segment (insert-pool bytes,
+//          duplication copy, reverse complement, TLI span) and the copy run after it; pass A resolves the piece
+//          covering each group's first byte, pass B one lane per piece that starts inside a group (masked dword
+//          LDS merges), pass B2 one lane per SNP record.  Every piece load is TWO ALIGNED 16-B loads + a byte
+//          funnel (round 2: the byte-shifted 20-B loads of round 1 cost 23 % of the kernel).
+//      The kernels are HBM-bound: per output byte one input byte read, one output byte written (+ 20 B per record).
 //
 // Integer/byte work only -- no MFMA.  Roofline: HBM bandwidth.
 #include <algorithm>

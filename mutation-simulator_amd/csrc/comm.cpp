@@ -160,6 +160,7 @@ int msim_gather_to_root(msim_ctx *p, int n, const int *contig_ids, const int *ow
         for (int i = 0; i < n; i++)
             if (owner[i] != 0) return fail(c, MSIM_ERR_ARG, "msim_gather_to_root before msim_comm_init");
     }
+    TraceRange tr("msim gather to root (RCCL)");
     std::vector<int64_t> ops((size_t)4 * (n ? n : 1));
     int n_ops = 0;
     int rc = msim_gather_plan(n, owner, out_len, rank, world, root, ops.data(), &n_ops);

@@ -78,6 +78,16 @@ struct Ctx {
     size_t cap_text_scratch = 0;
 };
 
+// roctx range (rocprofv3 --marker-trace shows PLAN / APPLY / text / gather per contig).  The marker library is
+// dlopen()ed on first use (librocprofiler-sdk-roctx, else libroctx64); without it the ranges cost one branch.
+struct TraceRange {
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    TraceRange(const TraceRange &) = delete;
+    TraceRange &operator=(const TraceRange &) = delete;
+    bool on;
+};
+
 int fail(Ctx *c, int code, const std::string &msg);
 int hip_fail(Ctx *c, hipError_t e, const char *what);
 

@@ -5,12 +5,38 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
+
 #include "ctx.h"
 #include "plan_gpu.h"
 
 namespace msim {
 
 static thread_local std::string g_create_error;
+
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"}) {
+            void *h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            *reinterpret_cast<void **>(&push) = dlsym(h, "roctxRangePushA");
+            *reinterpret_cast<void **>(&pop) = dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+Roctx &roctx() { static Roctx r; return r; }
+}  // namespace
+
+TraceRange::TraceRange(const char *name) : on(false) {
+    Roctx &r = roctx();
+    if (r.push) { (void)r.push(name); on = true; }
+}
+TraceRange::~TraceRange() { if (on) (void)roctx().pop(); }
 
 int fail(Ctx *c, int code, const std::string &msg) {
     if (c) c->err = msg; else g_create_error = msg;
@@ -30,6 +56,7 @@ uint8_t *ctx_lut(Ctx *c) { return dev_of(c)->d_lut; }
 // stream position, APPLY timings + KeyError words.  Returns the sampler's error, if any.
 static int drain(Ctx *c) {
     if (c->host_only) return MSIM_OK;
+    TraceRange tr("msim drain (collect deferred results)");
     int rc = c->gpu ? gpu_plan_finish(c, c->gpu) : MSIM_OK;
     int rc2 = apply_finish(c);
     if (rc) return rc;
@@ -373,6 +400,7 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     if (!g) return MSIM_ERR_ARG;
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
     int rc = MSIM_OK;
+    TraceRange tr("msim PLAN contig");
     reset_contig(*g);
     c->text_kind = 0;
     const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
@@ -451,6 +479,7 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     if (!g) return MSIM_ERR_ARG;
     NEED_GPU(c);
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "msim_apply_contig before msim_plan_contig");
+    TraceRange tr("msim APPLY contig");
     c->text_kind = 0;
     return apply_contig_device(c, *g);
 }
@@ -601,6 +630,7 @@ int msim_render_vcf_device(msim_ctx *p, int contig, const char *seq_name, char *
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    TraceRange tr("msim text: VCF lines");
     if (!(out && c->text_kind == 1 && c->text_contig == contig)) {      // not cached by a preceding size call
         int rc = drain(c);                                               // record aux bytes come from the emit stream
         if (rc) return rc;
@@ -621,6 +651,7 @@ int msim_fetch_sequence_framed(msim_ctx *p, int contig, uint32_t bpl, uint8_t *o
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    TraceRange tr("msim text: framed FASTA");
     if (!(out && c->text_kind == 2 && c->text_contig == contig && c->text_bpl == bpl)) {
         int rc = drain(c);
         if (rc) return rc;
@@ -646,6 +677,7 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
         const uint64_t last = (n_bases - 1) / lenc * lenb + (n_bases - 1) % lenc;    // offset of the last base
         if (last >= body_bytes) return fail(c, MSIM_ERR_ARG, "FASTA body shorter than n_bases at this line width");
     }
+    TraceRange tr("msim text: FASTA ingest");
     Contig *g;
     int rc = new_contig(c, n_bases, &g);
     if (rc) return rc;
