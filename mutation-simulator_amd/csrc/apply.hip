@@ -888,10 +888,19 @@ extern uint8_t *ctx_lut(Ctx *c);
 
 int apply_finish(Ctx *c) {
     if (c->pending_apply.empty()) return MSIM_OK;
+    // KeyError words + length-check words of every contig: two asynchronous copies into pinned memory behind the
+    // APPLY work, one synchronisation (two blocking hipMemcpy cost ~40 us each at every step boundary)
+    const size_t nc = c->contigs.size();
+    if (c->cap_h_errs < 2 * nc) {
+        if (c->h_errs) MSIM_HIP(c, hipHostFree(c->h_errs));
+        c->h_errs = nullptr; c->cap_h_errs = 0;
+        MSIM_HIP(c, hipHostMalloc(&c->h_errs, (2 * nc + 64) * sizeof(unsigned long long), hipHostMallocDefault));
+        c->cap_h_errs = 2 * nc + 64;
+    }
+    unsigned long long *errs = c->h_errs, *deltas = c->h_errs + nc;
+    MSIM_HIP(c, hipMemcpyAsync(errs, c->d_errs, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->emit_stream));
+    MSIM_HIP(c, hipMemcpyAsync(deltas, c->d_errs + MAX_CONTIGS, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->emit_stream));
     MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-    std::vector<unsigned long long> errs(c->contigs.size()), deltas(c->contigs.size());
-    MSIM_HIP(c, hipMemcpy(errs.data(), c->d_errs, errs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    MSIM_HIP(c, hipMemcpy(deltas.data(), c->d_errs + MAX_CONTIGS, deltas.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     bool delta_mismatch = false;
     for (int idx : c->pending_apply) {
         if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;

@@ -67,6 +67,8 @@ struct Ctx {
     size_t scratch_bytes = 0;
     unsigned long long *h_mail = nullptr;   // pinned, device-visible mailbox for small results
     unsigned long long *d_errs = nullptr;   // one KeyError word per contig
+    unsigned long long *h_errs = nullptr;   // pinned copy of them (apply_finish)
+    size_t cap_h_errs = 0;
     std::vector<int> pending_apply;
     // text on the device (text_gpu.hip): rendered VCF lines / framed FASTA body / raw FASTA body staging
     uint8_t *d_text = nullptr;

@@ -234,6 +234,7 @@ void msim_destroy(msim_ctx *p) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
     if (c->d_errs) (void)hipFree(c->d_errs);
+    if (c->h_errs) (void)hipHostFree(c->h_errs);
     if (c->d_text) (void)hipFree(c->d_text);
     if (c->d_text_scratch) (void)hipFree(c->d_text_scratch);
     comm_destroy(c);
@@ -713,6 +714,13 @@ int msim_dbg_chain_boundary(msim_ctx *p, const msim_range *r, uint64_t L, const 
     const int rc = chain_boundary_host(c, *r, L, pos, type, (size_t)n, words, (size_t)n_words, stop, &used, &nk, &delta);
     *consumed = used; *kept = nk; *len_delta = delta;
     return rc;
+}
+
+int msim_dbg_stream_status(msim_ctx *p, int out[8]) {
+    Ctx *c = C(p);
+    if (!c || !out || c->host_only || !c->gpu) return MSIM_ERR_ARG;
+    gpu_plan_stream_status(c, c->gpu, out);
+    return MSIM_OK;
 }
 
 int msim_stats(msim_ctx *p, msim_timing *out) {

@@ -27,6 +27,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
 bool gpu_plan_hostsample_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 
+void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]);
 // the same contigs with the chain of samples walked by one workgroup on the device (k_sample_walk): fully asynchronous
 bool gpu_plan_walk_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu_walk(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "ctx.h"
@@ -101,6 +102,8 @@ struct GpuPlan {
     uint8_t *h_ntype = nullptr; size_t cap_h_ntype = 0;
     uint32_t *h_nstop = nullptr; size_t cap_h_nstop = 0;
     uint32_t *walk_gbm = nullptr; size_t cap_walk_gbm = 0; // k_sample_walk: zeroed bitmap for ranges beyond its LDS bitmap
+    uint32_t *h_seed = nullptr;         // pinned staging of the two host generator states (reseed without a stream sync)
+    hipEvent_t seed_ev[2] = {nullptr, nullptr};   //   recorded behind the copies that read a slot
     hipStream_t gen_stream = nullptr;   // chunk generation (latency-bound, ~300 us per batch)
     hipStream_t jump_stream = nullptr;  // jump cascade: never waits for a generation batch
     std::vector<hipEvent_t> ev_pool;
@@ -174,6 +177,8 @@ void gpu_plan_destroy(GpuPlan *g) {
     if (g->t0) (void)hipEventDestroy(g->t0);
     if (g->t1) (void)hipEventDestroy(g->t1);
     if (g->walk_gbm) (void)hipFree(g->walk_gbm);
+    if (g->h_seed) (void)hipHostFree(g->h_seed);
+    for (auto e : g->seed_ev) if (e) (void)hipEventDestroy(e);
     if (g->d_poly) (void)hipFree(g->d_poly);
     if (g->d_ps) (void)hipFree(g->d_ps);
     if (g->h_mail) (void)hipHostFree(g->h_mail);
@@ -189,6 +194,21 @@ void gpu_plan_invalidate(GpuPlan *g) {
 }
 void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words) { g->reserve_words[0] = py_words; g->reserve_words[1] = np_words; }
 
+// Side streams of the stream machinery: the jump cascade and chunk generation run beside the plan chain.
+static int ensure_side_streams(Ctx *c, GpuPlan *g) {
+    if (g->gen_stream) return MSIM_OK;
+    // distinct priorities -> distinct hardware queues (streams of one priority may share a queue and
+    // then serialise): the cascade must not queue behind a generation batch
+    int lo = 0, hi = 0;
+    MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    (void)hi;
+    // bulk side work at the LOWEST priority: its workgroups (123 KB of LDS each for a jump) must not crowd out
+    // the chain kernels of the first contigs, which already wait for nothing but free CU resources
+    MSIM_HIP(c, hipStreamCreateWithPriority(&g->gen_stream, hipStreamNonBlocking, lo));
+    MSIM_HIP(c, hipStreamCreateWithPriority(&g->jump_stream, hipStreamNonBlocking, lo));
+    return MSIM_OK;
+}
+
 // Make x[0 .. upto) available to kernels on the PLAN stream.  Jumps and chunk generation are
 // enqueued on the generation stream, level by level (after cascade level r the states of chunks
 // < 2^(r+1) exist and those chunks can be generated), each batch followed by an event; the plan
@@ -197,16 +217,9 @@ void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words) { g->res
 // contigs instead of preceding it.
 static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
     GpuStream &s = g->s[si];
-    if (!g->gen_stream) {
-        // distinct priorities -> distinct hardware queues (streams of one priority may share a queue and
-        // then serialise): the cascade must not queue behind a 300 us generation batch
-        int lo = 0, hi = 0;
-        MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        (void)hi;
-        // bulk side work at the LOWEST priority: its workgroups (88 KB of LDS each for a jump) must not crowd out
-        // the chain kernels of the first contigs, which already wait for nothing but free CU resources
-        MSIM_HIP(c, hipStreamCreateWithPriority(&g->gen_stream, hipStreamNonBlocking, lo));
-        MSIM_HIP(c, hipStreamCreateWithPriority(&g->jump_stream, hipStreamNonBlocking, lo));
+    {
+        int rc0 = ensure_side_streams(c, g);
+        if (rc0) return rc0;
     }
     const uint64_t have = MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS;
     if (upto > have) {
@@ -346,11 +359,25 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
         MSIM_HIP(c, hipMalloc(&s.d_raw, (size_t)MT_N * sizeof(uint32_t)));
         s.cap = MT_N;
     }
-    if (g->jump_stream) MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));  // nothing of the old session in flight
-    if (g->gen_stream) MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
-    MSIM_HIP(c, hipMemcpyAsync(s.d_states, h.mt, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
-    MSIM_HIP(c, hipMemcpyAsync(s.d_raw, h.mt, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));       // h.mt may change right after
+    {
+        int rc0 = ensure_side_streams(c, g);
+        if (rc0) return rc0;
+    }
+    MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));     // nothing of the old session in flight
+    MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
+    // the state goes through a pinned staging slot (one per stream), so the copies need no host synchronisation:
+    // h.mt may change right after; the slot is rewritten only once the copies that read it are known to be done,
+    // and the side streams are ordered behind the copies by the same event
+    if (!g->h_seed) MSIM_HIP(c, hipHostMalloc(&g->h_seed, 2 * sizeof h.mt, hipHostMallocDefault));
+    if (!g->seed_ev[si]) MSIM_HIP(c, hipEventCreateWithFlags(&g->seed_ev[si], hipEventDisableTiming));
+    else MSIM_HIP(c, hipEventSynchronize(g->seed_ev[si]));
+    uint32_t *slot = g->h_seed + (size_t)si * MT_N;
+    memcpy(slot, h.mt, sizeof h.mt);
+    MSIM_HIP(c, hipMemcpyAsync(s.d_states, slot, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipMemcpyAsync(s.d_raw, slot, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipEventRecord(g->seed_ev[si], c->stream));
+    MSIM_HIP(c, hipStreamWaitEvent(g->jump_stream, g->seed_ev[si], 0));
+    MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, g->seed_ev[si], 0));
     for (auto e : s.ready_ev) g->ev_pool.push_back(e);
     s.ready_ev.clear();
     s.ready_hi.clear();
@@ -1069,6 +1096,13 @@ static unsigned long long *walk_prof() {
 #else
     return nullptr;
 #endif
+}
+
+// test hook: which of the context's streams still have work queued (hipStreamQuery; never blocks)
+void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]) {
+    auto q = [](hipStream_t s) { if (!s) return -1; const hipError_t e = hipStreamQuery(s); (void)hipGetLastError(); return e == hipSuccess ? 0 : e == hipErrorNotReady ? 1 : 2; };
+    out[0] = q(c->stream); out[1] = q(c->emit_stream); out[2] = q(g->gen_stream); out[3] = q(g->jump_stream);
+    out[4] = (int)g->s[0].n_chunks; out[5] = (int)g->s[0].n_states; out[6] = (int)g->s[0].ready_ev.size(); out[7] = (int)g->s[0].waited_chunks;
 }
 
 bool gpu_plan_walk_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {

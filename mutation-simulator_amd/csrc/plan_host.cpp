@@ -15,9 +15,99 @@
 
 #include "ctx.h"
 
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define MSIM_X86_HOST 1
+#endif
+
 namespace msim {
 
 namespace {
+
+// _randbelow() over a word window, in bulk: append to buf the next `need` ACCEPTED draws (word >> sh < n) starting at
+// word w and return the index one past the word that held the last of them (SIZE_MAX: the window ran out).  Exactly
+// what `need` calls of _randbelow_with_getrandbits consume.  The AVX-512 clone filters 16 words per step
+// (shift, compare, compress-store); the chain only meets the accepted values afterwards.
+inline size_t collect_accepted_scalar(const uint32_t *words, size_t w, size_t n_words, int sh, uint32_t n, size_t need,
+                                      uint32_t *buf) {
+    size_t got = 0;
+    while (got < need) {
+        if (w >= n_words) return SIZE_MAX;
+        const uint32_t v = words[w++] >> sh;
+        buf[got] = v;
+        got += v < n;
+    }
+    return w;
+}
+#ifdef MSIM_X86_HOST
+__attribute__((target("avx512f,bmi2,popcnt"))) size_t collect_accepted_avx512(const uint32_t *words, size_t w, size_t n_words,
+                                                                               int sh, uint32_t n, size_t need, uint32_t *buf) {
+    size_t got = 0;
+    const __m512i nv = _mm512_set1_epi32((int)n);
+    const __m128i shv = _mm_cvtsi32_si128(sh);
+    while (got < need && w + 16 <= n_words) {
+        const __m512i v = _mm512_srl_epi32(_mm512_loadu_si512(words + w), shv);
+        const __mmask16 m = _mm512_cmplt_epu32_mask(v, nv);
+        const unsigned c = (unsigned)__builtin_popcount(m);
+        if (got + c < need) {
+            _mm512_mask_compressstoreu_epi32(buf + got, m, v);
+            got += c;
+            w += 16;
+        } else {                                         // the need-th accepted draw is in this block: cut there
+            const unsigned r = (unsigned)(need - got);   // 1 <= r <= c
+            const unsigned pos = (unsigned)__builtin_ctz(_pdep_u32(1u << (r - 1), (unsigned)m));
+            const __mmask16 m2 = (__mmask16)(m & ((2u << pos) - 1u));
+            _mm512_mask_compressstoreu_epi32(buf + got, m2, v);
+            return w + pos + 1;
+        }
+    }
+    while (got < need) {                                 // tail of the window
+        if (w >= n_words) return SIZE_MAX;
+        const uint32_t v = words[w++] >> sh;
+        buf[got] = v;
+        got += v < n;
+    }
+    return w;
+}
+#endif
+// f(wi) for every non-zero 64-bit word of B[0 .. nw), ascending (B may be modified by f at wi only)
+template <class F>
+inline void nonzero_words_scalar(const uint64_t *B, size_t nw, F &f) {
+    for (size_t wi = 0; wi < nw; wi++)
+        if (B[wi]) f(wi);
+}
+#ifdef MSIM_X86_HOST
+template <class F>
+__attribute__((target("avx512f"))) void nonzero_words_avx512(const uint64_t *B, size_t nw, F &f) {
+    size_t wi = 0;
+    for (; wi + 8 <= nw; wi += 8) {
+        const __m512i v = _mm512_loadu_si512(B + wi);
+        unsigned m = (unsigned)_mm512_test_epi64_mask(v, v);
+        while (m) {
+            f(wi + (size_t)__builtin_ctz(m));
+            m &= m - 1;
+        }
+    }
+    for (; wi < nw; wi++)
+        if (B[wi]) f(wi);
+}
+#endif
+template <class F>
+inline void for_each_nonzero_word(const uint64_t *B, size_t nw, F &f) {
+#ifdef MSIM_X86_HOST
+    static const bool wide = __builtin_cpu_supports("avx512f");
+    if (wide) { nonzero_words_avx512(B, nw, f); return; }
+#endif
+    nonzero_words_scalar(B, nw, f);
+}
+
+inline size_t collect_accepted(const uint32_t *words, size_t w, size_t n_words, int sh, uint32_t n, size_t need, uint32_t *buf) {
+#ifdef MSIM_X86_HOST
+    static const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("bmi2");
+    if (wide) return collect_accepted_avx512(words, w, n_words, sh, n, need, buf);
+#endif
+    return collect_accepted_scalar(words, w, n_words, sh, n, need, buf);
+}
 
 struct Cand { int64_t pos; int32_t type; int64_t stop; int64_t src = 0; bool rev = false, linked = false; };
 
@@ -168,8 +258,9 @@ int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d
                        size_t n_words, uint32_t *pos_out, size_t *consumed) {
     const auto t0 = std::chrono::steady_clock::now();
     size_t w = 0, at = 0;
-    static thread_local std::vector<uint64_t> bits, summ;           // cleared while they are scanned
+    static thread_local std::vector<uint64_t> bits;                 // cleared while it is scanned
     std::vector<uint32_t> pool, picked;
+    static thread_local std::vector<uint32_t> accbuf;                // accepted draws of one round
     auto overflow = [&]() {
         std::fill(bits.begin(), bits.end(), 0);                       // keep the scratch bitmap clean for the next call
         return fail(c, MSIM_ERR_HIP, "host sampler: word window overflowed its margin");
@@ -203,52 +294,50 @@ int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d
         if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
         uint64_t *B = bits.data();
         int64_t got = 0;
-        if (nw <= 4096) {
-            // Bitmap in L1/L2.  Both data-dependent branches of the obvious loop (draw rejected? word of the
-            // bitmap empty?) mispredict about every second time, so: rejected draws are OR-ed into a dummy word
-            // instead of skipped, a summary bitmap (one bit per bitmap word) is kept while inserting, and the
-            // extraction visits only the non-empty words, writing three slots unconditionally.
-            const size_t ns = (nw + 63) / 64, dummy = nw;
-            if (summ.size() < ns + 1) summ.resize(ns + 1, 0);
-            uint64_t *S = summ.data();
+        if (nw <= 131072) {
+            // Bitmap in L1/L2 (up to 1 MB).  The data-dependent branches of the obvious loop (draw rejected? bitmap
+            // word empty?) mispredict about every second time, so the loop is split: accepted draws are collected
+            // in bulk without branches, inserted without branches, and the extraction finds the non-empty words
+            // eight at a time (AVX-512 test), writing three slots unconditionally per word.
             const uint32_t nn = (uint32_t)n;
+            // Rounds (the rule of the device sampler's tail): the next k - got accepted draws are consumed in any
+            // case -- each adds at most one distinct value -- so they are collected in bulk (vectorised filter) and
+            // only then meet the bitmap; the stream position stays exact.
+            if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + 32);
+            uint32_t *buf = accbuf.data();
             while (got < k) {
-                if (w >= n_words) { std::fill(summ.begin(), summ.end(), 0); return overflow(); }
-                const uint32_t v = words[w++] >> sh;
-                const bool ok = v < nn;
-                const size_t wi = ok ? (size_t)(v >> 6) : dummy;
-                const uint64_t m = (uint64_t)ok << (v & 63);
-                const uint64_t x = B[wi];
-                got += (int64_t)(ok & !(x & m));
-                B[wi] = x | m;
-                S[wi >> 6] |= 1ull << (wi & 63);
+                const size_t need = (size_t)(k - got);
+                const size_t w2 = collect_accepted(words, w, n_words, sh, nn, need, buf);
+                if (w2 == SIZE_MAX) return overflow();
+                w = w2;
+                for (size_t i = 0; i < need; i++) {
+                    const uint32_t v = buf[i];
+                    const size_t wi = v >> 6;
+                    const uint64_t m = 1ull << (v & 63);
+                    const uint64_t x = B[wi];
+                    got += (int64_t)!(x & m);
+                    B[wi] = x | m;
+                }
             }
-            B[dummy] = 0;
             uint32_t rank = 0;
-            for (size_t si = 0; si <= ns; si++) {                     // (the dummy's summary bit may sit in word ns)
-                uint64_t sm = S[si];
-                if (!sm) continue;
-                S[si] = 0;
-                do {
-                    const size_t wi = si * 64 + (size_t)__builtin_ctzll(sm);
-                    sm &= sm - 1;
-                    uint64_t x = B[wi];
-                    B[wi] = 0;
-                    const uint32_t cn = (uint32_t)__builtin_popcountll(x);
-                    const uint32_t p0 = base + (uint32_t)(wi * 64) + dd * rank;
-                    if (__builtin_expect(cn <= 3, 1)) {               // slots beyond cn are overwritten by the next word
-                        const uint64_t x1 = x & (x - 1), x2 = x1 & (x1 - 1), top = 1ull << 63;
-                        pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x | top);
-                        pos_out[at + 1] = p0 + dd + (uint32_t)__builtin_ctzll(x1 | top);
-                        pos_out[at + 2] = p0 + 2 * dd + (uint32_t)__builtin_ctzll(x2 | top);
-                    } else {
-                        uint32_t q = 0;
-                        while (x) { pos_out[at + q] = p0 + dd * q + (uint32_t)__builtin_ctzll(x); q++; x &= x - 1; }
-                    }
-                    at += cn;
-                    rank += cn;
-                } while (sm);
-            }
+            auto emit_word = [&](size_t wi) {
+                uint64_t x = B[wi];
+                B[wi] = 0;
+                const uint32_t cn = (uint32_t)__builtin_popcountll(x);
+                const uint32_t p0 = base + (uint32_t)(wi * 64) + dd * rank;
+                if (__builtin_expect(cn <= 3, 1)) {                   // slots beyond cn are overwritten by the next word
+                    const uint64_t x1 = x & (x - 1), x2 = x1 & (x1 - 1), top = 1ull << 63;
+                    pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x | top);
+                    pos_out[at + 1] = p0 + dd + (uint32_t)__builtin_ctzll(x1 | top);
+                    pos_out[at + 2] = p0 + 2 * dd + (uint32_t)__builtin_ctzll(x2 | top);
+                } else {
+                    uint32_t q = 0;
+                    while (x) { pos_out[at + q] = p0 + dd * q + (uint32_t)__builtin_ctzll(x); q++; x &= x - 1; }
+                }
+                at += cn;
+                rank += cn;
+            };
+            for_each_nonzero_word(B, nw, emit_word);
             continue;
         }
         {                                                            // large bitmap: batch + prefetch (see sample_sorted)
