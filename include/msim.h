@@ -203,6 +203,24 @@ int msim_fetch_sequence_framed(msim_ctx *ctx, int contig, uint32_t bpl, uint8_t 
 int msim_add_contig_text(msim_ctx *ctx, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases,
                          uint32_t lenc, uint32_t lenb, int *contig);
 
+/* ---- many small contigs in one pass ------------------------------------------------------------------------------- */
+/* mutate()'s loop body (mutator.py:111-141) for a run of SMALL contigs at once -- assemblies with thousands of scaffolds:
+ * per contig the file text of the record (as for msim_add_contig_text), its ranges and its name.  The RNG streams are
+ * consumed contig by contig exactly as by msim_plan_contig; ONE APPLY runs over the concatenation; the host frames the
+ * FASTA bodies (fasta_writer.py:40-58) and renders the VCF lines (vcf_writer.py:118-126).  Results stay in the context
+ * until the next batch.  MSIM_ERR_KEY: msim_batch_key_contig tells which contig hit the reference's KeyError.        */
+typedef struct msim_batch_contig {
+    const uint8_t *body; uint64_t body_bytes; uint64_t n_bases; uint32_t lenc, lenb;   /* as msim_add_contig_text     */
+    const msim_range *ranges; int32_t n_ranges;                                        /* as msim_plan_contig         */
+    const char *name;                                                                  /* CHROM of its VCF lines      */
+} msim_batch_contig;
+int msim_batch_run(msim_ctx *ctx, const msim_batch_contig *contigs, int n);
+/* per contig: bytes of its framed FASTA body, bytes of its VCF lines, plan-was-empty flag (mutator.py:125-129), records */
+int msim_batch_sizes(msim_ctx *ctx, int n, uint64_t *fasta_bytes, uint64_t *vcf_bytes, int32_t *empty, uint64_t *n_records);
+/* the framed bodies / the VCF lines of all contigs of the batch, back to back in contig order (either may be NULL)       */
+int msim_batch_fetch(msim_ctx *ctx, uint8_t *fasta_text, uint64_t fasta_cap, char *vcf_text, uint64_t vcf_cap);
+int msim_batch_key_contig(msim_ctx *ctx, int *contig);
+
 /* ---- multi-GPU: one process per GPU, contigs' APPLY sharded, gather over RCCL ------------------ */
 /* mutate()'s contig loop (mutator.py:111-141) is the unit of sharding: PLAN is replayed on every rank (the two
  * MT19937 streams chain across contigs), each rank APPLYs the contigs it owns, and the one exchange step is the

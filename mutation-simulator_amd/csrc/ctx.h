@@ -45,6 +45,7 @@ constexpr uint64_t PAD = 64;          // slack after every byte buffer so 16-B v
 
 struct GpuPlan;
 struct Comm;                          // comm.cpp: RCCL communicator + receive buffers of the gather
+struct Batch;                         // msim_api.hip: state of msim_batch_run
 
 struct Ctx {
     int device = 0;
@@ -58,6 +59,7 @@ struct Ctx {
     HostMT py, np;                    // stream states, host representation
     GpuPlan *gpu = nullptr;           // device representation of the streams + sampler scratch
     Comm *comm = nullptr;             // multi-GPU: set by msim_comm_init
+    Batch *batch = nullptr;           // last batch of small contigs (host buffers)
     msim_params params{};
     bool have_params = false;
     std::vector<Contig> contigs;
@@ -129,6 +131,10 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);
 int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes);
 int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
                         uint32_t lenb, uint8_t *d_dst);
+
+// render.cpp
+uint64_t render_vcf_unchecked(const msim_record *recs, uint64_t n_records, const uint8_t *insert_pool, const uint8_t *bases,
+                              uint64_t len, const char *seq_name, char *out);
 
 // comm.cpp
 void comm_destroy(Ctx *c);

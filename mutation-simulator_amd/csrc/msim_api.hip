@@ -46,6 +46,9 @@ int hip_fail(Ctx *c, hipError_t e, const char *what) {
     return fail(c, MSIM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 
+struct Batch;
+static void batch_free(Ctx *c);
+
 struct CtxDev {            // small device-side constants owned by the ctx
     uint8_t *d_lut = nullptr;
 };
@@ -237,6 +240,7 @@ void msim_destroy(msim_ctx *p) {
     if (c->h_errs) (void)hipHostFree(c->h_errs);
     if (c->d_text) (void)hipFree(c->d_text);
     if (c->d_text_scratch) (void)hipFree(c->d_text_scratch);
+    batch_free(c);
     comm_destroy(c);
     gpu_plan_destroy(c->gpu);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
@@ -742,6 +746,284 @@ int msim_reset_stats(msim_ctx *p) {
         if (rc) return rc;
     }
     c->t = msim_timing{};
+    return MSIM_OK;
+}
+
+}  // extern "C"
+
+// ---- batch of small contigs ----------------------------------------------------------------------------------------
+// An assembly with thousands of scaffolds pays a fixed ~0.35 ms of HIP API work per contig on the per-contig path
+// (allocations, ~40 runtime calls, two or three synchronising fetches): 20 000 scaffolds of 10 kb ran at 27 Mbases/s.
+// Here mutate()'s loop body (mutator.py:111-141) runs for MANY small contigs in one pass: the host strips the FASTA
+// text and walks the RNG chain contig by contig (plan_contig_host -- these contigs are below every device engine's
+// threshold anyway), the record tables are concatenated with their positions shifted to the contig's place in ONE
+// super-contig, the GPU runs ONE APPLY over it (records never cross a contig border, so the rewrite kernels need no
+// change), and the host frames the mutated stream per contig and renders the VCF lines (msim_render_vcf).
+namespace msim {
+
+struct Batch {
+    struct Item { uint64_t base = 0, len = 0, out_start = 0, out_len = 0, rec0 = 0, nrec = 0, pool0 = 0, npool = 0, text0 = 0, ntext = 0,
+                  vcf0 = 0, nvcf = 0; uint32_t bpl = 0; bool empty = true; };
+    std::vector<Item> items;
+    std::vector<msim_record> recs_rel;       // per-contig coordinates (what the VCF renderer reads)
+    std::vector<uint8_t> pool;
+    uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned
+    size_t cap_in = 0, cap_out = 0;
+    std::vector<uint8_t> fasta;
+    std::string vcf;
+    int key_contig = -1;
+};
+
+static void batch_free(Ctx *c) {
+    if (!c->batch) return;
+    if (c->batch->h_in) (void)hipHostFree(c->batch->h_in);
+    if (c->batch->h_out) (void)hipHostFree(c->batch->h_out);
+    delete c->batch;
+    c->batch = nullptr;
+}
+
+static int pinned_reserve(Ctx *c, uint8_t **p, size_t *cap, size_t want) {
+    if (*cap >= want) return MSIM_OK;
+    if (*p) MSIM_HIP(c, hipHostFree(*p));
+    *p = nullptr; *cap = 0;
+    const size_t sz = want + want / 4 + 4096;
+    MSIM_HIP(c, hipHostMalloc(p, sz, hipHostMallocDefault));
+    *cap = sz;
+    return MSIM_OK;
+}
+
+// output length change of one record (apply.hip: rec_lengths)
+static long long rec_delta(const msim_record &r) {
+    const long long len = (long long)r.stop - (long long)r.pos + 1;
+    switch (r.type) {
+        case MSIM_IN: return len;
+        case MSIM_DE: case MSIM_TL: return -len;
+        case MSIM_DU: return len;
+        case MSIM_TLI: return r.stop + 1 > r.extra ? (long long)r.stop + 1 - (long long)r.extra : 0;
+        default: return 0;
+    }
+}
+
+}  // namespace msim
+
+extern "C" {
+
+int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
+    Ctx *c = C(p);
+    if (!c || !contigs || n < 1) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
+    TraceRange tr("msim batch of small contigs");
+    static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_0 = now();
+    int rc = drain(c);
+    if (rc) return rc;
+    if (c->gpu) {                                          // the host planner continues from wherever the device streams stand
+        rc = gpu_plan_sync_to_host(c, c->gpu);
+        if (rc) return rc;
+    }
+    if (!c->batch) c->batch = new Batch();
+    Batch &B = *c->batch;
+    B.items.assign((size_t)n, Batch::Item());
+    B.recs_rel.clear(); B.pool.clear(); B.fasta.clear(); B.vcf.clear();
+    B.key_contig = -1;
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        const msim_batch_contig &q = contigs[i];
+        if ((!q.body && q.n_bases) || (q.n_ranges && !q.ranges) || q.n_ranges < 0 || !q.name) return fail(c, MSIM_ERR_ARG, "msim_batch_run: bad contig");
+        if (q.n_bases) {
+            if (q.lenc == 0 || q.lenb < q.lenc) return fail(c, MSIM_ERR_ARG, "line width / line stride of the FASTA body are inconsistent");
+            const uint64_t last = (q.n_bases - 1) / q.lenc * q.lenb + (q.n_bases - 1) % q.lenc;
+            if (last >= q.body_bytes) return fail(c, MSIM_ERR_ARG, "FASTA body shorter than n_bases at this line width");
+        }
+        B.items[(size_t)i].base = total;
+        B.items[(size_t)i].len = q.n_bases;
+        B.items[(size_t)i].bpl = q.lenc;
+        total += q.n_bases;
+    }
+    if (total >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "batch of 2 GiB or more: split it");
+    // ---- 1. FASTA text -> upper-cased bases (pyfaidx's sequence_always_upper, util.py:84-88), on the host
+    rc = pinned_reserve(c, &B.h_in, &B.cap_in, total + 64);
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+        const msim_batch_contig &q = contigs[i];
+        uint8_t *dst = B.h_in + B.items[(size_t)i].base;
+        uint64_t done = 0;
+        const uint8_t *src = q.body;
+        while (done < q.n_bases) {
+            const uint64_t take = std::min<uint64_t>(q.lenc, q.n_bases - done);
+            memcpy(dst + done, src, take);
+            done += take;
+            src += q.lenb;
+        }
+        for (uint64_t k = 0; k < q.n_bases; k++) {           // (auto-vectorised)
+            const uint8_t b = dst[k];
+            dst[k] = (uint8_t)(b - ((b >= 'a' && b <= 'z') ? 32 : 0));
+        }
+    }
+    const auto t_1 = now();
+    // ---- 2. PLAN: the RNG chain, contig by contig (mutator.py:111-131 + the draws of :334-358)
+    std::vector<msim_record> recs_abs;
+    long long delta_total = 0;
+    bool all_snp = true;
+    HostPlan hp;
+    for (int i = 0; i < n; i++) {
+        const msim_batch_contig &q = contigs[i];
+        Batch::Item &it = B.items[(size_t)i];
+        const uint64_t w_py = c->py.words, w_np = c->np.words;
+        rc = plan_contig_host(c, q.n_bases, q.ranges, q.n_ranges, hp);
+        if (rc) return rc;
+        c->t.py_words += c->py.words - w_py;
+        c->t.np_words += c->np.words - w_np;
+        it.empty = hp.empty;
+        it.rec0 = B.recs_rel.size(); it.nrec = hp.recs.size();
+        it.pool0 = B.pool.size(); it.npool = hp.pool.size();
+        long long delta = 0;
+        for (const msim_record &r : hp.recs) {
+            delta += rec_delta(r);
+            msim_record a = r;
+            a.pos += (uint32_t)it.base;
+            a.stop += (uint32_t)it.base;
+            if (r.type == MSIM_IN) a.extra += (uint32_t)it.pool0;
+            else if (r.type == MSIM_TLI) a.extra += (uint32_t)it.base;
+            if (r.type != MSIM_SN) all_snp = false;
+            recs_abs.push_back(a);
+        }
+        B.recs_rel.insert(B.recs_rel.end(), hp.recs.begin(), hp.recs.end());
+        B.pool.insert(B.pool.end(), hp.pool.begin(), hp.pool.end());
+        it.out_start = (uint64_t)((long long)it.base + delta_total);
+        it.out_len = (uint64_t)((long long)it.len + delta);
+        delta_total += delta;
+    }
+    if (B.pool.size() >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "batch insert pool of 2 GiB or more: split it");
+    const uint64_t out_total = (uint64_t)((long long)total + delta_total);
+    const auto t_2 = now();
+    // ---- 3. ONE APPLY over the super-contig
+    Contig *g;
+    rc = new_contig(c, total, &g);
+    if (rc) return rc;
+    const int gid = (int)c->contigs.size() - 1;
+    auto drop = [&]() { (void)free_contig(c, c->contigs[(size_t)gid], false); c->contigs.pop_back(); };
+    if (total) MSIM_HIP(c, hipMemcpyAsync(g->d_in + PAD, B.h_in, total, hipMemcpyHostToDevice, c->stream));
+    g->n_rec = recs_abs.size();
+    g->pool_len = B.pool.size();
+    g->plan_empty = recs_abs.empty();
+    g->all_snp = all_snp;
+    g->delta_known = true;
+    g->known_delta = delta_total;
+    if (g->n_rec) {
+        rc = dev_reserve(c, (void **)&g->d_recs, &g->cap_recs, g->n_rec * sizeof(msim_record));
+        if (rc) { drop(); return rc; }
+        MSIM_HIP(c, hipMemcpyAsync(g->d_recs, recs_abs.data(), g->n_rec * sizeof(msim_record), hipMemcpyHostToDevice, c->stream));
+    }
+    rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + 2 * PAD);
+    if (rc) { drop(); return rc; }
+    if (g->pool_len) MSIM_HIP(c, hipMemcpyAsync(g->d_pool + PAD, B.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));          // (the uploads read pageable vectors; APPLY runs on the emit stream)
+    g->planned = true;
+    rc = apply_contig_device(c, *g);
+    if (rc) { drop(); return rc; }
+    rc = pinned_reserve(c, &B.h_out, &B.cap_out, out_total + 64);
+    if (rc) { drop(); return rc; }
+    if (out_total) MSIM_HIP(c, hipMemcpyAsync(B.h_out, g->d_out, out_total, hipMemcpyDeviceToHost, c->emit_stream));
+    rc = apply_finish(c);                                  // synchronises the emit stream: the copy above included
+    if (rc) { drop(); return rc; }
+    if (g->out_len != out_total) { drop(); return fail(c, MSIM_ERR_HIP, "internal: batch planner and device disagree on the mutated length"); }
+    if (g->key_error) {                                    // the reference's KeyError: which contig, which base
+        const uint64_t kp = g->key_pos;
+        int who = 0;
+        for (int i = 0; i < n; i++) if (B.items[(size_t)i].base <= kp && kp < B.items[(size_t)i].base + B.items[(size_t)i].len) who = i;
+        B.key_contig = who;
+        const uint8_t kb = g->key_base;
+        drop();
+        return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)kb + "'");
+    }
+    drop();
+    const auto t_3 = now();
+    // ---- 4. FASTA framing ('\n' after every bpl bases, none after a partial last line; fasta_writer.py:40-58) and
+    //         VCF record lines (mutator.py:334-399 + vcf_writer.py:118-126) per contig, on the host
+    uint64_t text_total = 0;
+    for (Batch::Item &it : B.items) { it.text0 = text_total; it.ntext = it.bpl ? it.out_len + it.out_len / it.bpl : it.out_len; text_total += it.ntext; }
+    B.fasta.resize(text_total);
+    for (const Batch::Item &it : B.items) {
+        const uint8_t *src = B.h_out + it.out_start;
+        uint8_t *dst = B.fasta.data() + it.text0;
+        if (!it.bpl) { if (it.out_len) memcpy(dst, src, it.out_len); continue; }
+        uint64_t done = 0;
+        while (done + it.bpl <= it.out_len) { memcpy(dst, src + done, it.bpl); dst[it.bpl] = '\n'; dst += it.bpl + 1; done += it.bpl; }
+        if (done < it.out_len) memcpy(dst, src + done, it.out_len - done);
+    }
+    const auto t_4 = now();
+    {   // one rendering pass per contig into a buffer sized by a cheap upper bound (a line is name + fixed fields of
+        // < 96 bytes + REF and ALT, each at most span + insert + 1 long, twice for a duplication's ALT)
+        const msim_record *all = B.recs_rel.data();
+        uint64_t bound = 0;
+        for (int i = 0; i < n; i++) {
+            const Batch::Item &it = B.items[(size_t)i];
+            const uint64_t nl = strlen(contigs[i].name) + 96;
+            for (uint64_t k = 0; k < it.nrec; k++) {
+                const msim_record &r = all[it.rec0 + k];
+                const uint64_t span = r.type == MSIM_SN ? 1 : (uint64_t)(r.stop >= r.pos ? r.stop - r.pos + 1 : 0) + 2;
+                const uint64_t tli = r.type == MSIM_TLI && r.stop + 1 > r.extra ? (uint64_t)r.stop + 1 - r.extra : 0;
+                bound += nl + 3 * (span + tli) + 8;
+            }
+        }
+        B.vcf.resize(bound);
+        uint64_t at = 0;
+        for (int i = 0; i < n; i++) {
+            Batch::Item &it = B.items[(size_t)i];
+            it.vcf0 = at;
+            uint64_t need = 0;
+            if (it.nrec) {
+                need = render_vcf_unchecked(all + it.rec0, it.nrec, B.pool.data() + it.pool0, B.h_in + it.base, it.len,
+                                            contigs[i].name, &B.vcf[at]);
+                if (at + need > bound) return fail(c, MSIM_ERR_HIP, "internal: VCF bound of a batch too small");
+            }
+            it.nvcf = need;
+            at += need;
+        }
+        B.vcf.resize(at);
+    }
+    if (prof)
+        fprintf(stderr, "msim_batch_run: %d contigs, %.1f Mb: ingest %.1f ms, plan %.1f, upload+APPLY+download %.1f, framing %.1f, VCF %.1f\n",
+                n, total / 1e6, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3), ms(t_3, t_4), ms(t_4, now()));
+    return MSIM_OK;
+}
+
+int msim_batch_sizes(msim_ctx *p, int n, uint64_t *fasta_bytes, uint64_t *vcf_bytes, int32_t *empty, uint64_t *n_records) {
+    Ctx *c = C(p);
+    if (!c || !c->batch || (size_t)n != c->batch->items.size()) return MSIM_ERR_ARG;
+    for (int i = 0; i < n; i++) {
+        const Batch::Item &it = c->batch->items[(size_t)i];
+        if (fasta_bytes) fasta_bytes[i] = it.ntext;
+        if (vcf_bytes) vcf_bytes[i] = it.nvcf;
+        if (empty) empty[i] = it.empty ? 1 : 0;
+        if (n_records) n_records[i] = it.nrec;
+    }
+    return MSIM_OK;
+}
+
+int msim_batch_fetch(msim_ctx *p, uint8_t *fasta_text, uint64_t fasta_cap, char *vcf_text, uint64_t vcf_cap) {
+    Ctx *c = C(p);
+    if (!c || !c->batch) return MSIM_ERR_ARG;
+    Batch &B = *c->batch;
+    if (fasta_text) {
+        if (fasta_cap < B.fasta.size()) return fail(c, MSIM_ERR_ARG, "fasta buffer too small");
+        if (!B.fasta.empty()) memcpy(fasta_text, B.fasta.data(), B.fasta.size());
+    }
+    if (vcf_text) {
+        if (vcf_cap < B.vcf.size()) return fail(c, MSIM_ERR_ARG, "vcf buffer too small");
+        if (!B.vcf.empty()) memcpy(vcf_text, B.vcf.data(), B.vcf.size());
+    }
+    return MSIM_OK;
+}
+
+int msim_batch_key_contig(msim_ctx *p, int *contig) {
+    Ctx *c = C(p);
+    if (!c || !contig || !c->batch) return MSIM_ERR_ARG;
+    *contig = c->batch->key_contig;
     return MSIM_OK;
 }
 

@@ -145,6 +145,14 @@ uint64_t render(const msim_record *recs, uint64_t n, const uint8_t *pool, const 
 
 }  // namespace
 
+// single pass, no size check: the caller guarantees room (msim_batch_run sizes its buffer by an upper bound)
+namespace msim {
+uint64_t render_vcf_unchecked(const msim_record *recs, uint64_t n_records, const uint8_t *insert_pool, const uint8_t *bases,
+                              uint64_t len, const char *seq_name, char *out) {
+    return render(recs, n_records, insert_pool, bases, len, seq_name, out);
+}
+}  // namespace msim
+
 extern "C" int msim_render_vcf(const msim_record *recs, uint64_t n_records, const uint8_t *insert_pool,
                                const uint8_t *bases, uint64_t len, const char *seq_name, char *out,
                                uint64_t cap, uint64_t *needed) {

@@ -44,6 +44,12 @@ class Params(C.Structure):           # msim_params
     _fields_ = [("block", C.c_int64 * 8), ("ti_lim", C.c_uint64)]
 
 
+class BatchContig(C.Structure):      # msim_batch_contig
+    _fields_ = [("body", C.c_void_p), ("body_bytes", C.c_uint64), ("n_bases", C.c_uint64),
+                ("lenc", C.c_uint32), ("lenb", C.c_uint32), ("ranges", C.POINTER(Range)),
+                ("n_ranges", C.c_int32), ("name", C.c_char_p)]
+
+
 class Timing(C.Structure):           # msim_timing
     _fields_ = [("plan_host_ms", C.c_double), ("plan_gpu_ms", C.c_double),
                 ("upload_ms", C.c_double), ("apply_ms", C.c_double),
@@ -90,6 +96,10 @@ SYMBOLS = [
     ("msim_render_vcf_device", C.c_int, [_VP, C.c_int, C.c_char_p, _VP, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
+    ("msim_batch_run", C.c_int, [_VP, C.POINTER(BatchContig), C.c_int]),
+    ("msim_batch_sizes", C.c_int, [_VP, C.c_int, _U64P, _U64P, C.POINTER(C.c_int32), _U64P]),
+    ("msim_batch_fetch", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
+    ("msim_batch_key_contig", C.c_int, [_VP, _IP]),
     ("msim_comm_unique_id", C.c_int, [_VP]),
     ("msim_comm_init", C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     ("msim_comm_destroy", C.c_int, [_VP]),
@@ -333,6 +343,37 @@ class Engine:
         a, n = C.c_uint64(), C.c_uint64()
         self._check(self.lib.msim_result_device_ptr(self.h, contig, C.byref(a), C.byref(n)), contig)
         return a.value, n.value
+
+    # ------------------------------------------------------------------ many small contigs in one pass
+    def batch_run(self, items):
+        """``items``: list of (body uint8 array, n_bases, lenc, lenb, [Range], name).  Returns (fasta_text uint8 array,
+        per-contig fasta byte counts, vcf_text bytes, per-contig empty flags)."""
+        n = len(items)
+        arr = (BatchContig * n)()
+        keep = []
+        for i, (body, n_bases, lenc, lenb, ranges, name) in enumerate(items):
+            body = np.ascontiguousarray(body, dtype=np.uint8)
+            ra = (Range * max(len(ranges), 1))(*ranges)
+            nm = name.encode("utf-8", "replace")
+            keep.append((body, ra, nm))
+            arr[i].body = body.ctypes.data
+            arr[i].body_bytes = body.shape[0]
+            arr[i].n_bases = n_bases
+            arr[i].lenc, arr[i].lenb = lenc, lenb
+            arr[i].ranges = ra
+            arr[i].n_ranges = len(ranges)
+            arr[i].name = nm
+        self._check(self.lib.msim_batch_run(self.h, arr, n))
+        fb = (C.c_uint64 * n)()
+        vb = (C.c_uint64 * n)()
+        em = (C.c_int32 * n)()
+        self._check(self.lib.msim_batch_sizes(self.h, n, fb, vb, em, None))
+        fsz = np.frombuffer(fb, dtype=np.uint64).astype(np.int64)
+        vsz = int(np.frombuffer(vb, dtype=np.uint64).sum())
+        fasta = np.empty(int(fsz.sum()), dtype=np.uint8)
+        vcf = np.empty(vsz, dtype=np.uint8)
+        self._check(self.lib.msim_batch_fetch(self.h, _ptr(fasta), fasta.shape[0], _ptr(vcf), vcf.shape[0]))
+        return fasta, fsz, vcf, [bool(x) for x in em]
 
     # ------------------------------------------------------------------ multi-GPU (csrc/comm.cpp)
     def comm_init(self, unique_id: bytes, rank: int, world: int):

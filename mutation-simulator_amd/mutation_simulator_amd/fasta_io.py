@@ -111,37 +111,51 @@ class Fasta:
             return
         if hdr_lines[0] != 0 and np.any(ends[:hdr_lines[0]] > starts[:hdr_lines[0]]):
             raise FastaIndexingError("Sequence data found before the first defline")
-        for k, li in enumerate(hdr_lines):
-            h0, h1 = int(starts[li]) + 1, int(ends[li])
-            if h1 > h0 and raw[h1 - 1] == 13:
-                h1 -= 1
-            long_name = raw[h0:h1].tobytes().decode("utf-8", "replace")
+        # per-line quantities for the whole file, per-record reductions with reduceat: an assembly with tens of
+        # thousands of scaffolds must not pay a dozen small NumPy calls per record
+        n_lines = starts.shape[0]
+        l_start = starts.astype(np.int64)
+        l_end = ends.astype(np.int64)
+        cr = (l_end > l_start) & (raw[np.maximum(l_end - 1, 0)] == 13)
+        llen = l_end - l_start - cr
+        line_idx = np.arange(n_lines, dtype=np.int64)
+        body_line = ~is_hdr
+        body_line[:hdr_lines[0]] = False
+        rec_of_line = np.cumsum(is_hdr) - 1                               # (lines before the first defline: -1, masked)
+        lo = hdr_lines + 1
+        hi = np.concatenate((hdr_lines[1:], [n_lines]))
+        has_body = lo < hi
+        lo_c = np.minimum(lo, n_lines - 1)
+        n_bases = np.add.reduceat(np.where(body_line, llen, 0), hdr_lines)
+        lenc_r = np.where(has_body, llen[lo_c], 0)
+        lenb_r = np.where(has_body, l_end[lo_c] - l_start[lo_c] + 1, 0)
+        last_nz = np.maximum.reduceat(np.where(body_line & (llen > 0), line_idx, -1), hdr_lines)
+        rl = np.maximum(rec_of_line, 0)
+        before_last = body_line & (line_idx < last_nz[rl])
+        # every line but the last non-empty one must have the record's line length
+        bad_line = (before_last & (llen != lenc_r[rl])) | (body_line & (line_idx == last_nz[rl]) & (llen > lenc_r[rl]))
+        bad_rec = np.logical_or.reduceat(bad_line, hdr_lines)
+        # fixed stride: every full line has the first line's terminator ('\n' or '\r\n')
+        nonuni = np.logical_or.reduceat(before_last & (cr != cr[lo_c][rl]), hdr_lines)
+        h0s = l_start[hdr_lines] + 1
+        h1s = l_end[hdr_lines] - cr[hdr_lines]
+        b0s = l_start[lo_c]
+        b1s = l_end[np.maximum(hi - 1, 0)]
+        for k in range(hdr_lines.shape[0]):
+            long_name = raw[h0s[k]:h1s[k]].tobytes().decode("utf-8", "replace")
             toks = long_name.split()
             name = toks[0] if toks else ""
-            lo = li + 1
-            hi = int(hdr_lines[k + 1]) if k + 1 < hdr_lines.size else starts.shape[0]
             if name in self._records:
                 raise ValueError(f"Duplicate key \"{name}\"")
-            if lo >= hi:
-                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, 0, int(ends[li]) + 1, True)
+            if not has_body[k]:
+                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, 0, int(l_end[hdr_lines[k]]) + 1, True)
             else:
-                b0, b1 = int(starts[lo]), int(ends[hi - 1])
-                l_end = ends[lo:hi].astype(np.int64)
-                l_start = starts[lo:hi].astype(np.int64)
-                cr = (l_end > l_start) & (raw[np.maximum(l_end - 1, 0)] == 13)
-                llen = l_end - l_start - cr
-                lenc = int(llen[0])
-                lenb = int(l_end[0] - l_start[0]) + 1
-                # every line but the last non-empty one must have the record's line length
-                nz = np.flatnonzero(llen > 0)
-                if nz.size:
-                    body = llen[:nz[-1]]
-                    if np.any(body != lenc) or llen[nz[-1]] > lenc:
-                        raise FastaIndexingError(
-                            f"Line length of fasta file is not consistent in {name}")
-                # fixed stride: every full line has the first line's terminator ('\n' or '\r\n')
-                uniform = bool(nz.size == 0 or np.all(cr[:nz[-1]] == cr[0]))
-                rec = FastaRecord(name, long_name, raw[b0:b1], int(llen.sum()), lenc, lenb, b0, uniform)
+                if bad_rec[k]:
+                    raise FastaIndexingError(
+                        f"Line length of fasta file is not consistent in {name}")
+                b0 = int(b0s[k])
+                rec = FastaRecord(name, long_name, raw[b0:int(b1s[k])], int(n_bases[k]), int(lenc_r[k]), int(lenb_r[k]),
+                                  b0, not bool(nonuni[k]))
             self._records[name] = rec
             self._order.append(rec)
 

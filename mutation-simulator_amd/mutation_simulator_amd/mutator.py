@@ -74,27 +74,39 @@ def sample_setsize(k: int) -> int:
     return setsize
 
 
+_SETTINGS_CACHE: dict = {}       # id(MutationSettings) -> (settings, rate sum, template bytes): the per-settings part of msim_range
+
+
 def range_descriptor(rd) -> "_ffi.Range":
-    """One ``RangeDefinition`` with mutations -> ``msim_range`` (what mutator.py:157-174 derives)."""
+    """One ``RangeDefinition`` with mutations -> ``msim_range`` (what mutator.py:157-174 derives).  Everything that
+    depends only on the range's ``MutationSettings`` (type order, cdf thresholds, length bounds) is computed once per
+    settings object -- an assembly with 20 000 scaffolds shares one in ARGS mode -- and copied."""
     ms = rd.mutation_settings
-    rate_sum = sum(ms.mut_rates.values())                         # mutator.py:160
-    r = _ffi.Range()
+    hit = _SETTINGS_CACHE.get(id(ms))
+    if hit is None or hit[0] is not ms:
+        rate_sum = sum(ms.mut_rates.values())                     # mutator.py:160
+        t = _ffi.Range()
+        chances = list(ms.mut_chances.values())                   # mutator.py:172-173
+        # numpy.random.choice(p=...): cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
+        cdf = np.cumsum(np.array(chances, dtype=np.float64))
+        cdf /= cdf[-1]
+        t.n_types = len(chances)
+        for j, ty in enumerate(ms.mut_chances):
+            t.types[j] = ty.value
+            t.cdf_thr[j] = _ceil_scaled(float(cdf[j]))
+        if ms.mut_lengs:
+            for ty, v in ms.mut_lengs["min"].items():
+                t.min_len[ty.value] = v
+            for ty, v in ms.mut_lengs["max"].items():
+                t.max_len[ty.value] = v
+        if len(_SETTINGS_CACHE) > 4096:
+            _SETTINGS_CACHE.clear()
+        hit = (ms, rate_sum, bytes(t))
+        _SETTINGS_CACHE[id(ms)] = hit
+    r = _ffi.Range.from_buffer_copy(hit[2])
     r.start, r.stop = rd.start, rd.stop
-    r.k = int(((rd.stop - rd.start) + 1) * rate_sum)              # mutator.py:225
+    r.k = int(((rd.stop - rd.start) + 1) * hit[1])                # mutator.py:225
     r.setsize = sample_setsize(r.k)
-    chances = list(ms.mut_chances.values())                       # mutator.py:172-173
-    # numpy.random.choice(p=...): cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, u, 'right')
-    cdf = np.cumsum(np.array(chances, dtype=np.float64))
-    cdf /= cdf[-1]
-    r.n_types = len(chances)
-    for j, t in enumerate(ms.mut_chances):
-        r.types[j] = t.value
-        r.cdf_thr[j] = _ceil_scaled(float(cdf[j]))
-    if ms.mut_lengs:
-        for t, v in ms.mut_lengs["min"].items():
-            r.min_len[t.value] = v
-        for t, v in ms.mut_lengs["max"].items():
-            r.max_len[t.value] = v
     return r
 
 
@@ -134,6 +146,11 @@ def import_python_streams(engine: "_ffi.Engine") -> None:
     np.random.set_state((nst[0], mt, int(pos), nst[3], nst[4]))
 
 
+BATCH_MAX_LEN = 200_000          # contigs up to this length are batched (below every device PLAN engine's threshold)
+BATCH_MAX_BASES = 256 << 20      # bases per batch
+BATCH_MAX_CONTIGS = 16384
+
+
 class Mutator:
     """Runs the mutation pass of one genome on the GPU and writes ``*_ms.fa`` / ``*_ms.vcf``."""
 
@@ -162,6 +179,60 @@ class Mutator:
         except Exception:
             pass
 
+    def _batchable(self, chrom) -> bool:
+        rec = self._fasta[chrom.number]
+        return (getattr(rec, "uniform", False) and 0 < len(rec) <= BATCH_MAX_LEN
+                and self._fasta.faidx.index[rec.name].lenc > 0)
+
+    def _warn_empty(self, chrom):
+        if not self._args.ignore_warnings:
+            print(format_warning(
+                f"No mutations could be generated on sequence {chrom.number+1} "
+                "(mutation rates too low)", self._args.no_color), file=sys.stderr)
+
+    def _mutate_batch(self, eng, chroms):
+        items = []
+        for chrom in chroms:
+            rec = self._fasta[chrom.number]
+            items.append((rec.body, len(rec), rec.lenc, rec.lenb, plan_descriptors(chrom), rec.name))
+        fasta, fsz, vcf, empty = eng.batch_run(items)
+        at = 0
+        for k, chrom in enumerate(chroms):
+            rec = self._fasta[chrom.number]
+            if empty[k]:
+                self._warn_empty(chrom)
+            bpl = self._fasta.faidx.index[rec.name].lenc
+            self._fasta_writer.set_bpl(bpl)
+            self._fasta_writer.write_header(rec.long_name)
+            n = int(fsz[k])
+            q, r = divmod(n, bpl + 1)                      # text = L + L // bpl bytes  ->  L
+            self._fasta_writer.write_framed(fasta[at:at + n], q * bpl + r)
+            at += n
+        self._vcf_writer.write_raw(memoryview(vcf))
+
+    def _mutate_one(self, eng, chrom):
+        rec = self._fasta[chrom.number]
+        if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
+            cid = eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
+        else:
+            cid = eng.add_contig(rec.bases)
+        eng.plan_contig(cid, plan_descriptors(chrom))
+        if eng.plan_was_empty(cid):
+            self._warn_empty(chrom)
+        self._fasta_writer.set_bpl(self._fasta.faidx.index[rec.name].lenc)
+        self._fasta_writer.write_header(rec.long_name)
+        eng.apply_contig(cid)
+        bpl = self._fasta.faidx.index[rec.name].lenc
+        if bpl > 0:                                    # line framing and VCF text rendered on the device
+            text = eng.fetch_sequence_framed(cid, bpl, guess_len=len(rec))
+            q, r = divmod(int(text.shape[0]), bpl + 1)  # text = L + L // bpl bytes  ->  L
+            self._fasta_writer.write_framed(text, q * bpl + r)
+        else:
+            self._fasta_writer.write_array(eng.fetch_sequence(cid))
+        _, n_rec, _ = eng.result_sizes(cid, applied=False)     # (host-side bookkeeping, no round trip)
+        self._vcf_writer.write_raw(eng.render_vcf_device(cid, rec.name, guess=n_rec * (len(rec.name) + 40) + 256))
+        eng.clear()
+
     def mutate(self):
         if self._engine is None:
             self._engine = _ffi.Engine(getattr(self._args, "device", 0) or 0)
@@ -170,30 +241,28 @@ class Mutator:
         eng.set_params(params_descriptor(self._sim))
         eng.reset_stats()
         try:
-            for chrom in self._sim.chromosomes:
-                rec = self._fasta[chrom.number]
-                if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
-                    cid = eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
-                else:
-                    cid = eng.add_contig(rec.bases)
-                eng.plan_contig(cid, plan_descriptors(chrom))
-                if eng.plan_was_empty(cid) and not self._args.ignore_warnings:
-                    print(format_warning(
-                        f"No mutations could be generated on sequence {chrom.number+1} "
-                        "(mutation rates too low)", self._args.no_color), file=sys.stderr)
-                self._fasta_writer.set_bpl(self._fasta.faidx.index[rec.name].lenc)
-                self._fasta_writer.write_header(rec.long_name)
-                eng.apply_contig(cid)
-                bpl = self._fasta.faidx.index[rec.name].lenc
-                if bpl > 0:                                    # line framing and VCF text rendered on the device
-                    text = eng.fetch_sequence_framed(cid, bpl, guess_len=len(rec))
-                    q, r = divmod(int(text.shape[0]), bpl + 1)  # text = L + L // bpl bytes  ->  L
-                    self._fasta_writer.write_framed(text, q * bpl + r)
-                else:
-                    self._fasta_writer.write_array(eng.fetch_sequence(cid))
-                _, n_rec, _ = eng.result_sizes(cid, applied=False)     # (host-side bookkeeping, no round trip)
-                self._vcf_writer.write_raw(eng.render_vcf_device(cid, rec.name, guess=n_rec * (len(rec.name) + 40) + 256))
-                eng.clear()
+            chroms = list(self._sim.chromosomes)
+            i = 0
+            while i < len(chroms):
+                # a run of small contigs goes through libmsim in ONE pass (msim_batch_run); a KeyError / ValueError inside it is
+                # replayed contig by contig so that the files hold exactly what the reference had written by then
+                j = i
+                total = 0
+                while (j < len(chroms) and j - i < BATCH_MAX_CONTIGS and self._batchable(chroms[j])
+                       and total + len(self._fasta[chroms[j].number]) <= BATCH_MAX_BASES):
+                    total += len(self._fasta[chroms[j].number])
+                    j += 1
+                if j - i >= 2:
+                    saved = (eng.get_mt_state(0), eng.get_mt_state(1))
+                    try:
+                        self._mutate_batch(eng, chroms[i:j])
+                        i = j
+                        continue
+                    except (KeyError, ValueError):
+                        eng.set_mt_state(0, *saved[0])
+                        eng.set_mt_state(1, *saved[1])
+                self._mutate_one(eng, chroms[i])
+                i += 1
         finally:
             import_python_streams(eng)
             self.stats = eng.stats()

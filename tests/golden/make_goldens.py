@@ -750,6 +750,26 @@ sn 0.004 in 0.001 inmin 1 inmax 30 de 0.001 demin 1 demax 80 du 0.0005 dumin 20 
 """
 
 
+def make_cli_cases_scaffolds():
+    """An assembly-like input: hundreds of small scaffolds (the batch path of the product, msim_batch_run), with a
+    large contig in the middle so that the stream chain crosses batch -> device engine -> batch."""
+    print("CLI cases (many scaffolds)")
+    rs = np.random.RandomState(77)
+    contigs = []
+    for i in range(320):
+        L = int(rs.choice([37, 400, 1_500, 4_000, 9_000, 15_000]) + rs.randint(0, 300))
+        contigs.append({"defline": f"scaf{i:04d} len={L}", "length": L, "bpl": int(rs.choice([60, 60, 70, 80])), "seed": 900 + i,
+                        "decorate": bool(rs.randint(0, 4) == 0) and L > 2000})
+    contigs.insert(150, {"defline": "chrBig in the middle", "length": 900_000, "bpl": 60, "seed": 899})
+    cli_case("many_scaffolds", {"contigs": contigs},
+             ["args", "-sn", "0.01", "-titv", "2.0", "-in", "0.002", "-inmax", "6", "-de", "0.002", "-demax", "9",
+              "-du", "0.001", "-dumax", "20", "-iv", "0.001", "-ivmax", "15"], 21, 22, store="hash",
+             notes="321 contigs: 320 scaffolds of 37 b - 15 kb (batched) around one 900 kb contig (SV-mix engine)")
+    cli_case("many_scaffolds_tl", {"contigs": contigs[:60]},
+             ["args", "-sn", "0.01", "-tl", "0.004", "-tlmin", "2", "-tlmax", "40", "-de", "0.002", "-demax", "9"], 23, 24,
+             store="hash", notes="60 scaffolds with translocations (TL / TLI records inside a batch)")
+
+
 def make_cli_cases_engines():
     """Mid-size cases that reach the device PLAN engines in AUTO mode (k >= 4096 on one range, or many
     deterministic-SNP ranges): the reference's own output pins them, not only the host planner."""
@@ -807,6 +827,8 @@ def main():
         make_reference_timing()
     if "engines" in which:
         make_cli_cases_engines()
+    if "scaffolds" in which or "engines" in which:
+        make_cli_cases_scaffolds()
     if "rng" in which:
         make_rng_kat()
     if "settings" in which:
