@@ -299,15 +299,26 @@ def main():
     mine = parts[rank]
     seed = 42 if strong else 42 + rank       # replicas: every GPU mutates its own genome
 
-    eng = _ffi.Engine(local_rank)
+    # (MSIM_BENCH_DEVICE: put every rank on one GPU -- lets the N > 1 control flow run on a 1-GPU box)
+    eng = _ffi.Engine(int(os.environ.get("MSIM_BENCH_DEVICE", local_rank)))
     # genome resident in HBM before the timed region (3 GB; every rank holds every contig so that
     # contig numbering is global -- 288 GB of HBM make the replica free)
     cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
     eng.sync()
-    comm = None
+    comm, comm_error = None, None
     if strong:
         from mutation_simulator_amd.gather import Communicator
-        comm = Communicator(eng, rank, world, dist)
+        try:
+            comm = Communicator(eng, rank, world, dist)
+        except Exception as e:  # noqa: BLE001  (no RCCL / duplicate GPUs ...): the sharded step is still measured
+            comm_error = f"{type(e).__name__}: {e}"
+        flags = [None] * world
+        dist.all_gather_object(flags, comm_error)
+        if any(flags):                                   # every rank takes the same branch
+            comm_error = next(f for f in flags if f)
+            if comm is not None:
+                comm.close()
+            comm = None
 
     def barrier():
         eng.sync()
@@ -322,7 +333,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def measure(workload, steps, warmup, gather=False):
+    def measure(workload, steps, warmup, gather=False, owned=None, step_seed=None):
+        owned = mine if owned is None else owned
+        step_seed = seed if step_seed is None else step_seed
         sim = build_settings(workload, lengths)
         descs = {}                   # msim_range descriptors per contig: settings -> integers once, outside the timed steps
 
@@ -333,7 +346,7 @@ def main():
         eng.set_params(mm.params_descriptor(sim))
 
         def step():
-            one_step(eng, sim, cids, mine, seed, plan_descs)
+            one_step(eng, sim, cids, owned, step_seed, plan_descs)
             if gather:
                 comm.gather_to_root(cids, parts)
 
@@ -369,13 +382,22 @@ def main():
             "records_per_step": st["records"] // a.steps,
             "roofline": roofline_of(st, a.workload, a.steps),
         }
-    if strong:
+    if strong and comm is not None:
         # the exchange step north_star names: every peer sends its mutated contigs to rank 0 over its own xGMI link
         dtg, _ = measure(a.workload, a.steps, 1, gather=True)
         if rank == 0:
             line["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
                                    "ms_per_step": round(dtg / a.steps * 1e3, 3),
                                    "transport": comm.describe()}
+    elif strong and rank == 0:
+        line["with_gather"] = {"error": comm_error}
+    if strong:
+        # what DOES scale: N independent replicas (one whole genome per GPU, own seeds) -- the weak-scaling number
+        dtw, _ = measure(a.workload, a.steps, 1, owned=list(range(len(lengths))), step_seed=42 + rank)
+        if rank == 0:
+            line["weak_replicas"] = {"value": round(sum(lengths) * world * a.steps / dtw / 1e6, 3), "unit": "Mbases/s",
+                                     "ms_per_step": round(dtw / a.steps * 1e3, 3), "scaling": "weak",
+                                     "what": f"{world} independent replicas, one whole genome per GPU, streams seeded 42+rank"}
     if world == 1 and not a.no_secondary and a.workload == "c2":
         # BASELINE configs[2] and [3] on the same resident genome: 3 steps each, same definition of a step
         sec = {}
