@@ -39,6 +39,10 @@ struct GpuStream {
     uint32_t states_cap = 0;            // allocated states
     uint32_t n_states = 0;              // valid states = n_src * (m_done + 1)
     uint32_t lvl = 0, n_src = 1, m_done = 0;   // cascade position: level, states at its start, multipliers done
+    SnpMap *d_maps = nullptr;           // CPython stream only: SNP transducer maps of the absolute 8192-word blocks
+    size_t maps_cap = 0;                //   (entries)
+    uint32_t mapped_blocks = 0;         //   blocks [0, mapped_blocks) are mapped (enqueued on the generation stream)
+    unsigned long long maps_ti_lim = 0; //   with this transition threshold
     uint32_t *d_z = nullptr;            // extensions of the current level's source states (k_mt_extend)
     size_t z_cap = 0;                   // in source states
     int z_lvl = -1;                     // level whose sources d_z holds
@@ -147,6 +151,7 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (s.d_raw) (void)hipFree(s.d_raw);
         if (s.d_states) (void)hipFree(s.d_states);
         if (s.d_z) (void)hipFree(s.d_z);
+        if (s.d_maps) (void)hipFree(s.d_maps);
         for (auto e : s.ready_ev) (void)hipEventDestroy(e);
     }
     for (auto e : g->ev_pool) (void)hipEventDestroy(e);
@@ -258,6 +263,17 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                 s.d_states = ns;
                 s.states_cap = want_states;
             }
+            if (si == 0 && want_cap / SNP_BLOCK2 + 2 > s.maps_cap) {
+                SnpMap *nm = nullptr;
+                const size_t cap = (size_t)(want_cap / SNP_BLOCK2 + 2) * 5 / 4;
+                MSIM_HIP(c, hipMalloc(&nm, cap * sizeof(SnpMap)));
+                if (s.d_maps) {
+                    MSIM_HIP(c, hipMemcpy(nm, s.d_maps, (size_t)s.mapped_blocks * sizeof(SnpMap), hipMemcpyDeviceToDevice));
+                    MSIM_HIP(c, hipFree(s.d_maps));
+                }
+                s.d_maps = nm;
+                s.maps_cap = cap;
+            }
             if (want_cap > s.cap) {
                 uint32_t *nr = nullptr;
                 MSIM_HIP(c, hipMalloc(&nr, want_cap * sizeof(uint32_t)));
@@ -291,6 +307,16 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                 hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(GEN_THREADS), 0, g->gen_stream, s.d_states,
                                    s.d_raw, s.n_chunks);
                 MSIM_HIP(c, hipGetLastError());
+                if (si == 0) {                              // SNP transducer maps of every block the batch completed
+                    const uint32_t n_words = (uint32_t)(MT_N + (uint64_t)hi * MT_CHUNK_WORDS);
+                    const uint32_t complete = n_words / SNP_BLOCK2;
+                    if (complete > s.mapped_blocks) {
+                        hipLaunchKernelGGL(k_snp_maps_abs, dim3(complete - s.mapped_blocks), dim3(SNP_THREADS), 0, g->gen_stream,
+                                           s.d_raw, n_words, (unsigned long long)c->params.ti_lim, s.mapped_blocks, s.d_maps);
+                        MSIM_HIP(c, hipGetLastError());
+                        s.mapped_blocks = complete;
+                    }
+                }
                 hipEvent_t ev;
                 rc = take_event(ev);
                 if (rc) return rc;
@@ -386,6 +412,8 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     s.lvl = 0; s.n_src = 1; s.m_done = 0;
     s.z_lvl = -1;
     s.n_chunks = 0;
+    s.mapped_blocks = 0;
+    s.maps_ti_lim = c->params.ti_lim;
     s.pos = (uint64_t)h.idx;
     s.live = true;
     if (si == 0) { g->ps_valid = false; g->verified_pos = s.pos; }
@@ -562,6 +590,47 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     return MSIM_OK;
 }
 
+// SNP draws of a contig's K (kept) SNPs in position order, starting at the device position (ps->snp_base): the chain
+// part (k_snp_scan_cut_abs: exact end of the draws) on the plan stream, the aux bytes (k_snp_emit_abs) on the emit
+// stream.  pos_hi: upper bound of the start position on entry, of the end position on return.
+static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const uint32_t *sn_index, uint64_t &pos_hi, bool &grew) {
+    const msim_params &P = c->params;
+    GpuStream &py = g->s[0];
+    int rc;
+    const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
+    const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
+    if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
+    const uint32_t W2 = (uint32_t)w2;
+    const uint32_t nb2 = W2 / SNP_BLOCK2 + 2;              // window blocks incl. the partial first one
+    SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
+    if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
+    if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
+    if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
+    if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
+    // words AND absolute maps up to the end of the last window block
+    if ((rc = ensure_words(c, g, 0, ((pos_hi + W2) / SNP_BLOCK2 + 2) * SNP_BLOCK2))) return rc;
+    if (py.maps_ti_lim != P.ti_lim) {                      // titv changed inside a session: the maps are stale
+        if (!py.ready_ev.empty()) MSIM_HIP(c, hipStreamWaitEvent(c->stream, py.ready_ev.back(), 0));
+        if (py.mapped_blocks)
+            hipLaunchKernelGGL(k_snp_maps_abs, dim3(py.mapped_blocks), dim3(SNP_THREADS), 0, c->stream, py.d_raw,
+                               (uint32_t)(MT_N + (uint64_t)py.n_chunks * MT_CHUNK_WORDS), (unsigned long long)P.ti_lim, 0u, py.d_maps);
+        py.maps_ti_lim = P.ti_lim;
+    }
+    hipLaunchKernelGGL(k_snp_scan_cut_abs, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
+                       (unsigned long long)P.ti_lim, py.d_maps, T.maps, nb2, (uint32_t)K, T.base);
+    MSIM_HIP(c, hipGetLastError());
+    hipEvent_t ce = next_chain_event(g);
+    MSIM_HIP(c, hipEventRecord(ce, c->stream));
+    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+    hipLaunchKernelGGL(k_snp_emit_abs, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
+                       (unsigned long long)P.ti_lim, T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+    T.pending = true;
+    pos_hi += W2;
+    return MSIM_OK;
+}
+
 // Asynchronous: enqueues the contig's chain (stream positions) on the plan stream and its emit work
 // (records) on the emit stream; nothing is waited for.  Flags and the exact position are collected
 // by gpu_plan_finish at the next synchronising call.
@@ -591,7 +660,6 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     ct.pool_len = 0;
     ct.plan_empty = K == 0;
     ct.all_snp = true;                                    // every record is an SNP: output offset == position
-    const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
 
     GpuStream &py = g->s[0];
     if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
@@ -626,31 +694,8 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         pos_hi += W;
         rec_base += k;
     }
-    if (K) {                                               // SNP draws of the whole contig, in position order
-        const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
-        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
-        const uint32_t W2 = (uint32_t)w2;
-        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
-        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
-        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
-        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
-        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
-        if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
-        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
-        MSIM_HIP(c, hipGetLastError());
-        hipEvent_t ce = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce, c->stream));
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K, (const uint32_t *)nullptr);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
-        T.pending = true;
-        pos_hi += W2;
+    if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
+        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew))) return rc;
     }
     py.pos = pos_hi;                                       // bound until gpu_plan_finish reads the exact value
     g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k): 2 words per candidate
@@ -886,32 +931,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     MSIM_HIP(c, hipGetLastError());
     np.pos += pool_len;
     c->t.np_words += pool_len;
-    if (n_sn) {                                            // SNP draws of the kept SNPs, in position order
-        const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
-        const double w2 = (double)n_sn * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)n_sn) + 16384.0;
-        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
-        const uint32_t W2 = (uint32_t)w2;
-        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
-        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
-        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
-        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
-        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
-        if ((rc = ensure_words(c, g, 0, p_s + W2 + 1))) return rc;
-        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps, nb2, n_sn, T.base);
-        MSIM_HIP(c, hipGetLastError());
-        hipEvent_t ce2 = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce2, c->stream));
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce2, 0));
-        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, n_sn, (const uint32_t *)M.sn_index);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
-        T.pending = true;
-        pos_hi += W2;
+    if (n_sn) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
+        if ((rc = enqueue_snp_stage(c, g, ct, n_sn, M.sn_index, pos_hi, grew))) return rc;
     }
     MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
     M.pending = true;
@@ -1035,32 +1056,8 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     ct.plan_empty = false;
     ct.all_snp = true;
     uint64_t pos_hi = py.pos + consumed;
-    {   // SNP draws of the whole contig, in position order (as in plan_contig_gpu)
-        const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
-        const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
-        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
-        const uint32_t W2 = (uint32_t)w2;
-        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
-        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
-        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
-        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
-        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
-        if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
-        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
-        MSIM_HIP(c, hipGetLastError());
-        hipEvent_t ce = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce, c->stream));
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K, (const uint32_t *)nullptr);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
-        T.pending = true;
-        pos_hi += W2;
+    if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
+        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew))) return rc;
     }
     MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
     M.pending = true;
@@ -1249,32 +1246,8 @@ int plan_contig_gpu_walk(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *range
     ct.plan_empty = false;
     ct.all_snp = true;
     uint64_t pos_hi = pos_lo + W;
-    {   // SNP draws of the whole contig, in position order (as in plan_contig_gpu)
-        const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
-        const double w2 = (double)K * (2.0 + 2.0 * p_tv) + 16.0 * std::sqrt(4.0 * (double)K) + 16384.0;
-        if (w2 >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "SNP draw window beyond 2^32 words");
-        const uint32_t W2 = (uint32_t)w2;
-        const uint32_t nb2 = (W2 + SNP_BLOCK2 - 1) / SNP_BLOCK2;
-        SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-        if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
-        if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
-        if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
-        if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
-        if ((rc = ensure_words(c, g, 0, pos_hi + W2 + 1))) return rc;
-        hipLaunchKernelGGL(k_snp_reduce, dim3(nb2), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps);
-        hipLaunchKernelGGL(k_snp_scan_cut, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                           (unsigned long long)P.ti_lim, T.maps, nb2, (uint32_t)K, T.base);
-        MSIM_HIP(c, hipGetLastError());
-        hipEvent_t ce = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce, c->stream));
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-        hipLaunchKernelGGL(k_snp_emit, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                           (unsigned long long)P.ti_lim, T.maps, ct.d_recs, (uint32_t)K, (const uint32_t *)nullptr);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
-        T.pending = true;
-        pos_hi += W2;
+    if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
+        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew))) return rc;
     }
     MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
     M.pending = true;

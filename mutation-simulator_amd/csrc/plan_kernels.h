@@ -593,7 +593,7 @@ __device__ __forceinline__ SnpMap snp_identity() { SnpMap r; r.c[0] = r.c[1] = r
 //   B bit i : word i ends a randbelow(2) loop (getrandbits(2) < 2, i.e. top bit clear)
 //   T bit i : the transversion column word i would pick (bit 30)
 // With them the transducer walks SNP by SNP (ctz over the masks) instead of word by word.
-struct SnpBits { uint32_t A, B, T; int E; };             // E = valid words (0..32)
+struct SnpBits { uint32_t A, B, T; int S, E; };          // words [S, E) of the lane's 32 are live
 
 // Branch-free, bit-sliced transducer over one lane's <= 32 words.  Bit k (k = 0..2) of s0/s1/s2 says
 // whether the simulation that STARTED in state k is currently in state 0/1/2, so all three start
@@ -604,7 +604,7 @@ __device__ __forceinline__ SnpMap snp_lane_map(const SnpBits &m) {
     uint32_t s0 = 1u, s1 = 2u, s2 = 4u, cnt = 0;
 #pragma unroll
     for (int i = 0; i < 32; i++) {
-        const uint32_t live = i < m.E ? 7u : 0u;         // words beyond the window leave the state alone
+        const uint32_t live = (i >= m.S && i < m.E) ? 7u : 0u;   // words outside the window leave the state alone
         const uint32_t a = (0u - ((m.A >> i) & 1u)) & live;
         const uint32_t b = (0u - ((m.B >> i) & 1u)) & live;
         const uint32_t emit = (s1 & a) | (s2 & b);
@@ -632,7 +632,7 @@ __device__ __forceinline__ uint32_t snp_lane_emits(uint32_t st, const SnpBits &m
     emits = 0; from2 = 0;
 #pragma unroll
     for (int i = 0; i < 32; i++) {
-        const uint32_t live = i < m.E ? 1u : 0u;
+        const uint32_t live = (i >= m.S && i < m.E) ? 1u : 0u;
         const uint32_t a = (m.A >> i) & live, b = (m.B >> i) & live;
         const uint32_t e1 = s1 & a, e2 = s2 & b;
         const uint32_t n2 = (s1 & ~a & live) | (s2 & ~b & live) | (s2 & ~live & 1u);
@@ -652,7 +652,7 @@ constexpr int SNP_LDS_WORDS = SNP_BLOCK2 + SNP_BLOCK2 / 32 + 1;
 // Coalesced load of the workgroup's 8192 words (tempered) into LDS, row-padded (stride 33) so a
 // lane's 32 consecutive words are conflict-free; then each lane builds its masks.
 __device__ __forceinline__ SnpBits snp_stage(const uint32_t *__restrict__ raw, unsigned long long p0, uint32_t base,
-                                             uint32_t W, unsigned long long ti_lim, uint32_t *sw) {
+                                             uint32_t W, unsigned long long ti_lim, uint32_t *sw, uint32_t start_off = 0) {
     uint32_t w[SNP_ITEMS2];
 #pragma unroll
     for (int r = 0; r < SNP_ITEMS2; r++) {               // all 32 loads in flight before the first use
@@ -670,6 +670,10 @@ __device__ __forceinline__ SnpBits snp_stage(const uint32_t *__restrict__ raw, u
     m.A = m.B = m.T = 0;
     const uint32_t first = base + threadIdx.x * SNP_ITEMS2;
     m.E = first >= W ? 0 : (int)std::min<uint32_t>(SNP_ITEMS2, W - first);
+    {   // words of the block before `start_off` (block-relative) are not part of the window
+        const uint32_t lane0 = threadIdx.x * SNP_ITEMS2;
+        m.S = start_off <= lane0 ? 0 : (int)std::min<uint32_t>(SNP_ITEMS2, start_off - lane0);
+    }
     uint32_t prev = threadIdx.x ? sw[(threadIdx.x - 1) * 33 + 31] : sw[SNP_LDS_WORDS - 1];
     const uint32_t *mine = sw + threadIdx.x * 33;
 #pragma unroll
@@ -711,39 +715,58 @@ __device__ __forceinline__ SnpMap snp_block_scan2(const SnpMap &mine, SnpMap *wa
     return snp_compose(pre, ex);
 }
 
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_reduce(const uint32_t *__restrict__ raw,
-                                                            const PlanState *__restrict__ ps, uint32_t W,
-                                                            unsigned long long ti_lim, SnpMap *__restrict__ block_maps) {
+// The map of a block depends on the stream words and on ti_lim only -- not on where a contig's SNP draws start.
+// So the maps of ALL blocks of 8192 words, aligned to ABSOLUTE stream positions, are computed right behind chunk
+// generation on the generation stream (one launch per batch, off every chain; the event the plan stream waits for
+// anyway covers them).  On the chain only k_snp_scan_cut_abs is left: it maps the partial first block itself (the words
+// before the start position are masked out), scans the precomputed maps and re-walks the block in which the K-th SNP
+// completes.  Round 1 computed the maps per contig, relative to the start position, ON the chain (k_snp_reduce: 44 us
+// of ~200 per contig).
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_maps_abs(const uint32_t *__restrict__ raw, uint32_t n_words,
+                                                              unsigned long long ti_lim, uint32_t first_block,
+                                                              SnpMap *__restrict__ abs_maps) {
     __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
-    const SnpBits m = snp_stage(raw, ps->snp_base, blockIdx.x * SNP_BLOCK2, W, ti_lim, sw);
+    const uint32_t b = first_block + blockIdx.x;
+    const SnpBits m = snp_stage(raw, 0ull, b * SNP_BLOCK2, n_words, ti_lim, sw);
     SnpMap total;
     (void)snp_block_scan2(snp_lane_map(m), wave_tot, total);
-    if (threadIdx.x == 0) block_maps[blockIdx.x] = total;
+    if (threadIdx.x == 0) abs_maps[b] = total;
 }
 
-// Scan of the workgroup maps + exact end of the SNP draws, ONE workgroup (both steps sit on the stream-position
-// critical path, so they share a launch).  Afterwards block_maps[b] = (state, count) at the start of block b
-// when the stream starts in state 0 (c[0] = count, e = state) -- what k_snp_emit needs -- and the workgroup in
-// which the K-th SNP completes has been re-walked: the word on which it completes + 1 is the new stream
-// position.  Keeps the (large) emit pass off the critical path; also saves the base for the emit pass.
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
-                                                              uint32_t W, unsigned long long ti_lim,
-                                                              SnpMap *__restrict__ block_maps, uint32_t nb, uint32_t K,
-                                                              unsigned long long *__restrict__ base_out) {
+// ONE workgroup, on the stream-position critical path.  Window = absolute blocks b0 .. b0 + nb - 1 where b0 holds
+// the start position (its words before the start are masked).  Afterwards win_maps[j] = (state, count) at the start
+// of window block j when the stream starts in state 0 (c[0] = count, e = state) -- what k_snp_emit_abs needs -- and
+// the block in which the K-th SNP completes has been re-walked: the word on which it completes + 1 is the new
+// stream position.  Also saves the start position for the emit pass.
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
+                                                                  uint32_t W, unsigned long long ti_lim,
+                                                                  const SnpMap *__restrict__ abs_maps,
+                                                                  SnpMap *__restrict__ win_maps, uint32_t nb_max, uint32_t K,
+                                                                  unsigned long long *__restrict__ base_out) {
     __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    __shared__ SnpMap s_first;
     __shared__ uint32_t s_blk, s_bs, s_bc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long p0 = ps->snp_base;
+    const uint32_t b0 = (uint32_t)(p0 / SNP_BLOCK2), off = (uint32_t)(p0 % SNP_BLOCK2);
+    const uint32_t nb = min(nb_max, (off + W + SNP_BLOCK2 - 1) / SNP_BLOCK2);
+    const uint32_t w_end = (uint32_t)min<unsigned long long>(p0 + W, 0xffffffffull);       // words beyond the window are not live
     if (threadIdx.x == 0) { s_blk = 0xffffffffu; *base_out = p0; }
-    uint32_t c_state = 0, c_count = 0;                    // carried across chunks, identical in every lane
+    {   // the partial first block, mapped here
+        const SnpBits m0 = snp_stage(raw, 0ull, b0 * SNP_BLOCK2, w_end, ti_lim, sw, off);
+        SnpMap total;
+        (void)snp_block_scan2(snp_lane_map(m0), wave_tot, total);
+        if (threadIdx.x == 0) s_first = total;
+    }
     __syncthreads();
+    uint32_t c_state = 0, c_count = 0;                    // carried across chunks, identical in every lane
     for (uint32_t base = 0; base < nb; base += 4 * SNP_THREADS) {
         const uint32_t i0 = base + threadIdx.x * 4;
         SnpMap v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = i0 + q < nb ? block_maps[i0 + q] : snp_identity();
+        for (int q = 0; q < 4; q++) v[q] = i0 + q >= nb ? snp_identity() : (i0 + q == 0 ? s_first : abs_maps[b0 + i0 + q]);
         SnpMap incl = snp_compose(snp_compose(v[0], v[1]), snp_compose(v[2], v[3]));
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -767,8 +790,8 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut(const uint32_t *__
                 r.c[0] = c_count + run.c[c_state];
                 r.c[1] = r.c[2] = 0;
                 r.e = (run.e >> (2 * c_state)) & 3;
-                block_maps[i0 + q] = r;
-                // the workgroup in which the K-th SNP completes: count-before < K <= count-after
+                win_maps[i0 + q] = r;
+                // the block in which the K-th SNP completes: count-before < K <= count-after
                 const uint32_t after = c_count + nxt.c[c_state];
                 if (r.c[0] < K && K <= after) { s_blk = i0 + q; s_bs = r.e; s_bc = r.c[0]; }
             }
@@ -780,15 +803,15 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut(const uint32_t *__
         c_state = n_state;
     }
     if (threadIdx.x == 0) {                               // totals after the whole window
-        block_maps[nb].c[0] = c_count;
-        block_maps[nb].c[1] = s_blk;
-        block_maps[nb].e = c_state;
+        win_maps[nb_max].c[0] = c_count;
+        win_maps[nb_max].c[1] = nb;
+        win_maps[nb_max].e = c_state;
         if (c_count < K) ps->flags |= FLAG_SNP_OVERFLOW;
     }
     if (c_count < K) return;                              // uniform
     const uint32_t b = s_blk, bs = s_bs, bc = s_bc;
-    const uint32_t wbase = b * SNP_BLOCK2;
-    const SnpBits m = snp_stage(raw, p0, wbase, W, ti_lim, sw);
+    const uint32_t wbase = (b0 + b) * SNP_BLOCK2;         // absolute
+    const SnpBits m = snp_stage(raw, 0ull, wbase, w_end, ti_lim, sw, b == 0 ? off : 0u);
     SnpMap tot2;
     const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, tot2);
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
@@ -799,26 +822,30 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut(const uint32_t *__
     if (idx < K && K <= idx + mine) {                     // the K-th SNP completes in this lane: on which word?
         uint32_t e = emits;
         for (uint32_t q = idx + 1; q < K; q++) e &= e - 1; // drop the first K - idx - 1 emits
-        const unsigned long long w0 = p0 + wbase + (unsigned long long)threadIdx.x * SNP_ITEMS2;
+        const unsigned long long w0 = (unsigned long long)wbase + (unsigned long long)threadIdx.x * SNP_ITEMS2;
         ps->pos = w0 + (unsigned long long)__builtin_ctz(e) + 1;
     }
 }
 
-// aux of every SNP record (off the critical path; runs on the emit stream)
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit(const uint32_t *__restrict__ raw,
-                                                          const unsigned long long *__restrict__ base_in, uint32_t W,
-                                                          unsigned long long ti_lim,
-                                                          const SnpMap *__restrict__ block_maps,
-                                                          msim_record *__restrict__ recs, uint32_t K,
-                                                          const uint32_t *__restrict__ sn_index) {
+// aux of every SNP record (off the critical path; runs on the emit stream).  Window block j = absolute block b0 + j.
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const uint32_t *__restrict__ raw,
+                                                              const unsigned long long *__restrict__ base_in, uint32_t W,
+                                                              unsigned long long ti_lim,
+                                                              const SnpMap *__restrict__ win_maps, uint32_t nb_max,
+                                                              msim_record *__restrict__ recs, uint32_t K,
+                                                              const uint32_t *__restrict__ sn_index) {
     __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
-    const uint32_t bc = block_maps[blockIdx.x].c[0];
+    if (blockIdx.x >= win_maps[nb_max].c[1]) return;      // beyond the window (uniform)
+    const uint32_t bc = win_maps[blockIdx.x].c[0];
     if (bc >= K) return;                                  // window slack beyond the last SNP (uniform)
-    const SnpBits m = snp_stage(raw, *base_in, blockIdx.x * SNP_BLOCK2, W, ti_lim, sw);
+    const unsigned long long p0 = *base_in;
+    const uint32_t b0 = (uint32_t)(p0 / SNP_BLOCK2), off = (uint32_t)(p0 % SNP_BLOCK2);
+    const uint32_t w_end = (uint32_t)min<unsigned long long>(p0 + W, 0xffffffffull);
+    const SnpBits m = snp_stage(raw, 0ull, (b0 + blockIdx.x) * SNP_BLOCK2, w_end, ti_lim, sw, blockIdx.x == 0 ? off : 0u);
     SnpMap total;
     const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
-    const uint32_t bs = block_maps[blockIdx.x].e;
+    const uint32_t bs = win_maps[blockIdx.x].e;
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
     uint32_t idx = bc + ex.c[bs];
     uint32_t emits, from2;
