@@ -118,6 +118,33 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
                         const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept,
                         long long *len_delta);
 
+// The same walk over per-class "next accepted draw" tables built on the device (plan_kernels.h: k_accept_tables):
+// a class is a distinct (getrandbits shift, randint width) pair among the range's IN/DE/DU/IV lengths, and
+// T[(w << lg_rows) + class] = (words consumed from w up to and including the first accepted draw) << (24 + lg_rows)
+// | value -- the top byte is the increment of the slot index w << lg_rows, so the walk never scales anything -- or 0
+// where no draw is accepted within CHAIN_TABLE_REACH words / the end of the window; w = 0..n_words.
+constexpr uint32_t CHAIN_TABLE_REACH = 63;                           // acceptance >= 1/2: 63 rejections in a row never happen
+struct ChainClasses { uint32_t n; uint32_t sh[4]; uint32_t width[4]; uint8_t cls_of[8]; };
+inline uint32_t chain_lg_rows(const ChainClasses &cc) { return cc.n <= 1 ? 0u : (cc.n == 2 ? 1u : 2u); }
+bool chain_classes(const msim_range &r, ChainClasses &cc);          // false: some length does not fit the table entry
+void accept_tables_host(const ChainClasses &cc, const uint32_t *words, size_t n_words, uint32_t *T);   // test support
+// The walk is resumable, so that the host can start on the first piece of the table while the rest is still being
+// copied: run() walks candidates [j, n) while the next position stays below w_lim (positions [0, w_lim) are valid).
+struct ChainWalk {
+    size_t j = 0, ws = 0, nk = 0, n_words = 0;                       // ws: next word position << lg_rows
+    int64_t delta = 0, blk_hi = 0, bad = 0;                          // last_mut_range = range(0)
+    uint32_t bad_type = 0;
+    int64_t add[8], blk1[8], clamp[8], drop_from[8], dsign[8], in_mask[8];
+    size_t row[8];
+    uint32_t lg_rows = 0;
+    int init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses &cc, size_t n_words);
+    void run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop);
+    int finish(Ctx *c, size_t n, size_t *consumed, size_t *kept, long long *len_delta) const;
+};
+int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
+                          const ChainClasses &cc, const uint32_t *T, size_t n_words, uint32_t *stop, size_t *consumed,
+                          size_t *kept, long long *len_delta);
+
 // random.sample() of every drawing range of a contig (util.py:94-109), reading tempered CPython-stream words
 // from `words` instead of generating them: set path and pool path, exact word consumption.  Writes the
 // candidate positions (start + value + d * rank, ascending per range) to pos_out.  For contigs with many

@@ -720,6 +720,24 @@ int msim_dbg_chain_boundary(msim_ctx *p, const msim_range *r, uint64_t L, const 
     return rc;
 }
 
+// The table walk (chain_boundary_tables) over tables built on the host from the same words: same arguments and results
+// as msim_dbg_chain_boundary; MSIM_ERR_UNSUPPORTED when the range's lengths do not fit a table entry.
+int msim_dbg_chain_boundary_tables(msim_ctx *p, const msim_range *r, uint64_t L, const uint32_t *pos, const uint8_t *type,
+                                   uint64_t n, const uint32_t *words, uint64_t n_words, uint32_t *stop, uint64_t *consumed,
+                                   uint64_t *kept, int64_t *len_delta) {
+    Ctx *c = C(p);
+    if (!c || !r || !consumed || !kept || !len_delta) return MSIM_ERR_ARG;
+    ChainClasses cc;
+    if (!chain_classes(*r, cc)) return MSIM_ERR_UNSUPPORTED;
+    std::vector<uint32_t> T((size_t)(n_words + 1) << chain_lg_rows(cc));
+    accept_tables_host(cc, words, (size_t)n_words, T.data());
+    size_t used = 0, nk = 0;
+    long long delta = 0;
+    const int rc = chain_boundary_tables(c, *r, L, pos, type, (size_t)n, cc, T.data(), (size_t)n_words, stop, &used, &nk, &delta);
+    *consumed = used; *kept = nk; *len_delta = delta;
+    return rc;
+}
+
 int msim_dbg_stream_status(msim_ctx *p, int out[8]) {
     Ctx *c = C(p);
     if (!c || !out || c->host_only || !c->gpu) return MSIM_ERR_ARG;

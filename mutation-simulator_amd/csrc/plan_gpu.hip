@@ -18,6 +18,7 @@
 // Everything else (translocations, overlapping ranges, ValueError cases) goes through plan_host.cpp.
 // DESIGN.md section 3 has the reasoning and the measurements.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -114,6 +115,11 @@ struct GpuPlan {
     uint32_t *d_poly = nullptr;
     PlanState *d_ps = nullptr;
     PlanState *h_mail = nullptr;        // pinned, device-visible mailbox
+    // handover without a stream synchronisation (SV mix): sequence number of the mailbox (never 0), written last
+    uint32_t *h_sig = nullptr;
+    uint32_t epoch = 0;
+    hipStream_t copy_stream = nullptr;  // candidates D2H beside the plan stream
+    hipEvent_t ev_cand = nullptr, ev_piece[3] = {};
     SampleSet sample[N_SETS];
     SnpSet snp[N_SETS];
     uint32_t unit = 0, snp_unit = 0;    // rotation counters
@@ -187,6 +193,10 @@ void gpu_plan_destroy(GpuPlan *g) {
     if (g->d_poly) (void)hipFree(g->d_poly);
     if (g->d_ps) (void)hipFree(g->d_ps);
     if (g->h_mail) (void)hipHostFree(g->h_mail);
+    if (g->h_sig) (void)hipHostFree(g->h_sig);
+    if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
+    if (g->ev_cand) (void)hipEventDestroy(g->ev_cand);
+    for (auto e : g->ev_piece) if (e) (void)hipEventDestroy(e);
     delete g;
 }
 
@@ -756,14 +766,60 @@ bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_range
     return true;
 }
 
-// plan stream drained: exact stream position + counts from the mailbox, chain time accounted
-static int mixed_sync(Ctx *c, GpuPlan *g, PlanState &h) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
-    MSIM_HIP(c, hipGetLastError());
+// Wait for a word in pinned host memory that a kernel on `s` raises to `want`.  The stream is queried now and then so
+// that a failed launch or a device fault ends the wait with an error instead of a hang.
+static int spin_until(Ctx *c, const uint32_t *word, uint32_t want, hipStream_t s) {
+    for (uint64_t it = 1;; it++) {
+        if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return MSIM_OK;
+        __builtin_ia32_pause();
+        if ((it & 0x3ffff) == 0) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) {
+                if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return MSIM_OK;
+                return fail(c, MSIM_ERR_HIP, "plan stream drained without raising its signal");
+            }
+            if (e != hipErrorNotReady) return hip_fail(c, e, "hipStreamQuery(plan stream)");
+        }
+    }
+}
+
+static int spin_event(Ctx *c, hipEvent_t ev) {
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return MSIM_OK;
+        if (e != hipErrorNotReady) return hip_fail(c, e, "hipEventQuery");
+        __builtin_ia32_pause();
+    }
+}
+
+static int ensure_signals(Ctx *c, GpuPlan *g) {
+    if (!g->h_sig) {
+        MSIM_HIP(c, hipHostMalloc(&g->h_sig, 4096, hipHostMallocMapped));
+        memset(g->h_sig, 0, 4096);
+    }
+    if (!g->copy_stream) {
+        MSIM_HIP(c, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+        MSIM_HIP(c, hipEventCreateWithFlags(&g->ev_cand, hipEventDisableTiming));
+        for (auto &e : g->ev_piece) MSIM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    return MSIM_OK;
+}
+
+// Exact stream position + counts from the mailbox, chain time accounted -- without draining the stream: the mailbox
+// kernel writes a sequence word last and the host polls it (a stream synchronisation costs 25-35 us of wake-up
+// latency per call, twice per contig)
+static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h) {
+    int rc = ensure_signals(c, g);
+    if (rc) return rc;
+    if (++g->epoch == 0) g->epoch = 1;
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(k_publish_seq, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail, g->h_sig, g->epoch);
+    MSIM_HIP(c, hipGetLastError());
+    if ((rc = spin_until(c, g->h_sig, g->epoch, c->stream))) return rc;
     float ms = 0;
-    MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
+    hipError_t e = hipEventElapsedTime(&ms, g->t0, g->t1);
+    if (e == hipErrorNotReady) { MSIM_HIP(c, hipEventSynchronize(g->t1)); e = hipEventElapsedTime(&ms, g->t0, g->t1); }
+    MSIM_HIP(c, e);
     c->t.plan_gpu_ms += ms;
     h = *g->h_mail;
     if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
@@ -818,6 +874,13 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     if ((rc = grow(c, (void **)&M.cand_stop, &M.cap_stop, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.nsn_pos, &M.cap_npos, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.nsn_type, &M.cap_ntype, (size_t)k + 64, &grew))) return rc;
+    if (g->cap_h_npos < (size_t)k * 4 + 64 || g->cap_h_ntype < (size_t)k + 64 || g->cap_h_nstop < (size_t)k * 4 + 64) {
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
+        if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+        if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)k * 4 + 64))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_ntype, &g->cap_h_ntype, (size_t)k + 64))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_nstop, &g->cap_h_nstop, (size_t)k * 4 + 64))) return rc;
+    }
     if ((rc = grow(c, (void **)&M.nsn_rank, &M.cap_nrank, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)k * 4 + 64, &grew))) return rc;
@@ -846,8 +909,27 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                        M.nsn_pos, M.nsn_type, M.nsn_rank, g->d_ps);
     MSIM_HIP(c, hipGetLastError());
     S.pending = false;                                     // consumed on the plan stream itself
+    // The host walks the non-SNP candidates.  Their copy starts at once, beside the plan stream and before their number
+    // is known here: a 16-sigma bound of the type draw's binomial is copied (the rest, if ever, afterwards).
+    if ((rc = ensure_signals(c, g))) return rc;
+    double q_nsn = 0;
+    for (int j = 0; j < r.n_types; j++) {
+        const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+        if (r.types[j] != MSIM_SN && r.cdf_thr[j] > lo && lo < (1ull << 53))
+            q_nsn += (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - lo) / 9007199254740992.0;
+    }
+    q_nsn = std::min(1.0, q_nsn);
+    const uint32_t n_hi = (uint32_t)std::min<double>(k, q_nsn * k + 16.0 * std::sqrt(q_nsn * (1.0 - q_nsn) * k) + 64.0);
+    {
+        hipEvent_t se = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(se, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(g->copy_stream, se, 0));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_npos, M.nsn_pos, (size_t)n_hi * 4, hipMemcpyDeviceToHost, g->copy_stream));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_hi, hipMemcpyDeviceToHost, g->copy_stream));
+        MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
+    }
     PlanState h;
-    if ((rc = mixed_sync(c, g, h))) return rc;
+    if ((rc = mixed_poll(c, g, h))) return rc;
     const uint32_t n_nsn = h.n_nsn;
     const uint64_t p_b = h.pos;                            // the boundary pass draws from here
     np.pos = np_base + 2ull * k;
@@ -857,30 +939,79 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     size_t consumed = 0, kept_nsn = 0;
     long long len_delta = 0;
     if (n_nsn) {
-        double acc_min = 1.0;
-        for (int t = 1; t <= 7; t++) {
+        double acc_min = 1.0;                              // least acceptance of randint among the types this range draws
+        for (int j = 0; j < r.n_types; j++) {
+            const int t = r.types[j];
+            if (t == MSIM_SN || !range_type_drawable(r, j)) continue;
             const int64_t w = r.max_len[t] - r.min_len[t] + 1;
             if (w >= 1 && w < (1ll << 32)) acc_min = std::min(acc_min, (double)w / (double)(1ull << bit_length64((uint64_t)w)));
         }
         const double wb = (double)n_nsn / acc_min + 16.0 * std::sqrt((double)n_nsn) / acc_min + 4096.0;
         if (wb >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "boundary window beyond 2^32 words");
         const uint32_t Wb = (uint32_t)wb;
-        if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)Wb * 4, &grew))) return rc;
-        if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)Wb * 4))) return rc;
-        if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)n_nsn * 4))) return rc;
-        if ((rc = grow_host(c, (void **)&g->h_ntype, &g->cap_h_ntype, (size_t)n_nsn))) return rc;
-        if ((rc = grow_host(c, (void **)&g->h_nstop, &g->cap_h_nstop, (size_t)n_nsn * 4))) return rc;
+        ChainClasses cc;
+        const bool tables = chain_classes(r, cc);          // the host walks "next accepted draw" tables (ctx.h)
+        const uint32_t lg = chain_lg_rows(cc);
+        const size_t words_bytes = tables ? ((size_t)(Wb + 1) << lg) * 4 : (size_t)Wb * 4;
+        if (g->cap_h_words < words_bytes) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, words_bytes))) return rc;
+        }
+        if ((rc = grow(c, (void **)&M.words, &M.cap_words, words_bytes, &grew))) return rc;
         if ((rc = ensure_words(c, g, 0, p_b + Wb + 1))) return rc;
-        hipLaunchKernelGGL(k_temper_window, dim3((Wb + 255) / 256), dim3(256), 0, c->stream, py.d_raw,
-                           (unsigned long long)p_b, Wb, M.words);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipMemcpyAsync(g->h_npos, M.nsn_pos, (size_t)n_nsn * 4, hipMemcpyDeviceToHost, c->stream));
-        MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_nsn, hipMemcpyDeviceToHost, c->stream));
-        MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)Wb * 4, hipMemcpyDeviceToHost, c->stream));
-        MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
-        if ((rc = span_close(c, g))) return rc;
-        rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop, &consumed, &kept_nsn, &len_delta);
+        if (n_nsn > n_hi) {                                // beyond 16 sigma: the rest of the candidates
+            MSIM_HIP(c, hipMemcpyAsync(g->h_npos + n_hi, M.nsn_pos + n_hi, (size_t)(n_nsn - n_hi) * 4, hipMemcpyDeviceToHost, g->copy_stream));
+            MSIM_HIP(c, hipMemcpyAsync(g->h_ntype + n_hi, M.nsn_type + n_hi, (size_t)(n_nsn - n_hi), hipMemcpyDeviceToHost, g->copy_stream));
+            MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
+        }
+        if (tables) {
+            // The table comes over in three pieces (1/8, 3/8, 1/2 of the positions); the walk starts on the first one
+            // while the others are in flight -- it consumes the table at ~3 GB/s, the copies deliver 50 GB/s.
+            const size_t n_slots = (size_t)(Wb + 1) << lg;
+            hipLaunchKernelGGL(k_accept_tables, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, py.d_raw,
+                               (unsigned long long)p_b, Wb, cc, lg, M.words);
+            MSIM_HIP(c, hipGetLastError());
+            const size_t cut[4] = {0, (size_t)(Wb + 1) / 8, (size_t)(Wb + 1) / 2, (size_t)Wb + 1};
+            for (int q = 0; q < 3; q++) {
+                if (cut[q + 1] > cut[q])
+                    MSIM_HIP(c, hipMemcpyAsync(g->h_words + (cut[q] << lg), M.words + (cut[q] << lg),
+                                               ((cut[q + 1] - cut[q]) << lg) * 4, hipMemcpyDeviceToHost, c->stream));
+                MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+            }
+            MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+            const auto w0 = std::chrono::steady_clock::now();
+            ChainWalk cw;
+            if ((rc = cw.init(c, r, ct.len, cc, Wb))) return rc;
+            static const bool prof = getenv("MSIM_CHAIN_PROF") != nullptr;
+            double t_wait = 0, t_run = 0;
+            auto tp = std::chrono::steady_clock::now();
+            auto lap = [&](double &acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::micro>(n - tp).count(); tp = n; };
+            rc = spin_event(c, g->ev_cand);
+            for (int q = 0; q < 3 && !rc; q++) {
+                if ((rc = spin_event(c, g->ev_piece[q]))) break;
+                lap(t_wait);
+                cw.run(g->h_npos, g->h_ntype, n_nsn, g->h_words, cut[q + 1], g->h_nstop);
+                lap(t_run);
+            }
+            if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows);
+            if (!rc) rc = cw.finish(c, n_nsn, &consumed, &kept_nsn, &len_delta);
+            c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+            if (!rc) {
+                MSIM_HIP(c, hipEventSynchronize(g->t1));   // long complete
+                rc = span_close(c, g);
+            }
+        } else {
+            hipLaunchKernelGGL(k_temper_window, dim3((Wb + 255) / 256), dim3(256), 0, c->stream, py.d_raw,
+                               (unsigned long long)p_b, Wb, M.words);
+            MSIM_HIP(c, hipGetLastError());
+            MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, words_bytes, hipMemcpyDeviceToHost, c->stream));
+            MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+            if ((rc = span_close(c, g))) return rc;
+            rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop,
+                                     &consumed, &kept_nsn, &len_delta);
+        }
         if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
         MSIM_HIP(c, hipEventRecord(g->t0, c->stream));    // the host chain is not GPU time
         MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_nsn * 4, hipMemcpyHostToDevice, c->stream));
@@ -899,7 +1030,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                        bmax, cnt_keep, cnt_sn, cnt_ins);
     hipLaunchKernelGGL(k_scan3_u32, dim3(3), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, nbk, g->d_ps);
     MSIM_HIP(c, hipGetLastError());
-    if ((rc = mixed_sync(c, g, h))) return rc;
+    if ((rc = mixed_poll(c, g, h))) return rc;
     const uint32_t n_rec = h.n_rec, n_sn = h.n_sn, pool_len = h.pool_len;
 
     // ---- 4. records, insert pool, SNP draws

@@ -254,6 +254,116 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
     return MSIM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same walk over "next accepted draw" tables.  In chain_boundary_host two branches mispredict all the
+// time with BASELINE's SV mix (a quarter of the candidates are blocked, a fifth of the words are rejected by
+// randint's retry loop), which is most of its ~4.5 ns per candidate.  The device can take the retry loop
+// out of the chain: for every word position w of the window and every distinct (shift, width) pair of the
+// range's types it finds the first accepted draw at or after w in parallel (plan_kernels.h:
+// k_accept_tables) and hands over  T[w][class] = (words consumed) << 24 | value.  The walk is then one
+// table load per candidate with a branch-free keep / drop: the loop-carried chain is  w -> T[w] -> w  and
+// blk_hi -> dropped -> blk_hi, about 8 cycles.
+bool chain_classes(const msim_range &r, ChainClasses &cc) {
+    cc = ChainClasses{};
+    for (int t : {MSIM_IN, MSIM_DE, MSIM_DU, MSIM_IV}) {
+        const int64_t w = r.max_len[t] - r.min_len[t] + 1;
+        if (w < 1 || w >= (1ll << 24)) return false;                 // value field of a table entry: 24 bits
+        if (r.min_len[t] < 1 || r.max_len[t] >= (1ll << 30)) return false;   // keeps 0 <= stop < 2^32 - 1 without a check
+        const uint32_t sh = (uint32_t)(32 - bit_length64((uint64_t)w));
+        uint32_t k = 0;
+        while (k < cc.n && !(cc.sh[k] == sh && cc.width[k] == (uint32_t)w)) k++;
+        if (k == cc.n) { cc.sh[k] = sh; cc.width[k] = (uint32_t)w; cc.n++; }
+        cc.cls_of[t] = (uint8_t)k;
+    }
+    return true;
+}
+
+// test support (msim_dbg_chain_boundary_tables): the tables the device kernel builds, from tempered words
+void accept_tables_host(const ChainClasses &cc, const uint32_t *words, size_t n_words, uint32_t *T) {
+    const uint32_t lg = chain_lg_rows(cc);
+    for (uint32_t k = 0; k < cc.n; k++) {
+        uint32_t nd = 0, nv = 0;
+        T[(n_words << lg) + k] = 0;
+        for (size_t i = n_words; i-- > 0;) {
+            const uint32_t v = words[i] >> cc.sh[k];
+            if (v < cc.width[k]) { nd = 1; nv = v; }
+            else if (nd && nd < CHAIN_TABLE_REACH) nd++;
+            else nd = 0;
+            T[(i << lg) + k] = (nd << lg) << 24 | (nd ? nv : 0u);
+        }
+    }
+}
+
+int ChainWalk::init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses &cc, size_t nw) {
+    const msim_params &P = c->params;
+    const int64_t last = (int64_t)L - 1;
+    if (L >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "table walk: contig of 2^31 or more bases");
+    *this = ChainWalk{};
+    n_words = nw;
+    // per type id (ids outside the boundary pass behave like a dropped candidate and are reported by finish)
+    for (int t = 0; t < 8; t++) {
+        const bool chain_type = t == MSIM_IN || t == MSIM_DE || t == MSIM_DU || t == MSIM_IV;
+        add[t] = chain_type ? r.min_len[t] - 1 : 0;
+        blk1[t] = 1 + P.block[t];
+        clamp[t] = (t == MSIM_DU || t == MSIM_DE) ? last : INT64_MAX;              // mutator.py:253-264
+        drop_from[t] = t == MSIM_IV ? last - r.max_len[MSIM_IV] : (chain_type ? INT64_MAX : INT64_MIN);  // :240-245
+        dsign[t] = t == MSIM_IN || t == MSIM_DU ? 1 : (t == MSIM_DE ? -1 : 0);     // mutator.py:343-399
+        in_mask[t] = t == MSIM_IN ? 0 : -1;                                        // an insert blocks from its position
+        row[t] = chain_type ? cc.cls_of[t] : 0;
+    }
+    lg_rows = chain_lg_rows(cc);
+    return MSIM_OK;
+}
+
+void ChainWalk::run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop) {
+    size_t jj = j, s_at = ws, kept = nk;
+    int64_t dl = delta, hi = blk_hi, bd = bad;
+    uint32_t bt = bad_type;
+    const size_t s_lim = w_lim << lg_rows;
+    for (; jj < n && s_at < s_lim; jj++) {
+        const int64_t p = pos[jj];
+        const int t = type[jj] & 7;
+        bt |= (uint32_t)(type[jj] > 7) | (uint32_t)(drop_from[t] == INT64_MIN);
+        const uint32_t e = (T + row[t])[s_at];                                     // the one load of the chain
+        const int64_t d = e >> 24, v = e & 0xffffff;                               // d: slot increment
+        const bool dropped = (p < hi) | (p >= drop_from[t]);                       // mutator.py:190-191, 240-245
+        int64_t km = (int64_t)dropped - 1;                                         // all ones: kept
+        asm("" : "+r"(km));                            // keep the compiler from turning the masks back into branches
+        int64_t s = p + add[t] + v;
+        s = s > clamp[t] ? clamp[t] : s;
+        stop[jj] = (uint32_t)s | (uint32_t)~km;                                    // CHAIN_DROPPED = all ones
+        const int64_t nb = ((s & in_mask[t]) | (p & ~in_mask[t])) + blk1[t];
+        hi = (nb & km) | (hi & ~km);
+        bd |= (d - 1) & km;                                                        // kept with d == 0: no accepted draw in reach
+        s_at += (size_t)(d & km);
+        dl += (dsign[t] * (s - p + 1)) & km;
+        kept += (size_t)(km & 1);
+    }
+    j = jj; ws = s_at; nk = kept; delta = dl; blk_hi = hi; bad = bd; bad_type = bt;
+}
+
+int ChainWalk::finish(Ctx *c, size_t n, size_t *consumed, size_t *kept, long long *len_delta) const {
+    if (bad_type) return fail(c, MSIM_ERR_ARG, "chain_boundary_tables: type outside IN/DE/DU/IV");
+    if (bad < 0 || j < n) return fail(c, MSIM_ERR_HIP, "boundary chain: word window overflowed its margin");
+    *consumed = ws >> lg_rows;
+    *kept = nk;
+    *len_delta = delta;
+    return MSIM_OK;
+}
+
+int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
+                          const ChainClasses &cc, const uint32_t *T, size_t n_words, uint32_t *stop, size_t *consumed,
+                          size_t *kept, long long *len_delta) {
+    const auto t0 = std::chrono::steady_clock::now();
+    ChainWalk cw;
+    int rc = cw.init(c, r, L, cc, n_words);
+    if (rc) return rc;
+    cw.run(pos, type, n, T, n_words + 1, stop);          // entry n_words is the end-of-window sentinel
+    rc = cw.finish(c, n, consumed, kept, len_delta);
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
                        size_t n_words, uint32_t *pos_out, size_t *consumed) {
     const auto t0 = std::chrono::steady_clock::now();

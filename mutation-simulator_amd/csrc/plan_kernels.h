@@ -166,17 +166,19 @@ __global__ __launch_bounds__(GEN_THREADS) void k_mt_generate(const uint32_t *__r
 
 // ------------------------------------------------------------------ generic u32 exclusive scan
 // in place over a[0..n), total to a[n]; single workgroup (these scans sit on the stream-position critical
-// path, so: 4 items per lane, wave scan by shuffles, two barriers per 4096 items)
-__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
-    __shared__ uint32_t wsum[16];
+// path, so: wave scan by shuffles, two barriers per round; a round covers 4096 items, or 16384 when more than
+// one round of 4096 would be needed -- the loads of a round are independent, so the longer round costs one
+// memory latency, not four)
+template <int ITEMS>
+__device__ __forceinline__ void scan_rounds(uint32_t *__restrict__ a, uint32_t n, uint32_t *wsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 4096) {
-        const uint32_t i0 = base + threadIdx.x * 4;
-        uint32_t v[4];
+    for (uint32_t base = 0; base < n; base += 1024 * ITEMS) {
+        const uint32_t i0 = base + threadIdx.x * ITEMS;
+        uint32_t v[ITEMS];
+        uint32_t mine = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) v[q] = i0 + q < n ? a[i0 + q] : 0;
-        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        for (int q = 0; q < ITEMS; q++) { v[q] = i0 + q < n ? a[i0 + q] : 0; mine += v[q]; }
         uint32_t incl = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uin
         }
         uint32_t run = pre + incl - mine;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < ITEMS; q++) {
             if (i0 + q < n) a[i0 + q] = run;
             run += v[q];
         }
@@ -202,6 +204,12 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uin
         __syncthreads();
     }
     if (threadIdx.x == 0) a[n] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t wsum[16];
+    if (n <= 4096) scan_rounds<4>(a, n, wsum);
+    else scan_rounds<16>(a, n, wsum);
 }
 
 // ------------------------------------------------------------------ 2. accepted draws, in order
@@ -1005,6 +1013,26 @@ __global__ __launch_bounds__(256) void k_temper_window(const uint32_t *__restric
     if (i < n) dst[i] = mt_temper(raw[p0 + i]);
 }
 
+// "Next accepted draw" tables for the host walk (ctx.h: ChainWalk).  One thread per (word position, class):
+// randint's retry loop, started at every position of the window at once.  A thread reads 1 / acceptance <= 2
+// words on average, all from L2 (the window was generated moments ago).  Layout: position-major, the classes of
+// a position side by side (1 << lg_rows slots), so that a prefix of the window is a contiguous block -- it is
+// copied to the host in pieces while the host already walks the first ones.
+__global__ __launch_bounds__(256) void k_accept_tables(const uint32_t *__restrict__ raw, unsigned long long p0, uint32_t n,
+                                                       ChainClasses cc, uint32_t lg_rows, uint32_t *__restrict__ T) {
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = slot >> lg_rows, k = slot & ((1u << lg_rows) - 1);
+    if (i > n || k >= cc.n) return;                        // entry n: the end-of-window sentinel
+    const uint32_t sh = cc.sh[k], width = cc.width[k];
+    uint32_t e = 0;
+    const uint32_t end = min(n, i + CHAIN_TABLE_REACH);
+    for (uint32_t q = i; q < end; q++) {
+        const uint32_t v = mt_temper(raw[p0 + q]) >> sh;
+        if (v < width) { e = ((q - i + 1) << lg_rows) << 24 | v; break; }
+    }
+    T[slot] = e;
+}
+
 __global__ __launch_bounds__(256) void k_stop_scatter(const uint32_t *__restrict__ nsn_rank,
                                                       const uint32_t *__restrict__ nsn_stop, uint32_t n_nsn,
                                                       uint32_t *__restrict__ cand_stop) {
@@ -1631,6 +1659,14 @@ __global__ __launch_bounds__(BM_THREADS) void k_walk_expand(uint64_t *__restrict
 __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
     *mailbox = *ps;
     __threadfence_system();
+}
+
+// the same for a host that polls instead of synchronising the stream: the sequence word is written last
+__global__ void k_publish_seq(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox,
+                              uint32_t *__restrict__ seq_word, uint32_t seq) {
+    *mailbox = *ps;
+    __threadfence_system();
+    __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {

@@ -144,6 +144,9 @@ def _dbg(lib):
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
     lib.msim_dbg_sample_ranges.restype = C.c_int
     lib.msim_dbg_sample_ranges.argtypes = [vp, C.POINTER(_ffi.Range), C.c_int, vp, C.c_uint64, vp, u64p]
+    lib.msim_dbg_chain_boundary_tables.restype = C.c_int
+    lib.msim_dbg_chain_boundary_tables.argtypes = [vp, C.POINTER(_ffi.Range), C.c_uint64, vp, vp, C.c_uint64, vp, C.c_uint64,
+                                                   vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]
     lib.msim_dbg_chain_boundary.restype = C.c_int
     lib.msim_dbg_chain_boundary.argtypes = [vp, C.POINTER(_ffi.Range), C.c_uint64, vp, vp, C.c_uint64, vp, C.c_uint64,
                                             vp, u64p, u64p, C.POINTER(C.c_int64)]
@@ -216,10 +219,47 @@ def test_host_range_sampler_equals_cpython_sample(seed, d):
     eng.close()
 
 
+def test_host_boundary_tables_report_short_window_and_foreign_type():
+    """The table walk fails like the plain one: a window that ends before the chain does is an error, not a short
+    read, and so is a candidate type that does not belong to the boundary pass."""
+    import ctypes as C
+    rs = np.random.RandomState(9)
+    L, n = 100_000, 2_000
+    pos = np.sort(rs.choice(np.arange(0, L - 1), size=n, replace=False)).astype(np.uint32)
+    types = rs.choice([2, 3, 4, 5], size=n).astype(np.uint8)
+    r = _ffi.Range()
+    r.start, r.stop, r.k = 0, L - 1, n
+    for t in (2, 3, 4, 5):
+        r.min_len[t], r.max_len[t] = 1, 5
+    words = rs.randint(0, 2**32, size=4 * n, dtype=np.uint64).astype(np.uint32)
+    eng = _host_engine({t: 1 for t in range(1, 8)})
+    lib = _dbg(eng.lib)
+    stop = np.zeros(n, dtype=np.uint32)
+    used, nk, dl = C.c_uint64(), C.c_uint64(), C.c_int64()
+
+    def run(fn, ty, nw):
+        return fn(eng.h, C.byref(r), L, C.c_void_p(pos.ctypes.data), C.c_void_p(ty.ctypes.data), n,
+                  C.c_void_p(words.ctypes.data), nw, C.c_void_p(stop.ctypes.data), C.byref(used), C.byref(nk), C.byref(dl))
+    for fn in (lib.msim_dbg_chain_boundary, lib.msim_dbg_chain_boundary_tables):
+        assert run(fn, types, len(words)) == 0
+        full = used.value
+        assert run(fn, types, full) == 0 and used.value == full           # the window may end exactly where the chain does
+        assert run(fn, types, full - 1) != 0
+        bad = types.copy()
+        bad[0] = 1                                                         # an SNP is not a boundary candidate
+        assert run(fn, bad, len(words)) != 0
+    r.max_len[5] = 1 << 25                                                 # width beyond a table entry's value field
+    assert run(lib.msim_dbg_chain_boundary_tables, types, len(words)) != 0
+    eng.close()
+
+
+@pytest.mark.parametrize("walker", ["words", "tables"])
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
-def test_host_boundary_chain_equals_cpython_randint(seed):
+def test_host_boundary_chain_equals_cpython_randint(seed, walker):
     """The boundary pass over non-SNP candidates (mutator.py:184-265) restated with CPython's randint:
-    same stops, same drops (blocked / inversion reaching the contig end), same words consumed, same length delta."""
+    same stops, same drops (blocked / inversion reaching the contig end), same words consumed, same length delta.
+    `words`: the plain walk over tempered words; `tables`: the walk over "next accepted draw" tables that the SV-mix
+    engine uses (built here on the host, on the device by k_accept_tables)."""
     import ctypes as C
     rs = np.random.RandomState(seed)
     L = 400_000
@@ -258,9 +298,9 @@ def test_host_boundary_chain_equals_cpython_randint(seed):
     lib = _dbg(eng.lib)
     stop = np.zeros(n, dtype=np.uint32)
     used, nk, dl = C.c_uint64(), C.c_uint64(), C.c_int64()
-    rc = lib.msim_dbg_chain_boundary(eng.h, C.byref(r), L, C.c_void_p(pos.ctypes.data), C.c_void_p(types.ctypes.data), n,
-                                     C.c_void_p(words.ctypes.data), len(words), C.c_void_p(stop.ctypes.data),
-                                     C.byref(used), C.byref(nk), C.byref(dl))
+    fn = lib.msim_dbg_chain_boundary if walker == "words" else lib.msim_dbg_chain_boundary_tables
+    rc = fn(eng.h, C.byref(r), L, C.c_void_p(pos.ctypes.data), C.c_void_p(types.ctypes.data), n,
+            C.c_void_p(words.ctypes.data), len(words), C.c_void_p(stop.ctypes.data), C.byref(used), C.byref(nk), C.byref(dl))
     assert rc == 0
     assert stop.tolist() == want
     assert nk.value == kept and dl.value == delta
