@@ -130,16 +130,18 @@ bool chain_classes(const msim_range &r, ChainClasses &cc);          // false: so
 void accept_tables_host(const ChainClasses &cc, const uint32_t *words, size_t n_words, uint32_t *T);   // test support
 // The walk is resumable, so that the host can start on the first piece of the table while the rest is still being
 // copied: run() walks candidates [j, n) while the next position stays below w_lim (positions [0, w_lim) are valid).
+// It writes stops only; the kept count and the length delta are summed where the stops are consumed (device:
+// k_keep_flags; chain_boundary_tables: a pass of its own).  types_ok() is the argument check the loop leaves out.
 struct ChainWalk {
-    size_t j = 0, ws = 0, nk = 0, n_words = 0;                       // ws: next word position << lg_rows
-    int64_t delta = 0, blk_hi = 0, bad = 0;                          // last_mut_range = range(0)
-    uint32_t bad_type = 0;
-    int64_t add[8], blk1[8], clamp[8], drop_from[8], dsign[8], in_mask[8];
+    size_t j = 0, ws = 0, n_words = 0;                               // ws: next word position << lg_rows
+    int64_t blk_hi = 0, bad = 0;                                     // last_mut_range = range(0)
+    int64_t add[8], next_add[8], next_cap[8], clamp[8], drop_from[8], in_mask[8];
     size_t row[8];
     uint32_t lg_rows = 0;
     int init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses &cc, size_t n_words);
+    static bool types_ok(const uint8_t *type, size_t n);
     void run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop);
-    int finish(Ctx *c, size_t n, size_t *consumed, size_t *kept, long long *len_delta) const;
+    int finish(Ctx *c, size_t n, size_t *consumed) const;
 };
 int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
                           const ChainClasses &cc, const uint32_t *T, size_t n_words, uint32_t *stop, size_t *consumed,

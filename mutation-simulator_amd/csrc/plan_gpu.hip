@@ -936,8 +936,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     c->t.np_words += 2ull * k;
 
     // ---- 2. the sequential chain over the non-SNP candidates, on the host
-    size_t consumed = 0, kept_nsn = 0;
-    long long len_delta = 0;
+    size_t consumed = 0;
     if (n_nsn) {
         double acc_min = 1.0;                              // least acceptance of randint among the types this range draws
         for (int j = 0; j < r.n_types; j++) {
@@ -987,6 +986,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             auto tp = std::chrono::steady_clock::now();
             auto lap = [&](double &acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::micro>(n - tp).count(); tp = n; };
             rc = spin_event(c, g->ev_cand);
+            if (!rc && !ChainWalk::types_ok(g->h_ntype, n_nsn)) rc = fail(c, MSIM_ERR_HIP, "boundary chain: candidate type outside IN/DE/DU/IV");
             for (int q = 0; q < 3 && !rc; q++) {
                 if ((rc = spin_event(c, g->ev_piece[q]))) break;
                 lap(t_wait);
@@ -994,7 +994,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 lap(t_run);
             }
             if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows);
-            if (!rc) rc = cw.finish(c, n_nsn, &consumed, &kept_nsn, &len_delta);
+            if (!rc) rc = cw.finish(c, n_nsn, &consumed);
             c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             if (!rc) {
                 MSIM_HIP(c, hipEventSynchronize(g->t1));   // long complete
@@ -1009,8 +1009,10 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
             MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
             if ((rc = span_close(c, g))) return rc;
+            size_t kept_host = 0;
+            long long delta_host = 0;                      // both are summed on the device, where the stops end up
             rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop,
-                                     &consumed, &kept_nsn, &len_delta);
+                                     &consumed, &kept_host, &delta_host);
         }
         if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
         MSIM_HIP(c, hipEventRecord(g->t0, c->stream));    // the host chain is not GPU time
@@ -1027,7 +1029,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     hipLaunchKernelGGL(k_blk_reduce, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt, bmax);
     hipLaunchKernelGGL(k_scan_max_u32, dim3(1), dim3(1024), 0, c->stream, bmax, nbk);
     hipLaunchKernelGGL(k_keep_flags, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt,
-                       bmax, cnt_keep, cnt_sn, cnt_ins);
+                       bmax, cnt_keep, cnt_sn, cnt_ins, g->d_ps);
     hipLaunchKernelGGL(k_scan3_u32, dim3(3), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, nbk, g->d_ps);
     MSIM_HIP(c, hipGetLastError());
     if ((rc = mixed_poll(c, g, h))) return rc;
@@ -1046,9 +1048,9 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     ct.n_rec = n_rec;
     ct.pool_len = pool_len;
     ct.plan_empty = n_rec == 0;
-    ct.all_snp = kept_nsn == 0;
+    ct.all_snp = h.n_rec == h.n_sn;
     ct.delta_known = true;
-    ct.known_delta = len_delta;
+    ct.known_delta = h.len_delta;
     if (pool_len && (rc = ensure_words(c, g, 1, np.pos + pool_len + 1))) return rc;
     uint64_t pos_hi = p_s;
     hipEvent_t ce = next_chain_event(g);

@@ -300,54 +300,81 @@ int ChainWalk::init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses 
     if (L >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "table walk: contig of 2^31 or more bases");
     *this = ChainWalk{};
     n_words = nw;
-    // per type id (ids outside the boundary pass behave like a dropped candidate and are reported by finish)
-    for (int t = 0; t < 8; t++) {
+    lg_rows = chain_lg_rows(cc);
+    for (int t = 0; t < 8; t++) {                          // ids outside the boundary pass: see types_ok
         const bool chain_type = t == MSIM_IN || t == MSIM_DE || t == MSIM_DU || t == MSIM_IV;
+        const int64_t blk1 = 1 + P.block[t];
         add[t] = chain_type ? r.min_len[t] - 1 : 0;
-        blk1[t] = 1 + P.block[t];
-        clamp[t] = (t == MSIM_DU || t == MSIM_DE) ? last : INT64_MAX;              // mutator.py:253-264
-        drop_from[t] = t == MSIM_IV ? last - r.max_len[MSIM_IV] : (chain_type ? INT64_MAX : INT64_MIN);  // :240-245
-        dsign[t] = t == MSIM_IN || t == MSIM_DU ? 1 : (t == MSIM_DE ? -1 : 0);     // mutator.py:343-399
-        in_mask[t] = t == MSIM_IN ? 0 : -1;                                        // an insert blocks from its position
+        clamp[t] = (t == MSIM_DU || t == MSIM_DE) ? last : (int64_t)1 << 40;       // mutator.py:253-264
+        drop_from[t] = t == MSIM_IV ? last - r.max_len[MSIM_IV] : INT64_MAX;       // mutator.py:240-245
+        // the next blocked end: min(p + next_add + value, next_cap); an insert blocks from its position, whatever it draws
+        in_mask[t] = t == MSIM_IN ? 0 : -1;
+        next_add[t] = (t == MSIM_IN ? 0 : add[t]) + blk1;
+        next_cap[t] = clamp[t] + blk1;
         row[t] = chain_type ? cc.cls_of[t] : 0;
     }
-    lg_rows = chain_lg_rows(cc);
     return MSIM_OK;
 }
 
-void ChainWalk::run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop) {
-    size_t jj = j, s_at = ws, kept = nk;
-    int64_t dl = delta, hi = blk_hi, bd = bad;
-    uint32_t bt = bad_type;
-    const size_t s_lim = w_lim << lg_rows;
-    for (; jj < n && s_at < s_lim; jj++) {
-        const int64_t p = pos[jj];
-        const int t = type[jj] & 7;
-        bt |= (uint32_t)(type[jj] > 7) | (uint32_t)(drop_from[t] == INT64_MIN);
-        const uint32_t e = (T + row[t])[s_at];                                     // the one load of the chain
-        const int64_t d = e >> 24, v = e & 0xffffff;                               // d: slot increment
-        const bool dropped = (p < hi) | (p >= drop_from[t]);                       // mutator.py:190-191, 240-245
-        int64_t km = (int64_t)dropped - 1;                                         // all ones: kept
-        asm("" : "+r"(km));                            // keep the compiler from turning the masks back into branches
-        int64_t s = p + add[t] + v;
-        s = s > clamp[t] ? clamp[t] : s;
-        stop[jj] = (uint32_t)s | (uint32_t)~km;                                    // CHAIN_DROPPED = all ones
-        const int64_t nb = ((s & in_mask[t]) | (p & ~in_mask[t])) + blk1[t];
-        hi = (nb & km) | (hi & ~km);
-        bd |= (d - 1) & km;                                                        // kept with d == 0: no accepted draw in reach
-        s_at += (size_t)(d & km);
-        dl += (dsign[t] * (s - p + 1)) & km;
-        kept += (size_t)(km & 1);
-    }
-    j = jj; ws = s_at; nk = kept; delta = dl; blk_hi = hi; bad = bd; bad_type = bt;
+bool ChainWalk::types_ok(const uint8_t *type, size_t n) {
+    uint32_t bad_type = 0;
+    for (size_t i = 0; i < n; i++) bad_type |= (uint32_t)(uint8_t)(type[i] - MSIM_IN) > (uint32_t)(MSIM_IV - MSIM_IN);
+    static_assert(MSIM_IN == 2 && MSIM_DE == 3 && MSIM_DU == 4 && MSIM_IV == 5, "boundary types are ids 2..5");
+    return !bad_type;
 }
 
-int ChainWalk::finish(Ctx *c, size_t n, size_t *consumed, size_t *kept, long long *len_delta) const {
-    if (bad_type) return fail(c, MSIM_ERR_ARG, "chain_boundary_tables: type outside IN/DE/DU/IV");
+// One candidate: the loop-carried state is (slot, hi); everything else hangs off the candidate index.  On the chain:
+// table load -> value -> blocked end -> select, and table load -> increment -> select; both selects hang on one compare
+// (x86: a cmp and two cmov -- the compiler turns the portable form into a branch that mispredicts every fourth time).
+#define MSIM_CHAIN_STEP()                                                                                      \
+    do {                                                                                                       \
+        const int64_t p = pos[jj];                                                                             \
+        const int t = type[jj] & 7;                                                                            \
+        const int64_t pe = p >= drop_from[t] ? -1 : p;                 /* mutator.py:240-245: never kept */    \
+        const int64_t a0 = p + next_add[t];                                                                    \
+        const int64_t cap = (next_cap[t] & in_mask[t]) | (a0 & ~in_mask[t]);                                   \
+        const uint32_t e = (T + row[t])[s_at];                         /* the one load of the chain */         \
+        const int64_t d = e >> 24, v = e & 0xffffff;                   /* d: slot increment */                 \
+        int64_t nb = a0 + v;                                                                                   \
+        nb = nb > cap ? cap : nb;                                                                              \
+        const int64_t s_next = s_at + d;                                                                       \
+        int64_t s = p + add[t] + v;                                                                            \
+        s = s > clamp[t] ? clamp[t] : s;                                                                       \
+        int64_t km = -(int64_t)(pe >= hi);                             /* all ones: kept (mutator.py:190-191) */ \
+        asm("" : "+r"(km));                                                                                    \
+        stop[jj] = (uint32_t)s | (uint32_t)~km;                        /* CHAIN_DROPPED = all ones */          \
+        bd |= (d - 1) & km;                                            /* kept with d == 0: no accepted draw in reach */ \
+        MSIM_CHAIN_SELECT();                                                                                   \
+    } while (0)
+#if defined(__x86_64__)
+#define MSIM_CHAIN_SELECT()                                                                                    \
+    asm("cmp %[hi], %[pe]\n\tcmovge %[nb], %[hi]\n\tcmovge %[sn], %[at]"                                       \
+        : [hi] "+r"(hi), [at] "+r"(s_at) : [pe] "r"(pe), [nb] "r"(nb), [sn] "r"(s_next) : "cc")
+#else
+#define MSIM_CHAIN_SELECT() do { hi = (nb & km) | (hi & ~km); s_at = (s_next & km) | (s_at & ~km); } while (0)
+#endif
+
+void ChainWalk::run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop) {
+    size_t jj = j;
+    int64_t s_at = (int64_t)ws, hi = blk_hi, bd = bad;
+    const int64_t s_lim = (int64_t)(w_lim << lg_rows);
+    constexpr int64_t RUN = 32, RUN_SLOTS = RUN * 256;                // a candidate advances at most 63 << 2 slots
+    while (jj < n && s_at < s_lim) {
+        if (jj + RUN <= n && s_at + RUN_SLOTS <= s_lim) {
+            for (const size_t je = jj + RUN; jj < je; jj++) MSIM_CHAIN_STEP();
+        } else {
+            MSIM_CHAIN_STEP();
+            jj++;
+        }
+    }
+    j = jj; ws = (size_t)s_at; blk_hi = hi; bad = bd;
+}
+#undef MSIM_CHAIN_STEP
+#undef MSIM_CHAIN_SELECT
+
+int ChainWalk::finish(Ctx *c, size_t n, size_t *consumed) const {
     if (bad < 0 || j < n) return fail(c, MSIM_ERR_HIP, "boundary chain: word window overflowed its margin");
     *consumed = ws >> lg_rows;
-    *kept = nk;
-    *len_delta = delta;
     return MSIM_OK;
 }
 
@@ -355,13 +382,24 @@ int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_
                           const ChainClasses &cc, const uint32_t *T, size_t n_words, uint32_t *stop, size_t *consumed,
                           size_t *kept, long long *len_delta) {
     const auto t0 = std::chrono::steady_clock::now();
+    if (!ChainWalk::types_ok(type, n)) return fail(c, MSIM_ERR_ARG, "chain_boundary_tables: type outside IN/DE/DU/IV");
     ChainWalk cw;
     int rc = cw.init(c, r, L, cc, n_words);
     if (rc) return rc;
     cw.run(pos, type, n, T, n_words + 1, stop);          // entry n_words is the end-of-window sentinel
-    rc = cw.finish(c, n, consumed, kept, len_delta);
+    if ((rc = cw.finish(c, n, consumed))) return rc;
+    size_t nk = 0;
+    long long delta = 0;                                   // IN +len, DE -len, DU +len, IV 0   (mutator.py:343-399)
+    for (size_t i = 0; i < n; i++) {
+        if (stop[i] == CHAIN_DROPPED) continue;
+        const long long len = (long long)stop[i] - pos[i] + 1;
+        delta += type[i] == MSIM_DE ? -len : (type[i] == MSIM_IV ? 0 : len);
+        nk++;
+    }
+    *kept = nk;
+    *len_delta = delta;
     c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return rc;
+    return MSIM_OK;
 }
 
 int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,

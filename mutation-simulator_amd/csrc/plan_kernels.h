@@ -40,6 +40,7 @@ struct PlanState {
     uint32_t n_nsn;                // SV mixes: non-SNP candidates of the current range
     uint32_t n_rec, n_sn;          // SV mixes: kept mutations / kept SNPs of the current contig
     uint32_t pool_len;             // SV mixes: insert bases of the current contig
+    long long len_delta;           // SV mixes: output length - input length of the current contig (kept IN/DU +len, DE -len)
 };
 
 // ------------------------------------------------------------------ 1. MT19937 in bulk
@@ -1099,7 +1100,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
                                                            const uint32_t *__restrict__ cand_stop, uint32_t k,
                                                            BlockTable bt, const uint32_t *__restrict__ bmax,
                                                            uint32_t *__restrict__ cnt_keep, uint32_t *__restrict__ cnt_sn,
-                                                           uint32_t *__restrict__ cnt_ins) {
+                                                           uint32_t *__restrict__ cnt_ins, PlanState *__restrict__ ps) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint32_t pos[CB_ITEMS], stop[CB_ITEMS], before[CB_ITEMS];
@@ -1117,15 +1118,23 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
     uint32_t total;
     const uint32_t pre = max(bmax[blockIdx.x], block_scan_max(run, wsum, total));
     uint32_t nk = 0, ns = 0, ni = 0;
+    long long delta = 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         if (i0 + q >= k) continue;
         bool keep;
         if (t[q] == MSIM_SN) { keep = pos[q] >= max(pre, before[q]); ns += keep ? 1u : 0u; }   // mutator.py:190-196
-        else { keep = stop[q] != CHAIN_DROPPED; if (keep && t[q] == MSIM_IN) ni += stop[q] - pos[q] + 1; }
+        else {
+            keep = stop[q] != CHAIN_DROPPED;
+            const uint32_t len = stop[q] - pos[q] + 1;
+            if (keep && t[q] == MSIM_IN) ni += len;
+            if (keep) delta += t[q] == MSIM_DE ? -(long long)len : (t[q] == MSIM_IV ? 0ll : (long long)len);   // mutator.py:343-399
+        }
         nk += keep ? 1u : 0u;
         if (keep) cand_type[i0 + q] = t[q] | KEEP_BIT;
     }
+    for (int o = 32; o > 0; o >>= 1) delta += __shfl_down(delta, o, 64);
+    if ((threadIdx.x & 63) == 0 && delta) atomicAdd((unsigned long long *)&ps->len_delta, (unsigned long long)delta);
     uint32_t tk, ts, ti;
     (void)block_scan_add(nk, wsum, tk);
     (void)block_scan_add(ns, wsum, ts);
@@ -1221,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_pool_fill(const uint32_t *__restrict__ 
     *reinterpret_cast<uint32_t *>(pool + g) = x;         // the pool buffer is padded: whole dwords are in bounds
 }
 
-__global__ void k_set_pos(PlanState *ps, unsigned long long pos) { ps->pos = pos; ps->snp_base = pos; }
+__global__ void k_set_pos(PlanState *ps, unsigned long long pos) { ps->pos = pos; ps->snp_base = pos; ps->len_delta = 0; }
 
 // ---- host-sampled contigs (many small ranges): the device still owns the streams
 // tempered words from the CURRENT device position on (the host needs no round trip to learn it)
@@ -1672,6 +1681,7 @@ __global__ void k_publish_seq(const PlanState *__restrict__ ps, PlanState *__res
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
     ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0;
     ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;
+    ps->len_delta = 0;
 }
 
 }  // namespace
