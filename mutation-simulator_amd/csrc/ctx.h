@@ -147,6 +147,12 @@ int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_
                           const ChainClasses &cc, const uint32_t *T, size_t n_words, uint32_t *stop, size_t *consumed,
                           size_t *kept, long long *len_delta);
 
+// The stream cuts of the same samples without the samples: cut[i] = first word of the i-th drawing range (k > 0),
+// cut[number of drawing ranges] = words consumed; pool_pos: start + value of every pool-path draw (sum of k over the
+// ranges with n <= setsize slots).  The device derives the set-path positions from the cuts (k_interval_bits).
+int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words, size_t n_words,
+                    uint32_t *cut, uint32_t *pool_pos, size_t *n_pool_pos, size_t *consumed);
+
 // random.sample() of every drawing range of a contig (util.py:94-109), reading tempered CPython-stream words
 // from `words` instead of generating them: set path and pool path, exact word consumption.  Writes the
 // candidate positions (start + value + d * rank, ascending per range) to pos_out.  For contigs with many

@@ -708,6 +708,19 @@ int msim_dbg_sample_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, 
     return rc;
 }
 
+// cut_ranges_host: cut[] needs one slot per drawing range (k > 0) plus one, pool_pos the sum of k over pool-path ranges
+int msim_dbg_cut_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, const uint32_t *words, uint64_t n_words,
+                        uint32_t *cut, uint32_t *pool_pos, uint64_t *n_pool_pos, uint64_t *consumed) {
+    Ctx *c = C(p);
+    if (!c || !consumed || !n_pool_pos || !cut || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    int64_t d = c->params.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, c->params.block[t]);
+    size_t used = 0, np = 0;
+    const int rc = cut_ranges_host(c, ranges, n_ranges, d, words, (size_t)n_words, cut, pool_pos, &np, &used);
+    *consumed = used; *n_pool_pos = np;
+    return rc;
+}
+
 int msim_dbg_chain_boundary(msim_ctx *p, const msim_range *r, uint64_t L, const uint32_t *pos, const uint8_t *type,
                             uint64_t n, const uint32_t *words, uint64_t n_words, uint32_t *stop, uint64_t *consumed,
                             uint64_t *kept, int64_t *len_delta) {

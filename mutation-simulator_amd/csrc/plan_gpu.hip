@@ -89,7 +89,8 @@ struct MixedSet {                        // scratch of one SV-mix range (section
     uint32_t *sn_index = nullptr; size_t cap_snidx = 0;   // kept-SNP ordinal -> record index
     uint32_t *cnt = nullptr; size_t cap_cnt = 0;          // five per-workgroup counter arrays
     uint32_t *words = nullptr; size_t cap_words = 0;      // tempered word window for the host chain
-    WalkRange *walk_d = nullptr; size_t cap_walk_d = 0;   // device-walked contigs: range table
+    unsigned long long *p0_slot = nullptr;                // host-cut contigs: stream position their window started at
+    WalkRange *walk_d = nullptr; size_t cap_walk_d = 0;   // device-walked / host-cut contigs: range table
     WalkRange *walk_h = nullptr; size_t cap_walk_h = 0;   //   its pinned staging (one per set: the copy is asynchronous)
     uint32_t *wbits = nullptr; size_t cap_wbits = 0;      //   contig-wide bitmap of sampled positions (zero between uses)
     bool wbits_dirty = false;                             //   a failed pass may have left bits behind
@@ -177,7 +178,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     }
     for (auto &t : g->mixed) {
         void *bufs[] = {t.cand_pos, t.cand_type, t.cand_stop, t.nsn_pos, t.nsn_type, t.nsn_rank, t.nsn_stop, t.sn_index,
-                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt};
+                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt, t.p0_slot};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (t.walk_h) (void)hipHostFree(t.walk_h);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
@@ -1129,14 +1130,16 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     }
     g->unverified = true;
     // word window: expected consumption of every sample + 16 sigma of the total
-    uint64_t K = 0;
+    uint64_t K = 0, K_pool = 0;
+    uint32_t n_draw = 0;
     double e_words = 0, var = 0;
     for (int i = 0; i < n_ranges; i++) {
         const msim_range &r = ranges[i];
         if (r.k == 0) continue;
+        n_draw++;
         const double k = (double)r.k, n = (double)((r.stop - (r.k - 1) * d) - r.start);
         K += (uint64_t)r.k;
-        if (n <= (double)r.setsize) { e_words += 2.0 * k; var += 2.0 * k; continue; }   // pool path: < 2 words per draw
+        if (n <= (double)r.setsize) { K_pool += (uint64_t)r.k; e_words += 2.0 * k; var += 2.0 * k; continue; }   // pool path: < 2 words per draw
         const double p_acc = n / (double)(1ull << bit_length64((uint64_t)n));
         const double need = k >= n ? 64.0 * k : -n * std::log1p(-k / n);                // coupon collector
         e_words += need / p_acc;
@@ -1148,11 +1151,38 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     bool grew = false;
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
     if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;
+    if (M.pending) {                                       // the pinned range table of this set may still be in flight
+        MSIM_HIP(c, hipEventSynchronize(M.emit_done));
+        M.pending = false;
+    }
     if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
+    // what the host hands back: one cut per drawing range (+ the end) and the pool-path positions
+    const size_t n_back = (size_t)n_draw + 1 + K_pool;
     if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4, &grew))) return rc;
-    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;
-    if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)W * 4))) return rc;
-    if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)K * 4 + 64))) return rc;   // the sampler writes up to 2 slots ahead
+    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, n_back * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.walk_d, &M.cap_walk_d, (size_t)n_draw * sizeof(WalkRange) + 64, &grew))) return rc;
+    if ((rc = grow_host(c, (void **)&M.walk_h, &M.cap_walk_h, (size_t)n_draw * sizeof(WalkRange) + 64))) return rc;
+    if (g->cap_h_words < (size_t)W * 4 || g->cap_h_npos < n_back * 4 + 64) {
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
+        if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)W * 4))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, n_back * 4 + 64))) return rc;
+    }
+    if (!M.p0_slot) MSIM_HIP(c, hipMalloc(&M.p0_slot, 64));
+    const uint32_t bmw = (uint32_t)((ct.len + 63) / 64);  // contig-wide bitmap, 64-bit words
+    const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
+    {
+        const size_t want = (size_t)bmw * 8 + 64;
+        if (M.cap_wbits < want) {
+            const size_t before = M.cap_wbits;
+            if ((rc = grow(c, (void **)&M.wbits, &M.cap_wbits, want, &grew))) return rc;
+            if (M.cap_wbits != before) MSIM_HIP(c, hipMemset(M.wbits, 0, M.cap_wbits));   // k_walk_expand leaves it zeroed
+        }
+        if (M.wbits_dirty) {
+            MSIM_HIP(c, hipMemsetAsync(M.wbits, 0, M.cap_wbits, c->stream));
+            M.wbits_dirty = false;
+        }
+    }
+    if ((rc = grow(c, (void **)&M.wcnt, &M.cap_wcnt, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
     {   // the record table may still be read by an earlier apply of this contig
         const size_t want = (size_t)K * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
@@ -1162,26 +1192,51 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
         if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
         if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
     }
+    {
+        uint32_t at = 0, base = 0;
+        for (int i = 0; i < n_ranges; i++) {
+            const msim_range &r = ranges[i];
+            if (r.k == 0) continue;
+            const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+            WalkRange w;
+            w.start = (uint32_t)r.start; w.k = (uint32_t)r.k; w.n = (uint32_t)n; w.rec_base = base;
+            w.pool = n <= r.setsize ? 1u : 0u;
+            M.walk_h[at++] = w;
+            base += (uint32_t)r.k;
+        }
+    }
     if ((rc = ensure_words(c, g, 0, py.pos + W + 1))) return rc;
     hipLaunchKernelGGL(k_temper_window_ps, dim3((W + 255) / 256), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W, M.words);
     MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, hipMemcpyAsync(M.walk_d, M.walk_h, (size_t)n_draw * sizeof(WalkRange), hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipEventSynchronize(g->t1));
     if ((rc = span_close(c, g))) return rc;
-    size_t consumed = 0;
-    rc = sample_ranges_host(c, ranges, n_ranges, d, g->h_words, W, g->h_npos, &consumed);
-    if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
+    // ---- the host finds the stream cuts (and samples the pool-path ranges); everything per position stays here
+    size_t consumed = 0, n_pool_pos = 0;
+    uint32_t *h_cut = g->h_npos, *h_pool = g->h_npos + n_draw + 1;
+    rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed);
+    if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; M.wbits_dirty = true; return rc; }
     MSIM_HIP(c, hipEventRecord(g->t0, c->stream));        // the host chain is not GPU time
-    MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_advance_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)consumed);
+    MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, ((size_t)n_draw + 1 + n_pool_pos) * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_advance_pos_save, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)consumed, M.p0_slot);
     MSIM_HIP(c, hipGetLastError());
-    {   // records on the emit stream: ordered after any earlier APPLY that still reads this contig's table
+    {   // records on the emit stream (ordered after any earlier APPLY that still reads this contig's table): the words of
+        // every range -> contig-wide bitmap -> sorted sample -> records
         hipEvent_t ce0 = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(ce0, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce0, 0));
-        hipLaunchKernelGGL(k_records_from_pos, dim3(((uint32_t)K + 255) / 256), dim3(256), 0, c->emit_stream, M.cand_pos,
-                           (uint32_t)K, ct.d_recs);
+        hipLaunchKernelGGL(k_interval_bits, dim3(((uint32_t)consumed + 255) / 256), dim3(256), 0, c->emit_stream, py.d_raw,
+                           M.p0_slot, (uint32_t)consumed, M.cand_pos, M.walk_d, n_draw, reinterpret_cast<uint32_t *>(M.wbits));
+        if (n_pool_pos)
+            hipLaunchKernelGGL(k_list_to_bits, dim3(((uint32_t)n_pool_pos + 255) / 256), dim3(256), 0, c->emit_stream,
+                               M.cand_pos + n_draw + 1, (uint32_t)n_pool_pos, reinterpret_cast<uint32_t *>(M.wbits));
+        hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                           reinterpret_cast<const uint64_t *>(M.wbits), bmw, M.wcnt);
+        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, M.wcnt, bnb);
+        hipLaunchKernelGGL(k_walk_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                           reinterpret_cast<uint64_t *>(M.wbits), bmw, M.wcnt, M.walk_d, n_draw, (uint32_t)d, ct.d_recs);
         MSIM_HIP(c, hipGetLastError());
     }
     ct.n_rec = K;

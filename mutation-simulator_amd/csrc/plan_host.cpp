@@ -12,6 +12,7 @@
 // draw order of mutator.py:318-471 (__mutate_sequence, __get_snp, __get_insert).
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 
 #include "ctx.h"
 
@@ -398,6 +399,98 @@ int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_
     }
     *kept = nk;
     *len_delta = delta;
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
+// The stream cuts of the same samples, and nothing else: where in the word window does each drawing range start?
+// random.sample's set path consumes words until k DISTINCT accepted draws have been seen, so the cut after a range
+// needs its duplicates -- a bitmap insert per accepted draw -- but not the sorted sample: the device recomputes the
+// accepted draws of [cut[i], cut[i+1]) itself, ORs them into a contig-wide bitmap and expands that into records
+// (plan_kernels.h: k_interval_bits, k_walk_expand).  The host leaves out the extraction, which was half of its
+// time per position, and hands 4 bytes per range to the device instead of 4 per position.
+// Pool-path ranges (n <= setsize: partial Fisher-Yates, util.py / CPython random.sample) are sampled here as before;
+// their positions (start + value, any order) go to pool_pos.
+int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words, size_t n_words,
+                    uint32_t *cut, uint32_t *pool_pos, size_t *n_pool_pos, size_t *consumed) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t w = 0, at = 0, np = 0;
+    static thread_local std::vector<uint64_t> bits;                 // all zero between ranges
+    static thread_local std::vector<uint32_t> accbuf;               // accepted draws of one round
+    std::vector<uint32_t> pool;
+    auto overflow = [&]() {
+        std::fill(bits.begin(), bits.end(), 0);
+        return fail(c, MSIM_ERR_HIP, "host sampler: word window overflowed its margin");
+    };
+    for (int ri = 0; ri < n_ranges; ri++) {
+        const msim_range &r = ranges[ri];
+        const int64_t k = r.k;
+        if (k == 0) continue;
+        const int64_t n = (r.stop - (k - 1) * d) - r.start;          // util.py:104
+        if (k < 0 || k > n) return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
+        if (n >= (1ll << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "sampling range of 2^32 or more positions");
+        if (w >= (1ull << 32)) return overflow();
+        cut[at++] = (uint32_t)w;
+        const uint32_t base = (uint32_t)r.start;
+        if (n <= r.setsize) {                                        // pool path: partial Fisher-Yates
+            pool.resize((size_t)n);
+            for (int64_t i = 0; i < n; i++) pool[(size_t)i] = (uint32_t)i;
+            for (int64_t i = 0; i < k; i++) {
+                const uint64_t m = (uint64_t)(n - i);
+                const int sh = 32 - bit_length64(m);
+                uint64_t v;
+                do { if (w >= n_words) return overflow(); v = words[w++] >> sh; } while (v >= m);
+                pool_pos[np++] = base + pool[(size_t)v];
+                pool[(size_t)v] = pool[(size_t)(n - i - 1)];
+            }
+            continue;
+        }
+        const int sh = 32 - bit_length64((uint64_t)n);
+        const size_t nw = ((size_t)n + 63) / 64;
+        if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
+        uint64_t *B = bits.data();
+        int64_t got = 0;
+        if (nw <= 131072) {                                          // bitmap in L1/L2: rounds (see sample_ranges_host)
+            const uint32_t nn = (uint32_t)n;
+            if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + 32);
+            uint32_t *buf = accbuf.data();
+            while (got < k) {
+                const size_t need = (size_t)(k - got);
+                const size_t w2 = collect_accepted(words, w, n_words, sh, nn, need, buf);
+                if (w2 == SIZE_MAX) return overflow();
+                w = w2;
+                for (size_t i = 0; i < need; i++) {
+                    const uint32_t v = buf[i];
+                    const size_t wi = v >> 6;
+                    const uint64_t m = 1ull << (v & 63);
+                    const uint64_t x = B[wi];
+                    got += (int64_t)!(x & m);
+                    B[wi] = x | m;
+                }
+            }
+        } else {                                                     // large bitmap: batch + prefetch (see sample_sorted)
+            uint32_t batch[64];
+            while (got < k) {
+                const int want = (int)std::min<int64_t>(64, k - got);
+                int nb = 0;
+                while (nb < want) {
+                    if (w >= n_words) return overflow();
+                    const uint64_t v = words[w++] >> sh;
+                    if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&B[v >> 6], 1, 0); }
+                }
+                for (int i = 0; i < nb; i++) {
+                    uint64_t &x = B[batch[i] >> 6];
+                    const uint64_t m = 1ull << (batch[i] & 63);
+                    if (!(x & m)) { x |= m; got++; }
+                }
+            }
+        }
+        memset(B, 0, nw * 8);
+    }
+    if (w >= (1ull << 32)) return overflow();
+    cut[at] = (uint32_t)w;
+    *n_pool_pos = np;
+    *consumed = w;
     c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSIM_OK;
 }

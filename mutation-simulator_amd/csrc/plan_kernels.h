@@ -1239,16 +1239,6 @@ __global__ __launch_bounds__(256) void k_temper_window_ps(const uint32_t *__rest
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = mt_temper(raw[ps->pos + i]);
 }
-__global__ void k_advance_pos(PlanState *ps, unsigned long long words) { ps->pos += words; ps->snp_base = ps->pos; }
-// candidate positions -> SNP records (stop = pos, mutator.py:199-200)
-__global__ __launch_bounds__(256) void k_records_from_pos(const uint32_t *__restrict__ pos, uint32_t n,
-                                                          msim_record *__restrict__ recs) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    msim_record r;
-    r.pos = pos[i]; r.stop = r.pos; r.extra = 0; r.type = MSIM_SN; r.aux = 0; r.rsv = 0;
-    recs[i] = r;
-}
 
 // ------------------------------------------------------------------ 7. chains of small samples on the device
 // An RMT file in the style of the reference's examples leaves thousands of drawing ranges per contig, a few hundred
@@ -1611,6 +1601,48 @@ __global__ __launch_bounds__(WK_THREADS) void k_sample_walk(const uint32_t *__re
         ps->pos = p0 + w;
         ps->snp_base = p0 + w;
     }
+}
+
+// Host-cut contigs (ctx.h: cut_ranges_host): the host found where each range's sample starts in the word window;
+// every word of [0, consumed) looks up its range (cuts ascend strictly: a drawing range consumes at least one word),
+// repeats the acceptance test and ORs start + value into the contig-wide bitmap -- duplicates collapse by themselves.
+// Words of pool-path ranges are skipped (their positions come from the host as a list, k_list_to_bits).
+__global__ __launch_bounds__(256) void k_interval_bits(const uint32_t *__restrict__ raw, const unsigned long long *__restrict__ p0_slot,
+                                                       uint32_t consumed, const uint32_t *__restrict__ cut,
+                                                       const WalkRange *__restrict__ ranges, uint32_t n_draw,
+                                                       uint32_t *__restrict__ bits) {
+    __shared__ uint32_t span[2];
+    const uint32_t first = blockIdx.x * 256, i = first + threadIdx.x;
+    if (threadIdx.x < 2) {                                 // ranges of the workgroup's first and last word
+        const uint32_t key = threadIdx.x ? min(first + 255u, consumed - 1) : first;
+        uint32_t lo = 0, hi = n_draw;                      // last r with cut[r] <= key
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cut[mid] <= key) lo = mid; else hi = mid;
+        }
+        span[threadIdx.x] = lo;
+    }
+    __syncthreads();
+    if (i >= consumed) return;
+    uint32_t lo = span[0], hi = span[1] + 1;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (cut[mid] <= i) lo = mid; else hi = mid;
+    }
+    const WalkRange R = ranges[lo];
+    if (R.pool) return;
+    const uint32_t v = mt_temper(raw[*p0_slot + i]) >> __clz(R.n);                 // 32 - bit_length(n)
+    if (v < R.n) {
+        const uint32_t b = R.start + v;
+        atomicOr(&bits[b >> 5], 1u << (b & 31));
+    }
+}
+
+// the position the window started at stays available to kernels that run beside the chain
+__global__ void k_advance_pos_save(PlanState *ps, unsigned long long words, unsigned long long *p0_slot) {
+    *p0_slot = ps->pos;
+    ps->pos += words;
+    ps->snp_base = ps->pos;
 }
 
 // unordered list of sampled positions -> bits of the contig-wide bitmap (bulk, off the chain)

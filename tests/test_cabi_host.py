@@ -142,6 +142,8 @@ def test_host_planner_vcf_matches_reference(name, tmp_path):
 def _dbg(lib):
     import ctypes as C
     vp, u64p = C.c_void_p, C.POINTER(C.c_uint64)
+    lib.msim_dbg_cut_ranges.restype = C.c_int
+    lib.msim_dbg_cut_ranges.argtypes = [vp, C.POINTER(_ffi.Range), C.c_int, vp, C.c_uint64, vp, vp, u64p, u64p]
     lib.msim_dbg_sample_ranges.restype = C.c_int
     lib.msim_dbg_sample_ranges.argtypes = [vp, C.POINTER(_ffi.Range), C.c_int, vp, C.c_uint64, vp, u64p]
     lib.msim_dbg_chain_boundary_tables.restype = C.c_int
@@ -215,6 +217,63 @@ def test_host_range_sampler_equals_cpython_sample(seed, d):
     # a window that is too short is reported, never silently truncated
     rc = lib.msim_dbg_sample_ranges(eng.h, arr, len(ranges), C.c_void_p(words.ctypes.data), used.value - 1,
                                     C.c_void_p(got.ctypes.data), C.byref(used))
+    assert rc != 0
+    eng.close()
+
+
+@pytest.mark.parametrize("seed,d", [(1, 1), (2, 1), (3, 3), (4, 2)])
+def test_host_range_cuts_reproduce_cpython_sample(seed, d):
+    """The host-cut engine's host half: only WHERE each random.sample() starts in the word stream (plus the pool-path
+    draws).  Replaying the device half here -- accepted draws of [cut[i], cut[i+1]) as a set, sorted, + d * rank
+    (k_interval_bits / k_walk_expand) -- must give CPython's positions, and the cuts CPython's word consumption."""
+    import ctypes as C
+    rs = np.random.RandomState(seed)
+    ranges, at = [], 0
+    for i in range(300):
+        length = int(rs.choice([12, 40, 300, 1000, 5000, 60_000, 700_000]))
+        rate = float(rs.choice([0.001, 0.01, 0.05, 0.2, 0.3]))
+        k = int(length * rate)
+        n = (at + length - 1 - (k - 1) * d) - at
+        if k > 0 and n >= k:
+            ranges.append(_snp_only_range(at, at + length - 1, k))
+        at += length + int(rs.randint(1, 500))
+    K = sum(r.k for r in ranges)
+    ref = random.Random(seed)
+    clone = random.Random(seed)
+    words = np.array([clone.getrandbits(32) for _ in range(3 * K + 100_000)], dtype=np.uint32)
+    want = []
+    for r in ranges:
+        n = (r.stop - (r.k - 1) * d) - r.start
+        vals = sorted(ref.sample(range(n), r.k))                                       # util.py:104-109
+        want.append([r.start + v + d * i for i, v in enumerate(vals)])
+    nxt = ref.getrandbits(32)
+    eng = _host_engine({t: d for t in range(1, 8)})
+    lib = _dbg(eng.lib)
+    is_pool = [(r.stop - (r.k - 1) * d) - r.start <= r.setsize for r in ranges]
+    assert any(is_pool) and not all(is_pool)
+    cut = np.zeros(len(ranges) + 1, dtype=np.uint32)
+    pool = np.zeros(sum(r.k for r, p in zip(ranges, is_pool) if p) + 8, dtype=np.uint32)
+    used, n_pool = C.c_uint64(), C.c_uint64()
+    arr = (_ffi.Range * len(ranges))(*ranges)
+    rc = lib.msim_dbg_cut_ranges(eng.h, arr, len(ranges), C.c_void_p(words.ctypes.data), len(words),
+                                 C.c_void_p(cut.ctypes.data), C.c_void_p(pool.ctypes.data), C.byref(n_pool), C.byref(used))
+    assert rc == 0
+    assert int(words[used.value]) == nxt and int(cut[-1]) == used.value
+    assert np.all(np.diff(cut.astype(np.int64)) > 0)
+    pool_at = 0
+    for i, r in enumerate(ranges):
+        n = (r.stop - (r.k - 1) * d) - r.start
+        if is_pool[i]:
+            vals = np.sort(pool[pool_at:pool_at + r.k].astype(np.int64))
+            pool_at += r.k
+        else:
+            w = words[cut[i]:cut[i + 1]] >> np.uint32(32 - int(n).bit_length())
+            vals = np.unique(w[w < n]).astype(np.int64) + r.start
+        assert len(vals) == r.k
+        assert (vals + d * np.arange(r.k)).tolist() == want[i]
+    assert pool_at == n_pool.value
+    rc = lib.msim_dbg_cut_ranges(eng.h, arr, len(ranges), C.c_void_p(words.ctypes.data), used.value - 1,
+                                 C.c_void_p(cut.ctypes.data), C.c_void_p(pool.ctypes.data), C.byref(n_pool), C.byref(used))
     assert rc != 0
     eng.close()
 
