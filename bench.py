@@ -337,11 +337,11 @@ def main():
         owned = mine if owned is None else owned
         step_seed = seed if step_seed is None else step_seed
         sim = build_settings(workload, lengths)
-        descs = {}                   # msim_range descriptors per contig: settings -> integers once, outside the timed steps
+        descs = {}                   # msim_range table per contig: settings -> integers once, outside the timed steps
 
         def plan_descs(chrom):
             if chrom.number not in descs:
-                descs[chrom.number] = mm.plan_descriptors(chrom)
+                descs[chrom.number] = eng.range_table(mm.plan_descriptors(chrom))
             return descs[chrom.number]
         eng.set_params(mm.params_descriptor(sim))
 

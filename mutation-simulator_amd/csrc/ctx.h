@@ -150,8 +150,10 @@ int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_
 // The stream cuts of the same samples without the samples: cut[i] = first word of the i-th drawing range (k > 0),
 // cut[number of drawing ranges] = words consumed; pool_pos: start + value of every pool-path draw (sum of k over the
 // ranges with n <= setsize slots).  The device derives the set-path positions from the cuts (k_interval_bits).
+// feed (optional): the window is still arriving -- more() blocks until further words are there and raises *avail.
+struct WordFeed { int (*more)(void *user, size_t *avail); void *user; };
 int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words, size_t n_words,
-                    uint32_t *cut, uint32_t *pool_pos, size_t *n_pool_pos, size_t *consumed);
+                    uint32_t *cut, uint32_t *pool_pos, size_t *n_pool_pos, size_t *consumed, const WordFeed *feed = nullptr);
 
 // random.sample() of every drawing range of a contig (util.py:94-109), reading tempered CPython-stream words
 // from `words` instead of generating them: set path and pool path, exact word consumption.  Writes the

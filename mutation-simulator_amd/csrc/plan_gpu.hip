@@ -1113,6 +1113,9 @@ bool gpu_plan_hostsample_eligible(const Ctx *c, const msim_range *ranges, int n_
 }
 
 int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
+    static const bool prof = getenv("MSIM_CHAIN_PROF") != nullptr;
+    static std::chrono::steady_clock::time_point last_exit;
+    const auto tp0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;
     int64_t d = P.block[1];
     for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
@@ -1208,16 +1211,38 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     if ((rc = ensure_words(c, g, 0, py.pos + W + 1))) return rc;
     hipLaunchKernelGGL(k_temper_window_ps, dim3((W + 255) / 256), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W, M.words);
     MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, (size_t)W * 4, hipMemcpyDeviceToHost, c->stream));
+    // the window comes over in three pieces (1/8, 3/8, 1/2); the host starts on the first while the others are in flight
+    if ((rc = ensure_signals(c, g))) return rc;
+    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0};
+    for (int q = 0; q < 3; q++) {
+        if (fd.cut[q + 1] > fd.cut[q])
+            MSIM_HIP(c, hipMemcpyAsync(g->h_words + fd.cut[q], M.words + fd.cut[q], (fd.cut[q + 1] - fd.cut[q]) * 4,
+                                       hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+    }
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
     MSIM_HIP(c, hipMemcpyAsync(M.walk_d, M.walk_h, (size_t)n_draw * sizeof(WalkRange), hipMemcpyHostToDevice, c->stream));
-    MSIM_HIP(c, hipEventSynchronize(g->t1));
-    if ((rc = span_close(c, g))) return rc;
+    const auto tp1 = std::chrono::steady_clock::now();
+    const auto tp2 = tp1;
     // ---- the host finds the stream cuts (and samples the pool-path ranges); everything per position stays here
     size_t consumed = 0, n_pool_pos = 0;
     uint32_t *h_cut = g->h_npos, *h_pool = g->h_npos + n_draw + 1;
-    rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed);
+    WordFeed feed;
+    feed.user = &fd;
+    feed.more = [](void *u, size_t *avail) -> int {
+        Feed &f = *static_cast<Feed *>(u);
+        if (f.next >= 3) return MSIM_OK;
+        const int rc = spin_event(f.c, f.g->ev_piece[f.next]);
+        if (!rc) *avail = f.cut[++f.next];
+        return rc;
+    };
+    rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed, &feed);
+    if (!rc) {
+        MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned window is free again
+        rc = span_close(c, g);
+    }
     if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; M.wbits_dirty = true; return rc; }
+    const auto tp3 = std::chrono::steady_clock::now();
     MSIM_HIP(c, hipEventRecord(g->t0, c->stream));        // the host chain is not GPU time
     MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, ((size_t)n_draw + 1 + n_pool_pos) * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_advance_pos_save, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)consumed, M.p0_slot);
@@ -1253,6 +1278,13 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k) per drawing range
     c->t.np_words += 2 * K;
     ct.planned = true;
+    if (prof) {
+        const auto tp4 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "hostcut: n_draw %u K %llu W %u | outside %.0f setup %.0f wait %.0f cut %.0f post %.0f us\n", n_draw, (unsigned long long)K, W,
+                us(last_exit, tp0), us(tp0, tp1), us(tp1, tp2), us(tp2, tp3), us(tp3, tp4));
+        last_exit = tp4;
+    }
     return MSIM_OK;
 }
 

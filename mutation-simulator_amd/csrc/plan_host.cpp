@@ -412,15 +412,22 @@ int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_
 // Pool-path ranges (n <= setsize: partial Fisher-Yates, util.py / CPython random.sample) are sampled here as before;
 // their positions (start + value, any order) go to pool_pos.
 int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words, size_t n_words,
-                    uint32_t *cut, uint32_t *pool_pos, size_t *n_pool_pos, size_t *consumed) {
+                    uint32_t *cut, uint32_t *pool_pos, size_t *n_pool_pos, size_t *consumed, const WordFeed *feed) {
     const auto t0 = std::chrono::steady_clock::now();
     size_t w = 0, at = 0, np = 0;
+    size_t avail = feed ? 0 : n_words;                               // words [0, avail) have arrived
     static thread_local std::vector<uint64_t> bits;                 // all zero between ranges
-    static thread_local std::vector<uint32_t> accbuf;               // accepted draws of one round
+    static thread_local std::vector<uint32_t> accbuf;               // accepted draws of a range (all rounds)
     std::vector<uint32_t> pool;
+    int rc_feed = MSIM_OK;
     auto overflow = [&]() {
         std::fill(bits.begin(), bits.end(), 0);
-        return fail(c, MSIM_ERR_HIP, "host sampler: word window overflowed its margin");
+        return rc_feed ? rc_feed : fail(c, MSIM_ERR_HIP, "host sampler: word window overflowed its margin");
+    };
+    auto more = [&]() {                                              // false: nothing more will come
+        if (!feed || avail >= n_words) return false;
+        rc_feed = feed->more(feed->user, &avail);
+        return rc_feed == MSIM_OK;
     };
     for (int ri = 0; ri < n_ranges; ri++) {
         const msim_range &r = ranges[ri];
@@ -439,53 +446,59 @@ int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, c
                 const uint64_t m = (uint64_t)(n - i);
                 const int sh = 32 - bit_length64(m);
                 uint64_t v;
-                do { if (w >= n_words) return overflow(); v = words[w++] >> sh; } while (v >= m);
+                do {
+                    while (w >= avail) if (!more()) return overflow();
+                    v = words[w++] >> sh;
+                } while (v >= m);
                 pool_pos[np++] = base + pool[(size_t)v];
                 pool[(size_t)v] = pool[(size_t)(n - i - 1)];
             }
             continue;
         }
+        // set path.  Rounds (the rule of the device sampler's tail): the next k - got accepted draws are consumed in any
+        // case -- each adds at most one distinct value -- so they are collected in bulk (vectorised filter) and only
+        // then meet the bitmap; the stream position stays exact.
         const int sh = 32 - bit_length64((uint64_t)n);
         const size_t nw = ((size_t)n + 63) / 64;
         if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
         uint64_t *B = bits.data();
+        const uint32_t nn = (uint32_t)n;
+        const bool far = nw > 4096;                                  // bitmap beyond L1: prefetch ahead of the inserts
+        const bool sweep = nw <= 32768;                              // clear by memset (256 KB); larger ones draw by draw
         int64_t got = 0;
-        if (nw <= 131072) {                                          // bitmap in L1/L2: rounds (see sample_ranges_host)
-            const uint32_t nn = (uint32_t)n;
-            if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + 32);
-            uint32_t *buf = accbuf.data();
-            while (got < k) {
-                const size_t need = (size_t)(k - got);
-                const size_t w2 = collect_accepted(words, w, n_words, sh, nn, need, buf);
-                if (w2 == SIZE_MAX) return overflow();
-                w = w2;
+        size_t held = 0;                                             // accepted draws kept for the clearing pass
+        while (got < k) {
+            const size_t need = (size_t)(k - got);
+            if (accbuf.size() < held + need + 32) accbuf.resize(held + need + need / 2 + 1024);
+            uint32_t *buf = accbuf.data() + held;
+            size_t w2;
+            while ((w2 = collect_accepted(words, w, avail, sh, nn, need, buf)) == SIZE_MAX)
+                if (!more()) return overflow();
+            w = w2;
+            if (far) {
+                constexpr size_t AHEAD = 24;
+                for (size_t i = 0; i < std::min(AHEAD, need); i++) __builtin_prefetch(&B[buf[i] >> 6], 1, 0);
+                for (size_t i = 0; i < need; i++) {
+                    if (i + AHEAD < need) __builtin_prefetch(&B[buf[i + AHEAD] >> 6], 1, 0);
+                    const uint32_t v = buf[i];
+                    const uint64_t m = 1ull << (v & 63);
+                    const uint64_t x = B[v >> 6];
+                    got += (int64_t)!(x & m);
+                    B[v >> 6] = x | m;
+                }
+            } else {
                 for (size_t i = 0; i < need; i++) {
                     const uint32_t v = buf[i];
-                    const size_t wi = v >> 6;
                     const uint64_t m = 1ull << (v & 63);
-                    const uint64_t x = B[wi];
+                    const uint64_t x = B[v >> 6];
                     got += (int64_t)!(x & m);
-                    B[wi] = x | m;
+                    B[v >> 6] = x | m;
                 }
             }
-        } else {                                                     // large bitmap: batch + prefetch (see sample_sorted)
-            uint32_t batch[64];
-            while (got < k) {
-                const int want = (int)std::min<int64_t>(64, k - got);
-                int nb = 0;
-                while (nb < want) {
-                    if (w >= n_words) return overflow();
-                    const uint64_t v = words[w++] >> sh;
-                    if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&B[v >> 6], 1, 0); }
-                }
-                for (int i = 0; i < nb; i++) {
-                    uint64_t &x = B[batch[i] >> 6];
-                    const uint64_t m = 1ull << (batch[i] & 63);
-                    if (!(x & m)) { x |= m; got++; }
-                }
-            }
+            if (!sweep) held += need;
         }
-        memset(B, 0, nw * 8);
+        if (sweep) memset(B, 0, nw * 8);
+        else for (size_t i = 0; i < held; i++) B[accbuf[i] >> 6] = 0;
     }
     if (w >= (1ull << 32)) return overflow();
     cut[at] = (uint32_t)w;

@@ -261,9 +261,16 @@ class Engine:
     def set_params(self, params: Params):
         self._check(self.lib.msim_set_params(self.h, C.byref(params)))
 
-    def plan_contig(self, contig: int, ranges: list):
+    @staticmethod
+    def range_table(ranges: list):
+        """The ctypes array `plan_contig` passes on; a caller that plans the same contig repeatedly may build it once."""
         arr = (Range * max(len(ranges), 1))(*ranges)
-        self._check(self.lib.msim_plan_contig(self.h, contig, arr, len(ranges)), contig)
+        arr.n_ranges = len(ranges)
+        return arr
+
+    def plan_contig(self, contig: int, ranges):
+        arr = ranges if isinstance(ranges, C.Array) else self.range_table(ranges)
+        self._check(self.lib.msim_plan_contig(self.h, contig, arr, arr.n_ranges), contig)
 
     def plan_was_empty(self, contig: int) -> bool:
         e = C.c_int()
