@@ -156,8 +156,8 @@ int msim_plan_was_empty(msim_ctx *ctx, int contig, int *empty);
 /* ---- APPLY: Mutator.__mutate_sequence (mutator.py:318-426) -------------------------------------- */
 /* Execution model: msim_plan_contig (SNP sampler engine) and msim_apply_contig (device-planned tables) only
  * ENQUEUE work -- the chain that fixes stream positions on one HIP stream, record emission and the rewrite
- * kernel on another, overlapping the next contig's chain.  (The SV-mix and host-sampled engines synchronise
- * inside msim_plan_contig, where the host walks its chain.)  Deferred outcomes (the reference's KeyError, an
+ * kernel on another, overlapping the next contig's chain.  (The SV-mix and host-cut engines wait inside
+ * msim_plan_contig for the device data their host chain reads -- the boundary walk, the stream cuts.)  Deferred outcomes (the reference's KeyError, an
  * internal window overflow) are reported by the next call that synchronises: msim_sync,
  * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats, the text calls. */
 int msim_apply_contig(msim_ctx *ctx, int contig);

@@ -14,7 +14,7 @@
 // how much of the decision logic is a sequential chain that the host has to walk (over device-generated words):
 //   plan_contig_gpu            SNP sampler: nothing (fully asynchronous)            -- BASELINE config 2
 //   plan_contig_gpu_mixed      SV mix: the boundary chain over non-SNP candidates   -- BASELINE configs 3, 5
-//   plan_contig_gpu_hostsample many small deterministic-SNP ranges: the sample chain -- BASELINE config 4
+//   plan_contig_gpu_hostsample many small deterministic-SNP ranges: the stream cuts   -- BASELINE config 4
 // Everything else (translocations, overlapping ranges, ValueError cases) goes through plan_host.cpp.
 // DESIGN.md section 3 has the reasoning and the measurements.
 #include <algorithm>
@@ -1077,11 +1077,13 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
 }
 
 
-// ====================================================================== host-sampled contigs
+// ====================================================================== host-cut contigs
 // Deterministic-SNP ranges of any size and number (RMT gene-blocking files: thousands of small ranges per
 // contig, pool-path hot spots): the stream cuts form a chain of thousands of tiny data-dependent samples,
-// so the host walks them (plan_host.cpp: sample_ranges_host) -- but over words the DEVICE generated, and
-// everything per record (records, the SNP transducer of section 5, APPLY) stays on the device.
+// so the host finds them (plan_host.cpp: cut_ranges_host) -- over words the DEVICE generated, and nothing
+// but the cuts: the device repeats the acceptance test over every range's interval, builds the sorted sample
+// in a contig-wide bitmap and from it the records (k_interval_bits, k_walk_expand); the SNP transducer of
+// section 5 and APPLY follow as for every other engine.
 static bool range_is_deterministic_sn(const msim_range &r) {
     if (r.n_types < 1 || r.n_types > 8) return false;
     int zeros = 0;
