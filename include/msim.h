@@ -116,6 +116,10 @@ void msim_destroy(msim_ctx *ctx);                                     /* Mutator
 const char *msim_last_error(const msim_ctx *ctx);                     /* "" when none; ctx may be NULL  */
 int  msim_device_name(const msim_ctx *ctx, char *dst, int cap);
 int  msim_sync(msim_ctx *ctx);
+/* Change the PLAN mode of a live context (0 = AUTO, MSIM_PLAN_HOST, MSIM_PLAN_GPU).  The host package uses it to
+ * re-plan a contig through the sequential host planner when a device engine reports that a stream window
+ * overflowed its 16-sigma margin (the streams are put back with msim_set_mt_state first).                    */
+int  msim_set_plan_mode(msim_ctx *ctx, uint32_t mode);
 
 /* ---- the two global RNGs the reference draws from ---------------------------------------------- */
 /* random.seed(int) == init_by_array(little-endian 32-bit limbs of abs(seed));

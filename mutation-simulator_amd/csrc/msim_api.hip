@@ -398,6 +398,14 @@ int msim_set_params(msim_ctx *p, const msim_params *params) {
     return MSIM_OK;
 }
 
+int msim_set_plan_mode(msim_ctx *p, uint32_t mode) {
+    Ctx *c = C(p);
+    if (!c || (mode & ~(MSIM_PLAN_HOST | MSIM_PLAN_GPU)) || mode == (MSIM_PLAN_HOST | MSIM_PLAN_GPU)) return MSIM_ERR_ARG;
+    if ((mode & MSIM_PLAN_GPU) && c->host_only) return fail(c, MSIM_ERR_HIP, "host-only context: no device engine to force");
+    c->flags = (c->flags & ~(uint32_t)(MSIM_PLAN_HOST | MSIM_PLAN_GPU)) | mode;
+    return MSIM_OK;
+}
+
 int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ranges) {
     Ctx *c = C(p);
     if (!c || n_ranges < 0 || (n_ranges && !ranges)) return MSIM_ERR_ARG;
@@ -413,17 +421,22 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     const bool hs_ok = !gpu_ok && !mixed_ok && !c->host_only && c->gpu && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
     if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok && !mixed_ok && !hs_ok)
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
-    if (gpu_ok && !(c->flags & MSIM_PLAN_HOST)) return plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
-    if (mixed_ok && !(c->flags & MSIM_PLAN_HOST)) {
-        if (g->apply_pending) {                            // this contig's buffers may still be read by its last APPLY
-            rc = apply_finish(c);
-            if (rc) return rc;
-        }
-        return plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
-    }
-    if (hs_ok && !(c->flags & MSIM_PLAN_HOST)) {
-        if (gpu_plan_walk_eligible(c, ranges, n_ranges)) return plan_contig_gpu_walk(c, c->gpu, *g, ranges, n_ranges);
-        return plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
+    if ((gpu_ok || mixed_ok || hs_ok) && !(c->flags & MSIM_PLAN_HOST)) {
+        if (gpu_ok) rc = plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
+        else if (mixed_ok) {
+            if (g->apply_pending) {                        // this contig's buffers may still be read by its last APPLY
+                rc = apply_finish(c);
+                if (rc) return rc;
+            }
+            rc = plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
+        } else if (gpu_plan_walk_eligible(c, ranges, n_ranges)) rc = plan_contig_gpu_walk(c, c->gpu, *g, ranges, n_ranges);
+        else rc = plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
+        // test hook: MSIM_DBG_FORCE_OVERFLOW=n raises the window-overflow flag behind the n-th device-planned contig of
+        // the process (1-based), so that the callers' recovery (mutator.py: re-plan through the host planner) can be tested
+        static const int force_at = getenv("MSIM_DBG_FORCE_OVERFLOW") ? atoi(getenv("MSIM_DBG_FORCE_OVERFLOW")) : 0;
+        static int device_plans = 0;
+        if (!rc && force_at && ++device_plans == force_at) rc = gpu_plan_force_overflow(c, c->gpu);
+        return rc;
     }
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
         rc = gpu_plan_sync_to_host(c, c->gpu);

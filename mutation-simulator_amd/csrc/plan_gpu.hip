@@ -513,6 +513,15 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
     return MSIM_OK;
 }
 
+// test support (MSIM_DBG_FORCE_OVERFLOW): what a 16-sigma window overflow leaves behind
+int gpu_plan_force_overflow(Ctx *c, GpuPlan *g) {
+    if (!g->d_ps) return MSIM_OK;
+    hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, c->stream, g->d_ps, (uint32_t)FLAG_SAMPLE_OVERFLOW);
+    MSIM_HIP(c, hipGetLastError());
+    g->unverified = true;
+    return MSIM_OK;
+}
+
 static hipEvent_t next_chain_event(GpuPlan *g) {
     hipEvent_t &e = g->chain_ev[g->chain_i++ % (2 * N_SETS)];
     if (!e) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);

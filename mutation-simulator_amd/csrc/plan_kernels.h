@@ -1710,6 +1710,8 @@ __global__ void k_publish_seq(const PlanState *__restrict__ ps, PlanState *__res
     __hip_atomic_store(seq_word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+__global__ void k_raise_flag(PlanState *ps, uint32_t flag) { ps->flags |= flag; }
+
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
     ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0;
     ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;

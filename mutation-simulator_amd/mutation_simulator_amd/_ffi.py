@@ -71,6 +71,7 @@ SYMBOLS = [
     ("msim_last_error", C.c_char_p, [_VP]),
     ("msim_device_name", C.c_int, [_VP, C.c_char_p, C.c_int]),
     ("msim_sync", C.c_int, [_VP]),
+    ("msim_set_plan_mode", C.c_int, [_VP, C.c_uint32]),
     ("msim_seed", C.c_int, [_VP, _U32P, C.c_int, C.c_uint32]),
     ("msim_set_mt_state", C.c_int, [_VP, C.c_int, _U32P, C.c_int]),
     ("msim_get_mt_state", C.c_int, [_VP, C.c_int, _U32P, _IP]),
@@ -271,6 +272,10 @@ class Engine:
     def plan_contig(self, contig: int, ranges):
         arr = ranges if isinstance(ranges, C.Array) else self.range_table(ranges)
         self._check(self.lib.msim_plan_contig(self.h, contig, arr, arr.n_ranges), contig)
+
+    def set_plan_mode(self, mode: int):
+        """0 = AUTO, PLAN_HOST = force the sequential host planner, PLAN_GPU = force a device engine."""
+        self._check(self.lib.msim_set_plan_mode(self.h, mode))
 
     def plan_was_empty(self, contig: int) -> bool:
         e = C.c_int()

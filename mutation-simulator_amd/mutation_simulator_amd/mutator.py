@@ -146,6 +146,7 @@ def import_python_streams(engine: "_ffi.Engine") -> None:
     np.random.set_state((nst[0], mt, int(pos), nst[3], nst[4]))
 
 
+REPLANNED_CONTIGS = 0            # contigs that went through the host planner after a device window overflow (diagnostic)
 BATCH_MAX_LEN = 200_000          # contigs up to this length are batched (below every device PLAN engine's threshold)
 BATCH_MAX_BASES = 256 << 20      # bases per batch
 BATCH_MAX_CONTIGS = 16384
@@ -210,27 +211,61 @@ class Mutator:
             at += n
         self._vcf_writer.write_raw(memoryview(vcf))
 
-    def _mutate_one(self, eng, chrom):
+    def _mutate_one(self, eng, chrom, earlier=()):
+        """One contig through PLAN + APPLY + egress.  A device PLAN engine sizes its stream windows with 16-sigma
+        margins; should one ever overflow, libmsim reports it (never a short read) and the contig is planned again by
+        the sequential host planner -- same bytes, just slower.  The normal path pays nothing for this: the streams
+        are put back to where the run started (they came from Python's generators) and the contigs before this one
+        (`earlier`) are re-planned on the host, without output, to advance them."""
+        done = set()                                   # what of this contig is already in the files / on stderr
+        try:
+            self._run_contig(eng, chrom, done)
+        except _ffi.MsimError as e:
+            if "overflowed its" not in str(e):
+                raise
+            global REPLANNED_CONTIGS
+            REPLANNED_CONTIGS += 1
+            eng.clear()
+            export_python_streams(eng)                 # Python's generators still hold the states the run started with
+            eng.set_plan_mode(_ffi.PLAN_HOST)
+            try:
+                for prev in earlier:
+                    rec = self._fasta[prev.number]
+                    # PLAN reads lengths and ranges only, never bases: any contig of the same length stands in
+                    eng.plan_contig(eng.add_contig_synthetic(len(rec), 0), plan_descriptors(prev))
+                    eng.clear()
+                self._run_contig(eng, chrom, done)
+            finally:
+                eng.set_plan_mode(_ffi.PLAN_AUTO)
+
+    def _run_contig(self, eng, chrom, done):
         rec = self._fasta[chrom.number]
         if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
             cid = eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
         else:
             cid = eng.add_contig(rec.bases)
         eng.plan_contig(cid, plan_descriptors(chrom))
-        if eng.plan_was_empty(cid):
+        if eng.plan_was_empty(cid) and "warned" not in done:
             self._warn_empty(chrom)
-        self._fasta_writer.set_bpl(self._fasta.faidx.index[rec.name].lenc)
-        self._fasta_writer.write_header(rec.long_name)
-        eng.apply_contig(cid)
+            done.add("warned")
         bpl = self._fasta.faidx.index[rec.name].lenc
+        if "header" not in done:                       # the reference writes it before it mutates (mutator.py:131-133)
+            self._fasta_writer.set_bpl(bpl)
+            self._fasta_writer.write_header(rec.long_name)
+            done.add("header")
+        eng.apply_contig(cid)
         if bpl > 0:                                    # line framing and VCF text rendered on the device
             text = eng.fetch_sequence_framed(cid, bpl, guess_len=len(rec))
+        else:
+            text = eng.fetch_sequence(cid)
+        _, n_rec, _ = eng.result_sizes(cid, applied=False)     # (host-side bookkeeping, no round trip)
+        vcf = eng.render_vcf_device(cid, rec.name, guess=n_rec * (len(rec.name) + 40) + 256)
+        if bpl > 0:
             q, r = divmod(int(text.shape[0]), bpl + 1)  # text = L + L // bpl bytes  ->  L
             self._fasta_writer.write_framed(text, q * bpl + r)
         else:
-            self._fasta_writer.write_array(eng.fetch_sequence(cid))
-        _, n_rec, _ = eng.result_sizes(cid, applied=False)     # (host-side bookkeeping, no round trip)
-        self._vcf_writer.write_raw(eng.render_vcf_device(cid, rec.name, guess=n_rec * (len(rec.name) + 40) + 256))
+            self._fasta_writer.write_array(text)
+        self._vcf_writer.write_raw(vcf)
         eng.clear()
 
     def mutate(self):
@@ -261,7 +296,7 @@ class Mutator:
                     except (KeyError, ValueError):
                         eng.set_mt_state(0, *saved[0])
                         eng.set_mt_state(1, *saved[1])
-                self._mutate_one(eng, chroms[i])
+                self._mutate_one(eng, chroms[i], earlier=chroms[:i])
                 i += 1
         finally:
             import_python_streams(eng)

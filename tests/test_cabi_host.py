@@ -278,6 +278,17 @@ def test_host_range_cuts_reproduce_cpython_sample(seed, d):
     eng.close()
 
 
+def test_plan_mode_can_be_changed_on_a_live_context():
+    """msim_set_plan_mode: AUTO / HOST on any context, GPU only where a device exists, nonsense is refused."""
+    eng = _host_engine()
+    eng.set_plan_mode(_ffi.PLAN_HOST)
+    eng.set_plan_mode(_ffi.PLAN_AUTO)
+    for bad in (_ffi.PLAN_GPU, _ffi.PLAN_HOST | _ffi.PLAN_GPU, 8):
+        with pytest.raises(_ffi.MsimError):
+            eng.set_plan_mode(bad)
+    eng.close()
+
+
 def test_host_boundary_tables_report_short_window_and_foreign_type():
     """The table walk fails like the plain one: a window that ends before the chain does is an error, not a short
     read, and so is a candidate type that does not belong to the boundary pass."""

@@ -53,6 +53,43 @@ def test_cli_matches_reference_golden(name, tmp_path):
     assert [random.getrandbits(32) for _ in range(4)] == meta["py_next_words_after"]
 
 
+_OVERFLOW_SCRIPT = r"""
+import json, sys, tempfile
+from pathlib import Path
+sys.path[:0] = {paths!r}
+from helpers import CASES, case_meta, sha256
+from pipeline import run_product_case
+from mutation_simulator_amd import mutator
+meta = case_meta({name!r})
+res = run_product_case(meta, Path(tempfile.mkdtemp()))
+print(json.dumps(dict(exc=repr(res["exception"]), code=res["exit_code"], fasta=sha256(res["fasta"]), vcf=sha256(res["vcf"]),
+                      stderr=res["stderr"], replanned=mutator.REPLANNED_CONTIGS)))
+"""
+
+
+@pytest.mark.parametrize("name,nth", [("c1_snp_1mb", 1), ("svmix_1mb", 1), ("rmt_blocks_3mb", 1), ("rmt_blocks_3mb", 2),
+                                      ("rmt_svmix_blocks_3mb", 2)])
+def test_window_overflow_is_replanned_on_the_host(name, nth):
+    """A device PLAN engine that reports a 16-sigma window overflow (forced here by the MSIM_DBG_FORCE_OVERFLOW test hook,
+    one case per engine: SNP sampler, SV mix, host-cut) must not cost the run: the host package puts the streams back and
+    plans that contig with the sequential host planner -- the files still equal the reference's.  nth = 2: the overflow
+    hits a later contig, so the streams are first advanced over the earlier ones again."""
+    import json
+    import os
+    import subprocess
+    import sys
+    meta = case_meta(name)
+    env = dict(os.environ, MSIM_DBG_FORCE_OVERFLOW=str(nth))
+    out = subprocess.run([sys.executable, "-c", _OVERFLOW_SCRIPT.format(paths=sys.path[:8], name=name)], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["exc"] == "None" and got["code"] is None
+    assert got["replanned"] == 1
+    assert got["fasta"] == meta["fasta_sha256"] and got["vcf"] == meta["vcf_sha256"]
+    assert got["stderr"] == meta["stderr"]
+
+
 # ------------------------------------------------------------------ seeded sweeps vs the oracle
 def _sim_dump_from(sim):
     from test_host_settings import dump_sim
