@@ -1133,8 +1133,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
         nk += keep ? 1u : 0u;
         if (keep) cand_type[i0 + q] = t[q] | KEEP_BIT;
     }
+    // one atomic per workgroup: same-address 64-bit atomics serialise in L2 (one per wave made this kernel 4x longer)
+    __shared__ long long wdelta[CB_THREADS / 64];
     for (int o = 32; o > 0; o >>= 1) delta += __shfl_down(delta, o, 64);
-    if ((threadIdx.x & 63) == 0 && delta) atomicAdd((unsigned long long *)&ps->len_delta, (unsigned long long)delta);
+    if ((threadIdx.x & 63) == 0) wdelta[threadIdx.x >> 6] = delta;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < CB_THREADS / 64; w++) t += wdelta[w];
+        if (t) atomicAdd((unsigned long long *)&ps->len_delta, (unsigned long long)t);
+    }
     uint32_t tk, ts, ti;
     (void)block_scan_add(nk, wsum, tk);
     (void)block_scan_add(ns, wsum, ts);
