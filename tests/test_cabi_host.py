@@ -225,13 +225,19 @@ def test_host_range_sampler_equals_cpython_sample(seed, d):
 def test_host_range_cuts_reproduce_cpython_sample(seed, d):
     """The host-cut engine's host half: only WHERE each random.sample() starts in the word stream (plus the pool-path
     draws).  Replaying the device half here -- accepted draws of [cut[i], cut[i+1]) as a set, sorted, + d * rank
-    (k_interval_bits / k_walk_expand) -- must give CPython's positions, and the cuts CPython's word consumption."""
+    (k_interval_bits / k_walk_expand) -- must give CPython's positions, and the cuts CPython's word consumption.
+    Range sizes cover all three bitmap regimes of cut_ranges_host: L1 (plain inserts, memset), beyond L1 (prefetched
+    inserts) and beyond 256 KB (cleared draw by draw)."""
     import ctypes as C
     rs = np.random.RandomState(seed)
     ranges, at = [], 0
     for i in range(300):
         length = int(rs.choice([12, 40, 300, 1000, 5000, 60_000, 700_000]))
+        if i in (40, 170):
+            length = 3_000_000                                                         # bitmap of 375 KB
         rate = float(rs.choice([0.001, 0.01, 0.05, 0.2, 0.3]))
+        if length == 3_000_000:
+            rate = 0.002
         k = int(length * rate)
         n = (at + length - 1 - (k - 1) * d) - at
         if k > 0 and n >= k:
