@@ -267,6 +267,12 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
 bool chain_classes(const msim_range &r, ChainClasses &cc) {
     cc = ChainClasses{};
     for (int t : {MSIM_IN, MSIM_DE, MSIM_DU, MSIM_IV}) {
+        bool drawn = false;                                  // can the type draw of this range produce t at all?
+        for (int j = 0; j < r.n_types && j < 8; j++) {
+            const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+            if (r.types[j] == t && r.cdf_thr[j] > lo && lo < (1ull << 53)) drawn = true;
+        }
+        if (!drawn) continue;                                // its length bounds do not matter (class 0 is never looked up)
         const int64_t w = r.max_len[t] - r.min_len[t] + 1;
         if (w < 1 || w >= (1ll << 24)) return false;                 // value field of a table entry: 24 bits
         if (r.min_len[t] < 1 || r.max_len[t] >= (1ll << 30)) return false;   // keeps 0 <= stop < 2^32 - 1 without a check
@@ -276,6 +282,7 @@ bool chain_classes(const msim_range &r, ChainClasses &cc) {
         if (k == cc.n) { cc.sh[k] = sh; cc.width[k] = (uint32_t)w; cc.n++; }
         cc.cls_of[t] = (uint8_t)k;
     }
+    if (!cc.n) { cc.n = 1; cc.sh[0] = 31; cc.width[0] = 1; }     // nothing but SNPs drawn: an unused placeholder class
     return true;
 }
 

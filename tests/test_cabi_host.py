@@ -295,6 +295,17 @@ def test_plan_mode_can_be_changed_on_a_live_context():
     eng.close()
 
 
+def _sv_range(L, n):
+    """A range whose type draw can produce IN, DE, DU and IV (the boundary walk ignores the lengths of types it cannot)."""
+    r = _ffi.Range()
+    r.start, r.stop, r.k = 0, L - 1, n
+    r.n_types = 4
+    for j, t in enumerate((2, 3, 4, 5)):
+        r.types[j] = t
+        r.cdf_thr[j] = (j + 1) << 51
+    return r
+
+
 def test_host_boundary_tables_report_short_window_and_foreign_type():
     """The table walk fails like the plain one: a window that ends before the chain does is an error, not a short
     read, and so is a candidate type that does not belong to the boundary pass."""
@@ -303,8 +314,7 @@ def test_host_boundary_tables_report_short_window_and_foreign_type():
     L, n = 100_000, 2_000
     pos = np.sort(rs.choice(np.arange(0, L - 1), size=n, replace=False)).astype(np.uint32)
     types = rs.choice([2, 3, 4, 5], size=n).astype(np.uint8)
-    r = _ffi.Range()
-    r.start, r.stop, r.k = 0, L - 1, n
+    r = _sv_range(L, n)
     for t in (2, 3, 4, 5):
         r.min_len[t], r.max_len[t] = 1, 5
     words = rs.randint(0, 2**32, size=4 * n, dtype=np.uint64).astype(np.uint32)
@@ -326,6 +336,13 @@ def test_host_boundary_tables_report_short_window_and_foreign_type():
         assert run(fn, bad, len(words)) != 0
     r.max_len[5] = 1 << 25                                                 # width beyond a table entry's value field
     assert run(lib.msim_dbg_chain_boundary_tables, types, len(words)) != 0
+    # ... which only matters for a type the range can draw: with IV out of the type table the tables are back
+    r.n_types = 3
+    no_iv = np.where(types == 5, 4, types).astype(np.uint8)
+    assert run(lib.msim_dbg_chain_boundary, no_iv, len(words)) == 0
+    want = (stop.copy(), used.value, nk.value, dl.value)
+    assert run(lib.msim_dbg_chain_boundary_tables, no_iv, len(words)) == 0
+    assert (stop.tolist(), used.value, nk.value, dl.value) == (want[0].tolist(),) + want[1:]
     eng.close()
 
 
@@ -347,8 +364,7 @@ def test_host_boundary_chain_equals_cpython_randint(seed, walker):
     if seed == 5:
         lens[2] = (7, 7)                                                        # width-1 randint burns words until a 0 bit
     block = {1: 1, 2: int(rs.randint(1, 4)), 3: int(rs.randint(1, 30)), 4: 1, 5: int(rs.randint(1, 9)), 6: 1, 7: 1}
-    r = _ffi.Range()
-    r.start, r.stop, r.k = 0, L - 1, n
+    r = _sv_range(L, n)
     for t, (a, b) in lens.items():
         r.min_len[t], r.max_len[t] = a, b
     ref = random.Random(seed)

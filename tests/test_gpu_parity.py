@@ -370,3 +370,14 @@ def test_rmt_overlapping_large_snp_ranges_vs_oracle(tmp_path):
     text = "std\nit None\nNone\nchr 1\n1-600000 sn 0.02\n400001-1000000 sn 0.02\n"
     spec = {"contigs": [{"defline": "ovl big", "length": 1_200_000, "bpl": 60, "seed": 11}]}
     _product_vs_oracle(tmp_path, spec, [], 8, 9, rmt_text=text)
+
+
+def test_svmix_lengths_beyond_table_entries_vs_oracle(tmp_path):
+    """randint widths of 2^24 and more do not fit an entry of the boundary walk's next-accepted-draw tables: the SV-mix
+    engine then walks tempered words with the retry loop inside (chain_boundary_host).  Deletions / duplications that long
+    are clamped to the contig end (mutator.py:253-264), so the case is small; checked against the oracle."""
+    argv = ["args", "-sn", "0.004", "-de", "0.00002", "-demin", "1", "-demax", "20000000",
+            "-du", "0.00002", "-dumin", "5", "-dumax", "17000000", "-in", "0.0005", "-inmin", "1", "-inmax", "9"]
+    spec = {"contigs": [{"defline": "wide lens", "length": 2_400_000, "bpl": 60, "seed": 21},
+                        {"defline": "second", "length": 1_100_000, "bpl": 70, "seed": 22}]}
+    _product_vs_oracle(tmp_path, spec, argv, 5, 6)
