@@ -35,6 +35,7 @@ struct Contig {
     bool key_reported = false;
     int index = 0;                    // position in Ctx::contigs (selects the error word)
     bool apply_pending = false;       // APPLY enqueued, result not yet collected
+    bool defer_apply = false;         // planned by an engine with a host chain: its APPLY may wait for the next plan's chain
     hipEvent_t ea0 = nullptr, ea1 = nullptr, ea2 = nullptr;   // APPLY timing (emit stream)
     // host-only context (device_id -1): the record table stays here
     std::vector<msim_record> h_recs;
@@ -63,6 +64,7 @@ struct Ctx {
     msim_params params{};
     bool have_params = false;
     std::vector<Contig> contigs;
+    int deferred_apply = -1;              // contig whose APPLY msim_apply_contig deferred (msim_api.hip), -1: none
     msim_timing t{};
     // device scratch
     void *d_scratch = nullptr;
@@ -100,6 +102,10 @@ int hip_fail(Ctx *c, hipError_t e, const char *what);
         hipError_t e__ = (call);                                         \
         if (e__ != hipSuccess) return ::msim::hip_fail((ctx), e__, #call); \
     } while (0)
+
+// msim_api.hip: enqueue the APPLY that msim_apply_contig deferred, if any (the engines with a host chain call it when
+// their chain starts)
+int flush_deferred_apply(Ctx *c);
 
 // plan_host.cpp
 struct HostPlan {

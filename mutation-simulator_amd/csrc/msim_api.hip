@@ -68,6 +68,13 @@ static int drain(Ctx *c) {
     MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
     return MSIM_OK;
 }
+int flush_deferred_apply(Ctx *c) {
+    if (c->deferred_apply < 0) return MSIM_OK;
+    const int idx = c->deferred_apply;
+    c->deferred_apply = -1;
+    if (idx >= (int)c->contigs.size()) return MSIM_OK;
+    return apply_contig_device(c, c->contigs[(size_t)idx]);
+}
 static int key_error_of(Ctx *c, Contig &g) {
     g.key_reported = true;
     return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'");
@@ -108,6 +115,7 @@ static void build_lut(uint8_t *lut) {
 // forget a contig's plan/apply results; device buffers stay allocated for the next plan of this contig
 static void reset_contig(Contig &g) {   // (callers also drop the context's text cache: see text_kind)
     g.planned = g.applied = false;
+    g.defer_apply = false;
     g.delta_known = false;
     g.known_delta = 0;
     g.n_rec = g.pool_len = g.out_len = 0;
@@ -224,11 +232,19 @@ int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
 }
 
 static Ctx *C(msim_ctx *p) { return reinterpret_cast<Ctx *>(p); }
+// Every entry point except msim_plan_contig first enqueues an APPLY that msim_apply_contig deferred (see there).
+#define CTX_FLUSHED(c, p)                                   \
+    Ctx *c = C(p);                                          \
+    if (c) {                                                \
+        const int flush_rc_ = flush_deferred_apply(c);      \
+        if (flush_rc_) return flush_rc_;                    \
+    }
 #define NEED_GPU(c) do { if ((c)->host_only) return fail((c), MSIM_ERR_HIP, "host-only context: this call needs the GPU"); } while (0)
 
 void msim_destroy(msim_ctx *p) {
     if (!p) return;
     CtxFull *c = static_cast<CtxFull *>(C(p));
+    c->deferred_apply = -1;                                // nobody will ask for its result
     if (c->host_only) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
@@ -263,7 +279,7 @@ int msim_device_name(const msim_ctx *p, char *dst, int cap) {
 }
 
 int msim_sync(msim_ctx *p) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     if (c->host_only) return MSIM_OK;
     int rc = drain(c);
@@ -274,7 +290,7 @@ int msim_sync(msim_ctx *p) {
 }
 
 int msim_seed(msim_ctx *p, const uint32_t *py_key, int n_key, uint32_t np_seed) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !py_key || n_key < 1) return MSIM_ERR_ARG;
     {
         int rc = drain(c);
@@ -289,7 +305,7 @@ int msim_seed(msim_ctx *p, const uint32_t *py_key, int n_key, uint32_t np_seed) 
 }
 
 int msim_set_mt_state(msim_ctx *p, int stream, const uint32_t mt[624], int pos) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !mt || pos < 0 || pos > 624 || stream < 0 || stream > 1) return MSIM_ERR_ARG;
     if (c->gpu) {                      // keep the other stream's position before dropping the device copy
         int rc = gpu_plan_sync_to_host(c, c->gpu);
@@ -304,7 +320,7 @@ int msim_set_mt_state(msim_ctx *p, int stream, const uint32_t mt[624], int pos) 
 }
 
 int msim_get_mt_state(msim_ctx *p, int stream, uint32_t mt[624], int *pos) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !mt || !pos || stream < 0 || stream > 1) return MSIM_ERR_ARG;
     if (c->gpu) {
         int rc = gpu_plan_sync_to_host(c, c->gpu);
@@ -317,14 +333,14 @@ int msim_get_mt_state(msim_ctx *p, int stream, uint32_t mt[624], int *pos) {
 }
 
 int msim_reserve_streams(msim_ctx *p, uint64_t py_words, uint64_t np_words) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     if (c->gpu) gpu_plan_reserve(c->gpu, py_words, np_words);
     return MSIM_OK;
 }
 
 int msim_add_contig(msim_ctx *p, const uint8_t *bases, uint64_t len, int *contig) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || (!bases && len) || !contig) return MSIM_ERR_ARG;
     Contig *g;
     int rc = new_contig(c, len, &g);
@@ -338,7 +354,7 @@ int msim_add_contig(msim_ctx *p, const uint8_t *bases, uint64_t len, int *contig
 }
 
 int msim_add_contig_synthetic(msim_ctx *p, uint64_t len, uint64_t seed, int *contig) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !contig) return MSIM_ERR_ARG;
     NEED_GPU(c);
     Contig *g;
@@ -352,7 +368,7 @@ int msim_add_contig_synthetic(msim_ctx *p, uint64_t len, uint64_t seed, int *con
 }
 
 int msim_contig_length(msim_ctx *p, int contig, uint64_t *len) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !len) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -361,7 +377,7 @@ int msim_contig_length(msim_ctx *p, int contig, uint64_t *len) {
 }
 
 int msim_read_contig(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8_t *dst) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || (!dst && n)) return MSIM_ERR_ARG;
     NEED_GPU(c);
     Contig *g = get_contig(c, contig);
@@ -373,7 +389,7 @@ int msim_read_contig(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8
 }
 
 int msim_clear(msim_ctx *p) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     {
         int rc = drain(c);
@@ -389,7 +405,7 @@ int msim_clear(msim_ctx *p) {
 }
 
 int msim_set_params(msim_ctx *p, const msim_params *params) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !params) return MSIM_ERR_ARG;
     for (int t = 1; t <= 7; t++)
         if (params->block[t] < 1) return fail(c, MSIM_ERR_ARG, "block values must be >= 1 (rmt.py:326-345)");
@@ -399,7 +415,7 @@ int msim_set_params(msim_ctx *p, const msim_params *params) {
 }
 
 int msim_set_plan_mode(msim_ctx *p, uint32_t mode) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || (mode & ~(MSIM_PLAN_HOST | MSIM_PLAN_GPU)) || mode == (MSIM_PLAN_HOST | MSIM_PLAN_GPU)) return MSIM_ERR_ARG;
     if ((mode & MSIM_PLAN_GPU) && c->host_only) return fail(c, MSIM_ERR_HIP, "host-only context: no device engine to force");
     c->flags = (c->flags & ~(uint32_t)(MSIM_PLAN_HOST | MSIM_PLAN_GPU)) | mode;
@@ -414,11 +430,17 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
     int rc = MSIM_OK;
     TraceRange tr("msim PLAN contig");
-    reset_contig(*g);
-    c->text_kind = 0;
     const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
     const bool mixed_ok = !gpu_ok && !c->host_only && c->gpu && gpu_plan_mixed_eligible(c, ranges, n_ranges);
     const bool hs_ok = !gpu_ok && !mixed_ok && !c->host_only && c->gpu && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
+    // A deferred APPLY of the previous contig (msim_apply_contig) is enqueued when this plan's host chain starts --
+    // by the SV-mix / host-cut engine itself -- so that it fills the device's idle time instead of competing with this
+    // contig's latency-bound chain kernels.  Every other route enqueues it now.
+    const bool engine_flushes = (mixed_ok || (hs_ok && !gpu_plan_walk_eligible(c, ranges, n_ranges))) &&
+                                !(c->flags & MSIM_PLAN_HOST) && c->deferred_apply != contig;
+    if (!engine_flushes && (rc = flush_deferred_apply(c))) return rc;
+    reset_contig(*g);
+    c->text_kind = 0;
     if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok && !mixed_ok && !hs_ok)
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
     if ((gpu_ok || mixed_ok || hs_ok) && !(c->flags & MSIM_PLAN_HOST)) {
@@ -436,7 +458,9 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
         static const int force_at = getenv("MSIM_DBG_FORCE_OVERFLOW") ? atoi(getenv("MSIM_DBG_FORCE_OVERFLOW")) : 0;
         static int device_plans = 0;
         if (!rc && force_at && ++device_plans == force_at) rc = gpu_plan_force_overflow(c, c->gpu);
-        return rc;
+        const int frc = flush_deferred_apply(c);           // (an engine that returned early never reached its flush point)
+        g->defer_apply = !rc && (mixed_ok || (hs_ok && !gpu_plan_walk_eligible(c, ranges, n_ranges)));
+        return rc ? rc : frc;
     }
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
         rc = gpu_plan_sync_to_host(c, c->gpu);
@@ -481,7 +505,7 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
 }
 
 int msim_plan_was_empty(msim_ctx *p, int contig, int *empty) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !empty) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -491,7 +515,7 @@ int msim_plan_was_empty(msim_ctx *p, int contig, int *empty) {
 }
 
 int msim_apply_contig(msim_ctx *p, int contig) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -499,11 +523,19 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "msim_apply_contig before msim_plan_contig");
     TraceRange tr("msim APPLY contig");
     c->text_kind = 0;
+    // Contigs of the engines with a host chain: the next contig's plan starts with latency-bound device kernels and
+    // then leaves the device idle for a millisecond while the host walks -- that is where this APPLY belongs.  It is
+    // enqueued by the next entry point, whichever it is (the next plan at the start of its host chain).
+    static const bool no_defer = getenv("MSIM_NO_DEFER") != nullptr;
+    if (g->defer_apply && !no_defer) {
+        c->deferred_apply = contig;
+        return MSIM_OK;
+    }
     return apply_contig_device(c, *g);
 }
 
 int msim_key_error(msim_ctx *p, int contig, uint8_t *base, uint64_t *pos) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     Contig *g = nullptr;
     if (contig == -1) {                                    // first contig that hit it
@@ -520,7 +552,7 @@ int msim_key_error(msim_ctx *p, int contig, uint8_t *base, uint64_t *pos) {
 }
 
 int msim_result_sizes(msim_ctx *p, int contig, uint64_t *out_len, uint64_t *n_records, uint64_t *pool_len) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -538,7 +570,7 @@ int msim_result_sizes(msim_ctx *p, int contig, uint64_t *out_len, uint64_t *n_re
 }
 
 int msim_fetch_sequence(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8_t *dst) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || (!dst && n)) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -555,7 +587,7 @@ int msim_fetch_sequence(msim_ctx *p, int contig, uint64_t offset, uint64_t n, ui
 }
 
 int msim_fetch_records(msim_ctx *p, int contig, msim_record *dst, uint8_t *pool_dst) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -578,7 +610,7 @@ int msim_fetch_records(msim_ctx *p, int contig, msim_record *dst, uint8_t *pool_
 }
 
 int msim_result_checksum(msim_ctx *p, int contig, uint64_t *sum) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !sum) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -592,7 +624,7 @@ int msim_result_checksum(msim_ctx *p, int contig, uint64_t *sum) {
 }
 
 int msim_result_device_ptr(msim_ctx *p, int contig, uint64_t *device_address, uint64_t *len) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !device_address || !len) return MSIM_ERR_ARG;
     NEED_GPU(c);
     Contig *g = get_contig(c, contig);
@@ -607,7 +639,7 @@ int msim_result_device_ptr(msim_ctx *p, int contig, uint64_t *device_address, ui
 }
 
 int msim_planned_out_len(msim_ctx *p, int contig, uint64_t *out_len, int *known) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !out_len || !known) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -620,7 +652,7 @@ int msim_planned_out_len(msim_ctx *p, int contig, uint64_t *out_len, int *known)
 }
 
 int msim_release_result(msim_ctx *p, int contig) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
@@ -642,7 +674,7 @@ static int text_copy_out(Ctx *c, uint8_t *out, uint64_t cap, uint64_t *needed) {
 }
 
 int msim_render_vcf_device(msim_ctx *p, int contig, const char *seq_name, char *out, uint64_t cap, uint64_t *needed) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !seq_name || !needed) return MSIM_ERR_ARG;
     NEED_GPU(c);
     Contig *g = get_contig(c, contig);
@@ -663,7 +695,7 @@ int msim_render_vcf_device(msim_ctx *p, int contig, const char *seq_name, char *
 }
 
 int msim_fetch_sequence_framed(msim_ctx *p, int contig, uint32_t bpl, uint8_t *out, uint64_t cap, uint64_t *needed) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !needed || bpl == 0) return MSIM_ERR_ARG;
     NEED_GPU(c);
     Contig *g = get_contig(c, contig);
@@ -687,7 +719,7 @@ int msim_fetch_sequence_framed(msim_ctx *p, int contig, uint32_t bpl, uint8_t *o
 
 int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
                          uint32_t lenb, int *contig) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !contig || (!body && n_bases)) return MSIM_ERR_ARG;
     NEED_GPU(c);
     if (n_bases) {
@@ -711,7 +743,7 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
 // random.randint and run them under ASan/UBSan without a GPU (tests/test_cabi_host.py).
 int msim_dbg_sample_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, const uint32_t *words, uint64_t n_words,
                            uint32_t *pos_out, uint64_t *consumed) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !consumed || (n_ranges && !ranges)) return MSIM_ERR_ARG;
     int64_t d = c->params.block[1];
     for (int t = 2; t <= 7; t++) d = std::min(d, c->params.block[t]);
@@ -724,7 +756,7 @@ int msim_dbg_sample_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, 
 // cut_ranges_host: cut[] needs one slot per drawing range (k > 0) plus one, pool_pos the sum of k over pool-path ranges
 int msim_dbg_cut_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, const uint32_t *words, uint64_t n_words,
                         uint32_t *cut, uint32_t *pool_pos, uint64_t *n_pool_pos, uint64_t *consumed) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !consumed || !n_pool_pos || !cut || (n_ranges && !ranges)) return MSIM_ERR_ARG;
     int64_t d = c->params.block[1];
     for (int t = 2; t <= 7; t++) d = std::min(d, c->params.block[t]);
@@ -737,7 +769,7 @@ int msim_dbg_cut_ranges(msim_ctx *p, const msim_range *ranges, int n_ranges, con
 int msim_dbg_chain_boundary(msim_ctx *p, const msim_range *r, uint64_t L, const uint32_t *pos, const uint8_t *type,
                             uint64_t n, const uint32_t *words, uint64_t n_words, uint32_t *stop, uint64_t *consumed,
                             uint64_t *kept, int64_t *len_delta) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !r || !consumed || !kept || !len_delta) return MSIM_ERR_ARG;
     size_t used = 0, nk = 0;
     long long delta = 0;
@@ -751,7 +783,7 @@ int msim_dbg_chain_boundary(msim_ctx *p, const msim_range *r, uint64_t L, const 
 int msim_dbg_chain_boundary_tables(msim_ctx *p, const msim_range *r, uint64_t L, const uint32_t *pos, const uint8_t *type,
                                    uint64_t n, const uint32_t *words, uint64_t n_words, uint32_t *stop, uint64_t *consumed,
                                    uint64_t *kept, int64_t *len_delta) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !r || !consumed || !kept || !len_delta) return MSIM_ERR_ARG;
     ChainClasses cc;
     if (!chain_classes(*r, cc)) return MSIM_ERR_UNSUPPORTED;
@@ -765,14 +797,14 @@ int msim_dbg_chain_boundary_tables(msim_ctx *p, const msim_range *r, uint64_t L,
 }
 
 int msim_dbg_stream_status(msim_ctx *p, int out[8]) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !out || c->host_only || !c->gpu) return MSIM_ERR_ARG;
     gpu_plan_stream_status(c, c->gpu, out);
     return MSIM_OK;
 }
 
 int msim_stats(msim_ctx *p, msim_timing *out) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !out) return MSIM_ERR_ARG;
     {
         int rc = drain(c);
@@ -783,7 +815,7 @@ int msim_stats(msim_ctx *p, msim_timing *out) {
 }
 
 int msim_reset_stats(msim_ctx *p) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c) return MSIM_ERR_ARG;
     {
         int rc = drain(c);
@@ -853,7 +885,7 @@ static long long rec_delta(const msim_record &r) {
 extern "C" {
 
 int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !contigs || n < 1) return MSIM_ERR_ARG;
     NEED_GPU(c);
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
@@ -1037,7 +1069,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
 }
 
 int msim_batch_sizes(msim_ctx *p, int n, uint64_t *fasta_bytes, uint64_t *vcf_bytes, int32_t *empty, uint64_t *n_records) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !c->batch || (size_t)n != c->batch->items.size()) return MSIM_ERR_ARG;
     for (int i = 0; i < n; i++) {
         const Batch::Item &it = c->batch->items[(size_t)i];
@@ -1050,7 +1082,7 @@ int msim_batch_sizes(msim_ctx *p, int n, uint64_t *fasta_bytes, uint64_t *vcf_by
 }
 
 int msim_batch_fetch(msim_ctx *p, uint8_t *fasta_text, uint64_t fasta_cap, char *vcf_text, uint64_t vcf_cap) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !c->batch) return MSIM_ERR_ARG;
     Batch &B = *c->batch;
     if (fasta_text) {
@@ -1065,7 +1097,7 @@ int msim_batch_fetch(msim_ctx *p, uint8_t *fasta_text, uint64_t fasta_cap, char 
 }
 
 int msim_batch_key_contig(msim_ctx *p, int *contig) {
-    Ctx *c = C(p);
+    CTX_FLUSHED(c, p)
     if (!c || !contig || !c->batch) return MSIM_ERR_ARG;
     *contig = c->batch->key_contig;
     return MSIM_OK;

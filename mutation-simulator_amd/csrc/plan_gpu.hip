@@ -988,6 +988,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
             }
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+            if ((rc = flush_deferred_apply(c))) return rc;  // the previous contig's APPLY: the device is idle from here on
             const auto w0 = std::chrono::steady_clock::now();
             ChainWalk cw;
             if ((rc = cw.init(c, r, ct.len, cc, Wb))) return rc;
@@ -1016,6 +1017,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             MSIM_HIP(c, hipGetLastError());
             MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, words_bytes, hipMemcpyDeviceToHost, c->stream));
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+            if ((rc = flush_deferred_apply(c))) return rc;
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
             MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
             if ((rc = span_close(c, g))) return rc;
@@ -1247,6 +1249,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
         if (!rc) *avail = f.cut[++f.next];
         return rc;
     };
+    if ((rc = flush_deferred_apply(c))) return rc;        // the previous contig's APPLY: the device is idle from here on
     rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed, &feed);
     if (!rc) {
         MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned window is free again
