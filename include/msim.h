@@ -217,12 +217,19 @@ typedef struct msim_batch_contig {
     const uint8_t *body; uint64_t body_bytes; uint64_t n_bases; uint32_t lenc, lenb;   /* as msim_add_contig_text     */
     const msim_range *ranges; int32_t n_ranges;                                        /* as msim_plan_contig         */
     const char *name;                                                                  /* CHROM of its VCF lines      */
+    const char *header;      /* NULL: the FASTA text holds the framed bodies only.  Else the defline without '>': the text
+                                is the complete run of records as FastaWriter writes them (fasta_writer.py:31-38) --
+                                '>' header '\n' body, with a '\n' before a header iff the body before it ended mid-line */
 } msim_batch_contig;
 int msim_batch_run(msim_ctx *ctx, const msim_batch_contig *contigs, int n);
-/* per contig: bytes of its framed FASTA body, bytes of its VCF lines, plan-was-empty flag (mutator.py:125-129), records */
+/* per contig: bytes of its part of the FASTA text (header line included where given), bytes of its VCF lines, plan-was-empty flag (mutator.py:125-129), records */
 int msim_batch_sizes(msim_ctx *ctx, int n, uint64_t *fasta_bytes, uint64_t *vcf_bytes, int32_t *empty, uint64_t *n_records);
 /* the framed bodies / the VCF lines of all contigs of the batch, back to back in contig order (either may be NULL)       */
 int msim_batch_fetch(msim_ctx *ctx, uint8_t *fasta_text, uint64_t fasta_cap, char *vcf_text, uint64_t vcf_cap);
+/* the same texts in place (valid until the next batch / destroy): no copy of a few hundred MB.  *last_line_bases: bases on
+ * the partial last line of the FASTA text (what FastaWriter needs to know to continue after it)                           */
+int msim_batch_view(msim_ctx *ctx, const uint8_t **fasta_text, uint64_t *fasta_bytes, const char **vcf_text,
+                    uint64_t *vcf_bytes, uint64_t *last_line_bases);
 int msim_batch_key_contig(msim_ctx *ctx, int *contig);
 
 /* ---- multi-GPU: one process per GPU, contigs' APPLY sharded, gather over RCCL ------------------ */

@@ -1,9 +1,11 @@
 // C-ABI entry points of libmsim.so (include/msim.h).  gfx950 (MI355X) only.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <thread>
 
 #include <dlfcn.h>
 
@@ -845,8 +847,9 @@ struct Batch {
     std::vector<uint8_t> pool;
     uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned
     size_t cap_in = 0, cap_out = 0;
-    std::vector<uint8_t> fasta;
-    std::string vcf;
+    uint8_t *fasta = nullptr; size_t fasta_cap = 0, fasta_len = 0;   // malloc'ed: never zero-filled
+    char *vcf = nullptr; size_t vcf_cap = 0, vcf_len = 0;
+    uint64_t last_line_bases = 0;            // bases on the (partial) last line of the FASTA text
     int key_contig = -1;
 };
 
@@ -854,8 +857,37 @@ static void batch_free(Ctx *c) {
     if (!c->batch) return;
     if (c->batch->h_in) (void)hipHostFree(c->batch->h_in);
     if (c->batch->h_out) (void)hipHostFree(c->batch->h_out);
+    free(c->batch->fasta);
+    free(c->batch->vcf);
     delete c->batch;
     c->batch = nullptr;
+}
+
+template <class T> static bool raw_reserve(T **p, size_t *cap, size_t want) {
+    if (*cap >= want) return true;
+    free(*p);
+    *cap = want + want / 8 + 4096;
+    *p = static_cast<T *>(malloc(*cap));
+    if (!*p) *cap = 0;
+    return *p != nullptr;
+}
+
+// Contigs [0, n) in `parts` consecutive slices, one host thread each (text work of a batch: ingest, framing, VCF lines).
+static int batch_threads() {
+    static const int t = [] {
+        if (const char *e = getenv("MSIM_BATCH_THREADS")) return std::max(1, atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(16, std::max<unsigned>(1, hw / 2));
+    }();
+    return t;
+}
+template <class F> static void parallel_slices(int n, F f) {   // f(part, i0, i1)
+    const int parts = std::max(1, std::min(batch_threads(), n / 64));
+    if (parts == 1) { f(0, 0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < parts; t++) th.emplace_back(f, t, (int)((long long)n * t / parts), (int)((long long)n * (t + 1) / parts));
+    f(0, 0, (int)((long long)n / parts));
+    for (auto &x : th) x.join();
 }
 
 static int pinned_reserve(Ctx *c, uint8_t **p, size_t *cap, size_t want) {
@@ -903,7 +935,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     if (!c->batch) c->batch = new Batch();
     Batch &B = *c->batch;
     B.items.assign((size_t)n, Batch::Item());
-    B.recs_rel.clear(); B.pool.clear(); B.fasta.clear(); B.vcf.clear();
+    B.recs_rel.clear(); B.pool.clear(); B.fasta_len = 0; B.vcf_len = 0; B.last_line_bases = 0;
     B.key_contig = -1;
     uint64_t total = 0;
     for (int i = 0; i < n; i++) {
@@ -923,22 +955,24 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     // ---- 1. FASTA text -> upper-cased bases (pyfaidx's sequence_always_upper, util.py:84-88), on the host
     rc = pinned_reserve(c, &B.h_in, &B.cap_in, total + 64);
     if (rc) return rc;
-    for (int i = 0; i < n; i++) {
-        const msim_batch_contig &q = contigs[i];
-        uint8_t *dst = B.h_in + B.items[(size_t)i].base;
-        uint64_t done = 0;
-        const uint8_t *src = q.body;
-        while (done < q.n_bases) {
-            const uint64_t take = std::min<uint64_t>(q.lenc, q.n_bases - done);
-            memcpy(dst + done, src, take);
-            done += take;
-            src += q.lenb;
+    parallel_slices(n, [&](int, int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
+            const msim_batch_contig &q = contigs[i];
+            uint8_t *dst = B.h_in + B.items[(size_t)i].base;
+            uint64_t done = 0;
+            const uint8_t *src = q.body;
+            while (done < q.n_bases) {
+                const uint64_t take = std::min<uint64_t>(q.lenc, q.n_bases - done);
+                memcpy(dst + done, src, take);
+                done += take;
+                src += q.lenb;
+            }
+            for (uint64_t k = 0; k < q.n_bases; k++) {       // (auto-vectorised)
+                const uint8_t b = dst[k];
+                dst[k] = (uint8_t)(b - ((b >= 'a' && b <= 'z') ? 32 : 0));
+            }
         }
-        for (uint64_t k = 0; k < q.n_bases; k++) {           // (auto-vectorised)
-            const uint8_t b = dst[k];
-            dst[k] = (uint8_t)(b - ((b >= 'a' && b <= 'z') ? 32 : 0));
-        }
-    }
+    });
     const auto t_1 = now();
     // ---- 2. PLAN: the RNG chain, contig by contig (mutator.py:111-131 + the draws of :334-358)
     std::vector<msim_record> recs_abs;
@@ -1020,47 +1054,100 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     const auto t_3 = now();
     // ---- 4. FASTA framing ('\n' after every bpl bases, none after a partial last line; fasta_writer.py:40-58) and
     //         VCF record lines (mutator.py:334-399 + vcf_writer.py:118-126) per contig, on the host
+    // With a header per contig (msim_batch_contig.header) the text is the complete run of FASTA records as FastaWriter
+    // would have written them: '>' header '\n' body, and a '\n' before a header iff the previous body ended in a partial line.
     uint64_t text_total = 0;
-    for (Batch::Item &it : B.items) { it.text0 = text_total; it.ntext = it.bpl ? it.out_len + it.out_len / it.bpl : it.out_len; text_total += it.ntext; }
-    B.fasta.resize(text_total);
-    for (const Batch::Item &it : B.items) {
-        const uint8_t *src = B.h_out + it.out_start;
-        uint8_t *dst = B.fasta.data() + it.text0;
-        if (!it.bpl) { if (it.out_len) memcpy(dst, src, it.out_len); continue; }
-        uint64_t done = 0;
-        while (done + it.bpl <= it.out_len) { memcpy(dst, src + done, it.bpl); dst[it.bpl] = '\n'; dst += it.bpl + 1; done += it.bpl; }
-        if (done < it.out_len) memcpy(dst, src + done, it.out_len - done);
+    for (int i = 0; i < n; i++) {
+        Batch::Item &it = B.items[(size_t)i];
+        const bool prev_partial = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
+        const uint64_t head = contigs[i].header ? (prev_partial ? 1 : 0) + 1 + strlen(contigs[i].header) + 1 : 0;
+        it.text0 = text_total;
+        it.ntext = head + (it.bpl ? it.out_len + it.out_len / it.bpl : it.out_len);
+        text_total += it.ntext;
     }
-    const auto t_4 = now();
-    {   // one rendering pass per contig into a buffer sized by a cheap upper bound (a line is name + fixed fields of
-        // < 96 bytes + REF and ALT, each at most span + insert + 1 long, twice for a duplication's ALT)
-        const msim_record *all = B.recs_rel.data();
-        uint64_t bound = 0;
-        for (int i = 0; i < n; i++) {
+    if (!raw_reserve(&B.fasta, &B.fasta_cap, (size_t)text_total + 1)) return fail(c, MSIM_ERR_NOMEM, "batch FASTA text");
+    B.fasta_len = (size_t)text_total;
+    B.last_line_bases = B.items.back().bpl ? B.items.back().out_len % B.items.back().bpl : 0;
+    parallel_slices(n, [&](int, int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
             const Batch::Item &it = B.items[(size_t)i];
-            const uint64_t nl = strlen(contigs[i].name) + 96;
-            for (uint64_t k = 0; k < it.nrec; k++) {
-                const msim_record &r = all[it.rec0 + k];
-                const uint64_t span = r.type == MSIM_SN ? 1 : (uint64_t)(r.stop >= r.pos ? r.stop - r.pos + 1 : 0) + 2;
-                const uint64_t tli = r.type == MSIM_TLI && r.stop + 1 > r.extra ? (uint64_t)r.stop + 1 - r.extra : 0;
-                bound += nl + 3 * (span + tli) + 8;
+            const uint8_t *src = B.h_out + it.out_start;
+            uint8_t *dst = B.fasta + it.text0;
+            if (const char *hd = contigs[i].header) {
+                const bool prev_partial = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
+                if (prev_partial) *dst++ = '\n';
+                *dst++ = '>';
+                const size_t hl = strlen(hd);
+                memcpy(dst, hd, hl);
+                dst += hl;
+                *dst++ = '\n';
             }
+            if (!it.bpl) { if (it.out_len) memcpy(dst, src, it.out_len); continue; }
+            uint64_t done = 0;
+            while (done + it.bpl <= it.out_len) { memcpy(dst, src + done, it.bpl); dst[it.bpl] = '\n'; dst += it.bpl + 1; done += it.bpl; }
+            if (done < it.out_len) memcpy(dst, src + done, it.out_len - done);
         }
-        B.vcf.resize(bound);
+    });
+    const auto t_4 = now();
+    {   // VCF lines: every slice of contigs renders into a buffer of its own, sized by a cheap upper bound (a line is name +
+        // fixed fields of < 96 bytes + REF and ALT, each at most span + insert + 1 long, twice for a duplication's ALT);
+        // the slices are then joined in contig order
+        const msim_record *all = B.recs_rel.data();
+        const int max_parts = batch_threads();
+        std::vector<char *> part_buf((size_t)max_parts, nullptr);      // malloc'ed: never zero-filled
+        std::vector<uint64_t> part_len((size_t)max_parts, 0);
+        std::vector<int> part_first((size_t)max_parts, -1);
+        std::atomic<bool> bad{false};
+        parallel_slices(n, [&](int part, int i0, int i1) {
+            uint64_t bound = 0;
+            for (int i = i0; i < i1; i++) {
+                const Batch::Item &it = B.items[(size_t)i];
+                const uint64_t nl = strlen(contigs[i].name) + 96;
+                for (uint64_t k = 0; k < it.nrec; k++) {
+                    const msim_record &r = all[it.rec0 + k];
+                    const uint64_t span = r.type == MSIM_SN ? 1 : (uint64_t)(r.stop >= r.pos ? r.stop - r.pos + 1 : 0) + 2;
+                    const uint64_t tli = r.type == MSIM_TLI && r.stop + 1 > r.extra ? (uint64_t)r.stop + 1 - r.extra : 0;
+                    bound += nl + 3 * (span + tli) + 8;
+                }
+            }
+            char *out = static_cast<char *>(malloc((size_t)bound + 64));
+            part_buf[(size_t)part] = out;
+            part_first[(size_t)part] = i0;
+            if (!out) { bad = true; return; }
+            uint64_t at = 0;
+            for (int i = i0; i < i1; i++) {
+                Batch::Item &it = B.items[(size_t)i];
+                it.vcf0 = at;                                  // relative to the slice until the join
+                uint64_t need = 0;
+                if (it.nrec) {
+                    need = render_vcf_unchecked(all + it.rec0, it.nrec, B.pool.data() + it.pool0, B.h_in + it.base, it.len,
+                                                contigs[i].name, out + at);
+                    if (at + need > bound) bad = true;
+                }
+                it.nvcf = need;
+                at += need;
+            }
+            part_len[(size_t)part] = at;
+        });
+        auto free_parts = [&]() { for (char *q : part_buf) free(q); };
+        if (bad) { free_parts(); return fail(c, MSIM_ERR_HIP, "internal: VCF text of a batch: bound too small or out of memory"); }
+        // join in slice order (slices are consecutive contig ranges, part index ascending)
+        std::vector<int> order;
+        for (int t = 0; t < max_parts; t++) if (part_first[(size_t)t] >= 0) order.push_back(t);
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return part_first[(size_t)x] < part_first[(size_t)y]; });
+        uint64_t total_vcf = 0;
+        for (int t : order) total_vcf += part_len[(size_t)t];
+        if (!raw_reserve(&B.vcf, &B.vcf_cap, (size_t)total_vcf + 1)) { free_parts(); return fail(c, MSIM_ERR_NOMEM, "batch VCF text"); }
         uint64_t at = 0;
-        for (int i = 0; i < n; i++) {
-            Batch::Item &it = B.items[(size_t)i];
-            it.vcf0 = at;
-            uint64_t need = 0;
-            if (it.nrec) {
-                need = render_vcf_unchecked(all + it.rec0, it.nrec, B.pool.data() + it.pool0, B.h_in + it.base, it.len,
-                                            contigs[i].name, &B.vcf[at]);
-                if (at + need > bound) return fail(c, MSIM_ERR_HIP, "internal: VCF bound of a batch too small");
-            }
-            it.nvcf = need;
-            at += need;
+        for (size_t k = 0; k < order.size(); k++) {
+            const int t = order[k];
+            const int i0 = part_first[(size_t)t], i1 = k + 1 < order.size() ? part_first[(size_t)order[k + 1]] : n;
+            for (int i = i0; i < i1; i++) B.items[(size_t)i].vcf0 += at;
+            if (part_len[(size_t)t]) memcpy(B.vcf + at, part_buf[(size_t)t], (size_t)part_len[(size_t)t]);
+            at += part_len[(size_t)t];
         }
-        B.vcf.resize(at);
+        B.vcf_len = (size_t)at;
+        free_parts();
     }
     if (prof)
         fprintf(stderr, "msim_batch_run: %d contigs, %.1f Mb: ingest %.1f ms, plan %.1f, upload+APPLY+download %.1f, framing %.1f, VCF %.1f\n",
@@ -1086,13 +1173,26 @@ int msim_batch_fetch(msim_ctx *p, uint8_t *fasta_text, uint64_t fasta_cap, char 
     if (!c || !c->batch) return MSIM_ERR_ARG;
     Batch &B = *c->batch;
     if (fasta_text) {
-        if (fasta_cap < B.fasta.size()) return fail(c, MSIM_ERR_ARG, "fasta buffer too small");
-        if (!B.fasta.empty()) memcpy(fasta_text, B.fasta.data(), B.fasta.size());
+        if (fasta_cap < B.fasta_len) return fail(c, MSIM_ERR_ARG, "fasta buffer too small");
+        if (B.fasta_len) memcpy(fasta_text, B.fasta, B.fasta_len);
     }
     if (vcf_text) {
-        if (vcf_cap < B.vcf.size()) return fail(c, MSIM_ERR_ARG, "vcf buffer too small");
-        if (!B.vcf.empty()) memcpy(vcf_text, B.vcf.data(), B.vcf.size());
+        if (vcf_cap < B.vcf_len) return fail(c, MSIM_ERR_ARG, "vcf buffer too small");
+        if (B.vcf_len) memcpy(vcf_text, B.vcf, B.vcf_len);
     }
+    return MSIM_OK;
+}
+
+int msim_batch_view(msim_ctx *p, const uint8_t **fasta_text, uint64_t *fasta_bytes, const char **vcf_text, uint64_t *vcf_bytes,
+                    uint64_t *last_line_bases) {
+    CTX_FLUSHED(c, p)
+    if (!c || !c->batch) return MSIM_ERR_ARG;
+    Batch &B = *c->batch;
+    if (fasta_text) *fasta_text = B.fasta;
+    if (fasta_bytes) *fasta_bytes = B.fasta_len;
+    if (vcf_text) *vcf_text = B.vcf;
+    if (vcf_bytes) *vcf_bytes = B.vcf_len;
+    if (last_line_bases) *last_line_bases = B.last_line_bases;
     return MSIM_OK;
 }
 

@@ -47,7 +47,7 @@ class Params(C.Structure):           # msim_params
 class BatchContig(C.Structure):      # msim_batch_contig
     _fields_ = [("body", C.c_void_p), ("body_bytes", C.c_uint64), ("n_bases", C.c_uint64),
                 ("lenc", C.c_uint32), ("lenb", C.c_uint32), ("ranges", C.POINTER(Range)),
-                ("n_ranges", C.c_int32), ("name", C.c_char_p)]
+                ("n_ranges", C.c_int32), ("name", C.c_char_p), ("header", C.c_char_p)]
 
 
 class Timing(C.Structure):           # msim_timing
@@ -100,6 +100,7 @@ SYMBOLS = [
     ("msim_batch_run", C.c_int, [_VP, C.POINTER(BatchContig), C.c_int]),
     ("msim_batch_sizes", C.c_int, [_VP, C.c_int, _U64P, _U64P, C.POINTER(C.c_int32), _U64P]),
     ("msim_batch_fetch", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
+    ("msim_batch_view", C.c_int, [_VP, C.POINTER(C.c_void_p), _U64P, C.POINTER(C.c_void_p), _U64P, _U64P]),
     ("msim_batch_key_contig", C.c_int, [_VP, _IP]),
     ("msim_comm_unique_id", C.c_int, [_VP]),
     ("msim_comm_init", C.c_int, [_VP, _VP, C.c_int, C.c_int]),
@@ -358,34 +359,39 @@ class Engine:
 
     # ------------------------------------------------------------------ many small contigs in one pass
     def batch_run(self, items):
-        """``items``: list of (body uint8 array, n_bases, lenc, lenb, [Range], name).  Returns (fasta_text uint8 array,
-        per-contig fasta byte counts, vcf_text bytes, per-contig empty flags)."""
+        """``items``: list of (body uint8 array, n_bases, lenc, lenb, [Range], name, header).  Returns (fasta_text, vcf_text,
+        per-contig empty flags, bases on the last FASTA line): the texts are uint8 VIEWS of libmsim's buffers (valid until
+        the next batch); fasta_text is the complete run of records ('>' header lines included) as FastaWriter writes them."""
         n = len(items)
         arr = (BatchContig * n)()
         keep = []
-        for i, (body, n_bases, lenc, lenb, ranges, name) in enumerate(items):
+        for i, (body, n_bases, lenc, lenb, ranges, name, header) in enumerate(items):
             body = np.ascontiguousarray(body, dtype=np.uint8)
             ra = (Range * max(len(ranges), 1))(*ranges)
             nm = name.encode("utf-8", "replace")
-            keep.append((body, ra, nm))
-            arr[i].body = body.ctypes.data
-            arr[i].body_bytes = body.shape[0]
-            arr[i].n_bases = n_bases
-            arr[i].lenc, arr[i].lenb = lenc, lenb
-            arr[i].ranges = ra
-            arr[i].n_ranges = len(ranges)
-            arr[i].name = nm
+            hd = header.encode("utf-8", "replace")
+            keep.append((body, ra, nm, hd))
+            q = arr[i]
+            q.body = body.ctypes.data
+            q.body_bytes = body.shape[0]
+            q.n_bases = n_bases
+            q.lenc, q.lenb = lenc, lenb
+            q.ranges = ra
+            q.n_ranges = len(ranges)
+            q.name = nm
+            q.header = hd
         self._check(self.lib.msim_batch_run(self.h, arr, n))
-        fb = (C.c_uint64 * n)()
-        vb = (C.c_uint64 * n)()
         em = (C.c_int32 * n)()
-        self._check(self.lib.msim_batch_sizes(self.h, n, fb, vb, em, None))
-        fsz = np.frombuffer(fb, dtype=np.uint64).astype(np.int64)
-        vsz = int(np.frombuffer(vb, dtype=np.uint64).sum())
-        fasta = np.empty(int(fsz.sum()), dtype=np.uint8)
-        vcf = np.empty(vsz, dtype=np.uint8)
-        self._check(self.lib.msim_batch_fetch(self.h, _ptr(fasta), fasta.shape[0], _ptr(vcf), vcf.shape[0]))
-        return fasta, fsz, vcf, [bool(x) for x in em]
+        self._check(self.lib.msim_batch_sizes(self.h, n, None, None, em, None))
+        fp, vp = C.c_void_p(), C.c_void_p()
+        fn, vn, last = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.msim_batch_view(self.h, C.byref(fp), C.byref(fn), C.byref(vp), C.byref(vn), C.byref(last)))
+
+        def view(ptr, nbytes):
+            if not nbytes:
+                return np.empty(0, dtype=np.uint8)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
+        return view(fp, fn.value), view(vp, vn.value), np.frombuffer(em, dtype=np.int32) != 0, last.value
 
     # ------------------------------------------------------------------ multi-GPU (csrc/comm.cpp)
     def comm_init(self, unique_id: bytes, rank: int, world: int):

@@ -57,6 +57,18 @@ class FastaWriter:
             self._out.write(memoryview(np.ascontiguousarray(text)))
             self._written = n_bases % self._bpl
 
+    def write_records(self, text: np.ndarray, bpl: int, last_line_bases: int):
+        """Append a run of complete records -- header lines and wrapped bodies, exactly the bytes ``write_header`` +
+        ``write_framed`` would produce for each (``Engine.batch_run``).  ``bpl`` / ``last_line_bases``: line width of the
+        last record and the bases on its last line, so that whatever follows continues correctly."""
+        if text.shape[0] == 0:
+            return
+        if self._written != 0:
+            self._out.write(b"\n")
+        self._out.write(memoryview(np.ascontiguousarray(text)))
+        self._bpl = bpl
+        self._written = int(last_line_bases)
+
     def write_array(self, bases: np.ndarray):
         """Append ``bases`` (uint8) wrapped at the current line width."""
         n = int(bases.shape[0])

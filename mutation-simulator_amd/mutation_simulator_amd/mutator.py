@@ -195,20 +195,12 @@ class Mutator:
         items = []
         for chrom in chroms:
             rec = self._fasta[chrom.number]
-            items.append((rec.body, len(rec), rec.lenc, rec.lenb, plan_descriptors(chrom), rec.name))
-        fasta, fsz, vcf, empty = eng.batch_run(items)
-        at = 0
-        for k, chrom in enumerate(chroms):
-            rec = self._fasta[chrom.number]
-            if empty[k]:
-                self._warn_empty(chrom)
-            bpl = self._fasta.faidx.index[rec.name].lenc
-            self._fasta_writer.set_bpl(bpl)
-            self._fasta_writer.write_header(rec.long_name)
-            n = int(fsz[k])
-            q, r = divmod(n, bpl + 1)                      # text = L + L // bpl bytes  ->  L
-            self._fasta_writer.write_framed(fasta[at:at + n], q * bpl + r)
-            at += n
+            items.append((rec.body, len(rec), rec.lenc, rec.lenb, plan_descriptors(chrom), rec.name, rec.long_name))
+        fasta, vcf, empty, last_line = eng.batch_run(items)
+        for k in np.flatnonzero(empty):
+            self._warn_empty(chroms[int(k)])
+        last = self._fasta[chroms[-1].number]
+        self._fasta_writer.write_records(fasta, self._fasta.faidx.index[last.name].lenc, last_line)
         self._vcf_writer.write_raw(memoryview(vcf))
 
     def _mutate_one(self, eng, chrom, earlier=()):
