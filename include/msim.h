@@ -232,6 +232,24 @@ int msim_batch_view(msim_ctx *ctx, const uint8_t **fasta_text, uint64_t *fasta_b
                     uint64_t *vcf_bytes, uint64_t *last_line_bases);
 int msim_batch_key_contig(msim_ctx *ctx, int *contig);
 
+/* ---- FASTA index pass of the host loader (replaces pyfaidx's index, util.py:77-91) ---------------------------------- */
+/* Pure host code, no context: per record of a FASTA text the facts pyfaidx's index holds -- where the defline text and the
+ * body sit, bases, bases per line (lenc), bytes per line (lenb) -- and pyfaidx's consistency verdict.  The body is NOT
+ * touched otherwise: it goes to the device as text (msim_add_contig_text).  Call with records = NULL to count.
+ * MSIM_ERR_VALUE: sequence text before the first defline (pyfaidx: FastaIndexingError).                                */
+#define MSIM_FASTA_HAS_BODY    1u   /* at least one line follows the defline                                              */
+#define MSIM_FASTA_BAD_LINES   2u   /* a line before the last non-empty one differs from the first line's length, or the
+                                       last non-empty line is longer ("Line length of fasta file is not consistent")       */
+#define MSIM_FASTA_NONUNIFORM  4u   /* mixed "\n" / "\r\n" terminators inside the record: no fixed stride for the device  */
+typedef struct msim_fasta_record {
+    uint64_t h0, h1;       /* defline text [h0, h1): without '>' and without the line terminator                          */
+    uint64_t b0, b1;       /* body text [b0, b1): from the first base to the end of the record's last line (exclusive)     */
+    uint64_t n_bases;
+    uint32_t lenc, lenb;   /* bases / bytes of the first body line (bytes include its terminator)                          */
+    uint32_t flags, rsv;
+} msim_fasta_record;
+int msim_fasta_index(const uint8_t *text, uint64_t n, msim_fasta_record *records, uint64_t cap, uint64_t *n_records);
+
 /* ---- multi-GPU: one process per GPU, contigs' APPLY sharded, gather over RCCL ------------------ */
 /* mutate()'s contig loop (mutator.py:111-141) is the unit of sharding: PLAN is replayed on every rank (the two
  * MT19937 streams chain across contigs), each rank APPLYs the contigs it owns, and the one exchange step is the

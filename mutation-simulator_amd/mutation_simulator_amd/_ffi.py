@@ -102,6 +102,7 @@ SYMBOLS = [
     ("msim_batch_fetch", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     ("msim_batch_view", C.c_int, [_VP, C.POINTER(C.c_void_p), _U64P, C.POINTER(C.c_void_p), _U64P, _U64P]),
     ("msim_batch_key_contig", C.c_int, [_VP, _IP]),
+    ("msim_fasta_index", C.c_int, [_VP, C.c_uint64, _VP, C.c_uint64, _U64P]),
     ("msim_comm_unique_id", C.c_int, [_VP]),
     ("msim_comm_init", C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     ("msim_comm_destroy", C.c_int, [_VP]),
@@ -475,3 +476,27 @@ def render_vcf(recs: np.ndarray, pool: np.ndarray, bases: np.ndarray, seq_name: 
     if rc != OK:
         raise MsimError(f"msim_render_vcf failed ({rc})")
     return out.tobytes()
+
+
+FASTA_RECORD_DTYPE = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("b0", "<u8"), ("b1", "<u8"), ("n_bases", "<u8"),
+                               ("lenc", "<u4"), ("lenb", "<u4"), ("flags", "<u4"), ("rsv", "<u4")])   # msim_fasta_record
+FASTA_HAS_BODY, FASTA_BAD_LINES, FASTA_NONUNIFORM = 1, 2, 4
+
+
+def fasta_index(text: np.ndarray):
+    """Index pass over a whole FASTA text (uint8): structured array of msim_fasta_record, or None when sequence text
+    precedes the first defline (pyfaidx: FastaIndexingError)."""
+    lib = load()
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    n = C.c_uint64()
+    rc = lib.msim_fasta_index(_ptr(text), text.shape[0], None, 0, C.byref(n))
+    if rc == 3:                                        # MSIM_ERR_VALUE
+        return None
+    if rc:
+        raise MsimError(f"msim_fasta_index failed ({rc})")
+    out = np.zeros(n.value, dtype=FASTA_RECORD_DTYPE)
+    if n.value:
+        rc = lib.msim_fasta_index(_ptr(text), text.shape[0], out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+        if rc:
+            raise MsimError(f"msim_fasta_index failed ({rc})")
+    return out

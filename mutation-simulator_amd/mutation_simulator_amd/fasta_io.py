@@ -3,8 +3,8 @@
 Replaces what the reference gets from the third-party ``pyfaidx`` package (reference
 util.py:77-91: ``Fasta(path, one_based_attributes=False, as_raw=True, sequence_always_upper=True,
 read_ahead=10000)``).  The reference streams bases one at a time through pyfaidx; the HIP path wants
-each contig as one contiguous byte array to upload to HBM, so this loader parses the file once with
-vectorised NumPy passes and exposes the small part of the pyfaidx surface the path touches:
+each contig as one contiguous byte array to upload to HBM, so this loader indexes the file once (natively, in
+libmsim: ``msim_fasta_index``) and exposes the small part of the pyfaidx surface the path touches:
 
     fasta.keys()                       record names in file order
     fasta[i] / fasta[name]             -> FastaRecord
@@ -95,67 +95,32 @@ class Fasta:
 
     # ------------------------------------------------------------------ parsing
     def _parse(self, raw: np.ndarray) -> None:
-        n = raw.shape[0]
-        if n == 0:
+        """The index pass runs in libmsim (csrc/fasta_index.cpp: msim_fasta_index, several host threads): per record the
+        spans of the defline and of the body text, bases, bases / bytes per line and pyfaidx's line-length verdict.  A
+        3 Gb genome has 24 records, an assembly tens of thousands -- the loop below is all the per-record Python left."""
+        from . import _ffi
+        if raw.shape[0] == 0:
             return
-        nl = np.flatnonzero(raw == 10)
-        starts = np.concatenate(([0], nl + 1))
-        if starts[-1] >= n:
-            starts = starts[:-1]
-        ends = np.concatenate((nl, [n]))[:starts.shape[0]]          # exclusive, at the '\n'
-        is_hdr = raw[starts] == ord(">")
-        hdr_lines = np.flatnonzero(is_hdr)
-        if hdr_lines.size == 0:
-            if np.any(ends > starts):
-                raise FastaIndexingError("Sequence data found before the first defline")
-            return
-        if hdr_lines[0] != 0 and np.any(ends[:hdr_lines[0]] > starts[:hdr_lines[0]]):
+        idx = _ffi.fasta_index(raw)
+        if idx is None:
             raise FastaIndexingError("Sequence data found before the first defline")
-        # per-line quantities for the whole file, per-record reductions with reduceat: an assembly with tens of
-        # thousands of scaffolds must not pay a dozen small NumPy calls per record
-        n_lines = starts.shape[0]
-        l_start = starts.astype(np.int64)
-        l_end = ends.astype(np.int64)
-        cr = (l_end > l_start) & (raw[np.maximum(l_end - 1, 0)] == 13)
-        llen = l_end - l_start - cr
-        line_idx = np.arange(n_lines, dtype=np.int64)
-        body_line = ~is_hdr
-        body_line[:hdr_lines[0]] = False
-        rec_of_line = np.cumsum(is_hdr) - 1                               # (lines before the first defline: -1, masked)
-        lo = hdr_lines + 1
-        hi = np.concatenate((hdr_lines[1:], [n_lines]))
-        has_body = lo < hi
-        lo_c = np.minimum(lo, n_lines - 1)
-        n_bases = np.add.reduceat(np.where(body_line, llen, 0), hdr_lines)
-        lenc_r = np.where(has_body, llen[lo_c], 0)
-        lenb_r = np.where(has_body, l_end[lo_c] - l_start[lo_c] + 1, 0)
-        last_nz = np.maximum.reduceat(np.where(body_line & (llen > 0), line_idx, -1), hdr_lines)
-        rl = np.maximum(rec_of_line, 0)
-        before_last = body_line & (line_idx < last_nz[rl])
-        # every line but the last non-empty one must have the record's line length
-        bad_line = (before_last & (llen != lenc_r[rl])) | (body_line & (line_idx == last_nz[rl]) & (llen > lenc_r[rl]))
-        bad_rec = np.logical_or.reduceat(bad_line, hdr_lines)
-        # fixed stride: every full line has the first line's terminator ('\n' or '\r\n')
-        nonuni = np.logical_or.reduceat(before_last & (cr != cr[lo_c][rl]), hdr_lines)
-        h0s = l_start[hdr_lines] + 1
-        h1s = l_end[hdr_lines] - cr[hdr_lines]
-        b0s = l_start[lo_c]
-        b1s = l_end[np.maximum(hi - 1, 0)]
-        for k in range(hdr_lines.shape[0]):
-            long_name = raw[h0s[k]:h1s[k]].tobytes().decode("utf-8", "replace")
+        h0, h1, b0, b1 = (idx[k].tolist() for k in ("h0", "h1", "b0", "b1"))
+        n_bases, lenc, lenb, flags = (idx[k].tolist() for k in ("n_bases", "lenc", "lenb", "flags"))
+        for k in range(idx.shape[0]):
+            long_name = raw[h0[k]:h1[k]].tobytes().decode("utf-8", "replace")
             toks = long_name.split()
             name = toks[0] if toks else ""
             if name in self._records:
                 raise ValueError(f"Duplicate key \"{name}\"")
-            if not has_body[k]:
-                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, 0, int(l_end[hdr_lines[k]]) + 1, True)
+            fl = flags[k]
+            if not fl & _ffi.FASTA_HAS_BODY:
+                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, 0, b0[k], True)
             else:
-                if bad_rec[k]:
+                if fl & _ffi.FASTA_BAD_LINES:
                     raise FastaIndexingError(
                         f"Line length of fasta file is not consistent in {name}")
-                b0 = int(b0s[k])
-                rec = FastaRecord(name, long_name, raw[b0:int(b1s[k])], int(n_bases[k]), int(lenc_r[k]), int(lenb_r[k]),
-                                  b0, not bool(nonuni[k]))
+                rec = FastaRecord(name, long_name, raw[b0[k]:b1[k]], n_bases[k], lenc[k], lenb[k], b0[k],
+                                  not fl & _ffi.FASTA_NONUNIFORM)
             self._records[name] = rec
             self._order.append(rec)
 

@@ -1,0 +1,109 @@
+"""msim_fasta_index (csrc/fasta_index.cpp) -- the loader's index pass -- against a line-by-line restatement of what
+pyfaidx's index records and refuses (reference util.py:77-91 reads through pyfaidx): random FASTA texts with LF / CRLF
+terminators, short last lines, blank lines, records without sequence, '>' inside deflines, no final newline; plus a text
+large enough to be split over the host threads."""
+import numpy as np
+import pytest
+
+from mutation_simulator_amd import _ffi
+
+
+def _reference_index(text: bytes):
+    """Plain Python: list of dicts per record, or None for sequence text before the first defline."""
+    lines, at = [], 0
+    while at < len(text):
+        e = text.find(b"\n", at)
+        if e < 0:
+            e = len(text)
+        lines.append((at, e))
+        at = e + 1
+    recs, cur = [], None
+    for a, e in lines:
+        if text[a:a + 1] == b">":
+            cr = e > a + 1 and text[e - 1:e] == b"\r"
+            cur = dict(h0=a + 1, h1=e - cr, lines=[], after=e + 1)
+            recs.append(cur)
+        elif cur is None:
+            if e > a:
+                return None
+        else:
+            cr = e > a and text[e - 1:e] == b"\r"
+            cur["lines"].append((a, e, e - a - cr, cr))
+    out = []
+    for r in recs:
+        ls = r["lines"]
+        if not ls:
+            out.append(dict(h0=r["h0"], h1=r["h1"], b0=r["after"], b1=r["after"], n_bases=0, lenc=0, lenb=0, flags=0))
+            continue
+        lenc, first_cr = ls[0][2], ls[0][3]
+        nz = [i for i, l in enumerate(ls) if l[2] > 0]
+        last = nz[-1] if nz else -1
+        bad = any(l[2] != lenc for l in ls[:max(last, 0)]) or (last >= 0 and ls[last][2] > lenc)
+        nonuni = any(l[3] != first_cr for l in ls[:max(last, 0)])
+        out.append(dict(h0=r["h0"], h1=r["h1"], b0=ls[0][0], b1=ls[-1][1], n_bases=sum(l[2] for l in ls), lenc=lenc,
+                        lenb=ls[0][1] - ls[0][0] + 1, flags=1 | (2 if bad else 0) | (4 if nonuni else 0)))
+    return out
+
+
+def _check(text: bytes):
+    want = _reference_index(text)
+    got = _ffi.fasta_index(np.frombuffer(text, dtype=np.uint8))
+    if want is None:
+        assert got is None
+        return
+    assert got is not None and got.shape[0] == len(want)
+    for k, w in enumerate(want):
+        g = {f: int(got[f][k]) for f in w}
+        assert g == w, (k, g, w, text[max(0, w["h0"] - 1):w["h0"] + 40])
+
+
+def _random_text(rs, n_rec, big=False):
+    parts = []
+    if rs.rand() < 0.2:
+        parts.append(b"\n" * int(rs.randint(1, 4)))
+    for r in range(n_rec):
+        nl = b"\r\n" if rs.rand() < 0.3 else b"\n"
+        name = b"seq%d" % r + (b" desc >not a record" if rs.rand() < 0.3 else b"")
+        if rs.rand() < 0.05:
+            name = b""
+        parts.append(b">" + name + nl)
+        kind = rs.rand()
+        if kind < 0.1:
+            continue                                                       # record without sequence
+        bpl = int(rs.choice([1, 7, 60, 61, 80]))
+        n = int(rs.randint(0, 20000 if big else 400))
+        seq = bytes(rs.choice(np.frombuffer(b"ACGTNacgtRY", dtype=np.uint8), size=n))
+        body = [seq[i:i + bpl] for i in range(0, n, bpl)] or [b""]
+        for i, ln in enumerate(body):
+            t = nl
+            if rs.rand() < 0.02:
+                t = b"\r\n" if nl == b"\n" else b"\n"                       # mixed terminators
+            if rs.rand() < 0.01:
+                ln = ln + b"A"                                             # a line of the wrong length
+            parts.append(ln + t)
+        if rs.rand() < 0.15:
+            parts.append(nl * int(rs.randint(1, 3)))                       # trailing blank lines
+    text = b"".join(parts)
+    if rs.rand() < 0.3 and text.endswith(b"\n"):
+        text = text[:-1]                                                   # no final newline
+    return text
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_index_matches_line_by_line_restatement(seed):
+    rs = np.random.RandomState(seed)
+    for _ in range(25):
+        _check(_random_text(rs, int(rs.randint(0, 12))))
+
+
+def test_index_edge_texts():
+    for text in [b"", b"\n\n", b">", b">\n", b">a", b">a\n", b">a\nACGT", b">a\r\nAC\r\nGT\r\n", b"ACGT\n>a\nAC\n", b"\r\n>a\nAC\n",
+                 b">a\n\n\nAC\n", b">a\nAC\n\nAC\n", b">a\nACG\nAC\nA\n", b">a\nAC\nACG\n", b">a\n>b\n>c\nA\n", b">a\nAC>GT\nAC\n"]:
+        _check(text)
+
+
+def test_index_large_text_over_threads():
+    rs = np.random.RandomState(123)
+    text = _random_text(rs, 900, big=True)
+    assert len(text) > (8 << 20)                                            # more than one slice per pass
+    _check(text)
