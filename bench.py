@@ -252,6 +252,15 @@ def roofline_of(st, workload, steps):
             "avg_launch_ms": round(k_ms / launches, 4), "launches": launches}
 
 
+def step_roofline(st, dt):
+    """The same algorithmic bytes over the WHOLE timed region (PLAN chain included), for orientation: the step is bound by
+    the latency of the per-contig stream-position chain (and, for c3 / c4, by a host core), not by HBM."""
+    alg_bytes = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
+    achieved = alg_bytes / dt / 1e9 if dt > 0 else 0.0
+    return {"achieved": round(achieved, 1), "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "what": "algorithmic bytes of all APPLY launches / wall time of the timed steps"}
+
+
 def stages_of(st, steps):
     return {"plan_host": round(st["plan_host_ms"] / steps, 3), "plan_gpu": round(st["plan_gpu_ms"] / steps, 3),
             "record_upload": round(st["upload_ms"] / steps, 3), "apply_all_kernels": round(st["apply_ms"] / steps, 3),
@@ -382,6 +391,8 @@ def main():
             "records_per_step": st["records"] // a.steps,
             "roofline": roofline_of(st, a.workload, a.steps),
         }
+        if world == 1:
+            line["step_roofline"] = step_roofline(st, dt)
     if strong and comm is not None:
         # the exchange step north_star names: every peer sends its mutated contigs to rank 0 over its own xGMI link
         dtg, _ = measure(a.workload, a.steps, 1, gather=True)
@@ -408,7 +419,7 @@ def main():
             sec[w] = {"metric": WORKLOADS[w]["metric"], "value": round(sum(lengths) * n_sec / dts / 1e6, 3), "unit": "Mbases/s",
                       "ms_per_step": round(dts / n_sec * 1e3, 3), "steps": n_sec, "warmup": w_sec,
                       "stages_ms_per_step": stages_of(sts, n_sec), "records_per_step": sts["records"] // n_sec,
-                      "roofline": roofline_of(sts, w, n_sec)}
+                      "roofline": roofline_of(sts, w, n_sec), "step_roofline": step_roofline(sts, dts)}
         line["secondary"] = sec
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
