@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -96,8 +97,13 @@ extern "C" int msim_fasta_index(const uint8_t *text, uint64_t n, msim_fasta_reco
     };
     {
         std::vector<std::thread> th;
-        for (int t = 1; t < T; t++) th.emplace_back(scan, t);
+        int started = 1;
+        try {
+            for (int t = 1; t < T; t++, started++) th.emplace_back(scan, t);
+        } catch (const std::system_error &) {              // no more threads to be had: the remaining slices run here
+        }
         scan(0);
+        for (int t = started; t < T; t++) scan(t);
         for (auto &x : th) x.join();
     }
     std::vector<uint64_t> hdr;
@@ -120,7 +126,10 @@ extern "C" int msim_fasta_index(const uint8_t *text, uint64_t n, msim_fasta_reco
         }
     };
     const int T2 = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)index_threads(), (R + 63) / 64));
-    for (int t = 1; t < T2; t++) th.emplace_back(work);
+    try {
+        for (int t = 1; t < T2; t++) th.emplace_back(work);
+    } catch (const std::system_error &) {                  // fewer helpers: the shared counter hands their records to the others
+    }
     work();
     for (auto &x : th) x.join();
     return MSIM_OK;

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <system_error>
 #include <thread>
 
 #include <dlfcn.h>
@@ -885,8 +886,14 @@ template <class F> static void parallel_slices(int n, F f) {   // f(part, i0, i1
     const int parts = std::max(1, std::min(batch_threads(), n / 64));
     if (parts == 1) { f(0, 0, n); return; }
     std::vector<std::thread> th;
-    for (int t = 1; t < parts; t++) th.emplace_back(f, t, (int)((long long)n * t / parts), (int)((long long)n * (t + 1) / parts));
+    int started = 1;                                       // slices [0, started) run or have run; the rest falls to this thread
+    try {
+        for (int t = 1; t < parts; t++, started++)
+            th.emplace_back(f, t, (int)((long long)n * t / parts), (int)((long long)n * (t + 1) / parts));
+    } catch (const std::system_error &) {                  // no more threads to be had: the remaining slices run here
+    }
     f(0, 0, (int)((long long)n / parts));
+    for (int t = started; t < parts; t++) f(t, (int)((long long)n * t / parts), (int)((long long)n * (t + 1) / parts));
     for (auto &x : th) x.join();
 }
 
