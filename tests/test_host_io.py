@@ -74,6 +74,44 @@ def test_fasta_writer_single_base_api(tmp_path):
     assert out.read_bytes() == b">h1\nACG\nTA\n>h2\nACG\n>h3\nTT"
 
 
+def test_fasta_writer_whole_records_continue_like_single_writes(tmp_path):
+    """write_records (a run of complete records as libmsim's batch path returns them: header lines included, a newline
+    before a header iff the body before it ended mid-line) leaves the writer in the state the per-record calls would:
+    whatever follows -- another header, more records -- lands on the same bytes."""
+    import numpy as np
+    recs = [("a x", b"ACGTACG", 3), ("b", b"", 4), ("c", b"ACGTACGT", 4), ("d", b"AC", 5)]
+
+    def framed(seq, bpl):
+        return b"\n".join(seq[i:i + bpl] for i in range(0, len(seq), bpl)) + (b"\n" if seq and len(seq) % bpl == 0 else b"")
+
+    ref = msa.FastaWriter(tmp_path / "ref.fa")
+    ref.set_bpl(7)
+    ref.write_header("first")
+    ref.write_multi("ACGTA")                                  # the run starts behind a partial line
+    for name, seq, bpl in recs:
+        ref.set_bpl(bpl)
+        ref.write_header(name)
+        ref.write_framed(np.frombuffer(framed(seq, bpl), dtype=np.uint8), len(seq))
+    ref.write_header("after")
+    ref.write_multi("GG")
+    ref.close()
+
+    text = b""
+    for i, (name, seq, bpl) in enumerate(recs):
+        if i and recs[i - 1][1] and len(recs[i - 1][1]) % recs[i - 1][2]:
+            text += b"\n"
+        text += b">" + name.encode() + b"\n" + framed(seq, bpl)
+    got = msa.FastaWriter(tmp_path / "got.fa")
+    got.set_bpl(7)
+    got.write_header("first")
+    got.write_multi("ACGTA")
+    got.write_records(np.frombuffer(text, dtype=np.uint8), recs[-1][2], len(recs[-1][1]) % recs[-1][2])
+    got.write_header("after")
+    got.write_multi("GG")
+    got.close()
+    assert (tmp_path / "got.fa").read_bytes() == (tmp_path / "ref.fa").read_bytes()
+
+
 def test_vcf_writer_header_and_record(tmp_path):
     name = "snp_titv2_2ctg"
     meta = case_meta(name)
