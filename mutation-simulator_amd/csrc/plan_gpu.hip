@@ -776,12 +776,18 @@ bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_range
     return true;
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
 // Wait for a word in pinned host memory that a kernel on `s` raises to `want`.  The stream is queried now and then so
 // that a failed launch or a device fault ends the wait with an error instead of a hang.
 static int spin_until(Ctx *c, const uint32_t *word, uint32_t want, hipStream_t s) {
     for (uint64_t it = 1;; it++) {
         if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return MSIM_OK;
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((it & 0x3ffff) == 0) {
             const hipError_t e = hipStreamQuery(s);
             if (e == hipSuccess) {
@@ -798,7 +804,7 @@ static int spin_event(Ctx *c, hipEvent_t ev) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return MSIM_OK;
         if (e != hipErrorNotReady) return hip_fail(c, e, "hipEventQuery");
-        __builtin_ia32_pause();
+        cpu_relax();
     }
 }
 
