@@ -1320,7 +1320,6 @@ __global__ __launch_bounds__(WK_THREADS) void k_sample_walk(const uint32_t *__re
     const unsigned long long p0 = ps->pos;
     // ring: words [base, base + 3 Q) resident and tempered, [base + 3 Q, base + 4 Q) in flight -- loaded straight into
     // LDS (global_load_lds), so that no register and no compiler-inserted vmcnt wait ties the chain to global memory
-    typedef __attribute__((address_space(1))) const void wk_gmem;
     typedef __attribute__((address_space(3))) void wk_lmem;
     // (issued from inline asm: hipcc guards every LDS access that follows a global_load_lds it knows about with
     // vmcnt(0), which would turn the prefetch into a blocking load; the chain waits for it by hand, a refill later)
