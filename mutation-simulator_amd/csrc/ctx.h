@@ -169,6 +169,40 @@ int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, c
 int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
                        size_t n_words, uint32_t *pos_out, size_t *consumed);
 
+// ---- general host-chain engine (plan_gpu.hip: plan_contig_gpu_multimix) ---------------------------------------
+// Contigs whose drawing ranges differ in their settings (RMT files: gene blocks + an SV `std` line, hot / cold
+// ranges with their own rates and lengths) or whose SNP block exceeds the sampling distance.  Per range the
+// reference runs sample() -> type draw -> boundary pass (mutator.py:144-214) before it touches the next range, so
+// the CPython stream interleaves samples and randint draws: one chain over all ranges, walked here over words,
+// "next accepted draw" tables and candidate types the DEVICE produced.  Distinct MutationSettings are numbered
+// (`sets`); the randint classes of all of them share one table (at most 4 classes).
+struct MixSets {
+    ChainClasses gcc{};                     // union of the (shift, width) classes of every set; cls_of unused
+    std::vector<uint32_t> set_of;           // per DRAWING range (k > 0), in order: its set
+    std::vector<int> rep;                   // per set: index into ranges[] of one range that uses it
+    std::vector<ChainClasses> cc;           // per set: gcc with the set's own cls_of
+    bool sn_chained = false;                // block[SN] != d: SNPs block their successors -> every candidate is on the chain
+    uint64_t K = 0;                         // candidates of the contig
+    uint32_t n_draw = 0;
+};
+// false: outside the engine (translocations, overlapping / unsorted ranges, ValueError cases, > 4 randint classes,
+// lengths beyond a table entry, contig >= 2^31) -- the host planner decides
+bool multimix_prepare(const Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, MixSets &ms);
+// The walk.  ch_rank / ch_type: candidate ordinal and type of every candidate ON THE CHAIN in ordinal order (the
+// non-SNPs; all candidates when ms.sn_chained) -- types come from the NumPy stream by ordinal alone, so the device
+// knows them before any position exists.  words: tempered CPython-stream words from the current position on;
+// T: accept tables of ms.gcc over the same window (n_words + 1 entries << lg_rows).  Out: cand_pos[K] (every
+// candidate, position order), ch_stop[n_ch] (Mutation.stop or CHAIN_DROPPED), visit_from[n_draw]: candidates of
+// drawing range i below visit_from[i] lie inside a DE/DU/IV span of an EARLIER range (the blocked range is reset
+// per range, mutator.py:184) and are never visited by __mutate_sequence (mutator.py:376,386,398).
+int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, int64_t d, const MixSets &ms,
+                       const uint32_t *words, const uint32_t *T, size_t n_words, const uint32_t *ch_rank,
+                       const uint8_t *ch_type, size_t n_ch, uint32_t *cand_pos, uint32_t *ch_stop, uint32_t *visit_from,
+                       size_t *consumed, const WordFeed *feed = nullptr);
+// test support (msim_dbg_multimix_plan): the whole engine on the host -- the device's parts (types, tables, keep
+// flags, records) restated sequentially -- so the CPU tier can hold the algorithm against plan_contig_host
+int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out);
+
 // text_gpu.hip
 int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);
 int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes);

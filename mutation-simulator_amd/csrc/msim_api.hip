@@ -799,6 +799,25 @@ int msim_dbg_chain_boundary_tables(msim_ctx *p, const msim_range *r, uint64_t L,
     return rc;
 }
 
+// The general host-chain engine end to end on the host (multimix_plan_emulated): the record table and insert pool it
+// arrives at, for comparison with msim_plan_contig's host planner on the same streams.  Call with recs == NULL for the sizes.
+int msim_dbg_multimix_plan(msim_ctx *p, uint64_t L, const msim_range *ranges, int n_ranges, msim_record *recs, uint64_t cap_recs,
+                           uint8_t *pool, uint64_t cap_pool, uint64_t *n_recs, uint64_t *pool_len, int *empty) {
+    CTX_FLUSHED(c, p)
+    if (!c || !n_recs || !pool_len || !empty || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    if (!c->host_only) return fail(c, MSIM_ERR_ARG, "msim_dbg_multimix_plan needs a host-only context");
+    HostPlan hp;
+    const int rc = multimix_plan_emulated(c, L, ranges, n_ranges, hp);
+    if (rc) return rc;
+    *n_recs = hp.recs.size(); *pool_len = hp.pool.size(); *empty = hp.empty ? 1 : 0;
+    if (recs) {
+        if (cap_recs < hp.recs.size() || cap_pool < hp.pool.size()) return fail(c, MSIM_ERR_ARG, "buffers too small");
+        if (!hp.recs.empty()) memcpy(recs, hp.recs.data(), hp.recs.size() * sizeof(msim_record));
+        if (!hp.pool.empty() && pool) memcpy(pool, hp.pool.data(), hp.pool.size());
+    }
+    return MSIM_OK;
+}
+
 int msim_dbg_stream_status(msim_ctx *p, int out[8]) {
     CTX_FLUSHED(c, p)
     if (!c || !out || c->host_only || !c->gpu) return MSIM_ERR_ARG;

@@ -12,7 +12,10 @@
 // draw order of mutator.py:318-471 (__mutate_sequence, __get_snp, __get_insert).
 #include <algorithm>
 #include <chrono>
+#include <cstddef>
 #include <cstring>
+#include <string>
+#include <unordered_map>
 
 #include "ctx.h"
 
@@ -264,8 +267,9 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
 // k_accept_tables) and hands over  T[w][class] = (words consumed) << 24 | value.  The walk is then one
 // table load per candidate with a branch-free keep / drop: the loop-carried chain is  w -> T[w] -> w  and
 // blk_hi -> dropped -> blk_hi, about 8 cycles.
-bool chain_classes(const msim_range &r, ChainClasses &cc) {
-    cc = ChainClasses{};
+// append the classes of r's drawable IN/DE/DU/IV lengths to g (at most 4); cls_of[t] = class of type t
+static bool chain_classes_add(const msim_range &r, ChainClasses &g, uint8_t cls_of[8]) {
+    for (int t = 0; t < 8; t++) cls_of[t] = 0;
     for (int t : {MSIM_IN, MSIM_DE, MSIM_DU, MSIM_IV}) {
         bool drawn = false;                                  // can the type draw of this range produce t at all?
         for (int j = 0; j < r.n_types && j < 8; j++) {
@@ -278,10 +282,19 @@ bool chain_classes(const msim_range &r, ChainClasses &cc) {
         if (r.min_len[t] < 1 || r.max_len[t] >= (1ll << 30)) return false;   // keeps 0 <= stop < 2^32 - 1 without a check
         const uint32_t sh = (uint32_t)(32 - bit_length64((uint64_t)w));
         uint32_t k = 0;
-        while (k < cc.n && !(cc.sh[k] == sh && cc.width[k] == (uint32_t)w)) k++;
-        if (k == cc.n) { cc.sh[k] = sh; cc.width[k] = (uint32_t)w; cc.n++; }
-        cc.cls_of[t] = (uint8_t)k;
+        while (k < g.n && !(g.sh[k] == sh && g.width[k] == (uint32_t)w)) k++;
+        if (k == g.n) {
+            if (g.n >= 4) return false;                              // a table entry's increment field: 63 << 2 < 256
+            g.sh[k] = sh; g.width[k] = (uint32_t)w; g.n++;
+        }
+        cls_of[t] = (uint8_t)k;
     }
+    return true;
+}
+
+bool chain_classes(const msim_range &r, ChainClasses &cc) {
+    cc = ChainClasses{};
+    if (!chain_classes_add(r, cc, cc.cls_of)) return false;
     if (!cc.n) { cc.n = 1; cc.sh[0] = 31; cc.width[0] = 1; }     // nothing but SNPs drawn: an unused placeholder class
     return true;
 }
@@ -515,123 +528,386 @@ int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, c
     return MSIM_OK;
 }
 
-int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
-                       size_t n_words, uint32_t *pos_out, size_t *consumed) {
-    const auto t0 = std::chrono::steady_clock::now();
-    size_t w = 0, at = 0;
-    static thread_local std::vector<uint64_t> bits;                 // cleared while it is scanned
-    std::vector<uint32_t> pool, picked;
-    static thread_local std::vector<uint32_t> accbuf;                // accepted draws of one round
-    auto overflow = [&]() {
-        std::fill(bits.begin(), bits.end(), 0);                       // keep the scratch bitmap clean for the next call
-        return fail(c, MSIM_ERR_HIP, "host sampler: word window overflowed its margin");
-    };
-    for (int ri = 0; ri < n_ranges; ri++) {
-        const msim_range &r = ranges[ri];
-        const int64_t k = r.k;
-        if (k == 0) continue;
-        const int64_t n = (r.stop - (k - 1) * d) - r.start;          // util.py:104
-        if (k < 0 || k > n) return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
-        if (n >= (1ll << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "sampling range of 2^32 or more positions");
-        const uint32_t base = (uint32_t)r.start, dd = (uint32_t)d;
-        if (n <= r.setsize) {                                        // pool path: partial Fisher-Yates
-            pool.resize((size_t)n);
-            for (int64_t i = 0; i < n; i++) pool[(size_t)i] = (uint32_t)i;
-            picked.clear();
-            for (int64_t i = 0; i < k; i++) {
-                const uint64_t m = (uint64_t)(n - i);
-                const int sh = 32 - bit_length64(m);
-                uint64_t v;
-                do { if (w >= n_words) return overflow(); v = words[w++] >> sh; } while (v >= m);
-                picked.push_back(pool[(size_t)v]);
-                pool[(size_t)v] = pool[(size_t)(n - i - 1)];
-            }
-            std::sort(picked.begin(), picked.end());
-            for (int64_t i = 0; i < k; i++) pos_out[at++] = base + picked[(size_t)i] + dd * (uint32_t)i;
-            continue;
+// random.sample() of ONE drawing range (util.py:94-109) over a window of tempered words: the sorted positions
+// start + value + d * rank go to pos_out[0 .. k), *w_io advances by exactly the words CPython consumes.  `more`
+// is asked for further words when the window (words [0, *avail)) runs out; it returns false when none will come.
+// Returns 0, 1 (window exhausted) or -1 / -2 (the reference's ValueError / an unsupported size).
+template <class More>
+static inline int sample_one_range(const msim_range &r, int64_t d, const uint32_t *words, size_t *w_io, size_t *avail,
+                                   More &&more, uint32_t *pos_out) {
+    static thread_local std::vector<uint64_t> bits;                 // all zero between ranges (cleared while it is scanned)
+    static thread_local std::vector<uint32_t> accbuf;               // accepted draws of one round
+    static thread_local std::vector<uint32_t> pool, picked;
+    size_t w = *w_io, at = 0;
+    const int64_t k = r.k;
+    const int64_t n = (r.stop - (k - 1) * d) - r.start;              // util.py:104
+    if (k < 0 || k > n) return -1;
+    if (n >= (1ll << 32)) return -2;
+    const uint32_t base = (uint32_t)r.start, dd = (uint32_t)d;
+    auto fail_clean = [&]() { std::fill(bits.begin(), bits.end(), 0); return 1; };   // keep the scratch bitmap clean
+    if (n <= r.setsize) {                                            // pool path: partial Fisher-Yates
+        pool.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) pool[(size_t)i] = (uint32_t)i;
+        picked.clear();
+        for (int64_t i = 0; i < k; i++) {
+            const uint64_t m = (uint64_t)(n - i);
+            const int sh = 32 - bit_length64(m);
+            uint64_t v;
+            do {
+                while (w >= *avail) if (!more()) return 1;
+                v = words[w++] >> sh;
+            } while (v >= m);
+            picked.push_back(pool[(size_t)v]);
+            pool[(size_t)v] = pool[(size_t)(n - i - 1)];
         }
-        const int sh = 32 - bit_length64((uint64_t)n);
-        const size_t nw = ((size_t)n + 63) / 64;
-        if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
-        uint64_t *B = bits.data();
-        int64_t got = 0;
-        if (nw <= 131072) {
-            // Bitmap in L1/L2 (up to 1 MB).  The data-dependent branches of the obvious loop (draw rejected? bitmap
-            // word empty?) mispredict about every second time, so the loop is split: accepted draws are collected
-            // in bulk without branches, inserted without branches, and the extraction finds the non-empty words
-            // eight at a time (AVX-512 test), writing three slots unconditionally per word.
-            const uint32_t nn = (uint32_t)n;
-            // Rounds (the rule of the device sampler's tail): the next k - got accepted draws are consumed in any
-            // case -- each adds at most one distinct value -- so they are collected in bulk (vectorised filter) and
-            // only then meet the bitmap; the stream position stays exact.
-            if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + 32);
-            uint32_t *buf = accbuf.data();
-            while (got < k) {
-                const size_t need = (size_t)(k - got);
-                const size_t w2 = collect_accepted(words, w, n_words, sh, nn, need, buf);
-                if (w2 == SIZE_MAX) return overflow();
-                w = w2;
-                for (size_t i = 0; i < need; i++) {
-                    const uint32_t v = buf[i];
-                    const size_t wi = v >> 6;
-                    const uint64_t m = 1ull << (v & 63);
-                    const uint64_t x = B[wi];
-                    got += (int64_t)!(x & m);
-                    B[wi] = x | m;
-                }
-            }
-            uint32_t rank = 0;
-            auto emit_word = [&](size_t wi) {
-                uint64_t x = B[wi];
-                B[wi] = 0;
-                const uint32_t cn = (uint32_t)__builtin_popcountll(x);
-                const uint32_t p0 = base + (uint32_t)(wi * 64) + dd * rank;
-                if (__builtin_expect(cn <= 3, 1)) {                   // slots beyond cn are overwritten by the next word
-                    const uint64_t x1 = x & (x - 1), x2 = x1 & (x1 - 1), top = 1ull << 63;
-                    pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x | top);
-                    pos_out[at + 1] = p0 + dd + (uint32_t)__builtin_ctzll(x1 | top);
-                    pos_out[at + 2] = p0 + 2 * dd + (uint32_t)__builtin_ctzll(x2 | top);
-                } else {
-                    uint32_t q = 0;
-                    while (x) { pos_out[at + q] = p0 + dd * q + (uint32_t)__builtin_ctzll(x); q++; x &= x - 1; }
-                }
-                at += cn;
-                rank += cn;
-            };
-            for_each_nonzero_word(B, nw, emit_word);
-            continue;
-        }
-        {                                                            // large bitmap: batch + prefetch (see sample_sorted)
-            uint32_t batch[64];
-            while (got < k) {
-                const int want = (int)std::min<int64_t>(64, k - got);
-                int nb = 0;
-                while (nb < want) {
-                    if (w >= n_words) return overflow();
-                    const uint64_t v = words[w++] >> sh;
-                    if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&B[v >> 6], 1, 0); }
-                }
-                for (int i = 0; i < nb; i++) {
-                    uint64_t &x = B[batch[i] >> 6];
-                    const uint64_t m = 1ull << (batch[i] & 63);
-                    if (!(x & m)) { x |= m; got++; }
-                }
+        std::sort(picked.begin(), picked.end());
+        for (int64_t i = 0; i < k; i++) pos_out[at++] = base + picked[(size_t)i] + dd * (uint32_t)i;
+        *w_io = w;
+        return 0;
+    }
+    const int sh = 32 - bit_length64((uint64_t)n);
+    const size_t nw = ((size_t)n + 63) / 64;
+    if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
+    uint64_t *B = bits.data();
+    int64_t got = 0;
+    if (nw <= 131072) {
+        // Bitmap in L1/L2 (up to 1 MB).  The data-dependent branches of the obvious loop (draw rejected? bitmap
+        // word empty?) mispredict about every second time, so the loop is split: accepted draws are collected
+        // in bulk without branches, inserted without branches, and the extraction finds the non-empty words
+        // eight at a time (AVX-512 test), writing three slots unconditionally per word.
+        const uint32_t nn = (uint32_t)n;
+        // Rounds (the rule of the device sampler's tail): the next k - got accepted draws are consumed in any
+        // case -- each adds at most one distinct value -- so they are collected in bulk (vectorised filter) and
+        // only then meet the bitmap; the stream position stays exact.
+        if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + 32);
+        uint32_t *buf = accbuf.data();
+        while (got < k) {
+            const size_t need = (size_t)(k - got);
+            size_t w2;
+            while ((w2 = collect_accepted(words, w, *avail, sh, nn, need, buf)) == SIZE_MAX)
+                if (!more()) return fail_clean();
+            w = w2;
+            for (size_t i = 0; i < need; i++) {
+                const uint32_t v = buf[i];
+                const size_t wi = v >> 6;
+                const uint64_t m = 1ull << (v & 63);
+                const uint64_t x = B[wi];
+                got += (int64_t)!(x & m);
+                B[wi] = x | m;
             }
         }
         uint32_t rank = 0;
-        for (size_t wi = 0; wi < nw; wi++) {
+        auto emit_word = [&](size_t wi) {
             uint64_t x = B[wi];
-            if (!x) continue;
             B[wi] = 0;
-            while (x) {
-                pos_out[at++] = base + (uint32_t)(wi * 64 + (size_t)__builtin_ctzll(x)) + dd * rank;
-                rank++;
-                x &= x - 1;
+            const uint32_t cn = (uint32_t)__builtin_popcountll(x);
+            const uint32_t p0 = base + (uint32_t)(wi * 64) + dd * rank;
+            if (__builtin_expect(cn <= 3 && at + 3 <= (size_t)k, 1)) {   // slots beyond cn are overwritten by the next word
+                const uint64_t x1 = x & (x - 1), x2 = x1 & (x1 - 1), top = 1ull << 63;
+                pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x | top);
+                pos_out[at + 1] = p0 + dd + (uint32_t)__builtin_ctzll(x1 | top);
+                pos_out[at + 2] = p0 + 2 * dd + (uint32_t)__builtin_ctzll(x2 | top);
+            } else {
+                uint32_t q = 0;
+                while (x) { pos_out[at + q] = p0 + dd * q + (uint32_t)__builtin_ctzll(x); q++; x &= x - 1; }
+            }
+            at += cn;
+            rank += cn;
+        };
+        for_each_nonzero_word(B, nw, emit_word);
+        *w_io = w;
+        return 0;
+    }
+    {                                                                // large bitmap: batch + prefetch (see sample_sorted)
+        uint32_t batch[64];
+        while (got < k) {
+            const int want = (int)std::min<int64_t>(64, k - got);
+            int nb = 0;
+            while (nb < want) {
+                while (w >= *avail) if (!more()) return fail_clean();
+                const uint64_t v = words[w++] >> sh;
+                if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&B[v >> 6], 1, 0); }
+            }
+            for (int i = 0; i < nb; i++) {
+                uint64_t &x = B[batch[i] >> 6];
+                const uint64_t m = 1ull << (batch[i] & 63);
+                if (!(x & m)) { x |= m; got++; }
             }
         }
     }
+    uint32_t rank = 0;
+    for (size_t wi = 0; wi < nw; wi++) {
+        uint64_t x = B[wi];
+        if (!x) continue;
+        B[wi] = 0;
+        while (x) {
+            pos_out[at++] = base + (uint32_t)(wi * 64 + (size_t)__builtin_ctzll(x)) + dd * rank;
+            rank++;
+            x &= x - 1;
+        }
+    }
+    *w_io = w;
+    return 0;
+}
+
+static int sample_one_error(Ctx *c, int code, const char *who) {
+    if (code == -1) return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
+    if (code == -2) return fail(c, MSIM_ERR_UNSUPPORTED, "sampling range of 2^32 or more positions");
+    return fail(c, MSIM_ERR_HIP, std::string(who) + ": word window overflowed its margin");
+}
+
+int sample_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, const uint32_t *words,
+                       size_t n_words, uint32_t *pos_out, size_t *consumed) {
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t w = 0, at = 0, avail = n_words;
+    auto none = []() { return false; };
+    for (int ri = 0; ri < n_ranges; ri++) {
+        const msim_range &r = ranges[ri];
+        if (r.k == 0) continue;
+        const int code = sample_one_range(r, d, words, &w, &avail, none, pos_out + at);
+        if (code) return sample_one_error(c, code, "host sampler");
+        at += (size_t)r.k;
+    }
     *consumed = w;
     c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// General host-chain engine (ctx.h).  Per drawing range, in stream order: sample() -> sorted positions; the
+// candidates on the chain (types known by ordinal) walk the boundary pass over the accept tables; the stream
+// position after the walk is where the next range's sample starts.
+static bool type_drawable(const msim_range &r, int j) {
+    const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+    return r.cdf_thr[j] > lo && lo < (1ull << 53);
+}
+
+bool multimix_prepare(const Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, MixSets &ms) {
+    ms = MixSets{};
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    if (L >= (1ull << 31)) return false;                              // ChainWalk's clamp arithmetic
+    for (int t = 1; t <= 7; t++)
+        if (P.block[t] >= (1ll << 31)) return false;
+    ms.sn_chained = P.block[MSIM_SN] != d;
+    std::unordered_map<std::string, uint32_t> seen;
+    int64_t prev_stop = -1;
+    double pool_bound = 0;
+    constexpr size_t KEY_OFF = offsetof(msim_range, n_types);
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;                                       // draws nothing (mutator.py:163-164)
+        const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+        if (r.k < 0 || n < r.k || n >= (1ll << 32)) return false;     // ValueError / multi-word getrandbits: host planner
+        if (r.start <= prev_stop || r.start < 0 || r.stop > (int64_t)L) return false;   // overlapping / unsorted / outside
+        prev_stop = r.stop;
+        if (r.n_types < 1 || r.n_types > 8) return false;
+        const std::string key(reinterpret_cast<const char *>(&r) + KEY_OFF, sizeof(msim_range) - KEY_OFF);
+        auto it = seen.find(key);
+        uint32_t id;
+        if (it == seen.end()) {
+            ChainClasses own{};
+            for (int j = 0; j < r.n_types; j++) {
+                if (!type_drawable(r, j)) continue;
+                const int t = r.types[j];
+                if (t != MSIM_SN && t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return false;   // TL / TLI
+            }
+            if (!chain_classes_add(r, ms.gcc, own.cls_of)) return false;
+            id = (uint32_t)ms.rep.size();
+            ms.rep.push_back(i);
+            ms.cc.push_back(own);
+            seen.emplace(key, id);
+        } else id = it->second;
+        ms.set_of.push_back(id);
+        ms.K += (uint64_t)r.k;
+        ms.n_draw++;
+        for (int j = 0; j < r.n_types; j++)
+            if (r.types[j] == MSIM_IN && type_drawable(r, j)) pool_bound += (double)r.k * (double)r.max_len[MSIM_IN];
+    }
+    if (ms.K == 0 || ms.K >= (1ull << 31) || pool_bound >= 4.0e9) return false;
+    if (!ms.gcc.n) { ms.gcc.n = 1; ms.gcc.sh[0] = 31; ms.gcc.width[0] = 1; }   // SNPs only: an unused placeholder class
+    for (auto &cc : ms.cc) {                                          // every set looks the union's classes up
+        cc.n = ms.gcc.n;
+        for (uint32_t k = 0; k < 4; k++) { cc.sh[k] = ms.gcc.sh[k]; cc.width[k] = ms.gcc.width[k]; }
+    }
+    return true;
+}
+
+int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, int64_t d, const MixSets &ms,
+                       const uint32_t *words, const uint32_t *T, size_t n_words, const uint32_t *ch_rank,
+                       const uint8_t *ch_type, size_t n_ch, uint32_t *cand_pos, uint32_t *ch_stop, uint32_t *visit_from,
+                       size_t *consumed, const WordFeed *feed) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const msim_params &P = c->params;
+    if (ms.sn_chained) {
+        uint32_t bad = 0;
+        for (size_t i = 0; i < n_ch; i++) bad |= (uint32_t)(uint8_t)(ch_type[i] - MSIM_SN) > (uint32_t)(MSIM_IV - MSIM_SN);
+        if (bad) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside SN/IN/DE/DU/IV");
+    } else if (!ChainWalk::types_ok(ch_type, n_ch)) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside IN/DE/DU/IV");
+    std::vector<ChainWalk> proto(ms.rep.size());
+    for (size_t s = 0; s < proto.size(); s++) {
+        const int rc = proto[s].init(c, ranges[ms.rep[s]], L, ms.cc[s], n_words);
+        if (rc) return rc;
+    }
+    const uint32_t lg = chain_lg_rows(ms.gcc);
+    size_t w = 0, avail = feed ? 0 : n_words;                        // words [0, avail) have arrived; so has T[.. avail)
+    int rc_feed = MSIM_OK;
+    auto more = [&]() {                                              // false: nothing more will come
+        if (!feed || avail >= n_words) return false;
+        rc_feed = feed->more(feed->user, &avail);
+        return rc_feed == MSIM_OK;
+    };
+    auto overflow = [&]() { return rc_feed ? rc_feed : fail(c, MSIM_ERR_HIP, "host chain: word window overflowed its margin"); };
+    auto t_lim = [&]() { return avail + (avail >= n_words ? 1u : 0u); };   // entry n_words is the end-of-window sentinel
+    static thread_local std::vector<uint32_t> pbuf;
+    size_t qa = 0, di = 0;
+    uint64_t base = 0;
+    uint32_t vf = 0;                                                 // consumed_to + 1 of __mutate_sequence's walk
+    int64_t bad_acc = 0;
+    for (int ri = 0; ri < n_ranges; ri++) {
+        const msim_range &r = ranges[ri];
+        if (r.k == 0) continue;
+        const uint64_t k = (uint64_t)r.k;
+        const int code = sample_one_range(r, d, words, &w, &avail, more, cand_pos + base);
+        if (code) return rc_feed ? rc_feed : sample_one_error(c, code, "host chain");
+        size_t qb = qa;
+        while (qb < n_ch && ch_rank[qb] < base + k) qb++;
+        const size_t m = qb - qa;
+        if (pbuf.size() < m + 8) pbuf.resize(m + m / 2 + 64);
+        uint32_t *pb = pbuf.data();
+        for (size_t x = 0; x < m; x++) pb[x] = cand_pos[ch_rank[qa + x]];
+        const ChainWalk &pw = proto[ms.set_of[di]];
+        if (m && !ms.sn_chained) {
+            ChainWalk cw = pw;
+            cw.ws = w << lg;
+            for (;;) {
+                cw.run(pb, ch_type + qa, m, T, t_lim(), ch_stop + qa);
+                if (cw.j >= m) break;
+                if (!more()) return overflow();
+            }
+            bad_acc |= cw.bad;
+            w = cw.ws >> lg;
+        } else if (m) {                                              // SNPs block too (mutator.py:204-206): every candidate chains
+            int64_t hi = 0;                                          // last_mut_range = range(0), per range (mutator.py:184)
+            for (size_t x = 0; x < m; x++) {
+                const int64_t p = pb[x];
+                const int t = ch_type[qa + x] & 7;
+                if (p < hi) { ch_stop[qa + x] = CHAIN_DROPPED; continue; }              // mutator.py:190-191
+                if (t == MSIM_SN) { ch_stop[qa + x] = (uint32_t)p; hi = p + 1 + P.block[MSIM_SN]; continue; }
+                if (p >= pw.drop_from[t]) { ch_stop[qa + x] = CHAIN_DROPPED; continue; }   // mutator.py:240-245
+                while (w >= t_lim()) if (!more()) return overflow();
+                const uint32_t e = T[(w << lg) + pw.row[t]];
+                const uint32_t inc = e >> 24;
+                if (!inc) return overflow();                         // no accepted draw in reach: the window ends here
+                int64_t s = p + pw.add[t] + (int64_t)(e & 0xffffff);
+                s = s > pw.clamp[t] ? pw.clamp[t] : s;
+                ch_stop[qa + x] = (uint32_t)s;
+                hi = (t == MSIM_IN ? p : s) + 1 + P.block[t];
+                w += inc >> lg;
+            }
+        }
+        visit_from[di] = vf;
+        for (size_t x = m; x-- > 0;) {                               // the range's last kept DE / DU / IV: does it get visited?
+            const int t = ch_type[qa + x] & 7;
+            if (ch_stop[qa + x] == CHAIN_DROPPED || (t != MSIM_DE && t != MSIM_DU && t != MSIM_IV)) continue;
+            if (pb[x] >= vf) vf = ch_stop[qa + x] + 1;               // pos = muts[pos].stop (mutator.py:376,386,398)
+            break;
+        }
+        qa = qb;
+        base += k;
+        di++;
+    }
+    if (bad_acc < 0) return overflow();
+    *consumed = w;
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
+// Test support: the engine end to end on the host.  What the device does in plan_contig_gpu_multimix is restated
+// sequentially here (types by ordinal, accept tables, clipped running maximum for the SNP filter, visit filter,
+// records) -- same algorithm, no kernels -- so the CPU tier can compare it with plan_contig_host.
+int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    MixSets ms;
+    if (!multimix_prepare(c, L, ranges, n_ranges, ms)) return fail(c, MSIM_ERR_UNSUPPORTED, "outside the host-chain engine");
+    const size_t K = (size_t)ms.K;
+    std::vector<uint8_t> ty(K);
+    std::vector<uint32_t> rng_of(K), clip, ch_rank;
+    std::vector<uint8_t> ch_type;
+    {
+        size_t j = 0;
+        uint32_t di = 0;
+        for (int ri = 0; ri < n_ranges; ri++) {
+            const msim_range &r = ranges[ri];
+            if (r.k == 0) continue;
+            clip.push_back((uint32_t)(r.stop + 1));
+            for (int64_t i = 0; i < r.k; i++, j++) {
+                const uint64_t m = c->np.next53();                   // numpy.random.choice: mutator.py:170-174
+                int idx = 0;
+                while (idx < r.n_types && r.cdf_thr[idx] <= m) idx++;
+                if (idx >= r.n_types) idx = r.n_types - 1;
+                ty[j] = (uint8_t)r.types[idx];
+                rng_of[j] = di;
+                if (ms.sn_chained || ty[j] != MSIM_SN) { ch_rank.push_back((uint32_t)j); ch_type.push_back(ty[j]); }
+            }
+            di++;
+        }
+    }
+    std::vector<uint32_t> cand_pos(K + 8), ch_stop(ch_rank.size() + 8), visit_from(ms.n_draw + 1);
+    size_t consumed = 0;
+    const uint32_t lg = chain_lg_rows(ms.gcc);
+    for (size_t W = 4 * K + 65536;; W *= 4) {                        // a window that proves too short is simply retried
+        HostMT clone = c->py;
+        std::vector<uint32_t> words(W), T((W + 1) << lg);
+        for (size_t i = 0; i < W; i++) words[i] = clone.next();
+        accept_tables_host(ms.gcc, words.data(), W, T.data());
+        const int rc = multimix_walk_host(c, L, ranges, n_ranges, d, ms, words.data(), T.data(), W, ch_rank.data(),
+                                          ch_type.data(), ch_rank.size(), cand_pos.data(), ch_stop.data(), visit_from.data(),
+                                          &consumed);
+        if (rc == MSIM_OK) break;
+        if (rc != MSIM_ERR_HIP || W > (1ull << 31)) return rc;
+    }
+    for (size_t i = 0; i < consumed; i++) (void)c->py.next();
+    std::vector<uint32_t> stop(K, CHAIN_DROPPED);
+    for (size_t q = 0; q < ch_rank.size(); q++) stop[ch_rank[q]] = ch_stop[q];
+    out.recs.clear();
+    out.pool.clear();
+    static const uint8_t ATGC[4] = {'A', 'T', 'G', 'C'};
+    uint32_t run = 0;                                                // running maximum of the CLIPPED blocked ends
+    size_t kept = 0;
+    for (size_t j = 0; j < K; j++) {
+        const uint32_t p = cand_pos[j], di = rng_of[j];
+        const int t = ty[j];
+        bool keep;
+        if (t == MSIM_SN) keep = ms.sn_chained ? stop[j] != CHAIN_DROPPED : p >= run;
+        else {
+            keep = stop[j] != CHAIN_DROPPED;
+            if (keep) {
+                const uint64_t e = (uint64_t)(t == MSIM_IN ? p : stop[j]) + 1 + (uint64_t)P.block[t];
+                run = std::max(run, (uint32_t)std::min<uint64_t>(e, clip[di]));
+            }
+        }
+        if (!keep) continue;
+        kept++;
+        if (p < visit_from[di]) continue;                            // inside a span an earlier range's DE/DU/IV consumed
+        msim_record rec{};
+        rec.pos = p;
+        rec.type = (uint8_t)t;
+        rec.stop = t == MSIM_SN ? p : stop[j];
+        if (t == MSIM_SN) {
+            const uint64_t u = c->py.next53();
+            rec.aux = (u < P.ti_lim) ? 0 : (uint8_t)(1 + randbelow(c->py, 2));
+        } else if (t == MSIM_IN) {
+            const uint32_t len = rec.stop + 1 - p;
+            rec.extra = (uint32_t)out.pool.size();
+            for (uint32_t i = 0; i < len; i++) out.pool.push_back(ATGC[c->np.next() & 3u]);
+        }
+        out.recs.push_back(rec);
+    }
+    out.empty = kept == 0;
     return MSIM_OK;
 }
 

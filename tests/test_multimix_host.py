@@ -1,0 +1,240 @@
+"""The general host-chain PLAN engine (plan_contig_gpu_multimix: contigs whose drawing ranges have different
+settings, SV types on many small ranges, SNP block above the sampling distance) on the CPU tier.
+
+`msim_dbg_multimix_plan` runs the engine's algorithm end to end on the host -- the real host walk
+(`multimix_walk_host`: sample -> positions -> boundary chain over accept tables, range after range along one
+word window) plus a sequential restatement of what the device does around it (types by ordinal, accept tables,
+clipped running maximum for the SNP filter, the visit filter across range borders, records).  It must arrive at
+the host planner's record table, insert pool and stream positions; the host planner itself is held against the
+reference's goldens and the oracle elsewhere (test_cabi_host.py, test_property_host.py)."""
+from __future__ import annotations
+
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from mutation_simulator_amd import _ffi
+from mutation_simulator_amd import mutator as mm
+
+ARGS_ORDER = [1, 2, 3, 5, 4, 6, 7]
+
+
+def _engine(blocks, titv=1.0, seed=(1, 2)):
+    eng = _ffi.Engine(device=-1)
+    p = _ffi.Params()
+    for i in range(8):
+        p.block[i] = 1
+    for t, v in (blocks or {}).items():
+        p.block[t] = v
+    p_ti = titv * (1 / (titv + 1))
+    p.ti_lim = min(mm._floor_scaled(p_ti) + 1, 1 << 53)
+    eng.set_params(p)
+    eng.seed(*seed)
+    return eng
+
+
+def _range(start, stop, rate, chances, lens, order=None):
+    order = order or [t for t in ARGS_ORDER if t in chances] or [1]
+    r = _ffi.Range()
+    r.start, r.stop = start, stop
+    r.k = int(((stop - start) + 1) * rate)
+    r.setsize = mm.sample_setsize(r.k)
+    p = np.array([chances.get(t, 0.0) for t in order], dtype=np.float64)
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    r.n_types = len(order)
+    for j, t in enumerate(order):
+        r.types[j] = t
+        r.cdf_thr[j] = mm._ceil_scaled(float(cdf[j]))
+    for t in (2, 3, 4, 6):
+        r.min_len[t], r.max_len[t] = lens.get(t, (1, 2))
+    r.min_len[5], r.max_len[5] = lens.get(5, (2, 3))
+    return r
+
+
+def _dbg(lib):
+    lib.msim_dbg_multimix_plan.restype = C.c_int
+    lib.msim_dbg_multimix_plan.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(_ffi.Range), C.c_int, C.c_void_p, C.c_uint64,
+                                           C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                           C.POINTER(C.c_int)]
+    return lib
+
+
+def _next_words(mt, pos, n):
+    r = random.Random()
+    r.setstate((3, tuple(int(x) for x in mt) + (int(pos),), None))
+    return [r.getrandbits(32) for _ in range(n)]
+
+
+def _both(L, ranges, blocks, titv, seed, expect_unsupported=False):
+    arr = (_ffi.Range * len(ranges))(*ranges)
+    # host planner (a host-only context plans from the length alone)
+    eng = _engine(blocks, titv, seed)
+    cid = eng.add_contig(np.zeros(L, dtype=np.uint8))
+    eng.plan_contig(cid, list(ranges))
+    hrecs, hpool = eng.fetch_records(cid)
+    hempty = eng.plan_was_empty(cid)
+    hstates = [eng.get_mt_state(0), eng.get_mt_state(1)]
+    eng.close()
+    # the engine, emulated
+    eng = _engine(blocks, titv, seed)
+    lib = _dbg(eng.lib)
+    recs = np.zeros(sum(r.k for r in ranges) + 8, dtype=_ffi.RECORD_DTYPE)
+    pool = np.zeros(int(sum(r.k * max(1, r.max_len[2]) for r in ranges)) + 8, dtype=np.uint8)
+    n_recs, pool_len, empty = C.c_uint64(), C.c_uint64(), C.c_int()
+    rc = lib.msim_dbg_multimix_plan(eng.h, L, arr, len(ranges), C.c_void_p(recs.ctypes.data), len(recs),
+                                    C.c_void_p(pool.ctypes.data), len(pool), C.byref(n_recs), C.byref(pool_len), C.byref(empty))
+    if expect_unsupported:
+        assert rc == _ffi.ERR_UNSUPPORTED
+        eng.close()
+        return None
+    assert rc == 0, eng.lib.msim_last_error(eng.h)
+    states = [eng.get_mt_state(0), eng.get_mt_state(1)]
+    eng.close()
+    got = recs[:n_recs.value]
+    assert len(got) == len(hrecs)
+    for f in ("pos", "type", "stop", "aux", "extra"):
+        assert np.array_equal(got[f], hrecs[f]), f
+    assert np.array_equal(pool[:pool_len.value], hpool)
+    assert bool(empty.value) == bool(hempty)
+    for (hm, hp), (gm, gp) in zip(hstates, states):
+        assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
+    return hrecs
+
+
+C3_CHANCES = {1: 0.005, 2: 0.001, 3: 0.001, 4: 0.0005, 5: 0.0005}
+C3_LENS = {2: (1, 50), 3: (1, 50), 4: (50, 500), 5: (50, 500)}
+
+
+def _gene_block_layout(L, rs, n_blocks):
+    cuts = np.sort(rs.choice(np.arange(1, L - 1), size=2 * n_blocks, replace=False))
+    out, at = [], 0
+    for a, b in zip(cuts[0::2], cuts[1::2]):
+        if a - 1 > at:
+            out.append((at, int(a) - 1))
+        at = int(b) + 1
+    if at < L - 1:
+        out.append((at, L - 1))
+    return out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_gene_blocks_with_sv_std_line(seed):
+    """The mainstream RMT shape: blocked genes, std line `sn in de du iv` in the gaps (one settings object)."""
+    rs = np.random.RandomState(seed)
+    L = 3_000_000
+    ranges = [_range(s, e, 0.008, C3_CHANCES, C3_LENS) for s, e in _gene_block_layout(L, rs, 150)]
+    ranges = [r for r in ranges if r.k]
+    recs = _both(L, ranges, None, 2.0, (seed, seed + 5))
+    assert len(set(recs["type"].tolist())) == 5
+
+
+def test_adjacent_ranges_spans_cross_borders():
+    """Touching ranges with long DE / DU / IV: a span of range i swallows candidates of range i+1 (blocked range reset per
+    range, mutator.py:184; the walk of __mutate_sequence skips them, mutator.py:376,386,398) -- also across a whole tiny
+    range into the one after it."""
+    L = 400_000
+    ranges, at = [], 0
+    rs = np.random.RandomState(4)
+    while at < L - 10:
+        length = int(rs.choice([60, 300, 2_000, 9_000]))
+        e = min(L - 1, at + length - 1)
+        ranges.append(_range(at, e, 0.03, {1: 0.4, 3: 0.25, 4: 0.2, 5: 0.1, 2: 0.05},
+                             {3: (200, 900), 4: (100, 700), 5: (50, 800), 2: (1, 9)}))
+        at = e + 1
+    ranges = [r for r in ranges if r.k]
+    hrecs = _both(L, ranges, None, 1.0, (9, 9))
+    # the situation really occurs: some record starts inside the span of the record before it in the raw candidate walk
+    assert len(hrecs) > 1000
+
+
+def test_hot_cold_ranges_with_own_lengths_and_token_order():
+    """Ranges with different settings: own chances in RMT token order, own length bounds (-> several randint classes
+    in one table), a pool-path hot spot, SNP-only ranges in between, d = 2."""
+    L = 1_200_000
+    blocks = {t: 2 for t in range(1, 8)}
+    blocks[3] = 5
+    ranges = [
+        _range(0, 199_999, 0.01, {1: 1.0}, {}),
+        _range(200_000, 200_999, 0.2, {4: 0.1, 1: 0.8, 2: 0.1}, {4: (5, 8), 2: (1, 4)}, order=[4, 1, 2]),     # pool path
+        _range(201_000, 499_999, 0.008, C3_CHANCES, C3_LENS),
+        _range(500_000, 500_040, 0.1, {1: 0.5, 3: 0.5}, {3: (1, 50)}),                                       # k = 4
+        _range(500_100, 899_999, 0.02, {1: 0.3, 3: 0.3, 5: 0.4}, {3: (1, 50), 5: (50, 500)}, order=[5, 3, 1]),
+        _range(900_000, 1_199_999, 0.004, {2: 1.0}, {2: (3, 3)}),                                            # width-1 randint
+    ]
+    assert (ranges[1].stop - (ranges[1].k - 1) * 2) - ranges[1].start <= ranges[1].setsize
+    _both(L, ranges, blocks, 0.5, (21, 22))
+
+
+@pytest.mark.parametrize("sn_block", [2, 7])
+def test_snp_block_above_sampling_distance(sn_block):
+    """sn_block > min(block): a kept SNP blocks its successors (mutator.py:204-206), so every candidate is on the
+    chain -- SNP-only ranges included."""
+    L = 800_000
+    rs = np.random.RandomState(sn_block)
+    ranges = []
+    for s, e in _gene_block_layout(L, rs, 40):
+        kind = rs.randint(0, 3)
+        if kind == 0:
+            ranges.append(_range(s, e, 0.05, {1: 1.0}, {}))
+        elif kind == 1:
+            ranges.append(_range(s, e, 0.3, {1: 0.9, 2: 0.1}, {2: (1, 4)}))
+        else:
+            ranges.append(_range(s, e, 0.02, {1: 0.2, 3: 0.4, 5: 0.2, 4: 0.2}, {3: (3, 60), 5: (5, 90), 4: (4, 80)}))
+    ranges = [r for r in ranges if r.k and (r.stop - (r.k - 1)) - r.start >= r.k]
+    _both(L, ranges, {1: sn_block}, 1.7, (3, 4))
+
+
+def test_iv_drop_and_clamps_at_the_contig_end():
+    L = 300_000
+    ranges = [_range(0, 149_999, 0.01, {1: 0.5, 5: 0.5}, {5: (2, 100)}),
+              _range(150_000, L - 1, 0.01, {1: 0.2, 5: 0.3, 3: 0.25, 4: 0.25}, {5: (2, 60_000), 3: (1, 90_000), 4: (1, 90_000)})]
+    _both(L, ranges, None, 1.0, (5, 6))
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_layouts(case):
+    rs = np.random.RandomState(500 + case)
+    L = int(rs.randint(200_000, 1_500_000))
+    d = int(rs.choice([1, 1, 2, 4]))
+    blocks = {t: d + int(rs.choice([0, 0, 1, 5, 40])) for t in range(2, 8)}
+    blocks[1] = d if rs.rand() < 0.7 else d + int(rs.randint(1, 4))
+    blocks[int(rs.choice([2, 3, 4, 5]))] = d
+    n_sets = int(rs.randint(1, 5))
+    sets = []
+    widths = [(1, 1 + int(rs.choice([0, 3, 49, 450]))) for _ in range(2)]      # at most 4 classes in total
+    for _ in range(n_sets):
+        types = [1] + [t for t in (2, 3, 4, 5) if rs.rand() < 0.6]
+        chances = {t: float(rs.uniform(0.05, 1.0)) for t in types}
+        lens = {}
+        for t in (2, 3, 4):
+            a, b = widths[int(rs.randint(0, 2))]
+            off = int(rs.randint(0, 30))
+            lens[t] = (a + off, b + off)
+        a, b = widths[int(rs.randint(0, 2))]
+        lens[5] = (a + 1, b + 1)
+        order = [int(x) for x in rs.permutation(types)]
+        sets.append((chances, lens, order, float(rs.choice([0.002, 0.01, 0.03, 0.1]))))
+    ranges, at = [], int(rs.randint(0, 500))
+    while at < L - 50:
+        length = int(min(L - at, rs.choice([8, 30, 200, 2_000, 20_000, 150_000])))
+        chances, lens, order, rate = sets[int(rs.randint(0, n_sets))]
+        r = _range(at, at + length - 1, rate, chances, lens, order)
+        n = (r.stop - (r.k - 1) * d) - r.start
+        if r.k > 0 and n >= r.k:
+            ranges.append(r)
+        at += length + int(rs.choice([0, 0, 1, 50, 3_000]))
+    assert ranges
+    _both(L, ranges, blocks, float(rs.choice([0.0, 1.0, 2.0])), (case + 1, case + 11))
+
+
+def test_refuses_what_belongs_to_the_host_planner():
+    L = 200_000
+    tl = _range(0, L - 1, 0.01, {1: 0.5, 6: 0.5}, {6: (1, 20)}, order=[1, 6])
+    _both(L, [tl], None, 1.0, (1, 1), expect_unsupported=True)
+    a, b = _range(0, 99_999, 0.01, C3_CHANCES, C3_LENS), _range(50_000, 150_000, 0.01, C3_CHANCES, C3_LENS)
+    _both(L, [a, b], None, 1.0, (1, 1), expect_unsupported=True)                 # overlapping: dict semantics
+    five = [_range(i * 30_000, i * 30_000 + 29_999, 0.01, {1: 0.5, 3: 0.5}, {3: (1, 10 + 7 * i)}) for i in range(5)]
+    _both(L, five, None, 1.0, (1, 1), expect_unsupported=True)                   # five randint classes
