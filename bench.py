@@ -76,7 +76,12 @@ def workload_settings(lengths, snp=0.01, titv=2.0, extra=None):
 C4_FIXTURE = ROOT / "tests" / "golden" / "c4_blocks.npz"
 
 
-def c4_rmt_text(lengths, seed=4) -> str:
+C4_STD_SNP = "sn 0.01"
+C4_STD_SV = ("sn 0.005 in 0.001 inmin 1 inmax 50 de 0.001 demin 1 demax 50 du 0.0005 dumin 50 dumax 500 "
+             "iv 0.0005 ivmin 50 ivmax 500")
+
+
+def c4_rmt_text(lengths, seed=4, std_line=C4_STD_SNP) -> str:
     """BASELINE configs[3]: a NON-overlapping gene-blocking RMT (std `sn 0.01`, `a-b None` blocks) plus hot (`sn 0.05`)
     and cold (`sn 0.001`) ranges and 1 kb `sn 0.2` hot spots that take CPython's pool-path sample.
 
@@ -90,14 +95,14 @@ def c4_rmt_text(lengths, seed=4) -> str:
         z = np.load(C4_FIXTURE)
         if list(z["lengths"]) == list(lengths):
             what = ("None", "sn 0.05", "sn 0.001", "sn 0.2")
-            out = ["std", "it None", "sn 0.01", ""]
+            out = ["std", "it None", std_line, ""]
             for ci in range(len(lengths)):
                 out.append(f"chr {ci + 1}")
                 for a, e, k in zip(z[f"s{ci}"].tolist(), z[f"e{ci}"].tolist(), z[f"k{ci}"].tolist()):
                     out.append(f"{a}-{e} {what[k]}")
             return "\n".join(out) + "\n"
     rs = np.random.RandomState(seed)
-    out = ["std", "it None", "sn 0.01", ""]
+    out = ["std", "it None", std_line, ""]
     for ci, L in enumerate(lengths):
         out.append(f"chr {ci + 1}")
         n_blocks = max(1, int(L / 75_000))
@@ -173,6 +178,9 @@ WORKLOADS = {
            "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},
     "c4": {"mode": "RMT", "what": "RMT mode, gene-blocking file with hot/cold spots (BASELINE configs[3])",
            "kernel": "msim::k_rewrite_snp", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT hot/cold/blocked ranges"},
+    "c4sv": {"mode": "RMT", "what": "RMT mode, the configs[3] gene-blocking file with the configs[2] SV mix as its std line "
+                                    "(every gap between two blocked genes draws SN/IN/DE/DU/IV; hot/cold ranges keep their own settings)",
+             "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT gene blocks + SV std line"},
 }
 
 
@@ -181,6 +189,8 @@ def build_settings(workload: str, lengths):
         return workload_settings(lengths)
     if workload == "c3":
         return workload_settings(lengths, snp=0.005, titv=1.0, extra=C3_FLAGS)
+    if workload == "c4sv":
+        return workload_settings_rmt(lengths, c4_rmt_text(lengths, std_line=C4_STD_SV))
     return workload_settings_rmt(lengths, c4_rmt_text(lengths))
 
 
@@ -261,6 +271,11 @@ def step_roofline(st, dt):
             "what": "algorithmic bytes of all APPLY launches / wall time of the timed steps"}
 
 
+def engines_of(st, steps):
+    """Which PLAN engine the contigs of a step went through (msim_timing.contigs_*)."""
+    return {k[len("contigs_"):]: st[k] // steps for k in st if k.startswith("contigs_") and st[k]}
+
+
 def stages_of(st, steps):
     return {"plan_host": round(st["plan_host_ms"] / steps, 3), "plan_gpu": round(st["plan_gpu_ms"] / steps, 3),
             "record_upload": round(st["upload_ms"] / steps, 3), "apply_all_kernels": round(st["apply_ms"] / steps, 3),
@@ -276,9 +291,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 / config-4 secondary measurements")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4sv"], default="c2",
                     help="c2 = BASELINE configs[1] (headline: -sn 0.01 -titv 2.0); c3 = configs[2], the full SV mix; "
-                         "c4 = configs[3], RMT mode with ~40 k blocked ranges + hot/cold spots")
+                         "c4 = configs[3], RMT mode with ~40 k blocked ranges + hot/cold spots; c4sv = the c4 file with the "
+                         "c3 SV mix as its std line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="N > 1: 'strong' (default) = BASELINE configs[4]'s shape: ONE genome, PLAN replayed on every rank "
                          "(the MT19937 streams chain across contigs), contigs' APPLY sharded (LPT), RCCL gather to rank 0; "
@@ -388,6 +404,7 @@ def main():
                                        if strong else f"{world} independent replica(s): one whole genome per GPU, "
                                        f"streams seeded 42+rank, results left in HBM")},
             "stages_ms_per_step": stages_of(st, a.steps),
+            "plan_engines": engines_of(st, a.steps),
             "records_per_step": st["records"] // a.steps,
             "roofline": roofline_of(st, a.workload, a.steps),
         }
@@ -414,11 +431,12 @@ def main():
         # workload still grow scratch buffers), same definition of a step
         sec = {}
         n_sec, w_sec = 5, 2
-        for w in ("c3", "c4"):
+        for w in ("c3", "c4", "c4sv"):
             dts, sts = measure(w, n_sec, w_sec)
             sec[w] = {"metric": WORKLOADS[w]["metric"], "value": round(sum(lengths) * n_sec / dts / 1e6, 3), "unit": "Mbases/s",
                       "ms_per_step": round(dts / n_sec * 1e3, 3), "steps": n_sec, "warmup": w_sec,
-                      "stages_ms_per_step": stages_of(sts, n_sec), "records_per_step": sts["records"] // n_sec,
+                      "stages_ms_per_step": stages_of(sts, n_sec), "plan_engines": engines_of(sts, n_sec),
+                      "records_per_step": sts["records"] // n_sec,
                       "roofline": roofline_of(sts, w, n_sec), "step_roofline": step_roofline(sts, dts)}
         line["secondary"] = sec
     if rank == 0:

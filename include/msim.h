@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 1
+#define MSIM_ABI_VERSION 2
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -56,8 +56,9 @@ extern "C" {
 #define MSIM_PLAN_GPU    2u      /* force a device engine; MSIM_ERR_UNSUPPORTED where none can run             */
 /* Device PLAN engines: the device owns both MT19937 streams and does all per-record work;
  * SNP-only large ranges need nothing from the host, SV mixes hand the boundary chain over their non-SNP
- * candidates to the host, contigs with many small SNP ranges hand it the chain of sample() calls -- in both
- * cases over words the device generated.  Results are bit-identical whichever engine runs.                    */
+ * candidates to the host, contigs with many small SNP ranges hand it the chain of sample() calls, contigs whose
+ * ranges have their own SV settings (or whose SNPs block) hand it both -- always over words the device generated.
+ * Results are bit-identical whichever engine runs; msim_timing.contigs_* tells which one did.                  */
 
 typedef struct msim_ctx msim_ctx;
 
@@ -107,6 +108,13 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     uint64_t apply_launches;  /* rewrite-kernel launches accumulated since msim_reset_stats         */
     uint64_t bytes_in, bytes_out, records;   /* algorithmic traffic of those launches               */
     uint64_t py_words, np_words;             /* MT19937 words consumed from each stream             */
+    /* contigs planned per PLAN engine since msim_reset_stats: which engine a run went through   */
+    uint64_t contigs_snp;        /* SNP sampler: everything on the device                                              */
+    uint64_t contigs_svmix;      /* one large SV-mix range: the boundary chain on the host                             */
+    uint64_t contigs_hostcut;    /* many deterministic-SNP ranges: the stream cuts on the host                         */
+    uint64_t contigs_hostchain;  /* several ranges with their own settings / SNPs that block: samples + chain on the host */
+    uint64_t contigs_host;       /* sequential host planner (translocations, overlapping ranges, tiny contigs)         */
+    uint64_t contigs_batch;      /* contigs that went through msim_batch_run (host planner, one APPLY per batch)       */
 } msim_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

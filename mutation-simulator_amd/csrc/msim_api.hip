@@ -433,36 +433,40 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
     int rc = MSIM_OK;
     TraceRange tr("msim PLAN contig");
-    const bool gpu_ok = !c->host_only && c->gpu && gpu_plan_eligible(c, ranges, n_ranges);
-    const bool mixed_ok = !gpu_ok && !c->host_only && c->gpu && gpu_plan_mixed_eligible(c, ranges, n_ranges);
-    const bool hs_ok = !gpu_ok && !mixed_ok && !c->host_only && c->gpu && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
+    const bool dev = !c->host_only && c->gpu && !(c->flags & MSIM_PLAN_HOST);
+    const bool gpu_ok = dev && gpu_plan_eligible(c, ranges, n_ranges);
+    const bool mixed_ok = dev && !gpu_ok && gpu_plan_mixed_eligible(c, ranges, n_ranges);
+    const bool hs_ok = dev && !gpu_ok && !mixed_ok && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
+    const bool mm_ok = dev && !gpu_ok && !mixed_ok && !hs_ok && gpu_plan_multimix_eligible(c, c->gpu, g->len, ranges, n_ranges);
     // A deferred APPLY of the previous contig (msim_apply_contig) is enqueued when this plan's host chain starts --
-    // by the SV-mix / host-cut engine itself -- so that it fills the device's idle time instead of competing with this
-    // contig's latency-bound chain kernels.  Every other route enqueues it now.
-    const bool engine_flushes = (mixed_ok || (hs_ok && !gpu_plan_walk_eligible(c, ranges, n_ranges))) &&
-                                !(c->flags & MSIM_PLAN_HOST) && c->deferred_apply != contig;
+    // by the engine itself -- so that it fills the device's idle time instead of competing with this contig's
+    // latency-bound chain kernels.  Every other route enqueues it now.
+    const bool host_chain = mixed_ok || hs_ok || mm_ok;
+    const bool engine_flushes = host_chain && c->deferred_apply != contig;
     if (!engine_flushes && (rc = flush_deferred_apply(c))) return rc;
     reset_contig(*g);
     c->text_kind = 0;
-    if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok && !mixed_ok && !hs_ok)
+    if ((c->flags & MSIM_PLAN_GPU) && !gpu_ok && !host_chain)
         return fail(c, MSIM_ERR_UNSUPPORTED, "GPU sampler not available for this stream structure");
-    if ((gpu_ok || mixed_ok || hs_ok) && !(c->flags & MSIM_PLAN_HOST)) {
+    if (gpu_ok || host_chain) {
         if (gpu_ok) rc = plan_contig_gpu(c, c->gpu, *g, ranges, n_ranges);
-        else if (mixed_ok) {
-            if (g->apply_pending) {                        // this contig's buffers may still be read by its last APPLY
+        else {
+            if (g->apply_pending && (mixed_ok || mm_ok)) {   // this contig's buffers may still be read by its last APPLY
                 rc = apply_finish(c);
                 if (rc) return rc;
             }
-            rc = plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
-        } else if (gpu_plan_walk_eligible(c, ranges, n_ranges)) rc = plan_contig_gpu_walk(c, c->gpu, *g, ranges, n_ranges);
-        else rc = plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
+            if (mixed_ok) rc = plan_contig_gpu_mixed(c, c->gpu, *g, ranges, n_ranges);
+            else if (hs_ok) rc = plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
+            else rc = plan_contig_gpu_multimix(c, c->gpu, *g, ranges, n_ranges);
+        }
+        if (!rc) (gpu_ok ? c->t.contigs_snp : mixed_ok ? c->t.contigs_svmix : hs_ok ? c->t.contigs_hostcut : c->t.contigs_hostchain)++;
         // test hook: MSIM_DBG_FORCE_OVERFLOW=n raises the window-overflow flag behind the n-th device-planned contig of
         // the process (1-based), so that the callers' recovery (mutator.py: re-plan through the host planner) can be tested
         static const int force_at = getenv("MSIM_DBG_FORCE_OVERFLOW") ? atoi(getenv("MSIM_DBG_FORCE_OVERFLOW")) : 0;
         static int device_plans = 0;
         if (!rc && force_at && ++device_plans == force_at) rc = gpu_plan_force_overflow(c, c->gpu);
         const int frc = flush_deferred_apply(c);           // (an engine that returned early never reached its flush point)
-        g->defer_apply = !rc && (mixed_ok || (hs_ok && !gpu_plan_walk_eligible(c, ranges, n_ranges)));
+        g->defer_apply = !rc && host_chain;
         return rc ? rc : frc;
     }
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
@@ -477,6 +481,7 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     const uint64_t w_py = c->py.words, w_np = c->np.words;
     rc = plan_contig_host(c, g->len, ranges, n_ranges, hp);
     if (rc) return rc;
+    c->t.contigs_host++;
     c->t.py_words += c->py.words - w_py;
     c->t.np_words += c->np.words - w_np;
     const auto t0 = std::chrono::steady_clock::now();
@@ -1011,6 +1016,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
         const uint64_t w_py = c->py.words, w_np = c->np.words;
         rc = plan_contig_host(c, q.n_bases, q.ranges, q.n_ranges, hp);
         if (rc) return rc;
+        c->t.contigs_batch++;
         c->t.py_words += c->py.words - w_py;
         c->t.np_words += c->np.words - w_np;
         it.empty = hp.empty;

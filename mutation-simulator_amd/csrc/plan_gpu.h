@@ -26,11 +26,13 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
 // device generated; records, SNP draws and APPLY stay on the device
 bool gpu_plan_hostsample_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
+// everything else that is still a plain chain: several ranges with their own settings, SV types on many small ranges,
+// SNP block above the sampling distance -- the host walks samples and boundary passes in one go over device-made
+// words, accept tables and candidate types
+bool gpu_plan_multimix_eligible(const Ctx *c, GpuPlan *g, uint64_t L, const msim_range *ranges, int n_ranges);
+int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 int gpu_plan_force_overflow(Ctx *c, GpuPlan *g);          // test support
 
 void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]);
-// the same contigs with the chain of samples walked by one workgroup on the device (k_sample_walk): fully asynchronous
-bool gpu_plan_walk_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
-int plan_contig_gpu_walk(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 
 }  // namespace msim

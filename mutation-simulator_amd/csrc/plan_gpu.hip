@@ -95,6 +95,9 @@ struct MixedSet {                        // scratch of one SV-mix range (section
     uint32_t *wbits = nullptr; size_t cap_wbits = 0;      //   contig-wide bitmap of sampled positions (zero between uses)
     bool wbits_dirty = false;                             //   a failed pass may have left bits behind
     uint32_t *wcnt = nullptr; size_t cap_wcnt = 0;        //   per-workgroup popcounts / ranks of its expansion
+    uint32_t *tables = nullptr; size_t cap_tables = 0;    // host-chain engine: accept tables over the word window
+    uint8_t *mm_d = nullptr; size_t cap_mm_d = 0;         //   range table | settings' type tables | visit_from
+    uint8_t *mm_h = nullptr; size_t cap_mm_h = 0;         //   its pinned staging (one per set: the copies are asynchronous)
     hipEvent_t emit_done = nullptr;
     bool pending = false;
 };
@@ -107,7 +110,10 @@ struct GpuPlan {
     uint32_t *h_npos = nullptr; size_t cap_h_npos = 0;
     uint8_t *h_ntype = nullptr; size_t cap_h_ntype = 0;
     uint32_t *h_nstop = nullptr; size_t cap_h_nstop = 0;
-    uint32_t *walk_gbm = nullptr; size_t cap_walk_gbm = 0; // k_sample_walk: zeroed bitmap for ranges beyond its LDS bitmap
+    uint32_t *h_win = nullptr; size_t cap_h_win = 0;      // host-chain engine: the tempered word window (h_words holds the tables)
+    uint32_t *h_nrank = nullptr; size_t cap_h_nrank = 0;  //   candidate ordinals of the chain
+    MixSets mm_sets;                                       //   what gpu_plan_multimix_eligible derived for the contig being planned
+    const msim_range *mm_for = nullptr; int mm_n = 0;
     uint32_t *h_seed = nullptr;         // pinned staging of the two host generator states (reseed without a stream sync)
     hipEvent_t seed_ev[2] = {nullptr, nullptr};   //   recorded behind the copies that read a slot
     hipStream_t gen_stream = nullptr;   // chunk generation (latency-bound, ~300 us per batch)
@@ -178,17 +184,17 @@ void gpu_plan_destroy(GpuPlan *g) {
     }
     for (auto &t : g->mixed) {
         void *bufs[] = {t.cand_pos, t.cand_type, t.cand_stop, t.nsn_pos, t.nsn_type, t.nsn_rank, t.nsn_stop, t.sn_index,
-                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt, t.p0_slot};
+                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt, t.p0_slot, t.tables, t.mm_d};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (t.walk_h) (void)hipHostFree(t.walk_h);
+        if (t.mm_h) (void)hipHostFree(t.mm_h);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
-    void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop};
+    void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop, g->h_win, g->h_nrank};
     for (void *b : hb) if (b) (void)hipHostFree(b);
     for (auto e : g->chain_ev) if (e) (void)hipEventDestroy(e);
     if (g->t0) (void)hipEventDestroy(g->t0);
     if (g->t1) (void)hipEventDestroy(g->t1);
-    if (g->walk_gbm) (void)hipFree(g->walk_gbm);
     if (g->h_seed) (void)hipHostFree(g->h_seed);
     for (auto e : g->seed_ev) if (e) (void)hipEventDestroy(e);
     if (g->d_poly) (void)hipFree(g->d_poly);
@@ -859,6 +865,73 @@ static int span_close(Ctx *c, GpuPlan *g) {
     return MSIM_OK;
 }
 
+// Steps 3 and 4 of an SV-mix plan, shared by the single-range engine and the host-chain engine: the stops of the chain's
+// candidates are in M.cand_stop -> keep flags and counts -> records, insert pool, SNP draws.  p_s: where the SNP draws of
+// __mutate_sequence start in the CPython stream.  rt / visit_from / sn_chained: see k_keep_flags (nullptr for one range).
+static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, uint64_t p_s, const MixRangeDev *rt,
+                      uint32_t n_draw, const uint32_t *visit_from, bool sn_chained, bool &grew) {
+    const msim_params &P = c->params;
+    GpuStream &py = g->s[0], &np = g->s[1];
+    int rc;
+    const uint32_t nbk = (k + CB_BLOCK - 1) / CB_BLOCK;
+    uint32_t *bmax = M.cnt + (nbk + 2), *cnt_keep = M.cnt + 2 * (nbk + 2), *cnt_sn = M.cnt + 3 * (nbk + 2),
+             *cnt_ins = M.cnt + 4 * (nbk + 2);
+    hipLaunchKernelGGL(k_set_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)p_s);
+
+    // ---- 3. keep flags, counts
+    BlockTable bt{};
+    for (int t = 1; t <= 7; t++) bt.p1[t] = (uint32_t)std::min<int64_t>(P.block[t] + 1, 0xffffffffll);
+    hipLaunchKernelGGL(k_blk_reduce, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt, bmax,
+                       rt, n_draw);
+    hipLaunchKernelGGL(k_scan_max_u32, dim3(1), dim3(1024), 0, c->stream, bmax, nbk);
+    hipLaunchKernelGGL(k_keep_flags, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt,
+                       bmax, cnt_keep, cnt_sn, cnt_ins, g->d_ps, rt, n_draw, visit_from, sn_chained ? 1u : 0u);
+    hipLaunchKernelGGL(k_scan3_u32, dim3(3), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, nbk, g->d_ps);
+    MSIM_HIP(c, hipGetLastError());
+    PlanState h;
+    if ((rc = mixed_poll(c, g, h))) return rc;
+    const uint32_t n_rec = h.n_rec, n_sn = h.n_sn, pool_len = h.pool_len;
+
+    // ---- 4. records, insert pool, SNP draws
+    {   // the record table / pool may still be read by an earlier apply of this contig
+        const size_t want = std::max<uint64_t>(n_rec, 1) * sizeof(msim_record);
+        if (ct.cap_recs < want || ct.cap_pool < pool_len + 2 * PAD) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        }
+        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, pool_len + 2 * PAD))) return rc;
+    }
+    ct.n_rec = n_rec;
+    ct.pool_len = pool_len;
+    ct.plan_empty = n_rec == 0;
+    ct.all_snp = h.n_rec == h.n_sn;
+    ct.delta_known = true;
+    ct.known_delta = h.len_delta;
+    if (pool_len && (rc = ensure_words(c, g, 1, np.pos + pool_len + 1))) return rc;
+    uint64_t pos_hi = p_s;
+    hipEvent_t ce = next_chain_event(g);
+    MSIM_HIP(c, hipEventRecord(ce, c->stream));
+    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+    hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
+                       cnt_keep, cnt_sn, cnt_ins, ct.d_recs, M.sn_index);
+    if (pool_len)
+        hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
+                           (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
+    MSIM_HIP(c, hipGetLastError());
+    np.pos += pool_len;
+    c->t.np_words += pool_len;
+    if (n_sn) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
+        if ((rc = enqueue_snp_stage(c, g, ct, n_sn, M.sn_index, pos_hi, grew))) return rc;
+    }
+    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
+    M.pending = true;
+    py.pos = pos_hi;                                       // bound until the next sync reads the exact value
+    g->unverified = true;
+    ct.planned = true;
+    return MSIM_OK;
+}
+
 int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
     const msim_params &P = c->params;
     int64_t d = P.block[1];
@@ -901,8 +974,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, (size_t)5 * (nbk + 2) * 4, &grew))) return rc;
-    uint32_t *cnt_nsn = M.cnt, *bmax = M.cnt + (nbk + 2), *cnt_keep = M.cnt + 2 * (nbk + 2),
-             *cnt_sn = M.cnt + 3 * (nbk + 2), *cnt_ins = M.cnt + 4 * (nbk + 2);
+    uint32_t *cnt_nsn = M.cnt;                             // (the other four counter arrays: mixed_emit)
 
     // ---- 1. sample -> bitmap; bitmap -> candidates with types; non-SNP candidates compacted
     SampleLaunch sl;
@@ -919,10 +991,10 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     hipLaunchKernelGGL(k_bitmap_expand_cand, dim3(sl.bnb), dim3(BM_THREADS), 0, c->stream,
                        reinterpret_cast<const uint64_t *>(S.bitmap), sl.bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
                        np.d_raw, (unsigned long long)np_base, tt, M.cand_pos, M.cand_type);
-    hipLaunchKernelGGL(k_nsn_count, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_type, k, cnt_nsn);
+    hipLaunchKernelGGL(k_nsn_count, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_type, k, cnt_nsn, 0u);
     hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, cnt_nsn, nbk);
     hipLaunchKernelGGL(k_nsn_scatter, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, k, cnt_nsn, nbk,
-                       M.nsn_pos, M.nsn_type, M.nsn_rank, g->d_ps);
+                       M.nsn_pos, M.nsn_type, M.nsn_rank, g->d_ps, 0u);
     MSIM_HIP(c, hipGetLastError());
     S.pending = false;                                     // consumed on the plan stream itself
     // The host walks the non-SNP candidates.  Their copy starts at once, beside the plan stream and before their number
@@ -1039,58 +1111,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                            M.cand_stop);
     }
     const uint64_t p_s = p_b + consumed;                   // the SNP draws of __mutate_sequence start here
-    hipLaunchKernelGGL(k_set_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)p_s);
-
-    // ---- 3. keep flags, counts
-    BlockTable bt{};
-    for (int t = 1; t <= 7; t++) bt.p1[t] = (uint32_t)std::min<int64_t>(P.block[t] + 1, 0xffffffffll);
-    hipLaunchKernelGGL(k_blk_reduce, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt, bmax);
-    hipLaunchKernelGGL(k_scan_max_u32, dim3(1), dim3(1024), 0, c->stream, bmax, nbk);
-    hipLaunchKernelGGL(k_keep_flags, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt,
-                       bmax, cnt_keep, cnt_sn, cnt_ins, g->d_ps);
-    hipLaunchKernelGGL(k_scan3_u32, dim3(3), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, nbk, g->d_ps);
-    MSIM_HIP(c, hipGetLastError());
-    if ((rc = mixed_poll(c, g, h))) return rc;
-    const uint32_t n_rec = h.n_rec, n_sn = h.n_sn, pool_len = h.pool_len;
-
-    // ---- 4. records, insert pool, SNP draws
-    {   // the record table / pool may still be read by an earlier apply of this contig
-        const size_t want = std::max<uint64_t>(n_rec, 1) * sizeof(msim_record);
-        if (ct.cap_recs < want || ct.cap_pool < pool_len + 2 * PAD) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-        }
-        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
-        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, pool_len + 2 * PAD))) return rc;
-    }
-    ct.n_rec = n_rec;
-    ct.pool_len = pool_len;
-    ct.plan_empty = n_rec == 0;
-    ct.all_snp = h.n_rec == h.n_sn;
-    ct.delta_known = true;
-    ct.known_delta = h.len_delta;
-    if (pool_len && (rc = ensure_words(c, g, 1, np.pos + pool_len + 1))) return rc;
-    uint64_t pos_hi = p_s;
-    hipEvent_t ce = next_chain_event(g);
-    MSIM_HIP(c, hipEventRecord(ce, c->stream));
-    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-    hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
-                       cnt_keep, cnt_sn, cnt_ins, ct.d_recs, M.sn_index);
-    if (pool_len)
-        hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
-                           (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
-    MSIM_HIP(c, hipGetLastError());
-    np.pos += pool_len;
-    c->t.np_words += pool_len;
-    if (n_sn) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
-        if ((rc = enqueue_snp_stage(c, g, ct, n_sn, M.sn_index, pos_hi, grew))) return rc;
-    }
-    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
-    M.pending = true;
-    py.pos = pos_hi;                                       // bound until the next sync reads the exact value
-    g->unverified = true;
-    ct.planned = true;
-    return MSIM_OK;
+    return mixed_emit(c, g, ct, M, k, p_s, nullptr, 0, nullptr, false, grew);
 }
 
 
@@ -1309,68 +1330,44 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
 }
 
 
-// ====================================================================== device-walked contigs
-// The same contigs as the host-sampled engine above (deterministic-SNP ranges of any size and number), but the chain
-// of samples is walked by ONE workgroup on the device (k_sample_walk): no word window goes to the host, nothing
-// synchronises -- the contig is enqueued like an SNP-sampler contig.  Pool-path ranges beyond the kernel's LDS pool
-// keep the contig on the host-sampled engine.
-// MSIM_WALK_PROF builds: phase counters of k_sample_walk, printed at exit
-static unsigned long long *walk_prof() {
-#ifdef MSIM_WALK_PROF
-    static unsigned long long *d = nullptr;
-    if (!d) {
-        (void)hipMalloc(&d, 16 * 8);
-        (void)hipMemset(d, 0, 16 * 8);
-        atexit([]() {
-            unsigned long long h[16];
-            (void)hipDeviceSynchronize();
-            if (hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "walk prof: cycles %llu wall100MHz %llu pool %llu set %llu batches %llu refills %llu refill_cyc %llu inner %llu ranges %llu | per-batch phases: flags+exchange %llu, insert rounds %llu, append %llu, cut %llu\n",
-                        h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11], h[12]);
-        });
-    }
-    return d;
-#else
-    return nullptr;
-#endif
-}
+// ====================================================================== host-chain engine
+// Contigs the three engines above decline but whose stream structure is still a plain chain: several drawing ranges with
+// their own settings (RMT: gene blocks + an SV `std` line, hot / cold ranges), SV types on many small ranges, an SNP
+// block above the sampling distance.  Per range the reference runs sample -> type draw -> boundary pass before it touches
+// the next range (mutator.py:116-123,144-214), so the CPython stream interleaves samples and randint draws and the whole
+// contig is ONE chain: the host walks it (plan_host.cpp: multimix_walk_host) over a window of tempered words, the accept
+// tables of every randint class (k_accept_tables_ps) and the candidate TYPES -- a function of the candidate's ordinal
+// alone (k_types_multi), hence known before any position is -- all produced on the device.  Back on the device: the
+// SNP filter (blocked ends clipped per range), the visit filter across range borders, records, insert pool, SNP draws.
+constexpr uint64_t MM_MIN_K = 1024;                      // below: the host planner is as fast as the round trips
 
-// test hook: which of the context's streams still have work queued (hipStreamQuery; never blocks)
-void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]) {
-    auto q = [](hipStream_t s) { if (!s) return -1; const hipError_t e = hipStreamQuery(s); (void)hipGetLastError(); return e == hipSuccess ? 0 : e == hipErrorNotReady ? 1 : 2; };
-    out[0] = q(c->stream); out[1] = q(c->emit_stream); out[2] = q(g->gen_stream); out[3] = q(g->jump_stream);
-    out[4] = (int)g->s[0].n_chunks; out[5] = (int)g->s[0].n_states; out[6] = (int)g->s[0].ready_ev.size(); out[7] = (int)g->s[0].waited_chunks;
-}
-
-bool gpu_plan_walk_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
-    // Opt-in (MSIM_WALK=1): bit-exact and fully asynchronous, but measured SLOWER than the host walk in round 2 --
-    // a link of the chain costs ~12 dependent LDS / barrier phases of 400-1200 cycles each on the device (5 700 cycles =
-    // 2.4 us per range, 106 ms per 3 Gb config-4 genome) against 1.8 us on one host core (75 ms); DESIGN.md section 3.3.
-    static const bool enabled = []() { const char *e = getenv("MSIM_WALK"); return e && e[0] == '1'; }();
-    if (!enabled || !gpu_plan_hostsample_eligible(c, ranges, n_ranges)) return false;
-    const msim_params &P = c->params;
-    int64_t d = P.block[1];
-    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
-    if (d >= (1ll << 32)) return false;
-    for (int i = 0; i < n_ranges; i++) {
-        const msim_range &r = ranges[i];
-        if (r.k == 0) continue;
-        const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
-        if (n <= r.setsize && n > (int64_t)WK_POOL_MAX) return false;
-    }
+bool gpu_plan_multimix_eligible(const Ctx *c, GpuPlan *g, uint64_t L, const msim_range *ranges, int n_ranges) {
+    g->mm_for = nullptr;
+    if (!multimix_prepare(c, L, ranges, n_ranges, g->mm_sets)) return false;
+    if (g->mm_sets.K < MM_MIN_K) return false;
+    g->mm_for = ranges; g->mm_n = n_ranges;
     return true;
 }
 
-int plan_contig_gpu_walk(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
+int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
+    static const bool prof = getenv("MSIM_CHAIN_PROF") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;
     int64_t d = P.block[1];
     for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
     int rc;
+    if (g->mm_for != ranges || g->mm_n != n_ranges) {
+        if (!multimix_prepare(c, ct.len, ranges, n_ranges, g->mm_sets)) return fail(c, MSIM_ERR_UNSUPPORTED, "outside the host-chain engine");
+    }
+    g->mm_for = nullptr;
+    const MixSets &ms = g->mm_sets;
+    const uint32_t K = (uint32_t)ms.K, n_draw = ms.n_draw, n_sets = (uint32_t)ms.rep.size();
+    const uint32_t lg = chain_lg_rows(ms.gcc);
     if ((rc = stream_to_device(c, g, 0))) return rc;
     if ((rc = stream_to_device(c, g, 1))) return rc;
     if (!g->d_ps) MSIM_HIP(c, hipMalloc(&g->d_ps, sizeof(PlanState)));
     if (!g->h_mail) MSIM_HIP(c, hipHostMalloc(&g->h_mail, sizeof(PlanState), hipHostMallocMapped));
-    GpuStream &py = g->s[0];
+    GpuStream &py = g->s[0], &np = g->s[1];
     if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
     if (!g->unverified) MSIM_HIP(c, hipEventRecord(g->t0, c->stream));
     if (!g->ps_valid) {
@@ -1378,124 +1375,193 @@ int plan_contig_gpu_walk(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *range
         g->ps_valid = true;
     }
     g->unverified = true;
-    // word window: expected consumption of every sample + 16 sigma of the total (as for the host-sampled engine)
-    uint64_t K = 0, max_g = 0;
-    uint32_t n_draw = 0;
-    double e_words = 0, var = 0;
-    for (int i = 0; i < n_ranges; i++) {
-        const msim_range &r = ranges[i];
-        if (r.k == 0) continue;
-        n_draw++;
-        const double k = (double)r.k, n = (double)((r.stop - (r.k - 1) * d) - r.start);
-        K += (uint64_t)r.k;
-        if (n <= (double)r.setsize) { e_words += 2.0 * k; var += 2.0 * k; continue; }   // pool path: < 2 words per draw
-        if (n > (double)WK_LDS_BITS) max_g = std::max<uint64_t>(max_g, (uint64_t)n);
-        const double p_acc = n / (double)(1ull << bit_length64((uint64_t)n));
-        const double need = k >= n ? 64.0 * k : -n * std::log1p(-k / n);                // coupon collector
-        e_words += need / p_acc;
-        var += need * (1.0 - p_acc) / (p_acc * p_acc) + 4.0 * (need - k) / (p_acc * p_acc) + need / p_acc;
+    // ---- sizes: the word window (every sample + every randint, 16 sigma of the total) and the chain length
+    double e_words = 0, var = 0, e_ch = 0, var_ch = 0;
+    std::vector<double> q_nsn(n_sets, 0.0), acc_min(n_sets, 1.0);
+    for (uint32_t s = 0; s < n_sets; s++) {
+        const msim_range &r = ranges[ms.rep[s]];
+        for (int j = 0; j < r.n_types; j++) {
+            if (!range_type_drawable(r, j) || r.types[j] == MSIM_SN) continue;
+            const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+            q_nsn[s] += (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - lo) / 9007199254740992.0;
+            const int64_t w = r.max_len[r.types[j]] - r.min_len[r.types[j]] + 1;
+            acc_min[s] = std::min(acc_min[s], (double)w / (double)(1ull << bit_length64((uint64_t)w)));
+        }
+        q_nsn[s] = std::min(1.0, q_nsn[s]);
+    }
+    {
+        uint32_t di = 0;
+        for (int i = 0; i < n_ranges; i++) {
+            const msim_range &r = ranges[i];
+            if (r.k == 0) continue;
+            const uint32_t s = ms.set_of[di++];
+            const double k = (double)r.k, n = (double)((r.stop - (r.k - 1) * d) - r.start);
+            if (n <= (double)r.setsize) { e_words += 2.0 * k; var += 2.0 * k; }           // pool path: < 2 words per draw
+            else {
+                const double p_acc = n / (double)(1ull << bit_length64((uint64_t)n));
+                const double need = k >= n ? 64.0 * k : -n * std::log1p(-k / n);          // coupon collector
+                e_words += need / p_acc;
+                var += need * (1.0 - p_acc) / (p_acc * p_acc) + 4.0 * (need - k) / (p_acc * p_acc) + need / p_acc;
+            }
+            const double m = k * q_nsn[s];                                                 // randint draws: at most one per non-SNP
+            e_ch += m; var_ch += m * (1.0 - q_nsn[s]);
+            e_words += m / acc_min[s];
+            var += m / (acc_min[s] * acc_min[s]);
+        }
     }
     const double wd = e_words + 16.0 * std::sqrt(var) + 65536.0;
-    if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
+    if (wd >= 1.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "host-chain window beyond 2^30 words");
     const uint32_t W = (uint32_t)wd;
+    const uint32_t n_hi = ms.sn_chained ? K : (uint32_t)std::min<double>(K, e_ch + 16.0 * std::sqrt(var_ch) + 64.0);
     bool grew = false;
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
     if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;
-    if (M.pending) {                                       // the pinned range table of this set may still be in flight
+    if (M.pending) {                                       // the pinned tables of this set may still be in flight
         MSIM_HIP(c, hipEventSynchronize(M.emit_done));
         M.pending = false;
     }
     if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
-    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;   // unordered position list
-    if ((rc = grow(c, (void **)&M.walk_d, &M.cap_walk_d, (size_t)n_draw * sizeof(WalkRange) + 64, &grew))) return rc;
-    if ((rc = grow_host(c, (void **)&M.walk_h, &M.cap_walk_h, (size_t)n_draw * sizeof(WalkRange) + 64))) return rc;
-    const uint32_t bmw = (uint32_t)((ct.len + 63) / 64);  // contig-wide bitmap, 64-bit words
-    const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
+    const uint32_t nbk = (K + CB_BLOCK - 1) / CB_BLOCK;
+    const size_t n_slots = ((size_t)W + 1) << lg;
+    if ((rc = grow(c, (void **)&M.cand_pos, &M.cap_pos, (size_t)K * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cand_type, &M.cap_type, (size_t)K + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cand_stop, &M.cap_stop, (size_t)K * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_type, &M.cap_ntype, (size_t)K + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_rank, &M.cap_nrank, (size_t)K * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)K * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)K * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, (size_t)5 * (nbk + 2) * 4, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4 + 64, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.tables, &M.cap_tables, n_slots * 4 + 64, &grew))) return rc;
+    // range table | type tables | visit_from, one device block and one pinned block per scratch set
+    const size_t off_sets = ((size_t)n_draw * sizeof(MixRangeDev) + 63) & ~(size_t)63;
+    const size_t off_visit = (off_sets + (size_t)n_sets * sizeof(TypeTable) + 63) & ~(size_t)63;
+    const size_t mm_bytes = off_visit + (size_t)n_draw * 4 + 64;
+    if ((rc = grow(c, (void **)&M.mm_d, &M.cap_mm_d, mm_bytes, &grew))) return rc;
+    if ((rc = grow_host(c, (void **)&M.mm_h, &M.cap_mm_h, mm_bytes))) return rc;
+    if (g->cap_h_words < n_slots * 4 || g->cap_h_win < (size_t)W * 4 || g->cap_h_npos < (size_t)K * 4 + 64 ||
+        g->cap_h_ntype < (size_t)K + 64 || g->cap_h_nstop < (size_t)K * 4 + 64 || g->cap_h_nrank < (size_t)K * 4 + 64) {
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
+        if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+        if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, n_slots * 4))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_win, &g->cap_h_win, (size_t)W * 4))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)K * 4 + 64))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_ntype, &g->cap_h_ntype, (size_t)K + 64))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_nstop, &g->cap_h_nstop, (size_t)K * 4 + 64))) return rc;
+        if ((rc = grow_host(c, (void **)&g->h_nrank, &g->cap_h_nrank, (size_t)K * 4 + 64))) return rc;
+    }
+    MixRangeDev *rt_h = reinterpret_cast<MixRangeDev *>(M.mm_h);
+    TypeTable *sets_h = reinterpret_cast<TypeTable *>(M.mm_h + off_sets);
+    uint32_t *visit_h = reinterpret_cast<uint32_t *>(M.mm_h + off_visit);
+    const MixRangeDev *rt_d = reinterpret_cast<const MixRangeDev *>(M.mm_d);
+    const TypeTable *sets_d = reinterpret_cast<const TypeTable *>(M.mm_d + off_sets);
+    uint32_t *visit_d = reinterpret_cast<uint32_t *>(M.mm_d + off_visit);
     {
-        const size_t want = (size_t)bmw * 8 + 64;
-        if (M.cap_wbits < want) {
-            const size_t before = M.cap_wbits;
-            if ((rc = grow(c, (void **)&M.wbits, &M.cap_wbits, want, &grew))) return rc;
-            if (M.cap_wbits != before) MSIM_HIP(c, hipMemset(M.wbits, 0, M.cap_wbits));   // k_walk_expand leaves it zeroed
-        }
-        if (M.wbits_dirty) {
-            MSIM_HIP(c, hipMemsetAsync(M.wbits, 0, M.cap_wbits, c->stream));
-            M.wbits_dirty = false;
-        }
-    }
-    if ((rc = grow(c, (void **)&M.wcnt, &M.cap_wcnt, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
-    if (max_g) {
-        const size_t want = (size_t)((max_g + 31) / 32) * 4 + 64;
-        if (g->cap_walk_gbm < want) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            if (g->walk_gbm) MSIM_HIP(c, hipFree(g->walk_gbm));
-            g->walk_gbm = nullptr; g->cap_walk_gbm = 0;
-            MSIM_HIP(c, hipMalloc(&g->walk_gbm, want + want / 4));
-            MSIM_HIP(c, hipMemset(g->walk_gbm, 0, want + want / 4));      // the kernel leaves it zeroed
-            g->cap_walk_gbm = want + want / 4;
-        }
-    }
-    {   // the record table may still be read by an earlier apply of this contig
-        const size_t want = (size_t)K * sizeof(msim_record);
-        if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-        }
-        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
-        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
-    }
-    {
-        uint32_t at = 0, base = 0;
+        uint32_t di = 0, base = 0;
         for (int i = 0; i < n_ranges; i++) {
             const msim_range &r = ranges[i];
             if (r.k == 0) continue;
-            const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
-            WalkRange w;
-            w.start = (uint32_t)r.start; w.k = (uint32_t)r.k; w.n = (uint32_t)n; w.rec_base = base;
-            w.pool = n <= r.setsize ? 1u : 0u;
-            M.walk_h[at++] = w;
+            rt_h[di] = MixRangeDev{base, (uint32_t)(r.stop + 1), ms.set_of[di], 0u};
             base += (uint32_t)r.k;
+            di++;
+        }
+        for (uint32_t s = 0; s < n_sets; s++) {
+            const msim_range &r = ranges[ms.rep[s]];
+            TypeTable tt{};
+            tt.n = (uint32_t)r.n_types;
+            for (int j = 0; j < r.n_types; j++) { tt.thr[j] = r.cdf_thr[j]; tt.type[j] = (uint8_t)r.types[j]; }
+            sets_h[s] = tt;
         }
     }
-    const uint64_t pos_lo = py.pos;
-    if ((rc = ensure_words(c, g, 0, pos_lo + W + 1))) return rc;
-    MSIM_HIP(c, hipMemcpyAsync(M.walk_d, M.walk_h, (size_t)n_draw * sizeof(WalkRange), hipMemcpyHostToDevice, c->stream));
-    if (max_g)
-        hipLaunchKernelGGL(k_sample_walk<true>, dim3(1), dim3(WK_THREADS), 0, c->stream, py.d_raw, g->d_ps, W, M.walk_d, n_draw,
-                           M.cand_pos, g->walk_gbm, walk_prof());
-    else
-        hipLaunchKernelGGL(k_sample_walk<false>, dim3(1), dim3(WK_THREADS), 0, c->stream, py.d_raw, g->d_ps, W, M.walk_d, n_draw,
-                           M.cand_pos, g->walk_gbm, walk_prof());
+    // ---- 1. device: word window, accept tables, candidate types, the chain's candidates
+    const uint64_t np_base = np.pos;                       // exact: the NumPy stream never rejects
+    if ((rc = ensure_words(c, g, 0, py.pos + W + 1))) return rc;
+    if ((rc = ensure_words(c, g, 1, np_base + 2ull * K + 1))) return rc;
+    if ((rc = ensure_signals(c, g))) return rc;
+    MSIM_HIP(c, hipMemcpyAsync(M.mm_d, M.mm_h, off_visit, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_types_multi, dim3(nbk), dim3(CB_THREADS), 0, c->stream, np.d_raw, (unsigned long long)np_base, K, rt_d,
+                       n_draw, sets_d, M.cand_type);
+    hipLaunchKernelGGL(k_nsn_count, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_type, K, M.cnt, ms.sn_chained ? 1u : 0u);
+    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, M.cnt, nbk);
+    hipLaunchKernelGGL(k_nsn_scatter, dim3(nbk), dim3(CB_THREADS), 0, c->stream, (const uint32_t *)nullptr, M.cand_type, K, M.cnt, nbk,
+                       (uint32_t *)nullptr, M.nsn_type, M.nsn_rank, g->d_ps, ms.sn_chained ? 1u : 0u);
     MSIM_HIP(c, hipGetLastError());
-    {   // records on the emit stream (ordered after any earlier APPLY that still reads this contig's table): the
-        // contig-wide bitmap is the sorted sample
-        hipEvent_t ce0 = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce0, c->stream));
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce0, 0));
-        hipLaunchKernelGGL(k_list_to_bits, dim3(((uint32_t)K + 255) / 256), dim3(256), 0, c->emit_stream, M.cand_pos,
-                           (uint32_t)K, M.wbits);
-        hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
-                           reinterpret_cast<const uint64_t *>(M.wbits), bmw, M.wcnt);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, M.wcnt, bnb);
-        hipLaunchKernelGGL(k_walk_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
-                           reinterpret_cast<uint64_t *>(M.wbits), bmw, M.wcnt, M.walk_d, n_draw, (uint32_t)d, ct.d_recs);
-        MSIM_HIP(c, hipGetLastError());
+    {   // the chain's candidates go over beside the plan stream, a 16-sigma bound of their number first
+        hipEvent_t se = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(se, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(g->copy_stream, se, 0));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_nrank, M.nsn_rank, (size_t)n_hi * 4, hipMemcpyDeviceToHost, g->copy_stream));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_hi, hipMemcpyDeviceToHost, g->copy_stream));
+        MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
     }
-    ct.n_rec = K;
-    ct.pool_len = 0;
-    ct.plan_empty = false;
-    ct.all_snp = true;
-    uint64_t pos_hi = pos_lo + W;
-    if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
-        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew))) return rc;
+    hipLaunchKernelGGL(k_temper_window_ps, dim3((W + 255) / 256), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W, M.words);
+    hipLaunchKernelGGL(k_accept_tables_ps, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W,
+                       ms.gcc, lg, M.tables);
+    MSIM_HIP(c, hipGetLastError());
+    PlanState h;
+    if ((rc = mixed_poll(c, g, h))) return rc;             // exact stream position + the chain's length
+    const uint32_t n_ch = h.n_nsn;
+    const uint64_t p0 = h.pos;
+    np.pos = np_base + 2ull * K;
+    c->t.np_words += 2ull * K;
+    if (n_ch > n_hi) {                                     // beyond 16 sigma: the rest of the chain's candidates
+        MSIM_HIP(c, hipMemcpyAsync(g->h_nrank + n_hi, M.nsn_rank + n_hi, (size_t)(n_ch - n_hi) * 4, hipMemcpyDeviceToHost, g->copy_stream));
+        MSIM_HIP(c, hipMemcpyAsync(g->h_ntype + n_hi, M.nsn_type + n_hi, (size_t)(n_ch - n_hi), hipMemcpyDeviceToHost, g->copy_stream));
+        MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
     }
-    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
-    M.pending = true;
-    py.pos = pos_hi;                                       // bound until gpu_plan_finish reads the exact value
-    g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k) per drawing range
-    c->t.np_words += 2 * K;
-    ct.planned = true;
-    return MSIM_OK;
+    // window and tables come over in three pieces (1/8, 3/8, 1/2); the host starts on the first while the others are in flight
+    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0};
+    for (int q = 0; q < 3; q++) {
+        const size_t a = fd.cut[q], b = fd.cut[q + 1], tb = q == 2 ? (size_t)W + 1 : b;   // (+ the end-of-window sentinel)
+        if (b > a) MSIM_HIP(c, hipMemcpyAsync(g->h_win + a, M.words + a, (b - a) * 4, hipMemcpyDeviceToHost, c->stream));
+        if (tb > a) MSIM_HIP(c, hipMemcpyAsync(g->h_words + (a << lg), M.tables + (a << lg), ((tb - a) << lg) * 4, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+    }
+    MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+    if ((rc = flush_deferred_apply(c))) return rc;         // the previous contig's APPLY: the device is idle from here on
+    const auto tp1 = std::chrono::steady_clock::now();
+    // ---- 2. the chain, on the host
+    size_t consumed = 0;
+    WordFeed feed;
+    feed.user = &fd;
+    feed.more = [](void *u, size_t *avail) -> int {
+        Feed &f = *static_cast<Feed *>(u);
+        if (f.next >= 3) return MSIM_OK;
+        const int rc = spin_event(f.c, f.g->ev_piece[f.next]);
+        if (!rc) *avail = f.cut[++f.next];
+        return rc;
+    };
+    rc = spin_event(c, g->ev_cand);
+    if (!rc) rc = multimix_walk_host(c, ct.len, ranges, n_ranges, d, ms, g->h_win, g->h_words, W, g->h_nrank, g->h_ntype, n_ch,
+                                     g->h_npos, g->h_nstop, visit_h, &consumed, &feed);
+    if (!rc) {
+        MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned blocks are free again
+        rc = span_close(c, g);
+    }
+    if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
+    const auto tp2 = std::chrono::steady_clock::now();
+    MSIM_HIP(c, hipEventRecord(g->t0, c->stream));        // the host chain is not GPU time
+    // ---- 3. back on the device
+    MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, (size_t)K * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_ch) MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_ch * 4, hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipMemcpyAsync(visit_d, visit_h, (size_t)n_draw * 4, hipMemcpyHostToDevice, c->stream));
+    if (n_ch) hipLaunchKernelGGL(k_stop_scatter, dim3((n_ch + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_stop, n_ch, M.cand_stop);
+    MSIM_HIP(c, hipGetLastError());
+    rc = mixed_emit(c, g, ct, M, K, p0 + consumed, rt_d, n_draw, visit_d, ms.sn_chained, grew);
+    if (prof) {
+        const auto tp3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        fprintf(stderr, "hostchain: n_draw %u sets %u K %u chain %u W %u lg %u | pre %.0f walk %.0f (%.2f ns/cand) post %.0f us\n", n_draw, n_sets, K,
+                n_ch, W, lg, us(tp0, tp1), us(tp1, tp2), us(tp1, tp2) * 1e3 / K, us(tp2, tp3));
+    }
+    return rc;
+}
+
+// test hook: which of the context's streams still have work queued (hipStreamQuery; never blocks)
+void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]) {
+    auto q = [](hipStream_t s) { if (!s) return -1; const hipError_t e = hipStreamQuery(s); (void)hipGetLastError(); return e == hipSuccess ? 0 : e == hipErrorNotReady ? 1 : 2; };
+    out[0] = q(c->stream); out[1] = q(c->emit_stream); out[2] = q(g->gen_stream); out[3] = q(g->jump_stream);
+    out[4] = (int)g->s[0].n_chunks; out[5] = (int)g->s[0].n_states; out[6] = (int)g->s[0].ready_ev.size(); out[7] = (int)g->s[0].waited_chunks;
 }
 
 }  // namespace msim

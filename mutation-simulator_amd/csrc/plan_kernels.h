@@ -966,14 +966,15 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand_cand(const uint64_
     }
 }
 
+// (all != 0: every candidate counts -- contigs whose SNPs are on the boundary chain too, SNP block > sampling distance)
 __global__ __launch_bounds__(CB_THREADS) void k_nsn_count(const uint8_t *__restrict__ cand_type, uint32_t k,
-                                                          uint32_t *__restrict__ cnt) {
+                                                          uint32_t *__restrict__ cnt, uint32_t all) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint32_t c = 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++)
-        if (i0 + q < k && cand_type[i0 + q] != MSIM_SN) c++;
+        if (i0 + q < k && (all || cand_type[i0 + q] != MSIM_SN)) c++;
     uint32_t total;
     (void)block_scan_add(c, wsum, total);
     if (threadIdx.x == 0) cnt[blockIdx.x] = total;
@@ -983,22 +984,25 @@ __global__ __launch_bounds__(CB_THREADS) void k_nsn_scatter(const uint32_t *__re
                                                             const uint8_t *__restrict__ cand_type, uint32_t k,
                                                             const uint32_t *__restrict__ off, uint32_t n_blocks,
                                                             uint32_t *__restrict__ nsn_pos, uint8_t *__restrict__ nsn_type,
-                                                            uint32_t *__restrict__ nsn_rank, PlanState *__restrict__ ps) {
+                                                            uint32_t *__restrict__ nsn_rank, PlanState *__restrict__ ps,
+                                                            uint32_t all) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint8_t t[CB_ITEMS];
+    bool on[CB_ITEMS];
     uint32_t c = 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)MSIM_SN;
-        c += t[q] != MSIM_SN ? 1u : 0u;
+        on[q] = i0 + q < k && (all || t[q] != MSIM_SN);
+        c += on[q] ? 1u : 0u;
     }
     uint32_t total;
     uint32_t j = off[blockIdx.x] + block_scan_add(c, wsum, total);
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
-        if (t[q] != MSIM_SN) {
-            nsn_pos[j] = cand_pos[i0 + q];
+        if (on[q]) {
+            if (cand_pos) nsn_pos[j] = cand_pos[i0 + q];             // (the host-chain engine has no positions yet)
             nsn_type[j] = t[q];
             nsn_rank[j] = i0 + q;
             j++;
@@ -1034,6 +1038,65 @@ __global__ __launch_bounds__(256) void k_accept_tables(const uint32_t *__restric
     T[slot] = e;
 }
 
+// the same from the CURRENT device position on (the host-chain engine: no round trip to learn it)
+__global__ __launch_bounds__(256) void k_accept_tables_ps(const uint32_t *__restrict__ raw, const PlanState *__restrict__ ps,
+                                                          uint32_t n, ChainClasses cc, uint32_t lg_rows, uint32_t *__restrict__ T) {
+    const unsigned long long p0 = ps->pos;
+    const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = slot >> lg_rows, k = slot & ((1u << lg_rows) - 1);
+    if (i > n || k >= cc.n) return;
+    const uint32_t sh = cc.sh[k], width = cc.width[k];
+    uint32_t e = 0;
+    const uint32_t end = min(n, i + CHAIN_TABLE_REACH);
+    for (uint32_t q = i; q < end; q++) {
+        const uint32_t v = mt_temper(raw[p0 + q]) >> sh;
+        if (v < width) { e = ((q - i + 1) << lg_rows) << 24 | v; break; }
+    }
+    T[slot] = e;
+}
+
+// ---- host-chain engine (plan_gpu.hip: plan_contig_gpu_multimix): several drawing ranges with their own settings
+struct MixRangeDev { uint32_t rec_base, clip, set_id, rsv; };   // per drawing range: first candidate ordinal, stop + 1, settings
+__device__ __forceinline__ uint32_t mix_range_of(const MixRangeDev *__restrict__ rt, uint32_t n_draw, uint32_t ordinal) {
+    uint32_t lo = 0, hi = n_draw;                              // last range with rec_base <= ordinal
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rt[mid].rec_base <= ordinal) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// The type of candidate j is a function of j alone: NumPy words 2j, 2j+1 against the thresholds of the range that owns
+// ordinal j (mutator.py:170-174 per range; the NumPy stream never rejects, so ordinals map to words directly) --
+// known before any position exists, which is what lets the host walk sample and boundary pass in one go.
+__global__ __launch_bounds__(CB_THREADS) void k_types_multi(const uint32_t *__restrict__ np_raw, unsigned long long np_base,
+                                                            uint32_t K, const MixRangeDev *__restrict__ rt, uint32_t n_draw,
+                                                            const TypeTable *__restrict__ sets, uint8_t *__restrict__ cand_type) {
+    const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
+    if (i0 >= K) return;
+    uint32_t r = mix_range_of(rt, n_draw, i0);
+    TypeTable tt = sets[rt[r].set_id];
+    uint32_t next = r + 1 < n_draw ? rt[r + 1].rec_base : 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < CB_ITEMS; q++) {
+        const uint32_t j = i0 + q;
+        if (j >= K) break;
+        while (j >= next) {
+            r++;
+            tt = sets[rt[r].set_id];
+            next = r + 1 < n_draw ? rt[r + 1].rec_base : 0xffffffffu;
+        }
+        const uint32_t a = mt_temper(np_raw[np_base + 2ull * j]);
+        const uint32_t b = mt_temper(np_raw[np_base + 2ull * j + 1]);
+        const unsigned long long m = ((unsigned long long)(a >> 5) << 26) | (b >> 6);
+        uint32_t idx = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) idx += ((uint32_t)x < tt.n && tt.thr[x] <= m) ? 1u : 0u;
+        if (idx >= tt.n) idx = tt.n - 1;                 // unreachable: cdf[-1] == 1.0 > u
+        cand_type[j] = tt.type[idx];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_stop_scatter(const uint32_t *__restrict__ nsn_rank,
                                                       const uint32_t *__restrict__ nsn_stop, uint32_t n_nsn,
                                                       uint32_t *__restrict__ cand_stop) {
@@ -1052,15 +1115,24 @@ __device__ __forceinline__ uint32_t blocked_end(uint32_t pos, uint8_t type, uint
 __global__ __launch_bounds__(CB_THREADS) void k_blk_reduce(const uint32_t *__restrict__ cand_pos,
                                                            const uint8_t *__restrict__ cand_type,
                                                            const uint32_t *__restrict__ cand_stop, uint32_t k,
-                                                           BlockTable bt, uint32_t *__restrict__ bmax) {
+                                                           BlockTable bt, uint32_t *__restrict__ bmax,
+                                                           const MixRangeDev *__restrict__ rt, uint32_t n_draw) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint32_t m = 0;
+    // Several drawing ranges: the blocked range is reset per range (mutator.py:184).  Clipping every blocked end to its
+    // range's stop + 1 (<= the next range's start) makes the contig-wide running maximum equal the per-range one.
+    uint32_t r = (rt && i0 < k) ? mix_range_of(rt, n_draw, i0) : 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         if (i0 + q < k) {
+            uint32_t clip = 0xffffffffu;
+            if (rt) {
+                while (r + 1 < n_draw && rt[r + 1].rec_base <= i0 + q) r++;
+                clip = rt[r].clip;
+            }
             const uint8_t t = cand_type[i0 + q];
-            if (t != MSIM_SN) m = max(m, blocked_end(cand_pos[i0 + q], t, cand_stop[i0 + q], bt));
+            if (t != MSIM_SN) m = max(m, min(clip, blocked_end(cand_pos[i0 + q], t, cand_stop[i0 + q], bt)));
         }
     }
     uint32_t total;
@@ -1094,26 +1166,41 @@ __global__ __launch_bounds__(1024) void k_scan_max_u32(uint32_t *__restrict__ a,
     }
 }
 
-// keep flags (KEEP_BIT in cand_type) + per-workgroup counts of kept mutations, kept SNPs, insert bases
+// keep flags (KEEP_BIT in cand_type) + per-workgroup counts of kept mutations, kept SNPs, insert bases.
+// rt != nullptr (host-chain engine): blocked ends clipped per range (see k_blk_reduce); a candidate below its range's
+// visit_from lies inside a DE / DU / IV span of an EARLIER range and is never visited by __mutate_sequence
+// (mutator.py:376,386,398) -- it took part in its own range's boundary pass, but is no record and draws nothing;
+// sn_chained: the SNPs went through the host chain as well (cand_stop holds their verdict).
 __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__restrict__ cand_pos,
                                                            uint8_t *__restrict__ cand_type,
                                                            const uint32_t *__restrict__ cand_stop, uint32_t k,
                                                            BlockTable bt, const uint32_t *__restrict__ bmax,
                                                            uint32_t *__restrict__ cnt_keep, uint32_t *__restrict__ cnt_sn,
-                                                           uint32_t *__restrict__ cnt_ins, PlanState *__restrict__ ps) {
+                                                           uint32_t *__restrict__ cnt_ins, PlanState *__restrict__ ps,
+                                                           const MixRangeDev *__restrict__ rt, uint32_t n_draw,
+                                                           const uint32_t *__restrict__ visit_from, uint32_t sn_chained) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint32_t pos[CB_ITEMS], stop[CB_ITEMS], before[CB_ITEMS];
     uint8_t t[CB_ITEMS];
+    bool vis[CB_ITEMS];
     uint32_t run = 0;
+    uint32_t r = (rt && i0 < k) ? mix_range_of(rt, n_draw, i0) : 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         const bool in = i0 + q < k;
         pos[q] = in ? cand_pos[i0 + q] : 0;
         t[q] = in ? cand_type[i0 + q] : (uint8_t)0;
-        stop[q] = (in && t[q] != MSIM_SN) ? cand_stop[i0 + q] : CHAIN_DROPPED;
+        stop[q] = (in && (t[q] != MSIM_SN || sn_chained)) ? cand_stop[i0 + q] : CHAIN_DROPPED;
         before[q] = run;
-        if (in) run = max(run, blocked_end(pos[q], t[q], stop[q], bt));
+        uint32_t clip = 0xffffffffu;
+        vis[q] = true;
+        if (rt && in) {
+            while (r + 1 < n_draw && rt[r + 1].rec_base <= i0 + q) r++;
+            clip = rt[r].clip;
+            vis[q] = pos[q] >= visit_from[r];
+        }
+        if (in) run = max(run, min(clip, blocked_end(pos[q], t[q], stop[q], bt)));
     }
     uint32_t total;
     const uint32_t pre = max(bmax[blockIdx.x], block_scan_max(run, wsum, total));
@@ -1123,9 +1210,11 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
     for (int q = 0; q < CB_ITEMS; q++) {
         if (i0 + q >= k) continue;
         bool keep;
-        if (t[q] == MSIM_SN) { keep = pos[q] >= max(pre, before[q]); ns += keep ? 1u : 0u; }   // mutator.py:190-196
-        else {
-            keep = stop[q] != CHAIN_DROPPED;
+        if (t[q] == MSIM_SN) {                                           // mutator.py:190-196
+            keep = (sn_chained ? stop[q] != CHAIN_DROPPED : pos[q] >= max(pre, before[q])) && vis[q];
+            ns += keep ? 1u : 0u;
+        } else {
+            keep = stop[q] != CHAIN_DROPPED && vis[q];
             const uint32_t len = stop[q] - pos[q] + 1;
             if (keep && t[q] == MSIM_IN) ni += len;
             if (keep) delta += t[q] == MSIM_DE ? -(long long)len : (t[q] == MSIM_IV ? 0ll : (long long)len);   // mutator.py:343-399
@@ -1248,367 +1337,14 @@ __global__ __launch_bounds__(256) void k_temper_window_ps(const uint32_t *__rest
     if (i < n) dst[i] = mt_temper(raw[ps->pos + i]);
 }
 
-// ------------------------------------------------------------------ 7. chains of small samples on the device
+// ------------------------------------------------------------------ 7. many small sampled ranges
 // An RMT file in the style of the reference's examples leaves thousands of drawing ranges per contig, a few hundred
 // SNPs each.  Every random.sample() starts at the word where the previous one stopped and the stops are data
-// dependent, so the ranges form a chain -- but each link is short, and nothing in it needs the host: ONE workgroup
-// walks the contig's ranges in order, with the next stream words always staged in an LDS ring (refilled from
-// registers that were loaded a whole refill earlier, so the chain never waits for global memory) and the range's
-// de-dup bitmap in LDS.  Round 1 did this walk on the host over a D2H copy of the words (74 ms per 3 Gb genome,
-// with a synchronisation per contig).  Only what decides the next stream position is on the walk's critical path:
-//   set path  (Lib/random.py sample(), n > setsize): accepted draws in stream order are numbered by ballots; the
-//     first A = k of them are OR-ed into the LDS bitmap, every duplicate found raises A by one (the rule of
-//     k_sample_tail: distinct(first A) = A - dups(A) must reach k), until a round finds none; the cut is one past
-//     the word holding the A-th accepted draw.
-//   pool path (n <= setsize): the partial Fisher-Yates shuffle is a chain inside the chain; one lane walks it.
-// A lane that inserted a NEW value also sets bit (range start + value) of a contig-wide bitmap in global memory
-// (fire and forget).  Sorting, ranks and records happen afterwards, in bulk, off the chain (k_walk_expand):
-// pos = start + value + d * rank-inside-the-range (util.py:104-109).
+// dependent, so the ranges form a chain; the host finds the cuts (plan_host.cpp: cut_ranges_host) and the device
+// does everything per position, in bulk: pos = start + value + d * rank-inside-the-range (util.py:104-109).
+// (Round 2 also carried a single-workgroup device walk of that chain, k_sample_walk: bit-exact, but a link of the
+// chain is ~12 dependent LDS / barrier phases -- 2.4 us per range against 0.5 us on one host core -- removed in round 3.)
 struct WalkRange { uint32_t start, k, n, rec_base, pool; };    // pool = 1: n <= setsize (pool path)
-
-constexpr int WK_THREADS = 1024;                          // 16 waves, 4 per SIMD: the walk is bound by instruction latency, and
-constexpr int WK_WAVES = WK_THREADS / 64;                 //   four waves per SIMD interleave where one would idle between issues
-constexpr int WK_ITEMS = 1;
-constexpr int WK_BATCH = WK_THREADS * WK_ITEMS;           // stream words examined per round (1024): wave w owns words [64 w, 64 w + 64)
-constexpr int WK_RG = 256;                                // range descriptors staged in LDS at a time
-constexpr int WK_RING = 8192;                             // LDS ring of tempered words: four quarters (power of two)
-constexpr int WK_Q = WK_RING / 4;                         // three quarters resident, the fourth being loaded (direct-to-LDS)
-constexpr int WK_BM_WORDS = 16384;                        // 64 KB LDS bitmap: ranges of up to 524 288 positions
-constexpr uint32_t WK_LDS_BITS = (uint32_t)WK_BM_WORDS * 32u;
-constexpr uint32_t WK_POOL_MAX = WK_BM_WORDS;             // largest pool-path range handled here (the pool aliases the bitmap)
-constexpr int WK_LIST = 8192;                             // LDS staging of sampled positions between two flushes
-
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding GLOBAL access
-// (vmcnt(0)) -- here that would stall the chain on its own prefetch loads and list stores at every step.
-#define WK_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-
-// index (0..63) of the (r+1)-th set bit of m (r < popcount(m))
-__device__ __forceinline__ uint32_t wk_nth_bit(unsigned long long m, uint32_t r) {
-    uint32_t pos = 0;
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) {
-        const uint32_t c = (uint32_t)__popcll(m & ((1ull << sh) - 1ull));
-        if (r >= c) { r -= c; m >>= sh; pos += sh; }
-    }
-    return pos;
-}
-
-template <bool HAS_BIG>                                   // some range needs the de-dup bitmap in global memory
-__global__ __launch_bounds__(WK_THREADS) void k_sample_walk(const uint32_t *__restrict__ raw, PlanState *ps, uint32_t W,
-                                                            const WalkRange *__restrict__ ranges, uint32_t n_ranges,
-                                                            uint32_t *__restrict__ out_list /* K positions, any order */,
-                                                            uint32_t *gbm /* de-dup bitmap for n > WK_LDS_BITS, zeroed */,
-                                                            unsigned long long *prof) {
-#ifdef MSIM_WALK_PROF
-    unsigned long long pr_t0 = __builtin_readcyclecounter(), pr_w0 = wall_clock64(), pr_pool = 0, pr_set = 0, pr_batches = 0,
-                       pr_inner = 0, pr_ref = 0, pr_nref = 0, pr_p1 = 0, pr_p2 = 0, pr_p3 = 0, pr_p4 = 0, pr_p0 = 0;
-#define PR_NOW() __builtin_readcyclecounter()
-#define WK_PROF_REF0 const unsigned long long pr_r0 = PR_NOW();
-#define WK_PROF_REF1 pr_ref += PR_NOW() - pr_r0; pr_nref++;
-#else
-#define WK_PROF_REF0
-#define WK_PROF_REF1
-#endif
-    __shared__ uint32_t ring[WK_RING];
-    __shared__ uint32_t bm[WK_BM_WORDS];
-    __shared__ uint32_t list[WK_LIST];
-    __shared__ WalkRange rg[WK_RG];
-    __shared__ uint32_t wtot[2][WK_WAVES];                // accepted draws per wave of the batch (double-buffered)
-    __shared__ uint32_t dcnt[2][WK_WAVES];
-    __shared__ uint32_t s_w, s_done, s_over, s_lcnt, s_cut;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long p0 = ps->pos;
-    // ring: words [base, base + 3 Q) resident and tempered, [base + 3 Q, base + 4 Q) in flight -- loaded straight into
-    // LDS (global_load_lds), so that no register and no compiler-inserted vmcnt wait ties the chain to global memory
-    typedef __attribute__((address_space(3))) void wk_lmem;
-    // (issued from inline asm: hipcc guards every LDS access that follows a global_load_lds it knows about with
-    // vmcnt(0), which would turn the prefetch into a blocking load; the chain waits for it by hand, a refill later)
-#define WK_LOAD_QUARTER(first)                                                                     \
-    do {                                                                                           \
-        _Pragma("unroll") for (int i_ = 0; i_ < WK_Q / WK_THREADS; i_++) {                         \
-            const uint32_t row_ = (first) + (uint32_t)(i_ * WK_THREADS) + wave * 64;               \
-            const uint32_t lds_ = __builtin_amdgcn_readfirstlane(                                  \
-                (uint32_t)(size_t)(wk_lmem *)(ring + (row_ & (WK_RING - 1))));                     \
-            const uint32_t *src_ = raw + p0 + row_ + lane;                                         \
-            if (row_ + lane < W)                                                                   \
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"        \
-                             :: "s"(lds_), "v"(src_) : "memory");                            \
-        }                                                                                          \
-    } while (0)
-    for (uint32_t i = tid; i < (uint32_t)(3 * WK_Q); i += WK_THREADS) ring[i] = i < W ? mt_temper(raw[p0 + i]) : 0u;
-    for (uint32_t i = tid; i < (uint32_t)WK_BM_WORDS; i += WK_THREADS) bm[i] = 0;
-    uint32_t base = 0;
-    if (tid == 0) { s_over = 0; s_lcnt = 0; }
-    __syncthreads();
-    WK_LOAD_QUARTER(3 * WK_Q);
-    uint32_t w = 0;                                       // words consumed so far (identical in every lane)
-    uint32_t dpar = 0;                                    // which dcnt buffer the next round uses
-    uint32_t flushed = 0;                                 // positions already written to out_list
-    uint32_t lbound = 0;                                  // upper bound of the staged positions (no LDS read needed)
-    bool over = false;
-    // sampled positions go to global memory in bursts, right after the chain had to wait for its prefetch anyway
-#define WK_FLUSH()                                                                                 \
-    do {                                                                                           \
-        const uint32_t n_ = s_lcnt;                                                                \
-        for (uint32_t i_ = tid; i_ < n_; i_ += WK_THREADS) out_list[flushed + i_] = list[i_];      \
-        flushed += n_;                                                                             \
-        lbound = 0;                                                                                \
-        WK_BARRIER();                                                                              \
-        if (tid == 0) s_lcnt = 0;                                                                  \
-        WK_BARRIER();                                                                              \
-    } while (0)
-    // advance the ring until word `at` lies in its first quarter: then [at, at + 2 Q) is resident
-#define WK_REFILL(at)                                                                              \
-    while ((at) >= base + WK_Q) {                                                                  \
-        WK_PROF_REF0                                                                               \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* the quarter requested a refill ago */ \
-        WK_BARRIER();                                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < WK_Q / WK_THREADS; i_++) {                         \
-            const uint32_t s_ = (base + 3 * WK_Q + (uint32_t)(i_ * WK_THREADS) + tid) & (WK_RING - 1); \
-            ring[s_] = mt_temper(ring[s_]);                                                        \
-        }                                                                                          \
-        base += WK_Q;                                                                              \
-        WK_BARRIER();                                                                              \
-        WK_FLUSH();                                                                                \
-        WK_LOAD_QUARTER(base + 3 * WK_Q);                                                          \
-        WK_PROF_REF1                                                                               \
-    }
-    for (uint32_t r0 = 0; r0 < n_ranges && !over; r0 += WK_RG) {
-        WK_BARRIER();
-        if (tid < (uint32_t)WK_RG && r0 + tid < n_ranges) rg[tid] = ranges[r0 + tid];
-        __syncthreads();
-        const uint32_t in_chunk = min((uint32_t)WK_RG, n_ranges - r0);
-        for (uint32_t rr = 0; rr < in_chunk && !over; rr++) {
-            const WalkRange R = rg[rr];
-            const uint32_t n = R.n, k = R.k;
-            if (k == 0) continue;
-#ifdef MSIM_WALK_PROF
-            const unsigned long long pr_a = PR_NOW();
-#endif
-            if (R.pool) {
-                // ---- pool path: pool[j] = j; k times: j = randbelow(n - i), take pool[j], pool[j] = pool[n - i - 1].
-                // A chain inside the chain: wave 0 walks it in lockstep -- 64 stream words at a time in registers,
-                // picked out with v_readlane, every decision on the scalar unit.
-                uint32_t *pool = bm;                      // (the bitmap is all zero between ranges)
-                for (uint32_t i = tid; i < n; i += WK_THREADS) pool[i] = i;
-                WK_BARRIER();
-                uint32_t i = 0, wl = w;                   // draws done / next word (wave 0, uniform)
-                while (true) {
-                    WK_REFILL(w)
-                    if (lbound + WK_BATCH > (uint32_t)WK_LIST) { WK_BARRIER(); WK_FLUSH(); }
-                    if (wave == 0) {
-                        uint32_t cnt = 0, lc = s_lcnt;
-                        bool ov = false;
-                        while (i < k && cnt < (uint32_t)WK_BATCH && !ov) {
-                            const uint32_t wreg = ring[(wl + lane) & (WK_RING - 1)];
-                            const uint32_t have = min(64u, W > wl ? W - wl : 0u);
-                            if (have == 0) { ov = true; break; }
-                            uint32_t j = 0;
-                            while (j < have && i < k) {
-                                const uint32_t m = n - i;
-                                const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)wreg, (int)j) >> __builtin_clz(m);
-                                j++;
-                                if (v < m) {
-                                    const uint32_t pick = pool[v], last = pool[m - 1];
-                                    if (lane == 0) { pool[v] = last; list[lc] = R.start + pick; }
-                                    lc++; i++;
-                                }
-                            }
-                            wl += j; cnt += j;
-                        }
-                        if (lane == 0) {
-                            s_lcnt = lc;
-                            s_w = wl;
-                            s_done = (i == k || ov) ? 1u : 0u;
-                            if (ov) s_over = 1;
-                        }
-                    }
-                    lbound += WK_BATCH + 64;
-                    WK_BARRIER();
-                    w = s_w;
-                    const bool dn = s_done != 0;
-                    over = s_over != 0;
-                    WK_BARRIER();
-                    if (dn) break;
-                }
-                for (uint32_t i2 = tid; i2 < n; i2 += WK_THREADS) pool[i2] = 0;     // the area is bitmap again
-                WK_BARRIER();
-#ifdef MSIM_WALK_PROF
-                pr_pool += PR_NOW() - pr_a;
-#endif
-                continue;
-            }
-            // ---- set path
-            const bool use_g = HAS_BIG && n > WK_LDS_BITS;
-            const uint32_t sh = (uint32_t)__builtin_clz(n);                         // 32 - bit_length(n), n >= 1
-            uint32_t A = k, inserted = 0, acc_before = 0, wb = w;
-            bool first_batch = true, done = false;
-            while (!done) {
-                WK_REFILL(wb)
-#ifdef MSIM_WALK_PROF
-                pr_batches++;
-                const unsigned long long pr_b0 = PR_NOW();
-#endif
-                if (wb + WK_BATCH > W) { over = true; break; }                       // (window slack is far larger)
-                if (lbound + WK_BATCH > (uint32_t)WK_LIST) { WK_BARRIER(); WK_FLUSH(); }
-                uint32_t v[WK_ITEMS], myidx[WK_ITEMS];
-                unsigned long long bal[WK_ITEMS];         // wave-uniform accept ballots of this wave's four rows
-                uint32_t okm = 0, mine = 0;               // bit q: item q accepted / put a NEW value into the bitmap
-                uint32_t wsum_mine = 0;                   // accepted draws in this wave's segment
-#pragma unroll
-                for (int q = 0; q < WK_ITEMS; q++) v[q] = ring[(wb + wave * (64 * WK_ITEMS) + q * 64 + lane) & (WK_RING - 1)] >> sh;
-#pragma unroll
-                for (int q = 0; q < WK_ITEMS; q++) {
-                    const bool ok = v[q] < n;
-                    okm |= (ok ? 1u : 0u) << q;
-                    bal[q] = __ballot(ok);
-                    myidx[q] = wsum_mine + (uint32_t)__popcll(bal[q] & ((1ull << lane) - 1ull));
-                    wsum_mine += (uint32_t)__popcll(bal[q]);
-                }
-                if (lane == 0) wtot[dpar][wave] = wsum_mine;
-                WK_BARRIER();
-                // rank of every accepted draw in stream order: wave-major (a wave owns a contiguous segment)
-#ifdef MSIM_WALK_PROF
-                const unsigned long long pr_b1 = PR_NOW();
-#endif
-                uint32_t mybase = acc_before, avail = acc_before;                   // avail: accepted draws up to the end of this batch
-#pragma unroll
-                for (int ww = 0; ww < WK_WAVES; ww++) {
-                    const uint32_t t = wtot[dpar][ww];
-                    if ((uint32_t)ww < wave) mybase += t;
-                    avail += t;
-                }
-#pragma unroll
-                for (int q = 0; q < WK_ITEMS; q++) myidx[q] += mybase;
-                while (true) {
-                    const uint32_t lim = min(A, avail);
-#ifdef MSIM_WALK_PROF
-                    pr_inner++;
-#endif
-                    uint32_t old[WK_ITEMS];
-                    uint32_t act = 0;
-#pragma unroll
-                    for (int q = 0; q < WK_ITEMS; q++) {                            // all atomics in flight together
-                        old[q] = 0;
-                        if (((okm >> q) & 1u) && myidx[q] >= inserted && myidx[q] < lim) {
-                            act |= 1u << q;
-                            // (two address spaces, two instructions: a generic pointer would make this a FLAT atomic,
-                            // which goes through the vector-memory path even when it lands in LDS)
-                            if (HAS_BIG && use_g) old[q] = atomicOr(&gbm[v[q] >> 5], 1u << (v[q] & 31));
-                            else old[q] = atomicOr(&bm[v[q] >> 5], 1u << (v[q] & 31));
-                        }
-                    }
-                    uint32_t dl = 0;
-#pragma unroll
-                    for (int q = 0; q < WK_ITEMS; q++) {
-                        const bool dup = ((act >> q) & 1u) && ((old[q] >> (v[q] & 31)) & 1u);
-                        if (((act >> q) & 1u) && !dup) mine |= 1u << q;
-                        dl += (uint32_t)__popcll(__ballot(dup));                    // wave-uniform
-                    }
-                    if (lane == 0) dcnt[dpar][wave] = dl;
-                    WK_BARRIER();
-                    uint32_t dsum = 0;
-#pragma unroll
-                    for (int ww = 0; ww < WK_WAVES; ww++) dsum += dcnt[dpar][ww];
-                    dpar ^= 1;
-                    inserted = lim;
-                    A += dsum;
-                    if (dsum == 0 || inserted >= avail) break;
-                }
-#ifdef MSIM_WALK_PROF
-                const unsigned long long pr_b2 = PR_NOW();
-#endif
-                // the new values of this batch: range start + value, appended to the staging list (order is irrelevant;
-                // one LDS atomic per wave)
-                {
-                    uint32_t cntq[WK_ITEMS], tot = 0;
-                    unsigned long long nb[WK_ITEMS];
-#pragma unroll
-                    for (int q = 0; q < WK_ITEMS; q++) {
-                        nb[q] = __ballot((mine >> q) & 1u);
-                        cntq[q] = (uint32_t)__popcll(nb[q]);
-                        tot += cntq[q];
-                    }
-                    uint32_t at = 0;
-                    if (lane == 0 && tot) at = atomicAdd(&s_lcnt, tot);
-                    at = __builtin_amdgcn_readfirstlane(at);
-#pragma unroll
-                    for (int q = 0; q < WK_ITEMS; q++) {
-                        if ((mine >> q) & 1u) list[at + (uint32_t)__popcll(nb[q] & ((1ull << lane) - 1ull))] = R.start + v[q];
-                        at += cntq[q];
-                    }
-                    lbound += WK_BATCH;
-                }
-#ifdef MSIM_WALK_PROF
-                const unsigned long long pr_b3 = PR_NOW();
-                pr_p1 += pr_b1 - pr_b0; pr_p2 += pr_b2 - pr_b1; pr_p3 += pr_b3 - pr_b2;
-#endif
-                if (inserted == A) {                                                // distinct(first A) == k: the sample is complete
-                    // the word holding the A-th accepted draw: only the wave whose segment holds it looks
-                    const uint32_t tgt = A - 1;
-                    const uint32_t lo = mybase;
-                    if (tgt >= lo && tgt < lo + wsum_mine) {                        // wave-uniform
-                        uint32_t rem = tgt - lo, cut = 0;
-                        bool found = false;
-#pragma unroll
-                        for (int q = 0; q < WK_ITEMS; q++) {
-                            const uint32_t c = (uint32_t)__popcll(bal[q]);
-                            if (!found && rem < c) {
-                                cut = wb + wave * (64 * WK_ITEMS) + q * 64 + wk_nth_bit(bal[q], rem) + 1;
-                                found = true;
-                            }
-                            if (!found) rem -= c;
-                        }
-                        if (lane == 0) s_cut = cut;
-                    }
-                    if (first_batch && !use_g) {                                    // one batch: every lane clears what it set
-#pragma unroll
-                        for (int q = 0; q < WK_ITEMS; q++)
-                            if (mine & (1u << q)) bm[v[q] >> 5] = 0;
-                    }
-                    WK_BARRIER();
-                    w = s_cut;
-                    done = true;
-#ifdef MSIM_WALK_PROF
-                    pr_p4 += PR_NOW() - pr_b3;
-#endif
-                } else {
-                    acc_before = avail;
-                    wb += WK_BATCH;
-                    first_batch = false;
-                }
-            }
-            if (over) break;
-            if (!first_batch || use_g) {                                            // several batches: clear the whole bitmap
-                const uint32_t nwords = (n + 31) >> 5;
-                if (HAS_BIG && use_g) { for (uint32_t i = tid; i < nwords; i += WK_THREADS) gbm[i] = 0; __syncthreads(); }
-                else for (uint32_t i = tid; i < nwords; i += WK_THREADS) bm[i] = 0;
-            }
-            WK_BARRIER();                                                           // clears / appends before the next range touches them
-#ifdef MSIM_WALK_PROF
-            pr_set += PR_NOW() - pr_a;
-#endif
-        }
-    }
-    WK_BARRIER();
-    WK_FLUSH();
-#ifdef MSIM_WALK_PROF
-    if (tid == 0 && prof) {
-        atomicAdd(&prof[0], PR_NOW() - pr_t0); atomicAdd(&prof[1], wall_clock64() - pr_w0); atomicAdd(&prof[2], pr_pool);
-        atomicAdd(&prof[3], pr_set); atomicAdd(&prof[4], pr_batches); atomicAdd(&prof[5], pr_nref); atomicAdd(&prof[6], pr_ref);
-        atomicAdd(&prof[7], pr_inner); atomicAdd(&prof[8], (unsigned long long)n_ranges);
-        atomicAdd(&prof[9], pr_p1); atomicAdd(&prof[10], pr_p2); atomicAdd(&prof[11], pr_p3); atomicAdd(&prof[12], pr_p4);
-    }
-#endif
-#undef WK_REFILL
-#undef WK_FLUSH
-#undef WK_LOAD_QUARTER
-    if (tid == 0) {
-        if (over || s_over) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
-        ps->pos = p0 + w;
-        ps->snp_base = p0 + w;
-    }
-}
 
 // Host-cut contigs (ctx.h: cut_ranges_host): the host found where each range's sample starts in the word window;
 // every word of [0, consumed) looks up its range (cuts ascend strictly: a drawing range consumes at least one word),

@@ -55,7 +55,9 @@ class Timing(C.Structure):           # msim_timing
                 ("upload_ms", C.c_double), ("apply_ms", C.c_double),
                 ("apply_kernel_ms", C.c_double), ("apply_launches", C.c_uint64),
                 ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("records", C.c_uint64),
-                ("py_words", C.c_uint64), ("np_words", C.c_uint64)]
+                ("py_words", C.c_uint64), ("np_words", C.c_uint64),
+                ("contigs_snp", C.c_uint64), ("contigs_svmix", C.c_uint64), ("contigs_hostcut", C.c_uint64),
+                ("contigs_hostchain", C.c_uint64), ("contigs_host", C.c_uint64), ("contigs_batch", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -137,7 +139,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msim_abi_version() != 1:
+        if lib.msim_abi_version() != 2:
             raise MsimError("libmsim ABI version mismatch")
         _lib = lib
     return _lib

@@ -750,6 +750,39 @@ sn 0.004 in 0.001 inmin 1 inmax 30 de 0.001 demin 1 demax 80 du 0.0005 dumin 20 
 """
 
 
+def _rmt_gene_blocking_sv(lengths, seed, meta=("titv = 2.0",)):
+    """The same gene-blocking layout with an SV `std` line -- the mainstream RMT shape: every gap between two blocked
+    genes is a drawing range of the std settings -- plus hot ranges with their OWN SV settings (second settings object,
+    chances in token order), cold SNP-only ranges and 1 kb pool-path hot spots."""
+    rs = np.random.RandomState(seed)
+    out = list(meta) + ["", "std", "it None",
+                        "sn 0.005 in 0.001 inmin 1 inmax 50 de 0.001 demin 1 demax 50 du 0.0005 dumin 50 dumax 500 "
+                        "iv 0.0005 ivmin 50 ivmax 500", ""]
+    lines = ("None", "de 0.01 demin 1 demax 50 sn 0.03 du 0.002 dumin 50 dumax 500", "sn 0.001", "sn 0.2 in 0.01 inmin 1 inmax 50")
+    for ci, L in enumerate(lengths):
+        if L is None:
+            continue                                   # unlisted contig: std only
+        out.append(f"chr {ci + 1}")
+        n_blocks = max(4, L // 20_000)
+        kinds = rs.choice(4, size=n_blocks, p=[0.8, 0.08, 0.07, 0.05])
+        blen = np.minimum(np.exp(rs.normal(np.log(2500.0), 1.3, n_blocks)).astype(np.int64) + 30, 60_000)
+        blen[kinds == 3] = 1000
+        blen[kinds == 2] = rs.randint(20_000, 120_000, int((kinds == 2).sum()))
+        free = L - int(blen.sum()) - 2 * n_blocks - 500
+        while free < L // 3:
+            blen = np.maximum(blen // 2, 30)
+            free = L - int(blen.sum()) - 2 * n_blocks - 500
+        gaps = rs.dirichlet(np.ones(n_blocks + 1)) * free
+        at = 1
+        for b in range(n_blocks):
+            at += int(gaps[b]) + (2 if b % 7 else 0)   # every seventh block touches the range before it
+            a, e = at, at + int(blen[b]) - 1
+            out.append(f"{a}-{e} " + lines[kinds[b]])
+            at = e + 1
+        assert at < L
+    return "\n".join(out) + "\n"
+
+
 def make_cli_cases_scaffolds():
     """An assembly-like input: hundreds of small scaffolds (the batch path of the product, msim_batch_run), with a
     large contig in the middle so that the stream chain crosses batch -> device engine -> batch."""
@@ -785,6 +818,19 @@ def make_cli_cases_engines():
                         {"defline": "s2", "length": 700_011, "bpl": 70, "seed": 82}]}
     cli_case("rmt_svmix_blocks_3mb", spec, [], 11, 12, store="hash", rmt_text=RMT_SV_STD,
              notes="SV mix via the RMT std line, du/iv/de blocks 20/5/3 (SV-mix engine, 21 k + 4.9 k candidates)")
+    spec = {"contigs": [{"defline": "v1 gene blocking + SV std 3Mb", "length": 3_000_000, "bpl": 60, "seed": 91},
+                        {"defline": "v2 std only", "length": 600_000, "bpl": 80, "seed": 92},
+                        {"defline": "v3 dense blocks", "length": 500_000, "bpl": 60, "seed": 93}]}
+    cli_case("rmt_svstd_blocks_3mb", spec, [], 31, 32, store="hash",
+             rmt_text=_rmt_gene_blocking_sv([3_000_000, None, 500_000], 6),
+             notes="RMT gene blocking with an SV std line: ~170 drawing ranges of two SV settings objects, cold SNP ranges, "
+                   "pool-path hot spots with insertions, touching ranges (host-chain engine); an unlisted contig (SV-mix engine)")
+    spec = {"contigs": [{"defline": "w1 sn_block 3", "length": 1_500_000, "bpl": 60, "seed": 95},
+                        {"defline": "w2 std only", "length": 300_000, "bpl": 70, "seed": 96}]}
+    cli_case("rmt_snblock_svstd_1500k", spec, [], 33, 34, store="hash",
+             rmt_text=_rmt_gene_blocking_sv([1_500_000, None], 7, meta=("titv = 0.5", "sn_block = 3", "du_block = 9")),
+             notes="the same shape with sn_block 3 > min(block): kept SNPs block their successors, every candidate is on the "
+                   "boundary chain (host-chain engine, both contigs)")
 
 
 def make_reference_timing():

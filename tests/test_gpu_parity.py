@@ -68,10 +68,11 @@ print(json.dumps(dict(exc=repr(res["exception"]), code=res["exit_code"], fasta=s
 
 
 @pytest.mark.parametrize("name,nth", [("c1_snp_1mb", 1), ("svmix_1mb", 1), ("rmt_blocks_3mb", 1), ("rmt_blocks_3mb", 2),
-                                      ("rmt_svmix_blocks_3mb", 2)])
+                                      ("rmt_svmix_blocks_3mb", 2), ("rmt_svstd_blocks_3mb", 1),
+                                      ("rmt_snblock_svstd_1500k", 2)])
 def test_window_overflow_is_replanned_on_the_host(name, nth):
     """A device PLAN engine that reports a 16-sigma window overflow (forced here by the MSIM_DBG_FORCE_OVERFLOW test hook,
-    one case per engine: SNP sampler, SV mix, host-cut) must not cost the run: the host package puts the streams back and
+    one case per engine: SNP sampler, SV mix, host-cut, host-chain) must not cost the run: the host package puts the streams back and
     plans that contig with the sequential host planner -- the files still equal the reference's.  nth = 2: the overflow
     hits a later contig, so the streams are first advanced over the earlier ones again."""
     import json

@@ -126,10 +126,7 @@ def test_min_distance_three_vs_host():
 def test_ineligible_structures_are_refused_by_forced_gpu_mode():
     eng = _ffi.Engine(0, _ffi.PLAN_GPU)
     eng.seed(1, 1)
-    eng.set_params(_params({"SN": 2}))            # SNP block above the sampling distance
     cid = eng.add_contig_synthetic(1_000_000, 1)
-    with pytest.raises(_ffi.MsimUnsupported):
-        eng.plan_contig(cid, [_snp_range(0, 999_999, 10_000)])
     eng.set_params(_params())
     with pytest.raises(_ffi.MsimUnsupported):     # translocations -> host planner territory
         eng.plan_contig(cid, [_sv_range(0, 999_999, 8_000, {1: 0.5, 6: 0.5}, {6: (1, 20)})])
@@ -330,6 +327,142 @@ def test_sv_mix_contig_chain():
     assert hst["py_words"] == ast["py_words"] and hst["np_words"] == ast["np_words"]
     for (hm, hp), (am, ap) in zip(hs, as_):
         assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
+
+
+# ---------------------------------------------------------------------- host-chain engine (several settings per contig)
+# (samples AND boundary passes walked by the host in one go over device-made words, accept tables and candidate types;
+#  SNP filter with per-range reset, visit filter across range borders, records, pool and SNP draws on the device)
+def _gene_gaps(L, rs, n_blocks):
+    cuts = np.sort(rs.choice(np.arange(1, L - 1), size=2 * n_blocks, replace=False))
+    out, at = [], 0
+    for a, b in zip(cuts[0::2], cuts[1::2]):
+        if a - 1 > at:
+            out.append((at, int(a) - 1))
+        at = int(b) + 1
+    if at < L - 1:
+        out.append((at, L - 1))
+    return out
+
+
+def _rate_range(s, e, rate, chances, lens, order=None):
+    order = order or [t for t in ARGS_ORDER if t in chances]
+    return _sv_range(s, e, int(((e - s) + 1) * rate), chances, lens, order=order)
+
+
+@pytest.mark.parametrize("L,n_blocks,seed", [(3_000_000, 150, 1), (2_000_000, 600, 2), (6_000_000, 80, 3)])
+def test_gene_blocks_with_sv_std_vs_host(L, n_blocks, seed):
+    """The mainstream RMT shape: blocked genes, one SV `std` settings object in every gap."""
+    rs = np.random.RandomState(seed)
+    ranges = [_rate_range(s, e, 0.008, C3_CHANCES, C3_LENS) for s, e in _gene_gaps(L, rs, n_blocks)]
+    ranges = [r for r in ranges if r.k]
+    st = _compare([(L, ranges)], _params(titv=2.0), seed=(seed, seed + 5), host_chain=True)
+    assert st["contigs_hostchain"] == 1 and st["contigs_host"] == 0
+
+
+def test_host_chain_spans_cross_range_borders_vs_host():
+    """Touching ranges with long DE / DU / IV: spans of range i swallow candidates of range i+1 (and of i+2 across a tiny
+    range) -- they take part in their own boundary pass but are never visited (mutator.py:184, 376,386,398)."""
+    L = 1_500_000
+    ranges, at = [], 0
+    rs = np.random.RandomState(4)
+    while at < L - 10:
+        length = int(rs.choice([60, 300, 2_000, 9_000, 40_000]))
+        e = min(L - 1, at + length - 1)
+        ranges.append(_rate_range(at, e, 0.03, {1: 0.4, 3: 0.25, 4: 0.2, 5: 0.1, 2: 0.05},
+                                  {3: (200, 900), 4: (100, 700), 5: (50, 800), 2: (1, 9)}))
+        at = e + 1
+    ranges = [r for r in ranges if r.k]
+    _compare([(L, ranges)], _params(titv=1.0), seed=(9, 9), host_chain=True)
+
+
+def test_host_chain_hot_cold_own_lengths_pool_path_vs_host():
+    L = 2_400_000
+    blocks = {t: 2 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}
+    blocks["DE"] = 5
+    ranges = [
+        _rate_range(0, 399_999, 0.01, {1: 1.0}, {}),
+        _rate_range(400_000, 400_999, 0.2, {4: 0.1, 1: 0.8, 2: 0.1}, {4: (5, 8), 2: (1, 4)}, order=[4, 1, 2]),   # pool path
+        _rate_range(401_000, 999_999, 0.008, C3_CHANCES, C3_LENS),
+        _rate_range(1_000_000, 1_000_040, 0.1, {1: 0.5, 3: 0.5}, {3: (1, 50)}),                                # k = 4
+        _rate_range(1_000_100, 1_799_999, 0.02, {1: 0.3, 3: 0.3, 5: 0.4}, {3: (1, 50), 5: (50, 500)}, order=[5, 3, 1]),
+        _rate_range(1_800_000, 2_399_999, 0.004, {2: 1.0}, {2: (3, 3)}),                                      # width-1 randint
+    ]
+    assert (ranges[1].stop - (ranges[1].k - 1) * 2) - ranges[1].start <= ranges[1].setsize
+    st = _compare([(L, ranges)], _params(blocks, titv=0.5), seed=(21, 22), host_chain=True)
+    assert st["contigs_hostchain"] == 1
+
+
+@pytest.mark.parametrize("sn_block", [2, 7])
+def test_snp_block_above_sampling_distance_vs_host(sn_block):
+    """sn_block > min(block): SNPs block their successors, every candidate chains -- SNP-only contigs and single large
+    ranges included (the other device engines decline them)."""
+    L = 2_000_000
+    rs = np.random.RandomState(sn_block)
+    ranges = []
+    for s, e in _gene_gaps(L, rs, 60):
+        kind = rs.randint(0, 3)
+        if kind == 0:
+            ranges.append(_rate_range(s, e, 0.05, {1: 1.0}, {}))
+        elif kind == 1:
+            ranges.append(_rate_range(s, e, 0.3, {1: 0.9, 2: 0.1}, {2: (1, 4)}))
+        else:
+            ranges.append(_rate_range(s, e, 0.02, {1: 0.2, 3: 0.4, 5: 0.2, 4: 0.2}, {3: (3, 60), 5: (5, 90), 4: (4, 80)}))
+    ranges = [r for r in ranges if r.k and (r.stop - (r.k - 1)) - r.start >= r.k]
+    contigs = [(L, ranges), (1_000_000, [_snp_range(0, 999_999, 10_000)]),
+               (1_500_000, [_rate_range(0, 1_499_999, 0.008, C3_CHANCES, C3_LENS)])]
+    st = _compare(contigs, _params({"SN": sn_block}, titv=1.7), seed=(3, 4), host_chain=True)
+    assert st["contigs_hostchain"] == 3
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_host_chain_random_layouts_vs_host(case):
+    rs = np.random.RandomState(500 + case)
+    L = int(rs.randint(400_000, 4_000_000))
+    d = int(rs.choice([1, 1, 2, 4]))
+    blocks = {name: d + int(rs.choice([0, 0, 1, 5, 40])) for name in ("IN", "DE", "IV", "DU", "TL", "TLI")}
+    blocks["SN"] = d if rs.rand() < 0.7 else d + int(rs.randint(1, 4))
+    blocks[str(rs.choice(["IN", "DE", "IV", "DU"]))] = d
+    n_sets = int(rs.randint(1, 5))
+    widths = [(1, 1 + int(rs.choice([0, 3, 49, 450]))) for _ in range(2)]          # at most 4 randint classes in total
+    sets = []
+    for _ in range(n_sets):
+        types = [1] + [t for t in (2, 3, 4, 5) if rs.rand() < 0.6]
+        chances = {t: float(rs.uniform(0.05, 1.0)) for t in types}
+        lens = {}
+        for t in (2, 3, 4):
+            a, b = widths[int(rs.randint(0, 2))]
+            off = int(rs.randint(0, 30))
+            lens[t] = (a + off, b + off)
+        a, b = widths[int(rs.randint(0, 2))]
+        lens[5] = (a + 1, b + 1)
+        sets.append((chances, lens, [int(x) for x in rs.permutation(types)], float(rs.choice([0.002, 0.01, 0.03, 0.1]))))
+    ranges, at = [], int(rs.randint(0, 500))
+    while at < L - 50:
+        length = int(min(L - at, rs.choice([8, 30, 200, 2_000, 20_000, 150_000, 900_000])))
+        chances, lens, order, rate = sets[int(rs.randint(0, n_sets))]
+        r = _rate_range(at, at + length - 1, rate, chances, lens, order)
+        if r.k > 0 and (r.stop - (r.k - 1) * d) - r.start >= r.k:
+            ranges.append(r)
+        at += length + int(rs.choice([0, 0, 1, 50, 3_000]))
+    assert sum(r.k for r in ranges) >= 1024
+    _compare([(L, ranges)], _params(blocks, titv=float(rs.choice([0.0, 1.0, 2.0]))), seed=(case + 1, case + 11), host_chain=True)
+
+
+def test_host_chain_with_other_engines_along_one_stream():
+    rs = np.random.RandomState(6)
+    sv = lambda L, rate: _sv_range(0, L - 1, int(L * rate), C3_CHANCES, C3_LENS)
+    gaps = lambda L, n: [r for r in (_rate_range(s, e, 0.008, C3_CHANCES, C3_LENS) for s, e in _gene_gaps(L, rs, n)) if r.k]
+    contigs = [(2_000_000, gaps(2_000_000, 100)), (2_000_000, [_snp_range(0, 1_999_999, 20_000)]),
+               (1_500_000, [sv(1_500_000, 0.008)]), (1_000_000, _rmt_like_ranges(1_000_000, rs, 300, token_order=False)),
+               (900_000, gaps(900_000, 300)), (300_000, gaps(300_000, 10)), (700_000, _rmt_like_ranges(700_000, rs, 20))]
+    host, hs, hst = _run(_ffi.PLAN_HOST, contigs, _params(titv=2.0), (2, 3))
+    auto, as_, ast = _run(_ffi.PLAN_AUTO, contigs, _params(titv=2.0), (2, 3))
+    for (hr, he, hpool), (ar, ae, apool) in zip(host, auto):
+        assert he == ae and np.array_equal(hr.view(np.uint8), ar.view(np.uint8)) and np.array_equal(hpool, apool)
+    assert hst["py_words"] == ast["py_words"] and hst["np_words"] == ast["np_words"]
+    for (hm, hp), (am, ap) in zip(hs, as_):
+        assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
+    assert ast["contigs_hostchain"] >= 2 and ast["contigs_snp"] == 1 and ast["contigs_svmix"] == 1 and ast["contigs_hostcut"] == 2
 
 
 def test_full_size_sv_mix_gpu_vs_host_planner():
