@@ -13,6 +13,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -53,15 +55,17 @@ __attribute__((target("avx512f,bmi2,popcnt"))) size_t collect_accepted_avx512(co
         const __m512i v = _mm512_srl_epi32(_mm512_loadu_si512(words + w), shv);
         const __mmask16 m = _mm512_cmplt_epu32_mask(v, nv);
         const unsigned c = (unsigned)__builtin_popcount(m);
+        // (compress in the register + a full 16-lane store: the masked compress-STORE is microcoded on Zen 4; buf has
+        //  16 entries of slack behind `need`)
         if (got + c < need) {
-            _mm512_mask_compressstoreu_epi32(buf + got, m, v);
+            _mm512_storeu_si512(buf + got, _mm512_maskz_compress_epi32(m, v));
             got += c;
             w += 16;
         } else {                                         // the need-th accepted draw is in this block: cut there
             const unsigned r = (unsigned)(need - got);   // 1 <= r <= c
             const unsigned pos = (unsigned)__builtin_ctz(_pdep_u32(1u << (r - 1), (unsigned)m));
             const __mmask16 m2 = (__mmask16)(m & ((2u << pos) - 1u));
-            _mm512_mask_compressstoreu_epi32(buf + got, m2, v);
+            _mm512_storeu_si512(buf + got, _mm512_maskz_compress_epi32(m2, v));
             return w + pos + 1;
         }
     }
@@ -96,6 +100,37 @@ __attribute__((target("avx512f"))) void nonzero_words_avx512(const uint64_t *B, 
         if (B[wi]) f(wi);
 }
 #endif
+// indices of the non-zero 64-bit words of B[0 .. nw), ascending, into idx (room for nw + 16 entries); returns their number.
+// Branch-free per 8 words where AVX-512 is there: test -> 8-bit mask -> compress-store of the lane indices.
+inline size_t nonzero_index_scalar(const uint64_t *B, size_t nw, uint32_t *idx) {
+    size_t c = 0;
+    for (size_t wi = 0; wi < nw; wi++) { idx[c] = (uint32_t)wi; c += B[wi] != 0; }
+    return c;
+}
+#ifdef MSIM_X86_HOST
+__attribute__((target("avx512f,avx512vl,popcnt"))) size_t nonzero_index_avx512(const uint64_t *B, size_t nw, uint32_t *idx) {
+    size_t c = 0, wi = 0;
+    __m256i lane = _mm256_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7);
+    const __m256i step = _mm256_set1_epi32(8);
+    for (; wi + 8 <= nw; wi += 8) {
+        const __m512i v = _mm512_loadu_si512(B + wi);
+        const __mmask8 m = _mm512_test_epi64_mask(v, v);
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(idx + c), _mm256_maskz_compress_epi32(m, lane));   // (compress in the
+        c += (size_t)__builtin_popcount((unsigned)m);                    //  register: the store form is microcoded on Zen 4)
+        lane = _mm256_add_epi32(lane, step);
+    }
+    for (; wi < nw; wi++) { idx[c] = (uint32_t)wi; c += B[wi] != 0; }
+    return c;
+}
+#endif
+inline size_t nonzero_index(const uint64_t *B, size_t nw, uint32_t *idx) {
+#ifdef MSIM_X86_HOST
+    static const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+    if (wide) return nonzero_index_avx512(B, nw, idx);
+#endif
+    return nonzero_index_scalar(B, nw, idx);
+}
+
 template <class F>
 inline void for_each_nonzero_word(const uint64_t *B, size_t nw, F &f) {
 #ifdef MSIM_X86_HOST
@@ -496,10 +531,10 @@ int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, c
                 if (!more()) return overflow();
             w = w2;
             if (far) {
-                constexpr size_t AHEAD = 24;
-                for (size_t i = 0; i < std::min(AHEAD, need); i++) __builtin_prefetch(&B[buf[i] >> 6], 1, 0);
+                constexpr size_t AHEAD = 64;
+                for (size_t i = 0; i < std::min(AHEAD, need); i++) __builtin_prefetch(&B[buf[i] >> 6], 1, 3);
                 for (size_t i = 0; i < need; i++) {
-                    if (i + AHEAD < need) __builtin_prefetch(&B[buf[i + AHEAD] >> 6], 1, 0);
+                    if (i + AHEAD < need) __builtin_prefetch(&B[buf[i + AHEAD] >> 6], 1, 3);
                     const uint32_t v = buf[i];
                     const uint64_t m = 1ull << (v & 63);
                     const uint64_t x = B[v >> 6];
@@ -532,13 +567,23 @@ int cut_ranges_host(Ctx *c, const msim_range *ranges, int n_ranges, int64_t d, c
 // start + value + d * rank go to pos_out[0 .. k), *w_io advances by exactly the words CPython consumes.  `more`
 // is asked for further words when the window (words [0, *avail)) runs out; it returns false when none will come.
 // Returns 0, 1 (window exhausted) or -1 / -2 (the reference's ValueError / an unsupported size).
-template <class More>
+#ifdef MSIM_SAMPLE_PROF
+static unsigned long long g_sp[8];
+#define SP_T0() unsigned long long sp_t = __builtin_ia32_rdtsc()
+#define SP_LAP(i) do { const unsigned long long n_ = __builtin_ia32_rdtsc(); g_sp[i] += n_ - sp_t; sp_t = n_; } while (0)
+#else
+#define SP_T0() do {} while (0)
+#define SP_LAP(i) do {} while (0)
+#endif
+struct NoCutHook { void operator()(size_t) const {} };
+template <class More, class CutHook = NoCutHook>
 static inline int sample_one_range(const msim_range &r, int64_t d, const uint32_t *words, size_t *w_io, size_t *avail,
-                                   More &&more, uint32_t *pos_out) {
+                                   More &&more, uint32_t *pos_out, CutHook &&cut_known = CutHook()) {
     static thread_local std::vector<uint64_t> bits;                 // all zero between ranges (cleared while it is scanned)
     static thread_local std::vector<uint32_t> accbuf;               // accepted draws of one round
     static thread_local std::vector<uint32_t> pool, picked;
     size_t w = *w_io, at = 0;
+    SP_T0();
     const int64_t k = r.k;
     const int64_t n = (r.stop - (k - 1) * d) - r.start;              // util.py:104
     if (k < 0 || k > n) return -1;
@@ -560,9 +605,11 @@ static inline int sample_one_range(const msim_range &r, int64_t d, const uint32_
             picked.push_back(pool[(size_t)v]);
             pool[(size_t)v] = pool[(size_t)(n - i - 1)];
         }
+        cut_known(w);
         std::sort(picked.begin(), picked.end());
         for (int64_t i = 0; i < k; i++) pos_out[at++] = base + picked[(size_t)i] + dd * (uint32_t)i;
         *w_io = w;
+        SP_LAP(0);
         return 0;
     }
     const int sh = 32 - bit_length64((uint64_t)n);
@@ -570,84 +617,84 @@ static inline int sample_one_range(const msim_range &r, int64_t d, const uint32_
     if (bits.size() < nw + 1) bits.resize(nw + 1, 0);
     uint64_t *B = bits.data();
     int64_t got = 0;
-    if (nw <= 131072) {
-        // Bitmap in L1/L2 (up to 1 MB).  The data-dependent branches of the obvious loop (draw rejected? bitmap
-        // word empty?) mispredict about every second time, so the loop is split: accepted draws are collected
-        // in bulk without branches, inserted without branches, and the extraction finds the non-empty words
-        // eight at a time (AVX-512 test), writing three slots unconditionally per word.
+    {
+        // The data-dependent branches of the obvious loop (draw rejected? bitmap word empty?) mispredict about every
+        // second time, so the loop is split: accepted draws are collected in bulk without branches, inserted without
+        // branches (prefetched ahead when the bitmap is beyond L1), and the extraction runs over the list of non-empty
+        // words (found eight at a time), writing three slots unconditionally per word.
         const uint32_t nn = (uint32_t)n;
         // Rounds (the rule of the device sampler's tail): the next k - got accepted draws are consumed in any
         // case -- each adds at most one distinct value -- so they are collected in bulk (vectorised filter) and
         // only then meet the bitmap; the stream position stays exact.
-        if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + 32);
+        if (accbuf.size() < (size_t)k + 32) accbuf.resize((size_t)k + (size_t)k / 4 + 64);
         uint32_t *buf = accbuf.data();
+        const bool far = nw > 4096;                                  // bitmap beyond L1: prefetch ahead of the inserts
+        SP_LAP(1);
         while (got < k) {
             const size_t need = (size_t)(k - got);
             size_t w2;
             while ((w2 = collect_accepted(words, w, *avail, sh, nn, need, buf)) == SIZE_MAX)
                 if (!more()) return fail_clean();
             w = w2;
-            for (size_t i = 0; i < need; i++) {
-                const uint32_t v = buf[i];
-                const size_t wi = v >> 6;
-                const uint64_t m = 1ull << (v & 63);
-                const uint64_t x = B[wi];
-                got += (int64_t)!(x & m);
-                B[wi] = x | m;
+            SP_LAP(2);
+            if (far) {
+                constexpr size_t AHEAD = 64;
+                for (size_t i = 0; i < std::min(AHEAD, need); i++) __builtin_prefetch(&B[buf[i] >> 6], 1, 3);
+                for (size_t i = 0; i < need; i++) {
+                    if (i + AHEAD < need) __builtin_prefetch(&B[buf[i + AHEAD] >> 6], 1, 3);
+                    const uint32_t v = buf[i];
+                    const uint64_t m = 1ull << (v & 63);
+                    const uint64_t x = B[v >> 6];
+                    got += (int64_t)!(x & m);
+                    B[v >> 6] = x | m;
+                }
+            } else {
+                for (size_t i = 0; i < need; i++) {
+                    const uint32_t v = buf[i];
+                    const size_t wi = v >> 6;
+                    const uint64_t m = 1ull << (v & 63);
+                    const uint64_t x = B[wi];
+                    got += (int64_t)!(x & m);
+                    B[wi] = x | m;
+                }
             }
+            SP_LAP(3);
         }
-        uint32_t rank = 0;
-        auto emit_word = [&](size_t wi) {
+        cut_known(w);                                                // (the sample's end in the stream is fixed from here on)
+        // extraction in two passes, so that no branch depends on the bitmap's content: the non-empty words' indices first
+        // (8 words per step), then a loop of known length over them -- three slots written unconditionally per word
+        // (slots beyond its popcount are overwritten by the next word; words with more than three bits are rare)
+        static thread_local std::vector<uint32_t> nzidx;
+        if (nzidx.size() < nw + 16) nzidx.resize(nw + nw / 2 + 64);
+        uint32_t *idx = nzidx.data();
+        const size_t nz = nonzero_index(B, nw, idx);
+        SP_LAP(5);
+        // two slots per word unconditionally (a word holds one or two positions 97 % of the time at the reference's
+        // rates), the rest in a rarely taken branch; d * rank is carried along instead of multiplied
+        uint32_t drank = 0;
+        const size_t safe = (size_t)k >= 2 ? (size_t)k - 2 : 0;
+        for (size_t j = 0; j < nz; j++) {
+            if (far) __builtin_prefetch(&B[idx[j + 16]], 0, 3);       // (idx has slack behind nz)
+            const size_t wi = idx[j];
             uint64_t x = B[wi];
-            B[wi] = 0;
             const uint32_t cn = (uint32_t)__builtin_popcountll(x);
-            const uint32_t p0 = base + (uint32_t)(wi * 64) + dd * rank;
-            if (__builtin_expect(cn <= 3 && at + 3 <= (size_t)k, 1)) {   // slots beyond cn are overwritten by the next word
-                const uint64_t x1 = x & (x - 1), x2 = x1 & (x1 - 1), top = 1ull << 63;
-                pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x | top);
+            const uint32_t p0 = base + (uint32_t)(wi * 64) + drank;
+            if (__builtin_expect(cn <= 2 && at <= safe, 1)) {
+                const uint64_t x1 = x & (x - 1), top = 1ull << 63;
+                pos_out[at] = p0 + (uint32_t)__builtin_ctzll(x);
                 pos_out[at + 1] = p0 + dd + (uint32_t)__builtin_ctzll(x1 | top);
-                pos_out[at + 2] = p0 + 2 * dd + (uint32_t)__builtin_ctzll(x2 | top);
             } else {
                 uint32_t q = 0;
                 while (x) { pos_out[at + q] = p0 + dd * q + (uint32_t)__builtin_ctzll(x); q++; x &= x - 1; }
             }
             at += cn;
-            rank += cn;
-        };
-        for_each_nonzero_word(B, nw, emit_word);
+            drank += dd * cn;
+        }
+        memset(B, 0, nw * 8);                                        // (cheaper than a store per word inside the loop)
         *w_io = w;
+        SP_LAP(4);
         return 0;
     }
-    {                                                                // large bitmap: batch + prefetch (see sample_sorted)
-        uint32_t batch[64];
-        while (got < k) {
-            const int want = (int)std::min<int64_t>(64, k - got);
-            int nb = 0;
-            while (nb < want) {
-                while (w >= *avail) if (!more()) return fail_clean();
-                const uint64_t v = words[w++] >> sh;
-                if (v < (uint64_t)n) { batch[nb++] = (uint32_t)v; __builtin_prefetch(&B[v >> 6], 1, 0); }
-            }
-            for (int i = 0; i < nb; i++) {
-                uint64_t &x = B[batch[i] >> 6];
-                const uint64_t m = 1ull << (batch[i] & 63);
-                if (!(x & m)) { x |= m; got++; }
-            }
-        }
-    }
-    uint32_t rank = 0;
-    for (size_t wi = 0; wi < nw; wi++) {
-        uint64_t x = B[wi];
-        if (!x) continue;
-        B[wi] = 0;
-        while (x) {
-            pos_out[at++] = base + (uint32_t)(wi * 64 + (size_t)__builtin_ctzll(x)) + dd * rank;
-            rank++;
-            x &= x - 1;
-        }
-    }
-    *w_io = w;
-    return 0;
 }
 
 static int sample_one_error(Ctx *c, int code, const char *who) {
@@ -765,21 +812,34 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
     uint64_t base = 0;
     uint32_t vf = 0;                                                 // consumed_to + 1 of __mutate_sequence's walk
     int64_t bad_acc = 0;
+    static const bool prof = getenv("MSIM_WALK_PROF") != nullptr;
+    double t_sample = 0, t_gather = 0, t_chain = 0;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](double &acc) { if (prof) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::micro>(n - tp).count(); tp = n; } };
     for (int ri = 0; ri < n_ranges; ri++) {
         const msim_range &r = ranges[ri];
         if (r.k == 0) continue;
         const uint64_t k = (uint64_t)r.k;
-        const int code = sample_one_range(r, d, words, &w, &avail, more, cand_pos + base);
+        lap(t_chain);
+        const int code = sample_one_range(r, d, words, &w, &avail, more, cand_pos + base, [&](size_t w_end) {
+            // the boundary pass reads the tables from here on, in a burst of a few hundred bytes that the DMA engine wrote
+            // moments ago (nothing of it is in a cache) -- fetch it while the sample is being extracted
+            const char *t = reinterpret_cast<const char *>(T + (w_end << lg));
+            for (int q = 0; q < 8; q++) __builtin_prefetch(t + 64 * q, 0, 3);
+        });
         if (code) return rc_feed ? rc_feed : sample_one_error(c, code, "host chain");
+        lap(t_sample);
         size_t qb = qa;
         while (qb < n_ch && ch_rank[qb] < base + k) qb++;
         const size_t m = qb - qa;
         if (pbuf.size() < m + 8) pbuf.resize(m + m / 2 + 64);
         uint32_t *pb = pbuf.data();
         for (size_t x = 0; x < m; x++) pb[x] = cand_pos[ch_rank[qa + x]];
-        const ChainWalk &pw = proto[ms.set_of[di]];
+        lap(t_gather);
+        ChainWalk &pw = proto[ms.set_of[di]];
         if (m && !ms.sn_chained) {
-            ChainWalk cw = pw;
+            ChainWalk &cw = pw;                                      // (the set's walker: only its position is per range)
+            cw.j = 0; cw.blk_hi = 0; cw.bad = 0;                     // last_mut_range = range(0), per range (mutator.py:184)
             cw.ws = w << lg;
             for (;;) {
                 cw.run(pb, ch_type + qa, m, T, t_lim(), ch_stop + qa);
@@ -819,6 +879,11 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
         di++;
     }
     if (bad_acc < 0) return overflow();
+    lap(t_chain);
+    if (prof) fprintf(stderr, "walk: K %llu chain %zu ranges %zu | sample %.0f gather %.0f chain+visit %.0f us\n", (unsigned long long)ms.K, n_ch, di, t_sample, t_gather, t_chain);
+#ifdef MSIM_SAMPLE_PROF
+    if (prof) { fprintf(stderr, "  sample cycles: pool %llu setup %llu collect %llu insert %llu nzidx %llu extract %llu\n", g_sp[0], g_sp[1], g_sp[2], g_sp[3], g_sp[5], g_sp[4]); memset(g_sp, 0, sizeof g_sp); }
+#endif
     *consumed = w;
     c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return MSIM_OK;
