@@ -261,6 +261,21 @@ class Oracle:
         vcf = C.string_at(p, n.value) if n.value else b""
         return fa, vcf
 
+    def mutate_contig_stream(self, bases: np.ndarray, name: str, long_name: str, lenc: int, ranges: list):
+        """One iteration of mutate()'s contig loop (mutator.py:111-141) with the outputs cleared first: returns
+        (fasta text of this contig incl. its header line, its VCF record lines, had_mutations).  The RNG streams
+        continue across calls like the reference's; memory stays at one contig (full-size parity tests)."""
+        self.L.orc_clear_outputs(self.h)
+        rs = [r for r in (range_from_dump(rd) for rd in ranges) if r is not None]
+        arr = (OrcRange * max(len(rs), 1))(*rs)
+        had = C.c_int()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        rc = self.L.orc_mutate_contig(self.h, bases.ctypes.data, len(bases), name.encode(), long_name.encode(), lenc,
+                                      arr, len(rs), None, None, C.byref(had))
+        self._raise(rc)
+        fa, vcf = self.outputs()
+        return fa, vcf, bool(had.value)
+
     def run_genome(self, contigs, sim: dict, infile_name: str, date: str = "MASKED",
                    keep_records: bool = False):
         """Whole ``Mutator.__init__`` + ``mutate()`` (mutator.py:79-142).

@@ -112,6 +112,90 @@ def test_config4_rmt_240mb_vs_oracle(tmp_path):
     _engine_vs_oracle(lengths, None, tmp_path, sim=sim)
 
 
+def test_config4_fixture_scaled_vs_oracle(tmp_path):
+    """The REAL configs[3] workload -- the interval-merged Homo sapiens blocks of tests/golden/c4_blocks.npz -- cut down to
+    its first contigs' first 120 / 90 Mb: complete Fasta + VCF bytes against the oracle."""
+    z = np.load(bench.C4_FIXTURE)
+    lengths = [120_000_000, 90_000_000]
+    what = ("None", "sn 0.05", "sn 0.001", "sn 0.2")
+    out = ["std", "it None", "sn 0.01", ""]
+    for ci, L in enumerate(lengths):
+        out.append(f"chr {ci + 1}")
+        for a, e, k in zip(z[f"s{ci}"].tolist(), z[f"e{ci}"].tolist(), z[f"k{ci}"].tolist()):
+            if e < L:
+                out.append(f"{a}-{e} {what[k]}")
+    sim = bench.workload_settings_rmt(lengths, "\n".join(out) + "\n")
+    assert sum(len(mm.plan_descriptors(ch)) for ch in sim.chromosomes) > 1500
+    _engine_vs_oracle(lengths, None, tmp_path, sim=sim)
+
+
+# ---------------------------------------------------------------------- BASELINE configs at 3 Gb, straight against the oracle
+def _full_genome_vs_oracle(workload, engines):
+    """Every contig of the 3 Gb bench genome through PLAN + APPLY + device text, compared per contig with the ORACLE's
+    Fasta body and VCF lines (SHA-256; memory stays at one contig).  The oracle walks both MT19937 streams sequentially
+    across all 24 contigs, so one wrong stream cut anywhere shows up in every later contig."""
+    import hashlib
+    lengths = bench.contig_lengths(3_000_000_000)
+    sim = bench.build_settings(workload, lengths)
+    dump = dump_sim(sim)
+    eng = _ffi.Engine(0)
+    eng.seed(42, 42)
+    eng.set_params(mm.params_descriptor(sim))
+    o = orc.Oracle()
+    o.seed(42, 42)
+    o.configure(dump)
+    by_number = {ch["number"]: ch for ch in dump["chromosomes"]}
+    for chrom in sim.chromosomes:
+        L = lengths[chrom.number]
+        name = f"chr{chrom.number + 1}"
+        cid = eng.add_contig_synthetic(L, 1000 + chrom.number)
+        eng.plan_contig(cid, mm.plan_descriptors(chrom))
+        eng.apply_contig(cid)
+        text = eng.fetch_sequence_framed(cid, 60, guess_len=L)
+        _, n_rec, _ = eng.result_sizes(cid, applied=False)
+        vcf = eng.render_vcf_device(cid, name, guess=n_rec * 48 + 256)
+        bases = eng.read_contig(cid)
+        eng.clear()
+        want_fa, want_vcf, _ = o.mutate_contig_stream(bases, name, f"{name} synthetic", 60, by_number[chrom.number]["ranges"])
+        head = len(f">{name} synthetic\n")
+        assert hashlib.sha256(memoryview(want_fa)[head:]).digest() == hashlib.sha256(text).digest(), f"Fasta body of {name}"
+        assert hashlib.sha256(want_vcf).digest() == hashlib.sha256(vcf).digest(), f"VCF lines of {name}"
+        del bases, text, vcf, want_fa, want_vcf
+    st = eng.stats()
+    assert {k: v for k, v in st.items() if k.startswith("contigs_") and v} == engines
+    # both generators end where the oracle's do
+    for stream in (0, 1):
+        mt, pos = eng.get_mt_state(stream)
+        import random
+        r = random.Random()
+        r.setstate((3, tuple(int(x) for x in mt) + (int(pos),), None))
+        omt, opos = o.get_state(stream)
+        q = random.Random()
+        q.setstate((3, tuple(omt) + (opos,), None))
+        assert [r.getrandbits(32) for _ in range(8)] == [q.getrandbits(32) for _ in range(8)]
+    eng.close()
+
+
+def test_config2_full_genome_vs_oracle():
+    """BASELINE configs[1] at full size: 3 Gb, 30 M SNPs, titv 2 (SNP sampler engine)."""
+    _full_genome_vs_oracle("c2", {"contigs_snp": 24})
+
+
+def test_config3_full_genome_vs_oracle():
+    """BASELINE configs[2] at full size: the full SV mix, all 24 contigs planned AND applied (SV-mix engine)."""
+    _full_genome_vs_oracle("c3", {"contigs_svmix": 24})
+
+
+def test_config4_full_genome_vs_oracle():
+    """BASELINE configs[3] at full size with the real fixture: 34 k drawing ranges, pool-path hot spots (host-cut engine)."""
+    _full_genome_vs_oracle("c4", {"contigs_hostcut": 24})
+
+
+def test_config4sv_full_genome_vs_oracle():
+    """The configs[3] file with the configs[2] SV mix as its std line (host-chain engine)."""
+    _full_genome_vs_oracle("c4sv", {"contigs_hostchain": 24})
+
+
 def test_config3_full_genome_length_identity():
     """Full SV mix on 3 Gb: L_out = L + sum(ins) + sum(dup) - sum(del) per contig, from the records."""
     lengths = bench.contig_lengths(3_000_000_000)
