@@ -159,12 +159,13 @@ def workload_settings_rmt(lengths, rmt_text: str):
         os.unlink(path)
 
 
-def one_step(eng, sim, cids, my_contigs, seed=42, plan_descriptors=None):
-    """PLAN every contig in order (the RNG streams chain across contigs), APPLY this rank's."""
+def one_step(eng, sim, cids, my_contigs, seed=42, plan_descriptors=None, lengths=None):
+    """Walk the chain of both RNG streams over every contig in order; PLAN with emission + APPLY this rank's contigs
+    (`lengths` given: the others through msim_plan_chain -- stream positions only)."""
     from mutation_simulator_amd import mutator as mm
     from mutation_simulator_amd.sharding import run_sharded_pass
     eng.seed(seed, seed)
-    run_sharded_pass(eng, sim, cids, my_contigs, plan_descriptors or mm.plan_descriptors)
+    run_sharded_pass(eng, sim, cids, my_contigs, plan_descriptors or mm.plan_descriptors, lengths=lengths)
     eng.sync()
 
 
@@ -371,7 +372,7 @@ def main():
         eng.set_params(mm.params_descriptor(sim))
 
         def step():
-            one_step(eng, sim, cids, owned, step_seed, plan_descs)
+            one_step(eng, sim, cids, owned, step_seed, plan_descs, lengths if len(owned) < len(lengths) else None)
             if gather:
                 comm.gather_to_root(cids, parts)
 
@@ -426,6 +427,19 @@ def main():
             line["weak_replicas"] = {"value": round(sum(lengths) * world * a.steps / dtw / 1e6, 3), "unit": "Mbases/s",
                                      "ms_per_step": round(dtw / a.steps * 1e3, 3), "scaling": "weak",
                                      "what": f"{world} independent replicas, one whole genome per GPU, streams seeded 42+rank"}
+    # What N GPUs can give ONE genome (strong scaling): the chain of both MT19937 streams runs over every contig on every
+    # rank whatever N is; only emission + APPLY of the owned contigs shrink.  Measured, not modelled: a step that owns
+    # nothing (msim_plan_chain for all 24 contigs) against the full step.
+    dtc, _ = measure(a.workload, a.steps, 1, owned=[], step_seed=42)
+    dtf = dt
+    if strong:
+        dtf, _ = measure(a.workload, a.steps, 1, owned=list(range(len(lengths))), step_seed=42)
+    if rank == 0:
+        line["amdahl_ceiling"] = {"value": round(dtf / dtc, 3), "chain_only_ms_per_step": round(dtc / a.steps * 1e3, 3),
+                                  "full_step_ms": round(dtf / a.steps * 1e3, 3),
+                                  "what": "upper bound of the strong-scaling speed-up of one genome over N GPUs: full 1-GPU step / "
+                                          "step of a rank that owns no contig (stream chain only); N independent genomes "
+                                          "(weak_replicas / --scaling weak) scale linearly instead"}
     if world == 1 and not a.no_secondary and a.workload == "c2":
         # BASELINE configs[2] and [3] on the same resident genome: 5 steps each after 2 warm-up steps (the first steps of a
         # workload still grow scratch buffers), same definition of a step

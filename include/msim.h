@@ -162,6 +162,10 @@ int msim_set_params(msim_ctx *ctx, const msim_params *params);
  * leaves the contig's record table (+ insert pool) in HBM.  Contigs must be planned in index order
  * -- the streams are chained across contigs.                                                       */
 int msim_plan_contig(msim_ctx *ctx, int contig, const msim_range *ranges, int n_ranges);
+/* The same iteration for a contig this process does NOT mutate (multi-GPU runs: a rank that does not own a contig):
+ * both streams advance exactly as msim_plan_contig on a contig of `len` bases would leave them -- the chain across
+ * contigs stays intact -- but no record table, insert pool or SNP outcome is produced and no contig is created.   */
+int msim_plan_chain(msim_ctx *ctx, uint64_t len, const msim_range *ranges, int n_ranges);
 /* 1 if the last plan of this contig left `muts` empty (warning at mutator.py:125-129).             */
 int msim_plan_was_empty(msim_ctx *ctx, int contig, int *empty);
 

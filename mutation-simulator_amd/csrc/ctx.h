@@ -51,6 +51,7 @@ struct Batch;                         // msim_api.hip: state of msim_batch_run
 struct Ctx {
     int device = 0;
     bool host_only = false;           // msim_create(-1): PLAN + text rendering only, no GPU touched
+    bool chain_only = false;          // msim_plan_chain in progress: engines advance the streams and emit nothing
     uint32_t flags = 0;
     hipStream_t stream = nullptr;         // plan chain, uploads
     hipStream_t emit_stream = nullptr;    // record emission + APPLY (overlaps the next contig's chain)

@@ -425,14 +425,11 @@ int msim_set_plan_mode(msim_ctx *p, uint32_t mode) {
     return MSIM_OK;
 }
 
-int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ranges) {
-    Ctx *c = C(p);
-    if (!c || n_ranges < 0 || (n_ranges && !ranges)) return MSIM_ERR_ARG;
-    Contig *g = get_contig(c, contig);
-    if (!g) return MSIM_ERR_ARG;
-    if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
+// One iteration of mutate()'s contig loop up to the rewrite, for contig `g` (id `contig`; chain only: a length-only stand-in,
+// id -1): picks the PLAN engine, keeps the streams chained.
+static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges, int n_ranges) {
     int rc = MSIM_OK;
-    TraceRange tr("msim PLAN contig");
+    TraceRange tr(c->chain_only ? "msim PLAN contig (chain only)" : "msim PLAN contig");
     const bool dev = !c->host_only && c->gpu && !(c->flags & MSIM_PLAN_HOST);
     const bool gpu_ok = dev && gpu_plan_eligible(c, ranges, n_ranges);
     const bool mixed_ok = dev && !gpu_ok && gpu_plan_mixed_eligible(c, ranges, n_ranges);
@@ -459,14 +456,16 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
             else if (hs_ok) rc = plan_contig_gpu_hostsample(c, c->gpu, *g, ranges, n_ranges);
             else rc = plan_contig_gpu_multimix(c, c->gpu, *g, ranges, n_ranges);
         }
-        if (!rc) (gpu_ok ? c->t.contigs_snp : mixed_ok ? c->t.contigs_svmix : hs_ok ? c->t.contigs_hostcut : c->t.contigs_hostchain)++;
+        if (!rc && !c->chain_only)
+            (gpu_ok ? c->t.contigs_snp : mixed_ok ? c->t.contigs_svmix : hs_ok ? c->t.contigs_hostcut : c->t.contigs_hostchain)++;
         // test hook: MSIM_DBG_FORCE_OVERFLOW=n raises the window-overflow flag behind the n-th device-planned contig of
         // the process (1-based), so that the callers' recovery (mutator.py: re-plan through the host planner) can be tested
         static const int force_at = getenv("MSIM_DBG_FORCE_OVERFLOW") ? atoi(getenv("MSIM_DBG_FORCE_OVERFLOW")) : 0;
         static int device_plans = 0;
         if (!rc && force_at && ++device_plans == force_at) rc = gpu_plan_force_overflow(c, c->gpu);
         const int frc = flush_deferred_apply(c);           // (an engine that returned early never reached its flush point)
-        g->defer_apply = !rc && host_chain;
+        g->defer_apply = !rc && host_chain && !c->chain_only;
+        if (c->chain_only) g->planned = false;              // nothing to apply or fetch
         return rc ? rc : frc;
     }
     if (c->gpu) {                      // the host planner continues from wherever the device streams stand
@@ -481,9 +480,10 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     const uint64_t w_py = c->py.words, w_np = c->np.words;
     rc = plan_contig_host(c, g->len, ranges, n_ranges, hp);
     if (rc) return rc;
-    c->t.contigs_host++;
     c->t.py_words += c->py.words - w_py;
     c->t.np_words += c->np.words - w_np;
+    if (c->chain_only) return MSIM_OK;                     // the streams have advanced: that is all
+    c->t.contigs_host++;
     const auto t0 = std::chrono::steady_clock::now();
     g->n_rec = hp.recs.size();
     g->pool_len = hp.pool.size();
@@ -510,6 +510,28 @@ int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ra
     c->t.upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     g->planned = true;
     return MSIM_OK;
+}
+
+int msim_plan_contig(msim_ctx *p, int contig, const msim_range *ranges, int n_ranges) {
+    Ctx *c = C(p);
+    if (!c || n_ranges < 0 || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
+    return plan_dispatch(c, g, contig, ranges, n_ranges);
+}
+
+int msim_plan_chain(msim_ctx *p, uint64_t len, const msim_range *ranges, int n_ranges) {
+    Ctx *c = C(p);
+    if (!c || n_ranges < 0 || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
+    if (len >= (1ull << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "contig of 4 GiB or more (multi-word getrandbits)");
+    Contig stand_in;                                       // a length, nothing else: no bases, no tables
+    stand_in.len = len;
+    c->chain_only = true;
+    const int rc = plan_dispatch(c, &stand_in, -1, ranges, n_ranges);
+    c->chain_only = false;
+    return rc;
 }
 
 int msim_plan_was_empty(msim_ctx *p, int contig, int *empty) {
@@ -651,9 +673,9 @@ int msim_planned_out_len(msim_ctx *p, int contig, uint64_t *out_len, int *known)
     if (!c || !out_len || !known) return MSIM_ERR_ARG;
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
-    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
     *known = 0;
     *out_len = 0;
+    if (!g->planned) return MSIM_OK;                       // (a contig this rank only walked the chain for: its owner knows)
     if (g->all_snp || g->n_rec == 0) { *known = 1; *out_len = g->len; }
     else if (g->delta_known) { *known = 1; *out_len = (uint64_t)((long long)g->len + g->known_delta); }
     return MSIM_OK;

@@ -645,14 +645,16 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
     hipLaunchKernelGGL(k_snp_scan_cut_abs, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
                        (unsigned long long)P.ti_lim, py.d_maps, T.maps, nb2, (uint32_t)K, T.base);
     MSIM_HIP(c, hipGetLastError());
-    hipEvent_t ce = next_chain_event(g);
-    MSIM_HIP(c, hipEventRecord(ce, c->stream));
-    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-    hipLaunchKernelGGL(k_snp_emit_abs, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                       (unsigned long long)P.ti_lim, T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index);
-    MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
-    T.pending = true;
+    if (!c->chain_only) {                                 // (chain only: where the draws END is all that is wanted)
+        hipEvent_t ce = next_chain_event(g);
+        MSIM_HIP(c, hipEventRecord(ce, c->stream));
+        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+        hipLaunchKernelGGL(k_snp_emit_abs, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
+                           (unsigned long long)P.ti_lim, T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+        T.pending = true;
+    }
     pos_hi += W2;
     return MSIM_OK;
 }
@@ -673,7 +675,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     for (int i = 0; i < n_ranges; i++) K += (uint64_t)ranges[i].k;
     if (K >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "more than 2^31 mutations on one contig");
     bool grew = false;
-    {   // the record table may still be read by an earlier apply of this contig
+    if (!c->chain_only) {   // the record table may still be read by an earlier apply of this contig
         const size_t want = std::max<uint64_t>(K, 1) * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
@@ -704,19 +706,21 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if ((rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl))) return rc;
         SampleSet &S = *sl.S;
         const uint32_t W = sl.W, bmw = sl.bmw, bnb = sl.bnb;
-        hipEvent_t ce = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce, c->stream));
-        // ---- emit (emit stream): the bitmap is the sorted sample -> records
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-        hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
-                           reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, S.cnt2, bnb);
-        hipLaunchKernelGGL(k_bitmap_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
-                           reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
-                           ct.d_recs + rec_base);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
-        S.pending = true;
+        if (!c->chain_only) {
+            hipEvent_t ce = next_chain_event(g);
+            MSIM_HIP(c, hipEventRecord(ce, c->stream));
+            // ---- emit (emit stream): the bitmap is the sorted sample -> records
+            MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
+            hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                               reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2);
+            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, S.cnt2, bnb);
+            hipLaunchKernelGGL(k_bitmap_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                               reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
+                               ct.d_recs + rec_base);
+            MSIM_HIP(c, hipGetLastError());
+            MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
+            S.pending = true;
+        }
         pos_hi += W;
         rec_base += k;
     }
@@ -893,7 +897,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     const uint32_t n_rec = h.n_rec, n_sn = h.n_sn, pool_len = h.pool_len;
 
     // ---- 4. records, insert pool, SNP draws
-    {   // the record table / pool may still be read by an earlier apply of this contig
+    if (!c->chain_only) {   // the record table / pool may still be read by an earlier apply of this contig
         const size_t want = std::max<uint64_t>(n_rec, 1) * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < pool_len + 2 * PAD) {
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
@@ -913,12 +917,14 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     hipEvent_t ce = next_chain_event(g);
     MSIM_HIP(c, hipEventRecord(ce, c->stream));
     MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-    hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
-                       cnt_keep, cnt_sn, cnt_ins, ct.d_recs, M.sn_index);
-    if (pool_len)
-        hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
-                           (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
-    MSIM_HIP(c, hipGetLastError());
+    if (!c->chain_only) {
+        hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
+                           cnt_keep, cnt_sn, cnt_ins, ct.d_recs, M.sn_index);
+        if (pool_len)
+            hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
+                               (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
+        MSIM_HIP(c, hipGetLastError());
+    }
     np.pos += pool_len;
     c->t.np_words += pool_len;
     if (n_sn) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
@@ -1226,7 +1232,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
         }
     }
     if ((rc = grow(c, (void **)&M.wcnt, &M.cap_wcnt, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
-    {   // the record table may still be read by an earlier apply of this contig
+    if (!c->chain_only) {   // the record table may still be read by an earlier apply of this contig
         const size_t want = (size_t)K * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
@@ -1288,8 +1294,8 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     MSIM_HIP(c, hipMemcpyAsync(M.cand_pos, g->h_npos, ((size_t)n_draw + 1 + n_pool_pos) * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_advance_pos_save, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)consumed, M.p0_slot);
     MSIM_HIP(c, hipGetLastError());
-    {   // records on the emit stream (ordered after any earlier APPLY that still reads this contig's table): the words of
-        // every range -> contig-wide bitmap -> sorted sample -> records
+    if (!c->chain_only) {   // records on the emit stream (ordered after any earlier APPLY that still reads this contig's table): the
+        // words of every range -> contig-wide bitmap -> sorted sample -> records
         hipEvent_t ce0 = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(ce0, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce0, 0));

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("msim_clear", C.c_int, [_VP]),
     ("msim_set_params", C.c_int, [_VP, C.POINTER(Params)]),
     ("msim_plan_contig", C.c_int, [_VP, C.c_int, C.POINTER(Range), C.c_int]),
+    ("msim_plan_chain", C.c_int, [_VP, C.c_uint64, C.POINTER(Range), C.c_int]),
     ("msim_plan_was_empty", C.c_int, [_VP, C.c_int, _IP]),
     ("msim_apply_contig", C.c_int, [_VP, C.c_int]),
     ("msim_key_error", C.c_int, [_VP, C.c_int, _U8P, _U64P]),
@@ -275,7 +276,12 @@ class Engine:
 
     def plan_contig(self, contig: int, ranges):
         arr = ranges if isinstance(ranges, C.Array) else self.range_table(ranges)
-        self._check(self.lib.msim_plan_contig(self.h, contig, arr, arr.n_ranges), contig)
+        self._check(self.lib.msim_plan_contig(self.h, contig, arr, getattr(arr, "n_ranges", len(arr))), contig)
+
+    def plan_chain(self, length: int, ranges):
+        """Advance both streams over a contig this process does not mutate (multi-GPU: a rank that does not own it)."""
+        arr = ranges if isinstance(ranges, C.Array) else self.range_table(ranges)
+        self._check(self.lib.msim_plan_chain(self.h, length, arr, getattr(arr, "n_ranges", len(arr))))
 
     def set_plan_mode(self, mode: int):
         """0 = AUTO, PLAN_HOST = force the sequential host planner, PLAN_GPU = force a device engine."""

@@ -66,6 +66,9 @@ def build_parser() -> ArgumentParser:
                         help="Seed both random streams (random.seed(S); numpy.random.seed(S)) "
                              "for reproducible output")
     parser.add_argument("--device", type=int, default=0, help="GPU ordinal to run on")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="Shard the contigs over this many GPUs of the node (one worker process per GPU; output is "
+                             "byte-identical to a 1-GPU run). Default = 1")
     parser.add_argument("--bench-json", type=Path, default=None,
                         help="Write per-stage timings of the mutation pass to this JSON file")
 

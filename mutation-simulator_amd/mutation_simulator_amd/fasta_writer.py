@@ -69,6 +69,35 @@ class FastaWriter:
         self._bpl = bpl
         self._written = int(last_line_bases)
 
+    def begin_segment(self):
+        """Multi-GPU workers write the records they own into a part file of their own: a segment starts as if at the
+        beginning of a file (no newline owed to whatever precedes it there); ``append_segment`` of the assembling
+        process restores the rule between segments."""
+        self._written = 0
+
+    def tell(self) -> int:
+        self._out.flush()
+        return self._out.tell()
+
+    def append_segment(self, src, offset: int, nbytes: int):
+        """Append bytes [offset, offset + nbytes) of the open binary file ``src`` -- complete records written by another
+        writer after ``begin_segment`` -- keeping the reference's newline rule: a record that ended mid-line is followed
+        by a newline before the next header (fasta_writer.py:40-47)."""
+        if nbytes <= 0:
+            return
+        if self._written != 0:
+            self._out.write(b"\n")
+        src.seek(offset)
+        left, last = nbytes, b"\n"
+        while left:
+            chunk = src.read(min(left, 64 << 20))
+            if not chunk:
+                raise FastaWriterError("segment file shorter than its index says")
+            self._out.write(chunk)
+            last = chunk[-1:]
+            left -= len(chunk)
+        self._written = 0 if last == b"\n" else 1          # (only zero / non-zero matters before a header)
+
     def write_array(self, bases: np.ndarray):
         """Append ``bases`` (uint8) wrapped at the current line width."""
         n = int(bases.shape[0])

@@ -35,9 +35,20 @@ class Communicator:
         self.eng, self.rank, self.world, self.dist = engine, rank, world, dist
         self.live = False
         if world > 1:
-            box = [_ffi.comm_unique_id() if rank == 0 else None]
+            # rank 0 ALWAYS takes part in the broadcast: if it cannot produce the id (no librccl, dlopen failure) it
+            # broadcasts the reason instead, so that every rank raises the same error before any later collective --
+            # leaving the broadcast on one rank only would hang the others until the control plane times out
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [("id", _ffi.comm_unique_id())]
+                except Exception as e:  # noqa: BLE001
+                    box = [("error", f"{type(e).__name__}: {e}")]
             dist.broadcast_object_list(box, src=0)
-            engine.comm_init(box[0], rank, world)
+            kind, payload = box[0]
+            if kind == "error":
+                raise _ffi.MsimError(f"rank 0 could not open an RCCL communicator: {payload}")
+            engine.comm_init(payload, rank, world)
             self.live = True
 
     def describe(self) -> str:

@@ -260,7 +260,42 @@ class Mutator:
         self._vcf_writer.write_raw(vcf)
         eng.clear()
 
+    def _units(self, chroms):
+        """mutate()'s contig loop (mutator.py:111-141) cut into units of work: a run of >= 2 small contigs (ONE pass through
+        libmsim, msim_batch_run) or a single contig.  Units are also what a multi-GPU run shards (multi_gpu.py)."""
+        out, i = [], 0
+        while i < len(chroms):
+            j, total = i, 0
+            while (j < len(chroms) and j - i < BATCH_MAX_CONTIGS and self._batchable(chroms[j])
+                   and total + len(self._fasta[chroms[j].number]) <= BATCH_MAX_BASES):
+                total += len(self._fasta[chroms[j].number])
+                j += 1
+            if j - i >= 2:
+                out.append((i, j))
+                i = j
+            else:
+                out.append((i, i + 1))
+                i += 1
+        return out
+
+    def _process_unit(self, eng, chroms, i, j):
+        """A KeyError / ValueError inside a batch is replayed contig by contig (once: no re-batching behind the contig that
+        raised), so that the files hold exactly what the reference had written by then."""
+        if j - i >= 2:
+            saved = (eng.get_mt_state(0), eng.get_mt_state(1))
+            try:
+                self._mutate_batch(eng, chroms[i:j])
+                return
+            except (KeyError, ValueError):
+                eng.set_mt_state(0, *saved[0])
+                eng.set_mt_state(1, *saved[1])
+        for k in range(i, j):
+            self._mutate_one(eng, chroms[k], earlier=chroms[:k])
+
     def mutate(self):
+        if int(getattr(self._args, "gpus", 1) or 1) > 1 and self._engine is None:
+            from .multi_gpu import mutate_sharded      # one worker process per GPU, spawned before any GPU call here
+            return mutate_sharded(self)
         if self._engine is None:
             self._engine = _ffi.Engine(getattr(self._args, "device", 0) or 0)
         eng = self._engine
@@ -269,27 +304,8 @@ class Mutator:
         eng.reset_stats()
         try:
             chroms = list(self._sim.chromosomes)
-            i = 0
-            while i < len(chroms):
-                # a run of small contigs goes through libmsim in ONE pass (msim_batch_run); a KeyError / ValueError inside it is
-                # replayed contig by contig so that the files hold exactly what the reference had written by then
-                j = i
-                total = 0
-                while (j < len(chroms) and j - i < BATCH_MAX_CONTIGS and self._batchable(chroms[j])
-                       and total + len(self._fasta[chroms[j].number]) <= BATCH_MAX_BASES):
-                    total += len(self._fasta[chroms[j].number])
-                    j += 1
-                if j - i >= 2:
-                    saved = (eng.get_mt_state(0), eng.get_mt_state(1))
-                    try:
-                        self._mutate_batch(eng, chroms[i:j])
-                        i = j
-                        continue
-                    except (KeyError, ValueError):
-                        eng.set_mt_state(0, *saved[0])
-                        eng.set_mt_state(1, *saved[1])
-                self._mutate_one(eng, chroms[i], earlier=chroms[:i])
-                i += 1
+            for i, j in self._units(chroms):
+                self._process_unit(eng, chroms, i, j)
         finally:
             import_python_streams(eng)
             self.stats = eng.stats()

@@ -82,3 +82,7 @@ class VcfWriter:
 
     def write_raw(self, text: bytes):
         self._out.write(text)
+
+    def tell(self) -> int:
+        self._out.flush()
+        return self._out.tell()
