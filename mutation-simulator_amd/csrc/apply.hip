@@ -915,7 +915,8 @@ int apply_finish(Ctx *c) {
         const unsigned long long h_err = errs[(size_t)idx];
         g.key_error = h_err != ~0ull;
         if (g.key_error) { g.key_pos = h_err >> 8; g.key_base = (uint8_t)(h_err & 0xff); g.key_reported = false; }
-        if (g.delta_known && !g.all_snp && g.n_rec && (long long)deltas[(size_t)idx] != g.known_delta) delta_mismatch = true;
+        // (off_ready: the offsets came from the planner itself -- there is no second, independent sum to compare)
+        if (g.delta_known && !g.off_ready && !g.all_snp && g.n_rec && (long long)deltas[(size_t)idx] != g.known_delta) delta_mismatch = true;
     }
     c->pending_apply.clear();
     if (delta_mismatch) return fail(c, MSIM_ERR_HIP, "internal: planner and device disagree on the mutated length");
@@ -944,7 +945,10 @@ int apply_contig_device(Ctx *c, Contig &g) {
     long long total_delta = 0;
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     const uint32_t *d_off = nullptr;
-    if (n && !g.all_snp) {
+    if (n && !g.all_snp && g.off_ready) {                  // planned on the device: the offsets came with the records
+        total_delta = g.known_delta;
+        d_off = g.d_off;
+    } else if (n && !g.all_snp) {
         int rc = dev_reserve(c, (void **)&g.d_off, &g.cap_off, (size_t)n * sizeof(uint32_t));
         if (rc) return rc;
         rc = ensure_scratch(c, (size_t)(nb + 1) * sizeof(long long));

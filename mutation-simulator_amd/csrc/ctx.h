@@ -20,6 +20,7 @@ struct Contig {
     bool all_snp = false;             // record table holds SNPs only: no length change, offset == pos
     bool delta_known = false;         // the planner already knows out_len - len (SV mixes planned on the device):
     long long known_delta = 0;        //   APPLY needs no round trip for the output size
+    bool off_ready = false;           // ... and already left every record's output offset in d_off (k_emit_records)
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD

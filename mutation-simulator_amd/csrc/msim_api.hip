@@ -120,6 +120,7 @@ static void reset_contig(Contig &g) {   // (callers also drop the context's text
     g.planned = g.applied = false;
     g.defer_apply = false;
     g.delta_known = false;
+    g.off_ready = false;
     g.known_delta = 0;
     g.n_rec = g.pool_len = g.out_len = 0;
     g.h_recs.clear(); g.h_recs.shrink_to_fit();

@@ -869,6 +869,18 @@ static int span_close(Ctx *c, GpuPlan *g) {
     return MSIM_OK;
 }
 
+// The previous contig's deferred APPLY goes out when this contig's host chain starts -- and behind the last of the copies
+// that chain waits for, so that the rewrite kernel really runs on an idle device: launched right away it shared the CUs
+// with k_accept_tables and the D2H copies of the window (c3: 1.54 -> 1.92 ms of rewrite kernel per step).
+static int flush_deferred_apply_behind(Ctx *c, hipEvent_t last_copy) {
+    if (c->deferred_apply >= 0) MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, last_copy, 0));
+    return flush_deferred_apply(c);
+}
+
+// M.cnt: five u32 counter arrays of nbk + 2 entries, then (8-byte aligned) one 64-bit array of the same length
+static inline size_t mixed_cnt_words(uint32_t nbk) { return ((size_t)5 * (nbk + 2) + 1) & ~(size_t)1; }
+static inline size_t mixed_cnt_bytes(uint32_t nbk) { return mixed_cnt_words(nbk) * 4 + (size_t)(nbk + 2) * 8; }
+
 // Steps 3 and 4 of an SV-mix plan, shared by the single-range engine and the host-chain engine: the stops of the chain's
 // candidates are in M.cand_stop -> keep flags and counts -> records, insert pool, SNP draws.  p_s: where the SNP draws of
 // __mutate_sequence start in the CPython stream.  rt / visit_from / sn_chained: see k_keep_flags (nullptr for one range).
@@ -880,6 +892,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     const uint32_t nbk = (k + CB_BLOCK - 1) / CB_BLOCK;
     uint32_t *bmax = M.cnt + (nbk + 2), *cnt_keep = M.cnt + 2 * (nbk + 2), *cnt_sn = M.cnt + 3 * (nbk + 2),
              *cnt_ins = M.cnt + 4 * (nbk + 2);
+    long long *blk_delta = reinterpret_cast<long long *>(M.cnt + mixed_cnt_words(nbk));   // (8-byte aligned: see mixed_cnt_bytes)
     hipLaunchKernelGGL(k_set_pos, dim3(1), dim3(1), 0, c->stream, g->d_ps, (unsigned long long)p_s);
 
     // ---- 3. keep flags, counts
@@ -889,8 +902,8 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
                        rt, n_draw);
     hipLaunchKernelGGL(k_scan_max_u32, dim3(1), dim3(1024), 0, c->stream, bmax, nbk);
     hipLaunchKernelGGL(k_keep_flags, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt,
-                       bmax, cnt_keep, cnt_sn, cnt_ins, g->d_ps, rt, n_draw, visit_from, sn_chained ? 1u : 0u);
-    hipLaunchKernelGGL(k_scan3_u32, dim3(3), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, nbk, g->d_ps);
+                       bmax, cnt_keep, cnt_sn, cnt_ins, blk_delta, rt, n_draw, visit_from, sn_chained ? 1u : 0u);
+    hipLaunchKernelGGL(k_scan4, dim3(4), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, blk_delta, nbk, g->d_ps);
     MSIM_HIP(c, hipGetLastError());
     PlanState h;
     if ((rc = mixed_poll(c, g, h))) return rc;
@@ -905,6 +918,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
         }
         if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
         if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, pool_len + 2 * PAD))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_off, &ct.cap_off, std::max<uint64_t>(n_rec, 1) * sizeof(uint32_t)))) return rc;
     }
     ct.n_rec = n_rec;
     ct.pool_len = pool_len;
@@ -912,6 +926,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     ct.all_snp = h.n_rec == h.n_sn;
     ct.delta_known = true;
     ct.known_delta = h.len_delta;
+    ct.off_ready = !c->chain_only;                         // k_emit_records leaves every record's output offset in d_off
     if (pool_len && (rc = ensure_words(c, g, 1, np.pos + pool_len + 1))) return rc;
     uint64_t pos_hi = p_s;
     hipEvent_t ce = next_chain_event(g);
@@ -919,7 +934,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
     if (!c->chain_only) {
         hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
-                           cnt_keep, cnt_sn, cnt_ins, ct.d_recs, M.sn_index);
+                           cnt_keep, cnt_sn, cnt_ins, blk_delta, ct.d_recs, M.sn_index, ct.d_off);
         if (pool_len)
             hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
                                (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
@@ -979,7 +994,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     if ((rc = grow(c, (void **)&M.nsn_rank, &M.cap_nrank, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)k * 4 + 64, &grew))) return rc;
-    if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, (size_t)5 * (nbk + 2) * 4, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, mixed_cnt_bytes(nbk), &grew))) return rc;
     uint32_t *cnt_nsn = M.cnt;                             // (the other four counter arrays: mixed_emit)
 
     // ---- 1. sample -> bitmap; bitmap -> candidates with types; non-SNP candidates compacted
@@ -1072,7 +1087,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
             }
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-            if ((rc = flush_deferred_apply(c))) return rc;  // the previous contig's APPLY: the device is idle from here on
+            if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
             const auto w0 = std::chrono::steady_clock::now();
             ChainWalk cw;
             if ((rc = cw.init(c, r, ct.len, cc, Wb))) return rc;
@@ -1282,7 +1297,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
         if (!rc) *avail = f.cut[++f.next];
         return rc;
     };
-    if ((rc = flush_deferred_apply(c))) return rc;        // the previous contig's APPLY: the device is idle from here on
+    if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
     rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed, &feed);
     if (!rc) {
         MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned window is free again
@@ -1436,7 +1451,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     if ((rc = grow(c, (void **)&M.nsn_rank, &M.cap_nrank, (size_t)K * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)K * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)K * 4 + 64, &grew))) return rc;
-    if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, (size_t)5 * (nbk + 2) * 4, &grew))) return rc;
+    if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, mixed_cnt_bytes(nbk), &grew))) return rc;
     if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.tables, &M.cap_tables, n_slots * 4 + 64, &grew))) return rc;
     // range table | type tables | visit_from, one device block and one pinned block per scratch set
@@ -1524,7 +1539,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
         MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
     }
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-    if ((rc = flush_deferred_apply(c))) return rc;         // the previous contig's APPLY: the device is idle from here on
+    if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
     const auto tp1 = std::chrono::steady_clock::now();
     // ---- 2. the chain, on the host
     size_t consumed = 0;

@@ -927,6 +927,26 @@ __device__ __forceinline__ uint32_t block_scan_max(uint32_t v, uint32_t *wsum, u
     return max(pre, ex);
 }
 
+__device__ __forceinline__ long long block_scan_add64(long long v, long long *wsum, long long &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const long long t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    long long pre = 0;
+    total = 0;
+    for (int w = 0; w < CB_THREADS / 64; w++) {
+        if (w < wave) pre += wsum[w];
+        total += wsum[w];
+    }
+    __syncthreads();
+    return pre + incl - v;
+}
+
 // bitmap -> candidate i of the range: pos = start + value + d * rank (util.py:104-109), type from
 // numpy.random.choice(p=...) = searchsorted(cdf, u, 'right') on the 53-bit sample of words 2i, 2i+1
 // (mutator.py:170-174)
@@ -1176,7 +1196,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
                                                            const uint32_t *__restrict__ cand_stop, uint32_t k,
                                                            BlockTable bt, const uint32_t *__restrict__ bmax,
                                                            uint32_t *__restrict__ cnt_keep, uint32_t *__restrict__ cnt_sn,
-                                                           uint32_t *__restrict__ cnt_ins, PlanState *__restrict__ ps,
+                                                           uint32_t *__restrict__ cnt_ins, long long *__restrict__ blk_delta,
                                                            const MixRangeDev *__restrict__ rt, uint32_t n_draw,
                                                            const uint32_t *__restrict__ visit_from, uint32_t sn_chained) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
@@ -1222,7 +1242,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
         nk += keep ? 1u : 0u;
         if (keep) cand_type[i0 + q] = t[q] | KEEP_BIT;
     }
-    // one atomic per workgroup: same-address 64-bit atomics serialise in L2 (one per wave made this kernel 4x longer)
+    // the workgroup's length change: scanned with the counts (k_scan4) -- its prefix gives every record's output
+    // offset at emission (k_emit_records), its total the contig's length delta
     __shared__ long long wdelta[CB_THREADS / 64];
     for (int o = 32; o > 0; o >>= 1) delta += __shfl_down(delta, o, 64);
     if ((threadIdx.x & 63) == 0) wdelta[threadIdx.x >> 6] = delta;
@@ -1230,7 +1251,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
     if (threadIdx.x == 0) {
         long long t = 0;
         for (int w = 0; w < CB_THREADS / 64; w++) t += wdelta[w];
-        if (t) atomicAdd((unsigned long long *)&ps->len_delta, (unsigned long long)t);
+        blk_delta[blockIdx.x] = t;
     }
     uint32_t tk, ts, ti;
     (void)block_scan_add(nk, wsum, tk);
@@ -1239,34 +1260,48 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
     if (threadIdx.x == 0) { cnt_keep[blockIdx.x] = tk; cnt_sn[blockIdx.x] = ts; cnt_ins[blockIdx.x] = ti; }
 }
 
-// three exclusive scans in one launch (blockIdx.x selects the array), totals to a[n]; publishes them
-__global__ __launch_bounds__(1024) void k_scan3_u32(uint32_t *__restrict__ a0, uint32_t *__restrict__ a1,
-                                                    uint32_t *__restrict__ a2, uint32_t n, PlanState *__restrict__ ps) {
-    __shared__ uint32_t buf[1024];
-    __shared__ uint32_t carry;
-    uint32_t *a = blockIdx.x == 0 ? a0 : blockIdx.x == 1 ? a1 : a2;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
+// four exclusive scans in one launch (blockIdx.x selects the array), totals to a[n]; publishes them.  Workgroups 0..2:
+// kept mutations / kept SNPs / insert bases; workgroup 3: the 64-bit length deltas.  A wave scans by shuffles, the 16
+// wave totals go through LDS: two barriers per 1024 items.
+template <class T>
+__device__ __forceinline__ T scan_chunks(T *__restrict__ a, uint32_t n, T *wsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T carry = 0;
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + threadIdx.x;
-        const uint32_t v = i < n ? a[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const uint32_t t = threadIdx.x >= (unsigned)o ? buf[threadIdx.x - o] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += t;
-            __syncthreads();
+        const T v = i < n ? a[i] : (T)0;
+        T incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const T t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
         }
-        const uint32_t incl = buf[threadIdx.x], c = carry;
-        if (i < n) a[i] = c + incl - v;
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
+        T pre = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) pre += wsum[w];
+            tot += wsum[w];
+        }
+        if (i < n) a[i] = carry + pre + incl - v;
+        carry += tot;
         __syncthreads();
     }
+    return carry;
+}
+__global__ __launch_bounds__(1024) void k_scan4(uint32_t *__restrict__ a0, uint32_t *__restrict__ a1, uint32_t *__restrict__ a2,
+                                                long long *__restrict__ a3, uint32_t n, PlanState *__restrict__ ps) {
+    __shared__ long long wsum64[16];
+    if (blockIdx.x == 3) {
+        const long long total = scan_chunks<long long>(a3, n, wsum64);
+        if (threadIdx.x == 0) { a3[n] = total; ps->len_delta = total; }
+        return;
+    }
+    uint32_t *a = blockIdx.x == 0 ? a0 : blockIdx.x == 1 ? a1 : a2;
+    const uint32_t total = scan_chunks<uint32_t>(a, n, reinterpret_cast<uint32_t *>(wsum64));
     if (threadIdx.x == 0) {
-        a[n] = carry;
-        if (blockIdx.x == 0) ps->n_rec = carry; else if (blockIdx.x == 1) ps->n_sn = carry; else ps->pool_len = carry;
+        a[n] = total;
+        if (blockIdx.x == 0) ps->n_rec = total; else if (blockIdx.x == 1) ps->n_sn = total; else ps->pool_len = total;
     }
 }
 
@@ -1277,13 +1312,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_emit_records(const uint32_t *__r
                                                              const uint32_t *__restrict__ off_keep,
                                                              const uint32_t *__restrict__ off_sn,
                                                              const uint32_t *__restrict__ off_ins,
+                                                             const long long *__restrict__ off_delta,
                                                              msim_record *__restrict__ recs,
-                                                             uint32_t *__restrict__ sn_index) {
+                                                             uint32_t *__restrict__ sn_index, uint32_t *__restrict__ rec_off) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
+    __shared__ long long wsum64[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint8_t t[CB_ITEMS];
     uint32_t pos[CB_ITEMS], stop[CB_ITEMS];
     uint32_t nk = 0, ns = 0, ni = 0;
+    long long nd = 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)0;
@@ -1294,21 +1332,29 @@ __global__ __launch_bounds__(CB_THREADS) void k_emit_records(const uint32_t *__r
             stop[q] = ty == MSIM_SN ? pos[q] : cand_stop[i0 + q];
             nk++;
             if (ty == MSIM_SN) ns++;
-            if (ty == MSIM_IN) ni += stop[q] - pos[q] + 1;
+            const long long len = (long long)(stop[q] - pos[q] + 1);
+            if (ty == MSIM_IN) ni += (uint32_t)len;
+            nd += (ty == MSIM_IN || ty == MSIM_DU) ? len : (ty == MSIM_DE ? -len : 0ll);   // mutator.py:343-399
         }
     }
     uint32_t tot;
+    long long tot64;
     uint32_t r = off_keep[blockIdx.x] + block_scan_add(nk, wsum, tot);
     uint32_t s = off_sn[blockIdx.x] + block_scan_add(ns, wsum, tot);
     uint32_t p = off_ins[blockIdx.x] + block_scan_add(ni, wsum, tot);
+    long long shift = off_delta[blockIdx.x] + block_scan_add64(nd, wsum64, tot64);   // length change of every record before
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         if (!(t[q] & KEEP_BIT)) continue;
         const uint8_t ty = t[q] & 7;
         msim_record rec;
         rec.pos = pos[q]; rec.stop = stop[q]; rec.extra = 0; rec.type = ty; rec.aux = 0; rec.rsv = 0;
+        const long long len = (long long)(stop[q] - pos[q] + 1);
         if (ty == MSIM_SN) sn_index[s++] = r;
-        if (ty == MSIM_IN) { rec.extra = p; p += stop[q] - pos[q] + 1; }
+        if (ty == MSIM_IN) { rec.extra = p; p += (uint32_t)len; }
+        // the record's offset in the mutated stream, the table APPLY would otherwise scan for (apply.hip: k_offsets)
+        rec_off[r] = (uint32_t)((long long)pos[q] + shift);
+        shift += (ty == MSIM_IN || ty == MSIM_DU) ? len : (ty == MSIM_DE ? -len : 0ll);
         recs[r++] = rec;
     }
 }
