@@ -119,6 +119,9 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
 int  msim_abi_version(void);
+/* Initialise the HIP runtime for `device_id` (idempotent, thread-safe, no context): the first HIP call of a process costs
+ * ~0.2 s; a caller with host work of its own to do first (reading and indexing the FASTA) runs this beside it.        */
+int  msim_warm_up(int device_id);
 int  msim_create(int device_id, uint32_t flags, msim_ctx **out);     /* Mutator.__init__ mutator.py:79 */
 void msim_destroy(msim_ctx *ctx);                                     /* Mutator.close    mutator.py:95 */
 const char *msim_last_error(const msim_ctx *ctx);                     /* "" when none; ctx may be NULL  */
@@ -218,6 +221,12 @@ int msim_fetch_sequence_framed(msim_ctx *ctx, int contig, uint32_t bpl, uint8_t 
  * (sequence_always_upper=True, util.py:84-88).  Replaces msim_add_contig + host-side parsing.           */
 int msim_add_contig_text(msim_ctx *ctx, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases,
                          uint32_t lenc, uint32_t lenb, int *contig);
+
+/* Page-locked host memory for the caller's ingest / egress buffers: any host pointer is accepted by the text calls above,
+ * but copies to and from page-locked memory run at the link's speed without a staging pass (and without the page faults
+ * of a freshly allocated buffer) -- the CLI double-buffers its contigs through a few of these (mutator.py).            */
+int msim_host_alloc(msim_ctx *ctx, uint64_t bytes, void **ptr);
+int msim_host_free(msim_ctx *ctx, void *ptr);
 
 /* ---- many small contigs in one pass ------------------------------------------------------------------------------- */
 /* mutate()'s loop body (mutator.py:111-141) for a run of SMALL contigs at once -- assemblies with thousands of scaffolds:

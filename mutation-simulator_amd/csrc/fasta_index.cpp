@@ -8,6 +8,7 @@
 // the CLI's wall time.
 #include <algorithm>
 #include <atomic>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <system_error>
@@ -27,10 +28,67 @@ int index_threads() {
     return t;
 }
 
+// size from which a record's lines are checked in parallel slices (MSIM_INDEX_BIG_BYTES: tests lower it)
+uint64_t big_record_bytes() {
+    static const uint64_t v = [] {
+        const char *e = getenv("MSIM_INDEX_BIG_BYTES");
+        return e ? (uint64_t)strtoull(e, nullptr, 10) : (uint64_t)(64u << 20);
+    }();
+    return v;
+}
+
 // One record: [rec0, rec1) starts with its defline.  Lines are '\n'-separated; a trailing '\r' does not count as a base.
 // pyfaidx's rule: every body line before the last non-empty one has the first line's length (and, for the fixed-stride
 // ingest, its terminator); the last non-empty line may be shorter, never longer; trailing empty lines are ignored.
-void index_record(const uint8_t *text, uint64_t rec0, uint64_t rec1, msim_fasta_record &r) {
+struct LineWalk {
+    bool first = true, first_cr = false, seen_bad = false, seen_crdiff = false, bad = false, nonuni = false, any_nz = false;
+    uint64_t lenc = 0, n_bases = 0, last_nz_len = 0, last_end = 0;
+};
+
+// lines from p up to rec1 (or `max_lines` of them); returns where it stopped
+uint64_t walk_lines(const uint8_t *text, uint64_t p, uint64_t rec1, LineWalk &w, msim_fasta_record &r, uint64_t max_lines) {
+    while (p < rec1 && max_lines--) {
+        const uint8_t *q = static_cast<const uint8_t *>(memchr(text + p, '\n', rec1 - p));
+        const uint64_t e = q ? (uint64_t)(q - text) : rec1;
+        const bool cr = e > p && text[e - 1] == '\r';
+        const uint64_t len = e - p - (cr ? 1 : 0);
+        if (w.first) {
+            w.first = false;
+            w.lenc = len;
+            w.first_cr = cr;
+            r.b0 = p;
+            r.lenc = (uint32_t)std::min<uint64_t>(len, 0xffffffffu);
+            r.lenb = (uint32_t)std::min<uint64_t>(e - p + 1, 0xffffffffu);
+        }
+        w.n_bases += len;
+        if (len > 0) {                                   // every line before this one is "before the last non-empty line"
+            w.bad |= w.seen_bad;
+            w.nonuni |= w.seen_crdiff;
+            w.any_nz = true;
+            w.last_nz_len = len;
+        }
+        w.seen_bad |= len != w.lenc;
+        w.seen_crdiff |= cr != w.first_cr;
+        w.last_end = e;
+        p = e + 1;
+    }
+    return p;
+}
+
+// Lines [0, count) of a body that starts at b0 with `lenb` bytes per line: true iff every one of them is exactly like the
+// first line -- `lenb - 1 - cr` bases, the same terminator, no line feed inside.  (The common case for a chromosome: tens
+// of millions of identical lines.  Checked in slices on several threads; anything else goes through the sequential walk.)
+bool lines_uniform(const uint8_t *text, uint64_t b0, uint64_t lenb, bool cr, uint64_t i0, uint64_t i1) {
+    for (uint64_t i = i0; i < i1; i++) {
+        const uint8_t *ln = text + b0 + i * lenb;
+        if (ln[lenb - 1] != '\n') return false;
+        if (lenb >= 2 && (ln[lenb - 2] == '\r') != cr) return false;
+        if (memchr(ln, '\n', lenb - 1)) return false;
+    }
+    return true;
+}
+
+void index_record(const uint8_t *text, uint64_t rec0, uint64_t rec1, msim_fasta_record &r, int threads) {
     r = msim_fasta_record{};
     const uint8_t *nl = static_cast<const uint8_t *>(memchr(text + rec0, '\n', rec1 - rec0));
     const uint64_t h_end = nl ? (uint64_t)(nl - text) : rec1;                 // exclusive, at the '\n'
@@ -41,38 +99,44 @@ void index_record(const uint8_t *text, uint64_t rec0, uint64_t rec1, msim_fasta_
     r.b0 = r.b1 = p;                                                          // (offset of an empty record: after its defline)
     if (!nl || p >= rec1) return;                                             // no line after the defline
     r.flags |= MSIM_FASTA_HAS_BODY;
-    bool first = true, first_cr = false, seen_bad = false, seen_crdiff = false, bad = false, nonuni = false, any_nz = false;
-    uint64_t lenc = 0, n_bases = 0, last_nz_len = 0, last_end = p;
-    while (p < rec1) {
-        const uint8_t *q = static_cast<const uint8_t *>(memchr(text + p, '\n', rec1 - p));
-        const uint64_t e = q ? (uint64_t)(q - text) : rec1;
-        const bool cr = e > p && text[e - 1] == '\r';
-        const uint64_t len = e - p - (cr ? 1 : 0);
-        if (first) {
-            first = false;
-            lenc = len;
-            first_cr = cr;
-            r.b0 = p;
-            r.lenc = (uint32_t)std::min<uint64_t>(len, 0xffffffffu);
-            r.lenb = (uint32_t)std::min<uint64_t>(e - p + 1, 0xffffffffu);
+    LineWalk w;
+    w.last_end = p;
+    p = walk_lines(text, p, rec1, w, r, 1);                                   // the first line fixes lenc / lenb
+    const uint64_t lenb = (uint64_t)(w.last_end + 1 - r.b0);
+    if (threads > 1 && w.lenc > 0 && p < rec1 && lenb == r.lenb && rec1 - p > big_record_bytes() / 2) {
+        // a large record: the lines that are certainly complete -- all but the last two -- in parallel slices
+        const uint64_t avail = (rec1 - p) / lenb;
+        const uint64_t count = avail > 2 ? avail - 2 : 0;
+        std::vector<char> ok((size_t)threads, 1);
+        std::vector<std::thread> th;
+        auto slice = [&](int t) {
+            const uint64_t i0 = 1 + count * (uint64_t)t / (uint64_t)threads, i1 = 1 + count * (uint64_t)(t + 1) / (uint64_t)threads;
+            ok[(size_t)t] = lines_uniform(text, r.b0, lenb, w.first_cr, i0, i1) ? 1 : 0;
+        };
+        int started = 1;
+        try {
+            for (int t = 1; t < threads; t++, started++) th.emplace_back(slice, t);
+        } catch (const std::system_error &) {
         }
-        n_bases += len;
-        if (len > 0) {                                   // every line before this one is "before the last non-empty line"
-            bad |= seen_bad;
-            nonuni |= seen_crdiff;
-            any_nz = true;
-            last_nz_len = len;
+        slice(0);
+        for (int t = started; t < threads; t++) slice(t);
+        for (auto &x : th) x.join();
+        bool all = true;
+        for (char c : ok) all = all && c;
+        if (all && count) {                              // as if walk_lines had seen `count` more lines like the first
+            w.n_bases += count * w.lenc;
+            w.any_nz = true;
+            w.last_nz_len = w.lenc;
+            p += count * lenb;
+            w.last_end = p - 1;
         }
-        seen_bad |= len != lenc;
-        seen_crdiff |= cr != first_cr;
-        last_end = e;
-        p = e + 1;
     }
-    if (any_nz && last_nz_len > lenc) bad = true;
-    r.b1 = last_end;
-    r.n_bases = n_bases;
-    if (bad) r.flags |= MSIM_FASTA_BAD_LINES;
-    if (nonuni) r.flags |= MSIM_FASTA_NONUNIFORM;
+    walk_lines(text, p, rec1, w, r, UINT64_MAX);
+    if (w.any_nz && w.last_nz_len > w.lenc) w.bad = true;
+    r.b1 = w.last_end;
+    r.n_bases = w.n_bases;
+    if (w.bad) r.flags |= MSIM_FASTA_BAD_LINES;
+    if (w.nonuni) r.flags |= MSIM_FASTA_NONUNIFORM;
 }
 
 }  // namespace
@@ -114,18 +178,27 @@ extern "C" int msim_fasta_index(const uint8_t *text, uint64_t n, msim_fasta_reco
     *n_records = hdr.size();
     if (hdr.empty() || !records) return MSIM_OK;
     if (cap < hdr.size()) return MSIM_ERR_ARG;
-    // ---- 2. one record at a time, records shared out dynamically (a genome has a few huge ones, an assembly many small)
+    // ---- 2. records.  A genome has a few huge ones: each of those is walked by all threads together (index_record slices
+    // its lines); an assembly has many small ones: those are shared out dynamically, one thread per record.
+    const uint64_t R = hdr.size();
+    const int TH = index_threads();
+    auto end_of = [&](uint64_t k) { return k + 1 < R ? hdr[k + 1] : n; };
+    std::vector<uint64_t> small;
+    for (uint64_t k = 0; k < R; k++) {
+        if (end_of(k) - hdr[k] > big_record_bytes() && TH > 1) index_record(text, hdr[k], end_of(k), records[k], TH);
+        else small.push_back(k);
+    }
     std::vector<std::thread> th;
     std::atomic<uint64_t> next{0};
-    const uint64_t R = hdr.size();
+    const uint64_t S = small.size();
     auto work = [&]() {
         for (;;) {
             const uint64_t k0 = next.fetch_add(64);
-            if (k0 >= R) break;
-            for (uint64_t k = k0; k < std::min(R, k0 + 64); k++) index_record(text, hdr[k], k + 1 < R ? hdr[k + 1] : n, records[k]);
+            if (k0 >= S) break;
+            for (uint64_t q = k0; q < std::min(S, k0 + 64); q++) index_record(text, hdr[small[q]], end_of(small[q]), records[small[q]], 1);
         }
     };
-    const int T2 = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)index_threads(), (R + 63) / 64));
+    const int T2 = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)TH, (S + 63) / 64));
     try {
         for (int t = 1; t < T2; t++) th.emplace_back(work);
     } catch (const std::system_error &) {                  // fewer helpers: the shared counter hands their records to the others

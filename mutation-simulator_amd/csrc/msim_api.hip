@@ -171,6 +171,14 @@ extern "C" {
 
 int msim_abi_version(void) { return MSIM_ABI_VERSION; }
 
+int msim_warm_up(int device_id) {
+    if (device_id < 0) return MSIM_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id >= n) return MSIM_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return MSIM_ERR_HIP;
+    return hipFree(nullptr) == hipSuccess ? MSIM_OK : MSIM_ERR_HIP;     // forces the runtime + device context up
+}
+
 int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     if (!out) return MSIM_ERR_ARG;
     *out = nullptr;
@@ -766,6 +774,23 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
     rc = fasta_gather_device(c, body, body_bytes, n_bases, lenc, lenb, g->d_in + PAD);
     if (rc) return rc;
     *contig = (int)c->contigs.size() - 1;
+    return MSIM_OK;
+}
+
+int msim_host_alloc(msim_ctx *p, uint64_t bytes, void **ptr) {
+    Ctx *c = C(p);
+    if (!c || !ptr) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    *ptr = nullptr;
+    MSIM_HIP(c, hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return MSIM_OK;
+}
+
+int msim_host_free(msim_ctx *p, void *ptr) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    if (ptr) MSIM_HIP(c, hipHostFree(ptr));
     return MSIM_OK;
 }
 

@@ -68,6 +68,7 @@ _VP, _U8P, _U64P, _U32P, _IP = C.c_void_p, C.POINTER(C.c_uint8), C.POINTER(C.c_u
     C.POINTER(C.c_uint32), C.POINTER(C.c_int)
 SYMBOLS = [
     ("msim_abi_version", C.c_int, []),
+    ("msim_warm_up", C.c_int, [C.c_int]),
     ("msim_create", C.c_int, [C.c_int, C.c_uint32, C.POINTER(_VP)]),
     ("msim_destroy", None, [_VP]),
     ("msim_last_error", C.c_char_p, [_VP]),
@@ -100,6 +101,8 @@ SYMBOLS = [
     ("msim_render_vcf_device", C.c_int, [_VP, C.c_int, C.c_char_p, _VP, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
+    ("msim_host_alloc", C.c_int, [_VP, C.c_uint64, C.POINTER(_VP)]),
+    ("msim_host_free", C.c_int, [_VP, _VP]),
     ("msim_batch_run", C.c_int, [_VP, C.POINTER(BatchContig), C.c_int]),
     ("msim_batch_sizes", C.c_int, [_VP, C.c_int, _U64P, _U64P, C.POINTER(C.c_int32), _U64P]),
     ("msim_batch_fetch", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
@@ -146,6 +149,16 @@ def load():
     return _lib
 
 
+def warm_up_async(device: int = 0):
+    """Start the HIP runtime on a helper thread (the first HIP call of a process costs ~0.2 s) while the caller reads and
+    indexes its input; returns the thread (join it, or just create the Engine: HIP initialisation is serialised inside)."""
+    import threading
+    lib = load()
+    t = threading.Thread(target=lib.msim_warm_up, args=(int(device),), name="msim-warm-up", daemon=True)
+    t.start()
+    return t
+
+
 def _ptr(a: np.ndarray):
     return C.c_void_p(a.ctypes.data)
 
@@ -161,9 +174,13 @@ class Engine:
             msg = self.lib.msim_last_error(None).decode()
             self.h = None
             raise MsimError(f"msim_create failed ({rc}): {msg}")
+        self._pinned: list = []
 
     def close(self):
         if getattr(self, "h", None):
+            for p in getattr(self, "_pinned", []):
+                self.lib.msim_host_free(self.h, C.c_void_p(p))
+            self._pinned = []
             self.lib.msim_destroy(self.h)
             self.h = None
 
@@ -242,6 +259,14 @@ class Engine:
         cid = C.c_int()
         self._check(self.lib.msim_add_contig_text(self.h, _ptr(body), body.shape[0], n_bases, lenc, lenb, C.byref(cid)))
         return cid.value
+
+    def host_buffer(self, nbytes: int) -> np.ndarray:
+        """A page-locked uint8 buffer owned by this engine (freed at ``close``): ingest / egress through it runs at the
+        link's speed (no staging pass, no page faults of a fresh allocation)."""
+        p = _VP()
+        self._check(self.lib.msim_host_alloc(self.h, int(nbytes), C.byref(p)))
+        self._pinned.append(p.value)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(int(nbytes), 1),))[:nbytes]
 
     def add_contig_synthetic(self, length: int, seed: int) -> int:
         cid = C.c_int()
@@ -334,6 +359,31 @@ class Engine:
         if need.value:
             self._check(self.lib.msim_render_vcf_device(self.h, contig, name, _ptr(out), need.value, C.byref(need)), contig)
         return out
+
+    def render_vcf_device_size(self, contig: int, seq_name: str) -> int:
+        """Render the contig's VCF record lines on the device and report their size (the text stays in HBM for
+        ``render_vcf_device_into``)."""
+        need = C.c_uint64()
+        self._check(self.lib.msim_render_vcf_device(self.h, contig, seq_name.encode("utf-8", "replace"), None, 0,
+                                                    C.byref(need)), contig)
+        return need.value
+
+    def render_vcf_device_into(self, contig: int, seq_name: str, out: np.ndarray) -> int:
+        """... and copy them into the caller's buffer -- any writable uint8 array, e.g. a mapped span of the output file."""
+        need = C.c_uint64()
+        self._check(self.lib.msim_render_vcf_device(self.h, contig, seq_name.encode("utf-8", "replace"), _ptr(out),
+                                                    out.shape[0], C.byref(need)), contig)
+        return need.value
+
+    def fetch_sequence_framed_size(self, contig: int, bpl: int) -> int:
+        need = C.c_uint64()
+        self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, None, 0, C.byref(need)), contig)
+        return need.value
+
+    def fetch_sequence_framed_into(self, contig: int, bpl: int, out: np.ndarray) -> int:
+        need = C.c_uint64()
+        self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, _ptr(out), out.shape[0], C.byref(need)), contig)
+        return need.value
 
     def fetch_sequence_framed(self, contig: int, bpl: int, guess_len: int | None = None) -> np.ndarray:
         """The mutated contig as FASTA body text (newline after every ``bpl`` bases).  With ``guess_len`` (e.g. the
@@ -497,14 +547,17 @@ def fasta_index(text: np.ndarray):
     lib = load()
     text = np.ascontiguousarray(text, dtype=np.uint8)
     n = C.c_uint64()
-    rc = lib.msim_fasta_index(_ptr(text), text.shape[0], None, 0, C.byref(n))
-    if rc == 3:                                        # MSIM_ERR_VALUE
-        return None
-    if rc:
-        raise MsimError(f"msim_fasta_index failed ({rc})")
-    out = np.zeros(n.value, dtype=FASTA_RECORD_DTYPE)
-    if n.value:
-        rc = lib.msim_fasta_index(_ptr(text), text.shape[0], out.ctypes.data_as(C.c_void_p), n.value, C.byref(n))
+    cap = 4096                                         # one pass for anything but a large assembly (the defline scan reads
+    while True:                                        # the whole text: do not run it twice just to learn the count)
+        out = np.zeros(cap, dtype=FASTA_RECORD_DTYPE)
+        rc = lib.msim_fasta_index(_ptr(text), text.shape[0], out.ctypes.data_as(C.c_void_p), cap, C.byref(n))
+        if rc == 3:                                    # MSIM_ERR_VALUE
+            return None
+        if rc == ERR_ARG and n.value > cap:
+            cap = n.value
+            continue
         if rc:
             raise MsimError(f"msim_fasta_index failed ({rc})")
+        out = out[:n.value]
+        break
     return out

@@ -83,7 +83,9 @@ class Fasta:
         if not os.path.isfile(filename):
             raise FastaNotFoundError(f"Cannot read FASTA from file {filename}")
         self.filename = filename
-        raw = np.fromfile(filename, dtype=np.uint8)
+        # mapped, not read: the index pass and the per-record uploads touch the page cache directly (a 3 GB np.fromfile is a
+        # second copy of the genome in memory and ~0.1 s per GB before anything else can start)
+        raw = np.memmap(filename, dtype=np.uint8, mode="r") if os.path.getsize(filename) else np.zeros(0, np.uint8)
         self._records: dict[str, FastaRecord] = {}
         self._order: list[FastaRecord] = []
         self._parse(raw)

@@ -67,6 +67,7 @@ class ShardWorker(Mutator):
         self._own_engine = True
         self.stats: dict = {}
         self.warned: list = []
+        self._t = {"ingest_s": 0.0, "plan_apply_s": 0.0, "fasta_egress_s": 0.0, "vcf_egress_s": 0.0}
         self._host_only = os.environ.get("MSIM_SHARD_HOST_ONLY") == "1"
 
     def _warn_empty(self, chrom):

@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import random
 import sys
+import time
 from math import ceil, log
 from typing import Optional
 
@@ -161,10 +162,20 @@ class Mutator:
         self._sim = sim
         self._fasta_writer = FastaWriter(args.outfasta)
         self._vcf_writer = VcfWriter(args.outvcf)
+        try:                                           # the output is about as large as the input: allocate it meanwhile
+            total = 0
+            for k in fasta.keys():
+                r = fasta[k]
+                total += len(r) + len(r) // max(1, getattr(r, "lenc", 60) or 60) + len(r.long_name) + 3
+            if int(getattr(args, "gpus", 1) or 1) <= 1 and total > (64 << 20):
+                self._fasta_writer.preallocate(total)
+        except Exception:  # noqa: BLE001  (a size estimate only)
+            pass
         self._vcf_writer.write_header(args.infile.name, fasta, sim.assembly_name, sim.species_name,
                                       sim.sample_name)
         self._engine = engine
         self._own_engine = engine is None
+        self._t = {"ingest_s": 0.0, "plan_apply_s": 0.0, "fasta_egress_s": 0.0, "vcf_egress_s": 0.0}
         self.stats: dict = {}
 
     def close(self):
@@ -231,11 +242,15 @@ class Mutator:
                 eng.set_plan_mode(_ffi.PLAN_AUTO)
 
     def _run_contig(self, eng, chrom, done):
+        t = self._t
+        t0 = time.perf_counter()
         rec = self._fasta[chrom.number]
         if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
             cid = eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
         else:
             cid = eng.add_contig(rec.bases)
+        t1 = time.perf_counter()
+        t["ingest_s"] += t1 - t0
         eng.plan_contig(cid, plan_descriptors(chrom))
         if eng.plan_was_empty(cid) and "warned" not in done:
             self._warn_empty(chrom)
@@ -246,18 +261,34 @@ class Mutator:
             self._fasta_writer.write_header(rec.long_name)
             done.add("header")
         eng.apply_contig(cid)
-        if bpl > 0:                                    # line framing and VCF text rendered on the device
-            text = eng.fetch_sequence_framed(cid, bpl, guess_len=len(rec))
+        # Egress.  Line framing and VCF text are rendered on the device; the copies land DIRECTLY in the output files'
+        # page cache (the writers map the next region of their file): no intermediate buffer, no write() pass -- a
+        # write() of a 200 Mb contig into tmpfs costs 40-50 ms of one core, the D2H copy into the mapping 9-14.
+        if bpl > 0:
+            n_text = eng.fetch_sequence_framed_size(cid, bpl)          # (synchronises: PLAN + APPLY are done here)
+            t2 = time.perf_counter()
+            t["plan_apply_s"] += t2 - t1
+            region = self._fasta_writer.map_region(n_text)
+            try:
+                eng.fetch_sequence_framed_into(cid, bpl, region.view)
+            finally:
+                q, r = divmod(n_text, bpl + 1)          # text = L + L // bpl bytes  ->  L
+                self._fasta_writer.commit_region(region, q * bpl + r)
         else:
             text = eng.fetch_sequence(cid)
-        _, n_rec, _ = eng.result_sizes(cid, applied=False)     # (host-side bookkeeping, no round trip)
-        vcf = eng.render_vcf_device(cid, rec.name, guess=n_rec * (len(rec.name) + 40) + 256)
-        if bpl > 0:
-            q, r = divmod(int(text.shape[0]), bpl + 1)  # text = L + L // bpl bytes  ->  L
-            self._fasta_writer.write_framed(text, q * bpl + r)
-        else:
+            t2 = time.perf_counter()
+            t["plan_apply_s"] += t2 - t1
             self._fasta_writer.write_array(text)
-        self._vcf_writer.write_raw(vcf)
+        t3 = time.perf_counter()
+        t["fasta_egress_s"] += t3 - t2
+        n_vcf = eng.render_vcf_device_size(cid, rec.name)
+        region = self._vcf_writer.map_region(n_vcf)
+        try:
+            if n_vcf:
+                eng.render_vcf_device_into(cid, rec.name, region.view)
+        finally:
+            self._vcf_writer.commit_region(region)
+        t["vcf_egress_s"] += time.perf_counter() - t3
         eng.clear()
 
     def _units(self, chroms):
@@ -309,3 +340,4 @@ class Mutator:
         finally:
             import_python_streams(eng)
             self.stats = eng.stats()
+            self.stats["contig_path_s"] = {k: round(v, 4) for k, v in self._t.items()}

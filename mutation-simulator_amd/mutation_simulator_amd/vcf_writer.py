@@ -48,7 +48,7 @@ _HEADER_TAIL = (
 class VcfWriter:
     def __init__(self, fname):
         try:
-            self._out = open(fname, "wb")
+            self._out = open(fname, "w+b")         # (readable too: map_region maps spans of it)
         except IOError as e:
             raise VcfWriterError(f"Cannot write to VCF file {fname} {e}")
 
@@ -57,7 +57,11 @@ class VcfWriter:
 
     def close(self):
         out = getattr(self, "_out", None)
-        if out is not None:
+        if out is not None and not out.closed:
+            out.flush()
+            import os
+            if os.fstat(out.fileno()).st_size > out.tell():     # (a mapped region that was cut short)
+                os.ftruncate(out.fileno(), out.tell())
             out.close()
 
     def write_header(self, input_fasta, fasta, assembly_name: str, species_name: str,
@@ -82,6 +86,14 @@ class VcfWriter:
 
     def write_raw(self, text: bytes):
         self._out.write(text)
+
+    def map_region(self, nbytes: int):
+        """The next ``nbytes`` of the file mapped for writing (record lines rendered elsewhere land there directly)."""
+        from .fasta_writer import MappedRegion
+        return MappedRegion(self._out, nbytes)
+
+    def commit_region(self, region):
+        region.close(self._out)
 
     def tell(self) -> int:
         self._out.flush()

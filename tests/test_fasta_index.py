@@ -102,6 +102,31 @@ def test_index_edge_texts():
         _check(text)
 
 
+def test_large_records_are_sliced_over_threads():
+    """Records above a size threshold have their lines checked in parallel slices (csrc/fasta_index.cpp: lines_uniform);
+    anything that is not "millions of identical lines" must come out exactly as the sequential walk has it.  The
+    threshold is lowered to 2 KB in a child interpreter so that small texts with every kind of irregularity take the path."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path[:0] = %r\n"
+        "import numpy as np\n"
+        "import test_fasta_index as t\n"
+        "for seed in range(12):\n"
+        "    rs = np.random.RandomState(700 + seed)\n"
+        "    for _ in range(6):\n"
+        "        t._check(t._random_text(rs, int(rs.randint(1, 6)), big=True))\n"
+        "clean = b''.join(b'>r%%d\\n' %% i + b'\\n'.join([b'ACGTACGTAC'] * (400 + 13 * i)) + tail\n"
+        "                 for i, tail in enumerate([b'\\n', b'\\nACG\\n', b'\\nACG', b'\\n\\n\\n', b'', b'\\nACGTACGTACG\\n']))\n"
+        "t._check(clean)\n"
+        "t._check(clean.replace(b'\\n', b'\\r\\n'))\n"
+        "print('ok')\n" % (sys.path[:10],))
+    env = dict(os.environ, MSIM_INDEX_BIG_BYTES="2048", MSIM_BATCH_THREADS="5")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
+
+
 def test_index_large_text_over_threads():
     rs = np.random.RandomState(123)
     text = _random_text(rs, 900, big=True)
