@@ -241,6 +241,9 @@ typedef struct msim_batch_contig {
     const char *header;      /* NULL: the FASTA text holds the framed bodies only.  Else the defline without '>': the text
                                 is the complete run of records as FastaWriter writes them (fasta_writer.py:31-38) --
                                 '>' header '\n' body, with a '\n' before a header iff the body before it ended mid-line */
+    uint32_t name_len, header_len;   /* 0: `name` / `header` are NUL-terminated strings.  Else their length in bytes: they may
+                                then point straight into the FASTA file text (an assembly has 10^5 deflines; nobody has
+                                to copy them) */
 } msim_batch_contig;
 int msim_batch_run(msim_ctx *ctx, const msim_batch_contig *contigs, int n);
 /* per contig: bytes of its part of the FASTA text (header line included where given), bytes of its VCF lines, plan-was-empty flag (mutator.py:125-129), records */

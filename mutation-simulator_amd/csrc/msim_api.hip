@@ -980,6 +980,8 @@ static int pinned_reserve(Ctx *c, uint8_t **p, size_t *cap, size_t want) {
 }
 
 // output length change of one record (apply.hip: rec_lengths)
+static inline size_t batch_header_len(const msim_batch_contig &q) { return q.header_len ? q.header_len : strlen(q.header); }
+
 static long long rec_delta(const msim_record &r) {
     const long long len = (long long)r.stop - (long long)r.pos + 1;
     switch (r.type) {
@@ -1140,7 +1142,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     for (int i = 0; i < n; i++) {
         Batch::Item &it = B.items[(size_t)i];
         const bool prev_partial = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
-        const uint64_t head = contigs[i].header ? (prev_partial ? 1 : 0) + 1 + strlen(contigs[i].header) + 1 : 0;
+        const uint64_t head = contigs[i].header ? (prev_partial ? 1 : 0) + 1 + batch_header_len(contigs[i]) + 1 : 0;
         it.text0 = text_total;
         it.ntext = head + (it.bpl ? it.out_len + it.out_len / it.bpl : it.out_len);
         text_total += it.ntext;
@@ -1157,7 +1159,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
                 const bool prev_partial = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
                 if (prev_partial) *dst++ = '\n';
                 *dst++ = '>';
-                const size_t hl = strlen(hd);
+                const size_t hl = batch_header_len(contigs[i]);
                 memcpy(dst, hd, hl);
                 dst += hl;
                 *dst++ = '\n';
@@ -1182,7 +1184,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
             uint64_t bound = 0;
             for (int i = i0; i < i1; i++) {
                 const Batch::Item &it = B.items[(size_t)i];
-                const uint64_t nl = strlen(contigs[i].name) + 96;
+                const uint64_t nl = (contigs[i].name_len ? contigs[i].name_len : strlen(contigs[i].name)) + 96;
                 for (uint64_t k = 0; k < it.nrec; k++) {
                     const msim_record &r = all[it.rec0 + k];
                     const uint64_t span = r.type == MSIM_SN ? 1 : (uint64_t)(r.stop >= r.pos ? r.stop - r.pos + 1 : 0) + 2;
@@ -1200,8 +1202,9 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
                 it.vcf0 = at;                                  // relative to the slice until the join
                 uint64_t need = 0;
                 if (it.nrec) {
+                    const std::string nm = contigs[i].name_len ? std::string(contigs[i].name, contigs[i].name_len) : std::string();
                     need = render_vcf_unchecked(all + it.rec0, it.nrec, B.pool.data() + it.pool0, B.h_in + it.base, it.len,
-                                                contigs[i].name, out + at);
+                                                contigs[i].name_len ? nm.c_str() : contigs[i].name, out + at);
                     if (at + need > bound) bad = true;
                 }
                 it.nvcf = need;

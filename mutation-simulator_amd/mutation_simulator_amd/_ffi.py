@@ -47,7 +47,17 @@ class Params(C.Structure):           # msim_params
 class BatchContig(C.Structure):      # msim_batch_contig
     _fields_ = [("body", C.c_void_p), ("body_bytes", C.c_uint64), ("n_bases", C.c_uint64),
                 ("lenc", C.c_uint32), ("lenb", C.c_uint32), ("ranges", C.POINTER(Range)),
-                ("n_ranges", C.c_int32), ("name", C.c_char_p), ("header", C.c_char_p)]
+                ("n_ranges", C.c_int32), ("name", C.c_char_p), ("header", C.c_char_p),
+                ("name_len", C.c_uint32), ("header_len", C.c_uint32)]
+
+
+# the same two structs as numpy record dtypes: a batch over an assembly builds its tables with array operations
+RANGE_DTYPE = np.dtype([("start", "<i8"), ("stop", "<i8"), ("k", "<i8"), ("setsize", "<i8"), ("n_types", "<i4"),
+                        ("types", "<i4", (8,)), ("_pad", "<i4"), ("cdf_thr", "<u8", (8,)), ("min_len", "<i8", (8,)),
+                        ("max_len", "<i8", (8,))])
+BATCH_CONTIG_DTYPE = np.dtype([("body", "<u8"), ("body_bytes", "<u8"), ("n_bases", "<u8"), ("lenc", "<u4"), ("lenb", "<u4"),
+                               ("ranges", "<u8"), ("n_ranges", "<i4"), ("_pad", "<i4"), ("name", "<u8"), ("header", "<u8"),
+                               ("name_len", "<u4"), ("header_len", "<u4")])
 
 
 class Timing(C.Structure):           # msim_timing
@@ -440,6 +450,18 @@ class Engine:
             q.name = nm
             q.header = hd
         self._check(self.lib.msim_batch_run(self.h, arr, n))
+        return self._batch_result(n)
+
+    def batch_run_table(self, table: np.ndarray, keep=()):
+        """The same from a ready ``BATCH_CONTIG_DTYPE`` table (pointers into buffers the caller keeps alive -- ``keep`` --
+        for the duration of the call): an assembly's batch is built with array operations, not per contig."""
+        table = np.ascontiguousarray(table)
+        n = int(table.shape[0])
+        self._check(self.lib.msim_batch_run(self.h, C.cast(C.c_void_p(table.ctypes.data), C.POINTER(BatchContig)), n))
+        del keep
+        return self._batch_result(n)
+
+    def _batch_result(self, n: int):
         em = (C.c_int32 * n)()
         self._check(self.lib.msim_batch_sizes(self.h, n, None, None, em, None))
         fp, vp = C.c_void_p(), C.c_void_p()

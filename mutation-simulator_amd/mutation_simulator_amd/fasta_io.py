@@ -19,7 +19,9 @@ pyfaidx it leaves a samtools-style ``<infile>.fai`` next to the input when it ca
 """
 from __future__ import annotations
 
+import mmap
 import os
+from collections.abc import Mapping
 from types import SimpleNamespace
 
 import numpy as np
@@ -77,6 +79,24 @@ def _upper_inplace(a: np.ndarray) -> None:
     a[lower] -= 32
 
 
+class _FaidxIndex(Mapping):
+    """``fasta.faidx.index``: name -> (rlen, offset, lenc, lenb), built on demand (an assembly has 10^5 records; the
+    mutation pass asks for a handful of line widths)."""
+
+    def __init__(self, records: dict):
+        self._records = records
+
+    def __getitem__(self, name):
+        r = self._records[name]
+        return SimpleNamespace(rlen=len(r), offset=r.offset, lenc=r.lenc, lenb=r.lenb)
+
+    def __iter__(self):
+        return iter(self._records)
+
+    def __len__(self):
+        return len(self._records)
+
+
 class Fasta:
     def __init__(self, filename, write_index: bool = True, **_pyfaidx_compat):
         filename = str(filename)
@@ -85,13 +105,23 @@ class Fasta:
         self.filename = filename
         # mapped, not read: the index pass and the per-record uploads touch the page cache directly (a 3 GB np.fromfile is a
         # second copy of the genome in memory and ~0.1 s per GB before anything else can start)
-        raw = np.memmap(filename, dtype=np.uint8, mode="r") if os.path.getsize(filename) else np.zeros(0, np.uint8)
+        # (a plain ndarray over the mapping, not np.memmap: slicing a memmap costs microseconds per record)
+        size = os.path.getsize(filename)
+        if size:
+            with open(filename, "rb") as fh:
+                self._map = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ)
+            raw = np.frombuffer(self._map, dtype=np.uint8)
+        else:
+            self._map = None
+            raw = np.zeros(0, np.uint8)
+        self.text = raw                                # the whole file text (the batch path hands spans of it to libmsim)
+        self.text_bytes = size
+        self.index_table = None                        # msim_fasta_record per record, file order (numpy structured array)
+        self.name_bytes = None                         # per record: where its name (first token of the defline) sits in it
         self._records: dict[str, FastaRecord] = {}
         self._order: list[FastaRecord] = []
         self._parse(raw)
-        self.faidx = SimpleNamespace(index={
-            r.name: SimpleNamespace(rlen=len(r), offset=r.offset, lenc=r.lenc, lenb=r.lenb)
-            for r in self._order})
+        self.faidx = SimpleNamespace(index=_FaidxIndex(self._records))
         if write_index:
             self._write_fai()
 
@@ -106,12 +136,19 @@ class Fasta:
         idx = _ffi.fasta_index(raw)
         if idx is None:
             raise FastaIndexingError("Sequence data found before the first defline")
+        self.index_table = idx
         h0, h1, b0, b1 = (idx[k].tolist() for k in ("h0", "h1", "b0", "b1"))
         n_bases, lenc, lenb, flags = (idx[k].tolist() for k in ("n_bases", "lenc", "lenb", "flags"))
+        whole = raw.tobytes() if raw.shape[0] < (256 << 20) and idx.shape[0] > 1000 else None   # (deflines of an assembly: one copy
+        name_bytes = []                                                                         #  beats 10^5 tiny ones)
         for k in range(idx.shape[0]):
-            long_name = raw[h0[k]:h1[k]].tobytes().decode("utf-8", "replace")
+            hb = whole[h0[k]:h1[k]] if whole is not None else raw[h0[k]:h1[k]].tobytes()
+            long_name = hb.decode("utf-8", "replace")
             toks = long_name.split()
             name = toks[0] if toks else ""
+            nb = name.encode("utf-8")                  # where the name sits in the file text (the batch path points libmsim at it)
+            at = hb.find(nb) if nb else -1
+            name_bytes.append((at, len(nb)) if at >= 0 and long_name.encode("utf-8", "replace") == hb else (-1, 0))
             if name in self._records:
                 raise ValueError(f"Duplicate key \"{name}\"")
             fl = flags[k]
@@ -125,6 +162,7 @@ class Fasta:
                                   not fl & _ffi.FASTA_NONUNIFORM)
             self._records[name] = rec
             self._order.append(rec)
+        self.name_bytes = np.array(name_bytes, dtype=np.int64).reshape(-1, 2)    # (offset inside the defline, bytes) or (-1, 0)
 
     def _write_fai(self) -> None:
         path = self.filename + ".fai"
@@ -156,4 +194,4 @@ class Fasta:
         return self._records[name][start - 1:end]
 
     def close(self) -> None:
-        pass
+        pass                                           # (the mapping goes with the last array that views it)

@@ -116,9 +116,15 @@ class ShardWorker(Mutator):
         export_python_streams(eng)
         eng.set_params(params_descriptor(self._sim))
         eng.reset_stats()
-        chroms = list(self._sim.chromosomes)
+        chroms = self._chromosomes()
         units = self._units(chroms)
-        owner = unit_owners([sum(len(self._fasta[c.number]) for c in chroms[i:j]) for i, j in units], self.world)
+        tab = getattr(self._fasta, "index_table", None)
+        if tab is not None and len(tab) == len(chroms) and not isinstance(chroms, list):
+            cum = np.concatenate(([0], np.cumsum(tab["n_bases"].astype(np.int64))))
+            unit_bases = [int(cum[j] - cum[i]) for i, j in units]
+        else:
+            unit_bases = [sum(len(self._fasta[c.number]) for c in chroms[i:j]) for i, j in units]
+        owner = unit_owners(unit_bases, self.world)
         segments, error = [], None
         try:
             for u, (i, j) in enumerate(units):

@@ -67,6 +67,18 @@ def _floor_scaled(x: float) -> int:
     return (num * _TWO53) // den
 
 
+def sample_setsize_array(k: np.ndarray) -> np.ndarray:
+    """``sample_setsize`` for an int64 array.  In integers: 3k is never a power of 4, so ceil(log(3k, 4)) is the smallest m
+    with 4**m > 3k -- half the bit length of 3k - 1, rounded up -- and the float expression of CPython (whose distance
+    from the next integer is at least 1 / (3k ln 4), i.e. > 1e-10 for the k < 2**31 a contig below 4 GiB can have) cannot
+    land on the other side.  (Beyond k ~ 1e14 it does: the float expression is what counts, so this is for k < 2**33.)"""
+    k = np.asarray(k, dtype=np.int64)
+    x = np.maximum(3 * k - 1, 1)
+    bits = np.frexp(x.astype(np.float64))[1].astype(np.int64)      # bit_length, exact below 2**53
+    m = (bits + 1) // 2
+    return np.where(k > 5, 21 + (np.int64(1) << (2 * m)), 21).astype(np.int64)
+
+
 def sample_setsize(k: int) -> int:
     """CPython ``random.sample`` pool/set switch (Lib/random.py), same float expression."""
     setsize = 21
@@ -75,16 +87,33 @@ def sample_setsize(k: int) -> int:
     return setsize
 
 
-_SETTINGS_CACHE: dict = {}       # id(MutationSettings) -> (settings, rate sum, template bytes): the per-settings part of msim_range
+_SETTINGS_CACHE: dict = {}       # settings key -> (settings, rate sum, template bytes): the per-settings part of msim_range
+
+
+def _settings_key(ms):
+    """By VALUE: a settings object changed in place after its first descriptor (tests, callers adjusting rates) must not
+    meet its stale template."""
+    lengs = ms.mut_lengs or {}
+    return (tuple((t.value, r) for t, r in (ms.mut_rates or {}).items()),
+            tuple((t.value, c) for t, c in (ms.mut_chances or {}).items()),
+            tuple((t.value, v) for t, v in (lengs.get("min") or {}).items()),
+            tuple((t.value, v) for t, v in (lengs.get("max") or {}).items()))
 
 
 def range_descriptor(rd) -> "_ffi.Range":
     """One ``RangeDefinition`` with mutations -> ``msim_range`` (what mutator.py:157-174 derives).  Everything that
     depends only on the range's ``MutationSettings`` (type order, cdf thresholds, length bounds) is computed once per
-    settings object -- an assembly with 20 000 scaffolds shares one in ARGS mode -- and copied."""
+    distinct settings VALUE -- an assembly with 20 000 scaffolds shares one in ARGS mode -- and copied."""
     ms = rd.mutation_settings
-    hit = _SETTINGS_CACHE.get(id(ms))
-    if hit is None or hit[0] is not ms:
+    key = getattr(ms, "_msim_key", None)
+    if key is None or key != _settings_key(ms):
+        key = _settings_key(ms)
+        try:
+            ms._msim_key = key                          # (re-derived whenever the values differ from what it was made of)
+        except AttributeError:
+            pass
+    hit = _SETTINGS_CACHE.get(key)
+    if hit is None:
         rate_sum = sum(ms.mut_rates.values())                     # mutator.py:160
         t = _ffi.Range()
         chances = list(ms.mut_chances.values())                   # mutator.py:172-173
@@ -103,7 +132,7 @@ def range_descriptor(rd) -> "_ffi.Range":
         if len(_SETTINGS_CACHE) > 4096:
             _SETTINGS_CACHE.clear()
         hit = (ms, rate_sum, bytes(t))
-        _SETTINGS_CACHE[id(ms)] = hit
+        _SETTINGS_CACHE[key] = hit
     r = _ffi.Range.from_buffer_copy(hit[2])
     r.start, r.stop = rd.start, rd.stop
     r.k = int(((rd.stop - rd.start) + 1) * hit[1])                # mutator.py:225
@@ -162,17 +191,11 @@ class Mutator:
         self._sim = sim
         self._fasta_writer = FastaWriter(args.outfasta)
         self._vcf_writer = VcfWriter(args.outvcf)
-        try:                                           # the output is about as large as the input: allocate it meanwhile
-            total = 0
-            for k in fasta.keys():
-                r = fasta[k]
-                total += len(r) + len(r) // max(1, getattr(r, "lenc", 60) or 60) + len(r.long_name) + 3
-            if int(getattr(args, "gpus", 1) or 1) <= 1 and total > (64 << 20):
-                self._fasta_writer.preallocate(total)
-        except Exception:  # noqa: BLE001  (a size estimate only)
-            pass
         self._vcf_writer.write_header(args.infile.name, fasta, sim.assembly_name, sim.species_name,
                                       sim.sample_name)
+        total = int(getattr(fasta, "text_bytes", 0) or 0)   # the output is about as large as the input: allocate it meanwhile
+        if int(getattr(args, "gpus", 1) or 1) <= 1 and total > (64 << 20):
+            self._fasta_writer.preallocate(total)
         self._engine = engine
         self._own_engine = engine is None
         self._t = {"ingest_s": 0.0, "plan_apply_s": 0.0, "fasta_egress_s": 0.0, "vcf_egress_s": 0.0}
@@ -202,17 +225,65 @@ class Mutator:
                 f"No mutations could be generated on sequence {chrom.number+1} "
                 "(mutation rates too low)", self._args.no_color), file=sys.stderr)
 
-    def _mutate_batch(self, eng, chroms):
-        items = []
-        for chrom in chroms:
-            rec = self._fasta[chrom.number]
-            items.append((rec.body, len(rec), rec.lenc, rec.lenb, plan_descriptors(chrom), rec.name, rec.long_name))
-        fasta, vcf, empty, last_line = eng.batch_run(items)
+    def _mutate_batch(self, eng, chroms, i, j):
+        """Contigs [i, j) of ``chroms`` in ONE pass through libmsim (msim_batch_run)."""
+        table = self._batch_table(chroms, i, j)
+        if table is not None:
+            fasta, vcf, empty, last_line = eng.batch_run_table(table[0], keep=table[1:])
+            bpl_last = int(self._fasta.index_table["lenc"][j - 1])
+        else:
+            items = []
+            for chrom in chroms[i:j]:
+                rec = self._fasta[chrom.number]
+                items.append((rec.body, len(rec), rec.lenc, rec.lenb, plan_descriptors(chrom), rec.name, rec.long_name))
+            fasta, vcf, empty, last_line = eng.batch_run(items)
+            last = self._fasta[chroms[j - 1].number]
+            bpl_last = self._fasta.faidx.index[last.name].lenc
         for k in np.flatnonzero(empty):
-            self._warn_empty(chroms[int(k)])
-        last = self._fasta[chroms[-1].number]
-        self._fasta_writer.write_records(fasta, self._fasta.faidx.index[last.name].lenc, last_line)
+            self._warn_empty(chroms[i + int(k)])
+        self._fasta_writer.write_records(fasta, bpl_last, last_line)
         self._vcf_writer.write_raw(memoryview(vcf))
+
+    def _batch_table(self, chroms, i, j):
+        """``msim_batch_contig`` + ``msim_range`` tables of contigs [i, j) by array operations -- no Python per contig --
+        when every contig is the std range over its whole length (ARGS mode: ``StdChromosomes``) and its defline can be
+        handed over as it sits in the file.  None: the caller builds the batch contig by contig."""
+        from .rmt import StdChromosomes
+        fa = self._fasta
+        tab = getattr(fa, "index_table", None)
+        if not isinstance(chroms, StdChromosomes) or tab is None or getattr(fa, "name_bytes", None) is None:
+            return None
+        tab, names = tab[i:j], fa.name_bytes[i:j]
+        n = j - i
+        hlen = (tab["h1"] - tab["h0"]).astype(np.int64)
+        if n == 0 or (names[:, 1] <= 0).any() or (hlen <= 0).any() or hlen.max() >= (1 << 31):
+            return None
+        ms = chroms.std
+        probe = range_descriptor(type("RD", (), {"start": 0, "stop": 0, "mutation_settings": ms})())   # (fills the settings cache)
+        del probe
+        _, rate_sum, tmpl = _SETTINGS_CACHE[_settings_key(ms)]
+        lens = tab["n_bases"].astype(np.int64)
+        ranges = np.empty(n, dtype=_ffi.RANGE_DTYPE)
+        ranges[:] = np.frombuffer(tmpl, dtype=_ffi.RANGE_DTYPE)[0]
+        ranges["start"] = 0
+        ranges["stop"] = lens - 1
+        k = (lens.astype(np.float64) * rate_sum).astype(np.int64)          # int(((stop - start) + 1) * sum(rates))  mutator.py:225
+        ranges["k"] = k
+        ranges["setsize"] = sample_setsize_array(k)
+        base = fa.text.ctypes.data
+        t = np.zeros(n, dtype=_ffi.BATCH_CONTIG_DTYPE)
+        t["body"] = base + tab["b0"]
+        t["body_bytes"] = tab["b1"] - tab["b0"]
+        t["n_bases"] = tab["n_bases"]
+        t["lenc"] = tab["lenc"]
+        t["lenb"] = tab["lenb"]
+        t["ranges"] = ranges.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(_ffi.RANGE_DTYPE.itemsize)
+        t["n_ranges"] = 1 if ms.has_mutations else 0                    # (plan_descriptors: ranges whose settings mutate)
+        t["header"] = base + tab["h0"]
+        t["header_len"] = hlen
+        t["name"] = base + tab["h0"] + names[:, 0].astype(np.uint64)
+        t["name_len"] = names[:, 1]
+        return t, ranges, fa.text
 
     def _mutate_one(self, eng, chrom, earlier=()):
         """One contig through PLAN + APPLY + egress.  A device PLAN engine sizes its stream windows with 16-sigma
@@ -232,7 +303,7 @@ class Mutator:
             export_python_streams(eng)                 # Python's generators still hold the states the run started with
             eng.set_plan_mode(_ffi.PLAN_HOST)
             try:
-                for prev in earlier:
+                for prev in (earlier[0][q] for q in range(earlier[1])) if earlier else ():
                     rec = self._fasta[prev.number]
                     # PLAN reads lengths and ranges only, never bases: any contig of the same length stands in
                     eng.plan_contig(eng.add_contig_synthetic(len(rec), 0), plan_descriptors(prev))
@@ -293,20 +364,35 @@ class Mutator:
 
     def _units(self, chroms):
         """mutate()'s contig loop (mutator.py:111-141) cut into units of work: a run of >= 2 small contigs (ONE pass through
-        libmsim, msim_batch_run) or a single contig.  Units are also what a multi-GPU run shards (multi_gpu.py)."""
-        out, i = [], 0
-        while i < len(chroms):
-            j, total = i, 0
-            while (j < len(chroms) and j - i < BATCH_MAX_CONTIGS and self._batchable(chroms[j])
-                   and total + len(self._fasta[chroms[j].number]) <= BATCH_MAX_BASES):
-                total += len(self._fasta[chroms[j].number])
-                j += 1
-            if j - i >= 2:
-                out.append((i, j))
-                i = j
-            else:
-                out.append((i, i + 1))
-                i += 1
+        libmsim, msim_batch_run; at most BATCH_MAX_CONTIGS contigs and BATCH_MAX_BASES bases) or a single contig.  Units are
+        also what a multi-GPU run shards (multi_gpu.py).  Array operations only where the contigs are the std ones."""
+        from .rmt import StdChromosomes
+        n = len(chroms)
+        tab = getattr(self._fasta, "index_table", None)
+        if (isinstance(chroms, StdChromosomes) and tab is not None and len(tab) == n
+                and type(self)._batchable is Mutator._batchable):
+            lens = tab["n_bases"].astype(np.int64)
+            ok = ((tab["flags"] & _ffi.FASTA_NONUNIFORM) == 0) & (lens > 0) & (lens <= BATCH_MAX_LEN) & (tab["lenc"] > 0)
+        else:
+            lens = np.fromiter((len(self._fasta[c.number]) for c in chroms), dtype=np.int64, count=n)
+            ok = np.fromiter((self._batchable(c) for c in chroms), dtype=bool, count=n)
+        cum = np.concatenate(([0], np.cumsum(lens)))
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], ok.astype(np.int8), [0]))))
+        out, pos = [], 0
+        for a, b in zip(edges[0::2].tolist(), edges[1::2].tolist()):      # maximal runs of batchable contigs
+            out.extend((q, q + 1) for q in range(pos, a))
+            i = a
+            while i < b:
+                j = int(np.searchsorted(cum, cum[i] + BATCH_MAX_BASES, side="right")) - 1
+                j = min(j, b, i + BATCH_MAX_CONTIGS)
+                if j - i >= 2:
+                    out.append((i, j))
+                    i = j
+                else:
+                    out.append((i, i + 1))
+                    i += 1
+            pos = b
+        out.extend((q, q + 1) for q in range(pos, n))
         return out
 
     def _process_unit(self, eng, chroms, i, j):
@@ -315,13 +401,19 @@ class Mutator:
         if j - i >= 2:
             saved = (eng.get_mt_state(0), eng.get_mt_state(1))
             try:
-                self._mutate_batch(eng, chroms[i:j])
+                self._mutate_batch(eng, chroms, i, j)
                 return
             except (KeyError, ValueError):
                 eng.set_mt_state(0, *saved[0])
                 eng.set_mt_state(1, *saved[1])
         for k in range(i, j):
-            self._mutate_one(eng, chroms[k], earlier=chroms[:k])
+            self._mutate_one(eng, chroms[k], earlier=(chroms, k))
+
+    def _chromosomes(self):
+        """The contigs in the order of the pass: the settings' own sequence (a list, or the lazy ``StdChromosomes``)."""
+        from .rmt import StdChromosomes
+        ch = self._sim.chromosomes
+        return ch if isinstance(ch, StdChromosomes) else list(ch)
 
     def mutate(self):
         if int(getattr(self._args, "gpus", 1) or 1) > 1 and self._engine is None:
@@ -334,7 +426,7 @@ class Mutator:
         eng.set_params(params_descriptor(self._sim))
         eng.reset_stats()
         try:
-            chroms = list(self._sim.chromosomes)
+            chroms = self._chromosomes()
             for i, j in self._units(chroms):
                 self._process_unit(eng, chroms, i, j)
         finally:

@@ -181,6 +181,40 @@ class ChromosomeSettings:
             i += 1
 
 
+class StdChromosomes:
+    """``SimulationSettings.chromosomes`` when no contig has range definitions of its own (ARGS mode): contig i is ONE
+    range [0, len_i - 1] with the std settings (what ``_fill_missing_chroms`` would append, rmt.py:353-359).  The
+    ``ChromosomeSettings`` objects are made on demand -- an assembly has 10^5 contigs and the batch path of the mutation
+    pass never looks at them one by one -- and behave like the list they replace (len, index, slice, iteration)."""
+
+    def __init__(self, lengths, std: MutationSettings, std_it):
+        self.lengths = lengths
+        self.std = std
+        self.std_it = std_it
+
+    def __len__(self) -> int:
+        return len(self.lengths)
+
+    def _make(self, i: int) -> ChromosomeSettings:
+        return ChromosomeSettings(i, self.std_it, [RangeDefinition(0, int(self.lengths[i]) - 1, self.std)])
+
+    def __getitem__(self, key):
+        if isinstance(key, slice):
+            return [self._make(i) for i in range(*key.indices(len(self)))]
+        n = len(self)
+        if key < 0:
+            key += n
+        if not 0 <= key < n:
+            raise IndexError("chromosome index out of range")
+        return self._make(key)
+
+    def __iter__(self):
+        return (self._make(i) for i in range(len(self)))
+
+    def __repr__(self) -> str:
+        return repr(list(self))
+
+
 class SimulationSettings:
     """Everything the mutation pass needs (rmt.py:261-776)."""
 
@@ -298,8 +332,11 @@ class SimulationSettings:
                   titv=args.transitionstransversions, species_name=args.species,
                   assembly_name=args.assembly, sample_name=args.sample,
                   ignore_warnings=ignore_warnings)
-        sim._fill_missing_chroms(fasta)
-        sim._sort()
+        # no contig is listed: every one is the std range over its whole length (lazily, see StdChromosomes)
+        table = getattr(fasta, "index_table", None)
+        lengths = (table["n_bases"] if table is not None and len(table) == len(fasta.keys())
+                   else [len(fasta[i]) for i in range(len(list(fasta.keys())))])
+        sim.chromosomes = StdChromosomes(lengths, sim._std, sim._std_it)
         return sim
 
     @classmethod
@@ -337,11 +374,15 @@ class SimulationSettings:
     # ------------------------------------------------------------------ queries
     @property
     def has_mutations(self) -> bool:
+        if isinstance(self.chromosomes, StdChromosomes):
+            return len(self.chromosomes) > 0 and self._std.has_mutations
         return any(rd.mutation_settings.has_mutations
                    for c in self.chromosomes for rd in c.range_definitions)
 
     @property
     def has_it(self) -> bool:
+        if isinstance(self.chromosomes, StdChromosomes):
+            return len(self.chromosomes) > 0 and bool(self._std_it)
         return any(c.it_rate for c in self.chromosomes)
 
 

@@ -71,8 +71,7 @@ class VcfWriter:
                  f"##filedate={now.year}{now.month}{now.day}\n",      # unpadded, as the reference
                  "##source=Mutation-Simulator\n",
                  f"##reference={input_fasta}\n"]
-        for key in list(fasta.keys()):
-            rec = fasta[key]
+        for rec in (fasta if hasattr(fasta, "index_table") else (fasta[key] for key in list(fasta.keys()))):
             lines.append(f"##contig=<ID={rec.name},length={len(rec)},assembly={assembly_name},"
                          f"species=\"{species_name}\">\n")
         lines.append(_HEADER_TAIL)

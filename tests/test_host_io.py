@@ -142,3 +142,67 @@ def test_writer_errors(tmp_path):
         msa.FastaWriter(tmp_path / "nodir" / "x.fa")
     with pytest.raises(msa.VcfWriterError, match="Cannot write to VCF file"):
         msa.VcfWriter(tmp_path / "nodir" / "x.vcf")
+
+
+# ---------------------------------------------------------------------- the batch path's array formulations
+def test_sample_setsize_array_equals_cpythons_float_expression():
+    """``sample_setsize_array`` (integers) against ``sample_setsize`` (CPython's ``21 + 4 ** ceil(log(3 k, 4))``) around every
+    power of four and on random counts."""
+    import numpy as np
+    from mutation_simulator_amd import mutator as mm
+    ks = list(range(0, 3000))
+    for m in range(1, 18):                               # (k < 2**33: contigs are below 4 GiB, k below half of that)
+        ks += [4 ** m // 3 + d for d in range(-3, 4)]
+    ks += [int(x) for x in np.random.RandomState(3).randint(1, 2 ** 33, size=20000)]
+    ks = np.array([k for k in ks if k >= 0], dtype=np.int64)
+    assert np.array_equal(mm.sample_setsize_array(ks), np.array([mm.sample_setsize(int(k)) for k in ks]))
+
+
+def test_units_by_arrays_equal_units_by_contig(tmp_path, monkeypatch):
+    """The vectorised cut of the contig loop into batches / single contigs (ARGS mode) against the per-contig greedy rule, on
+    assemblies with runs of small contigs, large ones in between, and caps that bite."""
+    import numpy as np
+    import mutation_simulator_amd as msa
+    from mutation_simulator_amd import mutator as mm
+    rs = np.random.RandomState(11)
+    parts = []
+    for i in range(700):
+        L = int(rs.choice([0, 1, 50, 900, 5_000, 30_000]))
+        if i in (100, 101, 350):
+            L = 70_000
+        seq = rs.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=L).tobytes()
+        nl = b"\r\n" if i % 97 == 0 else b"\n"
+        body = nl.join(seq[a:a + 60] for a in range(0, L, 60))
+        if i % 53 == 0 and L > 200:                      # mixed terminators: not batchable
+            body = body.replace(b"\n", b"\r\n", 1) if nl == b"\n" else body
+        parts.append(b">s%d\n" % i + body + (nl if L else b""))
+    fa = tmp_path / "a.fa"
+    fa.write_bytes(b"".join(parts))
+    monkeypatch.setattr(mm, "BATCH_MAX_LEN", 40_000)
+    args = msa.get_args(["-q", "-o", str(tmp_path / "o"), str(fa), "args", "-sn", "0.01"])
+    fasta = msa.load_fasta(args.infile)
+    sim = msa.SimulationSettings.from_args(args, fasta, True)
+    m = msa.Mutator(args, fasta, sim)
+    hit_count_cap = hit_bases_cap = False
+    for max_contigs, max_bases in ((37, 120_000), (11, 10_000_000)):
+        monkeypatch.setattr(mm, "BATCH_MAX_CONTIGS", max_contigs)
+        monkeypatch.setattr(mm, "BATCH_MAX_BASES", max_bases)
+        lazy = m._units(sim.chromosomes)
+        plain = m._units(list(sim.chromosomes))
+        # the per-contig greedy rule, spelled out
+        chroms, want, i = list(sim.chromosomes), [], 0
+        while i < len(chroms):
+            j, total = i, 0
+            while (j < len(chroms) and j - i < max_contigs and m._batchable(chroms[j])
+                   and total + len(fasta[chroms[j].number]) <= max_bases):
+                total += len(fasta[chroms[j].number])
+                j += 1
+            if j - i >= 2:
+                want.append((i, j)); i = j
+            else:
+                want.append((i, i + 1)); i += 1
+        assert lazy == plain == want
+        hit_count_cap |= any(j - i == max_contigs for i, j in lazy)
+        hit_bases_cap |= any(2 <= j - i < max_contigs for i, j in lazy)
+    m.close()
+    assert hit_count_cap and hit_bases_cap
