@@ -83,18 +83,20 @@ class _FaidxIndex(Mapping):
     """``fasta.faidx.index``: name -> (rlen, offset, lenc, lenb), built on demand (an assembly has 10^5 records; the
     mutation pass asks for a handful of line widths)."""
 
-    def __init__(self, records: dict):
-        self._records = records
+    def __init__(self, fasta: "Fasta"):
+        self._fasta = fasta
 
     def __getitem__(self, name):
-        r = self._records[name]
-        return SimpleNamespace(rlen=len(r), offset=r.offset, lenc=r.lenc, lenb=r.lenb)
+        row = self._fasta.index_table[self._fasta._by_name[name]]
+        has = bool(row["flags"] & 1)
+        return SimpleNamespace(rlen=int(row["n_bases"]) if has else 0, offset=int(row["b0"]),
+                               lenc=int(row["lenc"]) if has else 0, lenb=int(row["lenb"]) if has else 0)
 
     def __iter__(self):
-        return iter(self._records)
+        return iter(self._fasta._by_name)
 
     def __len__(self):
-        return len(self._records)
+        return len(self._fasta._by_name)
 
 
 class Fasta:
@@ -116,12 +118,13 @@ class Fasta:
             raw = np.zeros(0, np.uint8)
         self.text = raw                                # the whole file text (the batch path hands spans of it to libmsim)
         self.text_bytes = size
-        self.index_table = None                        # msim_fasta_record per record, file order (numpy structured array)
-        self.name_bytes = None                         # per record: where its name (first token of the defline) sits in it
-        self._records: dict[str, FastaRecord] = {}
-        self._order: list[FastaRecord] = []
+        self.index_table = _ffi_empty_index()          # msim_fasta_record per record, file order (numpy structured array)
+        self.name_bytes = np.zeros((0, 2), dtype=np.int64)   # per record: where its name (first token of the defline) sits in it
+        self._names: list[str] = []
+        self._by_name: dict[str, int] = {}
+        self._cache: dict[int, FastaRecord] = {}
         self._parse(raw)
-        self.faidx = SimpleNamespace(index=_FaidxIndex(self._records))
+        self.faidx = SimpleNamespace(index=_FaidxIndex(self))
         if write_index:
             self._write_fai()
 
@@ -129,7 +132,8 @@ class Fasta:
     def _parse(self, raw: np.ndarray) -> None:
         """The index pass runs in libmsim (csrc/fasta_index.cpp: msim_fasta_index, several host threads): per record the
         spans of the defline and of the body text, bases, bases / bytes per line and pyfaidx's line-length verdict.  A
-        3 Gb genome has 24 records, an assembly tens of thousands -- the loop below is all the per-record Python left."""
+        3 Gb genome has 24 records, an assembly hundreds of thousands: per record this loop only takes the NAME out of the
+        defline (duplicates are an error, like pyfaidx's) -- ``FastaRecord`` objects are made when somebody asks for one."""
         from . import _ffi
         if raw.shape[0] == 0:
             return
@@ -137,61 +141,110 @@ class Fasta:
         if idx is None:
             raise FastaIndexingError("Sequence data found before the first defline")
         self.index_table = idx
-        h0, h1, b0, b1 = (idx[k].tolist() for k in ("h0", "h1", "b0", "b1"))
-        n_bases, lenc, lenb, flags = (idx[k].tolist() for k in ("n_bases", "lenc", "lenb", "flags"))
-        whole = raw.tobytes() if raw.shape[0] < (256 << 20) and idx.shape[0] > 1000 else None   # (deflines of an assembly: one copy
-        name_bytes = []                                                                         #  beats 10^5 tiny ones)
-        for k in range(idx.shape[0]):
-            hb = whole[h0[k]:h1[k]] if whole is not None else raw[h0[k]:h1[k]].tobytes()
-            long_name = hb.decode("utf-8", "replace")
-            toks = long_name.split()
-            name = toks[0] if toks else ""
-            nb = name.encode("utf-8")                  # where the name sits in the file text (the batch path points libmsim at it)
-            at = hb.find(nb) if nb else -1
-            name_bytes.append((at, len(nb)) if at >= 0 and long_name.encode("utf-8", "replace") == hb else (-1, 0))
-            if name in self._records:
+        n = idx.shape[0]
+        h0 = idx["h0"].astype(np.int64)
+        hl = idx["h1"].astype(np.int64) - h0
+        # every defline in one gather (they are tiny next to the bodies)
+        starts = np.concatenate(([0], np.cumsum(hl)))
+        total = int(starts[-1])
+        gather = np.arange(total, dtype=np.int64) + np.repeat(h0 - starts[:-1], hl)
+        blob = raw[gather].tobytes() if total else b""
+        try:
+            text = blob.decode("ascii")
+        except UnicodeDecodeError:
+            text = None
+        flags = idx["flags"].tolist()
+        offs = starts.tolist()
+        names, by_name = self._names, self._by_name
+        where = np.empty((n, 2), dtype=np.int64)
+        for k in range(n):
+            o, e = offs[k], offs[k + 1]
+            if text is not None:
+                long_name = text[o:e]
+                toks = long_name.split(None, 1)
+                name = toks[0] if toks else ""
+                at, nb = (len(long_name) - len(long_name.lstrip()), len(name)) if toks else (-1, 0)
+            else:
+                hb = blob[o:e]
+                long_name = hb.decode("utf-8", "replace")
+                toks = long_name.split(None, 1)
+                name = toks[0] if toks else ""
+                enc = name.encode("utf-8")
+                at = hb.find(enc) if enc else -1
+                at, nb = (at, len(enc)) if at >= 0 and long_name.encode("utf-8", "replace") == hb else (-1, 0)
+            if name in by_name:
                 raise ValueError(f"Duplicate key \"{name}\"")
             fl = flags[k]
+            if (fl & _ffi.FASTA_HAS_BODY) and (fl & _ffi.FASTA_BAD_LINES):
+                raise FastaIndexingError(f"Line length of fasta file is not consistent in {name}")
+            by_name[name] = k
+            names.append(name)
+            where[k, 0], where[k, 1] = at, nb
+        self.name_bytes = where
+
+    def _record(self, k: int) -> FastaRecord:
+        rec = self._cache.get(k)
+        if rec is None:
+            from . import _ffi
+            row = self.index_table[k]
+            long_name = self.text[int(row["h0"]):int(row["h1"])].tobytes().decode("utf-8", "replace")
+            fl = int(row["flags"])
             if not fl & _ffi.FASTA_HAS_BODY:
-                rec = FastaRecord(name, long_name, np.zeros(0, np.uint8), 0, 0, 0, b0[k], True)
+                rec = FastaRecord(self._names[k], long_name, np.zeros(0, np.uint8), 0, 0, 0, int(row["b0"]), True)
             else:
-                if fl & _ffi.FASTA_BAD_LINES:
-                    raise FastaIndexingError(
-                        f"Line length of fasta file is not consistent in {name}")
-                rec = FastaRecord(name, long_name, raw[b0[k]:b1[k]], n_bases[k], lenc[k], lenb[k], b0[k],
-                                  not fl & _ffi.FASTA_NONUNIFORM)
-            self._records[name] = rec
-            self._order.append(rec)
-        self.name_bytes = np.array(name_bytes, dtype=np.int64).reshape(-1, 2)    # (offset inside the defline, bytes) or (-1, 0)
+                rec = FastaRecord(self._names[k], long_name, self.text[int(row["b0"]):int(row["b1"])], int(row["n_bases"]),
+                                  int(row["lenc"]), int(row["lenb"]), int(row["b0"]), not fl & _ffi.FASTA_NONUNIFORM)
+            if len(self._cache) > (1 << 20):           # (bounded: an assembly is walked once, front to back)
+                self._cache.clear()
+            self._cache[k] = rec
+        return rec
 
     def _write_fai(self) -> None:
         path = self.filename + ".fai"
         if os.path.exists(path):
             return
         try:
+            t = self.index_table
+            has = (t["flags"] & 1) != 0
+            cols = zip(self._names, np.where(has, t["n_bases"], 0).tolist(), t["b0"].tolist(),
+                       np.where(has, t["lenc"], 0).tolist(), np.where(has, t["lenb"], 0).tolist())
             with open(path, "w") as fh:
-                for r in self._order:
-                    fh.write(f"{r.name}\t{len(r)}\t{r.offset}\t{r.lenc}\t{r.lenb}\n")
+                fh.write("".join(f"{a}\t{b}\t{c}\t{d}\t{e}\n" for a, b, c, d, e in cols))
         except OSError:
             pass
 
     # ------------------------------------------------------------------ pyfaidx-like surface
     def keys(self):
-        return self._records.keys()
+        return self._by_name.keys()
 
     def __len__(self) -> int:
-        return len(self._order)
+        return len(self._names)
 
     def __getitem__(self, key) -> FastaRecord:
         if isinstance(key, (int, np.integer)):
-            return self._order[key]
-        return self._records[key]
+            k = int(key)
+            if k < 0:
+                k += len(self._names)
+            if not 0 <= k < len(self._names):
+                raise IndexError("record index out of range")
+            return self._record(k)
+        return self._record(self._by_name[key])
 
     def __iter__(self):
-        return iter(self._order)
+        return (self._record(k) for k in range(len(self._names)))
+
+    def names_and_lengths(self):
+        """(name, bases) of every record in file order, without making the record objects."""
+        t = self.index_table
+        return zip(self._names, np.where((t["flags"] & 1) != 0, t["n_bases"], 0).tolist())
 
     def get_seq(self, name: str, start: int, end: int) -> str:
-        return self._records[name][start - 1:end]
+        return self[name][start - 1:end]
 
     def close(self) -> None:
         pass                                           # (the mapping goes with the last array that views it)
+
+
+def _ffi_empty_index():
+    from . import _ffi
+    return np.zeros(0, dtype=_ffi.FASTA_RECORD_DTYPE)

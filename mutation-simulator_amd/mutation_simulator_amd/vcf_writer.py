@@ -71,8 +71,12 @@ class VcfWriter:
                  f"##filedate={now.year}{now.month}{now.day}\n",      # unpadded, as the reference
                  "##source=Mutation-Simulator\n",
                  f"##reference={input_fasta}\n"]
-        for rec in (fasta if hasattr(fasta, "index_table") else (fasta[key] for key in list(fasta.keys()))):
-            lines.append(f"##contig=<ID={rec.name},length={len(rec)},assembly={assembly_name},"
+        if hasattr(fasta, "names_and_lengths"):          # (our loader: no record object per contig of an assembly)
+            pairs = fasta.names_and_lengths()
+        else:
+            pairs = ((fasta[key].name, len(fasta[key])) for key in list(fasta.keys()))
+        for name, length in pairs:
+            lines.append(f"##contig=<ID={name},length={length},assembly={assembly_name},"
                          f"species=\"{species_name}\">\n")
         lines.append(_HEADER_TAIL)
         lines.append(f"#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{sample_name}\n")
