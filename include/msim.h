@@ -289,6 +289,9 @@ int msim_planned_out_len(msim_ctx *ctx, int contig, uint64_t *out_len, int *know
 /* Slot i = contig contig_ids[i] (this context's id), applied by rank owner[i], out_len[i] bytes.  Synchronises, then
  * moves every slot to `root`.  device_addrs[i] (optional) = where slot i now lives on this rank: the contig's own
  * buffer (owner), a receive buffer of the context (root), 0 elsewhere.  Valid until the next gather / clear.   */
+/* A failure of this call on ONE rank (a slot that rank has not applied, a length that disagrees with its result) is fatal
+ * for the communicator: its peers have posted the matching transfers and wait for them.  Tear the communicator down
+ * (msim_comm_destroy on every rank) -- agree on the slots over the control plane first, as gather.Communicator does.      */
 int msim_gather_to_root(msim_ctx *ctx, int n, const int *contig_ids, const int *owner, const uint64_t *out_len,
                         int root, uint64_t *device_addrs);
 /* The transfers `rank` posts for that gather, without touching a GPU: ops[4k..] = kind (0 send, 1 recv, 2 already

@@ -1101,7 +1101,14 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     rc = new_contig(c, total, &g);
     if (rc) return rc;
     const int gid = (int)c->contigs.size() - 1;
-    auto drop = [&]() { (void)free_contig(c, c->contigs[(size_t)gid], false); c->contigs.pop_back(); };
+    // the temporary super-contig leaves the context on EVERY way out of this block (HIP failures included: a contig left
+    // behind would leak its device buffers and shift the ids of the caller's later contigs)
+    struct Drop {
+        Ctx *c; int gid; bool armed = true;
+        void now() { if (armed) { armed = false; (void)free_contig(c, c->contigs[(size_t)gid], false); c->contigs.pop_back(); } }
+        ~Drop() { now(); }
+    } guard{c, gid};
+    auto drop = [&]() { guard.now(); };
     if (total) MSIM_HIP(c, hipMemcpyAsync(g->d_in + PAD, B.h_in, total, hipMemcpyHostToDevice, c->stream));
     g->n_rec = recs_abs.size();
     g->pool_len = B.pool.size();

@@ -137,7 +137,10 @@ class Fasta:
         from . import _ffi
         if raw.shape[0] == 0:
             return
-        idx = _ffi.fasta_index(raw)
+        try:
+            idx = _ffi.fasta_index(raw)
+        except _ffi.MsimError:                         # no loadable libmsim (a host without ROCm): tooling that only wants
+            idx = _index_python(raw, _ffi)             # the loader still gets its index, from the plain restatement below
         if idx is None:
             raise FastaIndexingError("Sequence data found before the first defline")
         self.index_table = idx
@@ -243,6 +246,48 @@ class Fasta:
 
     def close(self) -> None:
         pass                                           # (the mapping goes with the last array that views it)
+
+
+def _index_python(raw: np.ndarray, _ffi):
+    """``msim_fasta_index`` restated line by line in Python (slow: a fallback for hosts where libmsim.so cannot be loaded,
+    and what tests/test_fasta_index.py checks the native pass against).  Same result array, or None for sequence text
+    before the first defline."""
+    text = raw.tobytes()
+    lines, at = [], 0
+    while at < len(text):
+        e = text.find(b"\n", at)
+        if e < 0:
+            e = len(text)
+        lines.append((at, e))
+        at = e + 1
+    recs, cur = [], None
+    for a, e in lines:
+        if text[a:a + 1] == b">":
+            cr = e > a + 1 and text[e - 1:e] == b"\r"
+            cur = [a + 1, e - cr, e + 1, []]
+            recs.append(cur)
+        elif cur is None:
+            if e > a:
+                return None
+        else:
+            cr = e > a and text[e - 1:e] == b"\r"
+            cur[3].append((a, e, e - a - cr, cr))
+    out = np.zeros(len(recs), dtype=_ffi.FASTA_RECORD_DTYPE)
+    for k, (h0, h1, after, ls) in enumerate(recs):
+        out["h0"][k], out["h1"][k] = h0, h1
+        if not ls:
+            out["b0"][k] = out["b1"][k] = after
+            continue
+        lenc, first_cr = ls[0][2], ls[0][3]
+        nz = [i for i, l in enumerate(ls) if l[2] > 0]
+        last = nz[-1] if nz else -1
+        bad = any(l[2] != lenc for l in ls[:max(last, 0)]) or (last >= 0 and ls[last][2] > lenc)
+        nonuni = any(l[3] != first_cr for l in ls[:max(last, 0)])
+        out["b0"][k], out["b1"][k] = ls[0][0], ls[-1][1]
+        out["n_bases"][k] = sum(l[2] for l in ls)
+        out["lenc"][k], out["lenb"][k] = lenc, ls[0][1] - ls[0][0] + 1
+        out["flags"][k] = 1 | (2 if bad else 0) | (4 if nonuni else 0)
+    return out
 
 
 def _ffi_empty_index():

@@ -96,6 +96,19 @@ def test_index_matches_line_by_line_restatement(seed):
         _check(_random_text(rs, int(rs.randint(0, 12))))
 
 
+def test_python_fallback_index_equals_the_native_pass():
+    """``fasta_io._index_python`` (used when libmsim.so cannot be loaded) against ``msim_fasta_index``."""
+    from mutation_simulator_amd import fasta_io
+    rs = np.random.RandomState(77)
+    for _ in range(60):
+        text = _random_text(rs, int(rs.randint(0, 9)))
+        raw = np.frombuffer(text, dtype=np.uint8)
+        want, got = _ffi.fasta_index(raw), fasta_io._index_python(raw, _ffi)
+        assert (want is None) == (got is None)
+        if want is not None:
+            assert want.tobytes() == got.tobytes()
+
+
 def test_index_edge_texts():
     for text in [b"", b"\n\n", b">", b">\n", b">a", b">a\n", b">a\nACGT", b">a\r\nAC\r\nGT\r\n", b"ACGT\n>a\nAC\n", b"\r\n>a\nAC\n",
                  b">a\n\n\nAC\n", b">a\nAC\n\nAC\n", b">a\nACG\nAC\nA\n", b">a\nAC\nACG\n", b">a\n>b\n>c\nA\n", b">a\nAC>GT\nAC\n"]:
