@@ -531,11 +531,14 @@ __device__ __forceinline__ void fix_merge(uint8_t *tile, uint32_t tile0, uint32_
 }
 
 template <int CAP>
-__device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t cnt, int32_t n_struct, uint8_t *tile,
+__device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t n_win, uint8_t *tile,
                                                  uint32_t *wtmp, const uint8_t *__restrict__ in,
                                                  uint8_t *__restrict__ out, const uint8_t *__restrict__ pool,
                                                  const uint8_t *lut, uint64_t tile0_64, uint64_t L_out,
-                                                 unsigned long long *err) {
+                                                 unsigned long long *err, const msim_record *__restrict__ recs,
+                                                 const uint32_t *__restrict__ off, int32_t r_lo, int32_t r_hi,
+                                                 uint32_t my_snp_o, uint32_t my_snp_aux, uint32_t my_snp_pos) {
+    const int32_t n_struct = n_win;
     const uint32_t INF = 0xffffffffu;
     const uint32_t tile0 = (uint32_t)tile0_64;
     const uint32_t tile_end = (uint32_t)min<uint64_t>(tile0_64 + TILE, L_out);
@@ -545,7 +548,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
     uint32_t *idx = reinterpret_cast<uint32_t *>(tile);
     *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x) = u32x4{0, 0, 0, 0};
     __syncthreads();
-    for (int32_t q = threadIdx.x; q < cnt; q += THREADS) {
+    for (int32_t q = threadIdx.x; q < n_win; q += THREADS) {
         const uint32_t o = win.o[q];
         const uint32_t g = o <= tile0 ? 0u : (o - tile0 + 15u) >> 4;
         if (g < (uint32_t)(TILE / GROUP)) atomicMax(&idx[g], (uint32_t)q + 1u);
@@ -595,12 +598,12 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
         if (u >= 2 * n_struct || (MSIM_ABL & 2)) return;
         const int32_t k = u >> 1;
         const bool run = u & 1;
-        const uint32_t q = win.m[k] >> 16;
+        const uint32_t q = (uint32_t)k;                    // (the window holds the structural records only, in order)
         const uint32_t oj = win.o[q], ej = win.e[q], sj = win.s[q], mj = win.m[q] & 0xffffu;
         uint32_t p = oj, end = ej;
         if (run) {
             p = ej;
-            end = k + 1 < n_struct ? win.o[win.m[k + 1] >> 16] : INF;   // later records start beyond this tile
+            end = k + 1 < n_struct ? win.o[k + 1] : INF;   // later records start beyond this tile
         }
         if (end <= p || p < tile0 || p >= tile_end || !(p & 15u)) return;
         f.on = true;
@@ -631,14 +634,24 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
         if (f.on) fix_merge(tile, tile0, f.p, f.end, piece_finish(piece_load(f.ps), f.ps.mode, lut));
     }
     __syncthreads();
-    // ---- pass B2: SNP bytes, one lane per record (mutator.py:334-341, 428-463)
-    for (int32_t q = threadIdx.x; q < ((MSIM_ABL & 4) ? 0 : cnt); q += THREADS) {
-        const uint32_t mj = win.m[q] & 0xffffu;
-        const uint32_t o = win.o[q];
-        if ((mj & 0xff) != MSIM_SN || o < tile0 || o >= tile_end) continue;
+    // ---- pass B2: SNP bytes, one lane per record (mutator.py:334-341, 428-463).  The SNPs are not in the window: an
+    // SNP does not break a copy run, so nothing above needs it -- a lane reads its record (and offset) from the table,
+    // coalesced and fresh in L2 from the window fill.  A tile of a hot spot with a thousand SNPs costs four rounds here.
+    // (the first THREADS records of the tile are still in registers from the window fill: my_snp_*)
+    if (!(MSIM_ABL & 4) && my_snp_aux != 0xffffffffu && my_snp_o >= tile0 && my_snp_o < tile_end) {
+        const uint32_t x = tile[my_snp_o - tile0];
+        const uint32_t nb = lut[my_snp_aux * 256 + x];
+        if (nb == 0 && my_snp_aux != 0) report_key_error(err, (uint64_t)my_snp_pos, lut[768 + x]);
+        else tile[my_snp_o - tile0] = (uint8_t)nb;
+    }
+    for (int32_t j = r_lo + THREADS + (int32_t)threadIdx.x; j <= ((MSIM_ABL & 4) ? r_lo - 1 : r_hi); j += THREADS) {
+        const msim_record r = recs[j];
+        if (r.type != MSIM_SN) continue;
+        const uint32_t o = off ? off[j] : r.pos;
+        if (o < tile0 || o >= tile_end) continue;
         const uint32_t x = tile[o - tile0];
-        const uint32_t nb = lut[(mj >> 8) * 256 + x];
-        if (nb == 0 && (mj >> 8) != 0) report_key_error(err, (uint64_t)win.s[q], lut[768 + x]);
+        const uint32_t nb = lut[(uint32_t)r.aux * 256 + x];
+        if (nb == 0 && r.aux != 0) report_key_error(err, (uint64_t)r.pos, lut[768 + x]);
         else tile[o - tile0] = (uint8_t)nb;
     }
     __syncthreads();
@@ -676,41 +689,50 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 
     const int32_t r_lo = f0 < 0 ? 0 : f0;
     const int32_t r_hi = f1;
     const int32_t cnt = any_rec ? r_hi - r_lo + 1 : 0;
-    const bool in_lds = cnt <= CAP;
     __shared__ uint32_t wtmp[THREADS / 64];
-    int32_t n_struct = 0;
-    if (in_lds) {
-        // window fill + ORDERED list of the structural (non-SNP) records: sidx lives in the upper halves of win.m
-        uint16_t *m16 = reinterpret_cast<uint16_t *>(win.m);
+    // The window holds the tile's ANCHOR (record r_lo, whatever its type: the run that enters the tile starts there) and
+    // the structural (non-SNP) records behind it, in order -- compacted while the table is read (ballot + popcount).
+    // SNPs stay out: they do not break a copy run, and pass B2 patches them straight from the table.  So the window's
+    // capacity bounds the STRUCTURAL records of a tile; an SNP hot spot (hundreds of SNPs in a tile) costs no LDS.
+    int32_t n_win = 0;
+    uint32_t my_snp_o = 0, my_snp_aux = 0xffffffffu, my_snp_pos = 0;   // this lane's SNP among the tile's first THREADS records
+    {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         for (int32_t q0 = 0; q0 < cnt; q0 += THREADS) {
             const int32_t q = q0 + (int32_t)threadIdx.x;
-            bool is_struct = false;
+            bool keep = false;
+            msim_record r{};
+            uint32_t o = 0;
             if (q < cnt) {
-                const msim_record r = recs[r_lo + q];
-                const uint32_t o = off ? off[r_lo + q] : r.pos;
-                uint32_t e, s;
-                rec_view(r, o, e, s);
-                win.o[q] = o;
-                win.e[q] = e;
-                win.s[q] = s;
-                m16[2 * q] = (uint16_t)((uint32_t)r.type | ((uint32_t)r.aux << 8));
-                win.x[q] = (r.type == MSIM_TLI && (r.aux & 1)) ? r.stop : r.extra;
-                is_struct = r.type != MSIM_SN;
+                r = recs[r_lo + q];
+                o = off ? off[r_lo + q] : r.pos;
+                keep = q == 0 || r.type != MSIM_SN;
+                if (q0 == 0 && r.type == MSIM_SN) { my_snp_o = o; my_snp_aux = r.aux; my_snp_pos = r.pos; }
             }
-            const unsigned long long bal = __ballot(is_struct);
+            const unsigned long long bal = __ballot(keep);
             if (lane == 0) wtmp[wave] = (uint32_t)__popcll(bal);
             __syncthreads();
             uint32_t base = 0, total = 0;
             for (int w = 0; w < THREADS / 64; w++) { if (w < wave) base += wtmp[w]; total += wtmp[w]; }
-            if (is_struct) m16[2 * (n_struct + (int32_t)base + __popcll(bal & ((1ull << lane) - 1ull))) + 1] = (uint16_t)q;
+            const int32_t k = n_win + (int32_t)base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (keep && k < CAP) {
+                uint32_t e, sgm;
+                rec_view(r, o, e, sgm);
+                win.o[k] = o;
+                win.e[k] = e;
+                win.s[k] = sgm;
+                win.m[k] = (uint32_t)r.type | ((uint32_t)r.aux << 8);
+                win.x[k] = (r.type == MSIM_TLI && (r.aux & 1)) ? r.stop : r.extra;
+            }
             __syncthreads();
-            n_struct += (int32_t)total;
+            n_win += (int32_t)total;
         }
     }
+    const bool in_lds = n_win <= CAP;
     __syncthreads();
     if (in_lds) {
-        rewrite_tile_lds<CAP>(win, cnt, n_struct, tile, wtmp, in, out, pool, lut, tile0, L_out, err);
+        rewrite_tile_lds<CAP>(win, n_win, tile, wtmp, in, out, pool, lut, tile0, L_out, err, recs, off, r_lo, r_hi,
+                              my_snp_o, my_snp_aux, my_snp_pos);
     } else {
         RecAccess<false, CAP> A{&win, recs, off, r_lo};
         rewrite_tile<false, CAP>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
