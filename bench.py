@@ -308,7 +308,7 @@ def roofline_of(st, workload, steps):
     k_ms = st["apply_kernel_ms"]
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, source = None, None   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         tf = ROOT / "profiles" / name
         if tf.exists():
             try:
@@ -427,9 +427,9 @@ def main():
         sim = build_settings(workload, lengths)
         # msim_range table per contig: settings -> integers ONCE, outside the timed steps (the settings do not change
         # between steps; the CLI pays this once per run).  What that costs is reported next to the value
-        # ("descriptor_marshalling_ms": Python range_descriptor + ctypes array for every drawing range of the genome).
+        # ("descriptor_marshalling_ms": the msim_range table of every contig, mutator.plan_table).
         t_m = time.perf_counter()
-        descs = {chrom.number: eng.range_table(mm.plan_descriptors(chrom)) for chrom in sim.chromosomes}
+        descs = {chrom.number: mm.plan_table(chrom) for chrom in sim.chromosomes}
         marshal_ms[workload] = round((time.perf_counter() - t_m) * 1e3, 3)
 
         def plan_descs(chrom):

@@ -309,14 +309,28 @@ class Engine:
         arr.n_ranges = len(ranges)
         return arr
 
+    @staticmethod
+    def _ranges_arg(ranges):
+        """(pointer, count, keep-alive) of a range table given as a list of ``Range``, a ctypes array or a numpy
+        ``RANGE_DTYPE`` table (``mutator.plan_table``)."""
+        if isinstance(ranges, np.ndarray):
+            if ranges.dtype != RANGE_DTYPE:
+                raise MsimError("range table of the wrong dtype")
+            ranges = np.ascontiguousarray(ranges)
+            return C.cast(C.c_void_p(ranges.ctypes.data), C.POINTER(Range)), int(ranges.shape[0]), ranges
+        arr = ranges if isinstance(ranges, C.Array) else Engine.range_table(ranges)
+        return arr, getattr(arr, "n_ranges", len(arr)), arr
+
     def plan_contig(self, contig: int, ranges):
-        arr = ranges if isinstance(ranges, C.Array) else self.range_table(ranges)
-        self._check(self.lib.msim_plan_contig(self.h, contig, arr, getattr(arr, "n_ranges", len(arr))), contig)
+        ptr, n, keep = self._ranges_arg(ranges)
+        self._check(self.lib.msim_plan_contig(self.h, contig, ptr, n), contig)
+        del keep
 
     def plan_chain(self, length: int, ranges):
         """Advance both streams over a contig this process does not mutate (multi-GPU: a rank that does not own it)."""
-        arr = ranges if isinstance(ranges, C.Array) else self.range_table(ranges)
-        self._check(self.lib.msim_plan_chain(self.h, length, arr, getattr(arr, "n_ranges", len(arr))))
+        ptr, n, keep = self._ranges_arg(ranges)
+        self._check(self.lib.msim_plan_chain(self.h, length, ptr, n))
+        del keep
 
     def set_plan_mode(self, mode: int):
         """0 = AUTO, PLAN_HOST = force the sequential host planner, PLAN_GPU = force a device engine."""

@@ -30,7 +30,8 @@ import numpy as np
 
 from . import _ffi
 from .fasta_writer import FastaWriter
-from .mutator import Mutator, export_python_streams, import_python_streams, params_descriptor, plan_descriptors
+from .mutator import (Mutator, export_python_streams, import_python_streams, params_descriptor, plan_descriptors,
+                      plan_table)
 from .sharding import lpt_partition
 from .vcf_writer import VcfWriter
 
@@ -98,7 +99,7 @@ class ShardWorker(Mutator):
         ``_mutate_one`` does: streams back to the run's start, everything up to k again through the host planner."""
         rec = self._fasta[chroms[k].number]
         try:
-            eng.plan_chain(len(rec), plan_descriptors(chroms[k]))
+            eng.plan_chain(len(rec), plan_table(chroms[k]))
         except _ffi.MsimError as e:
             if "overflowed its" not in str(e):
                 raise
@@ -107,7 +108,7 @@ class ShardWorker(Mutator):
             eng.set_plan_mode(_ffi.PLAN_HOST)
             try:
                 for prev in chroms[:k + 1]:
-                    eng.plan_chain(len(self._fasta[prev.number]), plan_descriptors(prev))
+                    eng.plan_chain(len(self._fasta[prev.number]), plan_table(prev))
             finally:
                 eng.set_plan_mode(_ffi.PLAN_AUTO)
 

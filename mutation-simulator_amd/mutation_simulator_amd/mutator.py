@@ -157,6 +157,40 @@ def plan_descriptors(chrom) -> list:
             if rd.mutation_settings.has_mutations]
 
 
+def plan_table(chrom) -> np.ndarray:
+    """``plan_descriptors`` as ONE ``msim_range`` table (numpy, ``_ffi.RANGE_DTYPE``), built with array operations: an RMT
+    file in the style of the reference's examples gives a contig thousands of ranges that share a handful of settings
+    objects -- the per-settings part is copied in bulk, ``k`` and ``setsize`` come from the same float / integer
+    expressions as ``range_descriptor`` (checked against it in the tests)."""
+    rds = [rd for rd in chrom.range_definitions if rd.mutation_settings.has_mutations]
+    n = len(rds)
+    out = np.zeros(n, dtype=_ffi.RANGE_DTYPE)
+    if n == 0:
+        return out
+    start = np.fromiter((rd.start for rd in rds), dtype=np.int64, count=n)
+    stop = np.fromiter((rd.stop for rd in rds), dtype=np.int64, count=n)
+    ids = np.fromiter((id(rd.mutation_settings) for rd in rds), dtype=np.int64, count=n)
+    rate = np.empty(n, dtype=np.float64)
+    uniq, first = np.unique(ids, return_index=True)
+    for u, f in zip(uniq.tolist(), first.tolist()):
+        ms = rds[f].mutation_settings
+        range_descriptor(rds[f])                                      # (fills the settings cache)
+        _, rate_sum, tmpl = _SETTINGS_CACHE[_settings_key(ms)]
+        sel = ids == u
+        out[sel] = np.frombuffer(tmpl, dtype=_ffi.RANGE_DTYPE)[0]
+        rate[sel] = rate_sum
+    out["start"] = start
+    out["stop"] = stop
+    k = (((stop - start) + 1).astype(np.float64) * rate).astype(np.int64)    # int(((stop - start) + 1) * sum(rates))  mutator.py:225
+    big = (((stop - start) + 1) >= (1 << 53)) | (k >= (1 << 33)) | (k < 0)
+    out["k"] = k
+    out["setsize"] = sample_setsize_array(np.maximum(k, 0))
+    for i in np.flatnonzero(big).tolist():                               # (outside the array formulation's domain)
+        r = range_descriptor(rds[i])
+        out["k"][i], out["setsize"][i] = r.k, r.setsize
+    return out
+
+
 # ---------------------------------------------------------------------- RNG hand-over
 def export_python_streams(engine: "_ffi.Engine") -> None:
     """Give libmsim the current states of ``random`` and ``numpy.random``."""
@@ -306,7 +340,7 @@ class Mutator:
                 for prev in (earlier[0][q] for q in range(earlier[1])) if earlier else ():
                     rec = self._fasta[prev.number]
                     # PLAN reads lengths and ranges only, never bases: any contig of the same length stands in
-                    eng.plan_contig(eng.add_contig_synthetic(len(rec), 0), plan_descriptors(prev))
+                    eng.plan_chain(len(rec), plan_table(prev))
                     eng.clear()
                 self._run_contig(eng, chrom, done)
             finally:
@@ -322,7 +356,7 @@ class Mutator:
             cid = eng.add_contig(rec.bases)
         t1 = time.perf_counter()
         t["ingest_s"] += t1 - t0
-        eng.plan_contig(cid, plan_descriptors(chrom))
+        eng.plan_contig(cid, plan_table(chrom))
         if eng.plan_was_empty(cid) and "warned" not in done:
             self._warn_empty(chrom)
             done.add("warned")

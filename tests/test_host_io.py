@@ -206,3 +206,33 @@ def test_units_by_arrays_equal_units_by_contig(tmp_path, monkeypatch):
         hit_bases_cap |= any(2 <= j - i < max_contigs for i, j in lazy)
     m.close()
     assert hit_count_cap and hit_bases_cap
+
+
+def test_plan_table_equals_plan_descriptors(tmp_path):
+    """``mutator.plan_table`` (array operations over a contig's ranges) against ``plan_descriptors`` (one ``Range`` at a time)
+    on an RMT with hot / cold / blocked ranges, SV settings of their own and an unlisted contig."""
+    import ctypes as C
+    import numpy as np
+    import bench
+    from mutation_simulator_amd import _ffi, mutator as mm
+    lengths = [3_000_000, 900_000, 40_000]
+    rs = np.random.RandomState(5)
+    rows, at = ["titv = 1.5", "", "std", "it None", bench.C4_STD_SV, "", "chr 1"], 1
+    for i in range(400):
+        at += int(rs.randint(2, 5000))
+        e = at + int(rs.randint(1, 9000))
+        if e >= lengths[0]:
+            break
+        rows.append(f"{at}-{e} " + ("None", "sn 0.05", "sn 0.001 de 0.002 demin 3 demax 60", "sn 0.2 in 0.01 inmin 1 inmax 50")[i % 4])
+        at = e + (1 if i % 9 else 0)
+    rows += ["chr 3", "100-20000 sn 0.3"]
+    sim = bench.workload_settings_rmt(lengths, "\n".join(rows) + "\n")
+    for chrom in sim.chromosomes:
+        want = mm.plan_descriptors(chrom)
+        got = mm.plan_table(chrom)
+        assert got.shape[0] == len(want) and got.dtype == _ffi.RANGE_DTYPE
+        raw = b"".join(bytes(r) for r in want)
+        masked = got.copy()
+        masked["_pad"] = 0
+        assert masked.tobytes() == raw
+    assert sum(len(mm.plan_descriptors(c)) for c in sim.chromosomes) > 300
