@@ -357,9 +357,10 @@ def main():
                          "c4 = configs[3], RMT mode with ~40 k blocked ranges + hot/cold spots; c4sv = the c4 file with the "
                          "c3 SV mix as its std line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
-                    help="N > 1: 'strong' (default) = BASELINE configs[4]'s shape: ONE genome, PLAN replayed on every rank "
-                         "(the MT19937 streams chain across contigs), contigs' APPLY sharded (LPT), RCCL gather to rank 0; "
-                         "'weak' = N independent replicas, one whole genome per GPU with its own seeded streams")
+                    help="N > 1: 'weak' (default) = N independent genomes, one per GPU with its own seeded streams (per-GPU work "
+                         "fixed); 'strong' = BASELINE configs[4]'s shape: ONE genome, contigs sharded (LPT), the MT19937 stream "
+                         "chain walked on every rank, RCCL gather to rank 0.  The other mode is measured too and reported in the "
+                         "same line")
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is always measured for N > 1, strong)")
     a = ap.parse_args()
 
@@ -379,10 +380,16 @@ def main():
     from mutation_simulator_amd.sharding import lpt_partition
 
     lengths = contig_lengths(a.total_bases)
-    scaling = a.scaling or ("strong" if world > 1 else "weak")
+    # N > 1.  "weak" (default; the contract's definition: per-GPU work fixed): N genomes at once, one per GPU, each with
+    # its own seeded streams -- the cohort case, no exchange step, scales with N.  "strong": ONE genome, contigs sharded
+    # (LPT), the stream chain walked by every rank (msim_plan_chain for contigs it does not own), RCCL gather to rank 0 --
+    # BASELINE configs[4]'s shape, Amdahl-bound by the chain (amdahl_ceiling).  Whichever is the headline, the other one is
+    # measured too and rides in the same line (weak_replicas / one_genome_sharded).
+    scaling = a.scaling or "weak"
     strong = scaling == "strong" and world > 1
-    parts = lpt_partition(lengths, world) if strong else [list(range(len(lengths)))] * world
-    mine = parts[rank]
+    parts = lpt_partition(lengths, world)               # ownership of the one-genome mode
+    everything = list(range(len(lengths)))
+    mine = parts[rank] if strong else everything
     seed = 42 if strong else 42 + rank       # replicas: every GPU mutates its own genome
 
     # (MSIM_BENCH_DEVICE: put every rank on one GPU -- lets the N > 1 control flow run on a 1-GPU box)
@@ -392,7 +399,7 @@ def main():
     cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
     eng.sync()
     comm, comm_error = None, None
-    if strong:
+    if world > 1:
         from mutation_simulator_amd.gather import Communicator
         try:
             comm = Communicator(eng, rank, world, dist)
@@ -465,7 +472,7 @@ def main():
             "config": {"workload": f"{W['mode']} mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), {W['what']}"
                                    ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
-                       "parallelism": (f"one genome, contigs' APPLY sharded over {world} GPUs (LPT), PLAN replayed per rank, "
+                       "parallelism": (f"one genome, contigs sharded over {world} GPUs (LPT), stream chain walked per rank, "
                                        "results left in HBM on the owning GPU ('with_gather' adds the RCCL gather to rank 0)"
                                        if strong else f"{world} independent replica(s): one whole genome per GPU, "
                                        f"streams seeded 42+rank, results left in HBM")},
@@ -477,29 +484,45 @@ def main():
         }
         if world == 1:
             line["step_roofline"] = step_roofline(st, dt)
-    if strong and comm is not None:
-        # the exchange step north_star names: every peer sends its mutated contigs to rank 0 over its own xGMI link
-        dtg, _ = measure(a.workload, a.steps, 1, gather=True)
+    def sharded_numbers(dt_sharded):
+        """One genome over the N GPUs: throughput without and with the exchange step north_star names (every peer sends its
+        mutated contigs to rank 0 over its own xGMI link)."""
+        out = None
         if rank == 0:
-            line["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
-                                   "ms_per_step": round(dtg / a.steps * 1e3, 3),
-                                   "transport": comm.describe()}
-    elif strong and rank == 0:
-        line["with_gather"] = {"error": comm_error}
+            out = {"value": round(sum(lengths) * a.steps / dt_sharded / 1e6, 3), "unit": "Mbases/s", "scaling": "strong",
+                   "ms_per_step": round(dt_sharded / a.steps * 1e3, 3),
+                   "what": f"ONE genome, contigs sharded over {world} GPUs (LPT), results left in HBM on the owning GPU"}
+        if comm is not None:
+            dtg, _ = measure(a.workload, a.steps, 1, gather=True, owned=parts[rank], step_seed=42)
+            if rank == 0:
+                out["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
+                                      "ms_per_step": round(dtg / a.steps * 1e3, 3), "transport": comm.describe()}
+        elif rank == 0:
+            out["with_gather"] = {"error": comm_error}
+        return out
+
     if strong:
+        sh = sharded_numbers(dt)
+        if rank == 0:
+            line["with_gather"] = sh["with_gather"]
         # what DOES scale: N independent replicas (one whole genome per GPU, own seeds) -- the weak-scaling number
-        dtw, _ = measure(a.workload, a.steps, 1, owned=list(range(len(lengths))), step_seed=42 + rank)
+        dtw, _ = measure(a.workload, a.steps, 1, owned=everything, step_seed=42 + rank)
         if rank == 0:
             line["weak_replicas"] = {"value": round(sum(lengths) * world * a.steps / dtw / 1e6, 3), "unit": "Mbases/s",
                                      "ms_per_step": round(dtw / a.steps * 1e3, 3), "scaling": "weak",
                                      "what": f"{world} independent replicas, one whole genome per GPU, streams seeded 42+rank"}
+    elif world > 1:
+        dts_, _ = measure(a.workload, a.steps, 1, owned=parts[rank], step_seed=42)
+        sh = sharded_numbers(dts_)
+        if rank == 0:
+            line["one_genome_sharded"] = sh
     # What N GPUs can give ONE genome (strong scaling): the chain of both MT19937 streams runs over every contig on every
     # rank whatever N is; only emission + APPLY of the owned contigs shrink.  Measured, not modelled: a step that owns
     # nothing (msim_plan_chain for all 24 contigs) against the full step.
     dtc, _ = measure(a.workload, a.steps, 1, owned=[], step_seed=42)
     dtf = dt
     if strong:
-        dtf, _ = measure(a.workload, a.steps, 1, owned=list(range(len(lengths))), step_seed=42)
+        dtf, _ = measure(a.workload, a.steps, 1, owned=everything, step_seed=42)
     if rank == 0:
         line["amdahl_ceiling"] = {"value": round(dtf / dtc, 3), "chain_only_ms_per_step": round(dtc / a.steps * 1e3, 3),
                                   "full_step_ms": round(dtf / a.steps * 1e3, 3),
