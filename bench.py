@@ -364,6 +364,11 @@ def main():
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is always measured for N > 1, strong)")
     a = ap.parse_args()
 
+    # ONE JSON line on stdout, nothing else: gloo and RCCL print banners to the process's stdout from C, so file descriptor 1
+    # is pointed at stderr for the whole run and the line goes to a private duplicate of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -550,7 +555,8 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload)      # bounded sample: ~6-10 s of CPU work
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if comm is not None:
         comm.close()
     eng.close()

@@ -400,3 +400,35 @@ def test_host_boundary_chain_equals_cpython_randint(seed, walker):
     assert int(words[used.value]) == nxt
     assert 0xFFFFFFFF in want and kept > 1000
     eng.close()
+
+
+def test_plan_chain_advances_like_plan_contig_on_a_host_only_context():
+    """msim_plan_chain without a GPU: the host planner runs, nothing is kept, both streams stand where msim_plan_contig
+    leaves them (the CPU tier of ``--gpus N`` relies on it)."""
+    from mutation_simulator_amd.mut_types import MutType
+
+    class S:
+        mut_block = {t: 1 for t in MutType}
+        titv = 2.0
+    r = _ffi.Range()
+    r.start, r.stop, r.k = 0, 99_999, 2_000
+    r.setsize = mm.sample_setsize(r.k)
+    r.n_types = 3
+    for j, (t, thr) in enumerate(((1, 0.6), (2, 0.8), (3, 1.0))):
+        r.types[j], r.cdf_thr[j] = t, int(thr * (1 << 53))
+    r.min_len[2], r.max_len[2], r.min_len[3], r.max_len[3] = 1, 9, 2, 30
+    states = []
+    for chain in (False, True):
+        eng = _ffi.Engine(device=-1)
+        eng.seed(3, 9)
+        eng.set_params(mm.params_descriptor(S))
+        for _ in range(3):
+            if chain:
+                eng.plan_chain(100_000, [r])
+            else:
+                eng.plan_contig(eng.add_contig(np.zeros(100_000, np.uint8)), [r])
+        states.append((eng.get_mt_state(0), eng.get_mt_state(1), eng.stats()))
+        eng.close()
+    (a0, a1, sa), (b0, b1, sb) = states
+    assert np.array_equal(a0[0], b0[0]) and a0[1] == b0[1] and np.array_equal(a1[0], b1[0]) and a1[1] == b1[1]
+    assert sa["py_words"] == sb["py_words"] and sa["contigs_host"] == 3 and sb["contigs_host"] == 0

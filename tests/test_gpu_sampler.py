@@ -465,6 +465,37 @@ def test_host_chain_with_other_engines_along_one_stream():
     assert ast["contigs_hostchain"] >= 2 and ast["contigs_snp"] == 1 and ast["contigs_svmix"] == 1 and ast["contigs_hostcut"] == 2
 
 
+def test_plan_chain_leaves_the_streams_where_plan_contig_does():
+    """msim_plan_chain (multi-GPU: a rank that does not own a contig) through every engine -- SNP sampler, SV mix, host-cut,
+    host-chain, host planner -- must advance both streams exactly like msim_plan_contig, alternating with owned contigs."""
+    rs = np.random.RandomState(8)
+    sv = lambda L, rate: _sv_range(0, L - 1, int(L * rate), C3_CHANCES, C3_LENS)
+    gaps = lambda L, n: [r for r in (_rate_range(s, e, 0.008, C3_CHANCES, C3_LENS) for s, e in _gene_gaps(L, rs, n)) if r.k]
+    contigs = [(2_000_000, [_snp_range(0, 1_999_999, 20_000)]), (1_500_000, [sv(1_500_000, 0.008)]),
+               (1_000_000, _rmt_like_ranges(1_000_000, rs, 300)), (2_000_000, gaps(2_000_000, 100)),
+               (300_000, [sv(300_000, 0.004)]), (900_000, [_snp_range(0, 899_999, 9_000)]), (1_200_000, gaps(1_200_000, 40))]
+    full, fs, fst = _run(_ffi.PLAN_AUTO, contigs, _params(titv=2.0), (4, 5))
+    for owner_mask in (0b0000000, 0b1010101, 0b0101010):
+        eng = _ffi.Engine(0)
+        eng.seed(4, 5)
+        eng.set_params(_params(titv=2.0))
+        for i, (L, ranges) in enumerate(contigs):
+            if owner_mask >> i & 1:
+                cid = eng.add_contig_synthetic(L, 7)
+                eng.plan_contig(cid, ranges)
+                recs, pool = eng.fetch_records(cid)
+                assert np.array_equal(recs.view(np.uint8), full[i][0].view(np.uint8)) and np.array_equal(pool, full[i][2])
+            else:
+                eng.plan_chain(L, ranges)
+        st = eng.stats()
+        assert st["py_words"] == fst["py_words"] and st["np_words"] == fst["np_words"]
+        for (hm, hp), stream in zip(fs, (0, 1)):
+            gm, gp = eng.get_mt_state(stream)
+            assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
+        assert sum(v for k, v in st.items() if k.startswith("contigs_")) == bin(owner_mask).count("1")
+        eng.close()
+
+
 def test_full_size_sv_mix_gpu_vs_host_planner():
     """BASELINE config 3 at full size (3 Gb, 24 contigs, 24 M candidates): records, insert pools and both
     final stream positions equal the sequential host planner's."""
