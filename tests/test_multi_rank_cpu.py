@@ -53,6 +53,14 @@ def _worker(rank: int, world: int, port: int, out_dir: str):
             recs, pool = eng.fetch_records(cid)
             digests.append(hashlib.sha256(recs.tobytes() + pool.tobytes()).hexdigest())
         state = [(hashlib.sha256(eng.get_mt_state(s)[0].tobytes()).hexdigest(), eng.get_mt_state(s)[1]) for s in (0, 1)]
+        # the pass as the product and the bench run it: contigs of OTHER ranks only walked (msim_plan_chain) -- the owned
+        # ones must come out as above and both streams must end where the full replay ends
+        eng.seed(42, 42)
+        run_sharded_pass(eng, sim, cids, parts[rank], mm.plan_table, apply=False, lengths=lengths)
+        for i in parts[rank]:
+            recs, pool = eng.fetch_records(cids[i])
+            assert hashlib.sha256(recs.tobytes() + pool.tobytes()).hexdigest() == digests[i]
+        assert state == [(hashlib.sha256(eng.get_mt_state(s)[0].tobytes()).hexdigest(), eng.get_mt_state(s)[1]) for s in (0, 1)]
         # ---- the gather's bookkeeping (msim_gather_plan: who sends what, sizes, posting order), driven end to end
         # with a host-memory transport: every rank "applies" its contigs (deterministic stand-in bytes whose LENGTH
         # differs from the input length, like a mutated contig's), rank 0 must end up with every contig intact
