@@ -184,6 +184,7 @@ struct MixSets {
     std::vector<int> rep;                   // per set: index into ranges[] of one range that uses it
     std::vector<ChainClasses> cc;           // per set: gcc with the set's own cls_of
     bool sn_chained = false;                // block[SN] != d: SNPs block their successors -> every candidate is on the chain
+    bool has_tl = false;                    // some range draws TL / TLI: __link_tls runs behind the last range (host)
     uint64_t K = 0;                         // candidates of the contig
     uint32_t n_draw = 0;
 };
@@ -197,10 +198,16 @@ bool multimix_prepare(const Ctx *c, uint64_t L, const msim_range *ranges, int n_
 // candidate, position order), ch_stop[n_ch] (Mutation.stop or CHAIN_DROPPED), visit_from[n_draw]: candidates of
 // drawing range i below visit_from[i] lie inside a DE/DU/IV span of an EARLIER range (the blocked range is reset
 // per range, mutator.py:184) and are never visited by __mutate_sequence (mutator.py:376,386,398).
+// ms.has_tl (translocations): ch_extra / ch_aux (n_ch entries each) receive, per chain candidate, what __link_tls
+// (mutator.py:267-316) decides behind the last range -- a linked TLI's source span start (its ch_stop becomes the TL's stop)
+// and flags: bit 0 reversed copy, bit 1 trans_insert_pos > 0, bit 7 TOMBSTONE (deleted by __fix_tl_amount: it took part in
+// the boundary pass -- its stop still blocks -- but is no record).
+constexpr uint8_t CHAIN_TOMBSTONE = 0x80;
 int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, int64_t d, const MixSets &ms,
                        const uint32_t *words, const uint32_t *T, size_t n_words, const uint32_t *ch_rank,
                        const uint8_t *ch_type, size_t n_ch, uint32_t *cand_pos, uint32_t *ch_stop, uint32_t *visit_from,
-                       size_t *consumed, const WordFeed *feed = nullptr);
+                       size_t *consumed, const WordFeed *feed = nullptr, uint32_t *ch_extra = nullptr,
+                       uint8_t *ch_aux = nullptr);
 // test support (msim_dbg_multimix_plan): the whole engine on the host -- the device's parts (types, tables, keep
 // flags, records) restated sequentially -- so the CPU tier can hold the algorithm against plan_contig_host
 int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out);

@@ -96,6 +96,10 @@ struct MixedSet {                        // scratch of one SV-mix range (section
     bool wbits_dirty = false;                             //   a failed pass may have left bits behind
     uint32_t *wcnt = nullptr; size_t cap_wcnt = 0;        //   per-workgroup popcounts / ranks of its expansion
     uint32_t *tables = nullptr; size_t cap_tables = 0;    // host-chain engine: accept tables over the word window
+    uint32_t *cand_extra = nullptr; size_t cap_cextra = 0;   //   translocations: linked span start per candidate,
+    uint8_t *cand_aux = nullptr; size_t cap_caux = 0;        //   flags (reversed / insert_pos > 0 / tombstone),
+    uint32_t *nsn_extra = nullptr; size_t cap_nextra = 0;    //   and their staging in chain order
+    uint8_t *nsn_aux = nullptr; size_t cap_naux = 0;
     uint8_t *mm_d = nullptr; size_t cap_mm_d = 0;         //   range table | settings' type tables | visit_from
     uint8_t *mm_h = nullptr; size_t cap_mm_h = 0;         //   its pinned staging (one per set: the copies are asynchronous)
     hipEvent_t emit_done = nullptr;
@@ -112,6 +116,8 @@ struct GpuPlan {
     uint32_t *h_nstop = nullptr; size_t cap_h_nstop = 0;
     uint32_t *h_win = nullptr; size_t cap_h_win = 0;      // host-chain engine: the tempered word window (h_words holds the tables)
     uint32_t *h_nrank = nullptr; size_t cap_h_nrank = 0;  //   candidate ordinals of the chain
+    uint32_t *h_nextra = nullptr; size_t cap_h_nextra = 0;   //   translocations: what __link_tls decided, chain order
+    uint8_t *h_naux = nullptr; size_t cap_h_naux = 0;
     MixSets mm_sets;                                       //   what gpu_plan_multimix_eligible derived for the contig being planned
     const msim_range *mm_for = nullptr; int mm_n = 0;
     uint32_t *h_seed = nullptr;         // pinned staging of the two host generator states (reseed without a stream sync)
@@ -184,13 +190,14 @@ void gpu_plan_destroy(GpuPlan *g) {
     }
     for (auto &t : g->mixed) {
         void *bufs[] = {t.cand_pos, t.cand_type, t.cand_stop, t.nsn_pos, t.nsn_type, t.nsn_rank, t.nsn_stop, t.sn_index,
-                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt, t.p0_slot, t.tables, t.mm_d};
+                        t.cnt, t.words, t.walk_d, t.wbits, t.wcnt, t.p0_slot, t.tables, t.mm_d, t.cand_extra, t.cand_aux,
+                        t.nsn_extra, t.nsn_aux};
         for (void *b : bufs) if (b) (void)hipFree(b);
         if (t.walk_h) (void)hipHostFree(t.walk_h);
         if (t.mm_h) (void)hipHostFree(t.mm_h);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
-    void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop, g->h_win, g->h_nrank};
+    void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop, g->h_win, g->h_nrank, g->h_nextra, g->h_naux};
     for (void *b : hb) if (b) (void)hipHostFree(b);
     for (auto e : g->chain_ev) if (e) (void)hipEventDestroy(e);
     if (g->t0) (void)hipEventDestroy(g->t0);
@@ -885,7 +892,9 @@ static inline size_t mixed_cnt_bytes(uint32_t nbk) { return mixed_cnt_words(nbk)
 // candidates are in M.cand_stop -> keep flags and counts -> records, insert pool, SNP draws.  p_s: where the SNP draws of
 // __mutate_sequence start in the CPython stream.  rt / visit_from / sn_chained: see k_keep_flags (nullptr for one range).
 static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, uint64_t p_s, const MixRangeDev *rt,
-                      uint32_t n_draw, const uint32_t *visit_from, bool sn_chained, bool &grew) {
+                      uint32_t n_draw, const uint32_t *visit_from, bool sn_chained, bool &grew, bool has_tl = false) {
+    const uint32_t *c_extra = has_tl ? M.cand_extra : nullptr;
+    const uint8_t *c_aux = has_tl ? M.cand_aux : nullptr;
     const msim_params &P = c->params;
     GpuStream &py = g->s[0], &np = g->s[1];
     int rc;
@@ -902,7 +911,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
                        rt, n_draw);
     hipLaunchKernelGGL(k_scan_max_u32, dim3(1), dim3(1024), 0, c->stream, bmax, nbk);
     hipLaunchKernelGGL(k_keep_flags, dim3(nbk), dim3(CB_THREADS), 0, c->stream, M.cand_pos, M.cand_type, M.cand_stop, k, bt,
-                       bmax, cnt_keep, cnt_sn, cnt_ins, blk_delta, rt, n_draw, visit_from, sn_chained ? 1u : 0u);
+                       bmax, cnt_keep, cnt_sn, cnt_ins, blk_delta, rt, n_draw, visit_from, sn_chained ? 1u : 0u, c_extra, c_aux);
     hipLaunchKernelGGL(k_scan4, dim3(4), dim3(1024), 0, c->stream, cnt_keep, cnt_sn, cnt_ins, blk_delta, nbk, g->d_ps);
     MSIM_HIP(c, hipGetLastError());
     PlanState h;
@@ -934,7 +943,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
     if (!c->chain_only) {
         hipLaunchKernelGGL(k_emit_records, dim3(nbk), dim3(CB_THREADS), 0, c->emit_stream, M.cand_pos, M.cand_type, M.cand_stop, k,
-                           cnt_keep, cnt_sn, cnt_ins, blk_delta, ct.d_recs, M.sn_index, ct.d_off);
+                           cnt_keep, cnt_sn, cnt_ins, blk_delta, ct.d_recs, M.sn_index, ct.d_off, c_extra, c_aux);
         if (pool_len)
             hipLaunchKernelGGL(k_pool_fill, dim3((pool_len / 4 + 256) / 256), dim3(256), 0, c->emit_stream, np.d_raw,
                                (unsigned long long)np.pos, pool_len, ct.d_pool + PAD);
@@ -1398,13 +1407,16 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     g->unverified = true;
     // ---- sizes: the word window (every sample + every randint, 16 sigma of the total) and the chain length
     double e_words = 0, var = 0, e_ch = 0, var_ch = 0;
-    std::vector<double> q_nsn(n_sets, 0.0), acc_min(n_sets, 1.0);
+    std::vector<double> q_nsn(n_sets, 0.0), acc_min(n_sets, 1.0), q_tl(n_sets, 0.0);
     for (uint32_t s = 0; s < n_sets; s++) {
         const msim_range &r = ranges[ms.rep[s]];
         for (int j = 0; j < r.n_types; j++) {
             if (!range_type_drawable(r, j) || r.types[j] == MSIM_SN) continue;
             const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
-            q_nsn[s] += (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - lo) / 9007199254740992.0;
+            const double q = (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - lo) / 9007199254740992.0;
+            q_nsn[s] += q;
+            if (r.types[j] == MSIM_TL || r.types[j] == MSIM_TLI) q_tl[s] += q;
+            if (r.types[j] == MSIM_TLI) continue;                     // (draws nothing in the boundary pass)
             const int64_t w = r.max_len[r.types[j]] - r.min_len[r.types[j]] + 1;
             acc_min[s] = std::min(acc_min[s], (double)w / (double)(1ull << bit_length64((uint64_t)w)));
         }
@@ -1428,6 +1440,8 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
             e_ch += m; var_ch += m * (1.0 - q_nsn[s]);
             e_words += m / acc_min[s];
             var += m / (acc_min[s] * acc_min[s]);
+            if (ms.has_tl) { e_words += 5.0 * k * q_tl[s]; var += 25.0 * k * q_tl[s]; }   // __link_tls: deletions, shuffle, one coin
+                                                                                            // per pair, <= 2 words per draw on average
         }
     }
     const double wd = e_words + 16.0 * std::sqrt(var) + 65536.0;
@@ -1454,6 +1468,12 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, mixed_cnt_bytes(nbk), &grew))) return rc;
     if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)W * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.tables, &M.cap_tables, n_slots * 4 + 64, &grew))) return rc;
+    if (ms.has_tl) {
+        if ((rc = grow(c, (void **)&M.cand_extra, &M.cap_cextra, (size_t)K * 4 + 64, &grew))) return rc;
+        if ((rc = grow(c, (void **)&M.cand_aux, &M.cap_caux, (size_t)K + 64, &grew))) return rc;
+        if ((rc = grow(c, (void **)&M.nsn_extra, &M.cap_nextra, (size_t)K * 4 + 64, &grew))) return rc;
+        if ((rc = grow(c, (void **)&M.nsn_aux, &M.cap_naux, (size_t)K + 64, &grew))) return rc;
+    }
     // range table | type tables | visit_from, one device block and one pinned block per scratch set
     const size_t off_sets = ((size_t)n_draw * sizeof(MixRangeDev) + 63) & ~(size_t)63;
     const size_t off_visit = (off_sets + (size_t)n_sets * sizeof(TypeTable) + 63) & ~(size_t)63;
@@ -1461,7 +1481,8 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     if ((rc = grow(c, (void **)&M.mm_d, &M.cap_mm_d, mm_bytes, &grew))) return rc;
     if ((rc = grow_host(c, (void **)&M.mm_h, &M.cap_mm_h, mm_bytes))) return rc;
     if (g->cap_h_words < n_slots * 4 || g->cap_h_win < (size_t)W * 4 || g->cap_h_npos < (size_t)K * 4 + 64 ||
-        g->cap_h_ntype < (size_t)K + 64 || g->cap_h_nstop < (size_t)K * 4 + 64 || g->cap_h_nrank < (size_t)K * 4 + 64) {
+        g->cap_h_ntype < (size_t)K + 64 || g->cap_h_nstop < (size_t)K * 4 + 64 || g->cap_h_nrank < (size_t)K * 4 + 64 ||
+        (ms.has_tl && (g->cap_h_nextra < (size_t)K * 4 + 64 || g->cap_h_naux < (size_t)K + 64))) {
         MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
         if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
         if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, n_slots * 4))) return rc;
@@ -1470,6 +1491,10 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
         if ((rc = grow_host(c, (void **)&g->h_ntype, &g->cap_h_ntype, (size_t)K + 64))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_nstop, &g->cap_h_nstop, (size_t)K * 4 + 64))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_nrank, &g->cap_h_nrank, (size_t)K * 4 + 64))) return rc;
+        if (ms.has_tl) {
+            if ((rc = grow_host(c, (void **)&g->h_nextra, &g->cap_h_nextra, (size_t)K * 4 + 64))) return rc;
+            if ((rc = grow_host(c, (void **)&g->h_naux, &g->cap_h_naux, (size_t)K + 64))) return rc;
+        }
     }
     MixRangeDev *rt_h = reinterpret_cast<MixRangeDev *>(M.mm_h);
     TypeTable *sets_h = reinterpret_cast<TypeTable *>(M.mm_h + off_sets);
@@ -1554,7 +1579,8 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     };
     rc = spin_event(c, g->ev_cand);
     if (!rc) rc = multimix_walk_host(c, ct.len, ranges, n_ranges, d, ms, g->h_win, g->h_words, W, g->h_nrank, g->h_ntype, n_ch,
-                                     g->h_npos, g->h_nstop, visit_h, &consumed, &feed);
+                                     g->h_npos, g->h_nstop, visit_h, &consumed, &feed, ms.has_tl ? g->h_nextra : nullptr,
+                                     ms.has_tl ? g->h_naux : nullptr);
     if (!rc) {
         MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned blocks are free again
         rc = span_close(c, g);
@@ -1567,8 +1593,17 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     if (n_ch) MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_ch * 4, hipMemcpyHostToDevice, c->stream));
     MSIM_HIP(c, hipMemcpyAsync(visit_d, visit_h, (size_t)n_draw * 4, hipMemcpyHostToDevice, c->stream));
     if (n_ch) hipLaunchKernelGGL(k_stop_scatter, dim3((n_ch + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_stop, n_ch, M.cand_stop);
+    if (ms.has_tl) {                                       // what __link_tls decided: linked spans, flags, tombstones
+        MSIM_HIP(c, hipMemsetAsync(M.cand_aux, 0, (size_t)K, c->stream));
+        if (n_ch) {
+            MSIM_HIP(c, hipMemcpyAsync(M.nsn_extra, g->h_nextra, (size_t)n_ch * 4, hipMemcpyHostToDevice, c->stream));
+            MSIM_HIP(c, hipMemcpyAsync(M.nsn_aux, g->h_naux, (size_t)n_ch, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_link_scatter, dim3((n_ch + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_extra, M.nsn_aux,
+                               n_ch, M.cand_extra, M.cand_aux);
+        }
+    }
     MSIM_HIP(c, hipGetLastError());
-    rc = mixed_emit(c, g, ct, M, K, p0 + consumed, rt_d, n_draw, visit_d, ms.sn_chained, grew);
+    rc = mixed_emit(c, g, ct, M, K, p0 + consumed, rt_d, n_draw, visit_d, ms.sn_chained, grew, ms.has_tl);
     if (prof) {
         const auto tp3 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };

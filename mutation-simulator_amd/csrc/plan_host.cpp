@@ -305,7 +305,7 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
 // append the classes of r's drawable IN/DE/DU/IV lengths to g (at most 4); cls_of[t] = class of type t
 static bool chain_classes_add(const msim_range &r, ChainClasses &g, uint8_t cls_of[8]) {
     for (int t = 0; t < 8; t++) cls_of[t] = 0;
-    for (int t : {MSIM_IN, MSIM_DE, MSIM_DU, MSIM_IV}) {
+    for (int t : {MSIM_IN, MSIM_DE, MSIM_DU, MSIM_IV, MSIM_TL}) {
         bool drawn = false;                                  // can the type draw of this range produce t at all?
         for (int j = 0; j < r.n_types && j < 8; j++) {
             const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
@@ -358,10 +358,10 @@ int ChainWalk::init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses 
     n_words = nw;
     lg_rows = chain_lg_rows(cc);
     for (int t = 0; t < 8; t++) {                          // ids outside the boundary pass: see types_ok
-        const bool chain_type = t == MSIM_IN || t == MSIM_DE || t == MSIM_DU || t == MSIM_IV;
+        const bool chain_type = t == MSIM_IN || t == MSIM_DE || t == MSIM_DU || t == MSIM_IV || t == MSIM_TL;
         const int64_t blk1 = 1 + P.block[t];
         add[t] = chain_type ? r.min_len[t] - 1 : 0;
-        clamp[t] = (t == MSIM_DU || t == MSIM_DE) ? last : (int64_t)1 << 40;       // mutator.py:253-264
+        clamp[t] = (t == MSIM_DU || t == MSIM_DE || t == MSIM_TL) ? last : (int64_t)1 << 40;   // mutator.py:253-264
         drop_from[t] = t == MSIM_IV ? last - r.max_len[MSIM_IV] : INT64_MAX;       // mutator.py:240-245
         // the next blocked end: min(p + next_add + value, next_cap); an insert blocks from its position, whatever it draws
         in_mask[t] = t == MSIM_IN ? 0 : -1;
@@ -758,7 +758,8 @@ bool multimix_prepare(const Ctx *c, uint64_t L, const msim_range *ranges, int n_
             for (int j = 0; j < r.n_types; j++) {
                 if (!type_drawable(r, j)) continue;
                 const int t = r.types[j];
-                if (t != MSIM_SN && t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return false;   // TL / TLI
+                if (t < MSIM_SN || t > MSIM_TLI) return false;
+                if (t == MSIM_TL || t == MSIM_TLI) ms.has_tl = true;   // translocations: linked after the last range (below)
             }
             if (!chain_classes_add(r, ms.gcc, own.cls_of)) return false;
             id = (uint32_t)ms.rep.size();
@@ -781,16 +782,39 @@ bool multimix_prepare(const Ctx *c, uint64_t L, const msim_range *ranges, int n_
     return true;
 }
 
+namespace {
+// A Python list under `del lst[i]` by index, without moving its tail: Fenwick tree over "still there" flags.
+// select(i) = position of the i-th remaining element; erase(pos) removes it.  (__fix_tl_amount, mutator.py:286-302)
+struct IndexedList {
+    std::vector<int32_t> tree;
+    size_t n = 0, alive = 0, top = 1;
+    explicit IndexedList(size_t size) : tree(size + 1, 0), n(size), alive(size) {
+        for (size_t i = 1; i <= n; i++) { tree[i] += 1; const size_t j = i + (i & (~i + 1)); if (j <= n) tree[j] += tree[i]; }
+        while (top * 2 <= n) top *= 2;
+    }
+    size_t select(size_t i) const {                                   // 0-based rank among the remaining -> 0-based position
+        size_t pos = 0, rem = i + 1;
+        for (size_t step = top; step; step >>= 1)
+            if (pos + step <= n && (size_t)tree[pos + step] < rem) { pos += step; rem -= (size_t)tree[pos]; }
+        return pos;
+    }
+    void erase(size_t pos) { for (size_t i = pos + 1; i <= n; i += i & (~i + 1)) tree[i] -= 1; alive--; }
+};
+}  // namespace
+
 int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, int64_t d, const MixSets &ms,
                        const uint32_t *words, const uint32_t *T, size_t n_words, const uint32_t *ch_rank,
                        const uint8_t *ch_type, size_t n_ch, uint32_t *cand_pos, uint32_t *ch_stop, uint32_t *visit_from,
-                       size_t *consumed, const WordFeed *feed) {
+                       size_t *consumed, const WordFeed *feed, uint32_t *ch_extra, uint8_t *ch_aux) {
     const auto t0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;
-    if (ms.sn_chained) {
+    const bool generic = ms.sn_chained || ms.has_tl;                 // the plain loop: SNPs on the chain and / or TL, TLI
+    if (ms.has_tl && (!ch_extra || !ch_aux)) return fail(c, MSIM_ERR_ARG, "host chain: translocations need ch_extra / ch_aux");
+    if (generic) {
         uint32_t bad = 0;
-        for (size_t i = 0; i < n_ch; i++) bad |= (uint32_t)(uint8_t)(ch_type[i] - MSIM_SN) > (uint32_t)(MSIM_IV - MSIM_SN);
-        if (bad) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside SN/IN/DE/DU/IV");
+        const uint32_t lo = ms.sn_chained ? MSIM_SN : MSIM_IN, hi_t = ms.has_tl ? MSIM_TLI : MSIM_IV;
+        for (size_t i = 0; i < n_ch; i++) bad |= (uint32_t)(uint8_t)(ch_type[i] - lo) > hi_t - lo;
+        if (bad) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside what its ranges draw");
     } else if (!ChainWalk::types_ok(ch_type, n_ch)) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside IN/DE/DU/IV");
     std::vector<ChainWalk> proto(ms.rep.size());
     for (size_t s = 0; s < proto.size(); s++) {
@@ -808,6 +832,9 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
     auto overflow = [&]() { return rc_feed ? rc_feed : fail(c, MSIM_ERR_HIP, "host chain: word window overflowed its margin"); };
     auto t_lim = [&]() { return avail + (avail >= n_words ? 1u : 0u); };   // entry n_words is the end-of-window sentinel
     static thread_local std::vector<uint32_t> pbuf;
+    std::vector<uint32_t> ch_pos;                                    // translocations: every chain candidate's position, and
+    std::vector<size_t> span;                                        //   each range's slice of the chain, for the passes behind
+    if (ms.has_tl) { ch_pos.resize(n_ch); span.reserve((size_t)ms.n_draw + 1); }
     size_t qa = 0, di = 0;
     uint64_t base = 0;
     uint32_t vf = 0;                                                 // consumed_to + 1 of __mutate_sequence's walk
@@ -837,7 +864,11 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
         for (size_t x = 0; x < m; x++) pb[x] = cand_pos[ch_rank[qa + x]];
         lap(t_gather);
         ChainWalk &pw = proto[ms.set_of[di]];
-        if (m && !ms.sn_chained) {
+        if (ms.has_tl) {
+            span.push_back(qa);
+            for (size_t x = 0; x < m; x++) { ch_pos[qa + x] = pb[x]; ch_aux[qa + x] = 0; ch_extra[qa + x] = 0; }
+        }
+        if (m && !generic) {
             ChainWalk &cw = pw;                                      // (the set's walker: only its position is per range)
             cw.j = 0; cw.blk_hi = 0; cw.bad = 0;                     // last_mut_range = range(0), per range (mutator.py:184)
             cw.ws = w << lg;
@@ -855,6 +886,11 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
                 const int t = ch_type[qa + x] & 7;
                 if (p < hi) { ch_stop[qa + x] = CHAIN_DROPPED; continue; }              // mutator.py:190-191
                 if (t == MSIM_SN) { ch_stop[qa + x] = (uint32_t)p; hi = p + 1 + P.block[MSIM_SN]; continue; }
+                if (t == MSIM_TLI) {                                  // no branch of __get_stop_position: stop stays 0, so the
+                    ch_stop[qa + x] = 0;                              // blocked range is range(start, 1 + block) (mutator.py:207)
+                    hi = 1 + P.block[MSIM_TLI];
+                    continue;
+                }
                 if (p >= pw.drop_from[t]) { ch_stop[qa + x] = CHAIN_DROPPED; continue; }   // mutator.py:240-245
                 while (w >= t_lim()) if (!more()) return overflow();
                 const uint32_t e = T[(w << lg) + pw.row[t]];
@@ -868,7 +904,7 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
             }
         }
         visit_from[di] = vf;
-        for (size_t x = m; x-- > 0;) {                               // the range's last kept DE / DU / IV: does it get visited?
+        for (size_t x = m; !ms.has_tl && x-- > 0;) {                 // the range's last kept DE / DU / IV: does it get visited?
             const int t = ch_type[qa + x] & 7;
             if (ch_stop[qa + x] == CHAIN_DROPPED || (t != MSIM_DE && t != MSIM_DU && t != MSIM_IV)) continue;
             if (pb[x] >= vf) vf = ch_stop[qa + x] + 1;               // pos = muts[pos].stop (mutator.py:376,386,398)
@@ -879,6 +915,73 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
         di++;
     }
     if (bad_acc < 0) return overflow();
+    if (ms.has_tl) {
+        // ---- __link_tls (mutator.py:130-131, 267-316), behind the last range: the kept TL spans and TLI sites of the whole
+        // contig, in range order; __fix_tl_amount deletes random surplus entries, shuffle(tls), one coin per pair
+        span.push_back(n_ch);
+        std::vector<uint32_t> tls, tlis;
+        for (size_t q = 0; q < n_ch; q++) {
+            if (ch_stop[q] == CHAIN_DROPPED) continue;
+            const int t = ch_type[q] & 7;
+            if (t == MSIM_TL) tls.push_back((uint32_t)q); else if (t == MSIM_TLI) tlis.push_back((uint32_t)q);
+        }
+        auto randbelow_w = [&](uint64_t n, uint64_t &out) -> bool {  // Lib/random.py _randbelow_with_getrandbits over the window
+            if (!n) { out = 0; return true; }
+            const int sh = 32 - bit_length64(n);
+            uint64_t v;
+            do {
+                while (w >= avail) if (!more()) return false;
+                v = words[w++] >> sh;
+            } while (v >= n);
+            out = v;
+            return true;
+        };
+        if (!tls.empty()) {
+            if (tls.size() != tlis.size()) {
+                std::vector<uint32_t> &longer = tls.size() > tlis.size() ? tls : tlis;
+                const size_t want = std::min(tls.size(), tlis.size());
+                IndexedList lst(longer.size());
+                while (lst.alive > want) {
+                    uint64_t idx;
+                    if (!randbelow_w(lst.alive, idx)) return overflow();          // randint(0, len - 1)
+                    const size_t at = lst.select((size_t)idx);
+                    ch_aux[longer[at]] |= CHAIN_TOMBSTONE;                          // del muts[...]: no record -- but it blocked
+                    lst.erase(at);
+                    longer[at] = 0xffffffffu;
+                }
+                longer.erase(std::remove(longer.begin(), longer.end(), 0xffffffffu), longer.end());
+            }
+            for (size_t i = tls.size(); i-- > 1;) {                   // random.shuffle(tls)
+                uint64_t j;
+                if (!randbelow_w((uint64_t)i + 1, j)) return overflow();
+                std::swap(tls[i], tls[(size_t)j]);
+            }
+            for (size_t i = 0; i < tls.size(); i++) {
+                const uint32_t tl = tls[i], tli = tlis[i];
+                uint64_t coin;
+                if (!randbelow_w(2, coin)) return overflow();         // __transloc_invert draws first, then looks at the length
+                const int64_t tlen = (int64_t)ch_stop[tl] + 1 - (int64_t)ch_pos[tl];
+                const bool rev = !(coin == 0 || tlen < 2);
+                ch_extra[tli] = ch_pos[tl];                           // Mutation(TLI, tl_pos, muts[tl_pos].stop, rev, tli_pos)
+                ch_stop[tli] = ch_stop[tl];
+                ch_aux[tli] = (uint8_t)((rev ? 1 : 0) | (ch_pos[tli] > 0 ? 2 : 0));
+            }
+        } else {
+            for (uint32_t q : tlis) { ch_extra[q] = ch_pos[q]; ch_stop[q] = 0; }   // unlinked: start = pos, stop = 0
+        }
+        // the visit filter, now that it is known which TL spans are records at all
+        uint32_t v2 = 0;
+        for (size_t r2 = 0; r2 + 1 < span.size(); r2++) {
+            visit_from[r2] = v2;
+            for (size_t q = span[r2 + 1]; q-- > span[r2];) {
+                const int t = ch_type[q] & 7;
+                if (ch_stop[q] == CHAIN_DROPPED || (ch_aux[q] & CHAIN_TOMBSTONE) ||
+                    (t != MSIM_DE && t != MSIM_DU && t != MSIM_IV && t != MSIM_TL)) continue;
+                if (ch_pos[q] >= v2) v2 = ch_stop[q] + 1;
+                break;
+            }
+        }
+    }
     lap(t_chain);
     if (prof) fprintf(stderr, "walk: K %llu chain %zu ranges %zu | sample %.0f gather %.0f chain+visit %.0f us\n", (unsigned long long)ms.K, n_ch, di, t_sample, t_gather, t_chain);
 #ifdef MSIM_SAMPLE_PROF
@@ -921,7 +1024,8 @@ int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_r
             di++;
         }
     }
-    std::vector<uint32_t> cand_pos(K + 8), ch_stop(ch_rank.size() + 8), visit_from(ms.n_draw + 1);
+    std::vector<uint32_t> cand_pos(K + 8), ch_stop(ch_rank.size() + 8), visit_from(ms.n_draw + 1), ch_extra(ch_rank.size() + 8);
+    std::vector<uint8_t> ch_aux(ch_rank.size() + 8);
     size_t consumed = 0;
     const uint32_t lg = chain_lg_rows(ms.gcc);
     for (size_t W = 4 * K + 65536;; W *= 4) {                        // a window that proves too short is simply retried
@@ -931,13 +1035,14 @@ int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_r
         accept_tables_host(ms.gcc, words.data(), W, T.data());
         const int rc = multimix_walk_host(c, L, ranges, n_ranges, d, ms, words.data(), T.data(), W, ch_rank.data(),
                                           ch_type.data(), ch_rank.size(), cand_pos.data(), ch_stop.data(), visit_from.data(),
-                                          &consumed);
+                                          &consumed, nullptr, ch_extra.data(), ch_aux.data());
         if (rc == MSIM_OK) break;
         if (rc != MSIM_ERR_HIP || W > (1ull << 31)) return rc;
     }
     for (size_t i = 0; i < consumed; i++) (void)c->py.next();
-    std::vector<uint32_t> stop(K, CHAIN_DROPPED);
-    for (size_t q = 0; q < ch_rank.size(); q++) stop[ch_rank[q]] = ch_stop[q];
+    std::vector<uint32_t> stop(K, CHAIN_DROPPED), extra(K, 0);
+    std::vector<uint8_t> aux(K, 0);
+    for (size_t q = 0; q < ch_rank.size(); q++) { stop[ch_rank[q]] = ch_stop[q]; extra[ch_rank[q]] = ch_extra[q]; aux[ch_rank[q]] = ch_aux[q]; }
     out.recs.clear();
     out.pool.clear();
     static const uint8_t ATGC[4] = {'A', 'T', 'G', 'C'};
@@ -950,10 +1055,12 @@ int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_r
         if (t == MSIM_SN) keep = ms.sn_chained ? stop[j] != CHAIN_DROPPED : p >= run;
         else {
             keep = stop[j] != CHAIN_DROPPED;
-            if (keep) {
-                const uint64_t e = (uint64_t)(t == MSIM_IN ? p : stop[j]) + 1 + (uint64_t)P.block[t];
+            if (keep) {                                              // (a TLI's blocked range is range(start, 1 + block): absolute)
+                const uint64_t e = t == MSIM_TLI ? 1 + (uint64_t)P.block[t]
+                                                 : (uint64_t)(t == MSIM_IN ? p : stop[j]) + 1 + (uint64_t)P.block[t];
                 run = std::max(run, (uint32_t)std::min<uint64_t>(e, clip[di]));
             }
+            if (aux[j] & CHAIN_TOMBSTONE) keep = false;              // deleted by __fix_tl_amount -- after it had blocked
         }
         if (!keep) continue;
         kept++;
@@ -969,6 +1076,9 @@ int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_r
             const uint32_t len = rec.stop + 1 - p;
             rec.extra = (uint32_t)out.pool.size();
             for (uint32_t i = 0; i < len; i++) out.pool.push_back(ATGC[c->np.next() & 3u]);
+        } else if (t == MSIM_TLI) {
+            rec.extra = extra[j];
+            rec.aux = aux[j] & 3;
         }
         out.recs.push_back(rec);
     }

@@ -1123,11 +1123,30 @@ __global__ __launch_bounds__(256) void k_stop_scatter(const uint32_t *__restrict
     const uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j < n_nsn) cand_stop[nsn_rank[j]] = nsn_stop[j];
 }
+// ... and what __link_tls decided for the chain's candidates (ctx.h: ch_extra / ch_aux), contigs with translocations
+__global__ __launch_bounds__(256) void k_link_scatter(const uint32_t *__restrict__ nsn_rank,
+                                                      const uint32_t *__restrict__ nsn_extra,
+                                                      const uint8_t *__restrict__ nsn_aux, uint32_t n_nsn,
+                                                      uint32_t *__restrict__ cand_extra, uint8_t *__restrict__ cand_aux) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n_nsn) { cand_extra[nsn_rank[j]] = nsn_extra[j]; cand_aux[nsn_rank[j]] = nsn_aux[j]; }
+}
+// output length change of one kept record (apply.hip: rec_lengths): IN / DU + len, DE / TL - len, IV 0, TLI + the copied span
+__device__ __forceinline__ long long record_delta(uint8_t type, uint32_t pos, uint32_t stop, uint32_t extra) {
+    const long long len = (long long)stop - (long long)pos + 1;
+    switch (type) {
+        case MSIM_IN: case MSIM_DU: return len;
+        case MSIM_DE: case MSIM_TL: return -len;
+        case MSIM_TLI: return stop + 1 > extra ? (long long)(stop + 1 - extra) : 0ll;
+        default: return 0ll;
+    }
+}
 
 // end (exclusive) of the blocked range a kept non-SNP opens: [pos, stop + block] resp. [pos, pos + block]
 // for an insertion (mutator.py:204-209); 0 for everything else
 __device__ __forceinline__ uint32_t blocked_end(uint32_t pos, uint8_t type, uint32_t stop, const BlockTable &bt) {
     if (type == MSIM_SN || stop == CHAIN_DROPPED) return 0;
+    if (type == MSIM_TLI) return bt.p1[MSIM_TLI];          // its stop is 0 in the boundary pass: range(start, 1 + block) (mutator.py:207)
     const unsigned long long e = (unsigned long long)(type == MSIM_IN ? pos : stop) + bt.p1[type & 7];
     return e > 0xffffffffull ? 0xffffffffu : (uint32_t)e;
 }
@@ -1198,7 +1217,9 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
                                                            uint32_t *__restrict__ cnt_keep, uint32_t *__restrict__ cnt_sn,
                                                            uint32_t *__restrict__ cnt_ins, long long *__restrict__ blk_delta,
                                                            const MixRangeDev *__restrict__ rt, uint32_t n_draw,
-                                                           const uint32_t *__restrict__ visit_from, uint32_t sn_chained) {
+                                                           const uint32_t *__restrict__ visit_from, uint32_t sn_chained,
+                                                           const uint32_t *__restrict__ cand_extra,
+                                                           const uint8_t *__restrict__ cand_aux) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint32_t pos[CB_ITEMS], stop[CB_ITEMS], before[CB_ITEMS];
@@ -1234,10 +1255,12 @@ __global__ __launch_bounds__(CB_THREADS) void k_keep_flags(const uint32_t *__res
             keep = (sn_chained ? stop[q] != CHAIN_DROPPED : pos[q] >= max(pre, before[q])) && vis[q];
             ns += keep ? 1u : 0u;
         } else {
-            keep = stop[q] != CHAIN_DROPPED && vis[q];
-            const uint32_t len = stop[q] - pos[q] + 1;
-            if (keep && t[q] == MSIM_IN) ni += len;
-            if (keep) delta += t[q] == MSIM_DE ? -(long long)len : (t[q] == MSIM_IV ? 0ll : (long long)len);   // mutator.py:343-399
+            // (translocations: an entry __fix_tl_amount deleted took part in the boundary pass -- its stop blocked above --
+            //  but is no record)
+            const bool tomb = cand_aux && (cand_aux[i0 + q] & CHAIN_TOMBSTONE);
+            keep = stop[q] != CHAIN_DROPPED && vis[q] && !tomb;
+            if (keep && t[q] == MSIM_IN) ni += stop[q] - pos[q] + 1;
+            if (keep) delta += record_delta(t[q], pos[q], stop[q], cand_extra ? cand_extra[i0 + q] : 0u);   // mutator.py:343-421
         }
         nk += keep ? 1u : 0u;
         if (keep) cand_type[i0 + q] = t[q] | KEEP_BIT;
@@ -1314,27 +1337,29 @@ __global__ __launch_bounds__(CB_THREADS) void k_emit_records(const uint32_t *__r
                                                              const uint32_t *__restrict__ off_ins,
                                                              const long long *__restrict__ off_delta,
                                                              msim_record *__restrict__ recs,
-                                                             uint32_t *__restrict__ sn_index, uint32_t *__restrict__ rec_off) {
+                                                             uint32_t *__restrict__ sn_index, uint32_t *__restrict__ rec_off,
+                                                             const uint32_t *__restrict__ cand_extra,
+                                                             const uint8_t *__restrict__ cand_aux) {
     __shared__ uint32_t wsum[CB_THREADS / 64];
     __shared__ long long wsum64[CB_THREADS / 64];
     const uint32_t i0 = blockIdx.x * CB_BLOCK + threadIdx.x * CB_ITEMS;
     uint8_t t[CB_ITEMS];
-    uint32_t pos[CB_ITEMS], stop[CB_ITEMS];
+    uint32_t pos[CB_ITEMS], stop[CB_ITEMS], ext[CB_ITEMS];
     uint32_t nk = 0, ns = 0, ni = 0;
     long long nd = 0;
 #pragma unroll
     for (int q = 0; q < CB_ITEMS; q++) {
         t[q] = i0 + q < k ? cand_type[i0 + q] : (uint8_t)0;
-        pos[q] = 0; stop[q] = 0;
+        pos[q] = 0; stop[q] = 0; ext[q] = 0;
         if (t[q] & KEEP_BIT) {
             pos[q] = cand_pos[i0 + q];
             const uint8_t ty = t[q] & 7;
             stop[q] = ty == MSIM_SN ? pos[q] : cand_stop[i0 + q];
+            if (ty == MSIM_TLI && cand_extra) ext[q] = cand_extra[i0 + q];
             nk++;
             if (ty == MSIM_SN) ns++;
-            const long long len = (long long)(stop[q] - pos[q] + 1);
-            if (ty == MSIM_IN) ni += (uint32_t)len;
-            nd += (ty == MSIM_IN || ty == MSIM_DU) ? len : (ty == MSIM_DE ? -len : 0ll);   // mutator.py:343-399
+            if (ty == MSIM_IN) ni += stop[q] - pos[q] + 1;
+            nd += record_delta(ty, pos[q], stop[q], ext[q]);             // mutator.py:343-421
         }
     }
     uint32_t tot;
@@ -1349,12 +1374,12 @@ __global__ __launch_bounds__(CB_THREADS) void k_emit_records(const uint32_t *__r
         const uint8_t ty = t[q] & 7;
         msim_record rec;
         rec.pos = pos[q]; rec.stop = stop[q]; rec.extra = 0; rec.type = ty; rec.aux = 0; rec.rsv = 0;
-        const long long len = (long long)(stop[q] - pos[q] + 1);
         if (ty == MSIM_SN) sn_index[s++] = r;
-        if (ty == MSIM_IN) { rec.extra = p; p += (uint32_t)len; }
+        if (ty == MSIM_IN) { rec.extra = p; p += stop[q] - pos[q] + 1; }
+        if (ty == MSIM_TLI) { rec.extra = ext[q]; rec.aux = cand_aux ? (uint8_t)(cand_aux[i0 + q] & 3) : (uint8_t)0; }   // linked span + flags
         // the record's offset in the mutated stream, the table APPLY would otherwise scan for (apply.hip: k_offsets)
         rec_off[r] = (uint32_t)((long long)pos[q] + shift);
-        shift += (ty == MSIM_IN || ty == MSIM_DU) ? len : (ty == MSIM_DE ? -len : 0ll);
+        shift += record_delta(ty, pos[q], stop[q], ext[q]);
         recs[r++] = rec;
     }
 }

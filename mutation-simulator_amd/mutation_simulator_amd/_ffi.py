@@ -179,6 +179,8 @@ class Engine:
     def __init__(self, device: int = 0, flags: int = PLAN_AUTO):
         self.lib = load()
         self.h = C.c_void_p()
+        if flags == PLAN_AUTO and os.environ.get("MSIM_PLAN_MODE"):      # diagnosis: 1 = host planner everywhere, 2 = device engines only
+            flags = int(os.environ["MSIM_PLAN_MODE"])
         rc = self.lib.msim_create(device, flags, C.byref(self.h))
         if rc != OK:
             msg = self.lib.msim_last_error(None).decode()

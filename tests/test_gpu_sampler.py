@@ -128,8 +128,8 @@ def test_ineligible_structures_are_refused_by_forced_gpu_mode():
     eng.seed(1, 1)
     cid = eng.add_contig_synthetic(1_000_000, 1)
     eng.set_params(_params())
-    with pytest.raises(_ffi.MsimUnsupported):     # translocations -> host planner territory
-        eng.plan_contig(cid, [_sv_range(0, 999_999, 8_000, {1: 0.5, 6: 0.5}, {6: (1, 20)})])
+    with pytest.raises(_ffi.MsimUnsupported):     # overlapping ranges (dict semantics) -> host planner territory
+        eng.plan_contig(cid, [_sv_range(0, 599_999, 8_000, C3_CHANCES, C3_LENS), _sv_range(400_000, 999_999, 8_000, C3_CHANCES, C3_LENS)])
     with pytest.raises(_ffi.MsimUnsupported):     # SV mix on a tiny range -> host planner territory
         eng.plan_contig(cid, [_sv_range(0, 9_999, 100, C3_CHANCES, C3_LENS)])
     eng.close()
@@ -463,6 +463,36 @@ def test_host_chain_with_other_engines_along_one_stream():
     for (hm, hp), (am, ap) in zip(hs, as_):
         assert _next_words(hm, hp, 8) == _next_words(am, ap, 8)
     assert ast["contigs_hostchain"] >= 2 and ast["contigs_snp"] == 1 and ast["contigs_svmix"] == 1 and ast["contigs_hostcut"] == 2
+
+
+TL_CHANCES = {1: 0.01, 2: 0.01, 3: 0.01, 5: 0.01, 4: 0.01, 6: 0.005, 7: 0.005}     # README: -sn -in -de -du -iv -tl 0.01 each
+TL_LENS = {2: (10, 100), 3: (1, 2), 4: (1, 2), 6: (1, 2)}
+
+
+@pytest.mark.parametrize("L,seed", [(3_000_000, 1), (1_200_000, 2)])
+def test_translocations_readme_flags_vs_host(L, seed):
+    """The reference's own benchmark flags (README "Performance": every type at 0.01, translocations included) through the
+    host-chain engine: TL / TLI on the chain, __link_tls behind the last range on the host, TLI records with their linked
+    spans from the device."""
+    r = _sv_range(0, L - 1, int(L * 0.06), TL_CHANCES, TL_LENS)
+    st = _compare([(L, [r])], _params(titv=1.0), seed=(seed, seed + 3), host_chain=True)
+    assert st["contigs_hostchain"] == 1
+
+
+def test_translocations_across_ranges_vs_host():
+    L = 1_800_000
+    blocks = {t: 2 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}
+    blocks["TL"] = 9
+    ranges = [
+        _rate_range(0, 399_999, 0.02, {1: 0.5, 6: 0.1, 7: 0.4}, {6: (5, 60)}, order=[7, 1, 6]),
+        _rate_range(400_000, 799_999, 0.01, {1: 1.0}, {}, order=[1]),
+        _rate_range(800_000, 1_199_999, 0.02, {1: 0.3, 6: 0.45, 7: 0.05, 3: 0.2}, {6: (200, 900), 3: (200, 900)}, order=[6, 3, 7, 1]),
+        _rate_range(1_200_000, 1_200_300, 0.1, {6: 0.5, 7: 0.5}, {6: (5, 60)}, order=[6, 7]),
+        _rate_range(1_200_301, L - 1, 0.015, {1: 0.4, 2: 0.2, 6: 0.2, 7: 0.2}, {2: (1, 9), 6: (5, 60)}),
+    ]
+    contigs = [(L, ranges), (600_000, [_rate_range(0, 599_999, 0.01, {1: 0.5, 7: 0.5}, {}, order=[1, 7])]),       # sites without spans
+               (900_000, [_sv_range(0, 899_999, 9_000, C3_CHANCES, C3_LENS)])]
+    _compare(contigs, _params(blocks, titv=2.0), seed=(13, 14), host_chain=True)
 
 
 def test_plan_chain_leaves_the_streams_where_plan_contig_does():

@@ -233,8 +233,77 @@ def test_random_layouts(case):
 def test_refuses_what_belongs_to_the_host_planner():
     L = 200_000
     tl = _range(0, L - 1, 0.01, {1: 0.5, 6: 0.5}, {6: (1, 20)}, order=[1, 6])
-    _both(L, [tl], None, 1.0, (1, 1), expect_unsupported=True)
+    _both(L, [tl], None, 1.0, (1, 1))                                            # (translocations: taken since round 3)
     a, b = _range(0, 99_999, 0.01, C3_CHANCES, C3_LENS), _range(50_000, 150_000, 0.01, C3_CHANCES, C3_LENS)
     _both(L, [a, b], None, 1.0, (1, 1), expect_unsupported=True)                 # overlapping: dict semantics
     five = [_range(i * 30_000, i * 30_000 + 29_999, 0.01, {1: 0.5, 3: 0.5}, {3: (1, 10 + 7 * i)}) for i in range(5)]
     _both(L, five, None, 1.0, (1, 1), expect_unsupported=True)                   # five randint classes
+
+
+# ---------------------------------------------------------------------- translocations (mutator.py:267-316)
+TL_CHANCES = {1: 0.01, 2: 0.01, 3: 0.01, 5: 0.01, 4: 0.01, 6: 0.005, 7: 0.005}     # README: -sn -in -de -du -iv -tl 0.01 each
+TL_LENS = {2: (10, 100), 3: (1, 2), 4: (1, 2), 6: (1, 2)}
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_translocations_readme_flags(seed):
+    """The reference's own benchmark flags (README "Performance"): TL spans and TLI sites linked behind the last range --
+    __fix_tl_amount's random deletions, shuffle, one coin per pair -- in ARGS order with the TLI chance appended."""
+    L = 1_500_000
+    r = _range(0, L - 1, 0.06, TL_CHANCES, TL_LENS, order=ARGS_ORDER)
+    recs = _both(L, [r], None, 1.0, (seed, seed + 3))
+    assert {6, 7} <= set(recs["type"].tolist())
+
+
+def test_translocations_across_ranges_and_tombstones():
+    """Several ranges with TL settings of their own (token order, longer spans, own blocks), SNP-only ranges between them,
+    far more TLI sites than TL spans in one range and the opposite in another (many deletions by __fix_tl_amount), spans
+    crossing range borders, d = 2."""
+    L = 900_000
+    blocks = {t: 2 for t in range(1, 8)}
+    blocks[6] = 9
+    ranges = [
+        _range(0, 199_999, 0.02, {1: 0.5, 6: 0.1, 7: 0.4}, {6: (5, 60)}, order=[7, 1, 6]),
+        _range(200_000, 399_999, 0.01, {1: 1.0}, {}),
+        _range(400_000, 599_999, 0.02, {1: 0.3, 6: 0.45, 7: 0.05, 3: 0.2}, {6: (200, 900), 3: (200, 900)}, order=[6, 3, 7, 1]),
+        _range(600_000, 600_300, 0.1, {6: 0.5, 7: 0.5}, {6: (5, 60)}, order=[6, 7]),
+        _range(600_301, L - 1, 0.015, {1: 0.4, 2: 0.2, 6: 0.2, 7: 0.2}, {2: (1, 9), 6: (5, 60)}, order=ARGS_ORDER),
+    ]
+    recs = _both(L, ranges, blocks, 2.0, (13, 14))
+    assert (recs["type"] == 7).sum() > 100 and (recs["type"] == 6).sum() > 100
+
+
+def test_translocation_sites_without_spans_stay_unlinked():
+    """tls empty: __link_tls is not called (mutator.py:130), every TLI keeps start = pos, stop = 0."""
+    L = 300_000
+    recs = _both(L, [_range(0, L - 1, 0.01, {1: 0.5, 7: 0.5}, {}, order=[1, 7])], None, 1.0, (2, 2))
+    t = recs[recs["type"] == 7]
+    assert len(t) > 500 and np.all(t["stop"] == 0) and np.array_equal(t["extra"], t["pos"])
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_layouts_with_translocations(case):
+    rs = np.random.RandomState(900 + case)
+    L = int(rs.randint(200_000, 1_000_000))
+    d = int(rs.choice([1, 1, 2]))
+    blocks = {t: d + int(rs.choice([0, 0, 1, 5])) for t in range(2, 8)}
+    blocks[1] = d if rs.rand() < 0.7 else d + 1
+    blocks[int(rs.choice([2, 3, 4, 5]))] = d
+    width = (1, 1 + int(rs.choice([1, 9, 60])))
+    sets = []
+    for _ in range(int(rs.randint(1, 4))):
+        types = [1] + [t for t in (2, 3, 4, 5, 6, 7) if rs.rand() < 0.6]
+        chances = {t: float(rs.uniform(0.05, 1.0)) for t in types}
+        lens = {t: (width[0] + int(rs.randint(0, 20)),) * 1 + (0,) for t in (2, 3, 4, 6)}
+        lens = {t: (a, a + width[1] - width[0]) for t, (a, _) in lens.items()}
+        lens[5] = (2, 2 + width[1] - width[0])
+        sets.append((chances, lens, [int(x) for x in rs.permutation(types)], float(rs.choice([0.005, 0.02, 0.06]))))
+    ranges, at = [], 0
+    while at < L - 50:
+        length = int(min(L - at, rs.choice([30, 2_000, 20_000, 150_000])))
+        chances, lens, order, rate = sets[int(rs.randint(0, len(sets)))]
+        r = _range(at, at + length - 1, rate, chances, lens, order)
+        if r.k > 0 and (r.stop - (r.k - 1) * d) - r.start >= r.k:
+            ranges.append(r)
+        at += length + int(rs.choice([0, 0, 1, 500]))
+    _both(L, ranges, blocks, 1.0, (case + 3, case + 30))
