@@ -143,12 +143,13 @@ void accept_tables_host(const ChainClasses &cc, const uint32_t *words, size_t n_
 struct ChainWalk {
     size_t j = 0, ws = 0, n_words = 0;                               // ws: next word position << lg_rows
     int64_t blk_hi = 0, bad = 0;                                     // last_mut_range = range(0)
-    int64_t add[8], next_add[8], next_cap[8], clamp[8], drop_from[8], in_mask[8];
+    int64_t add[8], next_add[8], next_cap[8], clamp[8], drop_from[8], in_mask[8], draw_mask[8];
     size_t row[8];
     uint32_t lg_rows = 0;
     int init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses &cc, size_t n_words);
-    static bool types_ok(const uint8_t *type, size_t n);
+    static bool types_ok(const uint8_t *type, size_t n, bool with_tl = false);
     void run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop);
+    void run_tl(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop);   // + TL / TLI
     int finish(Ctx *c, size_t n, size_t *consumed) const;
 };
 int chain_boundary_tables(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,

@@ -368,14 +368,24 @@ int ChainWalk::init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses 
         next_add[t] = (t == MSIM_IN ? 0 : add[t]) + blk1;
         next_cap[t] = clamp[t] + blk1;
         row[t] = chain_type ? cc.cls_of[t] : 0;
+        draw_mask[t] = -1;
     }
+    // TLI (run_tl only): no branch of __get_stop_position draws for it, its stop stays 0 and the blocked range it leaves is
+    // range(start, 1 + block) (mutator.py:207) -- an ABSOLUTE end: clamp the stop to 0, cap the next blocked end at 1 + block
+    // (p + next_add is never below it), and mask the table entry out of the slot increment
+    clamp[MSIM_TLI] = 0;
+    next_add[MSIM_TLI] = 1 + P.block[MSIM_TLI];
+    next_cap[MSIM_TLI] = 1 + P.block[MSIM_TLI];
+    draw_mask[MSIM_TLI] = 0;
     return MSIM_OK;
 }
 
-bool ChainWalk::types_ok(const uint8_t *type, size_t n) {
+bool ChainWalk::types_ok(const uint8_t *type, size_t n, bool with_tl) {
     uint32_t bad_type = 0;
-    for (size_t i = 0; i < n; i++) bad_type |= (uint32_t)(uint8_t)(type[i] - MSIM_IN) > (uint32_t)(MSIM_IV - MSIM_IN);
-    static_assert(MSIM_IN == 2 && MSIM_DE == 3 && MSIM_DU == 4 && MSIM_IV == 5, "boundary types are ids 2..5");
+    const uint32_t span = (uint32_t)((with_tl ? MSIM_TLI : MSIM_IV) - MSIM_IN);
+    for (size_t i = 0; i < n; i++) bad_type |= (uint32_t)(uint8_t)(type[i] - MSIM_IN) > span;
+    static_assert(MSIM_IN == 2 && MSIM_DE == 3 && MSIM_DU == 4 && MSIM_IV == 5 && MSIM_TL == 6 && MSIM_TLI == 7,
+                  "boundary types are ids 2..5, translocations 6 and 7");
     return !bad_type;
 }
 
@@ -390,7 +400,9 @@ bool ChainWalk::types_ok(const uint8_t *type, size_t n) {
         const int64_t a0 = p + next_add[t];                                                                    \
         const int64_t cap = (next_cap[t] & in_mask[t]) | (a0 & ~in_mask[t]);                                   \
         const uint32_t e = (T + row[t])[s_at];                         /* the one load of the chain */         \
-        const int64_t d = e >> 24, v = e & 0xffffff;                   /* d: slot increment */                 \
+        const int64_t d0 = e >> 24;                                    /* slot increment as tabulated */        \
+        const int64_t dm = MSIM_CHAIN_TL ? draw_mask[t] : -1;          /* TLI draws nothing */                  \
+        const int64_t d = d0 & dm, v = (int64_t)(e & 0xffffff) & dm;   /* d: slot increment */                 \
         int64_t nb = a0 + v;                                                                                   \
         nb = nb > cap ? cap : nb;                                                                              \
         const int64_t s_next = s_at + d;                                                                       \
@@ -399,7 +411,7 @@ bool ChainWalk::types_ok(const uint8_t *type, size_t n) {
         int64_t km = -(int64_t)(pe >= hi);                             /* all ones: kept (mutator.py:190-191) */ \
         asm("" : "+r"(km));                                                                                    \
         stop[jj] = (uint32_t)s | (uint32_t)~km;                        /* CHAIN_DROPPED = all ones */          \
-        bd |= (d - 1) & km;                                            /* kept with d == 0: no accepted draw in reach */ \
+        bd |= (d0 - 1) & km & dm;                                      /* kept with d == 0: no accepted draw in reach */ \
         MSIM_CHAIN_SELECT();                                                                                   \
     } while (0)
 #if defined(__x86_64__)
@@ -410,6 +422,7 @@ bool ChainWalk::types_ok(const uint8_t *type, size_t n) {
 #define MSIM_CHAIN_SELECT() do { hi = (nb & km) | (hi & ~km); s_at = (s_next & km) | (s_at & ~km); } while (0)
 #endif
 
+#define MSIM_CHAIN_TL 0
 void ChainWalk::run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop) {
     size_t jj = j;
     int64_t s_at = (int64_t)ws, hi = blk_hi, bd = bad;
@@ -425,6 +438,25 @@ void ChainWalk::run(const uint32_t *pos, const uint8_t *type, size_t n, const ui
     }
     j = jj; ws = (size_t)s_at; blk_hi = hi; bad = bd;
 }
+#undef MSIM_CHAIN_TL
+#define MSIM_CHAIN_TL 1
+// the same walk for contigs whose ranges draw translocations: TL behaves like DE, TLI draws nothing (draw_mask)
+void ChainWalk::run_tl(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop) {
+    size_t jj = j;
+    int64_t s_at = (int64_t)ws, hi = blk_hi, bd = bad;
+    const int64_t s_lim = (int64_t)(w_lim << lg_rows);
+    constexpr int64_t RUN = 32, RUN_SLOTS = RUN * 256;                // a candidate advances at most 63 << 2 slots
+    while (jj < n && s_at < s_lim) {
+        if (jj + RUN <= n && s_at + RUN_SLOTS <= s_lim) {
+            for (const size_t je = jj + RUN; jj < je; jj++) MSIM_CHAIN_STEP();
+        } else {
+            MSIM_CHAIN_STEP();
+            jj++;
+        }
+    }
+    j = jj; ws = (size_t)s_at; blk_hi = hi; bad = bd;
+}
+#undef MSIM_CHAIN_TL
 #undef MSIM_CHAIN_STEP
 #undef MSIM_CHAIN_SELECT
 
@@ -808,14 +840,14 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
                        size_t *consumed, const WordFeed *feed, uint32_t *ch_extra, uint8_t *ch_aux) {
     const auto t0 = std::chrono::steady_clock::now();
     const msim_params &P = c->params;
-    const bool generic = ms.sn_chained || ms.has_tl;                 // the plain loop: SNPs on the chain and / or TL, TLI
+    const bool generic = ms.sn_chained;                              // the plain loop: SNPs are on the chain as well
     if (ms.has_tl && (!ch_extra || !ch_aux)) return fail(c, MSIM_ERR_ARG, "host chain: translocations need ch_extra / ch_aux");
     if (generic) {
         uint32_t bad = 0;
         const uint32_t lo = ms.sn_chained ? MSIM_SN : MSIM_IN, hi_t = ms.has_tl ? MSIM_TLI : MSIM_IV;
         for (size_t i = 0; i < n_ch; i++) bad |= (uint32_t)(uint8_t)(ch_type[i] - lo) > hi_t - lo;
         if (bad) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside what its ranges draw");
-    } else if (!ChainWalk::types_ok(ch_type, n_ch)) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside IN/DE/DU/IV");
+    } else if (!ChainWalk::types_ok(ch_type, n_ch, ms.has_tl)) return fail(c, MSIM_ERR_HIP, "host chain: candidate type outside what its ranges draw");
     std::vector<ChainWalk> proto(ms.rep.size());
     for (size_t s = 0; s < proto.size(); s++) {
         const int rc = proto[s].init(c, ranges[ms.rep[s]], L, ms.cc[s], n_words);
@@ -873,7 +905,8 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
             cw.j = 0; cw.blk_hi = 0; cw.bad = 0;                     // last_mut_range = range(0), per range (mutator.py:184)
             cw.ws = w << lg;
             for (;;) {
-                cw.run(pb, ch_type + qa, m, T, t_lim(), ch_stop + qa);
+                if (ms.has_tl) cw.run_tl(pb, ch_type + qa, m, T, t_lim(), ch_stop + qa);
+                else cw.run(pb, ch_type + qa, m, T, t_lim(), ch_stop + qa);
                 if (cw.j >= m) break;
                 if (!more()) return overflow();
             }
