@@ -209,6 +209,11 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
                        const uint8_t *ch_type, size_t n_ch, uint32_t *cand_pos, uint32_t *ch_stop, uint32_t *visit_from,
                        size_t *consumed, const WordFeed *feed = nullptr, uint32_t *ch_extra = nullptr,
                        uint8_t *ch_aux = nullptr);
+// __link_tls for one contig's chain candidates over a plain word window (the SV-mix engine: one range, the window fetched
+// behind the boundary walk); *consumed = words drawn.  ch_extra / ch_aux are cleared first.
+int link_translocations(Ctx *c, const uint32_t *words, size_t n_words, const uint32_t *ch_pos, const uint8_t *ch_type,
+                        uint32_t *ch_stop, uint32_t *ch_extra, uint8_t *ch_aux, size_t n_ch, size_t *consumed);
+void count_translocations(const uint8_t *type, const uint32_t *stop, size_t n, size_t *n_tl, size_t *n_tli);
 // test support (msim_dbg_multimix_plan): the whole engine on the host -- the device's parts (types, tables, keep
 // flags, records) restated sequentially -- so the CPU tier can hold the algorithm against plan_contig_host
 int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out);

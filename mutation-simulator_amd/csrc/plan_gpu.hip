@@ -760,7 +760,13 @@ static bool range_type_drawable(const msim_range &r, int j) {
     return r.cdf_thr[j] > lo && lo < (1ull << 53);
 }
 
-// SV mix on one large set-path range (ARGS mode: one range per contig): SNPs plus any of IN/DE/DU/IV.
+static bool range_draws_translocations(const msim_range &r) {
+    for (int j = 0; j < r.n_types; j++)
+        if ((r.types[j] == MSIM_TL || r.types[j] == MSIM_TLI) && range_type_drawable(r, j)) return true;
+    return false;
+}
+
+// SV mix on one large set-path range (ARGS mode: one range per contig): SNPs plus any of IN/DE/DU/IV/TL/TLI.
 bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
     const msim_params &P = c->params;
     int64_t d = P.block[1];
@@ -783,13 +789,18 @@ bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_range
         if (!range_type_drawable(r, j)) continue;
         const int t = r.types[j];
         if (t == MSIM_SN) continue;
-        if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return false;   // TL / TLI: host planner
+        if (t == MSIM_TLI) continue;                      // an insertion site: no length draw
+        if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV && t != MSIM_TL) return false;
         const int64_t w = r.max_len[t] - r.min_len[t] + 1;
         if (r.min_len[t] < 1 || w < 1 || w >= (1ll << 32)) return false;
         if (t == MSIM_IN && (double)r.k * (double)r.max_len[t] >= 4.0e9) return false;     // insert pool offsets are 32-bit
     }
     for (int t = 1; t <= 7; t++)
         if (P.block[t] >= (1ll << 32)) return false;
+    if (range_draws_translocations(r)) {                  // their walk exists over accept tables only (ChainWalk::run_tl)
+        ChainClasses cc;
+        if (!chain_classes(r, cc)) return false;
+    }
     return true;
 }
 
@@ -962,6 +973,37 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     return MSIM_OK;
 }
 
+// __link_tls of the SV-mix engine (mutator.py:130-131 -- after the boundary pass, before __mutate_sequence): its draws follow
+// the boundary pass's in the CPython stream, so once the walk knows where that ended, a 16-sigma window of tempered words
+// from there comes over and plan_host.cpp links on it.  consumed grows by the words linking drew.
+static int mixed_link_translocations(Ctx *c, GpuPlan *g, MixedSet &M, uint32_t n_nsn, uint64_t p_b, size_t &consumed, bool &grew) {
+    size_t n_tl = 0, n_tli = 0;
+    count_translocations(g->h_ntype, g->h_nstop, n_nsn, &n_tl, &n_tli);
+    uint32_t Wl = 0;
+    int rc;
+    if (n_tl) {                                            // (no TL: `if tls:` is false and nothing is drawn)
+        // |n_tl - n_tli| deletions, min - 1 shuffle swaps and one coin per pair (randint(0, 1) takes two bits and rejects half
+        // of them): every draw accepts a word with probability >= 1/2 -- at most 2 words expected, variance 2
+        const double mn = (double)std::min(n_tl, n_tli), draws = (double)(std::max(n_tl, n_tli) - std::min(n_tl, n_tli)) + 2.0 * mn;
+        const double wl = 2.0 * draws + 16.0 * std::sqrt(2.0 * draws + 1.0) + 4096.0;
+        if (wl >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "linking window beyond 2^32 words");
+        Wl = (uint32_t)wl;
+        const uint64_t p_l = p_b + consumed;
+        if ((rc = ensure_words(c, g, 0, p_l + Wl + 1))) return rc;
+        if ((rc = grow(c, (void **)&M.words, &M.cap_words, (size_t)Wl * 4 + 64, &grew))) return rc;
+        if (g->cap_h_win < (size_t)Wl * 4 && (rc = grow_host(c, (void **)&g->h_win, &g->cap_h_win, (size_t)Wl * 4))) return rc;
+        hipLaunchKernelGGL(k_temper_window, dim3((Wl + 255) / 256), dim3(256), 0, c->stream, g->s[0].d_raw, (unsigned long long)p_l, Wl,
+                           M.words);
+        MSIM_HIP(c, hipGetLastError());
+        MSIM_HIP(c, hipMemcpyAsync(g->h_win, M.words, (size_t)Wl * 4, hipMemcpyDeviceToHost, c->stream));
+        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    size_t used = 0;
+    if ((rc = link_translocations(c, g->h_win, Wl, g->h_npos, g->h_ntype, g->h_nstop, g->h_nextra, g->h_naux, n_nsn, &used))) return rc;
+    consumed += used;
+    return MSIM_OK;
+}
+
 int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges) {
     const msim_params &P = c->params;
     int64_t d = P.block[1];
@@ -1004,6 +1046,19 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     if ((rc = grow(c, (void **)&M.nsn_stop, &M.cap_nstop, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.sn_index, &M.cap_snidx, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.cnt, &M.cap_cnt, mixed_cnt_bytes(nbk), &grew))) return rc;
+    const bool has_tl = range_draws_translocations(r);
+    if (has_tl) {                                          // what __link_tls decides, per candidate and in chain order
+        if ((rc = grow(c, (void **)&M.cand_extra, &M.cap_cextra, (size_t)k * 4 + 64, &grew))) return rc;
+        if ((rc = grow(c, (void **)&M.cand_aux, &M.cap_caux, (size_t)k + 64, &grew))) return rc;
+        if ((rc = grow(c, (void **)&M.nsn_extra, &M.cap_nextra, (size_t)k * 4 + 64, &grew))) return rc;
+        if ((rc = grow(c, (void **)&M.nsn_aux, &M.cap_naux, (size_t)k + 64, &grew))) return rc;
+        if (g->cap_h_nextra < (size_t)k * 4 + 64 || g->cap_h_naux < (size_t)k + 64) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+            if ((rc = grow_host(c, (void **)&g->h_nextra, &g->cap_h_nextra, (size_t)k * 4 + 64))) return rc;
+            if ((rc = grow_host(c, (void **)&g->h_naux, &g->cap_h_naux, (size_t)k + 64))) return rc;
+        }
+    }
     uint32_t *cnt_nsn = M.cnt;                             // (the other four counter arrays: mixed_emit)
 
     // ---- 1. sample -> bitmap; bitmap -> candidates with types; non-SNP candidates compacted
@@ -1059,7 +1114,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         double acc_min = 1.0;                              // least acceptance of randint among the types this range draws
         for (int j = 0; j < r.n_types; j++) {
             const int t = r.types[j];
-            if (t == MSIM_SN || !range_type_drawable(r, j)) continue;
+            if (t == MSIM_SN || t == MSIM_TLI || !range_type_drawable(r, j)) continue;
             const int64_t w = r.max_len[t] - r.min_len[t] + 1;
             if (w >= 1 && w < (1ll << 32)) acc_min = std::min(acc_min, (double)w / (double)(1ull << bit_length64((uint64_t)w)));
         }
@@ -1105,11 +1160,12 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             auto tp = std::chrono::steady_clock::now();
             auto lap = [&](double &acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::micro>(n - tp).count(); tp = n; };
             rc = spin_event(c, g->ev_cand);
-            if (!rc && !ChainWalk::types_ok(g->h_ntype, n_nsn)) rc = fail(c, MSIM_ERR_HIP, "boundary chain: candidate type outside IN/DE/DU/IV");
+            if (!rc && !ChainWalk::types_ok(g->h_ntype, n_nsn, has_tl)) rc = fail(c, MSIM_ERR_HIP, "boundary chain: candidate type outside the range's draw");
             for (int q = 0; q < 3 && !rc; q++) {
                 if ((rc = spin_event(c, g->ev_piece[q]))) break;
                 lap(t_wait);
-                cw.run(g->h_npos, g->h_ntype, n_nsn, g->h_words, cut[q + 1], g->h_nstop);
+                if (has_tl) cw.run_tl(g->h_npos, g->h_ntype, n_nsn, g->h_words, cut[q + 1], g->h_nstop);
+                else cw.run(g->h_npos, g->h_ntype, n_nsn, g->h_words, cut[q + 1], g->h_nstop);
                 lap(t_run);
             }
             if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows);
@@ -1134,14 +1190,25 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             rc = chain_boundary_host(c, r, ct.len, g->h_npos, g->h_ntype, n_nsn, g->h_words, Wb, g->h_nstop,
                                      &consumed, &kept_host, &delta_host);
         }
+        if (!rc && has_tl) rc = mixed_link_translocations(c, g, M, n_nsn, p_b, consumed, grew);
         if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }
         MSIM_HIP(c, hipEventRecord(g->t0, c->stream));    // the host chain is not GPU time
         MSIM_HIP(c, hipMemcpyAsync(M.nsn_stop, g->h_nstop, (size_t)n_nsn * 4, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_stop_scatter, dim3((n_nsn + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_stop, n_nsn,
                            M.cand_stop);
     }
+    if (has_tl) {
+        MSIM_HIP(c, hipMemsetAsync(M.cand_aux, 0, (size_t)k, c->stream));
+        if (n_nsn) {
+            MSIM_HIP(c, hipMemcpyAsync(M.nsn_extra, g->h_nextra, (size_t)n_nsn * 4, hipMemcpyHostToDevice, c->stream));
+            MSIM_HIP(c, hipMemcpyAsync(M.nsn_aux, g->h_naux, (size_t)n_nsn, hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(k_link_scatter, dim3((n_nsn + 255) / 256), dim3(256), 0, c->stream, M.nsn_rank, M.nsn_extra, M.nsn_aux,
+                               n_nsn, M.cand_extra, M.cand_aux);
+        }
+        MSIM_HIP(c, hipGetLastError());
+    }
     const uint64_t p_s = p_b + consumed;                   // the SNP draws of __mutate_sequence start here
-    return mixed_emit(c, g, ct, M, k, p_s, nullptr, 0, nullptr, false, grew);
+    return mixed_emit(c, g, ct, M, k, p_s, nullptr, 0, nullptr, false, grew, has_tl);
 }
 
 

@@ -834,6 +834,169 @@ struct IndexedList {
 };
 }  // namespace
 
+// The kept TL spans and TLI sites among the chain's candidates: their numbers, then their indices in chain order
+// (tls / tlis: room for 16 entries more than counted).
+void count_translocations(const uint8_t *type, const uint32_t *stop, size_t n, size_t *n_tl, size_t *n_tli) {
+    size_t a = 0, b = 0;
+    for (size_t q = 0; q < n; q++) {
+        const unsigned kept = stop[q] != CHAIN_DROPPED, t = type[q] & 7u;
+        a += kept & (t == (unsigned)MSIM_TL);
+        b += kept & (t == (unsigned)MSIM_TLI);
+    }
+    *n_tl = a;
+    *n_tli = b;
+}
+static void collect_translocations_scalar(const uint8_t *type, const uint32_t *stop, size_t q, size_t n, uint32_t *tls, size_t a,
+                                          uint32_t *tlis, size_t b) {
+    for (; q < n; q++) {
+        const unsigned kept = stop[q] != CHAIN_DROPPED, t = type[q] & 7u;
+        tls[a] = (uint32_t)q;
+        a += kept & (t == (unsigned)MSIM_TL);
+        tlis[b] = (uint32_t)q;
+        b += kept & (t == (unsigned)MSIM_TLI);
+    }
+}
+#ifdef MSIM_X86_HOST
+__attribute__((target("avx512f,avx512bw,avx512vl,popcnt"))) static void collect_translocations_avx512(
+    const uint8_t *type, const uint32_t *stop, size_t n, uint32_t *tls, uint32_t *tlis) {
+    size_t a = 0, b = 0, q = 0;
+    __m512i lane = _mm512_setr_epi32(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const __m512i step = _mm512_set1_epi32(16), dropped = _mm512_set1_epi32((int)CHAIN_DROPPED), seven = _mm512_set1_epi32(7);
+    const __m512i v_tl = _mm512_set1_epi32(MSIM_TL), v_tli = _mm512_set1_epi32(MSIM_TLI);
+    for (; q + 16 <= n; q += 16) {
+        const __m512i t = _mm512_and_si512(_mm512_cvtepu8_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i *>(type + q))), seven);
+        const __mmask16 kept = _mm512_cmpneq_epu32_mask(_mm512_loadu_si512(stop + q), dropped);
+        const __mmask16 m_tl = _mm512_mask_cmpeq_epu32_mask(kept, t, v_tl), m_tli = _mm512_mask_cmpeq_epu32_mask(kept, t, v_tli);
+        _mm512_storeu_si512(tls + a, _mm512_maskz_compress_epi32(m_tl, lane));      // (compress in the register: see collect_accepted)
+        _mm512_storeu_si512(tlis + b, _mm512_maskz_compress_epi32(m_tli, lane));
+        a += (size_t)__builtin_popcount((unsigned)m_tl);
+        b += (size_t)__builtin_popcount((unsigned)m_tli);
+        lane = _mm512_add_epi32(lane, step);
+    }
+    collect_translocations_scalar(type, stop, q, n, tls, a, tlis, b);
+}
+#endif
+static void collect_translocations(const uint8_t *type, const uint32_t *stop, size_t n, uint32_t *tls, uint32_t *tlis) {
+#ifdef MSIM_X86_HOST
+    static const bool wide = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl");
+    if (wide) { collect_translocations_avx512(type, stop, n, tls, tlis); return; }
+#endif
+    collect_translocations_scalar(type, stop, 0, n, tls, 0, tlis, 0);
+}
+
+// __link_tls (mutator.py:130-131, 267-316) over the chain's candidates of one contig, in order: the kept TL spans and TLI
+// sites; __fix_tl_amount deletes random surplus entries (they stay in ch_stop -- they blocked -- and get CHAIN_TOMBSTONE),
+// shuffle(tls), one coin per pair.  src: the tempered CPython-stream words that follow -- words[w .. avail) are there,
+// more() makes avail grow (false: the window is exhausted).
+template <class More>
+struct LinkWords { const uint32_t *words; size_t w; const size_t &avail; More more; };
+template <class Src>
+static bool link_translocations_impl(const uint32_t *ch_pos, const uint8_t *ch_type, uint32_t *ch_stop, uint32_t *ch_extra,
+                                     uint8_t *ch_aux, size_t n_ch, Src &src) {
+    auto next_word = [&](uint32_t &out) -> bool {
+        while (src.w >= src.avail) if (!src.more()) return false;
+        out = src.words[src.w++];
+        return true;
+    };
+    static const bool prof = getenv("MSIM_WALK_PROF") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    double t_ph[4] = {0, 0, 0, 0};
+    auto lap = [&](int ph) { if (prof) { const auto n = std::chrono::steady_clock::now(); t_ph[ph] += std::chrono::duration<double, std::micro>(n - tp).count(); tp = n; } };
+    size_t n_tl = 0, n_tli = 0;
+    count_translocations(ch_type, ch_stop, n_ch, &n_tl, &n_tli);
+    std::vector<uint32_t> tls(n_tl + 16), tlis(n_tli + 16);           // (16: the collectors store whole vectors)
+    collect_translocations(ch_type, ch_stop, n_ch, tls.data(), tlis.data());
+    tls.resize(n_tl);
+    tlis.resize(n_tli);
+    auto randbelow_w = [&](uint64_t n, uint64_t &out) -> bool {      // Lib/random.py _randbelow_with_getrandbits
+        if (!n) { out = 0; return true; }
+        const int sh = 32 - bit_length64(n);
+        uint64_t v;
+        do {
+            uint32_t word;
+            if (!next_word(word)) return false;
+            v = word >> sh;
+        } while (v >= n);
+        out = v;
+        return true;
+    };
+    if (tls.empty()) {
+        for (uint32_t q : tlis) { ch_extra[q] = ch_pos[q]; ch_stop[q] = 0; }   // `if tls:` is false: start = pos, stop = 0 stay
+        return true;
+    }
+    lap(0);
+    if (tls.size() != tlis.size()) {
+        std::vector<uint32_t> &longer = tls.size() > tlis.size() ? tls : tlis;
+        const size_t want = std::min(tls.size(), tlis.size());
+        IndexedList lst(longer.size());
+        while (lst.alive > want) {
+            uint64_t idx;
+            if (!randbelow_w(lst.alive, idx)) return false;              // randint(0, len - 1)
+            const size_t at = lst.select((size_t)idx);
+            ch_aux[longer[at]] |= CHAIN_TOMBSTONE;                          // del muts[...]: no record -- but it blocked
+            lst.erase(at);
+            longer[at] = 0xffffffffu;
+        }
+        longer.erase(std::remove(longer.begin(), longer.end(), 0xffffffffu), longer.end());
+    }
+    lap(1);
+    for (size_t i = tls.size(); i > 1;) {                             // random.shuffle(tls): for i = n-1 .. 1: swap(i, randbelow(i + 1))
+        uint32_t js[32];                                              // (the draws of a batch first: their targets are random cache lines)
+        const size_t nb = std::min<size_t>(32, i - 1);
+        for (size_t b = 0; b < nb; b++) {
+            uint64_t j;
+            if (!randbelow_w((uint64_t)(i - b), j)) return false;
+            js[b] = (uint32_t)j;
+            __builtin_prefetch(&tls[(size_t)j], 1);
+        }
+        for (size_t b = 0; b < nb; b++) std::swap(tls[i - 1 - b], tls[js[b]]);
+        i -= nb;
+    }
+    lap(2);
+    // __transloc_invert draws its coin first and looks at the length afterwards: randint(0, 1) = getrandbits(2) until < 2 -- a word
+    // is accepted when its top bit is clear, the coin is the bit below.  All coins first, branch-free.
+    std::vector<uint8_t> coins(tls.size() + 1);
+    for (size_t got = 0; got < tls.size();) {
+        while (src.w >= src.avail) if (!src.more()) return false;
+        const size_t e = src.avail;
+        size_t w = src.w;
+        while (w < e && got < tls.size()) {
+            const uint32_t word = src.words[w++];
+            coins[got] = (uint8_t)((word >> 30) & 1u);
+            got += (word >> 31) ^ 1u;
+        }
+        src.w = w;
+    }
+    for (size_t i = 0; i < tls.size(); i++) {
+        if (i + 24 < tls.size()) { __builtin_prefetch(ch_pos + tls[i + 24]); __builtin_prefetch(ch_stop + tls[i + 24]); }
+        const uint32_t tl = tls[i], tli = tlis[i];
+        const unsigned coin = coins[i];
+        const int64_t tlen = (int64_t)ch_stop[tl] + 1 - (int64_t)ch_pos[tl];
+        const bool rev = !(coin == 0 || tlen < 2);
+        ch_extra[tli] = ch_pos[tl];                                   // Mutation(TLI, tl_pos, muts[tl_pos].stop, rev, tli_pos)
+        ch_stop[tli] = ch_stop[tl];
+        ch_aux[tli] = (uint8_t)((ch_aux[tli] & CHAIN_TOMBSTONE) | (rev ? 1 : 0) | (ch_pos[tli] > 0 ? 2 : 0));
+    }
+    lap(3);
+    if (prof) fprintf(stderr, "link: %zu pairs | collect %.0f fix %.0f shuffle %.0f pair %.0f us\n", tls.size(), t_ph[0], t_ph[1], t_ph[2], t_ph[3]);
+    return true;
+}
+
+int link_translocations(Ctx *c, const uint32_t *words, size_t n_words, const uint32_t *ch_pos, const uint8_t *ch_type,
+                        uint32_t *ch_stop, uint32_t *ch_extra, uint8_t *ch_aux, size_t n_ch, size_t *consumed) {
+    const auto t0 = std::chrono::steady_clock::now();
+    auto none = []() { return false; };
+    const size_t avail = n_words;
+    LinkWords<decltype(none)> src{words, 0, avail, none};
+    memset(ch_extra, 0, n_ch * sizeof(uint32_t));
+    memset(ch_aux, 0, n_ch);
+    if (!link_translocations_impl(ch_pos, ch_type, ch_stop, ch_extra, ch_aux, n_ch, src))
+        return fail(c, MSIM_ERR_HIP, "translocation linking: word window overflowed its margin");
+    *consumed = src.w;
+    c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return MSIM_OK;
+}
+
 int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, int64_t d, const MixSets &ms,
                        const uint32_t *words, const uint32_t *T, size_t n_words, const uint32_t *ch_rank,
                        const uint8_t *ch_type, size_t n_ch, uint32_t *cand_pos, uint32_t *ch_stop, uint32_t *visit_from,
@@ -952,56 +1115,11 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
         // ---- __link_tls (mutator.py:130-131, 267-316), behind the last range: the kept TL spans and TLI sites of the whole
         // contig, in range order; __fix_tl_amount deletes random surplus entries, shuffle(tls), one coin per pair
         span.push_back(n_ch);
-        std::vector<uint32_t> tls, tlis;
-        for (size_t q = 0; q < n_ch; q++) {
-            if (ch_stop[q] == CHAIN_DROPPED) continue;
-            const int t = ch_type[q] & 7;
-            if (t == MSIM_TL) tls.push_back((uint32_t)q); else if (t == MSIM_TLI) tlis.push_back((uint32_t)q);
-        }
-        auto randbelow_w = [&](uint64_t n, uint64_t &out) -> bool {  // Lib/random.py _randbelow_with_getrandbits over the window
-            if (!n) { out = 0; return true; }
-            const int sh = 32 - bit_length64(n);
-            uint64_t v;
-            do {
-                while (w >= avail) if (!more()) return false;
-                v = words[w++] >> sh;
-            } while (v >= n);
-            out = v;
-            return true;
-        };
-        if (!tls.empty()) {
-            if (tls.size() != tlis.size()) {
-                std::vector<uint32_t> &longer = tls.size() > tlis.size() ? tls : tlis;
-                const size_t want = std::min(tls.size(), tlis.size());
-                IndexedList lst(longer.size());
-                while (lst.alive > want) {
-                    uint64_t idx;
-                    if (!randbelow_w(lst.alive, idx)) return overflow();          // randint(0, len - 1)
-                    const size_t at = lst.select((size_t)idx);
-                    ch_aux[longer[at]] |= CHAIN_TOMBSTONE;                          // del muts[...]: no record -- but it blocked
-                    lst.erase(at);
-                    longer[at] = 0xffffffffu;
-                }
-                longer.erase(std::remove(longer.begin(), longer.end(), 0xffffffffu), longer.end());
-            }
-            for (size_t i = tls.size(); i-- > 1;) {                   // random.shuffle(tls)
-                uint64_t j;
-                if (!randbelow_w((uint64_t)i + 1, j)) return overflow();
-                std::swap(tls[i], tls[(size_t)j]);
-            }
-            for (size_t i = 0; i < tls.size(); i++) {
-                const uint32_t tl = tls[i], tli = tlis[i];
-                uint64_t coin;
-                if (!randbelow_w(2, coin)) return overflow();         // __transloc_invert draws first, then looks at the length
-                const int64_t tlen = (int64_t)ch_stop[tl] + 1 - (int64_t)ch_pos[tl];
-                const bool rev = !(coin == 0 || tlen < 2);
-                ch_extra[tli] = ch_pos[tl];                           // Mutation(TLI, tl_pos, muts[tl_pos].stop, rev, tli_pos)
-                ch_stop[tli] = ch_stop[tl];
-                ch_aux[tli] = (uint8_t)((rev ? 1 : 0) | (ch_pos[tli] > 0 ? 2 : 0));
-            }
-        } else {
-            for (uint32_t q : tlis) { ch_extra[q] = ch_pos[q]; ch_stop[q] = 0; }   // unlinked: start = pos, stop = 0
-        }
+        auto step = [&]() -> bool { return more(); };                 // (raises `avail`, which the source sees by reference)
+        LinkWords<decltype(step)> src{words, w, avail, step};
+        const bool linked = link_translocations_impl(ch_pos.data(), ch_type, ch_stop, ch_extra, ch_aux, n_ch, src);
+        w = src.w;
+        if (!linked) return overflow();
         // the visit filter, now that it is known which TL spans are records at all
         uint32_t v2 = 0;
         for (size_t r2 = 0; r2 + 1 < span.size(); r2++) {

@@ -17,17 +17,18 @@ import numpy as np
 class MappedRegion:
     """The next ``nbytes`` of an output file as a writable uint8 array (``view``): the file is extended and that span
     mapped, so whoever fills it -- a device-to-host copy -- writes straight into the page cache.  ``close`` unmaps.
-    ``whole``: a mapping of the file's preallocated head that already covers the span (``FastaWriter.preallocate``)."""
+    ``ahead``: the writer's ``Preallocator``; a span inside one of its arenas is a slice of that mapping."""
     __slots__ = ("pos", "nbytes", "view", "_map")
 
-    def __init__(self, fileobj, nbytes: int, whole=None):
+    def __init__(self, fileobj, nbytes: int, ahead=None):
         fileobj.flush()
         self.pos = fileobj.tell()
         self.nbytes = int(nbytes)
         self._map = None
-        if self.nbytes and whole is not None and self.pos + self.nbytes <= len(whole):
-            self.view = np.frombuffer(whole, dtype=np.uint8, count=self.nbytes, offset=self.pos)
-        elif self.nbytes:
+        self.view = ahead.view(self.pos, self.nbytes) if (ahead is not None and self.nbytes) else None
+        if self.view is not None:
+            return
+        if self.nbytes:
             fd = fileobj.fileno()
             if os.fstat(fd).st_size < self.pos + self.nbytes:
                 # allocate the span's pages in bulk: faulting fresh pages of a just-extended file in one by one costs
@@ -53,50 +54,87 @@ class MappedRegion:
 _MADV_POPULATE_WRITE = 23          # Linux >= 5.14: allocate + map the pages of a range now
 
 
-def _preallocate(owner, fileobj, nbytes: int):
-    """Background: allocate the file's first ``nbytes`` (fallocate: bulk page allocation), map them once and populate the
-    mapping's page tables chunk by chunk, ahead of the copies that will land there -- a device-to-host copy into a
-    populated mapping runs at the link's speed (4 ms per 200 MB), into fresh file pages at a tenth of it."""
-    import threading
-    if nbytes <= 0 or getattr(owner, "_prealloc", None) is not None:
-        return
-    fd = fileobj.fileno()
-    owner._whole = None
+class Preallocator:
+    """Background allocation of spans of an output file ahead of the copies that will land there: ``request(start, end)``
+    queues file bytes [start, end) -- an estimate of what is about to be written -- and a worker thread allocates them
+    (fallocate: bulk page allocation), maps them as one arena and populates the mapping's page tables chunk by chunk.  A
+    device-to-host copy into a populated mapping runs at the link's speed (4 ms per 200 MB), into fresh file pages at a
+    tenth of it.  Estimates may overlap and may be wrong: a span no arena covers is mapped by ``MappedRegion`` itself, and
+    ``finish`` cuts the file to what was written."""
 
-    def job():
-        try:
-            os.posix_fallocate(fd, 0, int(nbytes))
-            whole = mmap.mmap(fd, int(nbytes), access=mmap.ACCESS_WRITE)
-            owner._whole = whole
+    def __init__(self, fileobj):
+        import queue
+        self._fd = fileobj.fileno()
+        self._arenas = []                       # (start, length, mmap), appended by the worker
+        self._q = queue.SimpleQueue()
+        self._thread = None
+        self._stop = False
+        self._pending = 0                       # requests queued and not mapped yet
+
+    def request(self, start: int, end: int):
+        import threading
+        start -= start % mmap.ALLOCATIONGRANULARITY
+        if end <= start or self._stop:
+            return
+        self._pending += 1
+        self._q.put((int(start), int(end)))
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._work, name="msim-fallocate", daemon=True)
+            self._thread.start()
+
+    def _work(self):
+        while True:
+            job = self._q.get()
+            if job is None:
+                return
+            start, end = job
+            arena = None
+            try:
+                if not self._stop:
+                    os.posix_fallocate(self._fd, start, end - start)
+                    arena = mmap.mmap(self._fd, end - start, access=mmap.ACCESS_WRITE, offset=start)
+                    self._arenas.append((start, end - start, arena))
+            except (OSError, ValueError):
+                arena = None
+            self._pending -= 1
             step = 64 << 20
-            for a in range(0, int(nbytes), step):
-                if getattr(owner, "_prealloc_stop", False):
+            for a in range(0, end - start if arena is not None else 0, step):
+                if self._stop:
                     break
                 try:
-                    whole.madvise(_MADV_POPULATE_WRITE, a, min(step, int(nbytes) - a))
+                    arena.madvise(_MADV_POPULATE_WRITE, a, min(step, end - start - a))
                 except (OSError, ValueError):
                     break                       # older kernel: the copies fault the pages in themselves
-        except (OSError, ValueError):
-            pass
-    owner._prealloc = threading.Thread(target=job, name="msim-fallocate", daemon=True)
-    owner._prealloc.start()
 
+    def view(self, pos: int, nbytes: int):
+        """[pos, pos + nbytes) as a slice of an arena, or None.  (An arena that is requested but not mapped yet is waited
+        for: the fallocate + mmap at its start take a few ms per 100 MB; its population may still be running behind --
+        a page it has not reached simply faults in.)"""
+        for _ in range(4000):
+            for start, length, arena in reversed(self._arenas):
+                if start <= pos and pos + nbytes <= start + length:
+                    return np.frombuffer(arena, dtype=np.uint8, count=nbytes, offset=pos - start)
+            if self._pending <= 0 or self._thread is None or not self._thread.is_alive():
+                return None
+            time.sleep(0.0005)
+        return None
 
-def _finish_preallocated(owner, fileobj):
-    """Stop a background preallocation, drop its mapping and cut the file to what was written."""
-    t = getattr(owner, "_prealloc", None)
-    if t is not None:
-        owner._prealloc_stop = True
-        t.join()
-        owner._prealloc = None
-        whole, owner._whole = getattr(owner, "_whole", None), None
-        if whole is not None:
+    def finish(self, fileobj):
+        """Stop the worker, drop the arenas and cut the file to what was written."""
+        self._stop = True
+        if self._thread is not None:
+            self._q.put(None)
+            self._thread.join()
+            self._thread = None
+        for _, _, arena in self._arenas:
             try:
-                whole.close()
+                arena.close()
             except BufferError:                 # (a view of it is still alive somewhere: the mapping goes with it)
                 pass
+        self._arenas = []
         fileobj.flush()
-        os.ftruncate(fileobj.fileno(), fileobj.tell())
+        if os.fstat(fileobj.fileno()).st_size > fileobj.tell():
+            os.ftruncate(fileobj.fileno(), fileobj.tell())
 
 
 class FastaWriterError(Exception):
@@ -118,13 +156,17 @@ class FastaWriter:
     def close(self):
         out = getattr(self, "_out", None)
         if out is not None and not out.closed:
-            _finish_preallocated(self, out)
+            ahead, self._ahead = getattr(self, "_ahead", None), None
+            if ahead is not None:
+                ahead.finish(out)
             out.close()
 
     def preallocate(self, nbytes: int):
         """Allocate the file's first ``nbytes`` in the background (a size estimate: the file is cut to what was really
         written at ``close``).  Mapped regions inside it then cost no page allocation."""
-        _preallocate(self, self._out, nbytes)
+        if getattr(self, "_ahead", None) is None and nbytes > 0:
+            self._ahead = Preallocator(self._out)
+            self._ahead.request(0, int(nbytes))
 
     def set_bpl(self, bpl: int):
         self._bpl = bpl
@@ -157,16 +199,7 @@ class FastaWriter:
         start a line).  ``commit_region(region, n_bases)`` finishes it."""
         if self._written != 0:
             raise FastaWriterError("map_region needs to start at the beginning of a line")
-        # (a span inside the preallocated, already mapped head of the file is a slice of that mapping; the background
-        #  thread may still be populating pages further on -- a span it has not reached yet simply faults its pages in)
-        whole = getattr(self, "_whole", None)
-        if whole is None and getattr(self, "_prealloc", None) is not None and self._prealloc.is_alive():
-            for _ in range(2000):                      # the fallocate + mmap at its start take a few ms per 100 MB
-                if getattr(self, "_whole", None) is not None or not self._prealloc.is_alive():
-                    break
-                time.sleep(0.0005)
-            whole = getattr(self, "_whole", None)
-        return MappedRegion(self._out, nbytes, whole)
+        return MappedRegion(self._out, nbytes, getattr(self, "_ahead", None))
 
     def commit_region(self, region: MappedRegion, n_bases: int):
         region.close(self._out)

@@ -356,7 +356,14 @@ class Mutator:
             cid = eng.add_contig(rec.bases)
         t1 = time.perf_counter()
         t["ingest_s"] += t1 - t0
-        eng.plan_contig(cid, plan_table(chrom))
+        table = plan_table(chrom)
+        # the VCF span this contig will fill, estimated from its candidate count and the bytes per candidate seen so far
+        # (first contig: a generous guess), is allocated and mapped in the background while the device plans
+        n_cand = int(table["k"].sum()) if len(table) else 0
+        rate = getattr(self, "_vcf_bytes_per_candidate", None) or (len(rec.name.encode("utf-8", "replace")) + 64.0)
+        if n_cand * rate >= (8 << 20):
+            self._vcf_writer.expect(int(n_cand * rate * 1.04) + 65536)
+        eng.plan_contig(cid, table)
         if eng.plan_was_empty(cid) and "warned" not in done:
             self._warn_empty(chrom)
             done.add("warned")
@@ -387,6 +394,8 @@ class Mutator:
         t3 = time.perf_counter()
         t["fasta_egress_s"] += t3 - t2
         n_vcf = eng.render_vcf_device_size(cid, rec.name)
+        if n_cand:
+            self._vcf_bytes_per_candidate = n_vcf / n_cand
         region = self._vcf_writer.map_region(n_vcf)
         try:
             if n_vcf:

@@ -469,13 +469,37 @@ TL_CHANCES = {1: 0.01, 2: 0.01, 3: 0.01, 5: 0.01, 4: 0.01, 6: 0.005, 7: 0.005}  
 TL_LENS = {2: (10, 100), 3: (1, 2), 4: (1, 2), 6: (1, 2)}
 
 
-@pytest.mark.parametrize("L,seed", [(3_000_000, 1), (1_200_000, 2)])
+@pytest.mark.parametrize("L,seed", [(3_000_000, 1), (1_200_000, 2), (80_000_000, 3)])
 def test_translocations_readme_flags_vs_host(L, seed):
-    """The reference's own benchmark flags (README "Performance": every type at 0.01, translocations included) through the
-    host-chain engine: TL / TLI on the chain, __link_tls behind the last range on the host, TLI records with their linked
-    spans from the device."""
+    """The reference's own benchmark flags (README "Performance": every type at 0.01, translocations included), one range
+    per contig as ARGS mode makes them: the SV-mix engine -- device sample, TL / TLI on the host's boundary walk,
+    __link_tls on a word window fetched behind it, TLI records with their linked spans from the device."""
     r = _sv_range(0, L - 1, int(L * 0.06), TL_CHANCES, TL_LENS)
     st = _compare([(L, [r])], _params(titv=1.0), seed=(seed, seed + 3), host_chain=True)
+    assert st["contigs_svmix"] == 1
+
+
+@pytest.mark.parametrize("chances,lens,order", [
+    ({1: 0.5, 6: 0.1, 7: 0.4}, {6: (5, 60)}, [7, 1, 6]),                 # many more sites than spans: __fix_tl_amount deletes sites
+    ({1: 0.3, 6: 0.45, 7: 0.05, 3: 0.2}, {6: (200, 900), 3: (200, 900)}, [6, 3, 7, 1]),   # ... deletes spans (which still blocked)
+    ({1: 0.5, 7: 0.5}, {}, [1, 7]),                                      # sites only: nothing is drawn, start = pos, stop = 0
+    ({1: 0.5, 6: 0.5}, {6: (1, 1)}, [1, 6]),                             # spans only, length 1: all deleted
+    ({6: 0.5, 7: 0.5}, {6: (1, 3)}, [6, 7]),                             # no SNPs at all; lengths below 2 never invert
+])
+def test_translocations_sv_mix_shapes_vs_host(chances, lens, order):
+    L = 2_000_000
+    blocks = {t: 2 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}
+    blocks["TL"] = 7
+    contigs = [(L, [_rate_range(0, L - 1, 0.01, chances, lens, order=order)]),
+               (700_000, [_rate_range(1_000, 650_000, 0.02, chances, lens, order=order)])]
+    st = _compare(contigs, _params(blocks, titv=2.0), seed=(21, 22), host_chain=True)
+    assert st["contigs_svmix"] == 2
+
+
+def test_translocations_readme_flags_in_two_ranges_take_the_host_chain_engine():
+    L = 2_400_000
+    ranges = [_sv_range(0, L // 2 - 1, int(L * 0.03), TL_CHANCES, TL_LENS), _sv_range(L // 2, L - 1, int(L * 0.03), TL_CHANCES, TL_LENS)]
+    st = _compare([(L, ranges)], _params(titv=1.0), seed=(5, 8), host_chain=True)
     assert st["contigs_hostchain"] == 1
 
 
