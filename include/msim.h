@@ -233,7 +233,10 @@ int msim_host_free(msim_ctx *ctx, void *ptr);
  * per contig the file text of the record (as for msim_add_contig_text), its ranges and its name.  The RNG streams are
  * consumed contig by contig exactly as by msim_plan_contig; ONE APPLY runs over the concatenation; the host frames the
  * FASTA bodies (fasta_writer.py:40-58) and renders the VCF lines (vcf_writer.py:118-126).  Results stay in the context
- * until the next batch.  MSIM_ERR_KEY: msim_batch_key_contig tells which contig hit the reference's KeyError.        */
+ * until the next batch; the FASTA text is framed when it is asked for -- by msim_batch_fetch straight into the caller's
+ * memory (a mapped span of the output file), by msim_batch_view into a buffer of the context -- so the deflines
+ * (msim_batch_contig.header) must stay valid until then.  MSIM_ERR_KEY: msim_batch_key_contig tells which contig hit the
+ * reference's KeyError.                                                                                                */
 typedef struct msim_batch_contig {
     const uint8_t *body; uint64_t body_bytes; uint64_t n_bases; uint32_t lenc, lenb;   /* as msim_add_contig_text     */
     const msim_range *ranges; int32_t n_ranges;                                        /* as msim_plan_contig         */

@@ -7,6 +7,7 @@
 #include <new>
 #include <system_error>
 #include <thread>
+#include <sys/mman.h>
 
 #include <dlfcn.h>
 
@@ -258,9 +259,14 @@ void msim_destroy(msim_ctx *p) {
     CtxFull *c = static_cast<CtxFull *>(C(p));
     c->deferred_apply = -1;                                // nobody will ask for its result
     if (c->host_only) { delete c; return; }
+    static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    double ph[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int i) { const auto n = std::chrono::steady_clock::now(); ph[i] += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->emit_stream);
+    lap(0);
     for (auto &g : c->contigs) (void)free_contig(c, g, false);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->dev.d_lut) (void)hipFree(c->dev.d_lut);
@@ -268,14 +274,19 @@ void msim_destroy(msim_ctx *p) {
     if (c->h_errs) (void)hipHostFree(c->h_errs);
     if (c->d_text) (void)hipFree(c->d_text);
     if (c->d_text_scratch) (void)hipFree(c->d_text_scratch);
+    lap(1);
     batch_free(c);
+    lap(2);
     comm_destroy(c);
     gpu_plan_destroy(c->gpu);
+    lap(3);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
     hipEvent_t evs[4] = {c->ev0, c->ev1, c->ev2, c->ev3};
     for (auto ev : evs) if (ev) (void)hipEventDestroy(ev);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->emit_stream) (void)hipStreamDestroy(c->emit_stream);
+    lap(4);
+    if (prof) fprintf(stderr, "msim_destroy: drain %.1f ms, contigs+scratch %.1f, batch buffers %.1f, plan engines %.1f, streams %.1f\n", ph[0], ph[1], ph[2], ph[3], ph[4]);
     delete c;
 }
 
@@ -914,13 +925,15 @@ namespace msim {
 
 struct Batch {
     struct Item { uint64_t base = 0, len = 0, out_start = 0, out_len = 0, rec0 = 0, nrec = 0, pool0 = 0, npool = 0, text0 = 0, ntext = 0,
-                  vcf0 = 0, nvcf = 0; uint32_t bpl = 0; bool empty = true; };
+                  vcf0 = 0, nvcf = 0; uint32_t bpl = 0; bool empty = true;
+                  const char *header = nullptr; uint32_t header_len = 0; bool nl_before = false; };   // the record's defline (caller's memory)
     std::vector<Item> items;
     std::vector<msim_record> recs_rel;       // per-contig coordinates (what the VCF renderer reads)
     std::vector<uint8_t> pool;
     uint8_t *h_in = nullptr, *h_out = nullptr;   // page-aligned host staging (see pinned_reserve)
     size_t cap_in = 0, cap_out = 0;
-    uint8_t *fasta = nullptr; size_t fasta_cap = 0, fasta_len = 0;   // malloc'ed: never zero-filled
+    uint8_t *fasta = nullptr; size_t fasta_cap = 0, fasta_len = 0;   // malloc'ed: never zero-filled; framed on demand (msim_batch_view)
+    bool framed = false;
     char *vcf = nullptr; size_t vcf_cap = 0, vcf_len = 0;
     uint64_t last_line_bases = 0;            // bases on the (partial) last line of the FASTA text
     int key_contig = -1;
@@ -928,11 +941,14 @@ struct Batch {
 
 static void batch_free(Ctx *c) {
     if (!c->batch) return;
-    free(c->batch->h_in);
-    free(c->batch->h_out);
-    free(c->batch->fasta);
-    free(c->batch->vcf);
-    delete c->batch;
+    static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) { const auto n = std::chrono::steady_clock::now(); if (prof) fprintf(stderr, "  batch_free %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - tp).count()); tp = n; };
+    free(c->batch->h_in); lap("h_in");
+    free(c->batch->h_out); lap("h_out");
+    free(c->batch->fasta); lap("fasta");
+    free(c->batch->vcf); lap("vcf");
+    delete c->batch; lap("vectors");
     c->batch = nullptr;
 }
 
@@ -976,16 +992,20 @@ static int pinned_reserve(Ctx *c, uint8_t **p, size_t *cap, size_t want) {
     if (*cap >= want) return MSIM_OK;
     free(*p);
     *p = nullptr; *cap = 0;
-    const size_t sz = (want + want / 4 + 8191) & ~(size_t)4095;
-    *p = static_cast<uint8_t *>(aligned_alloc(4096, sz));
+    const size_t huge = (size_t)2 << 20;
+    const size_t sz = (want + want / 4 + huge) & ~(huge - 1);
+    *p = static_cast<uint8_t *>(aligned_alloc(huge, sz));
     if (!*p) return fail(c, MSIM_ERR_NOMEM, "batch staging buffer");
+#ifdef MADV_HUGEPAGE
+    (void)madvise(*p, sz, MADV_HUGEPAGE);                  // 2 MB pages where the kernel grants them: 512x fewer faults and unmaps
+#endif
     *cap = sz;
     return MSIM_OK;
 }
 
-// output length change of one record (apply.hip: rec_lengths)
 static inline size_t batch_header_len(const msim_batch_contig &q) { return q.header_len ? q.header_len : strlen(q.header); }
 
+// output length change of one record (apply.hip: rec_lengths)
 static long long rec_delta(const msim_record &r) {
     const long long len = (long long)r.stop - (long long)r.pos + 1;
     switch (r.type) {
@@ -995,6 +1015,30 @@ static long long rec_delta(const msim_record &r) {
         case MSIM_TLI: return r.stop + 1 > r.extra ? (long long)r.stop + 1 - (long long)r.extra : 0;
         default: return 0;
     }
+}
+
+// FASTA framing of a batch's mutated bases into `dst` (B.fasta_len bytes): '\n' after every bpl bases, none after a partial
+// last line (fasta_writer.py:40-58).  With a header per contig the text is the complete run of FASTA records as FastaWriter
+// would have written them: '>' header '\n' body, and a '\n' before a header iff the previous body ended in a partial line.
+static void batch_frame_into(const Batch &B, uint8_t *out) {
+    parallel_slices((int)B.items.size(), [&](int, int i0, int i1) {
+        for (int i = i0; i < i1; i++) {
+            const Batch::Item &it = B.items[(size_t)i];
+            const uint8_t *src = B.h_out + it.out_start;
+            uint8_t *dst = out + it.text0;
+            if (it.header) {
+                if (it.nl_before) *dst++ = '\n';
+                *dst++ = '>';
+                memcpy(dst, it.header, it.header_len);
+                dst += it.header_len;
+                *dst++ = '\n';
+            }
+            if (!it.bpl) { if (it.out_len) memcpy(dst, src, it.out_len); continue; }
+            uint64_t done = 0;
+            while (done + it.bpl <= it.out_len) { memcpy(dst, src + done, it.bpl); dst[it.bpl] = '\n'; dst += it.bpl + 1; done += it.bpl; }
+            if (done < it.out_len) memcpy(dst, src + done, it.out_len - done);
+        }
+    });
 }
 
 }  // namespace msim
@@ -1020,7 +1064,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     if (!c->batch) c->batch = new Batch();
     Batch &B = *c->batch;
     B.items.assign((size_t)n, Batch::Item());
-    B.recs_rel.clear(); B.pool.clear(); B.fasta_len = 0; B.vcf_len = 0; B.last_line_bases = 0;
+    B.recs_rel.clear(); B.pool.clear(); B.fasta_len = 0; B.vcf_len = 0; B.last_line_bases = 0; B.framed = false;
     B.key_contig = -1;
     uint64_t total = 0;
     for (int i = 0; i < n; i++) {
@@ -1037,28 +1081,64 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
         total += q.n_bases;
     }
     if (total >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "batch of 2 GiB or more: split it");
-    // ---- 1. FASTA text -> upper-cased bases (pyfaidx's sequence_always_upper, util.py:84-88), on the host
+    // ---- 1. FASTA text -> upper-cased bases (pyfaidx's sequence_always_upper, util.py:84-88) on the host and up to the
+    //         device -- on a thread of its own, beside PLAN: the RNG chain never looks at a base
     rc = pinned_reserve(c, &B.h_in, &B.cap_in, total + 64);
     if (rc) return rc;
-    parallel_slices(n, [&](int, int i0, int i1) {
-        for (int i = i0; i < i1; i++) {
-            const msim_batch_contig &q = contigs[i];
-            uint8_t *dst = B.h_in + B.items[(size_t)i].base;
-            uint64_t done = 0;
-            const uint8_t *src = q.body;
-            while (done < q.n_bases) {
-                const uint64_t take = std::min<uint64_t>(q.lenc, q.n_bases - done);
-                memcpy(dst + done, src, take);
-                done += take;
-                src += q.lenb;
+    Contig *g;
+    rc = new_contig(c, total, &g);
+    if (rc) return rc;
+    const int gid = (int)c->contigs.size() - 1;
+    // the temporary super-contig leaves the context on EVERY way out of this block (HIP failures included: a contig left
+    // behind would leak its device buffers and shift the ids of the caller's later contigs)
+    struct Drop {
+        Ctx *c; int gid; bool armed = true;
+        void now() { if (armed) { armed = false; (void)free_contig(c, c->contigs[(size_t)gid], false); c->contigs.pop_back(); } }
+        ~Drop() { now(); }
+    } guard{c, gid};
+    auto drop = [&]() { guard.now(); };
+    struct Side {                                           // a helper thread that is always joined before its captures die
+        std::thread th;
+        void join() { if (th.joinable()) th.join(); }
+        ~Side() { join(); }
+    };
+    hipError_t ingest_err = hipSuccess;
+    double ingest_ms = 0;
+    uint8_t *const d_in = g->d_in;                          // (c->contigs does not grow during the batch: g stays valid)
+    auto ingest = [&, d_in]() {
+        const auto a0 = now();
+        parallel_slices(n, [&](int, int i0, int i1) {
+            for (int i = i0; i < i1; i++) {
+                const msim_batch_contig &q = contigs[i];
+                uint8_t *dst = B.h_in + B.items[(size_t)i].base;
+                uint64_t done = 0;
+                const uint8_t *src = q.body;
+                while (done < q.n_bases) {
+                    const uint64_t take = std::min<uint64_t>(q.lenc, q.n_bases - done);
+                    memcpy(dst + done, src, take);
+                    done += take;
+                    src += q.lenb;
+                }
+                for (uint64_t k = 0; k < q.n_bases; k++) {       // (auto-vectorised)
+                    const uint8_t b = dst[k];
+                    dst[k] = (uint8_t)(b - ((b >= 'a' && b <= 'z') ? 32 : 0));
+                }
             }
-            for (uint64_t k = 0; k < q.n_bases; k++) {       // (auto-vectorised)
-                const uint8_t b = dst[k];
-                dst[k] = (uint8_t)(b - ((b >= 'a' && b <= 'z') ? 32 : 0));
-            }
+        });
+        ingest_ms = ms(a0, now());
+        if (total) {
+            ingest_err = hipSetDevice(c->device);
+            if (ingest_err == hipSuccess) ingest_err = hipMemcpyAsync(d_in + PAD, B.h_in, total, hipMemcpyHostToDevice, c->stream);
         }
-    });
+    };
+    Side side_in;
+    try { side_in.th = std::thread(ingest); } catch (const std::system_error &) { ingest(); }
     const auto t_1 = now();
+    for (int i = 0; i < n; i++) {                            // (kept for the framing, which runs when the text is asked for)
+        Batch::Item &it = B.items[(size_t)i];
+        it.header = contigs[i].header;
+        it.header_len = contigs[i].header ? (uint32_t)batch_header_len(contigs[i]) : 0u;
+    }
     // ---- 2. PLAN: the RNG chain, contig by contig (mutator.py:111-131 + the draws of :334-358)
     std::vector<msim_record> recs_abs;
     long long delta_total = 0;
@@ -1097,92 +1177,16 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     const uint64_t out_total = (uint64_t)((long long)total + delta_total);
     const auto t_2 = now();
     // ---- 3. ONE APPLY over the super-contig
-    Contig *g;
-    rc = new_contig(c, total, &g);
-    if (rc) return rc;
-    const int gid = (int)c->contigs.size() - 1;
-    // the temporary super-contig leaves the context on EVERY way out of this block (HIP failures included: a contig left
-    // behind would leak its device buffers and shift the ids of the caller's later contigs)
-    struct Drop {
-        Ctx *c; int gid; bool armed = true;
-        void now() { if (armed) { armed = false; (void)free_contig(c, c->contigs[(size_t)gid], false); c->contigs.pop_back(); } }
-        ~Drop() { now(); }
-    } guard{c, gid};
-    auto drop = [&]() { guard.now(); };
-    if (total) MSIM_HIP(c, hipMemcpyAsync(g->d_in + PAD, B.h_in, total, hipMemcpyHostToDevice, c->stream));
-    g->n_rec = recs_abs.size();
-    g->pool_len = B.pool.size();
-    g->plan_empty = recs_abs.empty();
-    g->all_snp = all_snp;
-    g->delta_known = true;
-    g->known_delta = delta_total;
-    if (g->n_rec) {
-        rc = dev_reserve(c, (void **)&g->d_recs, &g->cap_recs, g->n_rec * sizeof(msim_record));
-        if (rc) { drop(); return rc; }
-        MSIM_HIP(c, hipMemcpyAsync(g->d_recs, recs_abs.data(), g->n_rec * sizeof(msim_record), hipMemcpyHostToDevice, c->stream));
-    }
-    rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + 2 * PAD);
-    if (rc) { drop(); return rc; }
-    if (g->pool_len) MSIM_HIP(c, hipMemcpyAsync(g->d_pool + PAD, B.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));          // (the uploads read pageable vectors; APPLY runs on the emit stream)
-    g->planned = true;
-    rc = apply_contig_device(c, *g);
-    if (rc) { drop(); return rc; }
-    rc = pinned_reserve(c, &B.h_out, &B.cap_out, out_total + 64);
-    if (rc) { drop(); return rc; }
-    if (out_total) MSIM_HIP(c, hipMemcpyAsync(B.h_out, g->d_out, out_total, hipMemcpyDeviceToHost, c->emit_stream));
-    rc = apply_finish(c);                                  // synchronises the emit stream: the copy above included
-    if (rc) { drop(); return rc; }
-    if (g->out_len != out_total) { drop(); return fail(c, MSIM_ERR_HIP, "internal: batch planner and device disagree on the mutated length"); }
-    if (g->key_error) {                                    // the reference's KeyError: which contig, which base
-        const uint64_t kp = g->key_pos;
-        int who = 0;
-        for (int i = 0; i < n; i++) if (B.items[(size_t)i].base <= kp && kp < B.items[(size_t)i].base + B.items[(size_t)i].len) who = i;
-        B.key_contig = who;
-        const uint8_t kb = g->key_base;
-        drop();
-        return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)kb + "'");
-    }
-    drop();
-    const auto t_3 = now();
-    // ---- 4. FASTA framing ('\n' after every bpl bases, none after a partial last line; fasta_writer.py:40-58) and
-    //         VCF record lines (mutator.py:334-399 + vcf_writer.py:118-126) per contig, on the host
-    // With a header per contig (msim_batch_contig.header) the text is the complete run of FASTA records as FastaWriter
-    // would have written them: '>' header '\n' body, and a '\n' before a header iff the previous body ended in a partial line.
-    uint64_t text_total = 0;
-    for (int i = 0; i < n; i++) {
-        Batch::Item &it = B.items[(size_t)i];
-        const bool prev_partial = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
-        const uint64_t head = contigs[i].header ? (prev_partial ? 1 : 0) + 1 + batch_header_len(contigs[i]) + 1 : 0;
-        it.text0 = text_total;
-        it.ntext = head + (it.bpl ? it.out_len + it.out_len / it.bpl : it.out_len);
-        text_total += it.ntext;
-    }
-    if (!raw_reserve(&B.fasta, &B.fasta_cap, (size_t)text_total + 1)) return fail(c, MSIM_ERR_NOMEM, "batch FASTA text");
-    B.fasta_len = (size_t)text_total;
-    B.last_line_bases = B.items.back().bpl ? B.items.back().out_len % B.items.back().bpl : 0;
-    parallel_slices(n, [&](int, int i0, int i1) {
-        for (int i = i0; i < i1; i++) {
-            const Batch::Item &it = B.items[(size_t)i];
-            const uint8_t *src = B.h_out + it.out_start;
-            uint8_t *dst = B.fasta + it.text0;
-            if (const char *hd = contigs[i].header) {
-                const bool prev_partial = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
-                if (prev_partial) *dst++ = '\n';
-                *dst++ = '>';
-                const size_t hl = batch_header_len(contigs[i]);
-                memcpy(dst, hd, hl);
-                dst += hl;
-                *dst++ = '\n';
-            }
-            if (!it.bpl) { if (it.out_len) memcpy(dst, src, it.out_len); continue; }
-            uint64_t done = 0;
-            while (done + it.bpl <= it.out_len) { memcpy(dst, src + done, it.bpl); dst[it.bpl] = '\n'; dst += it.bpl + 1; done += it.bpl; }
-            if (done < it.out_len) memcpy(dst, src + done, it.out_len - done);
-        }
-    });
-    const auto t_4 = now();
-    {   // VCF lines: every slice of contigs renders into a buffer of its own, sized by a cheap upper bound (a line is name +
+    side_in.join();
+    if (ingest_err != hipSuccess) { drop(); return hip_fail(c, ingest_err, "batch input upload"); }
+    // ---- 3b. VCF record lines (mutator.py:334-399 + vcf_writer.py:118-126) per contig, on the host -- beside the APPLY: they
+    //          read the records and the INPUT bases only
+    int vcf_rc = MSIM_OK;
+    const char *vcf_msg = "";
+    double vcf_ms = 0;
+    auto render_vcf = [&]() {
+        const auto v0 = now();
+    // VCF lines: every slice of contigs renders into a buffer of its own, sized by a cheap upper bound (a line is name +
         // fixed fields of < 96 bytes + REF and ALT, each at most span + insert + 1 long, twice for a duplication's ALT);
         // the slices are then joined in contig order
         const msim_record *all = B.recs_rel.data();
@@ -1224,14 +1228,14 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
             part_len[(size_t)part] = at;
         });
         auto free_parts = [&]() { for (char *q : part_buf) free(q); };
-        if (bad) { free_parts(); return fail(c, MSIM_ERR_HIP, "internal: VCF text of a batch: bound too small or out of memory"); }
+        if (bad) { free_parts(); vcf_rc = MSIM_ERR_HIP; vcf_msg = "internal: VCF text of a batch: bound too small or out of memory"; return; }
         // join in slice order (slices are consecutive contig ranges, part index ascending)
         std::vector<int> order;
         for (int t = 0; t < max_parts; t++) if (part_first[(size_t)t] >= 0) order.push_back(t);
         std::sort(order.begin(), order.end(), [&](int x, int y) { return part_first[(size_t)x] < part_first[(size_t)y]; });
         uint64_t total_vcf = 0;
         for (int t : order) total_vcf += part_len[(size_t)t];
-        if (!raw_reserve(&B.vcf, &B.vcf_cap, (size_t)total_vcf + 1)) { free_parts(); return fail(c, MSIM_ERR_NOMEM, "batch VCF text"); }
+        if (!raw_reserve(&B.vcf, &B.vcf_cap, (size_t)total_vcf + 1)) { free_parts(); vcf_rc = MSIM_ERR_NOMEM; vcf_msg = "batch VCF text"; return; }
         uint64_t at = 0;
         for (size_t k = 0; k < order.size(); k++) {
             const int t = order[k];
@@ -1242,10 +1246,62 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
         }
         B.vcf_len = (size_t)at;
         free_parts();
+        vcf_ms = ms(v0, now());
+    };
+    Side side_vcf;
+    try { side_vcf.th = std::thread(render_vcf); } catch (const std::system_error &) { render_vcf(); }
+    g->n_rec = recs_abs.size();
+    g->pool_len = B.pool.size();
+    g->plan_empty = recs_abs.empty();
+    g->all_snp = all_snp;
+    g->delta_known = true;
+    g->known_delta = delta_total;
+    if (g->n_rec) {
+        rc = dev_reserve(c, (void **)&g->d_recs, &g->cap_recs, g->n_rec * sizeof(msim_record));
+        if (rc) return rc;
+        MSIM_HIP(c, hipMemcpyAsync(g->d_recs, recs_abs.data(), g->n_rec * sizeof(msim_record), hipMemcpyHostToDevice, c->stream));
     }
+    rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + 2 * PAD);
+    if (rc) return rc;
+    if (g->pool_len) MSIM_HIP(c, hipMemcpyAsync(g->d_pool + PAD, B.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
+    MSIM_HIP(c, hipStreamSynchronize(c->stream));          // (the uploads read pageable vectors; APPLY runs on the emit stream)
+    g->planned = true;
+    rc = apply_contig_device(c, *g);
+    if (rc) return rc;
+    rc = pinned_reserve(c, &B.h_out, &B.cap_out, out_total + 64);
+    if (rc) return rc;
+    if (out_total) MSIM_HIP(c, hipMemcpyAsync(B.h_out, g->d_out, out_total, hipMemcpyDeviceToHost, c->emit_stream));
+    rc = apply_finish(c);                                  // synchronises the emit stream: the copy above included
+    if (rc) return rc;
+    if (g->out_len != out_total) return fail(c, MSIM_ERR_HIP, "internal: batch planner and device disagree on the mutated length");
+    if (g->key_error) {                                    // the reference's KeyError: which contig, which base
+        const uint64_t kp = g->key_pos;
+        int who = 0;
+        for (int i = 0; i < n; i++) if (B.items[(size_t)i].base <= kp && kp < B.items[(size_t)i].base + B.items[(size_t)i].len) who = i;
+        B.key_contig = who;
+        const uint8_t kb = g->key_base;
+        return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)kb + "'");
+    }
+    drop();
+    const auto t_3 = now();
+    // ---- 4. the FASTA text's layout; the framing itself runs when the text is asked for, straight into the caller's
+    //         memory (msim_batch_fetch) or into a buffer of the context (msim_batch_view)
+    uint64_t text_total = 0;
+    for (int i = 0; i < n; i++) {
+        Batch::Item &it = B.items[(size_t)i];
+        it.nl_before = i > 0 && B.items[(size_t)i - 1].bpl && B.items[(size_t)i - 1].out_len % B.items[(size_t)i - 1].bpl;
+        const uint64_t head = it.header ? (it.nl_before ? 1 : 0) + 1 + it.header_len + 1 : 0;
+        it.text0 = text_total;
+        it.ntext = head + (it.bpl ? it.out_len + it.out_len / it.bpl : it.out_len);
+        text_total += it.ntext;
+    }
+    B.fasta_len = (size_t)text_total;
+    B.last_line_bases = B.items.back().bpl ? B.items.back().out_len % B.items.back().bpl : 0;
+    side_vcf.join();
+    if (vcf_rc) return fail(c, vcf_rc, vcf_msg);
     if (prof)
-        fprintf(stderr, "msim_batch_run: %d contigs, %.1f Mb: ingest %.1f ms, plan %.1f, upload+APPLY+download %.1f, framing %.1f, VCF %.1f\n",
-                n, total / 1e6, ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3), ms(t_3, t_4), ms(t_4, now()));
+        fprintf(stderr, "msim_batch_run: %d contigs, %.1f Mb in %.1f ms: plan %.1f (beside it: ingest %.1f), upload+APPLY+download %.1f (beside it: VCF %.1f), wait for VCF %.1f\n",
+                n, total / 1e6, ms(t_0, now()), ms(t_1, t_2), ingest_ms, ms(t_2, t_3), vcf_ms, ms(t_3, now()));
     return MSIM_OK;
 }
 
@@ -1266,9 +1322,10 @@ int msim_batch_fetch(msim_ctx *p, uint8_t *fasta_text, uint64_t fasta_cap, char 
     CTX_FLUSHED(c, p)
     if (!c || !c->batch) return MSIM_ERR_ARG;
     Batch &B = *c->batch;
-    if (fasta_text) {
+    if (fasta_text) {                                      // framed straight into the caller's memory (a mapped file, say)
         if (fasta_cap < B.fasta_len) return fail(c, MSIM_ERR_ARG, "fasta buffer too small");
-        if (B.fasta_len) memcpy(fasta_text, B.fasta, B.fasta_len);
+        if (B.fasta_len && B.framed) memcpy(fasta_text, B.fasta, B.fasta_len);
+        else if (B.fasta_len) batch_frame_into(B, fasta_text);
     }
     if (vcf_text) {
         if (vcf_cap < B.vcf_len) return fail(c, MSIM_ERR_ARG, "vcf buffer too small");
@@ -1282,6 +1339,11 @@ int msim_batch_view(msim_ctx *p, const uint8_t **fasta_text, uint64_t *fasta_byt
     CTX_FLUSHED(c, p)
     if (!c || !c->batch) return MSIM_ERR_ARG;
     Batch &B = *c->batch;
+    if (fasta_text && !B.framed) {
+        if (!raw_reserve(&B.fasta, &B.fasta_cap, B.fasta_len + 1)) return fail(c, MSIM_ERR_NOMEM, "batch FASTA text");
+        if (B.fasta_len) batch_frame_into(B, B.fasta);
+        B.framed = true;
+    }
     if (fasta_text) *fasta_text = B.fasta;
     if (fasta_bytes) *fasta_bytes = B.fasta_len;
     if (vcf_text) *vcf_text = B.vcf;

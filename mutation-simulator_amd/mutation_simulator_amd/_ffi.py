@@ -466,29 +466,38 @@ class Engine:
             q.name = nm
             q.header = hd
         self._check(self.lib.msim_batch_run(self.h, arr, n))
-        return self._batch_result(n)
+        return self._batch_result(n)          # (frames the FASTA text now: the deflines in `keep` die with this call)
 
-    def batch_run_table(self, table: np.ndarray, keep=()):
+    def batch_run_table(self, table: np.ndarray, keep=(), defer_fasta: bool = False):
         """The same from a ready ``BATCH_CONTIG_DTYPE`` table (pointers into buffers the caller keeps alive -- ``keep`` --
-        for the duration of the call): an assembly's batch is built with array operations, not per contig."""
+        for the duration of the call): an assembly's batch is built with array operations, not per contig.
+        ``defer_fasta``: the first result is the FASTA text's SIZE; ``batch_fetch_fasta(dst)`` then frames it straight into
+        ``dst`` (a mapped span of the output file) -- the deflines the table points at must still be alive then."""
         table = np.ascontiguousarray(table)
         n = int(table.shape[0])
         self._check(self.lib.msim_batch_run(self.h, C.cast(C.c_void_p(table.ctypes.data), C.POINTER(BatchContig)), n))
         del keep
-        return self._batch_result(n)
+        return self._batch_result(n, defer_fasta)
 
-    def _batch_result(self, n: int):
+    def batch_fetch_fasta(self, dst: np.ndarray):
+        """Frame the last batch's FASTA text into ``dst`` (writable, contiguous uint8, at least the text's size)."""
+        if dst.dtype != np.uint8 or not dst.flags.c_contiguous or not dst.flags.writeable:
+            raise ValueError("batch_fetch_fasta needs a writable contiguous uint8 array")
+        self._check(self.lib.msim_batch_fetch(self.h, C.c_void_p(dst.ctypes.data), dst.shape[0], None, 0))
+
+    def _batch_result(self, n: int, defer_fasta: bool = False):
         em = (C.c_int32 * n)()
         self._check(self.lib.msim_batch_sizes(self.h, n, None, None, em, None))
         fp, vp = C.c_void_p(), C.c_void_p()
         fn, vn, last = C.c_uint64(), C.c_uint64(), C.c_uint64()
-        self._check(self.lib.msim_batch_view(self.h, C.byref(fp), C.byref(fn), C.byref(vp), C.byref(vn), C.byref(last)))
+        self._check(self.lib.msim_batch_view(self.h, None if defer_fasta else C.byref(fp), C.byref(fn), C.byref(vp), C.byref(vn),
+                                             C.byref(last)))
 
         def view(ptr, nbytes):
             if not nbytes:
                 return np.empty(0, dtype=np.uint8)
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nbytes,))
-        return view(fp, fn.value), view(vp, vn.value), np.frombuffer(em, dtype=np.int32) != 0, last.value
+        return (fn.value if defer_fasta else view(fp, fn.value)), view(vp, vn.value), np.frombuffer(em, dtype=np.int32) != 0, last.value
 
     # ------------------------------------------------------------------ multi-GPU (csrc/comm.cpp)
     def comm_init(self, unique_id: bytes, rank: int, world: int):

@@ -218,6 +218,20 @@ class FastaWriter:
         self._bpl = bpl
         self._written = int(last_line_bases)
 
+    def map_records(self, nbytes: int) -> MappedRegion:
+        """The span a run of complete records of ``nbytes`` bytes will occupy (see ``write_records``), mapped for writing;
+        ``commit_records(region, bpl, last_line_bases)`` finishes it."""
+        if nbytes and self._written != 0:
+            self._out.write(b"\n")
+            self._written = 0
+        return MappedRegion(self._out, nbytes, getattr(self, "_ahead", None))
+
+    def commit_records(self, region: MappedRegion, bpl: int, last_line_bases: int):
+        region.close(self._out)
+        if region.nbytes:
+            self._bpl = bpl
+            self._written = int(last_line_bases)
+
     def begin_segment(self):
         """Multi-GPU workers write the records they own into a part file of their own: a segment starts as if at the
         beginning of a file (no newline owed to whatever precedes it there); ``append_segment`` of the assembling

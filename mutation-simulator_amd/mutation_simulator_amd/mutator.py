@@ -263,7 +263,9 @@ class Mutator:
         """Contigs [i, j) of ``chroms`` in ONE pass through libmsim (msim_batch_run)."""
         table = self._batch_table(chroms, i, j)
         if table is not None:
-            fasta, vcf, empty, last_line = eng.batch_run_table(table[0], keep=table[1:])
+            # the FASTA text is framed straight into the output file's next span (mapped; the deflines sit in the input
+            # file's text, which outlives the call)
+            fasta, vcf, empty, last_line = eng.batch_run_table(table[0], keep=table[1:], defer_fasta=True)
             bpl_last = int(self._fasta.index_table["lenc"][j - 1])
         else:
             items = []
@@ -275,7 +277,15 @@ class Mutator:
             bpl_last = self._fasta.faidx.index[last.name].lenc
         for k in np.flatnonzero(empty):
             self._warn_empty(chroms[i + int(k)])
-        self._fasta_writer.write_records(fasta, bpl_last, last_line)
+        if isinstance(fasta, int):
+            region = self._fasta_writer.map_records(fasta)
+            try:
+                if fasta:
+                    eng.batch_fetch_fasta(region.view)
+            finally:
+                self._fasta_writer.commit_records(region, bpl_last, last_line)
+        else:
+            self._fasta_writer.write_records(fasta, bpl_last, last_line)
         self._vcf_writer.write_raw(memoryview(vcf))
 
     def _batch_table(self, chroms, i, j):
