@@ -228,6 +228,15 @@ int msim_add_contig_text(msim_ctx *ctx, const uint8_t *body, uint64_t body_bytes
 int msim_host_alloc(msim_ctx *ctx, uint64_t bytes, void **ptr);
 int msim_host_free(msim_ctx *ctx, void *ptr);
 
+/* ---- interchromosomal translocations (the reference's second pass, it_mutator.py) --------------------------------- */
+/* __write_with_bp (it_mutator.py:121-146) for one contig: a NEW contig whose mutated stream is contig `a` cut at bp_a[0..n_bp)
+ * and contig `b` cut at bp_b[0..n_bp), the segments taken alternately -- a's first, b's second, a's third ... (segment i =
+ * bases [bp[i-1], bp[i]) with bp[-1] = 0 and bp[n_bp] = the contig's length; 0-based, as pairwise() over [0] + bp + [len]
+ * cuts them).  The segments are read from the contigs' INPUT bases (the IT pass reads the file the mutation pass wrote).
+ * n_bp = 0: a copy of a (__write_chrom_full, it_mutator.py:148-156; b is ignored).  The result counts as applied:
+ * msim_fetch_sequence(_framed), msim_result_sizes and msim_result_checksum read it; it has no records.              */
+int msim_splice_contigs(msim_ctx *ctx, int a, int b, uint64_t n_bp, const uint64_t *bp_a, const uint64_t *bp_b, int *contig);
+
 /* ---- many small contigs in one pass ------------------------------------------------------------------------------- */
 /* mutate()'s loop body (mutator.py:111-141) for a run of SMALL contigs at once -- assemblies with thousands of scaffolds:
  * per contig the file text of the record (as for msim_add_contig_text), its ranges and its name.  The RNG streams are

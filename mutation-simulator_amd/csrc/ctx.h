@@ -221,6 +221,8 @@ int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_r
 // text_gpu.hip
 int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);
 int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes);
+int splice_device(Ctx *c, const Contig &a, const Contig *b, const uint32_t *seg_out, const uint32_t *seg_src, uint32_t n_seg,
+                  Contig &dst);
 int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
                         uint32_t lenb, uint8_t *d_dst);
 

@@ -788,6 +788,47 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
     return MSIM_OK;
 }
 
+int msim_splice_contigs(msim_ctx *p, int a, int b, uint64_t n_bp, const uint64_t *bp_a, const uint64_t *bp_b, int *contig) {
+    CTX_FLUSHED(c, p)
+    if (!c || !contig || (n_bp && (!bp_a || !bp_b))) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    if (!get_contig(c, a) || (n_bp && !get_contig(c, b))) return MSIM_ERR_ARG;
+    TraceRange tr("msim IT: splice two contigs");
+    const uint64_t len_a = c->contigs[(size_t)a].len, len_b = n_bp ? c->contigs[(size_t)b].len : 0;
+    if (n_bp >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "2^31 breakpoints or more");
+    // segment i = [bp[i-1], bp[i]) of its contig, bp[-1] = 0, bp[n_bp] = the contig's length; even i from a, odd i from b
+    const uint32_t n_seg = (uint32_t)n_bp + 1;
+    std::vector<uint32_t> seg_out((size_t)n_seg + 1), seg_src(n_seg);
+    uint64_t out = 0, pa = 0, pb = 0;
+    for (uint32_t i = 0; i < n_seg; i++) {
+        const uint64_t ea = i < n_bp ? bp_a[i] : len_a, eb = i < n_bp ? bp_b[i] : len_b;
+        if (ea < pa || ea > len_a || (n_bp && (eb < pb || eb > len_b)))
+            return fail(c, MSIM_ERR_ARG, "breakpoints must ascend and lie inside their contig");
+        seg_out[i] = (uint32_t)out;
+        seg_src[i] = (uint32_t)((i & 1u) ? pb : pa);
+        out += (i & 1u) ? eb - pb : ea - pa;
+        if (out >= (1ull << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "spliced contig of 4 GiB or more");
+        pa = ea;
+        pb = eb;
+    }
+    seg_out[n_seg] = (uint32_t)out;
+    int rc = drain(c);
+    if (rc) return rc;
+    Contig *g;
+    rc = new_contig(c, 0, &g);                             // (no input of its own: the result is its mutated stream)
+    if (rc) return rc;
+    const Contig &ga = c->contigs[(size_t)a];              // (after new_contig: the vector may have moved)
+    const Contig *gb = n_bp ? &c->contigs[(size_t)b] : nullptr;
+    c->text_kind = 0;
+    rc = splice_device(c, ga, gb, seg_out.data(), seg_src.data(), n_seg, *g);
+    if (rc) { (void)free_contig(c, *g, false); c->contigs.pop_back(); return rc; }
+    g->planned = true;
+    g->plan_empty = true;
+    g->applied = true;
+    *contig = (int)c->contigs.size() - 1;
+    return MSIM_OK;
+}
+
 int msim_host_alloc(msim_ctx *p, uint64_t bytes, void **ptr) {
     Ctx *c = C(p);
     if (!c || !ptr) return MSIM_ERR_ARG;

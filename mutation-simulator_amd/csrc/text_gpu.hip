@@ -12,6 +12,8 @@
 //   FASTA  k_frame  : mutated stream -> text with '\n' after every `bpl` bases (fasta_writer.py:40-58)
 //          k_gather : FASTA body text (uniform line width, as pyfaidx requires) -> upper-cased uint8 bases
 //                     (what pyfaidx hands the reference with sequence_always_upper=True, util.py:84-88)
+//   IT     k_splice : interchromosomal translocation of one contig -- segments of two contigs taken alternately
+//                     (it_mutator.py:121-146 __write_with_bp)
 // Byte/integer work, HBM-bound; no MFMA.
 #include <cstring>
 
@@ -303,6 +305,45 @@ __global__ __launch_bounds__(TX_THREADS) void k_frame(const uint8_t *__restrict_
     }
 }
 
+// ---- interchromosomal translocation: output byte o belongs to segment j = the last one with seg_out[j] <= o; even segments
+// are cut from contig a, odd ones from contig b, seg_src[j] is where the segment starts in its contig.  16 output bytes per
+// thread: one binary search, then a forward walk (segments are at least two bases long -- breakpoints keep a base between them)
+__global__ __launch_bounds__(TX_THREADS) void k_splice(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b,
+                                                       const uint32_t *__restrict__ seg_out, const uint32_t *__restrict__ seg_src,
+                                                       uint32_t n_seg, unsigned long long out_len, uint8_t *__restrict__ dst) {
+    const unsigned long long o0 = ((unsigned long long)blockIdx.x * TX_THREADS + threadIdx.x) * 16;
+    if (o0 >= out_len) return;
+    uint32_t lo = 0, hi = n_seg;                           // seg_out[lo] <= o0 < seg_out[hi]   (seg_out[n_seg] = out_len)
+    while (hi - lo > 1) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((unsigned long long)seg_out[mid] <= o0) lo = mid; else hi = mid;
+    }
+    uint32_t j = lo;
+    unsigned long long next = seg_out[j + 1];
+    const uint8_t *src = ((j & 1u) ? b : a) + seg_src[j] - seg_out[j];      // src[o] is output byte o while o is in segment j
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const unsigned long long o = o0 + q;
+        uint8_t c = 0;
+        if (o < out_len) {
+            while (o >= next) {                            // (a while: an empty segment can not occur, but costs nothing to allow)
+                j++;
+                next = seg_out[j + 1];
+                src = ((j & 1u) ? b : a) + seg_src[j] - seg_out[j];
+            }
+            c = src[o];
+        }
+        w[q >> 2] |= (uint32_t)c << ((q & 3) * 8);
+    }
+    if (o0 + 16 <= out_len) {
+        uint4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        *reinterpret_cast<uint4 *>(dst + o0) = v;
+    } else {
+        for (int q = 0; o0 + q < out_len; q++) dst[o0 + q] = (uint8_t)(w[q >> 2] >> ((q & 3) * 8));
+    }
+}
+
 // ---- FASTA ingest: base i of the record sits at body[(i / lenc) * lenb + i % lenc]; a-z -> A-Z
 __global__ __launch_bounds__(TX_THREADS) void k_gather(const uint8_t *__restrict__ body, unsigned long long n_bases,
                                                        uint32_t lenc, uint32_t lenb, uint8_t *__restrict__ dst) {
@@ -403,6 +444,33 @@ int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64
     MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
     c->text_len = 0;
+    return MSIM_OK;
+}
+
+// Segments of the inputs of two contigs, taken alternately, as the mutated stream of `dst` (seg tables: see k_splice; host
+// memory, n_seg + 1 and n_seg entries).  b may be nullptr when no odd segment exists.
+int splice_device(Ctx *c, const Contig &a, const Contig *b, const uint32_t *seg_out, const uint32_t *seg_src, uint32_t n_seg,
+                  Contig &dst) {
+    const uint64_t out_len = seg_out[n_seg];
+    int rc = dev_reserve(c, (void **)&dst.d_out, &dst.cap_out, out_len + PAD);
+    if (rc) return rc;
+    dst.out_len = out_len;
+    if (!out_len) return MSIM_OK;
+    uint32_t *d_tab = nullptr;
+    const size_t tab_bytes = ((size_t)2 * n_seg + 1) * sizeof(uint32_t);
+    MSIM_HIP(c, hipMalloc(&d_tab, tab_bytes));
+    hipError_t e = hipMemcpyAsync(d_tab, seg_out, ((size_t)n_seg + 1) * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab + n_seg + 1, seg_src, (size_t)n_seg * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const uint64_t groups = (out_len + 15) / 16;
+        hipLaunchKernelGGL(k_splice, dim3((uint32_t)((groups + TX_THREADS - 1) / TX_THREADS)), dim3(TX_THREADS), 0, c->stream,
+                           a.d_in + PAD, b ? b->d_in + PAD : a.d_in + PAD, d_tab, d_tab + n_seg + 1, n_seg,
+                           (unsigned long long)out_len, dst.d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_tab);
+    if (e != hipSuccess) return hip_fail(c, e, "splice");
     return MSIM_OK;
 }
 

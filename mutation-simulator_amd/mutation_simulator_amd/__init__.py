@@ -5,9 +5,11 @@ build covers; the work behind ``Mutator`` runs as hand-written HIP kernels throu
 """
 from ._version import __version__
 from .argument_parser import get_args
+from .bedpe_writer import BedpeWriter, BedpeWriterError
 from .colors import Colors
 from .fasta_io import FastaIndexingError, FastaNotFoundError
 from .fasta_writer import FastaWriter, FastaWriterError
+from .it_mutator import ITMutator
 from .mut_types import MutType
 from .mutator import Mutation, Mutator
 from .rmt import (ChromNotExistError, ITNotEnoughAvailChromsError, ItRateTooHighError,

@@ -18,7 +18,7 @@ _INIT_ERRORS = (FileNotFoundError, ITNotEnoughAvailChromsError, RatesTooHighErro
 
 def initialize(argv=None):
     args = get_args(argv)
-    if (args.gpus or 1) <= 1 and args.mode != "it":
+    if (args.gpus or 1) <= 1:
         try:                       # the GPU comes up while the FASTA is read and indexed (never in the parent of --gpus N)
             from ._ffi import warm_up_async
             warm_up_async(args.device or 0)
@@ -54,10 +54,6 @@ def main(argv=None):
         import numpy
         random.seed(args.seed)
         numpy.random.seed(args.seed)
-    if sim.has_it:
-        exit_with_error(MsimUnsupported(
-            "interchromosomal translocations (it) are outside the MI355X mutation path; "
-            "run the reference for the IT pass on the *_ms output"), args.no_color)
     if sim.has_mutations:
         try:
             mutator = Mutator(args, fasta, sim)
@@ -73,6 +69,21 @@ def main(argv=None):
                 stats["cli_s"] = {"load_index_settings": round(loaded - start, 4), "mutate_and_write": round(timer() - loaded, 4)}
                 args.bench_json.write_text(json.dumps(stats, indent=1) + "\n")
         except (FastaWriterError, VcfWriterError, MsimError) as e:
+            exit_with_error(e, args.no_color)
+    if sim.has_it:                         # the second pass reads what the first one wrote (reference __main__.py:88-102)
+        if sim.has_mutations:
+            try:
+                fasta = load_fasta(args.outfasta)
+            except (FastaDuplicateHeaderError, FastaIndexingError, FastaNotFoundError) as e:
+                exit_with_error(e, args.no_color)
+        try:
+            it_mutator = ITMutator(args, fasta, sim)
+            try:
+                it_mutator.mutate()
+            finally:
+                it_mutator.close()
+            fasta.close()
+        except (FastaWriterError, BedpeWriterError, MsimError) as e:
             exit_with_error(e, args.no_color)
     runtime = round(timer() - start, 4)
     if not args.quiet:

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("msim_render_vcf_device", C.c_int, [_VP, C.c_int, C.c_char_p, _VP, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
+    ("msim_splice_contigs", C.c_int, [_VP, C.c_int, C.c_int, C.c_uint64, _U64P, _U64P, _IP]),
     ("msim_host_alloc", C.c_int, [_VP, C.c_uint64, C.POINTER(_VP)]),
     ("msim_host_free", C.c_int, [_VP, _VP]),
     ("msim_batch_run", C.c_int, [_VP, C.POINTER(BatchContig), C.c_int]),
@@ -270,6 +271,19 @@ class Engine:
         body = np.ascontiguousarray(body, dtype=np.uint8)
         cid = C.c_int()
         self._check(self.lib.msim_add_contig_text(self.h, _ptr(body), body.shape[0], n_bases, lenc, lenb, C.byref(cid)))
+        return cid.value
+
+    def splice_contigs(self, a: int, b: int, bp_a, bp_b) -> int:
+        """Interchromosomal translocation of contig ``a`` with partner ``b`` (it_mutator.py:121-146): a new contig made of
+        a's and b's segments between the breakpoints, taken alternately.  No breakpoints: a copy of ``a``."""
+        bp_a = np.ascontiguousarray(bp_a, dtype=np.uint64)
+        bp_b = np.ascontiguousarray(bp_b, dtype=np.uint64)
+        if bp_a.shape != bp_b.shape or bp_a.ndim != 1:
+            raise ValueError("both contigs need the same number of breakpoints")
+        cid = C.c_int()
+        n = int(bp_a.shape[0])
+        self._check(self.lib.msim_splice_contigs(self.h, a, b, n, C.cast(C.c_void_p(bp_a.ctypes.data), _U64P) if n else None,
+                                                 C.cast(C.c_void_p(bp_b.ctypes.data), _U64P) if n else None, C.byref(cid)))
         return cid.value
 
     def host_buffer(self, nbytes: int) -> np.ndarray:

@@ -1,0 +1,158 @@
+"""Interchromosomal translocations: the reference's second pass (it_mutator.py:20-220) over the Fasta the mutation pass wrote
+(or over the input, in ``it`` mode).
+
+Host side (this file): which contigs take part, who is whose partner, how many breakpoints a pair gets and where they
+fall -- a few draws from CPython's ``random`` (``shuffle``, ``choice``, ``sample``), made by that very generator, in the
+reference's order, so the stream position and every result agree by construction.  Device side (libmsim): the contigs
+go up as file text, ``msim_splice_contigs`` (csrc/text_gpu.hip: ``k_splice``) cuts both at their breakpoints and takes
+the segments alternately, the framing kernel wraps the result, and the copy lands in the mapped output file."""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+
+from . import _ffi
+from .bedpe_writer import BedpeWriter
+from .fasta_writer import FastaWriter
+from .util import print_warning
+
+
+def sample_with_minimum_distance(start: int, stop: int, k: int, d: int) -> np.ndarray:
+    """k sorted positions in [start, stop) that keep at least d between neighbours (reference util.py:93-109): a plain
+    ``random.sample`` of a range shortened by (k - 1) * d, sorted, the r-th smallest moved up by r * d.  Raises
+    CPython's own ValueError when the range is too short for k."""
+    picked = random.sample(range(start, stop - (k - 1) * d), k)
+    out = np.sort(np.asarray(picked, dtype=np.int64))
+    return out + d * np.arange(k, dtype=np.int64)
+
+
+class ITMutator:
+    def __init__(self, args, fasta, sim):
+        self._args = args
+        self._fasta = fasta
+        self._sim = sim
+        self._fasta_writer = FastaWriter(args.outfastait)
+        self._bedpe_writer = BedpeWriter(args.outbedpe)
+        total = int(getattr(fasta, "text_bytes", 0) or 0)   # segments only change places: the output is as large as the input
+        if total > (64 << 20):
+            self._fasta_writer.preallocate(total + (total >> 6))
+        self._eng = None
+        self._assign_partners(self._available())
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        for w in (getattr(self, "_fasta_writer", None), getattr(self, "_bedpe_writer", None)):
+            if w is not None:
+                w.close()
+        eng, self._eng = getattr(self, "_eng", None), None
+        if eng is not None:
+            eng.close()
+
+    # ------------------------------------------------------------------ who with whom (it_mutator.py:50-83)
+    def _available(self) -> list:
+        """Contigs with an it rate (0 counts, None does not) and more than two bases."""
+        return [c.number for c in self._sim.chromosomes if c.it_rate is not None and len(self._fasta[c.number]) > 2]
+
+    def _assign_partners(self, avail: list):
+        """A shuffle, then every contig the walk reaches picks a random partner among those left.  The reference walks
+        the very list it removes from, so the walk skips: after taking the contig at index i (and a partner) out, index
+        i + 1 is looked at next.  Kept as is -- which contigs stay single depends on it."""
+        self._partners = {}
+        random.shuffle(avail)
+        i = 0
+        while i < len(avail):
+            chrom = avail[i]
+            i += 1
+            avail.remove(chrom)
+            if avail:
+                partner = random.choice(avail)
+                self._partners[partner] = chrom
+                self._partners[chrom] = partner
+                avail.remove(partner)
+
+    def _pairs_once(self) -> list:
+        """One contig of every pair, in the order the pairs were made (it_mutator.py:85-94)."""
+        chroms = list(self._partners.keys())
+        for chrom, partner in self._partners.items():
+            if chrom in chroms:
+                chroms.remove(partner)
+        return chroms
+
+    # ------------------------------------------------------------------ breakpoints (it_mutator.py:96-119, 158-190)
+    def _warn(self, text: str):
+        if not self._args.ignore_warnings:
+            print_warning(text, self._args.no_color)
+
+    def _breakpoints_of_pair(self, chrom: int):
+        partner = self._partners[chrom]
+        len1, len2 = len(self._fasta[chrom]), len(self._fasta[partner])
+        rate1, rate2 = self._sim.chromosomes[chrom].it_rate, self._sim.chromosomes[partner].it_rate
+        amount = int((len1 + len2 - 4) / 2 * ((rate1 + rate2) / 2))
+        bp1 = bp2 = np.zeros(0, dtype=np.int64)
+        try:                                           # one base at least stays between two breakpoints
+            bp1 = sample_with_minimum_distance(1, len1, amount, 1)
+            bp2 = sample_with_minimum_distance(1, len2, amount, 1)
+        except ValueError:
+            self._warn(f"Interchromosomal translocation rate too high for sequence {chrom+1} and {partner+1}.")
+        return bp1, bp2
+
+    def _generate_all_breakpoints(self) -> dict:
+        out = {}
+        for chrom in self._pairs_once():
+            partner = self._partners[chrom]
+            bp1, bp2 = self._breakpoints_of_pair(chrom)
+            if len(bp1) and len(bp2):
+                out[chrom] = (bp1, bp2)
+                out[partner] = (bp2, bp1)
+            else:
+                self._warn(f"No interchromosomal translocations could be generated between sequence {chrom+1} and "
+                           f"{partner+1} (it rates too low).")
+        return out
+
+    # ------------------------------------------------------------------ output (it_mutator.py:121-156, 192-220)
+    def _engine(self):
+        if self._eng is None:
+            self._eng = _ffi.Engine(getattr(self._args, "device", 0) or 0)
+        return self._eng
+
+    def _ingest(self, eng, rec) -> int:
+        if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
+            return eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
+        return eng.add_contig(rec.bases)
+
+    def _mutate_sequence(self, breakpoints: dict):
+        eng = self._engine()
+        none = np.zeros(0, dtype=np.uint64)
+        for chrom in self._sim.chromosomes:
+            rec = self._fasta[chrom.number]
+            bpl = self._fasta.faidx.index[rec.name].lenc
+            self._fasta_writer.set_bpl(bpl)
+            self._fasta_writer.write_header(rec.long_name)
+            a = self._ingest(eng, rec)
+            if chrom.number in breakpoints:
+                partner = self._fasta[self._partners[chrom.number]]
+                own, other = breakpoints[chrom.number]
+                cid = eng.splice_contigs(a, self._ingest(eng, partner), own.astype(np.uint64), other.astype(np.uint64))
+                self._bedpe_writer.write(rec.name, own, len(rec), partner.name, other, len(partner))
+            else:
+                # (the reference's __write_chrom_full writes the header again, it_mutator.py:148-156 after :199-202: a contig
+                #  without breakpoints carries its defline twice.  Kept: the files are compared byte by byte)
+                self._fasta_writer.write_header(rec.long_name)
+                cid = eng.splice_contigs(a, -1, none, none)
+            if bpl > 0:
+                n_text = eng.fetch_sequence_framed_size(cid, bpl)
+                region = self._fasta_writer.map_region(n_text)
+                try:
+                    eng.fetch_sequence_framed_into(cid, bpl, region.view)
+                finally:
+                    q, r = divmod(n_text, bpl + 1)
+                    self._fasta_writer.commit_region(region, q * bpl + r)
+            else:
+                self._fasta_writer.write_array(eng.fetch_sequence(cid))
+            eng.clear()
+
+    def mutate(self):
+        self._mutate_sequence(self._generate_all_breakpoints())

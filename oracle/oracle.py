@@ -315,3 +315,99 @@ class Oracle:
                 self.L.orc_release(recs)
         fa, vcf = self.outputs()
         return fa, vcf, empty, (recs_out if keep_records else None)
+
+    # ---- interchromosomal translocations: the reference's second pass
+    def shuffle(self, items: list) -> list:
+        """Lib/random.py shuffle, by randbelow (msim_oracle.c: orc_shuffle does the same over int64)."""
+        x = list(items)
+        for i in range(len(x) - 1, 0, -1):
+            j = self.randbelow(i + 1)
+            x[i], x[j] = x[j], x[i]
+        return x
+
+    def it_pass(self, contigs, it_rates, ignore_warnings: bool = False):
+        """``ITMutator.__init__`` + ``mutate()`` (it_mutator.py:24-220, bedpe_writer.py:36-55, fasta_writer.py:31-58).
+
+        ``contigs``: list of dicts {name, long_name, lenc, bases(np.uint8, upper-cased)} -- the Fasta the pass reads;
+        ``it_rates``: per contig a float or None.  Draws from THIS oracle's CPython stream.
+        Returns (fasta_bytes, bedpe_bytes, [warning texts])."""
+        warnings = []
+
+        def warn(text):
+            if not ignore_warnings:
+                warnings.append(text)
+        # it_mutator.py:50-57  contigs with a rate (0 counts) and more than two bases
+        avail = [i for i, r in enumerate(it_rates) if r is not None and len(contigs[i]["bases"]) > 2]
+        # it_mutator.py:59-71  shuffle, then a walk over the very list that is being emptied
+        avail = self.shuffle(avail)
+        partners = {}
+        i = 0
+        while i < len(avail):
+            chrom = avail[i]
+            i += 1
+            avail.remove(chrom)
+            if avail:
+                partner = avail[self.randbelow(len(avail))]            # random.choice
+                partners[partner] = chrom
+                partners[chrom] = partner
+                avail.remove(partner)
+        # it_mutator.py:73-83  one contig per pair
+        once = list(partners.keys())
+        for chrom, partner in partners.items():
+            if chrom in once:
+                once.remove(partner)
+        # it_mutator.py:158-190  breakpoints of every pair
+        bps = {}
+        for chrom in once:
+            partner = partners[chrom]
+            l1, l2 = len(contigs[chrom]["bases"]), len(contigs[partner]["bases"])
+            amount = int((l1 + l2 - 4) / 2 * ((it_rates[chrom] + it_rates[partner]) / 2))      # it_mutator.py:96
+            b1, b2 = [], []
+            try:
+                b1 = [int(x) for x in self.sample_min_dist(1, l1, amount, 1)]
+                b2 = [int(x) for x in self.sample_min_dist(1, l2, amount, 1)]
+            except OracleValueError:
+                warn(f"Interchromosomal translocation rate too high for sequence {chrom+1} and {partner+1}.")
+            if b1 and b2:
+                bps[chrom] = (b1, b2)
+                bps[partner] = (b2, b1)
+            else:
+                warn(f"No interchromosomal translocations could be generated between sequence {chrom+1} and {partner+1} "
+                     "(it rates too low).")
+        # it_mutator.py:192-216  write every contig, in file order
+        fa, bedpe = bytearray(), bytearray()
+        written = 0
+        for k, c in enumerate(contigs):
+            if written:                                                  # fasta_writer.py:31-38
+                fa += b"\n"
+            fa += b">" + c["long_name"].encode() + b"\n"
+            written = 0
+            if k in bps:
+                own, other = bps[k]
+                p = contigs[partners[k]]
+                ca, cb = [0] + own + [len(c["bases"])], [0] + other + [len(p["bases"])]
+                parts = [(p["bases"][cb[j]:cb[j + 1]] if j % 2 else c["bases"][ca[j]:ca[j + 1]]) for j in range(len(ca) - 1)]
+                seq = np.concatenate(parts) if parts else np.zeros(0, dtype=np.uint8)
+                n = len(own)                                             # bedpe_writer.py:44-55
+                for j in range(0, n, 2):
+                    if j != n - 1:
+                        bedpe += f"{c['name']}\t{own[j]}\t{own[j+1]}\t{p['name']}\t{other[j]}\t{other[j+1]}\n".encode()
+                    elif n % 2:
+                        bedpe += f"{c['name']}\t{own[j]}\t{len(c['bases'])}\t{p['name']}\t{other[j]}\t{len(p['bases'])}\n".encode()
+            else:
+                # __write_chrom_full (it_mutator.py:148-156) writes the header itself -- after __mutate_sequence already
+                # did (it_mutator.py:199-202): a contig without breakpoints carries its defline twice
+                fa += b">" + c["long_name"].encode() + b"\n"
+                seq = c["bases"]
+            bpl = c["lenc"]
+            raw = bytes(np.asarray(seq, dtype=np.uint8))
+            for a in range(0, len(raw), bpl):                            # fasta_writer.py:40-58
+                line = raw[a:a + bpl]
+                fa += line
+                if len(line) == bpl:
+                    fa += b"\n"
+                    written = 0
+                else:
+                    written = len(line)
+        return bytes(fa), bytes(bedpe), warnings
+

@@ -213,6 +213,7 @@ def cli_case(name: str, spec: dict, argv_tail: list[str], seed_py: int, seed_np:
                     a2 = ref.get_args()
                     f2 = ref_util.load_fasta(a2.infile)
                     sim2 = (SimulationSettings.from_args(a2, f2, True) if a2.mode == "args"
+                            else SimulationSettings.from_it(a2.interchromosomalrate, f2, True) if a2.mode == "it"
                             else SimulationSettings.from_rmt(a2.rmtfile, f2, True))
                 meta["sim"] = dump_sim(sim2)
                 meta["contigs"] = [{"name": f2[k].name, "long_name": f2[k].long_name,
@@ -220,7 +221,19 @@ def cli_case(name: str, spec: dict, argv_tail: list[str], seed_py: int, seed_np:
                                    for k in f2.keys()]
             finally:
                 sys.argv = old
-        if exc is None and code is None:
+        it_fa, it_bedpe = td / f"out_ms_it{stem}", td / "out_ms_it.bedpe"
+        if exc is None and code is None and it_fa.exists():
+            # the interchromosomal-translocation pass (it_mutator.py): its Fasta and its BEDPE
+            fa_it, bedpe = it_fa.read_bytes(), it_bedpe.read_bytes()
+            meta.update({"it_fasta_sha256": sha256(fa_it), "it_fasta_len": len(fa_it),
+                         "bedpe_sha256": sha256(bedpe), "bedpe_len": len(bedpe),
+                         "bedpe_head": bedpe[:400].decode(), "it_fasta_head": fa_it[:200].decode()})
+            if store == "full":
+                (case_dir / "expected_ms_it.fa").write_bytes(fa_it)
+                (case_dir / "expected_ms_it.bedpe").write_bytes(bedpe)
+                if not out_fa.exists():
+                    (case_dir / "input.fa").write_bytes(infile.read_bytes())
+        if exc is None and code is None and out_fa.exists():
             fa = out_fa.read_bytes()
             vcf = mask_vcf(out_vcf.read_bytes())
             vcf_lines = vcf.split(b"\n")
@@ -866,11 +879,69 @@ def make_reference_timing():
     (HERE / "reference_timing.json").write_text(json.dumps(out, indent=1) + "\n")
 
 
+RMT_IT = """\
+# mutations AND interchromosomal translocations: the second pass reads what the first one wrote
+titv = 2.0
+
+std
+it 0.0004
+sn 0.01 in 0.002 inmin 1 inmax 9 de 0.002 demin 1 demax 12
+
+chr 2
+it None
+chr 3
+it 0.002
+1-3000 None
+3001-END sn 0.02
+chr 5
+it 0
+"""
+
+
+def make_cli_cases_it():
+    """The `it` sub-command and RMT files with `it` lines (it_mutator.py, bedpe_writer.py)."""
+    print("CLI cases (interchromosomal translocations)")
+    four = {"contigs": [{"defline": "a1 first", "length": 50_000, "bpl": 60, "seed": 301},
+                        {"defline": "a2", "length": 30_011, "bpl": 70, "seed": 302},
+                        {"defline": "a3 third one", "length": 20_000, "bpl": 60, "seed": 303, "decorate": True},
+                        {"defline": "a4", "length": 41_234, "bpl": 80, "seed": 304}]}
+    cli_case("it_only_4ctg", four, ["it", "0.0005"], 51, 52, notes="`it` mode: two pairs, 17-22 breakpoints each; no _ms files")
+    odd = {"contigs": [{"defline": "b1", "length": 9_000, "bpl": 60, "seed": 311},
+                       {"defline": "b2 two bases", "length": 2, "bpl": 60, "seed": 312},
+                       {"defline": "b3", "length": 12_345, "bpl": 50, "seed": 313},
+                       {"defline": "b4", "length": 7_000, "bpl": 60, "seed": 314},
+                       {"defline": "b5 three bases", "length": 3, "bpl": 60, "seed": 315},
+                       {"defline": "b6", "length": 15_000, "bpl": 61, "seed": 316},
+                       {"defline": "b7", "length": 4_321, "bpl": 60, "seed": 317}]}
+    for sp, sn_ in ((61, 62), (63, 64), (65, 66)):
+        cli_case(f"it_only_odd_s{sp}", odd, ["it", "0.002"], sp, sn_,
+                 notes="`it` mode: a 2-base contig is left out, six take part -- who stays single depends on the walk over "
+                       "the list the reference removes from; a 3-base contig can get a partner")
+    cli_case("it_rate_high_low", {"contigs": [{"defline": "c1", "length": 100, "bpl": 60, "seed": 321},
+                                               {"defline": "c2", "length": 300, "bpl": 60, "seed": 322},
+                                               {"defline": "c3", "length": 280, "bpl": 60, "seed": 323},
+                                               {"defline": "c4", "length": 90, "bpl": 60, "seed": 324}]},
+             ["it", "0.5"], 71, 72, notes="rate 0.5 on short contigs: sample() raises on the shorter one of each pair -- first or "
+                                        "second, after the longer one already drew -- both warnings, full copies written")
+    cli_case("it_rate_tiny", four, ["it", "0.0000001"], 73, 74, notes="no breakpoint at all: the 'rates too low' warnings")
+    spec = {"contigs": [{"defline": "m1", "length": 60_000, "bpl": 60, "seed": 331},
+                        {"defline": "m2 no it", "length": 25_000, "bpl": 60, "seed": 332},
+                        {"defline": "m3", "length": 33_333, "bpl": 70, "seed": 333},
+                        {"defline": "m4", "length": 47_000, "bpl": 60, "seed": 334},
+                        {"defline": "m5 it 0", "length": 52_000, "bpl": 80, "seed": 335},
+                        {"defline": "m6", "length": 8_000, "bpl": 60, "seed": 336}]}
+    cli_case("it_rmt_mutations", spec, [], 81, 82, rmt_text=RMT_IT,
+             notes="RMT with mutations and it rates (std 0.0004, one contig None, one 0.002, one 0): mutation pass, then the IT "
+                   "pass over the mutated Fasta; _ms and _ms_it files")
+
+
 def main():
     os.chdir(HERE)
-    which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli", "engines"}
+    which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli", "engines", "it"}
     if "timing" in which:
         make_reference_timing()
+    if "it" in which:
+        make_cli_cases_it()
     if "engines" in which:
         make_cli_cases_engines()
     if "scaffolds" in which or "engines" in which:

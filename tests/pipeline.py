@@ -36,6 +36,8 @@ def build_settings(argv):
     fasta = msa.load_fasta(args.infile)
     if args.mode == "args":
         sim = msa.SimulationSettings.from_args(args, fasta, args.ignore_warnings)
+    elif args.mode == "it":
+        sim = msa.SimulationSettings.from_it(args.interchromosomalrate, fasta, args.ignore_warnings)
     else:
         sim = msa.SimulationSettings.from_rmt(args.rmtfile, fasta, args.ignore_warnings)
     return args, fasta, sim
@@ -85,11 +87,16 @@ def run_product_case(meta: dict, tmp: Path):
     except BaseException as e:  # noqa: BLE001
         exc = e
     res = {"exit_code": code, "exception": exc, "stdout": out.getvalue(), "stderr": err.getvalue(),
-           "fasta": None, "vcf": None}
+           "fasta": None, "vcf": None, "it_fasta": None, "bedpe": None}
     suffix = Path(meta["infile_name"]).suffix
     fa, vcf = tmp / f"out_ms{suffix}", tmp / "out_ms.vcf"
     if fa.exists():
         res["fasta"] = fa.read_bytes()
     if vcf.exists():
         res["vcf"] = mask_vcf(vcf.read_bytes())
+    it_fa, bedpe = tmp / f"out_ms_it{suffix}", tmp / "out_ms_it.bedpe"      # the interchromosomal-translocation pass
+    if it_fa.exists():
+        res["it_fasta"] = it_fa.read_bytes()
+    if bedpe.exists():
+        res["bedpe"] = bedpe.read_bytes()
     return res

@@ -44,11 +44,22 @@ def test_cli_matches_reference_golden(name, tmp_path):
             assert str(res["exception"]) == meta["exception"]["message"]
         return
     assert res["exception"] is None and res["exit_code"] is None, (res["exception"], res["stderr"])
-    assert len(res["fasta"]) == meta["fasta_len"] and sha256(res["fasta"]) == meta["fasta_sha256"]
-    assert len(res["vcf"]) == meta["vcf_len"] and sha256(res["vcf"]) == meta["vcf_sha256"]
-    if meta["store"] == "full":
-        assert res["fasta"] == (CASES / name / "expected_ms.fa").read_bytes()
-        assert res["vcf"] == (CASES / name / "expected_ms.vcf").read_bytes()
+    if "fasta_len" in meta:                     # (absent in `it` mode: no mutation pass, no _ms files)
+        assert len(res["fasta"]) == meta["fasta_len"] and sha256(res["fasta"]) == meta["fasta_sha256"]
+        assert len(res["vcf"]) == meta["vcf_len"] and sha256(res["vcf"]) == meta["vcf_sha256"]
+        if meta["store"] == "full":
+            assert res["fasta"] == (CASES / name / "expected_ms.fa").read_bytes()
+            assert res["vcf"] == (CASES / name / "expected_ms.vcf").read_bytes()
+    else:
+        assert res["fasta"] is None and res["vcf"] is None
+    if "it_fasta_len" in meta:                  # the interchromosomal-translocation pass: its Fasta and its BEDPE
+        assert len(res["it_fasta"]) == meta["it_fasta_len"] and sha256(res["it_fasta"]) == meta["it_fasta_sha256"]
+        assert len(res["bedpe"]) == meta["bedpe_len"] and sha256(res["bedpe"]) == meta["bedpe_sha256"]
+        if meta["store"] == "full":
+            assert res["it_fasta"] == (CASES / name / "expected_ms_it.fa").read_bytes()
+            assert res["bedpe"] == (CASES / name / "expected_ms_it.bedpe").read_bytes()
+    else:
+        assert res["it_fasta"] is None and res["bedpe"] is None
     assert res["stderr"] == meta["stderr"]
     assert [random.getrandbits(32) for _ in range(4)] == meta["py_next_words_after"]
 

@@ -152,3 +152,40 @@ def test_ingest_from_text_equals_host_parse(lenc, eol):
     with pytest.raises(_ffi.MsimError):
         eng.add_contig_text(np.frombuffer(body[:1000], dtype=np.uint8), L, lenc, lenc + len(eol))
     eng.close()
+
+
+def _splice_numpy(A, B, bp_a, bp_b):
+    """it_mutator.py:121-146: pairwise([0] + bp + [len]) over both contigs, even intervals from A, odd ones from B."""
+    ca, cb = [0] + [int(x) for x in bp_a] + [len(A)], [0] + [int(x) for x in bp_b] + [len(B)]
+    parts = [(B[cb[j]:cb[j + 1]] if j % 2 else A[ca[j]:ca[j + 1]]) for j in range(len(ca) - 1)]
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("la,lb,n_bp,seed", [(50_000, 30_011, 17, 1), (1_000_000, 700_000, 200_000, 2), (3, 9, 1, 3),
+                                             (4_000_000, 2_500_000, 1, 4), (100_003, 100_003, 49_000, 5), (64, 1_000_000, 31, 6)])
+def test_splice_contigs_equals_numpy(la, lb, n_bp, seed):
+    """msim_splice_contigs (k_splice): interchromosomal translocation of one contig, for a few breakpoints and for as many
+    as fit (segments of two bases), through the plain and the framed fetch."""
+    rs = np.random.RandomState(seed)
+    A, B = random_bases(la, seed), random_bases(lb, seed + 50)
+
+    def breakpoints(L):                               # sample_with_minimum_distance(1, L, n_bp, 1): sorted, >= 2 apart
+        s = np.sort(rs.choice(np.arange(1, L - (n_bp - 1)), size=n_bp, replace=False))
+        return (s + np.arange(n_bp)).astype(np.uint64)
+    bp_a, bp_b = breakpoints(la), breakpoints(lb)
+    eng = _ffi.Engine(0)
+    a, b = eng.add_contig(A), eng.add_contig(B)
+    for own, other, x, y, X, Y in ((bp_a, bp_b, a, b, A, B), (bp_b, bp_a, b, a, B, A)):
+        cid = eng.splice_contigs(x, y, own, other)
+        want = _splice_numpy(X, Y, own, other)
+        got = eng.fetch_sequence(cid)
+        assert got.shape == want.shape and np.array_equal(got, want)
+        for bpl in (60, 7):
+            assert eng.fetch_sequence_framed(cid, bpl).tobytes() == _wrap(want, bpl)
+    full = eng.splice_contigs(a, -1, np.zeros(0, np.uint64), np.zeros(0, np.uint64))      # __write_chrom_full
+    assert np.array_equal(eng.fetch_sequence(full), A)
+    with pytest.raises(_ffi.MsimError):               # breakpoints must ascend and lie inside their contig
+        eng.splice_contigs(a, b, np.array([5, 3], np.uint64), np.array([1, 2], np.uint64))
+    with pytest.raises(_ffi.MsimError):
+        eng.splice_contigs(a, b, np.array([1], np.uint64), np.array([lb + 1], np.uint64))
+    eng.close()

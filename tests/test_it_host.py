@@ -1,0 +1,155 @@
+"""Interchromosomal translocations (the reference's second pass: it_mutator.py, bedpe_writer.py) -- CPU tier.
+
+* the oracle's restatement (``Oracle.it_pass``) is pinned against what the REAL reference wrote for the ``it_*`` cases
+  of tests/golden/cases (Fasta with its doubled deflines, BEDPE, warnings, stream position);
+* the product's host side (``ITMutator``: who with whom, breakpoints, BEDPE, writer calls, CLI flow) runs here against the
+  same goldens with the device replaced by a numpy stand-in for the five engine calls it makes -- the device side
+  (``msim_splice_contigs`` / ``k_splice``, framing, mapped egress) is the GPU tier's (tests/test_gpu_parity.py).
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import pytest
+
+from helpers import CASES, all_case_names, case_input_bytes, case_meta, parse_fasta_bytes
+from oracle import oracle as orc
+from pipeline import run_product_case
+
+IT_CASES = [n for n in all_case_names() if n.startswith("it_")]
+IT_ONLY = [n for n in IT_CASES if "fasta_len" not in case_meta(n)]
+
+
+def _warnings_text(ws):
+    return "".join(f"WARNING: {w}\n" for w in ws)
+
+
+@pytest.mark.parametrize("name", IT_ONLY)
+def test_oracle_it_pass_matches_reference_golden(name):
+    meta = case_meta(name)
+    contigs = parse_fasta_bytes(case_input_bytes(meta))
+    o = orc.Oracle()
+    o.seed(meta["seed_py"], meta["seed_np"])
+    fa, bedpe, ws = o.it_pass(contigs, [c["it_rate"] for c in meta["sim"]["chromosomes"]])
+    assert fa == (CASES / name / "expected_ms_it.fa").read_bytes()
+    assert bedpe == (CASES / name / "expected_ms_it.bedpe").read_bytes()
+    assert _warnings_text(ws) == meta["stderr"]
+    assert o.py_words32(4) == meta["py_next_words_after"]
+
+
+def test_oracle_mutation_pass_then_it_pass_matches_reference_golden():
+    """RMT with mutations and it rates: the IT pass reads the mutated Fasta, its draws follow the mutation pass's."""
+    name = "it_rmt_mutations"
+    meta = case_meta(name)
+    contigs = parse_fasta_bytes(case_input_bytes(meta))
+    o = orc.Oracle()
+    o.seed(meta["seed_py"], meta["seed_np"])
+    fa, vcf, _, _ = o.run_genome(contigs, meta["sim"], meta["infile_name"])
+    assert fa == (CASES / name / "expected_ms.fa").read_bytes()
+    mutated = parse_fasta_bytes(fa)
+    for c, src in zip(mutated, meta["contigs"]):
+        c["lenc"] = src["lenc"]                      # (the mutated file keeps every record's line width)
+    fa_it, bedpe, ws = o.it_pass(mutated, [c["it_rate"] for c in meta["sim"]["chromosomes"]])
+    assert fa_it == (CASES / name / "expected_ms_it.fa").read_bytes()
+    assert bedpe == (CASES / name / "expected_ms_it.bedpe").read_bytes()
+    assert _warnings_text(ws) == meta["stderr"]
+    assert o.py_words32(4) == meta["py_next_words_after"]
+
+
+class NumpyEngine:
+    """Test double for the engine calls ``ITMutator`` makes (same meaning as the C-ABI entries they bind)."""
+
+    def __init__(self, device=0, flags=0):
+        self.contigs = []
+
+    def add_contig_text(self, body, n_bases, lenc, lenb):
+        raw = bytes(np.asarray(body, dtype=np.uint8)).replace(b"\r", b"").replace(b"\n", b"").upper()
+        assert len(raw) >= n_bases
+        self.contigs.append(np.frombuffer(raw[:n_bases], dtype=np.uint8).copy())
+        return len(self.contigs) - 1
+
+    def add_contig(self, bases):
+        self.contigs.append(np.asarray(bases, dtype=np.uint8).copy())
+        return len(self.contigs) - 1
+
+    def splice_contigs(self, a, b, bp_a, bp_b):
+        A = self.contigs[a]
+        if len(bp_a) == 0:
+            self.contigs.append(A.copy())
+            return len(self.contigs) - 1
+        B = self.contigs[b]
+        ca = [0] + [int(x) for x in bp_a] + [len(A)]
+        cb = [0] + [int(x) for x in bp_b] + [len(B)]
+        parts = [(B[cb[j]:cb[j + 1]] if j % 2 else A[ca[j]:ca[j + 1]]) for j in range(len(ca) - 1)]
+        self.contigs.append(np.concatenate(parts))
+        return len(self.contigs) - 1
+
+    def fetch_sequence(self, cid):
+        return self.contigs[cid]
+
+    def fetch_sequence_framed_size(self, cid, bpl):
+        n = len(self.contigs[cid])
+        return n + n // bpl
+
+    def fetch_sequence_framed_into(self, cid, bpl, view):
+        s = bytes(self.contigs[cid])
+        text = b"".join(s[i:i + bpl] + (b"\n" if len(s[i:i + bpl]) == bpl else b"") for i in range(0, len(s), bpl))
+        view[:len(text)] = np.frombuffer(text, dtype=np.uint8)
+
+    def clear(self):
+        self.contigs = []
+
+    def close(self):
+        pass
+
+
+@pytest.mark.parametrize("name", IT_ONLY)
+def test_it_mode_cli_host_side_matches_reference_golden(name, tmp_path, monkeypatch):
+    """``mutation-simulator file it <rate>`` through the product's CLI with the device stood in for: partner assignment,
+    breakpoints, the doubled defline of untouched contigs, BEDPE lines, warnings, the generator's position."""
+    from mutation_simulator_amd import _ffi
+    monkeypatch.setattr(_ffi, "Engine", NumpyEngine)
+    monkeypatch.setattr(_ffi, "warm_up_async", lambda device=0: None)
+    meta = case_meta(name)
+    res = run_product_case(meta, tmp_path)
+    assert res["exception"] is None and res["exit_code"] is None, (res["exception"], res["stderr"])
+    assert res["fasta"] is None and res["vcf"] is None              # no mutation pass: no _ms files
+    assert res["it_fasta"] == (CASES / name / "expected_ms_it.fa").read_bytes()
+    assert res["bedpe"] == (CASES / name / "expected_ms_it.bedpe").read_bytes()
+    assert res["stderr"] == meta["stderr"]
+    assert [random.getrandbits(32) for _ in range(4)] == meta["py_next_words_after"]
+
+
+def test_bedpe_writer_lines():
+    """bedpe_writer.py:44-55: a line per pair of breakpoints, a closing line to both contig ends for an odd count; the
+    header line exists as a method the reference never calls."""
+    import mutation_simulator_amd as msa
+    import tempfile
+    from pathlib import Path
+    with tempfile.TemporaryDirectory() as td:
+        p = Path(td) / "x.bedpe"
+        w = msa.BedpeWriter(p)
+        w.write("c1", [5, 9, 30], 100, "c2", [2, 7, 11], 50)
+        w.write("c2", np.array([2, 7]), 50, "c1", np.array([5, 9]), 100)
+        w.write("c3", [], 10, "c4", [], 10)
+        w.close()
+        assert p.read_text() == "c1\t5\t9\tc2\t2\t7\nc1\t30\t100\tc2\t11\t50\nc2\t2\t7\tc1\t5\t9\n"
+        with pytest.raises(msa.BedpeWriterError):
+            msa.BedpeWriter(Path(td) / "no_such_dir" / "x.bedpe")
+
+
+def test_sample_with_minimum_distance_is_the_references():
+    """util.py:93-109 on CPython's own generator, against the oracle's restatement on its own MT19937."""
+    from mutation_simulator_amd.it_mutator import sample_with_minimum_distance
+    for seed, (start, stop, k, d) in enumerate([(1, 1000, 40, 1), (1, 90, 44, 1), (0, 5000, 7, 30), (1, 50, 0, 1)]):
+        random.seed(seed)
+        got = sample_with_minimum_distance(start, stop, k, d)
+        o = orc.Oracle()
+        o.seed(seed, 0)
+        want = o.sample_min_dist(start, stop, k, d)
+        assert got.tolist() == [int(x) for x in want]
+        assert np.all(np.diff(got) > d) if k > 1 else True
+    random.seed(3)
+    with pytest.raises(ValueError):
+        sample_with_minimum_distance(1, 100, 51, 1)
