@@ -159,7 +159,8 @@ def test_apply(case):
 
 
 # ------------------------------------------------------------------------------ whole-CLI goldens
-RUNNABLE = [n for n in all_case_names() if case_meta(n).get("sim") is not None]
+# (cases with an interchromosomal-translocation pass: tests/test_it_host.py -- mutation pass included where there is one)
+RUNNABLE = [n for n in all_case_names() if case_meta(n).get("sim") is not None and "it_fasta_len" not in case_meta(n)]
 
 
 @pytest.mark.parametrize("name", RUNNABLE)
