@@ -69,14 +69,15 @@ class Preallocator:
         self._q = queue.SimpleQueue()
         self._thread = None
         self._stop = False
-        self._pending = 0                       # requests queued and not mapped yet
+        self._requested = 0                     # requests queued (written by the requesting thread only)
+        self._mapped = 0                        # requests whose arena is mapped, or that failed (written by the worker only)
 
     def request(self, start: int, end: int):
         import threading
         start -= start % mmap.ALLOCATIONGRANULARITY
         if end <= start or self._stop:
             return
-        self._pending += 1
+        self._requested += 1
         self._q.put((int(start), int(end)))
         if self._thread is None:
             self._thread = threading.Thread(target=self._work, name="msim-fallocate", daemon=True)
@@ -96,7 +97,7 @@ class Preallocator:
                     self._arenas.append((start, end - start, arena))
             except (OSError, ValueError):
                 arena = None
-            self._pending -= 1
+            self._mapped += 1
             step = 64 << 20
             for a in range(0, end - start if arena is not None else 0, step):
                 if self._stop:
@@ -114,7 +115,7 @@ class Preallocator:
             for start, length, arena in reversed(self._arenas):
                 if start <= pos and pos + nbytes <= start + length:
                     return np.frombuffer(arena, dtype=np.uint8, count=nbytes, offset=pos - start)
-            if self._pending <= 0 or self._thread is None or not self._thread.is_alive():
+            if self._mapped >= self._requested or self._thread is None or not self._thread.is_alive():
                 return None
             time.sleep(0.0005)
         return None

@@ -19,6 +19,9 @@ grep -h "k_rewrite" $O/pmc_*.txt
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 16 > $O/cli_profile.txt 2>&1
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- args -sn 0.005 -in 0.001 -inmin 1 -inmax 50 -de 0.001 -demin 1 -demax 50 -du 0.0005 -dumin 50 -dumax 500 -iv 0.0005 -ivmin 50 -ivmax 500 >> $O/cli_profile.txt 2>&1
+# the reference's own benchmark flags (README "Performance": every type at 0.01, translocations included), and the IT pass
+python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- args -sn 0.01 -in 0.01 -de 0.01 -du 0.01 -iv 0.01 -tl 0.01 >> $O/cli_profile.txt 2>&1
+python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- it 0.0001 >> $O/cli_profile.txt 2>&1
 (MSIM_BATCH_PROF=1 python3 mutation-simulator_amd/tools/scaffold_bench.py 20000 10000; python3 mutation-simulator_amd/tools/scaffold_bench.py 200000 1000) > $O/scaffold_bench.txt 2>&1
 timeout 100 python3 mutation-simulator_amd/tools/apply_microbench.py 10 > $O/apply_microbench.txt 2>&1
 head -30 $O/kernel_stats_c4sv.txt

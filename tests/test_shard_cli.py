@@ -81,6 +81,18 @@ def test_sharded_cli_matches_reference_golden(name, gpus, tmp_path, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_sharded_mutation_pass_then_it_pass(tmp_path, monkeypatch):
+    """--gpus 2 on an RMT with mutations and `it` lines: the workers write the mutation pass, the parent takes the generator
+    back and runs the interchromosomal-translocation pass over the assembled _ms Fasta -- all four files as the reference's."""
+    name = "it_rmt_mutations"
+    meta, res = _run_sharded(name, tmp_path, monkeypatch, 2, host_only=False)
+    _check_vcf_rng_stderr(meta, res)
+    assert res["fasta"] == (CASES / name / "expected_ms.fa").read_bytes()
+    assert res["it_fasta"] == (CASES / name / "expected_ms_it.fa").read_bytes()
+    assert res["bedpe"] == (CASES / name / "expected_ms_it.bedpe").read_bytes()
+
+
+@pytest.mark.gpu
 def test_sharded_cli_key_error_leaves_what_one_gpu_leaves(tmp_path, monkeypatch):
     """A transversion on a base outside AGTCN (mutator.py:449-455) in a contig owned by some rank: the KeyError reaches
     the caller and the files hold what the 1-GPU run leaves behind."""
