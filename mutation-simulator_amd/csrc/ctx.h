@@ -132,8 +132,11 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
 // | value -- the top byte is the increment of the slot index w << lg_rows, so the walk never scales anything -- or 0
 // where no draw is accepted within CHAIN_TABLE_REACH words / the end of the window; w = 0..n_words.
 constexpr uint32_t CHAIN_TABLE_REACH = 63;                           // acceptance >= 1/2: 63 rejections in a row never happen
-struct ChainClasses { uint32_t n; uint32_t sh[4]; uint32_t width[4]; uint8_t cls_of[8]; };
-inline uint32_t chain_lg_rows(const ChainClasses &cc) { return cc.n <= 1 ? 0u : (cc.n == 2 ? 1u : 2u); }
+// Up to eight classes: five SV types with five different length widths on one contig take 8 slots per word position.  The
+// slot increment of an entry is at most 63 << lg_rows: 8 bits above a 24-bit value up to four classes, 9 above 23 beyond.
+struct ChainClasses { uint32_t n; uint32_t sh[8]; uint32_t width[8]; uint8_t cls_of[8]; };
+inline uint32_t chain_lg_rows(const ChainClasses &cc) { return cc.n <= 1 ? 0u : (cc.n == 2 ? 1u : (cc.n <= 4 ? 2u : 3u)); }
+constexpr uint32_t chain_value_bits(uint32_t lg_rows) { return lg_rows <= 2 ? 24u : 23u; }
 bool chain_classes(const msim_range &r, ChainClasses &cc);          // false: some length does not fit the table entry
 void accept_tables_host(const ChainClasses &cc, const uint32_t *words, size_t n_words, uint32_t *T);   // test support
 // The walk is resumable, so that the host can start on the first piece of the table while the rest is still being
@@ -145,7 +148,7 @@ struct ChainWalk {
     int64_t blk_hi = 0, bad = 0;                                     // last_mut_range = range(0)
     int64_t add[8], next_add[8], next_cap[8], clamp[8], drop_from[8], in_mask[8], draw_mask[8];
     size_t row[8];
-    uint32_t lg_rows = 0;
+    uint32_t lg_rows = 0, vbits = 24;                                // table entry = slot increment << vbits | value
     int init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses &cc, size_t n_words);
     static bool types_ok(const uint8_t *type, size_t n, bool with_tl = false);
     void run(const uint32_t *pos, const uint8_t *type, size_t n, const uint32_t *T, size_t w_lim, uint32_t *stop);

@@ -302,7 +302,7 @@ int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t 
 // k_accept_tables) and hands over  T[w][class] = (words consumed) << 24 | value.  The walk is then one
 // table load per candidate with a branch-free keep / drop: the loop-carried chain is  w -> T[w] -> w  and
 // blk_hi -> dropped -> blk_hi, about 8 cycles.
-// append the classes of r's drawable IN/DE/DU/IV lengths to g (at most 4); cls_of[t] = class of type t
+// append the classes of r's drawable IN/DE/DU/IV/TL lengths to g (at most 8); cls_of[t] = class of type t
 static bool chain_classes_add(const msim_range &r, ChainClasses &g, uint8_t cls_of[8]) {
     for (int t = 0; t < 8; t++) cls_of[t] = 0;
     for (int t : {MSIM_IN, MSIM_DE, MSIM_DU, MSIM_IV, MSIM_TL}) {
@@ -313,17 +313,20 @@ static bool chain_classes_add(const msim_range &r, ChainClasses &g, uint8_t cls_
         }
         if (!drawn) continue;                                // its length bounds do not matter (class 0 is never looked up)
         const int64_t w = r.max_len[t] - r.min_len[t] + 1;
-        if (w < 1 || w >= (1ll << 24)) return false;                 // value field of a table entry: 24 bits
+        if (w < 1 || w >= (1ll << 24)) return false;                 // value field of a table entry: 24 bits (23 beyond four classes: below)
         if (r.min_len[t] < 1 || r.max_len[t] >= (1ll << 30)) return false;   // keeps 0 <= stop < 2^32 - 1 without a check
         const uint32_t sh = (uint32_t)(32 - bit_length64((uint64_t)w));
         uint32_t k = 0;
         while (k < g.n && !(g.sh[k] == sh && g.width[k] == (uint32_t)w)) k++;
         if (k == g.n) {
-            if (g.n >= 4) return false;                              // a table entry's increment field: 63 << 2 < 256
+            if (g.n >= 8) return false;
             g.sh[k] = sh; g.width[k] = (uint32_t)w; g.n++;
         }
         cls_of[t] = (uint8_t)k;
     }
+    if (g.n > 4)                                                     // 8 slots per position: increments up to 63 << 3 take a 9th bit
+        for (uint32_t k = 0; k < g.n; k++)
+            if (g.width[k] >= (1u << chain_value_bits(3))) return false;
     return true;
 }
 
@@ -345,7 +348,7 @@ void accept_tables_host(const ChainClasses &cc, const uint32_t *words, size_t n_
             if (v < cc.width[k]) { nd = 1; nv = v; }
             else if (nd && nd < CHAIN_TABLE_REACH) nd++;
             else nd = 0;
-            T[(i << lg) + k] = (nd << lg) << 24 | (nd ? nv : 0u);
+            T[(i << lg) + k] = (nd << lg) << chain_value_bits(lg) | (nd ? nv : 0u);
         }
     }
 }
@@ -357,6 +360,7 @@ int ChainWalk::init(Ctx *c, const msim_range &r, uint64_t L, const ChainClasses 
     *this = ChainWalk{};
     n_words = nw;
     lg_rows = chain_lg_rows(cc);
+    vbits = chain_value_bits(lg_rows);
     for (int t = 0; t < 8; t++) {                          // ids outside the boundary pass: see types_ok
         const bool chain_type = t == MSIM_IN || t == MSIM_DE || t == MSIM_DU || t == MSIM_IV || t == MSIM_TL;
         const int64_t blk1 = 1 + P.block[t];
@@ -400,9 +404,9 @@ bool ChainWalk::types_ok(const uint8_t *type, size_t n, bool with_tl) {
         const int64_t a0 = p + next_add[t];                                                                    \
         const int64_t cap = (next_cap[t] & in_mask[t]) | (a0 & ~in_mask[t]);                                   \
         const uint32_t e = (T + row[t])[s_at];                         /* the one load of the chain */         \
-        const int64_t d0 = e >> 24;                                    /* slot increment as tabulated */        \
+        const int64_t d0 = e >> vb;                                    /* slot increment as tabulated */        \
         const int64_t dm = MSIM_CHAIN_TL ? draw_mask[t] : -1;          /* TLI draws nothing */                  \
-        const int64_t d = d0 & dm, v = (int64_t)(e & 0xffffff) & dm;   /* d: slot increment */                 \
+        const int64_t d = d0 & dm, v = (int64_t)(e & vm) & dm;         /* d: slot increment */                 \
         int64_t nb = a0 + v;                                                                                   \
         nb = nb > cap ? cap : nb;                                                                              \
         const int64_t s_next = s_at + d;                                                                       \
@@ -427,7 +431,8 @@ void ChainWalk::run(const uint32_t *pos, const uint8_t *type, size_t n, const ui
     size_t jj = j;
     int64_t s_at = (int64_t)ws, hi = blk_hi, bd = bad;
     const int64_t s_lim = (int64_t)(w_lim << lg_rows);
-    constexpr int64_t RUN = 32, RUN_SLOTS = RUN * 256;                // a candidate advances at most 63 << 2 slots
+    const uint32_t vb = vbits, vm = (1u << vbits) - 1u;
+    const int64_t RUN = 32, RUN_SLOTS = RUN * ((int64_t)64 << lg_rows);   // a candidate advances at most 63 << lg_rows slots
     while (jj < n && s_at < s_lim) {
         if (jj + RUN <= n && s_at + RUN_SLOTS <= s_lim) {
             for (const size_t je = jj + RUN; jj < je; jj++) MSIM_CHAIN_STEP();
@@ -445,7 +450,8 @@ void ChainWalk::run_tl(const uint32_t *pos, const uint8_t *type, size_t n, const
     size_t jj = j;
     int64_t s_at = (int64_t)ws, hi = blk_hi, bd = bad;
     const int64_t s_lim = (int64_t)(w_lim << lg_rows);
-    constexpr int64_t RUN = 32, RUN_SLOTS = RUN * 256;                // a candidate advances at most 63 << 2 slots
+    const uint32_t vb = vbits, vm = (1u << vbits) - 1u;
+    const int64_t RUN = 32, RUN_SLOTS = RUN * ((int64_t)64 << lg_rows);   // a candidate advances at most 63 << lg_rows slots
     while (jj < n && s_at < s_lim) {
         if (jj + RUN <= n && s_at + RUN_SLOTS <= s_lim) {
             for (const size_t je = jj + RUN; jj < je; jj++) MSIM_CHAIN_STEP();
@@ -809,7 +815,7 @@ bool multimix_prepare(const Ctx *c, uint64_t L, const msim_range *ranges, int n_
     if (!ms.gcc.n) { ms.gcc.n = 1; ms.gcc.sh[0] = 31; ms.gcc.width[0] = 1; }   // SNPs only: an unused placeholder class
     for (auto &cc : ms.cc) {                                          // every set looks the union's classes up
         cc.n = ms.gcc.n;
-        for (uint32_t k = 0; k < 4; k++) { cc.sh[k] = ms.gcc.sh[k]; cc.width[k] = ms.gcc.width[k]; }
+        for (uint32_t k = 0; k < 8; k++) { cc.sh[k] = ms.gcc.sh[k]; cc.width[k] = ms.gcc.width[k]; }
     }
     return true;
 }
@@ -1090,9 +1096,9 @@ int multimix_walk_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
                 if (p >= pw.drop_from[t]) { ch_stop[qa + x] = CHAIN_DROPPED; continue; }   // mutator.py:240-245
                 while (w >= t_lim()) if (!more()) return overflow();
                 const uint32_t e = T[(w << lg) + pw.row[t]];
-                const uint32_t inc = e >> 24;
+                const uint32_t inc = e >> pw.vbits;
                 if (!inc) return overflow();                         // no accepted draw in reach: the window ends here
-                int64_t s = p + pw.add[t] + (int64_t)(e & 0xffffff);
+                int64_t s = p + pw.add[t] + (int64_t)(e & ((1u << pw.vbits) - 1u));
                 s = s > pw.clamp[t] ? pw.clamp[t] : s;
                 ch_stop[qa + x] = (uint32_t)s;
                 hi = (t == MSIM_IN ? p : s) + 1 + P.block[t];

@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_accept_tables(const uint32_t *__restric
     const uint32_t end = min(n, i + CHAIN_TABLE_REACH);
     for (uint32_t q = i; q < end; q++) {
         const uint32_t v = mt_temper(raw[p0 + q]) >> sh;
-        if (v < width) { e = ((q - i + 1) << lg_rows) << 24 | v; break; }
+        if (v < width) { e = ((q - i + 1) << lg_rows) << chain_value_bits(lg_rows) | v; break; }
     }
     T[slot] = e;
 }
@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_accept_tables_ps(const uint32_t *__rest
     const uint32_t end = min(n, i + CHAIN_TABLE_REACH);
     for (uint32_t q = i; q < end; q++) {
         const uint32_t v = mt_temper(raw[p0 + q]) >> sh;
-        if (v < width) { e = ((q - i + 1) << lg_rows) << 24 | v; break; }
+        if (v < width) { e = ((q - i + 1) << lg_rows) << chain_value_bits(lg_rows) | v; break; }
     }
     T[slot] = e;
 }

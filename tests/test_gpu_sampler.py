@@ -654,3 +654,18 @@ def test_full_size_genome_gpu_sampler_vs_host_planner():
     assert hst["py_words"] == gst["py_words"] and hst["np_words"] == gst["np_words"]
     for (hm, hp), (gm, gp) in zip(hs, gs):
         assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
+
+
+def test_five_and_eight_randint_classes_vs_host():
+    """Five SV types with five different length widths on one range (SV-mix engine) and eight widths over the settings of
+    one contig (host-chain engine): 8 table slots per word position, 9-bit slot increments."""
+    L = 3_000_000
+    five = {3: (1, 9), 2: (1, 30), 5: (2, 120), 4: (5, 700), 6: (3, 50)}
+    chances = {1: 0.3, 3: 0.15, 2: 0.15, 5: 0.1, 4: 0.1, 6: 0.12, 7: 0.08}
+    st = _compare([(L, [_rate_range(0, L - 1, 0.01, chances, five)])], _params(titv=2.0), seed=(3, 4), host_chain=True)
+    assert st["contigs_svmix"] == 1
+    other = {3: (2, 70), 2: (1, 5), 5: (2, 14), 4: (5, 700), 6: (3, 50)}
+    ranges = [_rate_range(0, 999_999, 0.01, chances, five), _rate_range(1_000_000, 1_999_999, 0.012, chances, other),
+              _rate_range(2_000_000, L - 1, 0.01, {1: 0.5, 2: 0.5}, {2: (1, 30)})]
+    st = _compare([(L, ranges)], _params({"DE": 3, "TL": 4}, titv=1.0), seed=(5, 6), host_chain=True)
+    assert st["contigs_hostchain"] == 1

@@ -237,7 +237,9 @@ def test_refuses_what_belongs_to_the_host_planner():
     a, b = _range(0, 99_999, 0.01, C3_CHANCES, C3_LENS), _range(50_000, 150_000, 0.01, C3_CHANCES, C3_LENS)
     _both(L, [a, b], None, 1.0, (1, 1), expect_unsupported=True)                 # overlapping: dict semantics
     five = [_range(i * 30_000, i * 30_000 + 29_999, 0.01, {1: 0.5, 3: 0.5}, {3: (1, 10 + 7 * i)}) for i in range(5)]
-    _both(L, five, None, 1.0, (1, 1), expect_unsupported=True)                   # five randint classes
+    _both(L, five, None, 1.0, (1, 1))                                            # (five randint classes: wide tables, late round 3)
+    nine = [_range(i * 20_000, i * 20_000 + 19_999, 0.02, {1: 0.5, 3: 0.5}, {3: (1, 10 + 7 * i)}) for i in range(9)]
+    _both(L, nine, None, 1.0, (1, 1), expect_unsupported=True)                   # nine
 
 
 # ---------------------------------------------------------------------- translocations (mutator.py:267-316)
@@ -307,3 +309,23 @@ def test_random_layouts_with_translocations(case):
             ranges.append(r)
         at += length + int(rs.choice([0, 0, 1, 500]))
     _both(L, ranges, blocks, 1.0, (case + 3, case + 30))
+
+
+def test_five_to_eight_randint_classes_take_the_wide_tables():
+    """Five SV types with five different length widths (and more, over several settings objects of one contig): beyond four
+    classes the accept tables hold 8 slots per word position and the entries 9 bits of slot increment above 23 of value."""
+    L = 600_000
+    five = {3: (1, 9), 2: (1, 30), 5: (2, 120), 4: (5, 700), 6: (3, 50)}             # widths 9, 30, 119, 696, 48
+    chances = {1: 0.3, 3: 0.15, 2: 0.15, 5: 0.1, 4: 0.1, 6: 0.12, 7: 0.08}
+    ranges = [_range(0, 299_999, 0.02, chances, five), _range(300_000, L - 1, 0.03, chances, five)]
+    _both(L, ranges, {3: 3, 6: 4}, 2.0, (5, 6))
+    other = {3: (2, 70), 2: (1, 5), 5: (2, 14), 4: (5, 700), 6: (3, 50)}              # + 69, 5, 13: eight classes on the contig
+    ranges = [_range(0, 199_999, 0.02, chances, five), _range(200_000, 399_999, 0.03, chances, other),
+              _range(400_000, L - 1, 0.01, {1: 0.5, 2: 0.5}, {2: (1, 30)})]
+    _both(L, ranges, {5: 2}, 1.0, (7, 8))
+    ninth = {3: (1, 9), 2: (1, 30), 5: (2, 120), 4: (5, 700), 6: (1, 1000)}           # a ninth width: the host planner's
+    ranges = [_range(0, 199_999, 0.02, chances, five), _range(200_000, 399_999, 0.03, chances, other),
+              _range(400_000, L - 1, 0.01, chances, ninth)]
+    _both(L, ranges, {}, 1.0, (9, 10), expect_unsupported=True)
+    wide = {3: (1, 9), 2: (1, 30), 5: (2, 120), 4: (5, 700), 6: (1, 1 << 23)}          # 2^23 values do not fit beside 9 bits
+    _both(L, [_range(0, L - 1, 0.02, chances, wide)], {}, 1.0, (11, 12), expect_unsupported=True)
