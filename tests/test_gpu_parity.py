@@ -393,3 +393,48 @@ def test_svmix_lengths_beyond_table_entries_vs_oracle(tmp_path):
     spec = {"contigs": [{"defline": "wide lens", "length": 2_400_000, "bpl": 60, "seed": 21},
                         {"defline": "second", "length": 1_100_000, "bpl": 70, "seed": 22}]}
     _product_vs_oracle(tmp_path, spec, argv, 5, 6)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_it_mode_random_sweep_vs_oracle(seed, tmp_path):
+    """`mutation-simulator file it <rate>` on random contig sets (1-base and 3-base contigs, odd counts, lower case and
+    ambiguity codes in the input, rates from "no breakpoint" to "ValueError on the shorter contig") against the oracle's
+    restatement of it_mutator.py: _ms_it Fasta, BEDPE, warnings and the generator's position."""
+    import inputs as gin
+    from mutation_simulator_amd import __main__ as msa_main
+    rs = np.random.RandomState(500 + seed)
+    for it in range(6):
+        n = int(rs.randint(2, 10))
+        lengths = [int(rs.choice([1, 2, 3, 5, 40, 700, 9_000, 120_000, 400_000])) + int(rs.randint(0, 50)) * (rs.rand() < 0.7)
+                   for _ in range(n)]
+        spec = {"contigs": [{"defline": f"z{it}_{i} it fuzz", "length": int(L), "bpl": int(rs.choice([50, 60, 61, 80])),
+                             "seed": 7_000 * seed + 20 * it + i, "decorate": bool(rs.rand() < 0.4) and L > 2000}
+                            for i, L in enumerate(lengths)]}
+        rate = float(rs.choice([1e-7, 1e-4, 2e-3, 0.03, 0.3, 0.5]))
+        d = tmp_path / f"it{it}"
+        d.mkdir()
+        infile = gin.write_input(spec, d / "in.fa")
+        sp = int(rs.randint(0, 1 << 30))
+        random.seed(sp)
+        err = io.StringIO()
+        argv = ["-o", str(d / "out"), str(infile), "it", repr(rate)]
+        code = None
+        with contextlib.redirect_stderr(err), contextlib.redirect_stdout(io.StringIO()):
+            try:
+                msa_main.main(argv)
+            except SystemExit as e:                   # fewer than two usable contigs: ITNotEnoughAvailChromsError -> exit(1)
+                code = e.code
+        contigs = parse_fasta_bytes(infile.read_bytes())
+        usable = [c for c in contigs if len(c["bases"]) > 2]
+        if len(usable) < 2:
+            assert code == 1
+            continue
+        assert code is None, err.getvalue()
+        nxt = [random.getrandbits(32) for _ in range(4)]
+        o = orc.Oracle()
+        o.seed(sp, 0)
+        fa, bedpe, ws = o.it_pass(contigs, [rate] * len(contigs))
+        assert (d / "out_ms_it.fa").read_bytes() == fa
+        assert (d / "out_ms_it.bedpe").read_bytes() == bedpe
+        assert err.getvalue() == "".join(f"WARNING: {w}\n" for w in ws)
+        assert nxt == o.py_words32(4)
