@@ -236,6 +236,11 @@ int msim_host_free(msim_ctx *ctx, void *ptr);
  * n_bp = 0: a copy of a (__write_chrom_full, it_mutator.py:148-156; b is ignored).  The result counts as applied:
  * msim_fetch_sequence(_framed), msim_result_sizes and msim_result_checksum read it; it has no records.              */
 int msim_splice_contigs(msim_ctx *ctx, int a, int b, uint64_t n_bp, const uint64_t *bp_a, const uint64_t *bp_b, int *contig);
+/* sample_with_minimum_distance(start, stop, k, d) (util.py:93-109) on the context's CPython stream: the breakpoints of one
+ * contig (it_mutator.py:96-119 calls it with (1, len, k, 1)).  setsize: CPython's 21 + 4^ceil(log4(3k)) for k > 5, else 21
+ * (the caller evaluates the float expression, as for msim_range).  out: k ascending positions.  Works on a host-only
+ * context.  MSIM_ERR_VALUE: "Sample larger than population or is negative" -- nothing was drawn.                       */
+int msim_sample_min_distance(msim_ctx *ctx, int64_t start, int64_t stop, int64_t k, int64_t d, int64_t setsize, int64_t *out);
 
 /* ---- many small contigs in one pass ------------------------------------------------------------------------------- */
 /* mutate()'s loop body (mutator.py:111-141) for a run of SMALL contigs at once -- assemblies with thousands of scaffolds:

@@ -122,6 +122,7 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
 // Mutation.stop, or CHAIN_DROPPED for a candidate that is blocked / dropped.  Valid when
 // block[SN] == min(block): an SNP then never blocks a successor, so SNPs cannot influence the chain.
 constexpr uint32_t CHAIN_DROPPED = 0xffffffffu;
+int sample_min_distance_host(Ctx *c, int64_t start, int64_t stop, int64_t k, int64_t d, int64_t setsize, int64_t *out);
 int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
                         const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept,
                         long long *len_delta);

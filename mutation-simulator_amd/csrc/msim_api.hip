@@ -788,6 +788,20 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
     return MSIM_OK;
 }
 
+int msim_sample_min_distance(msim_ctx *p, int64_t start, int64_t stop, int64_t k, int64_t d, int64_t setsize, int64_t *out) {
+    CTX_FLUSHED(c, p)
+    if (!c || (!out && k > 0)) return MSIM_ERR_ARG;
+    if (!c->host_only) {
+        int rc = drain(c);
+        if (rc) return rc;
+        if (c->gpu && (rc = gpu_plan_sync_to_host(c, c->gpu))) return rc;      // continue from wherever the device streams stand
+    }
+    const uint64_t w0 = c->py.words;
+    const int rc = sample_min_distance_host(c, start, stop, k, d, setsize, out);
+    c->t.py_words += c->py.words - w0;
+    return rc;
+}
+
 int msim_splice_contigs(msim_ctx *p, int a, int b, uint64_t n_bp, const uint64_t *bp_a, const uint64_t *bp_b, int *contig) {
     CTX_FLUSHED(c, p)
     if (!c || !contig || (n_bp && (!bp_a || !bp_b))) return MSIM_ERR_ARG;

@@ -239,6 +239,17 @@ int sample_sorted(Ctx *c, HostMT &g, int64_t n, int64_t k, int64_t setsize, std:
 
 }  // namespace
 
+// util.py:93-109 sample_with_minimum_distance(start, stop, k, d) on the context's CPython stream: sample(range(start, stop -
+// (k - 1) * d), k), sorted, the r-th smallest moved up by r * d.  (The IT pass draws its breakpoints this way,
+// it_mutator.py:96-119: a quarter of a million per pair of human chromosomes at rate 0.001.)
+int sample_min_distance_host(Ctx *c, int64_t start, int64_t stop, int64_t k, int64_t d, int64_t setsize, int64_t *out) {
+    std::vector<int64_t> s;
+    const int rc = sample_sorted(c, c->py, (stop - (k - 1) * d) - start, k, setsize, s);
+    if (rc) return rc;
+    for (int64_t r = 0; r < k; r++) out[r] = start + s[(size_t)r] + d * r;
+    return MSIM_OK;
+}
+
 int chain_boundary_host(Ctx *c, const msim_range &r, uint64_t L, const uint32_t *pos, const uint8_t *type, size_t n,
                         const uint32_t *words, size_t n_words, uint32_t *stop, size_t *consumed, size_t *kept,
                         long long *len_delta) {

@@ -112,6 +112,7 @@ SYMBOLS = [
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
     ("msim_splice_contigs", C.c_int, [_VP, C.c_int, C.c_int, C.c_uint64, _U64P, _U64P, _IP]),
+    ("msim_sample_min_distance", C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP]),
     ("msim_host_alloc", C.c_int, [_VP, C.c_uint64, C.POINTER(_VP)]),
     ("msim_host_free", C.c_int, [_VP, _VP]),
     ("msim_batch_run", C.c_int, [_VP, C.POINTER(BatchContig), C.c_int]),
@@ -272,6 +273,13 @@ class Engine:
         cid = C.c_int()
         self._check(self.lib.msim_add_contig_text(self.h, _ptr(body), body.shape[0], n_bases, lenc, lenb, C.byref(cid)))
         return cid.value
+
+    def sample_min_distance(self, start: int, stop: int, k: int, d: int, setsize: int) -> np.ndarray:
+        """``sample_with_minimum_distance`` (util.py:93-109) on this context's CPython stream; ValueError as CPython's."""
+        out = np.empty(max(int(k), 0), dtype=np.int64)
+        self._check(self.lib.msim_sample_min_distance(self.h, int(start), int(stop), int(k), int(d), int(setsize),
+                                                      C.c_void_p(out.ctypes.data)))
+        return out
 
     def splice_contigs(self, a: int, b: int, bp_a, bp_b) -> int:
         """Interchromosomal translocation of contig ``a`` with partner ``b`` (it_mutator.py:121-146): a new contig made of

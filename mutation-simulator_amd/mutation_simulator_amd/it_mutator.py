@@ -13,18 +13,39 @@ import random
 import numpy as np
 
 from . import _ffi
+from ._ffi import Engine as _HostEngine            # (the host-only context that samples: no GPU involved)
 from .bedpe_writer import BedpeWriter
 from .fasta_writer import FastaWriter
 from .util import print_warning
 
 
+NATIVE_SAMPLE_FROM = 512          # breakpoints per contig from which libmsim's sampler takes over (same draws, ~100x faster)
+
+
 def sample_with_minimum_distance(start: int, stop: int, k: int, d: int) -> np.ndarray:
     """k sorted positions in [start, stop) that keep at least d between neighbours (reference util.py:93-109): a plain
     ``random.sample`` of a range shortened by (k - 1) * d, sorted, the r-th smallest moved up by r * d.  Raises
-    CPython's own ValueError when the range is too short for k."""
-    picked = random.sample(range(start, stop - (k - 1) * d), k)
-    out = np.sort(np.asarray(picked, dtype=np.int64))
-    return out + d * np.arange(k, dtype=np.int64)
+    CPython's own ValueError when the range is too short for k.
+
+    A handful of breakpoints are drawn by CPython itself.  A pair of human chromosomes at rate 0.001 gets a quarter of a
+    million per contig -- a second of ``random.sample`` each: those go through ``msim_sample_min_distance`` (libmsim's
+    host sampler on a host-only context: the generator's state goes in, the same words are consumed, the state comes
+    back; pinned against CPython in tests/test_it_host.py)."""
+    if k < NATIVE_SAMPLE_FROM:
+        picked = random.sample(range(start, stop - (k - 1) * d), k)
+        out = np.sort(np.asarray(picked, dtype=np.int64))
+        return out + d * np.arange(k, dtype=np.int64)
+    from .mutator import sample_setsize
+    st = random.getstate()
+    eng = _HostEngine(device=-1)
+    try:
+        eng.set_mt_state(0, np.array(st[1][:624], dtype=np.uint32), st[1][624])
+        out = eng.sample_min_distance(start, stop, k, d, sample_setsize(k))      # (ValueError: nothing was drawn)
+        mt, pos = eng.get_mt_state(0)
+    finally:
+        eng.close()
+    random.setstate((st[0], tuple(int(x) for x in mt) + (int(pos),), st[2]))
+    return out
 
 
 class ITMutator:

@@ -153,3 +153,26 @@ def test_sample_with_minimum_distance_is_the_references():
     random.seed(3)
     with pytest.raises(ValueError):
         sample_with_minimum_distance(1, 100, 51, 1)
+
+
+@pytest.mark.parametrize("start,stop,k,d", [(1, 2_000_000, 50_000, 1), (1, 3_000, 1_400, 1), (1, 250_000, 600, 1),
+                                            (0, 90_000, 30_000, 2), (1, 5_000_000, 512, 1)])
+def test_native_breakpoint_sampler_equals_cpython(start, stop, k, d, monkeypatch):
+    """Above NATIVE_SAMPLE_FROM breakpoints the draws go through msim_sample_min_distance (set path with its duplicate
+    handling, pool path for dense samples): same positions, same stream position as CPython's own random.sample."""
+    from mutation_simulator_amd import it_mutator
+    assert k >= it_mutator.NATIVE_SAMPLE_FROM
+    random.seed(1234 + k)
+    got = it_mutator.sample_with_minimum_distance(start, stop, k, d)
+    after = [random.getrandbits(32) for _ in range(4)]
+    monkeypatch.setattr(it_mutator, "NATIVE_SAMPLE_FROM", 1 << 62)
+    random.seed(1234 + k)
+    want = it_mutator.sample_with_minimum_distance(start, stop, k, d)
+    assert got.tolist() == want.tolist()
+    assert after == [random.getrandbits(32) for _ in range(4)]
+    monkeypatch.undo()
+    random.seed(5)
+    before = random.getstate()
+    with pytest.raises(ValueError, match="Sample larger than population or is negative"):
+        it_mutator.sample_with_minimum_distance(1, 2_000, 1_001, 1)
+    assert random.getstate() == before               # nothing was drawn
