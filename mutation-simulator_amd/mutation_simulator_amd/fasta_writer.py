@@ -35,7 +35,10 @@ class MappedRegion:
                 # 40-50 ms per 200 MB on tmpfs, fallocate 9 (and the copy into the allocated span 15)
                 try:
                     os.posix_fallocate(fd, self.pos, self.nbytes)
-                except OSError:
+                except OSError as e:
+                    import errno
+                    if e.errno not in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL):
+                        raise                   # (no space left: better an exception here than a SIGBUS in the copy)
                     os.ftruncate(fd, self.pos + self.nbytes)
             start = self.pos - self.pos % mmap.ALLOCATIONGRANULARITY
             self._map = mmap.mmap(fd, self.pos + self.nbytes - start, access=mmap.ACCESS_WRITE, offset=start)
