@@ -489,16 +489,17 @@ def main():
         }
         if world == 1:
             line["step_roofline"] = step_roofline(st, dt)
-    def sharded_numbers(dt_sharded):
+    def sharded_numbers(dt_sharded, workload=None):
         """One genome over the N GPUs: throughput without and with the exchange step north_star names (every peer sends its
         mutated contigs to rank 0 over its own xGMI link)."""
+        workload = workload or a.workload
         out = None
         if rank == 0:
             out = {"value": round(sum(lengths) * a.steps / dt_sharded / 1e6, 3), "unit": "Mbases/s", "scaling": "strong",
                    "ms_per_step": round(dt_sharded / a.steps * 1e3, 3),
                    "what": f"ONE genome, contigs sharded over {world} GPUs (LPT), results left in HBM on the owning GPU"}
         if comm is not None:
-            dtg, _ = measure(a.workload, a.steps, 1, gather=True, owned=parts[rank], step_seed=42)
+            dtg, _ = measure(workload, a.steps, 1, gather=True, owned=parts[rank], step_seed=42)
             if rank == 0:
                 out["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
                                       "ms_per_step": round(dtg / a.steps * 1e3, 3), "transport": comm.describe()}
@@ -521,6 +522,14 @@ def main():
         sh = sharded_numbers(dts_)
         if rank == 0:
             line["one_genome_sharded"] = sh
+        if a.workload == "c2" and not a.no_secondary:
+            # BASELINE configs[4] as written: the full SV mix (c3) on ONE genome, contigs sharded over the N GPUs, RCCL gather
+            dt4, st4 = measure("c3", a.steps, 2, owned=parts[rank], step_seed=42)
+            sh4 = sharded_numbers(dt4, "c3")
+            if rank == 0:
+                sh4["metric"] = WORKLOADS["c3"]["metric"]
+                sh4["plan_engines_rank0"] = engines_of(st4, a.steps)
+                line["configs4_sv_mix_sharded"] = sh4
     # What N GPUs can give ONE genome (strong scaling): the chain of both MT19937 streams runs over every contig on every
     # rank whatever N is; only emission + APPLY of the owned contigs shrink.  Measured, not modelled: a step that owns
     # nothing (msim_plan_chain for all 24 contigs) against the full step.
