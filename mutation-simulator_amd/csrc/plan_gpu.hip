@@ -167,10 +167,31 @@ GpuPlan *gpu_plan_create() { return new GpuPlan(); }
 // registered with the runtime.  Measured on the bench box per GiB: hipHostMalloc 182 ms + 90 ms to free; aligned_alloc +
 // MADV_HUGEPAGE + hipHostRegister 43 ms, unregister + free 37 ms -- and copies are just as asynchronous and as fast
 // (57 GB/s; into plain touched memory the "async" copy blocks the caller).  A 1 Gb contig needs 1.7 GB of them at once.
+// (mapped, not malloc'ed: a freed block must leave the address space -- glibc would hand a heap block to the next caller
+//  while the runtime may still know the range as registered.  The size sits in a header page in front of the block.)
+constexpr size_t STAGE_HUGE = (size_t)2 << 20;
+static void *host_stage_alloc(size_t sz, hipError_t *err) {
+    *err = hipSuccess;
+    const size_t total = sz + 2 * STAGE_HUGE;              // room to align the block and for the header in front of it
+    void *raw = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (raw == MAP_FAILED) return nullptr;
+    uint8_t *q = reinterpret_cast<uint8_t *>(((uintptr_t)raw + STAGE_HUGE + STAGE_HUGE - 1) & ~(uintptr_t)(STAGE_HUGE - 1));
+    size_t *hdr = reinterpret_cast<size_t *>(q - 4096);
+    hdr[0] = (size_t)(uintptr_t)raw;
+    hdr[1] = total;
+#ifdef MADV_HUGEPAGE
+    (void)madvise(q, sz, MADV_HUGEPAGE);
+#endif
+    *err = hipHostRegister(q, sz, hipHostRegisterDefault);
+    if (*err != hipSuccess) { munmap(raw, total); return nullptr; }
+    return q;
+}
 static void host_stage_free(void *p) {
     if (!p) return;
+    (void)hipDeviceSynchronize();                          // (what hipHostFree does by itself: no copy may still use the block)
     (void)hipHostUnregister(p);
-    free(p);
+    const size_t *hdr = reinterpret_cast<const size_t *>(static_cast<uint8_t *>(p) - 4096);
+    munmap(reinterpret_cast<void *>((uintptr_t)hdr[0]), hdr[1]);
 }
 
 void gpu_plan_destroy(GpuPlan *g) {
@@ -758,15 +779,10 @@ static int grow_host(Ctx *c, void **p, size_t *cap, size_t want_bytes) {
     if (*cap >= want_bytes) return MSIM_OK;
     host_stage_free(*p);
     *p = nullptr; *cap = 0;
-    const size_t huge = (size_t)2 << 20;
-    const size_t sz = (want_bytes + want_bytes / 4 + huge) & ~(huge - 1);
-    void *q = aligned_alloc(huge, sz);
-    if (!q) return fail(c, MSIM_ERR_NOMEM, "host staging buffer");
-#ifdef MADV_HUGEPAGE
-    (void)madvise(q, sz, MADV_HUGEPAGE);
-#endif
-    const hipError_t e = hipHostRegister(q, sz, hipHostRegisterDefault);
-    if (e != hipSuccess) { free(q); return hip_fail(c, e, "hipHostRegister(host staging buffer)"); }
+    const size_t sz = (want_bytes + want_bytes / 4 + STAGE_HUGE) & ~(STAGE_HUGE - 1);
+    hipError_t e;
+    void *q = host_stage_alloc(sz, &e);
+    if (!q) return e != hipSuccess ? hip_fail(c, e, "hipHostRegister(host staging buffer)") : fail(c, MSIM_ERR_NOMEM, "host staging buffer");
     *p = q;
     *cap = sz;
     return MSIM_OK;

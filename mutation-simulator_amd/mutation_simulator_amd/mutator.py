@@ -21,6 +21,7 @@ All floating-point expressions of the path are evaluated here with the reference
 """
 from __future__ import annotations
 
+import os
 import random
 import sys
 import time
@@ -211,7 +212,11 @@ def import_python_streams(engine: "_ffi.Engine") -> None:
 
 
 REPLANNED_CONTIGS = 0            # contigs that went through the host planner after a device window overflow (diagnostic)
-BATCH_MAX_LEN = 200_000          # contigs up to this length are batched (below every device PLAN engine's threshold)
+BATCH_MAX_LEN = int(os.environ.get("MSIM_BATCH_MAX_LEN", 200_000))   # contigs up to this length are batched (below every device PLAN engine's threshold)
+BATCH_SPARSE_MAX_LEN = 4_000_000                 # ... longer ones too while they hold few candidates:
+BATCH_SPARSE_MAX_CANDIDATES = 8_000              #     a contig on its own costs ~0.6 ms of launches and round trips whatever its size, the batch's
+                                                 #     host planner ~40 ns per candidate (measured, -sn 0.01: 300 kb contigs 480 -> 1150 Mbases/s
+                                                 #     in batches, 1 Mb contigs the same either way, 3 Mb contigs 1300 vs 960)
 BATCH_MAX_BASES = 256 << 20      # bases per batch
 BATCH_MAX_CONTIGS = 16384
 
@@ -250,8 +255,13 @@ class Mutator:
 
     def _batchable(self, chrom) -> bool:
         rec = self._fasta[chrom.number]
-        return (getattr(rec, "uniform", False) and 0 < len(rec) <= BATCH_MAX_LEN
-                and self._fasta.faidx.index[rec.name].lenc > 0)
+        if not (getattr(rec, "uniform", False) and 0 < len(rec) <= BATCH_SPARSE_MAX_LEN
+                and self._fasta.faidx.index[rec.name].lenc > 0):
+            return False
+        if len(rec) <= BATCH_MAX_LEN:
+            return True
+        table = plan_table(chrom)                      # a longer contig: batched while it holds few candidates
+        return (int(table["k"].sum()) if len(table) else 0) <= BATCH_SPARSE_MAX_CANDIDATES
 
     def _warn_empty(self, chrom):
         if not self._args.ignore_warnings:
@@ -425,7 +435,14 @@ class Mutator:
         if (isinstance(chroms, StdChromosomes) and tab is not None and len(tab) == n
                 and type(self)._batchable is Mutator._batchable):
             lens = tab["n_bases"].astype(np.int64)
-            ok = ((tab["flags"] & _ffi.FASTA_NONUNIFORM) == 0) & (lens > 0) & (lens <= BATCH_MAX_LEN) & (tab["lenc"] > 0)
+            ms = chroms.std
+            rate_sum = 0.0
+            if ms.has_mutations:
+                range_descriptor(type("RD", (), {"start": 0, "stop": 0, "mutation_settings": ms})())      # (fills the settings cache)
+                rate_sum = float(_SETTINGS_CACHE[_settings_key(ms)][1])
+            k = (lens.astype(np.float64) * rate_sum).astype(np.int64)       # int(((stop - start) + 1) * sum(rates))  mutator.py:225
+            small = (lens <= BATCH_MAX_LEN) | ((lens <= BATCH_SPARSE_MAX_LEN) & (k <= BATCH_SPARSE_MAX_CANDIDATES))
+            ok = ((tab["flags"] & _ffi.FASTA_NONUNIFORM) == 0) & (lens > 0) & small & (tab["lenc"] > 0)
         else:
             lens = np.fromiter((len(self._fasta[c.number]) for c in chroms), dtype=np.int64, count=n)
             ok = np.fromiter((self._batchable(c) for c in chroms), dtype=bool, count=n)

@@ -3,6 +3,7 @@ fields, header text and line format; ``write_raw`` takes pre-rendered record lin
 renderer (``msim_render_vcf``) so 30 M records do not go through Python objects."""
 from __future__ import annotations
 
+import os
 from datetime import datetime
 
 
@@ -58,7 +59,6 @@ class VcfWriter:
     def close(self):
         out = getattr(self, "_out", None)
         if out is not None and not out.closed:
-            import os
             ahead, self._ahead = getattr(self, "_ahead", None), None
             if ahead is not None:
                 ahead.finish(out)
