@@ -172,6 +172,8 @@ def one_step(eng, sim, cids, my_contigs, seed=42, plan_descriptors=None, lengths
 C3_FLAGS = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-demin", "1", "-demax", "50",
             "-du", "0.0005", "-dumin", "50", "-dumax", "500", "-iv", "0.0005", "-ivmin", "50", "-ivmax", "500"]
 
+README_FLAGS = ["-in", "0.01", "-de", "0.01", "-du", "0.01", "-iv", "0.01", "-tl", "0.01"]     # + -sn 0.01: README.md:430-446
+
 WORKLOADS = {
     "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp",
            "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01"},
@@ -182,6 +184,9 @@ WORKLOADS = {
     "c4sv": {"mode": "RMT", "what": "RMT mode, the configs[3] gene-blocking file with the configs[2] SV mix as its std line "
                                     "(every gap between two blocked genes draws SN/IN/DE/DU/IV; hot/cold ranges keep their own settings)",
              "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT gene blocks + SV std line"},
+    "readme": {"mode": "ARGS", "what": "the reference README's benchmark flags: -sn -in -de -du -iv -tl 0.01 each, default lengths "
+                                       "(180 M candidates per 3 Gb, translocations linked per contig)",
+               "kernel": "msim::k_rewrite<140|1024>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS every type at 0.01"},
 }
 
 
@@ -190,6 +195,8 @@ def build_settings(workload: str, lengths):
         return workload_settings(lengths)
     if workload == "c3":
         return workload_settings(lengths, snp=0.005, titv=1.0, extra=C3_FLAGS)
+    if workload == "readme":
+        return workload_settings(lengths, snp=0.01, titv=1.0, extra=README_FLAGS)
     if workload == "c4sv":
         return workload_settings_rmt(lengths, c4_rmt_text(lengths, std_line=C4_STD_SV))
     return workload_settings_rmt(lengths, c4_rmt_text(lengths))
@@ -352,7 +359,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-3 / config-4 secondary measurements")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4sv"], default="c2",
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c4sv", "readme"], default="c2",
                     help="c2 = BASELINE configs[1] (headline: -sn 0.01 -titv 2.0); c3 = configs[2], the full SV mix; "
                          "c4 = configs[3], RMT mode with ~40 k blocked ranges + hot/cold spots; c4sv = the c4 file with the "
                          "c3 SV mix as its std line")

@@ -130,12 +130,12 @@ def test_config4_fixture_scaled_vs_oracle(tmp_path):
 
 
 # ---------------------------------------------------------------------- BASELINE configs at 3 Gb, straight against the oracle
-def _full_genome_vs_oracle(workload, engines):
+def _full_genome_vs_oracle(workload, engines, total=3_000_000_000):
     """Every contig of the 3 Gb bench genome through PLAN + APPLY + device text, compared per contig with the ORACLE's
     Fasta body and VCF lines (SHA-256; memory stays at one contig).  The oracle walks both MT19937 streams sequentially
     across all 24 contigs, so one wrong stream cut anywhere shows up in every later contig."""
     import hashlib
-    lengths = bench.contig_lengths(3_000_000_000)
+    lengths = bench.contig_lengths(total)
     sim = bench.build_settings(workload, lengths)
     dump = dump_sim(sim)
     eng = _ffi.Engine(0)
@@ -194,6 +194,13 @@ def test_config4_full_genome_vs_oracle():
 def test_config4sv_full_genome_vs_oracle():
     """The configs[3] file with the configs[2] SV mix as its std line (host-chain engine)."""
     _full_genome_vs_oracle("c4sv", {"contigs_hostchain": 24})
+
+
+def test_readme_flags_720mb_vs_oracle():
+    """The reference README's own benchmark flags (every type at 0.01, translocations included) on the bench genome scaled to
+    720 Mb: 43 M candidates, TL / TLI on the boundary walk of the SV-mix engine, __link_tls per contig over the device's
+    words, TLI records with linked spans -- per contig against the oracle, both streams to the end."""
+    _full_genome_vs_oracle("readme", {"contigs_svmix": 24}, total=720_000_000)
 
 
 def test_config3_full_genome_length_identity():
