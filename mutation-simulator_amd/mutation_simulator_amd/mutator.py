@@ -241,11 +241,21 @@ class Mutator:
         self.stats: dict = {}
 
     def close(self):
-        self._fasta_writer.close()
-        self._vcf_writer.close()
-        if self._own_engine and self._engine is not None:
-            self._engine.close()
-            self._engine = None
+        # the context's teardown (device buffers, registered staging memory) beside the writers' (unmapping the output files)
+        eng, self._engine = (self._engine if self._own_engine else None), None
+        side = None
+        if eng is not None and os.environ.get("MSIM_SERIAL_CLOSE") != "1":
+            import threading
+            side = threading.Thread(target=eng.close, name="msim-destroy")
+            side.start()
+        try:
+            self._fasta_writer.close()
+            self._vcf_writer.close()
+        finally:
+            if side is not None:
+                side.join()
+            elif eng is not None:
+                eng.close()
 
     def __del__(self):
         try:
