@@ -3,7 +3,7 @@
 # are copied into profiles/ (r03_*) afterwards.  Counters in passes of their own (never with a trace domain).
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3ev; mkdir -p $O
-for w in c2 c3 c4 c4sv; do
+for w in c2 c3 c4 c4sv readme; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/ks_$w -o ks -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/ks_$w.log 2>&1
   python3 profiles/summarize_rocprof.py stats $O/ks_$w/ks_results.db > $O/kernel_stats_$w.txt 2>&1
   rm -rf $O/ks_$w
@@ -23,7 +23,7 @@ python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- args -sn 0.01 -in 0.01 -de 0.01 -du 0.01 -iv 0.01 -tl 0.01 >> $O/cli_profile.txt 2>&1
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- it 0.0001 >> $O/cli_profile.txt 2>&1
 # the README's performance table (README.md:430-446: one random sequence of 1 / 10 / 100 / 1000 Mbp, the flags above), one process each
-(for mb in 1 10 100 1000; do TMPDIR=/dev/shm python3 mutation-simulator_amd/tools/cli_profile.py --mb $mb --contigs 1 --top 1 -- args -sn 0.01 -in 0.01 -de 0.01 -du 0.01 -iv 0.01 -tl 0.01 2>&1 | grep "CLI wall"; done) > $O/readme_table.txt 2>&1
+(for mb in 1 10 100 1000; do TMPDIR=/dev/shm python3 mutation-simulator_amd/tools/cli_profile.py --mb $mb --contigs 1 --top 1 -- args -sn 0.01 -in 0.01 -de 0.01 -du 0.01 -iv 0.01 -tl 0.01 2>&1 | grep "CLI wall"; done) > $O/readme_table.txt 2>&1      # (lines: 1, 10, 100, 1000 Mbp; profiles/r03_readme_table.txt adds the labels)
 (MSIM_BATCH_PROF=1 python3 mutation-simulator_amd/tools/scaffold_bench.py 20000 10000; python3 mutation-simulator_amd/tools/scaffold_bench.py 200000 1000) > $O/scaffold_bench.txt 2>&1
 timeout 100 python3 mutation-simulator_amd/tools/apply_microbench.py 10 > $O/apply_microbench.txt 2>&1
 head -30 $O/kernel_stats_c4sv.txt
