@@ -410,20 +410,7 @@ def main():
     # contig numbering is global -- 288 GB of HBM make the replica free)
     cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
     eng.sync()
-    comm, comm_error = None, None
-    if world > 1:
-        from mutation_simulator_amd.gather import Communicator
-        try:
-            comm = Communicator(eng, rank, world, dist)
-        except Exception as e:  # noqa: BLE001  (no RCCL / duplicate GPUs ...): the sharded step is still measured
-            comm_error = f"{type(e).__name__}: {e}"
-        flags = [None] * world
-        dist.all_gather_object(flags, comm_error)
-        if any(flags):                                   # every rank takes the same branch
-            comm_error = next(f for f in flags if f)
-            if comm is not None:
-                comm.close()
-            comm = None
+    comm, comm_error = None, None                       # the RCCL communicator: opened LAST (gather phase at the end of main)
 
     def barrier():
         eng.sync()
@@ -496,6 +483,8 @@ def main():
         }
         if world == 1:
             line["step_roofline"] = step_roofline(st, dt)
+    gather_jobs = []                                    # (workload, its dict in the line): measured in the gather phase
+
     def sharded_numbers(dt_sharded, workload=None):
         """One genome over the N GPUs: throughput without and with the exchange step north_star names (every peer sends its
         mutated contigs to rank 0 over its own xGMI link)."""
@@ -505,19 +494,15 @@ def main():
             out = {"value": round(sum(lengths) * a.steps / dt_sharded / 1e6, 3), "unit": "Mbases/s", "scaling": "strong",
                    "ms_per_step": round(dt_sharded / a.steps * 1e3, 3),
                    "what": f"ONE genome, contigs sharded over {world} GPUs (LPT), results left in HBM on the owning GPU"}
-        if comm is not None:
-            dtg, _ = measure(workload, a.steps, 1, gather=True, owned=parts[rank], step_seed=42)
-            if rank == 0:
-                out["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
-                                      "ms_per_step": round(dtg / a.steps * 1e3, 3), "transport": comm.describe()}
-        elif rank == 0:
-            out["with_gather"] = {"error": comm_error}
+        if rank == 0:
+            out["with_gather"] = {"error": "not measured: the RCCL phase did not complete"}      # (filled in by the gather phase)
+        gather_jobs.append((workload, out))
         return out
 
     if strong:
         sh = sharded_numbers(dt)
         if rank == 0:
-            line["with_gather"] = sh["with_gather"]
+            line["with_gather"] = sh["with_gather"]          # (replaced by the gather phase at the end)
         # what DOES scale: N independent replicas (one whole genome per GPU, own seeds) -- the weak-scaling number
         dtw, _ = measure(a.workload, a.steps, 1, owned=everything, step_seed=42 + rank)
         if rank == 0:
@@ -568,11 +553,62 @@ def main():
         except Exception as e:  # noqa: BLE001  (no tmpfs / disk space: the kernels' numbers above still stand)
             sec["e2e"] = {"error": f"{type(e).__name__}: {e}"}
         line["secondary"] = sec
-    if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload)      # bounded sample: ~6-10 s of CPU work
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload)      # bounded sample: ~6-10 s of CPU work
+    printed = [False]
+
+    def emit_line():
+        if rank == 0 and not printed[0]:
+            printed[0] = True
+            if strong and gather_jobs:
+                line["with_gather"] = gather_jobs[0][1]["with_gather"]
+            sys.stdout.flush()
+            os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+    # ---- the RCCL phase: LAST, and under a watchdog.  Everything above needs no communicator; the gather over xGMI is the one
+    # part of this file that has never run on more than one GPU (1-GPU boxes only), so a hang in ncclCommInitRank or in the
+    # grouped send / recv must not cost the line: when the limit passes, rank 0 prints what it has and every rank leaves.
+    if world > 1 and gather_jobs:
+        import threading
+        limit = float(os.environ.get("MSIM_BENCH_RCCL_TIMEOUT", "240"))
+
+        def on_timeout():
+            if rank == 0:
+                for _, out in gather_jobs:
+                    if "value" not in out["with_gather"]:
+                        out["with_gather"] = {"error": f"the RCCL phase did not finish within {limit:.0f} s"}
+                emit_line()
+            os._exit(0)
+        watchdog = threading.Timer(limit, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
+        from mutation_simulator_amd.gather import Communicator
+        try:
+            comm = Communicator(eng, rank, world, dist)
+        except Exception as e:  # noqa: BLE001  (no RCCL / duplicate GPUs ...)
+            comm_error = f"{type(e).__name__}: {e}"
+        flags = [None] * world
+        dist.all_gather_object(flags, comm_error)
+        if any(flags):                                   # every rank takes the same branch
+            comm_error = next(f for f in flags if f)
+            if comm is not None:
+                comm.close()
+            comm = None
+        for workload, out in gather_jobs:
+            if comm is not None:
+                dtg, _ = measure(workload, a.steps, 1, gather=True, owned=parts[rank], step_seed=42)
+                if rank == 0:
+                    out["with_gather"] = {"value": round(sum(lengths) * a.steps / dtg / 1e6, 3), "unit": "Mbases/s",
+                                          "ms_per_step": round(dtg / a.steps * 1e3, 3), "transport": comm.describe()}
+            elif rank == 0:
+                out["with_gather"] = {"error": comm_error}
+        watchdog.cancel()
+    emit_line()
+    if world > 1:                                        # (the same for the teardown: the line is out, nothing may hang now)
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
     if comm is not None:
         comm.close()
     eng.close()
