@@ -144,36 +144,105 @@ class ITMutator:
             return eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
         return eng.add_contig(rec.bases)
 
+    def _untouched_runs(self, n: int, breakpoints: dict) -> list:
+        """[a, b) spans of >= 2 consecutive contigs that keep their sequence and are small: an assembly's thousands of
+        scaffolds below any breakpoint go through libmsim in ONE pass per span (msim_batch_run with no ranges: a contig on
+        its own costs ~0.4 ms of launches and round trips).  Needs the loader's index table; [] otherwise."""
+        from .mutator import BATCH_MAX_BASES, BATCH_MAX_CONTIGS, BATCH_MAX_LEN
+        tab = getattr(self._fasta, "index_table", None)
+        if tab is None or len(tab) != n or getattr(self._fasta, "text", None) is None:
+            return []
+        lens = tab["n_bases"].astype(np.int64)
+        ok = ((tab["flags"] & _ffi.FASTA_NONUNIFORM) == 0) & (lens > 0) & (lens <= BATCH_MAX_LEN) & (tab["lenc"] > 0)
+        if breakpoints:
+            ok[np.fromiter(breakpoints.keys(), dtype=np.int64)] = False
+        cum = np.concatenate(([0], np.cumsum(lens)))
+        edges = np.flatnonzero(np.diff(np.concatenate(([0], ok.astype(np.int8), [0]))))
+        out = []
+        for a, b in zip(edges[0::2].tolist(), edges[1::2].tolist()):
+            i = a
+            while b - i >= 2:
+                j = min(int(np.searchsorted(cum, cum[i] + BATCH_MAX_BASES, side="right")) - 1, b, i + BATCH_MAX_CONTIGS)
+                if j - i < 2:
+                    break
+                out.append((i, j))
+                i = j
+        return out
+
+    def _copy_run(self, eng, a: int, b: int):
+        """Contigs [a, b) as they are (upper-cased, re-wrapped at their own line width), each with its defline TWICE -- the
+        reference's __write_chrom_full writes the header again (it_mutator.py:148-156 after :199-202)."""
+        from .mutator import params_descriptor
+        fa = self._fasta
+        tab = fa.index_table[a:b]
+        n = b - a
+        text = fa.text
+        heads = [text[int(h0):int(h1)].tobytes() for h0, h1 in zip(tab["h0"], tab["h1"])]
+        blob = np.frombuffer(b"".join(h + b"\n>" + h for h in heads), dtype=np.uint8)
+        hlen = np.fromiter((2 * len(h) + 2 for h in heads), dtype=np.int64, count=n)
+        hoff = np.concatenate(([0], np.cumsum(hlen)[:-1]))
+        t = np.zeros(n, dtype=_ffi.BATCH_CONTIG_DTYPE)
+        t["body"] = text.ctypes.data + tab["b0"]
+        t["body_bytes"] = tab["b1"] - tab["b0"]
+        t["n_bases"] = tab["n_bases"]
+        t["lenc"] = tab["lenc"]
+        t["lenb"] = tab["lenb"]
+        t["header"] = blob.ctypes.data + hoff.astype(np.uint64)
+        t["header_len"] = hlen
+        t["name"] = t["header"]                        # (no VCF lines: the name is never read, it only must not be NULL)
+        t["name_len"] = 1
+        eng.set_params(params_descriptor(self._sim))
+        n_text, _, _, last_line = eng.batch_run_table(t, keep=(blob, text), defer_fasta=True)
+        region = self._fasta_writer.map_records(n_text)
+        try:
+            if n_text:
+                eng.batch_fetch_fasta(region.view)
+        finally:
+            self._fasta_writer.commit_records(region, int(tab["lenc"][-1]), last_line)
+        del blob
+
     def _mutate_sequence(self, breakpoints: dict):
         eng = self._engine()
+        chroms = self._sim.chromosomes
+        in_order = all(chroms[k].number == k for k in range(len(chroms)))
+        runs = dict(self._untouched_runs(len(chroms), breakpoints)) if in_order else {}
+        k = 0
+        while k < len(chroms):
+            if k in runs:
+                self._copy_run(eng, k, runs[k])
+                k = runs[k]
+            else:
+                self._one_contig(eng, chroms[k], breakpoints)
+                k += 1
+
+    def _one_contig(self, eng, chrom, breakpoints: dict):
         none = np.zeros(0, dtype=np.uint64)
-        for chrom in self._sim.chromosomes:
-            rec = self._fasta[chrom.number]
-            bpl = self._fasta.faidx.index[rec.name].lenc
-            self._fasta_writer.set_bpl(bpl)
+        rec = self._fasta[chrom.number]
+        bpl = self._fasta.faidx.index[rec.name].lenc
+        self._fasta_writer.set_bpl(bpl)
+        self._fasta_writer.write_header(rec.long_name)
+        a = self._ingest(eng, rec)
+        if chrom.number in breakpoints:
+            partner = self._fasta[self._partners[chrom.number]]
+            own, other = breakpoints[chrom.number]
+            cid = eng.splice_contigs(a, self._ingest(eng, partner), own.astype(np.uint64), other.astype(np.uint64))
+            self._bedpe_writer.write(rec.name, own, len(rec), partner.name, other, len(partner))
+        else:
+            # (the reference's __write_chrom_full writes the header again, it_mutator.py:148-156 after :199-202: a contig
+            #  without breakpoints carries its defline twice.  Kept: the files are compared byte by byte)
             self._fasta_writer.write_header(rec.long_name)
-            a = self._ingest(eng, rec)
-            if chrom.number in breakpoints:
-                partner = self._fasta[self._partners[chrom.number]]
-                own, other = breakpoints[chrom.number]
-                cid = eng.splice_contigs(a, self._ingest(eng, partner), own.astype(np.uint64), other.astype(np.uint64))
-                self._bedpe_writer.write(rec.name, own, len(rec), partner.name, other, len(partner))
-            else:
-                # (the reference's __write_chrom_full writes the header again, it_mutator.py:148-156 after :199-202: a contig
-                #  without breakpoints carries its defline twice.  Kept: the files are compared byte by byte)
-                self._fasta_writer.write_header(rec.long_name)
-                cid = eng.splice_contigs(a, -1, none, none)
-            if bpl > 0:
-                n_text = eng.fetch_sequence_framed_size(cid, bpl)
-                region = self._fasta_writer.map_region(n_text)
-                try:
-                    eng.fetch_sequence_framed_into(cid, bpl, region.view)
-                finally:
-                    q, r = divmod(n_text, bpl + 1)
-                    self._fasta_writer.commit_region(region, q * bpl + r)
-            else:
-                self._fasta_writer.write_array(eng.fetch_sequence(cid))
-            eng.clear()
+            cid = eng.splice_contigs(a, -1, none, none)
+        if bpl > 0:
+            n_text = eng.fetch_sequence_framed_size(cid, bpl)
+            region = self._fasta_writer.map_region(n_text)
+            try:
+                eng.fetch_sequence_framed_into(cid, bpl, region.view)
+            finally:
+                q, r = divmod(n_text, bpl + 1)
+                self._fasta_writer.commit_region(region, q * bpl + r)
+        else:
+            self._fasta_writer.write_array(eng.fetch_sequence(cid))
+        eng.clear()
 
     def mutate(self):
         self._mutate_sequence(self._generate_all_breakpoints())

@@ -97,6 +97,32 @@ class NumpyEngine:
         text = b"".join(s[i:i + bpl] + (b"\n" if len(s[i:i + bpl]) == bpl else b"") for i in range(0, len(s), bpl))
         view[:len(text)] = np.frombuffer(text, dtype=np.uint8)
 
+    def set_params(self, params):
+        pass
+
+    def batch_run_table(self, table, keep=(), defer_fasta=False):
+        """msim_batch_run for contigs without ranges: the complete run of records, each '>' header line + wrapped body."""
+        import ctypes as C
+        assert defer_fasta and (table["n_ranges"] == 0).all()
+        out = bytearray()
+        partial = False
+        for row in table:
+            body = C.string_at(int(row["body"]), int(row["body_bytes"]))
+            head = C.string_at(int(row["header"]), int(row["header_len"]))
+            raw = body.replace(b"\r", b"").replace(b"\n", b"").upper()[:int(row["n_bases"])]
+            bpl = int(row["lenc"])
+            if partial:
+                out += b"\n"
+            out += b">" + head + b"\n"
+            out += b"".join(raw[i:i + bpl] + (b"\n" if len(raw[i:i + bpl]) == bpl else b"") for i in range(0, len(raw), bpl))
+            partial = len(raw) % bpl != 0
+            last = len(raw) % bpl
+        self._batch_text = bytes(out)
+        return len(out), np.zeros(0, dtype=np.uint8), np.zeros(len(table), dtype=bool), last
+
+    def batch_fetch_fasta(self, dst):
+        dst[:len(self._batch_text)] = np.frombuffer(self._batch_text, dtype=np.uint8)
+
     def clear(self):
         self.contigs = []
 
