@@ -898,6 +898,24 @@ it 0
 """
 
 
+def make_cli_cases_readme():
+    """The commands of the reference README's "How Tos" (README.md:205-240) at a size where the device PLAN engines engage."""
+    print("CLI cases (README how-tos)")
+    spec = {"contigs": [{"defline": "h1 how-to", "length": 800_000, "bpl": 60, "seed": 401},
+                        {"defline": "h2", "length": 400_000, "bpl": 70, "seed": 402}]}
+    cli_case("readme_howto_sn", spec, ["args", "-sn", "0.05"], 91, 92, store="hash",
+             notes="README.md:210: SNPs every 20th base (SNP sampler engine)")
+    cli_case("readme_howto_sn_titv", spec, ["args", "-sn", "0.05", "-titv", "0.5"], 93, 94, store="hash",
+             notes="README.md:218: ti/tv 0.5")
+    cli_case("readme_howto_snb", spec, ["args", "-sn", "0.05", "-snb", "10", "-titv", "0.5"], 95, 96, store="hash",
+             notes="README.md:225: SNP block 10 -- above the sampling distance: every candidate is on the boundary chain "
+                   "(host-chain engine, one range per contig)")
+    cli_case("readme_howto_sv", spec, ["args", "-sn", "0.01", "-in", "0.01", "-de", "0.01", "-du", "0.01", "-iv", "0.01",
+                                       "-tl", "0.01", "-inmin", "10", "-inmax", "100"], 97, 98, store="hash",
+             notes="README.md:236: every type at 0.01 with inserts of 10-100 bases (SV-mix engine with translocations: 48 k + "
+                   "24 k candidates)")
+
+
 def make_cli_cases_it():
     """The `it` sub-command and RMT files with `it` lines (it_mutator.py, bedpe_writer.py)."""
     print("CLI cases (interchromosomal translocations)")
@@ -937,11 +955,13 @@ def make_cli_cases_it():
 
 def main():
     os.chdir(HERE)
-    which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli", "engines", "it"}
+    which = set(sys.argv[1:]) or {"rng", "settings", "plan", "apply", "cli", "engines", "it", "readme"}
     if "timing" in which:
         make_reference_timing()
     if "it" in which:
         make_cli_cases_it()
+    if "readme" in which:
+        make_cli_cases_readme()
     if "engines" in which:
         make_cli_cases_engines()
     if "scaffolds" in which or "engines" in which:
