@@ -300,6 +300,43 @@ def e2e_cli(eng, total_bases=1_200_000_000, n_contigs=6):
         shutil.rmtree(td, ignore_errors=True)
 
 
+def fast_rng_steps(lengths, mm, steps=5, warmup=3):
+    """c2 and c4 with `--rng fast` (msim.h: MSIM_RNG_FAST): a counter-based generator instead of the reference's two MT19937
+    streams.  NOT a parity number -- same distributions, different draws -- and never the headline: it shows what the step
+    costs once PLAN has no sequential chain."""
+    from mutation_simulator_amd import _ffi
+    eng = _ffi.Engine(int(os.environ.get("MSIM_BENCH_DEVICE", 0)), _ffi.RNG_FAST)
+    out = {"what": "NOT stream-compatible with the reference (Philox4x32-10 draws; same construction and distributions): PLAN without "
+                   "its sequential chain, same APPLY kernels; results left in HBM", "steps": steps, "warmup": warmup}
+    try:
+        cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
+        for w in ("c2", "c4"):
+            sim = build_settings(w, lengths)
+            tables = [mm.plan_table(ch) for ch in sim.chromosomes]
+            eng.set_params(mm.params_descriptor(sim))
+
+            def step():
+                eng.set_fast_key(42)
+                for ch, t in zip(sim.chromosomes, tables):
+                    eng.plan_contig(cids[ch.number], t)
+                    eng.apply_contig(cids[ch.number])
+                eng.sync()
+            for _ in range(warmup):
+                step()
+            eng.reset_stats()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            dt = time.perf_counter() - t0
+            st = eng.stats()
+            out[w] = {"value": round(sum(lengths) * steps / dt / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dt / steps * 1e3, 3),
+                      "records_per_step": st["records"] // steps, "stages_ms_per_step": stages_of(st, steps),
+                      "step_roofline": step_roofline(st, dt)}
+    finally:
+        eng.close()
+    return out
+
+
 def _snp_only_params():
     from mutation_simulator_amd import _ffi
     p = _ffi.Params()
@@ -548,6 +585,10 @@ def main():
                       "plan_engines": engines_of(sts, n_sec),
                       "records_per_step": sts["records"] // n_sec,
                       "roofline": roofline_of(sts, w, n_sec), "step_roofline": step_roofline(sts, dts)}
+        try:
+            sec["fast_rng"] = fast_rng_steps(lengths, mm)
+        except Exception as e:  # noqa: BLE001
+            sec["fast_rng"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             sec["e2e"] = e2e_cli(eng)
         except Exception as e:  # noqa: BLE001  (no tmpfs / disk space: the kernels' numbers above still stand)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 2
+#define MSIM_ABI_VERSION 3
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -54,6 +54,12 @@ extern "C" {
 #define MSIM_PLAN_AUTO   0u      /* per contig: a device PLAN engine where one applies, else the host planner */
 #define MSIM_PLAN_HOST   1u      /* force the sequential host planner (cross-check / debugging)               */
 #define MSIM_PLAN_GPU    2u      /* force a device engine; MSIM_ERR_UNSUPPORTED where none can run             */
+#define MSIM_RNG_FAST    4u      /* NOT stream-compatible with the reference: a counter-based generator (Philox4x32-10)
+                                    replaces the two MT19937 streams, so that no draw depends on another one and PLAN has no
+                                    sequential chain.  Same construction as the reference -- k = int(len * rate) positions per
+                                    range as a uniform k-subset with the minimum distance, transition with probability p_ti --
+                                    same distributions, different numbers.  SNP-only settings (MSIM_ERR_UNSUPPORTED otherwise);
+                                    msim_seed / msim_set_mt_state are ignored, msim_set_fast_key seeds it.                */
 /* Device PLAN engines: the device owns both MT19937 streams and does all per-record work;
  * SNP-only large ranges need nothing from the host, SV mixes hand the boundary chain over their non-SNP
  * candidates to the host, contigs with many small SNP ranges hand it the chain of sample() calls, contigs whose
@@ -115,6 +121,7 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     uint64_t contigs_hostchain;  /* several ranges with their own settings / SNPs that block: samples + chain on the host */
     uint64_t contigs_host;       /* sequential host planner (translocations, overlapping ranges, tiny contigs)         */
     uint64_t contigs_batch;      /* contigs that went through msim_batch_run (host planner, one APPLY per batch)       */
+    uint64_t contigs_fast;       /* MSIM_RNG_FAST contexts: contigs planned with the counter-based generator            */
 } msim_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -145,6 +152,9 @@ int msim_get_mt_state(msim_ctx *ctx, int stream, uint32_t mt[624], int *pos);
 /* Optional sizing hint for the GPU sampler: how many words of each stream the coming plan calls
  * will roughly consume, so stream chunks are generated in one batch.  Never changes results.      */
 int msim_reserve_streams(msim_ctx *ctx, uint64_t py_words, uint64_t np_words);
+/* MSIM_RNG_FAST contexts: the generator's key; also restarts the contig ordinal that every msim_plan_contig /
+ * msim_plan_chain call advances (so ranks that skip contigs they do not own stay aligned with those that plan them). */
+int msim_set_fast_key(msim_ctx *ctx, uint64_t key);
 
 /* ---- genome in HBM ----------------------------------------------------------------------------- */
 /* Upload one contig (upper-cased bases, what pyfaidx hands the reference: util.py:84-88).

@@ -67,6 +67,8 @@ struct Ctx {
     bool have_params = false;
     std::vector<Contig> contigs;
     int deferred_apply = -1;              // contig whose APPLY msim_apply_contig deferred (msim_api.hip), -1: none
+    uint64_t fast_key = 0x9E3779B97F4A7C15ull;   // MSIM_RNG_FAST: Philox key (msim_set_fast_key) ...
+    uint32_t fast_seq = 0;                //   ... and the ordinal of the next contig planned or walked past
     msim_timing t{};
     // device scratch
     void *d_scratch = nullptr;

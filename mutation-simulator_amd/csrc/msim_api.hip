@@ -450,6 +450,20 @@ int msim_set_plan_mode(msim_ctx *p, uint32_t mode) {
 static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges, int n_ranges) {
     int rc = MSIM_OK;
     TraceRange tr(c->chain_only ? "msim PLAN contig (chain only)" : "msim PLAN contig");
+    if (c->flags & MSIM_RNG_FAST) {                        // counter-based generator: nothing chains, nothing is stream-compatible
+        const uint32_t seq = c->fast_seq++;
+        if (c->chain_only) return MSIM_OK;                 // (a contig another rank owns: only its ordinal matters)
+        if (c->host_only || !c->gpu) return fail(c, MSIM_ERR_HIP, "fast RNG mode needs the GPU");
+        if (!gpu_plan_fast_eligible(c, ranges, n_ranges))
+            return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: SNP-only ranges (sorted, at most every second position drawn) "
+                                                 "with the SNP block at the minimum block");
+        if ((rc = flush_deferred_apply(c))) return rc;
+        reset_contig(*g);
+        c->text_kind = 0;
+        rc = plan_contig_fast(c, c->gpu, *g, ranges, n_ranges, c->fast_key, seq);
+        if (!rc) c->t.contigs_fast++;
+        return rc;
+    }
     const bool dev = !c->host_only && c->gpu && !(c->flags & MSIM_PLAN_HOST);
     const bool gpu_ok = dev && gpu_plan_eligible(c, ranges, n_ranges);
     const bool mixed_ok = dev && !gpu_ok && gpu_plan_mixed_eligible(c, ranges, n_ranges);
@@ -785,6 +799,14 @@ int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, 
     rc = fasta_gather_device(c, body, body_bytes, n_bases, lenc, lenb, g->d_in + PAD);
     if (rc) return rc;
     *contig = (int)c->contigs.size() - 1;
+    return MSIM_OK;
+}
+
+int msim_set_fast_key(msim_ctx *p, uint64_t key) {
+    CTX_FLUSHED(c, p)
+    if (!c) return MSIM_ERR_ARG;
+    c->fast_key = key;
+    c->fast_seq = 0;
     return MSIM_OK;
 }
 

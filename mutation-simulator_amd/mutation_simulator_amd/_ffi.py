@@ -15,6 +15,7 @@ LIB_CANDIDATES = [PKG_DIR.parent / "lib" / "libmsim.so"]
 
 OK, ERR_ARG, ERR_HIP, ERR_VALUE, ERR_KEY, ERR_UNSUPPORTED, ERR_NOMEM = range(7)
 PLAN_AUTO, PLAN_HOST, PLAN_GPU = 0, 1, 2
+RNG_FAST = 4           # Engine flag: counter-based generator, NOT stream-compatible with the reference (msim.h: MSIM_RNG_FAST)
 
 
 class MsimError(RuntimeError):
@@ -67,7 +68,8 @@ class Timing(C.Structure):           # msim_timing
                 ("bytes_in", C.c_uint64), ("bytes_out", C.c_uint64), ("records", C.c_uint64),
                 ("py_words", C.c_uint64), ("np_words", C.c_uint64),
                 ("contigs_snp", C.c_uint64), ("contigs_svmix", C.c_uint64), ("contigs_hostcut", C.c_uint64),
-                ("contigs_hostchain", C.c_uint64), ("contigs_host", C.c_uint64), ("contigs_batch", C.c_uint64)]
+                ("contigs_hostchain", C.c_uint64), ("contigs_host", C.c_uint64), ("contigs_batch", C.c_uint64),
+                ("contigs_fast", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -112,6 +114,7 @@ SYMBOLS = [
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
     ("msim_splice_contigs", C.c_int, [_VP, C.c_int, C.c_int, C.c_uint64, _U64P, _U64P, _IP]),
+    ("msim_set_fast_key", C.c_int, [_VP, C.c_uint64]),
     ("msim_sample_min_distance", C.c_int, [_VP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _VP]),
     ("msim_host_alloc", C.c_int, [_VP, C.c_uint64, C.POINTER(_VP)]),
     ("msim_host_free", C.c_int, [_VP, _VP]),
@@ -155,7 +158,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msim_abi_version() != 2:
+        if lib.msim_abi_version() != 3:
             raise MsimError("libmsim ABI version mismatch")
         _lib = lib
     return _lib
@@ -255,6 +258,10 @@ class Engine:
         self._check(self.lib.msim_get_mt_state(self.h, stream, arr.ctypes.data_as(_U32P),
                                                C.byref(pos)))
         return arr, pos.value
+
+    def set_fast_key(self, key: int):
+        """Key of the counter-based generator of a ``RNG_FAST`` context (restarts its contig ordinal)."""
+        self._check(self.lib.msim_set_fast_key(self.h, int(key) & 0xFFFFFFFFFFFFFFFF))
 
     def reserve_streams(self, py_words: int, np_words: int = 0):
         self._check(self.lib.msim_reserve_streams(self.h, int(py_words), int(np_words)))

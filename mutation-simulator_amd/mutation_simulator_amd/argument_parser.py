@@ -1,6 +1,6 @@
 """Command line of ``mutation-simulator`` -- flag-for-flag the reference's ``args`` and ``rmt``
 sub-commands (reference argument_parser.py:31-240) plus a few additions of ours that never change
-a default: ``--seed``, ``--device``, ``--gpus``, ``--bench-json``.
+a default: ``--seed``, ``--device``, ``--gpus``, ``--rng``, ``--bench-json``.
 
 The ``it`` sub-command (inter-chromosomal translocations, a second pass over the *output* Fasta)
 is outside the hot path this build accelerates; it is parsed so that scripts fail with a clear
@@ -69,6 +69,10 @@ def build_parser() -> ArgumentParser:
     parser.add_argument("--gpus", type=int, default=1,
                         help="Shard the contigs over this many GPUs of the node (one worker process per GPU; output is "
                              "byte-identical to a 1-GPU run). Default = 1")
+    parser.add_argument("--rng", choices=["compat", "fast"], default="compat",
+                        help="compat (default): the reference's two MT19937 streams, output bit-identical to the reference "
+                             "under the same seeds. fast: a counter-based generator (Philox) -- same distributions, NOT the "
+                             "reference's numbers; no sequential chain in the draw; SNP-only settings")
     parser.add_argument("--bench-json", type=Path, default=None,
                         help="Write per-stage timings of the mutation pass to this JSON file")
 

@@ -113,8 +113,7 @@ class ShardWorker(Mutator):
                 eng.set_plan_mode(_ffi.PLAN_AUTO)
 
     def run(self, device: int) -> dict:
-        self._engine = eng = _ffi.Engine(-1 if self._host_only else device)
-        export_python_streams(eng)
+        self._engine = eng = self._open_engine(-1 if self._host_only else device)
         eng.set_params(params_descriptor(self._sim))
         eng.reset_stats()
         chroms = self._chromosomes()
@@ -147,7 +146,7 @@ class ShardWorker(Mutator):
                 if error:
                     break
         finally:
-            if error is None:
+            if error is None and not self._fast_rng:
                 import_python_streams(eng)
             self.stats = eng.stats()
         rng = (random.getstate(), np.random.get_state()) if self.rank == 0 and error is None else None

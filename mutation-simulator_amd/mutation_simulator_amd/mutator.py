@@ -263,6 +263,22 @@ class Mutator:
         except Exception:
             pass
 
+    @property
+    def _fast_rng(self) -> bool:
+        """``--rng fast``: libmsim's counter-based generator instead of the reference's streams (msim.h: MSIM_RNG_FAST)."""
+        return getattr(self._args, "rng", "compat") == "fast"
+
+    def _open_engine(self, device: int):
+        eng = _ffi.Engine(device, _ffi.RNG_FAST if self._fast_rng else _ffi.PLAN_AUTO)
+        self._seed_engine(eng)
+        return eng
+
+    def _seed_engine(self, eng):
+        if self._fast_rng:
+            eng.set_fast_key(random.getrandbits(64))       # (from Python's generator: --seed / random.seed() decide the run)
+        else:
+            export_python_streams(eng)
+
     def _batchable(self, chrom) -> bool:
         rec = self._fasta[chrom.number]
         if not (getattr(rec, "uniform", False) and 0 < len(rec) <= BATCH_SPARSE_MAX_LEN
@@ -441,6 +457,8 @@ class Mutator:
         also what a multi-GPU run shards (multi_gpu.py).  Array operations only where the contigs are the std ones."""
         from .rmt import StdChromosomes
         n = len(chroms)
+        if self._fast_rng:                             # no chain to amortise, and batches are planned on the host's streams
+            return [(q, q + 1) for q in range(n)]
         tab = getattr(self._fasta, "index_table", None)
         if (isinstance(chroms, StdChromosomes) and tab is not None and len(tab) == n
                 and type(self)._batchable is Mutator._batchable):
@@ -500,9 +518,10 @@ class Mutator:
             from .multi_gpu import mutate_sharded      # one worker process per GPU, spawned before any GPU call here
             return mutate_sharded(self)
         if self._engine is None:
-            self._engine = _ffi.Engine(getattr(self._args, "device", 0) or 0)
+            self._engine = self._open_engine(getattr(self._args, "device", 0) or 0)
+        else:
+            self._seed_engine(self._engine)
         eng = self._engine
-        export_python_streams(eng)
         eng.set_params(params_descriptor(self._sim))
         eng.reset_stats()
         try:
@@ -510,6 +529,7 @@ class Mutator:
             for i, j in self._units(chroms):
                 self._process_unit(eng, chroms, i, j)
         finally:
-            import_python_streams(eng)
+            if not self._fast_rng:
+                import_python_streams(eng)
             self.stats = eng.stats()
             self.stats["contig_path_s"] = {k: round(v, 4) for k, v in self._t.items()}
