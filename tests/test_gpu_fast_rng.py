@@ -278,3 +278,44 @@ def test_cli_rng_fast_end_to_end(tmp_path):
     with pytest.raises(SystemExit), contextlib.redirect_stderr(err):
         cli.main(["-q", "--rng", "fast", "-o", str(tmp_path / "e"), str(infile), "args", "-sn", "0.01", "-de", "0.001"])
     assert "fast RNG mode" in err.getvalue()
+
+
+@pytest.mark.parametrize("workload,engines", [("c2", 24), ("c4", 24)])
+def test_full_genome_fast_properties(workload, engines):
+    """The bench genome (3 Gb, 24 contigs) through the fast mode with the settings of BASELINE configs[1] / configs[3]: per
+    contig exactly sum(k) records, sorted, at least d + 1 apart, every range holding exactly its k positions; APPLY changes
+    exactly those bases (checksum of the changed positions against the records' outcomes is the rewrite kernels' own test:
+    here only the count of differing bases is taken, on the largest contig)."""
+    import bench
+    from mutation_simulator_amd import mutator as mm
+    lengths = bench.contig_lengths(3_000_000_000)
+    sim = bench.build_settings(workload, lengths)
+    eng = _ffi.Engine(0, _ffi.RNG_FAST)
+    eng.set_params(mm.params_descriptor(sim))
+    eng.set_fast_key(2024)
+    total = 0
+    for chrom in sim.chromosomes:
+        L = lengths[chrom.number]
+        table = mm.plan_table(chrom)
+        cid = eng.add_contig_synthetic(L, 1000 + chrom.number)
+        eng.plan_contig(cid, table)
+        recs, _ = eng.fetch_records(cid)
+        pos = recs["pos"].astype(np.int64)
+        k = table["k"].astype(np.int64)
+        assert len(pos) == int(k.sum())
+        assert np.all(np.diff(pos) > 1)
+        drawing = table[k > 0]
+        edges = np.searchsorted(pos, drawing["start"].astype(np.int64))
+        counts = np.diff(np.concatenate((edges, [len(pos)])))
+        assert np.array_equal(counts, drawing["k"].astype(np.int64))                    # every range: exactly its k positions ...
+        last = pos[np.cumsum(counts) - 1]
+        assert np.all(last <= drawing["stop"].astype(np.int64))                          # ... none beyond its stop
+        if chrom.number == 0:
+            before = eng.read_contig(cid)
+            eng.apply_contig(cid)
+            after = eng.fetch_sequence(cid)
+            assert int((before != after).sum()) == len(pos)
+        total += len(pos)
+        eng.clear()
+    assert eng.stats()["contigs_fast"] == engines and total > 10_000_000
+    eng.close()
