@@ -83,24 +83,45 @@ class ITMutator:
         i + 1 is looked at next.  Kept as is -- which contigs stay single depends on it."""
         self._partners = {}
         random.shuffle(avail)
+        # (the list as "the slots of the shuffled order that are still there": an assembly has 10^5 contigs, and
+        #  list.remove() made this quadratic -- 20 s of it.  Same elements at the same indices, same draws.)
+        try:
+            from sortedcontainers import SortedList
+            left = SortedList(range(len(avail)))       # slots still in the list, ascending = list order
+        except ImportError:                            # plain lists do the same, slower
+            left = None
+        if left is None:
+            i = 0
+            while i < len(avail):
+                chrom = avail[i]
+                i += 1
+                avail.remove(chrom)
+                if avail:
+                    partner = random.choice(avail)
+                    self._partners[partner] = chrom
+                    self._partners[chrom] = partner
+                    avail.remove(partner)
+            return
         i = 0
-        while i < len(avail):
-            chrom = avail[i]
+        while i < len(left):
+            slot = left[i]
             i += 1
-            avail.remove(chrom)
-            if avail:
-                partner = random.choice(avail)
+            left.remove(slot)
+            chrom = avail[slot]
+            if left:
+                pslot = left[random.randrange(len(left))]      # random.choice(seq) is seq[_randbelow(len(seq))]
+                left.remove(pslot)
+                partner = avail[pslot]
                 self._partners[partner] = chrom
                 self._partners[chrom] = partner
-                avail.remove(partner)
 
     def _pairs_once(self) -> list:
         """One contig of every pair, in the order the pairs were made (it_mutator.py:85-94)."""
-        chroms = list(self._partners.keys())
+        gone = set()                                   # (list.remove() per pair: quadratic over an assembly's contigs)
         for chrom, partner in self._partners.items():
-            if chrom in chroms:
-                chroms.remove(partner)
-        return chroms
+            if chrom not in gone:
+                gone.add(partner)
+        return [c for c in self._partners if c not in gone]
 
     # ------------------------------------------------------------------ breakpoints (it_mutator.py:96-119, 158-190)
     def _warn(self, text: str):

@@ -202,3 +202,45 @@ def test_native_breakpoint_sampler_equals_cpython(start, stop, k, d, monkeypatch
     with pytest.raises(ValueError, match="Sample larger than population or is negative"):
         it_mutator.sample_with_minimum_distance(1, 2_000, 1_001, 1)
     assert random.getstate() == before               # nothing was drawn
+
+
+def test_partner_walk_equals_the_references_list_walk():
+    """``_assign_partners`` keeps the reference's semantics -- a walk over the very list it removes from
+    (it_mutator.py:59-71) -- without its quadratic ``list.remove``: same pairs in the same dict order, same one-per-pair list
+    (it_mutator.py:73-83), same generator state, for every small size and a few larger ones."""
+    from mutation_simulator_amd import it_mutator
+
+    class Bare(it_mutator.ITMutator):
+        def __init__(self):
+            pass
+
+        def __del__(self):
+            pass
+
+    def plain(avail):
+        partners = {}
+        random.shuffle(avail)
+        remain = avail                                  # (the reference's alias)
+        for chrom in avail:
+            remain.remove(chrom)
+            if remain:
+                partner = random.choice(remain)
+                partners[partner] = chrom
+                partners[chrom] = partner
+                remain.remove(partner)
+        once = list(partners.keys())
+        for c, p in partners.items():
+            if c in once:
+                once.remove(p)
+        return partners, once
+    for n in list(range(0, 12)) + [33, 100, 1001]:
+        for seed in range(4):
+            random.seed(seed * 1000 + n)
+            want = plain(list(range(n)))
+            state = random.getstate()
+            random.seed(seed * 1000 + n)
+            b = Bare()
+            b._assign_partners(list(range(n)))
+            assert list(b._partners.items()) == list(want[0].items())
+            assert b._pairs_once() == want[1]
+            assert random.getstate() == state
