@@ -142,7 +142,7 @@ struct GpuPlan {
     uint32_t *h_sig = nullptr;
     uint32_t epoch = 0;
     hipStream_t copy_stream = nullptr;  // candidates D2H beside the plan stream
-    hipEvent_t ev_cand = nullptr, ev_piece[3] = {};
+    hipEvent_t ev_cand = nullptr, ev_piece[3] = {}, ev_cpiece[3] = {};
     SampleSet sample[N_SETS];
     SnpSet snp[N_SETS];
     uint32_t unit = 0, snp_unit = 0;    // rotation counters
@@ -255,6 +255,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     if (g->h_sig) (void)hipHostFree(g->h_sig);
     if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
     if (g->ev_cand) (void)hipEventDestroy(g->ev_cand);
+    for (auto e : g->ev_cpiece) if (e) (void)hipEventDestroy(e);
     for (auto e : g->ev_piece) if (e) (void)hipEventDestroy(e);
     delete g;
 }
@@ -924,6 +925,7 @@ static int ensure_signals(Ctx *c, GpuPlan *g) {
         MSIM_HIP(c, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
         MSIM_HIP(c, hipEventCreateWithFlags(&g->ev_cand, hipEventDisableTiming));
         for (auto &e : g->ev_piece) MSIM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : g->ev_cpiece) MSIM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     return MSIM_OK;
 }
@@ -1172,12 +1174,21 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     }
     q_nsn = std::min(1.0, q_nsn);
     const uint32_t n_hi = (uint32_t)std::min<double>(k, q_nsn * k + 16.0 * std::sqrt(q_nsn * (1.0 - q_nsn) * k) + 64.0);
+    const size_t ccut[4] = {0, (size_t)n_hi / 8, (size_t)n_hi / 2, (size_t)n_hi};
     {
         hipEvent_t se = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(se, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(g->copy_stream, se, 0));
-        MSIM_HIP(c, hipMemcpyAsync(g->h_npos, M.nsn_pos, (size_t)n_hi * 4, hipMemcpyDeviceToHost, g->copy_stream));
-        MSIM_HIP(c, hipMemcpyAsync(g->h_ntype, M.nsn_type, (size_t)n_hi, hipMemcpyDeviceToHost, g->copy_stream));
+        // in three pieces (1/8, 3/8, 1/2), like the tables: the walk starts on the first one -- with one copy of 3.75 MB (a big
+        // contig of config 3) it was the candidates, not the table, that the walk waited for
+        for (int q = 0; q < 3; q++) {
+            const size_t a = ccut[q], b = ccut[q + 1];
+            if (b > a) {
+                MSIM_HIP(c, hipMemcpyAsync(g->h_npos + a, M.nsn_pos + a, (b - a) * 4, hipMemcpyDeviceToHost, g->copy_stream));
+                MSIM_HIP(c, hipMemcpyAsync(g->h_ntype + a, M.nsn_type + a, b - a, hipMemcpyDeviceToHost, g->copy_stream));
+            }
+            MSIM_HIP(c, hipEventRecord(g->ev_cpiece[q], g->copy_stream));
+        }
         MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
     }
     PlanState h;
@@ -1238,15 +1249,33 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             double t_wait = 0, t_run = 0;
             auto tp = std::chrono::steady_clock::now();
             auto lap = [&](double &acc) { const auto n = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::micro>(n - tp).count(); tp = n; };
-            rc = spin_event(c, g->ev_cand);
-            if (!rc && !ChainWalk::types_ok(g->h_ntype, n_nsn, has_tl)) rc = fail(c, MSIM_ERR_HIP, "boundary chain: candidate type outside the range's draw");
-            for (int q = 0; q < 3 && !rc; q++) {
-                if ((rc = spin_event(c, g->ev_piece[q]))) break;
+            // candidates and table both arrive in pieces; the walk runs over what is there and waits for whichever ran out
+            int ci = 0, ti = 0;
+            size_t avail_c = 0, avail_w = 0;
+            while (!rc && cw.j < n_nsn) {
+                const bool need_c = cw.j >= avail_c, need_w = (cw.ws >> cw.lg_rows) >= avail_w;
+                if (!need_c && !need_w) break;             // (run stops for one of the two reasons only)
+                if (need_c) {
+                    const size_t had = avail_c;
+                    if (ci < 3) { if ((rc = spin_event(c, g->ev_cpiece[ci]))) break; avail_c = std::min<size_t>(ccut[++ci], n_nsn); }
+                    else if (avail_c < n_nsn) { if ((rc = spin_event(c, g->ev_cand))) break; avail_c = n_nsn; }   // (beyond 16 sigma)
+                    else break;
+                    if (!ChainWalk::types_ok(g->h_ntype + had, avail_c - had, has_tl)) {
+                        rc = fail(c, MSIM_ERR_HIP, "boundary chain: candidate type outside the range's draw");
+                        break;
+                    }
+                }
+                if (need_w) {
+                    if (ti >= 3) break;                    // the window is used up: finish() reports it
+                    if ((rc = spin_event(c, g->ev_piece[ti]))) break;
+                    avail_w = cut[++ti];
+                }
                 lap(t_wait);
-                if (has_tl) cw.run_tl(g->h_npos, g->h_ntype, n_nsn, g->h_words, cut[q + 1], g->h_nstop);
-                else cw.run(g->h_npos, g->h_ntype, n_nsn, g->h_words, cut[q + 1], g->h_nstop);
+                if (has_tl) cw.run_tl(g->h_npos, g->h_ntype, avail_c, g->h_words, avail_w, g->h_nstop);
+                else cw.run(g->h_npos, g->h_ntype, avail_c, g->h_words, avail_w, g->h_nstop);
                 lap(t_run);
             }
+            if (!rc) rc = spin_event(c, g->ev_cand);       // (every copy into the pinned blocks has landed before they are reused)
             if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows);
             if (!rc) rc = cw.finish(c, n_nsn, &consumed);
             c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
