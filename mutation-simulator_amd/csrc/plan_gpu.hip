@@ -933,13 +933,17 @@ static int ensure_signals(Ctx *c, GpuPlan *g) {
 // Exact stream position + counts from the mailbox, chain time accounted -- without draining the stream: the mailbox
 // kernel writes a sequence word last and the host polls it (a stream synchronisation costs 25-35 us of wake-up
 // latency per call, twice per contig)
-static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h) {
+// behind_mailbox: device work the caller can already enqueue behind the mailbox kernel -- the host would otherwise sit in the
+// poll and only then start launching it (20-35 us of launches + their latency, per contig)
+template <class F>
+static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h, F &&behind_mailbox) {
     int rc = ensure_signals(c, g);
     if (rc) return rc;
     if (++g->epoch == 0) g->epoch = 1;
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
     hipLaunchKernelGGL(k_publish_seq, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail, g->h_sig, g->epoch);
     MSIM_HIP(c, hipGetLastError());
+    if ((rc = behind_mailbox())) return rc;
     if ((rc = spin_until(c, g->h_sig, g->epoch, c->stream))) return rc;
     float ms = 0;
     hipError_t e = hipEventElapsedTime(&ms, g->t0, g->t1);
@@ -957,6 +961,10 @@ static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h) {
     g->s[0].pos = h.pos;
     MSIM_HIP(c, hipEventRecord(g->t0, c->stream));        // the next span starts here
     return MSIM_OK;
+}
+
+static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h) {
+    return mixed_poll(c, g, h, []() { return MSIM_OK; });
 }
 
 // The plan stream is about to idle while the host walks a chain: close the timed GPU span (t1 must have been
@@ -1191,8 +1199,53 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         }
         MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
     }
+    // The accept tables of the boundary walk depend on where the sample ended (the device knows) and on the window's size --
+    // which follows from the number of non-SNP candidates, known only after the poll: they are launched BEHIND the mailbox
+    // kernel over a 16-sigma bound of it, so that they are under way while the host still polls.
+    double acc_min = 1.0;                                  // least acceptance of randint among the types this range draws
+    for (int j = 0; j < r.n_types; j++) {
+        const int t = r.types[j];
+        if (t == MSIM_SN || t == MSIM_TLI || !range_type_drawable(r, j)) continue;
+        const int64_t w = r.max_len[t] - r.min_len[t] + 1;
+        if (w >= 1 && w < (1ll << 32)) acc_min = std::min(acc_min, (double)w / (double)(1ull << bit_length64((uint64_t)w)));
+    }
+    auto window_of = [&](double n) { return n / acc_min + 16.0 * std::sqrt(n) / acc_min + 4096.0; };
+    ChainClasses cc;
+    const bool tables = chain_classes(r, cc);              // the host walks "next accepted draw" tables (ctx.h)
+    const uint32_t lg = chain_lg_rows(cc);
+    const bool early = tables && n_hi > 0 && window_of((double)n_hi) < 4.0e9;
+    const uint32_t Wb_hi = early ? (uint32_t)window_of((double)n_hi) : 0u;
+    size_t cut[4] = {0, 0, 0, 0};
+    if (early) {
+        const size_t bytes = ((size_t)(Wb_hi + 1) << lg) * 4;
+        if (g->cap_h_words < bytes) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, bytes))) return rc;
+        }
+        if ((rc = grow(c, (void **)&M.words, &M.cap_words, bytes, &grew))) return rc;
+        if ((rc = ensure_words(c, g, 0, py.pos + sl.W + Wb_hi + 2))) return rc;      // (the sample ends below py.pos + W)
+    }
     PlanState h;
-    if ((rc = mixed_poll(c, g, h))) return rc;
+    const auto tq0 = std::chrono::steady_clock::now();
+    rc = mixed_poll(c, g, h, [&]() -> int {
+        if (!early) return MSIM_OK;
+        const size_t n_slots = (size_t)(Wb_hi + 1) << lg;
+        hipLaunchKernelGGL(k_accept_tables_ps, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, py.d_raw, g->d_ps, Wb_hi,
+                           cc, lg, M.words);
+        MSIM_HIP(c, hipGetLastError());
+        // three pieces (1/8, 3/8, 1/2 of the positions): the walk starts on the first one while the others are in flight -- it
+        // consumes the table at ~3 GB/s, the copies deliver 50 GB/s
+        cut[1] = (size_t)(Wb_hi + 1) / 8; cut[2] = (size_t)(Wb_hi + 1) / 2; cut[3] = (size_t)Wb_hi + 1;
+        for (int q = 0; q < 3; q++) {
+            if (cut[q + 1] > cut[q])
+                MSIM_HIP(c, hipMemcpyAsync(g->h_words + (cut[q] << lg), M.words + (cut[q] << lg), ((cut[q + 1] - cut[q]) << lg) * 4,
+                                           hipMemcpyDeviceToHost, c->stream));
+            MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+        }
+        return MSIM_OK;
+    });
+    if (rc) return rc;
+    const auto tq1 = std::chrono::steady_clock::now();
     const uint32_t n_nsn = h.n_nsn;
     const uint64_t p_b = h.pos;                            // the boundary pass draws from here
     np.pos = np_base + 2ull * k;
@@ -1200,45 +1253,39 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
 
     // ---- 2. the sequential chain over the non-SNP candidates, on the host
     size_t consumed = 0;
+    const bool early_ok = early && n_nsn > 0 && n_nsn <= n_hi;    // (beyond 16 sigma: the window is built again, exactly, below)
+    if (early && !early_ok) MSIM_HIP(c, hipStreamSynchronize(c->stream));   // nobody reads that table: the blocks are free again
     if (n_nsn) {
-        double acc_min = 1.0;                              // least acceptance of randint among the types this range draws
-        for (int j = 0; j < r.n_types; j++) {
-            const int t = r.types[j];
-            if (t == MSIM_SN || t == MSIM_TLI || !range_type_drawable(r, j)) continue;
-            const int64_t w = r.max_len[t] - r.min_len[t] + 1;
-            if (w >= 1 && w < (1ll << 32)) acc_min = std::min(acc_min, (double)w / (double)(1ull << bit_length64((uint64_t)w)));
-        }
-        const double wb = (double)n_nsn / acc_min + 16.0 * std::sqrt((double)n_nsn) / acc_min + 4096.0;
+        const double wb = window_of((double)n_nsn);
         if (wb >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "boundary window beyond 2^32 words");
-        const uint32_t Wb = (uint32_t)wb;
-        ChainClasses cc;
-        const bool tables = chain_classes(r, cc);          // the host walks "next accepted draw" tables (ctx.h)
-        const uint32_t lg = chain_lg_rows(cc);
+        const uint32_t Wb = early_ok ? Wb_hi : (uint32_t)wb;
         const size_t words_bytes = tables ? ((size_t)(Wb + 1) << lg) * 4 : (size_t)Wb * 4;
-        if (g->cap_h_words < words_bytes) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, words_bytes))) return rc;
+        if (!early_ok) {
+            if (g->cap_h_words < words_bytes) {
+                MSIM_HIP(c, hipStreamSynchronize(c->stream));
+                if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, words_bytes))) return rc;
+            }
+            if ((rc = grow(c, (void **)&M.words, &M.cap_words, words_bytes, &grew))) return rc;
+            if ((rc = ensure_words(c, g, 0, p_b + Wb + 1))) return rc;
         }
-        if ((rc = grow(c, (void **)&M.words, &M.cap_words, words_bytes, &grew))) return rc;
-        if ((rc = ensure_words(c, g, 0, p_b + Wb + 1))) return rc;
         if (n_nsn > n_hi) {                                // beyond 16 sigma: the rest of the candidates
             MSIM_HIP(c, hipMemcpyAsync(g->h_npos + n_hi, M.nsn_pos + n_hi, (size_t)(n_nsn - n_hi) * 4, hipMemcpyDeviceToHost, g->copy_stream));
             MSIM_HIP(c, hipMemcpyAsync(g->h_ntype + n_hi, M.nsn_type + n_hi, (size_t)(n_nsn - n_hi), hipMemcpyDeviceToHost, g->copy_stream));
             MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
         }
         if (tables) {
-            // The table comes over in three pieces (1/8, 3/8, 1/2 of the positions); the walk starts on the first one
-            // while the others are in flight -- it consumes the table at ~3 GB/s, the copies deliver 50 GB/s.
-            const size_t n_slots = (size_t)(Wb + 1) << lg;
-            hipLaunchKernelGGL(k_accept_tables, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, py.d_raw,
-                               (unsigned long long)p_b, Wb, cc, lg, M.words);
-            MSIM_HIP(c, hipGetLastError());
-            const size_t cut[4] = {0, (size_t)(Wb + 1) / 8, (size_t)(Wb + 1) / 2, (size_t)Wb + 1};
-            for (int q = 0; q < 3; q++) {
-                if (cut[q + 1] > cut[q])
-                    MSIM_HIP(c, hipMemcpyAsync(g->h_words + (cut[q] << lg), M.words + (cut[q] << lg),
-                                               ((cut[q + 1] - cut[q]) << lg) * 4, hipMemcpyDeviceToHost, c->stream));
-                MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+            if (!early_ok) {                               // (not launched behind the mailbox: now, with the exact window)
+                const size_t n_slots = (size_t)(Wb + 1) << lg;
+                hipLaunchKernelGGL(k_accept_tables, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, py.d_raw,
+                                   (unsigned long long)p_b, Wb, cc, lg, M.words);
+                MSIM_HIP(c, hipGetLastError());
+                cut[0] = 0; cut[1] = (size_t)(Wb + 1) / 8; cut[2] = (size_t)(Wb + 1) / 2; cut[3] = (size_t)Wb + 1;
+                for (int q = 0; q < 3; q++) {
+                    if (cut[q + 1] > cut[q])
+                        MSIM_HIP(c, hipMemcpyAsync(g->h_words + (cut[q] << lg), M.words + (cut[q] << lg),
+                                                   ((cut[q + 1] - cut[q]) << lg) * 4, hipMemcpyDeviceToHost, c->stream));
+                    MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+                }
             }
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
             if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
@@ -1276,7 +1323,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 lap(t_run);
             }
             if (!rc) rc = spin_event(c, g->ev_cand);       // (every copy into the pinned blocks has landed before they are reused)
-            if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows);
+            if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu | poll %.0f us, enqueue %.0f us\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows,
+                              std::chrono::duration<double, std::micro>(tq1 - tq0).count(), std::chrono::duration<double, std::micro>(w0 - tq1).count());
             if (!rc) rc = cw.finish(c, n_nsn, &consumed);
             c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             if (!rc) {
