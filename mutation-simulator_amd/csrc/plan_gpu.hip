@@ -1957,8 +1957,20 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     hipLaunchKernelGGL(k_accept_tables_ps, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, c->stream, py.d_raw, g->d_ps, W,
                        ms.gcc, lg, M.tables);
     MSIM_HIP(c, hipGetLastError());
+    // window and tables come over in three pieces (1/8, 3/8, 1/2); the host starts on the first while the others are in flight.
+    // Their copies go out behind the mailbox kernel, before the host polls: nothing of them depends on what the poll tells.
+    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0};
     PlanState h;
-    if ((rc = mixed_poll(c, g, h))) return rc;             // exact stream position + the chain's length
+    rc = mixed_poll(c, g, h, [&]() -> int {                // exact stream position + the chain's length
+        for (int q = 0; q < 3; q++) {
+            const size_t a = fd.cut[q], b = fd.cut[q + 1], tb = q == 2 ? (size_t)W + 1 : b;   // (+ the end-of-window sentinel)
+            if (b > a) MSIM_HIP(c, hipMemcpyAsync(g->h_win + a, M.words + a, (b - a) * 4, hipMemcpyDeviceToHost, c->stream));
+            if (tb > a) MSIM_HIP(c, hipMemcpyAsync(g->h_words + (a << lg), M.tables + (a << lg), ((tb - a) << lg) * 4, hipMemcpyDeviceToHost, c->stream));
+            MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
+        }
+        return MSIM_OK;
+    });
+    if (rc) return rc;
     const uint32_t n_ch = h.n_nsn;
     const uint64_t p0 = h.pos;
     np.pos = np_base + 2ull * K;
@@ -1967,14 +1979,6 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
         MSIM_HIP(c, hipMemcpyAsync(g->h_nrank + n_hi, M.nsn_rank + n_hi, (size_t)(n_ch - n_hi) * 4, hipMemcpyDeviceToHost, g->copy_stream));
         MSIM_HIP(c, hipMemcpyAsync(g->h_ntype + n_hi, M.nsn_type + n_hi, (size_t)(n_ch - n_hi), hipMemcpyDeviceToHost, g->copy_stream));
         MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
-    }
-    // window and tables come over in three pieces (1/8, 3/8, 1/2); the host starts on the first while the others are in flight
-    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0};
-    for (int q = 0; q < 3; q++) {
-        const size_t a = fd.cut[q], b = fd.cut[q + 1], tb = q == 2 ? (size_t)W + 1 : b;   // (+ the end-of-window sentinel)
-        if (b > a) MSIM_HIP(c, hipMemcpyAsync(g->h_win + a, M.words + a, (b - a) * 4, hipMemcpyDeviceToHost, c->stream));
-        if (tb > a) MSIM_HIP(c, hipMemcpyAsync(g->h_words + (a << lg), M.tables + (a << lg), ((tb - a) << lg) * 4, hipMemcpyDeviceToHost, c->stream));
-        MSIM_HIP(c, hipEventRecord(g->ev_piece[q], c->stream));
     }
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
     if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
