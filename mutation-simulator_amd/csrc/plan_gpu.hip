@@ -1288,6 +1288,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 }
             }
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+            if (c->deferred_apply >= 0) MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, g->ev_cand, 0));   // (... and behind the candidates' copies)
             if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
             const auto w0 = std::chrono::steady_clock::now();
             ChainWalk cw;
@@ -1981,6 +1982,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
         MSIM_HIP(c, hipEventRecord(g->ev_cand, g->copy_stream));
     }
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
+    if (c->deferred_apply >= 0) MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, g->ev_cand, 0));   // (behind the candidates' copies too)
     if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
     const auto tp1 = std::chrono::steady_clock::now();
     // ---- 2. the chain, on the host
