@@ -2,9 +2,9 @@
 sub-commands (reference argument_parser.py:31-240) plus a few additions of ours that never change
 a default: ``--seed``, ``--device``, ``--gpus``, ``--rng``, ``--bench-json``.
 
-The ``it`` sub-command (inter-chromosomal translocations, a second pass over the *output* Fasta)
-is outside the hot path this build accelerates; it is parsed so that scripts fail with a clear
-message rather than an argparse usage error.
+The ``it`` sub-command (inter-chromosomal translocations, reference it_mutator.py: a second pass over
+the Fasta) runs through ``ITMutator`` / ``BedpeWriter``.  ``--rng fast`` applies to the mutation pass
+(``args`` / ``rmt``) only: the IT pass always draws from CPython's generator.
 """
 from __future__ import annotations
 
@@ -102,8 +102,7 @@ def build_parser() -> ArgumentParser:
         p_args.add_argument(short, long, default=default,
                             help=f"{what} name for the VCF file. Default = '{default}'")
 
-    p_it = sub.add_parser("it", help="Generate interchromosomal translocations via the command "
-                                     "line (not part of this build)")
+    p_it = sub.add_parser("it", help="Generate interchromosomal translocations via the command line")
     p_it.add_argument("interchromosomalrate", type=float,
                       help="Rate of interchromosomal translocations")
 

@@ -7,11 +7,39 @@ last line, and a newline *before* the next header only if the previous line was 
 """
 from __future__ import annotations
 
+import ctypes
+import errno
 import mmap
 import os
 import time
 
 import numpy as np
+
+_libc = None
+
+
+def fallocate_native(fd: int, offset: int, nbytes: int) -> bool:
+    """Linux ``fallocate(2)``, mode 0, called directly.  True: the span is allocated.  False: the filesystem has no
+    native fallocate (EOPNOTSUPP / ENOSYS / EINVAL) -- nothing was touched.  Other errors (ENOSPC ...) raise.
+
+    Deliberately NOT ``os.posix_fallocate``: where the filesystem lacks the operation (NFS, some FUSE / overlay
+    mounts) glibc *emulates* it by reading one byte per block and writing a zero back where it read none -- a byte
+    another thread (or a device-to-host copy into a mapping of the same span) writes between that read and that
+    write is silently zeroed, and the emulation costs a syscall per 4 KiB block."""
+    global _libc
+    if _libc is None:
+        _libc = ctypes.CDLL(None, use_errno=True)
+        _libc.fallocate.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
+        _libc.fallocate.restype = ctypes.c_int
+    while True:
+        if _libc.fallocate(fd, 0, offset, nbytes) == 0:
+            return True
+        e = ctypes.get_errno()
+        if e == errno.EINTR:
+            continue
+        if e in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL):
+            return False
+        raise OSError(e, os.strerror(e))
 
 
 class MappedRegion:
@@ -33,12 +61,8 @@ class MappedRegion:
             if os.fstat(fd).st_size < self.pos + self.nbytes:
                 # allocate the span's pages in bulk: faulting fresh pages of a just-extended file in one by one costs
                 # 40-50 ms per 200 MB on tmpfs, fallocate 9 (and the copy into the allocated span 15)
-                try:
-                    os.posix_fallocate(fd, self.pos, self.nbytes)
-                except OSError as e:
-                    import errno
-                    if e.errno not in (errno.EOPNOTSUPP, errno.ENOSYS, errno.EINVAL):
-                        raise                   # (no space left: better an exception here than a SIGBUS in the copy)
+                # (no space left raises: better an exception here than a SIGBUS in the copy)
+                if not fallocate_native(fd, self.pos, self.nbytes):
                     os.ftruncate(fd, self.pos + self.nbytes)
             start = self.pos - self.pos % mmap.ALLOCATIONGRANULARITY
             self._map = mmap.mmap(fd, self.pos + self.nbytes - start, access=mmap.ACCESS_WRITE, offset=start)
@@ -95,7 +119,11 @@ class Preallocator:
             arena = None
             try:
                 if not self._stop:
-                    os.posix_fallocate(self._fd, start, end - start)
+                    if not fallocate_native(self._fd, start, end - start):
+                        # no native fallocate here: no allocation ahead of the writers at all (an emulated one would race
+                        # with them); MappedRegion extends the file by ftruncate and the copies fault their pages in
+                        self._stop = True
+                        raise OSError(errno.EOPNOTSUPP, "fallocate not supported")
                     arena = mmap.mmap(self._fd, end - start, access=mmap.ACCESS_WRITE, offset=start)
                     self._arenas.append((start, end - start, arena))
             except (OSError, ValueError):

@@ -215,17 +215,33 @@ def mutate_sharded(m: Mutator):
         for r in range(world):
             procs.append(subprocess.Popen([sys.executable, "-m", "mutation_simulator_amd.multi_gpu", str(job), str(r)],
                                           env=env, stdout=subprocess.DEVNULL))
-        results = []
-        for r, p in enumerate(procs):
-            code = p.wait()
-            out = part_dir / f"result{r}.pkl"
-            if out.exists():
-                results.append(pickle.loads(out.read_bytes()))
-            else:
-                results.append({"fatal": f"worker process ended with exit code {code} and no result"})
-        for r, res in enumerate(results):
-            if "fatal" in res:
-                raise _ffi.MsimError(f"--gpus {world}: worker {r} failed: {res['fatal']}\n{res.get('traceback', '')}")
+        # All workers are watched together: the first one that dies without a result or reports a fatal error (no device,
+        # a bad MSIM_SHARD_DEVICES) ends the run at once -- the others are killed (finally:) instead of being left to finish
+        # their whole share -- and a worker that hangs (a stuck GPU) is bounded by MSIM_SHARD_TIMEOUT seconds (0 = none).
+        import time
+        limit = float(os.environ.get("MSIM_SHARD_TIMEOUT", "0") or 0)
+        t_start = time.monotonic()
+        results = [None] * world
+        while any(res is None for res in results):
+            progressed = False
+            for r, p in enumerate(procs):
+                if results[r] is not None:
+                    continue
+                code = p.poll()
+                if code is None:
+                    continue
+                progressed = True
+                out = part_dir / f"result{r}.pkl"
+                res = pickle.loads(out.read_bytes()) if out.exists() else {
+                    "fatal": f"worker process ended with exit code {code} and no result"}
+                if "fatal" in res:
+                    raise _ffi.MsimError(f"--gpus {world}: worker {r} failed: {res['fatal']}\n{res.get('traceback', '')}")
+                results[r] = res
+            if limit and time.monotonic() - t_start > limit:
+                stuck = [r for r, res in enumerate(results) if res is None]
+                raise _ffi.MsimError(f"--gpus {world}: worker(s) {stuck} still running after MSIM_SHARD_TIMEOUT={limit:g} s")
+            if not progressed:
+                time.sleep(0.002)
         errors = [res["error"] for res in results if res["error"]]
         fail_unit = min((e["unit"] for e in errors), default=None)
         where = {}

@@ -375,7 +375,9 @@ class Mutator:
         try:
             self._run_contig(eng, chrom, done)
         except _ffi.MsimError as e:
-            if "overflowed its" not in str(e):
+            # (fast RNG mode has no host planner to fall back to, and a replay through plan_chain would advance the
+            #  contig ordinal -- every later contig, and every other rank of a --gpus run, would draw other numbers)
+            if "overflowed its" not in str(e) or getattr(self._args, "rng", "compat") == "fast":
                 raise
             global REPLANNED_CONTIGS
             REPLANNED_CONTIGS += 1
