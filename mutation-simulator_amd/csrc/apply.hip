@@ -160,11 +160,15 @@ __global__ __launch_bounds__(THREADS) void k_offsets(const msim_record *__restri
 // ------------------------------------------------------------------ 2. tile index
 // first[t] = index of the last record whose output offset is <= t*TILE, or -1
 // (off == nullptr: SNP-only table, a record's output offset is its position)
+// dyn != nullptr (tables of the counter-based PLAN engine, plan_fast.hip): the record count is only known on the device --
+// dyn[0] = records, dyn[1] = mutated length; n / n_entries are then upper bounds the grid was sized with
 __global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restrict__ off,
                                                         const msim_record *__restrict__ recs, uint32_t n,
-                                                        int32_t *__restrict__ first, uint32_t n_entries) {
+                                                        int32_t *__restrict__ first, uint32_t n_entries,
+                                                        const uint32_t *__restrict__ dyn) {
     const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
     if (t >= n_entries) return;
+    if (dyn) n = dyn[0];
     const uint64_t target = (uint64_t)t * TILE;
     uint32_t lo = 0, hi = n;                               // upper bound: first index with off > target
     while (lo < hi) {
@@ -672,7 +676,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 
                                                      const int32_t *__restrict__ first, uint32_t n_rec,
                                                      uint64_t L_out, const uint8_t *__restrict__ pool,
                                                      const uint8_t *__restrict__ lut_g,
-                                                     unsigned long long *err) {
+                                                     unsigned long long *err, const uint32_t *__restrict__ dyn) {
+    if (dyn) {                                             // sizes from the device (see k_tile_index); surplus tiles leave
+        n_rec = dyn[0];
+        L_out = dyn[1];
+        if ((uint64_t)blockIdx.x * TILE >= L_out) return;
+    }
     __shared__ RecWin<CAP> win;
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
@@ -747,7 +756,8 @@ __global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restri
                                                          const msim_record *__restrict__ recs,
                                                          const int32_t *__restrict__ first, uint32_t n_rec,
                                                          uint64_t L, const uint8_t *__restrict__ lut_g,
-                                                         unsigned long long *err) {
+                                                         unsigned long long *err, const uint32_t *__restrict__ dyn) {
+    if (dyn) n_rec = dyn[0];
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[1024];
     const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
@@ -909,6 +919,10 @@ int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum) {
 extern uint8_t *ctx_lut(Ctx *c);
 
 int apply_finish(Ctx *c) {
+    {   // sizes the counter-based engine left on the device (synchronises its streams; no-op when nothing is pending)
+        const int rc = fast_plan_collect(c);
+        if (rc) { c->pending_apply.clear(); for (auto &g : c->contigs) g.apply_pending = g.dyn_applied = false; return rc; }
+    }
     if (c->pending_apply.empty()) return MSIM_OK;
     // KeyError words + length-check words of every contig: two asynchronous copies into pinned memory behind the
     // APPLY work, one synchronisation (two blocking hipMemcpy cost ~40 us each at every step boundary)
@@ -929,6 +943,11 @@ int apply_finish(Ctx *c) {
         Contig &g = c->contigs[(size_t)idx];
         if (!g.apply_pending) continue;
         g.apply_pending = false;
+        if (g.dyn_applied) {                              // (sizes collected above)
+            g.dyn_applied = false;
+            c->t.bytes_out += g.out_len;
+            c->t.records += g.n_rec;
+        }
         float ms_all = 0, ms_k = 0;
         MSIM_HIP(c, hipEventElapsedTime(&ms_all, g.ea0, g.ea2));
         MSIM_HIP(c, hipEventElapsedTime(&ms_k, g.ea1, g.ea2));
@@ -950,7 +969,11 @@ int apply_finish(Ctx *c) {
 // apply_finish at the next synchronising call.  Tables with indels need the scanned total length to
 // size the output, so that path synchronises once.
 int apply_contig_device(Ctx *c, Contig &g) {
-    const uint32_t n = (uint32_t)g.n_rec;
+    // (d_dyn: planned by the counter-based engine with types beyond SNPs -- the record count and the mutated length sit in
+    //  device memory; `n` and the output length below are then the bounds the plan allocated for, and the kernels read
+    //  the exact values themselves)
+    const uint32_t *dyn = g.d_dyn;
+    const uint32_t n = (uint32_t)(dyn ? g.n_rec_cap : g.n_rec);
     hipStream_t st = c->emit_stream;
     if (!g.ea0) {
         MSIM_HIP(c, hipEventCreate(&g.ea0));
@@ -967,7 +990,10 @@ int apply_contig_device(Ctx *c, Contig &g) {
     long long total_delta = 0;
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
     const uint32_t *d_off = nullptr;
-    if (n && !g.all_snp && g.off_ready) {                  // planned on the device: the offsets came with the records
+    if (dyn) {
+        total_delta = g.all_snp ? 0 : (long long)g.out_cap_len - (long long)g.len;
+        d_off = g.all_snp ? nullptr : g.d_off;
+    } else if (n && !g.all_snp && g.off_ready) {           // planned on the device: the offsets came with the records
         total_delta = g.known_delta;
         d_off = g.d_off;
     } else if (n && !g.all_snp) {
@@ -1014,34 +1040,41 @@ int apply_contig_device(Ctx *c, Contig &g) {
         if (rc) return rc;
         d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
         hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, st,
-                           d_off, g.d_recs, n, d_first, n_tiles + 1);
+                           d_off, g.d_recs, n, d_first, n_tiles + 1, dyn);
         MSIM_HIP(c, hipGetLastError());
     }
     // ---- 3. rewrite
     MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
     MSIM_HIP(c, hipEventRecord(g.ea1, st));
     if (n_tiles) {
+        // small window: mean records per tile < 80 % of it (dyn: only the STRUCTURAL records take window slots, and their
+        // expected number is what the host knows -- mean structural candidates per tile below half the window)
+        const bool small_win = dyn ? g.n_struct_est * 2 < (uint64_t)n_tiles * REC_CAP_SMALL
+                                   : (uint64_t)n * 5 + 64 * 4 < (uint64_t)n_tiles * REC_CAP_SMALL * 4;
         if (g.all_snp)
             hipLaunchKernelGGL(k_rewrite_snp, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
-                               d_first, n, g.out_len, ctx_lut(c), d_err);
-        else if ((uint64_t)n * 5 + 64 * 4 < (uint64_t)n_tiles * REC_CAP_SMALL * 4)   // mean records per tile < 80 % of the small window
+                               d_first, n, g.out_len, ctx_lut(c), d_err, dyn);
+        else if (small_win)
             hipLaunchKernelGGL(k_rewrite<REC_CAP_SMALL>, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
-                               d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err);
+                               d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err, dyn);
         else
             hipLaunchKernelGGL(k_rewrite<REC_CAP>, dim3(n_tiles), dim3(THREADS), 0, st, g.d_in + PAD, g.d_out, g.d_recs,
-                               d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err);
+                               d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err, dyn);
         MSIM_HIP(c, hipGetLastError());
     }
     MSIM_HIP(c, hipEventRecord(g.ea2, st));
     c->t.apply_launches += n_tiles ? 1 : 0;
     c->t.bytes_in += g.len;
-    c->t.bytes_out += g.out_len;
-    c->t.records += n;
+    if (!dyn) {                                            // (dyn: counted when the sizes are collected, apply_finish)
+        c->t.bytes_out += g.out_len;
+        c->t.records += n;
+    }
     g.applied = true;
     g.apply_pending = true;
+    g.dyn_applied = dyn != nullptr;
     g.key_error = false;
     c->pending_apply.push_back(g.index);
-    if (g.all_snp || g.delta_known) return MSIM_OK;        // asynchronous
+    if (g.all_snp || g.delta_known || dyn) return MSIM_OK; // asynchronous
     int rc = apply_finish(c);
     if (rc) return rc;
     if (g.key_error) { g.key_reported = true; return fail(c, MSIM_ERR_KEY, std::string("KeyError: '") + (char)g.key_base + "'"); }

@@ -21,6 +21,14 @@ struct Contig {
     bool delta_known = false;         // the planner already knows out_len - len (SV mixes planned on the device):
     long long known_delta = 0;        //   APPLY needs no round trip for the output size
     bool off_ready = false;           // ... and already left every record's output offset in d_off (k_emit_records)
+    // counter-based engine (plan_fast.hip), types beyond SNPs: how many candidates survive is decided on the device and
+    // nobody waits for it -- n_rec / pool_len / out_len are filled in when a synchronising call collects d_dyn
+    const uint32_t *d_dyn = nullptr;  // {records, mutated length, insert pool bytes, flags} on the device; null: host-known sizes
+    bool sizes_pending = false;       // d_dyn not collected yet
+    bool dyn_applied = false;         // the APPLY in flight was sized by d_dyn (its byte counts are added when collected)
+    uint64_t n_rec_cap = 0;           // candidates: the record table's allocation
+    uint64_t out_cap_len = 0;         // 16-sigma bound of the mutated length: d_out's allocation and the APPLY grid
+    uint64_t n_struct_est = 0;        // expected non-SNP candidates (selects the rewrite kernel's window)
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD
@@ -46,6 +54,7 @@ struct Contig {
 constexpr uint64_t PAD = 64;          // slack after every byte buffer so 16-B vector accesses stay in bounds
 
 struct GpuPlan;
+struct FastPlan;                      // plan_fast.hip: the counter-based PLAN engine's streams + scratch
 struct Comm;                          // comm.cpp: RCCL communicator + receive buffers of the gather
 struct Batch;                         // msim_api.hip: state of msim_batch_run
 
@@ -69,6 +78,7 @@ struct Ctx {
     int deferred_apply = -1;              // contig whose APPLY msim_apply_contig deferred (msim_api.hip), -1: none
     uint64_t fast_key = 0x9E3779B97F4A7C15ull;   // MSIM_RNG_FAST: Philox key (msim_set_fast_key) ...
     uint32_t fast_seq = 0;                //   ... and the ordinal of the next contig planned or walked past
+    FastPlan *fast = nullptr;             //   ... and the engine's streams + scratch (plan_fast.hip)
     msim_timing t{};
     // device scratch
     void *d_scratch = nullptr;
@@ -223,6 +233,18 @@ void count_translocations(const uint8_t *type, const uint32_t *stop, size_t n, s
 // test support (msim_dbg_multimix_plan): the whole engine on the host -- the device's parts (types, tables, keep
 // flags, records) restated sequentially -- so the CPU tier can hold the algorithm against plan_contig_host
 int multimix_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, HostPlan &out);
+
+// plan_fast.hip: the counter-based PLAN engine (MSIM_RNG_FAST)
+struct FastPlan;
+void fast_plan_destroy(Ctx *c);
+// MSIM_OK / MSIM_ERR_VALUE (the reference's ValueError: a sample larger than its population) / MSIM_ERR_UNSUPPORTED
+int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges);
+int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq);
+// everything the engine enqueued has completed (the caller synchronised): sticky flags, sizes of the contigs planned with
+// device-side counts.  Idempotent.
+int fast_plan_collect(Ctx *c);
+// test support (msim_dbg_fast_plan): the engine restated sequentially on the host over the same arithmetic (fast_math.h)
+int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq, HostPlan &out);
 
 // text_gpu.hip
 int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);

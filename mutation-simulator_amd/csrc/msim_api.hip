@@ -65,7 +65,7 @@ static int drain(Ctx *c) {
     if (c->host_only) return MSIM_OK;
     TraceRange tr("msim drain (collect deferred results)");
     int rc = c->gpu ? gpu_plan_finish(c, c->gpu) : MSIM_OK;
-    int rc2 = apply_finish(c);
+    int rc2 = apply_finish(c);                             // (collects the counter-based engine's flags and sizes too)
     if (rc) return rc;
     if (rc2) return rc2;
     MSIM_HIP(c, hipStreamSynchronize(c->stream));
@@ -123,6 +123,9 @@ static void reset_contig(Contig &g) {   // (callers also drop the context's text
     g.delta_known = false;
     g.off_ready = false;
     g.known_delta = 0;
+    g.d_dyn = nullptr;
+    g.sizes_pending = false;
+    g.n_rec_cap = g.out_cap_len = g.n_struct_est = 0;
     g.n_rec = g.pool_len = g.out_len = 0;
     g.h_recs.clear(); g.h_recs.shrink_to_fit();
     g.h_pool.clear(); g.h_pool.shrink_to_fit();
@@ -278,6 +281,7 @@ void msim_destroy(msim_ctx *p) {
     batch_free(c);
     lap(2);
     comm_destroy(c);
+    fast_plan_destroy(c);
     gpu_plan_destroy(c->gpu);
     lap(3);
     if (c->h_mail) (void)hipHostFree(c->h_mail);
@@ -452,15 +456,15 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
     TraceRange tr(c->chain_only ? "msim PLAN contig (chain only)" : "msim PLAN contig");
     if (c->flags & MSIM_RNG_FAST) {                        // counter-based generator: nothing chains, nothing is stream-compatible
         const uint32_t seq = c->fast_seq++;
-        if (c->chain_only) return MSIM_OK;                 // (a contig another rank owns: only its ordinal matters)
+        // (a contig another rank owns: only its ordinal matters -- but what the reference refuses (ValueError) and what this
+        //  mode does not cover is refused on every rank alike)
+        if (c->chain_only) return fast_plan_check(c, g->len, ranges, n_ranges);
         if (c->host_only || !c->gpu) return fail(c, MSIM_ERR_HIP, "fast RNG mode needs the GPU");
-        if (!gpu_plan_fast_eligible(c, ranges, n_ranges))
-            return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: SNP-only ranges (sorted, at most every second position drawn) "
-                                                 "with the SNP block at the minimum block");
         if ((rc = flush_deferred_apply(c))) return rc;
+        if (g->apply_pending && (rc = apply_finish(c))) return rc;      // this contig's tables may still be read by its last APPLY
         reset_contig(*g);
         c->text_kind = 0;
-        rc = plan_contig_fast(c, c->gpu, *g, ranges, n_ranges, c->fast_key, seq);
+        rc = plan_contig_fast(c, *g, ranges, n_ranges, c->fast_key, seq);
         if (!rc) c->t.contigs_fast++;
         return rc;
     }
@@ -574,6 +578,10 @@ int msim_plan_was_empty(msim_ctx *p, int contig, int *empty) {
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    if (g->sizes_pending) {                                // the counter-based engine decides on the device what survives
+        const int rc = drain(c);
+        if (rc) return rc;
+    }
     *empty = g->plan_empty ? 1 : 0;
     return MSIM_OK;
 }
@@ -621,6 +629,10 @@ int msim_result_sizes(msim_ctx *p, int contig, uint64_t *out_len, uint64_t *n_re
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    if (g->sizes_pending) {
+        const int rc = drain(c);
+        if (rc) return rc;
+    }
     if (out_len) {
         if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
         int rc = drain(c);
@@ -710,6 +722,7 @@ int msim_planned_out_len(msim_ctx *p, int contig, uint64_t *out_len, int *known)
     *known = 0;
     *out_len = 0;
     if (!g->planned) return MSIM_OK;                       // (a contig this rank only walked the chain for: its owner knows)
+    if (g->sizes_pending && !g->all_snp) return MSIM_OK;   // (decided on the device, not collected yet)
     if (g->all_snp || g->n_rec == 0) { *known = 1; *out_len = g->len; }
     else if (g->delta_known) { *known = 1; *out_len = (uint64_t)((long long)g->len + g->known_delta); }
     return MSIM_OK;
@@ -949,6 +962,25 @@ int msim_dbg_multimix_plan(msim_ctx *p, uint64_t L, const msim_range *ranges, in
     if (!c->host_only) return fail(c, MSIM_ERR_ARG, "msim_dbg_multimix_plan needs a host-only context");
     HostPlan hp;
     const int rc = multimix_plan_emulated(c, L, ranges, n_ranges, hp);
+    if (rc) return rc;
+    *n_recs = hp.recs.size(); *pool_len = hp.pool.size(); *empty = hp.empty ? 1 : 0;
+    if (recs) {
+        if (cap_recs < hp.recs.size() || cap_pool < hp.pool.size()) return fail(c, MSIM_ERR_ARG, "buffers too small");
+        if (!hp.recs.empty()) memcpy(recs, hp.recs.data(), hp.recs.size() * sizeof(msim_record));
+        if (!hp.pool.empty() && pool) memcpy(pool, hp.pool.data(), hp.pool.size());
+    }
+    return MSIM_OK;
+}
+
+// The counter-based engine (MSIM_RNG_FAST) restated sequentially on the host (fast_plan_emulated): what msim_plan_contig of
+// a fast context leaves for the same key, contig ordinal and ranges.  Works on a host-only context.  recs == NULL: sizes only.
+int msim_dbg_fast_plan(msim_ctx *p, uint64_t L, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq, msim_record *recs,
+                       uint64_t cap_recs, uint8_t *pool, uint64_t cap_pool, uint64_t *n_recs, uint64_t *pool_len, int *empty) {
+    CTX_FLUSHED(c, p)
+    if (!c || !n_recs || !pool_len || !empty || (n_ranges && !ranges)) return MSIM_ERR_ARG;
+    if (!c->have_params) return fail(c, MSIM_ERR_ARG, "msim_set_params has not been called");
+    HostPlan hp;
+    const int rc = fast_plan_emulated(c, L, ranges, n_ranges, key, seq, hp);
     if (rc) return rc;
     *n_recs = hp.recs.size(); *pool_len = hp.pool.size(); *empty = hp.empty ? 1 : 0;
     if (recs) {

@@ -1,0 +1,522 @@
+// PLAN with the counter-based generator (MSIM_RNG_FAST, "--rng fast"): host orchestration.  gfx950 (MI355X) only.
+//
+// fast_math.h: the construction (the reference's, mutator.py:144-265 / util.py:93-109) and its arithmetic;
+// fast_kernels.h: the kernels.  Nothing here is stream-compatible with the reference and nothing chains: a contig is
+// 2 launches (SNP-only settings) or 7-10 (types beyond SNPs) on one of four streams, its APPLY follows on the emit stream
+// behind an event, and the host never waits for a count -- the kernels read record counts and mutated lengths from device
+// memory (Contig::d_dyn), the host collects them at the next synchronising call.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ctx.h"
+#include "fast_kernels.h"
+
+namespace msim {
+
+namespace {
+
+constexpr int F_SETS = 4;                                  // contigs in flight (one stream + one scratch set each)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;                                        // elements
+};
+template <class T>
+struct PinBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+};
+
+struct FastSet {
+    DevBuf<FRange> ranges;
+    DevBuf<Settings> sets;
+    PinBuf<uint8_t> h_tab;                                 // pinned: FRange table + Settings table of the contig in flight
+    DevBuf<LeafDesc> leaves;
+    DevBuf<uint32_t> leaf_m;
+    DevBuf<uint32_t> cand_pos, cand_stop, cand_bend, blk_out;
+    DevBuf<uint8_t> cand_meta;
+    DevBuf<uint32_t> blk_u32;                              // S | indep | in | nrec | pool  (5 arrays of nb + 1)
+    DevBuf<long long> blk_delta;
+    uint32_t *kept_any = nullptr;                          // one word
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+
+}  // namespace
+
+struct FastPlan {
+    hipStream_t lane[F_SETS] = {};
+    FastSet set[F_SETS];
+    uint32_t *d_flags = nullptr;                           // sticky FF_* flags of everything since the last collection
+    DynSizes *d_dyn = nullptr;                             // one per contig of the context
+    DynSizes *h_dyn = nullptr;                             // pinned copy (collection)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    bool pending = false;                                  // work enqueued since the last collection
+    std::vector<int> sized;                                // contigs whose sizes are still on the device only
+};
+
+namespace {
+
+template <class T>
+int dev_grow(Ctx *c, FastPlan *f, DevBuf<T> &b, size_t want) {
+    if (b.cap >= want) return MSIM_OK;
+    // a buffer is replaced: nothing that may still use the old one can be in flight
+    for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+    if (b.p) MSIM_HIP(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    const size_t n = want + want / 4 + 1024;
+    MSIM_HIP(c, hipMalloc(&b.p, n * sizeof(T)));
+    b.cap = n;
+    return MSIM_OK;
+}
+
+struct Prep {
+    std::vector<FRange> fr;
+    std::vector<Settings> sets;
+    uint64_t K = 0;
+    uint64_t n_leaves = 0;
+    uint32_t lgB_max = LG_LEAF_MIN;
+    bool snp_only = true;                                  // every candidate is an SNP that blocks nothing: records straight from the leaves
+    bool all_sn = true;                                    // every candidate is an SNP (no length change)
+    bool need_visit = false;                               // several ranges and a consuming type: the visit filter can drop records
+    uint32_t maxspan = 1, maxspan_visit = 1;
+    uint64_t pool_cap = 0, out_cap = 0, n_struct_est = 0;
+    Block1 block1{};
+    int64_t d = 1;
+};
+
+bool type_drawable(const msim_range &r, int j) {
+    const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+    return r.cdf_thr[j] > lo && lo < (1ull << 53);
+}
+
+// msim_range tables -> what the kernels read.  Returns MSIM_OK, MSIM_ERR_VALUE (the reference's ValueError) or
+// MSIM_ERR_UNSUPPORTED with the reason in c->err.
+int prepare(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, Prep &P) {
+    const msim_params &mp = c->params;
+    int64_t d = mp.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, mp.block[t]);
+    if (d < 0 || d >= (1ll << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: block sizes beyond 2^31");
+    P.d = d;
+    for (int t = 0; t < 8; t++) {
+        const int64_t b = t ? mp.block[t] : 0;
+        P.block1.v[t] = b < 0 ? 1u : (b >= 0xfffffffell ? 0xffffffffu : (uint32_t)(b + 1));
+    }
+    if (L >= (1ull << 32)) return fail(c, MSIM_ERR_UNSUPPORTED, "contig of 4 GiB or more");
+    const bool sn_blocks = mp.block[MSIM_SN] != d;         // an SNP then blocks successors (mutator.py:204-206)
+    int64_t prev_stop = -1;
+    double pool_mean = 0, pool_var = 0, grow_mean = 0, grow_var = 0, max_piece = 0, struct_est = 0;
+    bool consuming = false;
+    uint32_t n_draw = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k == 0) continue;
+        const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
+        // random.sample(range(start, stop - (k - 1) d), k): "Sample larger than population or is negative" (util.py:104)
+        if (r.k < 0 || n < r.k) return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
+        if (r.start < 0 || r.stop >= (1ll << 32) || n >= (1ll << 32))
+            return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: range beyond 2^32 positions");
+        if (r.start <= prev_stop)
+            return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: overlapping or unsorted ranges (the reference's dict semantics) are not covered");
+        if ((uint64_t)r.stop >= L) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: range beyond the contig end");
+        prev_stop = r.stop;
+        if (r.n_types < 1 || r.n_types > 8) return fail(c, MSIM_ERR_ARG, "range with no or more than 8 mutation types");
+        Settings s;
+        memset(&s, 0, sizeof s);
+        s.n_types = (uint32_t)r.n_types;
+        bool sn_only = true;
+        for (int j = 0; j < r.n_types; j++) {
+            s.thr[j] = r.cdf_thr[j];
+            s.type[j] = (uint8_t)r.types[j];
+            if (!type_drawable(r, j)) continue;
+            const int t = r.types[j];
+            const double p = (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - (j ? r.cdf_thr[j - 1] : 0)) / 9007199254740992.0;
+            if (t == MSIM_SN) continue;
+            sn_only = false;
+            if (t == MSIM_TL || t == MSIM_TLI)
+                return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: translocations (-tl) are not covered; use --rng compat");
+            if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return fail(c, MSIM_ERR_ARG, "unknown mutation type");
+            const int64_t lo = r.min_len[t], hi = r.max_len[t];
+            if (lo < 1 || hi < lo || hi >= (1ll << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: mutation lengths outside 1 .. 2^31");
+            struct_est += (double)r.k * p;
+            if (t == MSIM_IN) { pool_mean += (double)r.k * p * hi; pool_var += (double)r.k * p * hi * hi; }
+            if (t == MSIM_IN || t == MSIM_DU) { grow_mean += (double)r.k * p * hi; grow_var += (double)r.k * p * hi * hi; max_piece = std::max(max_piece, (double)hi); }
+            if (t == MSIM_DE || t == MSIM_DU || t == MSIM_IV) {
+                consuming = true;
+                P.maxspan_visit = std::max<uint64_t>(P.maxspan_visit, (uint64_t)hi);
+                P.maxspan = (uint32_t)std::min<uint64_t>(0xffffffffull, std::max<uint64_t>(P.maxspan, (uint64_t)hi - 1 + P.block1.v[t]));
+            } else {
+                P.maxspan = std::max(P.maxspan, P.block1.v[t]);
+            }
+        }
+        P.maxspan = std::max(P.maxspan, P.block1.v[MSIM_SN]);
+        for (int t = 0; t < 8; t++) {
+            const int64_t lo = std::max<int64_t>(r.min_len[t], 0), hi = std::max<int64_t>(r.max_len[t], lo);
+            s.min_len[t] = (uint32_t)std::min<int64_t>(lo, 0x7fffffff);
+            s.max_len[t] = (uint32_t)std::min<int64_t>(hi, 0x7fffffff);
+            s.width[t] = s.max_len[t] - s.min_len[t] + 1;
+        }
+        if (!sn_only) { P.all_sn = false; P.snp_only = false; }
+        if (sn_blocks) P.snp_only = false;
+        uint32_t set = 0;
+        for (; set < P.sets.size(); set++) if (!memcmp(&P.sets[set], &s, sizeof s)) break;
+        if (set == P.sets.size()) P.sets.push_back(s);
+        FRange f;
+        f.start = (uint32_t)r.start;
+        f.n = (uint32_t)n;
+        f.k = (uint32_t)r.k;
+        f.cand_base = (uint32_t)P.K;
+        f.leaf_base = (uint32_t)P.n_leaves;
+        f.lgB = leaf_lg((uint64_t)n, (uint64_t)r.k);
+        f.clip = (uint32_t)std::min<int64_t>(r.stop + 1, 0xffffffffll);
+        f.set = set;
+        P.fr.push_back(f);
+        P.lgB_max = std::max(P.lgB_max, f.lgB);
+        P.K += (uint64_t)r.k;
+        P.n_leaves += ((uint64_t)n + (1ull << f.lgB) - 1) >> f.lgB;
+        n_draw++;
+        if (P.K >= (1ull << 31) || P.n_leaves >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: 2^31 or more candidates on one contig");
+    }
+    if (n_draw >= (1u << 24)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: 2^24 or more drawing ranges on one contig");
+    P.need_visit = n_draw > 1 && consuming;
+    P.n_struct_est = (uint64_t)struct_est;
+    const double pool_cap = pool_mean + 16.0 * std::sqrt(pool_var) + max_piece + 64.0;
+    const double out_cap = (double)L + grow_mean + 16.0 * std::sqrt(grow_var) + max_piece + 64.0;
+    if (!P.all_sn && (pool_cap >= 4.0e9 || out_cap >= 4294967295.0))
+        return fail(c, MSIM_ERR_UNSUPPORTED, "mutated contig (or its insert pool) of 4 GiB or more");
+    P.pool_cap = P.all_sn ? 0 : (uint64_t)pool_cap;
+    P.out_cap = P.all_sn ? L : (uint64_t)out_cap;
+    return MSIM_OK;
+}
+
+int ensure_plan(Ctx *c) {
+    if (c->fast) return MSIM_OK;
+    FastPlan *f = new FastPlan();
+    c->fast = f;
+    for (auto &st : f->lane) MSIM_HIP(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (auto &s : f->set) {
+        MSIM_HIP(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        MSIM_HIP(c, hipMalloc(&s.kept_any, 64));
+    }
+    MSIM_HIP(c, hipMalloc(&f->d_flags, 64));
+    MSIM_HIP(c, hipMemset(f->d_flags, 0, 64));
+    MSIM_HIP(c, hipMalloc(&f->d_dyn, sizeof(DynSizes) * MAX_CONTIGS));
+    MSIM_HIP(c, hipHostMalloc(&f->h_dyn, sizeof(DynSizes) * MAX_CONTIGS + 64, hipHostMallocDefault));
+    MSIM_HIP(c, hipEventCreate(&f->t0));
+    MSIM_HIP(c, hipEventCreate(&f->t1));
+    return MSIM_OK;
+}
+
+}  // namespace
+
+void fast_plan_destroy(Ctx *c) {
+    FastPlan *f = c->fast;
+    if (!f) return;
+    for (auto st : f->lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto &s : f->set) {
+        void *bufs[] = {s.ranges.p, s.sets.p, s.leaves.p, s.leaf_m.p, s.cand_pos.p, s.cand_stop.p, s.cand_bend.p, s.blk_out.p,
+                        s.cand_meta.p, s.blk_u32.p, s.blk_delta.p, s.kept_any};
+        for (void *p : bufs) if (p) (void)hipFree(p);
+        if (s.h_tab.p) (void)hipHostFree(s.h_tab.p);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    if (f->d_flags) (void)hipFree(f->d_flags);
+    if (f->d_dyn) (void)hipFree(f->d_dyn);
+    if (f->h_dyn) (void)hipHostFree(f->h_dyn);
+    if (f->t0) (void)hipEventDestroy(f->t0);
+    if (f->t1) (void)hipEventDestroy(f->t1);
+    delete f;
+    c->fast = nullptr;
+}
+
+int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges) {
+    Prep P;
+    return prepare(c, L, ranges, n_ranges, P);
+}
+
+int fast_plan_collect(Ctx *c) {
+    FastPlan *f = c->fast;
+    if (!f || !f->pending) return MSIM_OK;
+    f->pending = false;
+    for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+    MSIM_HIP(c, hipEventRecord(f->t1, f->lane[0]));
+    MSIM_HIP(c, hipStreamSynchronize(f->lane[0]));
+    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    float ms = 0;
+    MSIM_HIP(c, hipEventElapsedTime(&ms, f->t0, f->t1));
+    c->t.plan_gpu_ms += ms;
+    for (auto &s : f->set) s.pending = false;
+    uint32_t flags = 0;
+    MSIM_HIP(c, hipMemcpy(&flags, f->d_flags, sizeof flags, hipMemcpyDeviceToHost));
+    if (!f->sized.empty()) {
+        int hi = 0;
+        for (int idx : f->sized) hi = std::max(hi, idx);
+        MSIM_HIP(c, hipMemcpy(f->h_dyn, f->d_dyn, sizeof(DynSizes) * (size_t)(hi + 1), hipMemcpyDeviceToHost));
+        for (int idx : f->sized) {
+            if ((size_t)idx >= c->contigs.size()) continue;
+            Contig &g = c->contigs[(size_t)idx];
+            if (!g.sizes_pending) continue;
+            const DynSizes s = f->h_dyn[idx];
+            flags |= s.flags & 0xffu;
+            g.sizes_pending = false;
+            g.d_dyn = nullptr;                             // host-known from here on (an APPLY in flight keeps its copy of the pointer)
+            g.n_rec = s.n_rec;
+            g.pool_len = s.pool_len;
+            g.plan_empty = !(s.flags & 0x100u);
+            if (!g.all_snp) {
+                g.known_delta = (long long)s.out_len - (long long)g.len;
+                g.delta_known = true;
+                if (g.applied) g.out_len = s.out_len;
+            }
+        }
+        f->sized.clear();
+    }
+    if (flags) {
+        MSIM_HIP(c, hipMemset(f->d_flags, 0, 64));
+        if (flags & (FF_POOL_OVERFLOW | FF_OUT_OVERFLOW))
+            return fail(c, MSIM_ERR_HIP, "fast RNG sampler: the mutated length or the insert pool overflowed its 16-sigma allocation (results discarded)");
+        return fail(c, MSIM_ERR_HIP, "fast RNG sampler: internal error (flags " + std::to_string(flags) + "; results discarded)");
+    }
+    return MSIM_OK;
+}
+
+int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key64, uint32_t seq) {
+    Prep P;
+    int rc = prepare(c, ct.len, ranges, n_ranges, P);
+    if (rc) return rc;
+    const uint64_t K = P.K;
+    ct.n_rec = P.snp_only ? K : 0;
+    ct.n_rec_cap = K;
+    ct.pool_len = 0;
+    ct.plan_empty = K == 0;
+    ct.all_snp = P.all_sn;
+    ct.d_dyn = nullptr;
+    ct.sizes_pending = false;
+    ct.out_cap_len = P.out_cap;
+    ct.n_struct_est = P.n_struct_est;
+    ct.planned = true;
+    if (!K) return MSIM_OK;
+    if ((rc = ensure_plan(c))) return rc;
+    FastPlan *f = c->fast;
+    // scratch set and stream by the contig's ordinal: a genome planned again finds every buffer at its size
+    const uint32_t li = seq % F_SETS;
+    FastSet &S = f->set[li];
+    hipStream_t st = f->lane[li];
+    if (S.pending) {                                       // its last user's tables may still be in flight
+        MSIM_HIP(c, hipEventSynchronize(S.done));
+        S.pending = false;
+    }
+    if (!f->pending) MSIM_HIP(c, hipEventRecord(f->t0, st));
+    f->pending = true;
+    const Key key{(uint32_t)key64, (uint32_t)(key64 >> 32), seq};
+    const uint32_t n_draw = (uint32_t)P.fr.size(), n_sets = (uint32_t)P.sets.size();
+    const uint32_t n_leaves = (uint32_t)P.n_leaves;
+    // ---- tables
+    const size_t tab_bytes = (size_t)n_draw * sizeof(FRange) + (size_t)n_sets * sizeof(Settings);
+    if (S.h_tab.cap < tab_bytes) {
+        if (S.h_tab.p) MSIM_HIP(c, hipHostFree(S.h_tab.p));
+        S.h_tab.p = nullptr; S.h_tab.cap = 0;
+        MSIM_HIP(c, hipHostMalloc(&S.h_tab.p, tab_bytes * 2 + 4096, hipHostMallocDefault));
+        S.h_tab.cap = tab_bytes * 2 + 4096;
+    }
+    if ((rc = dev_grow(c, f, S.ranges, n_draw))) return rc;
+    if ((rc = dev_grow(c, f, S.sets, n_sets))) return rc;
+    if ((rc = dev_grow(c, f, S.leaves, n_leaves))) return rc;
+    if ((rc = dev_grow(c, f, S.leaf_m, (size_t)n_leaves + 1))) return rc;
+    memcpy(S.h_tab.p, P.fr.data(), (size_t)n_draw * sizeof(FRange));
+    memcpy(S.h_tab.p + (size_t)n_draw * sizeof(FRange), P.sets.data(), (size_t)n_sets * sizeof(Settings));
+    {   // the record table (and what APPLY reads beside it) may still be in use by an earlier APPLY of this contig
+        const size_t want = (size_t)K * sizeof(msim_record);
+        const size_t want_pool = (size_t)P.pool_cap + 2 * PAD, want_off = P.all_sn ? 0 : (size_t)K * sizeof(uint32_t);
+        if (ct.cap_recs < want || ct.cap_pool < want_pool || ct.cap_off < want_off) {
+            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        } else if (ct.apply_pending && ct.ea2) {
+            MSIM_HIP(c, hipStreamWaitEvent(st, ct.ea2, 0));
+        }
+        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, want_pool))) return rc;
+        if (want_off && (rc = dev_reserve(c, (void **)&ct.d_off, &ct.cap_off, want_off))) return rc;
+    }
+    MSIM_HIP(c, hipMemcpyAsync(S.ranges.p, S.h_tab.p, (size_t)n_draw * sizeof(FRange), hipMemcpyHostToDevice, st));
+    if (!P.snp_only)
+        MSIM_HIP(c, hipMemcpyAsync(S.sets.p, S.h_tab.p + (size_t)n_draw * sizeof(FRange), (size_t)n_sets * sizeof(Settings),
+                                   hipMemcpyHostToDevice, st));
+    // ---- positions
+    hipLaunchKernelGGL(k_fsplit, dim3(n_draw), dim3(256), 0, st, S.ranges.p, key, S.leaf_m.p, S.leaves.p, f->d_flags);
+    const uint32_t bm_words = (1u << P.lgB_max) / 32 + 2;
+    const size_t lds = (size_t)4 * bm_words * sizeof(uint32_t);
+    const uint32_t leaf_blocks = (n_leaves + 3) / 4;
+    if (P.snp_only) {
+        hipLaunchKernelGGL(k_fleaf<false>, dim3(leaf_blocks), dim3(256), lds, st, S.ranges.p, S.leaves.p, n_leaves, bm_words, key,
+                           (uint32_t)P.d, ct.len, (const Settings *)nullptr, P.block1, (unsigned long long)c->params.ti_lim, ct.d_recs,
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, f->d_flags);
+        MSIM_HIP(c, hipGetLastError());
+    } else {
+        const uint32_t nb = (uint32_t)((K + OB_BLOCK - 1) / OB_BLOCK);
+        if ((rc = dev_grow(c, f, S.cand_pos, K))) return rc;
+        if ((rc = dev_grow(c, f, S.cand_stop, K))) return rc;
+        if ((rc = dev_grow(c, f, S.cand_bend, K))) return rc;
+        if ((rc = dev_grow(c, f, S.blk_out, K))) return rc;
+        if ((rc = dev_grow(c, f, S.cand_meta, K + 16))) return rc;
+        if ((rc = dev_grow(c, f, S.blk_u32, (size_t)5 * (nb + 1)))) return rc;
+        if ((rc = dev_grow(c, f, S.blk_delta, (size_t)nb + 1))) return rc;
+        uint32_t *blk_S = S.blk_u32.p, *blk_indep = blk_S + (nb + 1), *blk_in = blk_indep + (nb + 1), *blk_nrec = blk_in + (nb + 1),
+                 *blk_pool = blk_nrec + (nb + 1);
+        hipLaunchKernelGGL(k_fleaf<true>, dim3(leaf_blocks), dim3(256), lds, st, S.ranges.p, S.leaves.p, n_leaves, bm_words, key,
+                           (uint32_t)P.d, ct.len, S.sets.p, P.block1, (unsigned long long)c->params.ti_lim, (msim_record *)nullptr,
+                           S.cand_pos.p, S.cand_stop.p, S.cand_bend.p, S.cand_meta.p, f->d_flags);
+        MSIM_HIP(c, hipMemsetAsync(S.kept_any, 0, 4, st));
+        // ---- boundary pass (mutator.py:184-213)
+        hipLaunchKernelGGL(k_forbit_local, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, (uint32_t)K, P.maxspan,
+                           S.blk_out.p, blk_S, blk_indep);
+        hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)K, nb, blk_in);
+        if (!P.need_visit) {
+            hipLaunchKernelGGL((k_forbit_mark<false, true>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, S.cand_stop.p,
+                               S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any);
+        } else {
+            hipLaunchKernelGGL((k_forbit_mark<false, false>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, S.cand_stop.p,
+                               S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any);
+            // ---- visit filter (mutator.py:376,386,398): the same orbit over what the kept records consume
+            hipLaunchKernelGGL(k_forbit_local, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, (uint32_t)K, P.maxspan_visit,
+                               S.blk_out.p, blk_S, blk_indep);
+            hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)K, nb, blk_in);
+            hipLaunchKernelGGL((k_forbit_mark<true, true>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, S.cand_stop.p,
+                               S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any);
+        }
+        DynSizes *dyn = f->d_dyn + ct.index;
+        hipLaunchKernelGGL(k_fscan, dim3(1), dim3(1024), 0, st, blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap,
+                           S.kept_any, f->d_flags, dyn);
+        hipLaunchKernelGGL(k_femit, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, (uint32_t)K, blk_nrec,
+                           blk_pool, S.blk_delta.p, dyn, key, (unsigned long long)c->params.ti_lim, ct.d_recs,
+                           P.all_sn ? S.blk_out.p : ct.d_off, ct.d_pool + PAD);
+        MSIM_HIP(c, hipGetLastError());
+        ct.d_dyn = reinterpret_cast<const uint32_t *>(dyn);
+        ct.sizes_pending = true;
+        ct.off_ready = !P.all_sn;
+        f->sized.push_back(ct.index);
+    }
+    // ---- whatever reads the records (APPLY, text) runs on the emit stream behind this contig's PLAN
+    MSIM_HIP(c, hipEventRecord(S.done, st));
+    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, S.done, 0));
+    S.pending = true;
+    return MSIM_OK;
+}
+
+// ======================================================================================== host restatement (test support)
+// The engine, sequentially: the same draws (fast_math.h), but the boundary pass and the visit filter written the way the
+// reference writes them (mutator.py:184-213: a blocked range that is reset per range; :318-421: the rewrite's walk) rather
+// than as orbits -- so that the CPU tier holds the kernels' formulation against the plain one (tests/test_fast_host.py).
+int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, uint64_t key64, uint32_t seq, HostPlan &out) {
+    Prep P;
+    int rc = prepare(c, L, ranges, n_ranges, P);
+    if (rc) return rc;
+    const Key key{(uint32_t)key64, (uint32_t)(key64 >> 32), seq};
+    out.recs.clear();
+    out.pool.clear();
+    out.empty = true;
+    struct Kept { uint32_t pos, stop, ord; uint8_t type; };
+    std::vector<Kept> kept;
+    for (size_t ri = 0; ri < P.fr.size(); ri++) {
+        const FRange &R = P.fr[ri];
+        const uint32_t lgB = R.lgB, B = 1u << lgB;
+        const uint32_t T = (uint32_t)(((uint64_t)R.n + B - 1) >> lgB);
+        uint32_t lgP = 0;
+        while ((1u << lgP) < T) lgP++;
+        std::vector<uint32_t> m((size_t)1 << lgP, 0);
+        m[0] = R.k;
+        for (uint32_t lev = 0; lev < lgP; lev++) {
+            const uint32_t S = 1u << (lgP - lev), half = S >> 1;
+            for (uint32_t i = 0; i < (1u << lev); i++) {
+                const uint32_t a = i * S, mid = a + half;
+                if (mid >= T) continue;
+                const uint32_t Kn = m[a];
+                const uint64_t va = (uint64_t)a << lgB, vm = (uint64_t)mid << lgB, vb = std::min((uint64_t)(a + S) << lgB, (uint64_t)R.n);
+                const uint32_t kl = (uint32_t)hypergeometric(vm - va, vb - vm, Kn, key, (1u << lev) + i, (uint32_t)ri);
+                m[a] = kl;
+                m[mid] = Kn - kl;
+            }
+        }
+        uint32_t ord = R.cand_base;
+        int64_t blocked_end = 0;                                         // last_mut_range = range(0)   mutator.py:184
+        std::vector<uint8_t> seen;
+        for (uint32_t t = 0; t < T; t++) {
+            const uint32_t v0 = t << lgB, len = std::min(B, R.n - v0), mt = m[t];
+            if (!mt) continue;
+            const bool inv = 2 * mt > len;
+            const uint32_t need = inv ? len - mt : mt;
+            seen.assign(len, 0);
+            for (uint32_t have = 0, j = 0; have < need; j++) {
+                const uint32_t v = leaf_draw(key, R.leaf_base + t, j, len);
+                if (!seen[v]) { seen[v] = 1; have++; }
+            }
+            for (uint32_t v = 0; v < len; v++) {
+                if ((seen[v] != 0) == inv) continue;
+                const uint32_t pos = R.start + v0 + v + (uint32_t)P.d * (ord - R.cand_base);
+                const Cand cd = cand_draw(key, ord, pos, L, P.sets[R.set], P.block1.v, R.clip);
+                const uint32_t o = ord++;
+                if ((int64_t)pos < blocked_end) continue;                // mutator.py:190-192
+                if (cd.meta & CAND_DROPPED) continue;                    // mutator.py:199-201
+                const uint8_t ty = cd.meta & 7;
+                blocked_end = (ty == MSIM_SN || ty == MSIM_IN) ? (int64_t)pos + P.block1.v[ty] : (int64_t)cd.stop + P.block1.v[ty];
+                kept.push_back({pos, cd.stop, o, ty});
+            }
+        }
+    }
+    out.empty = kept.empty();
+    int64_t cover = -1;                                                  // last base an earlier visited record consumed
+    for (const Kept &q : kept) {
+        if ((int64_t)q.pos <= cover) continue;                           // never visited   mutator.py:376,386,398
+        msim_record rec;
+        rec.pos = q.pos; rec.stop = q.stop; rec.extra = 0; rec.type = q.type; rec.aux = 0; rec.rsv = 0;
+        if (q.type == MSIM_SN) rec.aux = snp_outcome(key, q.ord, c->params.ti_lim);
+        if (q.type == MSIM_IN) {
+            rec.extra = (uint32_t)out.pool.size();
+            const uint32_t len = q.stop - q.pos + 1;
+            for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+                const U4 ch = draw4(key, c0 >> 6, q.ord, TAG_INS);
+                for (uint32_t j = 0; j < std::min(64u, len - c0); j++) out.pool.push_back(insert_base_of(ch, j));
+            }
+        }
+        if (q.type == MSIM_DE || q.type == MSIM_DU || q.type == MSIM_IV) cover = q.stop;
+        out.recs.push_back(rec);
+    }
+    return MSIM_OK;
+}
+
+}  // namespace msim
+
+// ---- test support: the arithmetic of fast_math.h from the host (tests/test_fast_host.py holds it against the numpy restatement
+// and against the exact hypergeometric law) -- no context, no GPU
+extern "C" {
+
+// out[i] = Hypergeometric(good, bad, sample) drawn from node counter node0 + i of drawing range `range`
+int msim_dbg_fast_hypergeom(uint64_t good, uint64_t bad, uint64_t sample, uint64_t key, uint32_t seq, uint32_t node0, uint32_t range,
+                            uint64_t n, uint64_t *out) {
+    if (!out || sample > good + bad) return MSIM_ERR_ARG;
+    const msim::fastrng::Key k{(uint32_t)key, (uint32_t)(key >> 32), seq};
+    for (uint64_t i = 0; i < n; i++) out[i] = msim::fastrng::hypergeometric(good, bad, sample, k, node0 + (uint32_t)i, range);
+    return MSIM_OK;
+}
+// op 0: d_log(x)  1: d_sqrt(x)  2: log_factorial((uint64) x)  3: d_log1p(x)  4: log_factorial_diff((uint64) x, (int64) y[i])
+int msim_dbg_fast_math(int op, const double *x, const double *y, uint64_t n, double *out) {
+    if (!x || !out) return MSIM_ERR_ARG;
+    for (uint64_t i = 0; i < n; i++) {
+        switch (op) {
+            case 0: out[i] = msim::fastrng::d_log(x[i]); break;
+            case 1: out[i] = msim::fastrng::d_sqrt(x[i]); break;
+            case 2: out[i] = msim::fastrng::log_factorial((uint64_t)x[i]); break;
+            case 3: out[i] = msim::fastrng::d_log1p(x[i]); break;
+            case 4: if (!y) return MSIM_ERR_ARG; out[i] = msim::fastrng::log_factorial_diff((uint64_t)x[i], (int64_t)y[i]); break;
+            default: return MSIM_ERR_ARG;
+        }
+    }
+    return MSIM_OK;
+}
+
+}
+

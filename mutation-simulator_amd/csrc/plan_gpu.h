@@ -24,8 +24,6 @@ bool gpu_plan_mixed_eligible(const Ctx *c, const msim_range *ranges, int n_range
 int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 // deterministic-SNP ranges of any size and number (RMT mode): the host walks the chain of samples over words the
 // device generated; records, SNP draws and APPLY stay on the device
-bool gpu_plan_fast_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
-int plan_contig_fast(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq);
 bool gpu_plan_hostsample_eligible(const Ctx *c, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
 // everything else that is still a plain chain: several ranges with their own settings, SV types on many small ranges,

@@ -103,8 +103,6 @@ struct MixedSet {                        // scratch of one SV-mix range (section
     uint8_t *nsn_aux = nullptr; size_t cap_naux = 0;
     uint8_t *mm_d = nullptr; size_t cap_mm_d = 0;         //   range table | settings' type tables | visit_from
     uint8_t *mm_h = nullptr; size_t cap_mm_h = 0;         //   its pinned staging (one per set: the copies are asynchronous)
-    FastState *fast_st = nullptr; size_t cap_fast_st = 0;        // fast RNG mode: per-range round state,
-    uint32_t *fast_prefix = nullptr; size_t cap_fast_prefix = 0; //   prefix of the round's draws over the ranges (+ total)
     hipEvent_t emit_done = nullptr;
     bool pending = false;
 };
@@ -131,13 +129,6 @@ struct GpuPlan {
     uint32_t *d_poly = nullptr;
     PlanState *d_ps = nullptr;
     PlanState *h_mail = nullptr;        // pinned, device-visible mailbox
-    uint32_t *d_fast = nullptr;         // fast RNG mode: [0] sticky flags, [1] draws of the current round
-    static constexpr int FAST_LANES = 4;                     //   contigs are independent: their chains go round-robin over streams
-    hipStream_t fast_stream[FAST_LANES] = {};
-    uint32_t fast_lane = 0;
-    uint32_t *fast_raw[FAST_LANES] = {}; size_t cap_fast_raw[FAST_LANES] = {};   //   one big range: the contig's own word stream ...
-    PlanState *d_ps_fast = nullptr;     //   ... and the bookkeeping blocks (one per lane) the binned sampler keeps over them
-    bool fast_pending = false;          //   work enqueued whose flag has not been looked at
     // handover without a stream synchronisation (SV mix): sequence number of the mailbox (never 0), written last
     uint32_t *h_sig = nullptr;
     uint32_t epoch = 0;
@@ -232,7 +223,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     for (auto &t : g->mixed) {
         void *bufs[] = {t.cand_pos, t.cand_type, t.cand_stop, t.nsn_pos, t.nsn_type, t.nsn_rank, t.nsn_stop, t.sn_index,
                         t.cnt, t.words, t.walk_d, t.wbits, t.wcnt, t.p0_slot, t.tables, t.mm_d, t.cand_extra, t.cand_aux,
-                        t.nsn_extra, t.nsn_aux, t.fast_st, t.fast_prefix};
+                        t.nsn_extra, t.nsn_aux};
         for (void *b : bufs) if (b) (void)hipFree(b);
         host_stage_free(t.walk_h);
         host_stage_free(t.mm_h);
@@ -247,10 +238,6 @@ void gpu_plan_destroy(GpuPlan *g) {
     for (auto e : g->seed_ev) if (e) (void)hipEventDestroy(e);
     if (g->d_poly) (void)hipFree(g->d_poly);
     if (g->d_ps) (void)hipFree(g->d_ps);
-    if (g->d_fast) (void)hipFree(g->d_fast);
-    for (auto p : g->fast_raw) if (p) (void)hipFree(p);
-    for (auto st : g->fast_stream) if (st) (void)hipStreamDestroy(st);
-    if (g->d_ps_fast) (void)hipFree(g->d_ps_fast);
     if (g->h_mail) (void)hipHostFree(g->h_mail);
     if (g->h_sig) (void)hipHostFree(g->h_sig);
     if (g->copy_stream) (void)hipStreamDestroy(g->copy_stream);
@@ -547,31 +534,6 @@ bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
 
 // Everything enqueued so far has completed: collect the sticky flags and the exact stream position.
 int gpu_plan_finish(Ctx *c, GpuPlan *g) {
-    if (g->fast_pending) {                                 // fast RNG mode: nothing chains; one sticky flag to look at
-        g->fast_pending = false;
-        for (auto st : g->fast_stream) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
-        MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-        float ms = 0;
-        MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
-        c->t.plan_gpu_ms += ms;
-        for (auto &t : g->mixed) t.pending = false;
-        uint32_t flag = 0;
-        MSIM_HIP(c, hipMemcpy(&flag, g->d_fast, sizeof flag, hipMemcpyDeviceToHost));
-        if (g->d_ps_fast) {                                // (the binned sampler's own sticky flags: a window's 16-sigma margin)
-            PlanState h[GpuPlan::FAST_LANES];
-            MSIM_HIP(c, hipMemcpy(h, g->d_ps_fast, sizeof h, hipMemcpyDeviceToHost));
-            for (auto &t : g->sample) t.pending = false;
-            for (const PlanState &q : h) if (q.flags & FLAG_SAMPLE_OVERFLOW) flag |= 2u;
-        }
-        if (flag) {
-            MSIM_HIP(c, hipMemset(g->d_fast, 0, 8));
-            for (auto &t : g->mixed) t.wbits_dirty = true;
-            if (g->d_ps_fast) MSIM_HIP(c, hipMemset(g->d_ps_fast, 0, sizeof(PlanState) * GpuPlan::FAST_LANES));
-            return fail(c, MSIM_ERR_HIP, "fast RNG sampler: a range did not reach its k distinct positions (results discarded)");
-        }
-    }
     if (!g->unverified) return MSIM_OK;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
     MSIM_HIP(c, hipGetLastError());
@@ -1583,196 +1545,6 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     return MSIM_OK;
 }
 
-
-// ====================================================================== fast RNG mode (plan_kernels.h: Philox, rounds)
-// SNP-only settings; nothing of it is stream-compatible with the reference (see the kernels' header).  Every contig is
-// independent: all of PLAN on the plan stream, the records' consumers (APPLY, text) behind an event on the emit stream.
-bool gpu_plan_fast_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
-    const msim_params &P = c->params;
-    int64_t d = P.block[1];
-    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
-    if (P.block[MSIM_SN] != d) return false;
-    int64_t prev_stop = -1;
-    uint64_t K = 0;
-    for (int i = 0; i < n_ranges; i++) {
-        const msim_range &r = ranges[i];
-        if (r.k == 0) continue;
-        const int64_t n = (r.stop - (r.k - 1) * d) - r.start;
-        if (r.k < 0 || n < 2 * r.k || n >= (1ll << 32)) return false;     // (denser than every second slot: not for the round scheme)
-        if (r.start <= prev_stop || r.stop >= (1ll << 32)) return false;
-        if (!range_is_deterministic_sn(r)) return false;
-        prev_stop = r.stop;
-        K += (uint64_t)r.k;
-    }
-    return K < (1ull << 31);
-}
-
-int plan_contig_fast(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq) {
-    const msim_params &P = c->params;
-    int64_t d = P.block[1];
-    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
-    int rc;
-    uint64_t K = 0;
-    uint32_t n_draw = 0;
-    double q_max = 0;
-    for (int i = 0; i < n_ranges; i++) {
-        const msim_range &r = ranges[i];
-        if (r.k == 0) continue;
-        n_draw++;
-        K += (uint64_t)r.k;
-        q_max = std::max(q_max, (double)r.k / (double)((r.stop - (r.k - 1) * d) - r.start));
-    }
-    ct.n_rec = K;
-    ct.pool_len = 0;
-    ct.plan_empty = K == 0;
-    ct.all_snp = true;
-    ct.planned = true;
-    if (!K || c->chain_only) return MSIM_OK;
-    if (!g->t0) { MSIM_HIP(c, hipEventCreate(&g->t0)); MSIM_HIP(c, hipEventCreate(&g->t1)); }
-    if (!g->d_fast) { MSIM_HIP(c, hipMalloc(&g->d_fast, 8)); MSIM_HIP(c, hipMemset(g->d_fast, 0, 8)); }
-    if (!g->fast_pending) MSIM_HIP(c, hipEventRecord(g->t0, c->stream));
-    g->fast_pending = true;
-    // contigs are independent: their latency-bound chains of small kernels go round-robin over a few streams (the helpers all
-    // launch on c->stream: it is switched for the duration of this call)
-    // (scratch sets and lanes by the contig's ordinal, so that a genome planned again finds every buffer at its size: with
-    //  the engines' free-running rotation a big contig kept landing on sets a small one had sized -- 1 ms of free + malloc)
-    g->unit = g->mixed_unit = g->fast_lane = seq;
-    const uint32_t lane = g->fast_lane++ % GpuPlan::FAST_LANES;
-    if (!g->fast_stream[lane]) MSIM_HIP(c, hipStreamCreateWithFlags(&g->fast_stream[lane], hipStreamNonBlocking));
-    struct StreamSwap {
-        Ctx *c; hipStream_t saved;
-        ~StreamSwap() { c->stream = saved; }
-    } swap{c, c->stream};
-    c->stream = g->fast_stream[lane];
-    bool grew = false;
-    static const bool prof = getenv("MSIM_CHAIN_PROF") != nullptr;
-    const auto tp0 = std::chrono::steady_clock::now();
-    MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
-    if (M.pending) {                                       // its last user's records / pinned range table may still be in flight
-        MSIM_HIP(c, hipEventSynchronize(M.emit_done));
-        M.pending = false;
-    }
-    const auto tp1 = std::chrono::steady_clock::now();
-    if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
-    if ((rc = grow(c, (void **)&M.walk_d, &M.cap_walk_d, (size_t)n_draw * sizeof(WalkRange) + 64, &grew))) return rc;
-    if ((rc = grow_host(c, (void **)&M.walk_h, &M.cap_walk_h, (size_t)n_draw * sizeof(WalkRange) + 64))) return rc;
-    if ((rc = grow(c, (void **)&M.fast_st, &M.cap_fast_st, (size_t)n_draw * sizeof(FastState) + 64, &grew))) return rc;
-    if ((rc = grow(c, (void **)&M.fast_prefix, &M.cap_fast_prefix, ((size_t)n_draw + 4) * 4, &grew))) return rc;
-    const uint32_t bmw = (uint32_t)((ct.len + 63) / 64);  // contig-wide bitmap, 64-bit words
-    const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
-    {
-        const size_t want = (size_t)bmw * 8 + 64;
-        if (M.cap_wbits < want) {
-            const size_t before = M.cap_wbits;
-            if ((rc = grow(c, (void **)&M.wbits, &M.cap_wbits, want, &grew))) return rc;
-            if (M.cap_wbits != before) MSIM_HIP(c, hipMemset(M.wbits, 0, M.cap_wbits));   // k_walk_expand leaves it zeroed
-        }
-        if (M.wbits_dirty) {
-            MSIM_HIP(c, hipMemsetAsync(M.wbits, 0, M.cap_wbits, c->stream));
-            M.wbits_dirty = false;
-        }
-    }
-    if ((rc = grow(c, (void **)&M.wcnt, &M.cap_wcnt, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
-    {   // the record table may still be read by an earlier apply of this contig
-        const size_t want = (size_t)K * sizeof(msim_record);
-        if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-        }
-        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
-        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
-    }
-    {
-        uint32_t at = 0, base = 0;
-        for (int i = 0; i < n_ranges; i++) {
-            const msim_range &r = ranges[i];
-            if (r.k == 0) continue;
-            WalkRange w;
-            w.start = (uint32_t)r.start; w.k = (uint32_t)r.k; w.n = (uint32_t)((r.stop - (r.k - 1) * d) - r.start);
-            w.rec_base = base; w.pool = 0;
-            M.walk_h[at++] = w;
-            base += (uint32_t)r.k;
-        }
-    }
-    MSIM_HIP(c, hipMemcpyAsync(M.walk_d, M.walk_h, (size_t)n_draw * sizeof(WalkRange), hipMemcpyHostToDevice, c->stream));
-    // rounds over the whole grid while a round still has thousands of draws to make (a round leaves about a fraction
-    // q = k / n of its draws missing again), then the tail in one launch
-    const double q = std::min(0.5, std::max(q_max, 1e-9));
-    const uint2 k2 = make_uint2((uint32_t)key, (uint32_t)(key >> 32));
-    if (n_draw == 1 && K >= 65536) {
-        // One big range (ARGS mode): global atomics into a 30 MB bitmap make 2.5 M draws cost 0.5 ms; the binned sampler of
-        // section 3 (LDS counting sort by 2^20-value bin, LDS bitmaps) does it in a tenth.  It wants a word stream: the
-        // contig gets one of its own, position 0.
-        const msim_range *rp = nullptr;
-        for (int i = 0; i < n_ranges; i++) if (ranges[i].k) rp = &ranges[i];
-        const msim_range &r = *rp;
-        const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
-        const double p_acc = (double)n / (double)(1ull << bit_length64(n));
-        const double need_acc = -(double)n * std::log1p(-(double)r.k / (double)n);
-        const double target = need_acc + 16.0 * std::sqrt(need_acc) + 4096.0;
-        const double wd = target / p_acc + 16.0 * std::sqrt(target) / p_acc + 8192.0;      // (enqueue_sample_chain's window)
-        if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
-        const uint32_t W = (uint32_t)wd + 64;
-        if ((rc = grow(c, (void **)&g->fast_raw[lane], &g->cap_fast_raw[lane], (size_t)W * 4 + 64, &grew))) return rc;
-        if (!g->d_ps_fast) {
-            MSIM_HIP(c, hipMalloc(&g->d_ps_fast, sizeof(PlanState) * GpuPlan::FAST_LANES));
-            MSIM_HIP(c, hipMemset(g->d_ps_fast, 0, sizeof(PlanState) * GpuPlan::FAST_LANES));
-        }
-        PlanState *ps_lane = g->d_ps_fast + lane;
-        hipLaunchKernelGGL(k_fast_words, dim3((W / 4 + 256) / 256), dim3(256), 0, c->stream, g->fast_raw[lane], W, k2, seq);
-        hipLaunchKernelGGL(k_state_init_keep_flags, dim3(1), dim3(1), 0, c->stream, ps_lane);
-        SampleLaunch sl;
-        if ((rc = enqueue_sample_chain(c, g, r, d, 0, grew, sl, g->fast_raw[lane], ps_lane))) return rc;
-        SampleSet &S = *sl.S;
-        // the records on the emit stream: behind whatever APPLY of this contig still reads the table, ahead of the next one
-        hipEvent_t ce = next_chain_event(g);
-        MSIM_HIP(c, hipEventRecord(ce, c->stream));
-        MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-        hipLaunchKernelGGL(k_bitmap_count, dim3(sl.bnb), dim3(BM_THREADS), 0, c->emit_stream, reinterpret_cast<const uint64_t *>(S.bitmap),
-                           sl.bmw, S.cnt2);
-        hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, S.cnt2, sl.bnb);
-        hipLaunchKernelGGL(k_bitmap_expand, dim3(sl.bnb), dim3(BM_THREADS), 0, c->emit_stream, reinterpret_cast<const uint64_t *>(S.bitmap),
-                           sl.bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d, ct.d_recs);
-        hipLaunchKernelGGL(k_fast_aux, dim3(((uint32_t)K + 255) / 256), dim3(256), 0, c->emit_stream, ct.d_recs, (uint32_t)K, k2, seq,
-                           (unsigned long long)P.ti_lim);
-        MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
-        S.pending = true;
-        MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
-        M.pending = true;
-        if (prof) {
-            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-            fprintf(stderr, "fast: K %llu wait-set %.0f us, enqueue %.0f us\n", (unsigned long long)K, us(tp0, tp1), us(tp1, std::chrono::steady_clock::now()));
-        }
-        return MSIM_OK;
-    }
-    uint32_t *d_total = M.fast_prefix + n_draw + 1;        // (behind the prefix array's n_draw + 1 entries)
-    double expect = (double)K;
-    for (int r = 0; r < 64 && (r == 0 || expect > 2048.0); r++) {
-        hipLaunchKernelGGL(k_fast_prefix, dim3(1), dim3(1024), 0, c->stream, M.walk_d, n_draw, (uint32_t)r, M.fast_st, M.fast_prefix, d_total);
-        const uint32_t blocks = (uint32_t)std::min<double>(65536.0, std::max(8.0, 4.0 * expect / 256.0 + 8.0));   // (grid-stride: any grid is right)
-        hipLaunchKernelGGL(k_fast_draw, dim3(blocks), dim3(256), 0, c->stream, M.walk_d, n_draw, M.fast_st, M.fast_prefix, d_total, k2, seq,
-                           M.wbits);
-        expect *= q;
-    }
-    hipLaunchKernelGGL(k_fast_finish, dim3(1), dim3(1024), 0, c->stream, M.walk_d, n_draw, M.fast_st, k2, seq, M.wbits, 4096u, g->d_fast);
-    hipLaunchKernelGGL(k_fast_check, dim3((n_draw + 255) / 256), dim3(256), 0, c->stream, M.fast_st, n_draw, g->d_fast);
-    MSIM_HIP(c, hipGetLastError());
-    hipEvent_t ce = next_chain_event(g);                   // the records on the emit stream (see the one-range path)
-    MSIM_HIP(c, hipEventRecord(ce, c->stream));
-    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-    hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream, reinterpret_cast<const uint64_t *>(M.wbits), bmw, M.wcnt);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, M.wcnt, bnb);
-    hipLaunchKernelGGL(k_walk_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream, reinterpret_cast<uint64_t *>(M.wbits), bmw, M.wcnt,
-                       M.walk_d, n_draw, (uint32_t)d, ct.d_recs);
-    hipLaunchKernelGGL(k_fast_aux, dim3(((uint32_t)K + 255) / 256), dim3(256), 0, c->emit_stream, ct.d_recs, (uint32_t)K, k2, seq,
-                       (unsigned long long)P.ti_lim);
-    MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipEventRecord(M.emit_done, c->emit_stream));
-    M.pending = true;
-    (void)grew;
-    return MSIM_OK;
-}
 
 // ====================================================================== host-chain engine
 // Contigs the three engines above decline but whose stream structure is still a plain chain: several drawing ranges with

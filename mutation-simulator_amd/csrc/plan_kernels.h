@@ -1510,170 +1510,7 @@ __global__ __launch_bounds__(BM_THREADS) void k_walk_expand(uint64_t *__restrict
     }
 }
 
-// ====================================================================== fast RNG mode (MSIM_RNG_FAST; NOT stream-compatible)
-// The reference's draws come from two sequential MT19937 streams, which is what makes PLAN a chain (plan_gpu.hip).  This
-// mode keeps the reference's *construction* -- k = int(len * rate) positions per range as a uniform k-subset of
-// range(start, stop - (k - 1) d) moved up by rank * d (util.py:93-109), transition with probability p_ti, else one of the
-// two transversions (mutator.py:428-455) -- and replaces the generator by a counter-based one (Philox4x32-10, Salmon et
-// al. 2011): every draw is a pure function of (key, contig ordinal, range, draw index), so nothing chains and nothing is
-// bit-identical to the reference.  SNP-only settings.  The k-subset: draw, OR into the contig-wide bitmap, count the new
-// bits, draw as many again as are still missing -- a procedure symmetric in the values, hence uniform over k-subsets.
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c.x, p1 = (unsigned long long)0xCD9E8D57u * c.z;
-        uint4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k.x;
-        n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k.y;
-        n.w = (uint32_t)p0;
-        c = n;
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-// words of a contig's own stream (one big range: the binned sampler of section 3 runs over them as it does over the CPython
-// stream -- the first k distinct accepted draws are a uniform k-subset whatever generated the words): word 4 i + q = lane q
-// of philox((i, 0, seq, FAST_TAG_WORDS))
-__global__ __launch_bounds__(256) void k_fast_words(uint32_t *__restrict__ out, uint32_t n_words, uint2 key, uint32_t seq) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (4 * (unsigned long long)i >= n_words) return;
-    uint4 ctr; ctr.x = i; ctr.y = 0; ctr.z = seq; ctr.w = 2u;      // FAST_TAG_WORDS
-    const uint4 x = philox4x32_10(ctr, key);
-    if (4 * i + 4 <= n_words) *reinterpret_cast<uint4 *>(out + 4 * (size_t)i) = x;
-    else {
-        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-        for (uint32_t q = 0; 4 * i + q < n_words; q++) out[4 * (size_t)i + q] = w[q];
-    }
-}
-struct FastState { uint32_t rem, done, fresh, rsv; };          // per drawing range: still missing / draws made / new bits of the round
-constexpr uint32_t FAST_TAG_POS = 0, FAST_TAG_SNP = 1;
-enum : uint32_t { FLAG_FAST_UNCONVERGED = 1u };
-
-// Between two rounds (one workgroup): settle the last round (rem -= fresh, done += what was drawn), then the exclusive
-// prefix of the draws of the coming round over the ranges and their total.  round 0: rem = k.
-__global__ __launch_bounds__(1024) void k_fast_prefix(const WalkRange *__restrict__ ranges, uint32_t n_draw, uint32_t round,
-                                                      FastState *__restrict__ st, uint32_t *__restrict__ prefix,
-                                                      uint32_t *__restrict__ total) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_draw; base += 1024) {
-        const uint32_t r = base + threadIdx.x;
-        uint32_t rem = 0;
-        if (r < n_draw) {
-            FastState s = st[r];
-            if (round == 0) { s.rem = ranges[r].k; s.done = 0; }
-            else { s.done += s.rem; s.rem -= s.fresh; }
-            s.fresh = 0;
-            st[r] = s;
-            rem = s.rem;
-        }
-        part[threadIdx.x] = rem;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        if (r < n_draw) prefix[r] = carry + part[threadIdx.x] - rem;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { prefix[n_draw] = carry; *total = carry; }
-}
-
-// One round of draws, all ranges of the contig at once (grid-stride over the round's total, which only the device knows).
-__global__ __launch_bounds__(256) void k_fast_draw(const WalkRange *__restrict__ ranges, uint32_t n_draw,
-                                                   FastState *__restrict__ st, const uint32_t *__restrict__ prefix,
-                                                   const uint32_t *__restrict__ total, uint2 key, uint32_t seq,
-                                                   uint32_t *__restrict__ bits) {
-    const uint32_t T = *total;
-    for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
-        uint32_t lo = 0, hi = n_draw;                      // last range with prefix <= t
-        while (hi - lo > 1) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (prefix[mid] <= t) lo = mid; else hi = mid;
-        }
-        const uint32_t r = lo, j = st[r].done + (t - prefix[r]);
-        uint4 ctr; ctr.x = j; ctr.y = r; ctr.z = seq; ctr.w = FAST_TAG_POS;
-        const uint4 x = philox4x32_10(ctr, key);
-        // 64 random bits scaled to [0, n): bias below n / 2^64
-        const uint32_t v = (uint32_t)__umul64hi(((unsigned long long)x.y << 32) | x.x, (unsigned long long)ranges[r].n);
-        const uint32_t bit = ranges[r].start + v, m = 1u << (bit & 31);
-        const uint32_t old = atomicOr(&bits[bit >> 5], m);
-        const bool fresh = !(old & m);
-        // the new bits are counted per range: one atomic per wave where the whole wave works on one range (a contig with one
-        // big range would otherwise hammer a single counter with millions of atomics: 350 ms instead of 2)
-        const unsigned long long active = __ballot(1);
-        const int first = __ffsll((long long)active) - 1;
-        const uint32_t r0 = (uint32_t)__shfl((int)r, first);
-        if (__all(r == r0)) {
-            const unsigned long long f = __ballot(fresh);
-            if ((int)(threadIdx.x & 63) == first && f) atomicAdd(&st[r].fresh, (uint32_t)__popcll(f));
-        } else if (fresh) {
-            atomicAdd(&st[r].fresh, 1u);
-        }
-    }
-}
-
-// The tail of the rounds in ONE launch (one workgroup): the same rounds -- settle, draw what is missing, count -- repeated
-// until every range has its k positions.  The grid rounds before it leave a handful of draws; a launch per round for those
-// would cost more than all the rest of the contig's PLAN.
-__global__ __launch_bounds__(1024) void k_fast_finish(const WalkRange *__restrict__ ranges, uint32_t n_draw,
-                                                      FastState *__restrict__ st, uint2 key, uint32_t seq,
-                                                      uint32_t *__restrict__ bits, uint32_t max_rounds, uint32_t *__restrict__ flag) {
-    __shared__ uint32_t left;
-    for (uint32_t round = 0; round < max_rounds; round++) {
-        if (threadIdx.x == 0) left = 0;
-        __syncthreads();
-        for (uint32_t r = threadIdx.x; r < n_draw; r += 1024) {       // settle the last round
-            FastState s = st[r];
-            s.done += s.rem;
-            s.rem -= s.fresh;
-            s.fresh = 0;
-            st[r] = s;
-            if (s.rem) atomicAdd(&left, s.rem);
-        }
-        __syncthreads();
-        if (!left) return;                                            // uniform
-        __threadfence();
-        for (uint32_t r = threadIdx.x; r < n_draw; r += 1024) {       // (few ranges are unfinished and their rem is tiny: a lane each)
-            const uint32_t rem = st[r].rem, done = st[r].done;
-            for (uint32_t j = 0; j < rem; j++) {
-                uint4 ctr; ctr.x = done + j; ctr.y = r; ctr.z = seq; ctr.w = FAST_TAG_POS;
-                const uint4 x = philox4x32_10(ctr, key);
-                const uint32_t v = (uint32_t)__umul64hi(((unsigned long long)x.y << 32) | x.x, (unsigned long long)ranges[r].n);
-                const uint32_t bit = ranges[r].start + v, m = 1u << (bit & 31);
-                if (!(atomicOr(&bits[bit >> 5], m) & m)) atomicAdd(&st[r].fresh, 1u);
-            }
-        }
-        __threadfence();
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicOr(flag, FLAG_FAST_UNCONVERGED);
-}
-
-__global__ __launch_bounds__(256) void k_fast_check(const FastState *__restrict__ st, uint32_t n_draw, uint32_t *__restrict__ flag) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-    if (r < n_draw && st[r].rem != st[r].fresh) atomicOr(flag, FLAG_FAST_UNCONVERGED);
-}
-
-// SNP outcome of every record: 53 random bits against the transition threshold (mutator.py:428-447: random() < p_ti), else
-// one of the two transversion columns (mutator.py:449-455)
-__global__ __launch_bounds__(256) void k_fast_aux(msim_record *__restrict__ recs, uint32_t K, uint2 key, uint32_t seq,
-                                                  unsigned long long ti_lim) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= K) return;
-    uint4 ctr; ctr.x = i; ctr.y = 0; ctr.z = seq; ctr.w = FAST_TAG_SNP;
-    const uint4 x = philox4x32_10(ctr, key);
-    const unsigned long long u53 = (((unsigned long long)x.y << 32) | x.x) >> 11;
-    recs[i].aux = u53 < ti_lim ? (uint8_t)0 : (uint8_t)(1 + (x.z & 1u));
-}
+// (the counter-based engine of MSIM_RNG_FAST lives in fast_math.h / fast_kernels.h / plan_fast.hip)
 
 // single lane: the bookkeeping block goes to the pinned host mailbox (plain stores over PCIe)
 __global__ void k_publish(const PlanState *__restrict__ ps, PlanState *__restrict__ mailbox) {
@@ -1691,13 +1528,6 @@ __global__ void k_publish_seq(const PlanState *__restrict__ ps, PlanState *__res
 
 __global__ void k_raise_flag(PlanState *ps, uint32_t flag) { ps->flags |= flag; }
 
-// fast RNG mode: a contig's own word stream starts at 0; the sticky flags of earlier contigs stay until somebody looks
-__global__ void k_state_init_keep_flags(PlanState *ps) {
-    const uint32_t f = ps->flags;
-    ps->pos = 0; ps->snp_base = 0; ps->flags = f; ps->dups = 0; ps->accepted_used = 0;
-    ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;
-    ps->len_delta = 0;
-}
 __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
     ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0;
     ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;
