@@ -301,16 +301,16 @@ def e2e_cli(eng, total_bases=1_200_000_000, n_contigs=6):
 
 
 def fast_rng_steps(lengths, mm, steps=5, warmup=3):
-    """c2 and c4 with `--rng fast` (msim.h: MSIM_RNG_FAST): a counter-based generator instead of the reference's two MT19937
-    streams.  NOT a parity number -- same distributions, different draws -- and never the headline: it shows what the step
-    costs once PLAN has no sequential chain."""
+    """c2 / c3 / c4 / c4sv with `--rng fast` (msim.h: MSIM_RNG_FAST): the counter-based PLAN engine (plan_fast.hip) instead of the
+    reference's two MT19937 streams.  NOT a parity number -- same construction and distributions, different draws -- and never the
+    headline: it shows what the step costs once PLAN has no sequential chain and no host work (plan_host = 0 by construction)."""
     from mutation_simulator_amd import _ffi
     eng = _ffi.Engine(int(os.environ.get("MSIM_BENCH_DEVICE", 0)), _ffi.RNG_FAST)
     out = {"what": "NOT stream-compatible with the reference (Philox4x32-10 draws; same construction and distributions): PLAN without "
                    "its sequential chain, same APPLY kernels; results left in HBM", "steps": steps, "warmup": warmup}
     try:
         cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
-        for w in ("c2", "c4"):
+        for w in ("c2", "c3", "c4", "c4sv"):
             sim = build_settings(w, lengths)
             tables = [mm.plan_table(ch) for ch in sim.chromosomes]
             eng.set_params(mm.params_descriptor(sim))
@@ -329,8 +329,12 @@ def fast_rng_steps(lengths, mm, steps=5, warmup=3):
                 step()
             dt = time.perf_counter() - t0
             st = eng.stats()
+            k_ms = st["apply_kernel_ms"]
+            alg = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
             out[w] = {"value": round(sum(lengths) * steps / dt / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dt / steps * 1e3, 3),
                       "records_per_step": st["records"] // steps, "stages_ms_per_step": stages_of(st, steps),
+                      "plan_engines": engines_of(st, steps),
+                      "rewrite_kernel_frac_of_hbm_peak": round(alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
                       "step_roofline": step_roofline(st, dt)}
     finally:
         eng.close()

@@ -165,8 +165,9 @@ __global__ __launch_bounds__(THREADS) void k_offsets(const msim_record *__restri
 __global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restrict__ off,
                                                         const msim_record *__restrict__ recs, uint32_t n,
                                                         int32_t *__restrict__ first, uint32_t n_entries,
-                                                        const uint32_t *__restrict__ dyn) {
+                                                        const uint32_t *__restrict__ dyn, unsigned long long *__restrict__ err) {
     const uint32_t t = blockIdx.x * THREADS + threadIdx.x;
+    if (t == 0) *err = ~0ull;                              // the contig's KeyError word: none so far (the rewrite kernel follows)
     if (t >= n_entries) return;
     if (dyn) n = dyn[0];
     const uint64_t target = (uint64_t)t * TILE;
@@ -924,6 +925,14 @@ int apply_finish(Ctx *c) {
         if (rc) { c->pending_apply.clear(); for (auto &g : c->contigs) g.apply_pending = g.dyn_applied = false; return rc; }
     }
     if (c->pending_apply.empty()) return MSIM_OK;
+    {   // APPLYs that ran on a stream of their own (counter-based engine)
+        hipStream_t last = nullptr;
+        for (int idx : c->pending_apply) {
+            if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
+            hipStream_t s = c->contigs[(size_t)idx].apply_stream;
+            if (s && s != last) { MSIM_HIP(c, hipStreamSynchronize(s)); last = s; }
+        }
+    }
     // KeyError words + length-check words of every contig: two asynchronous copies into pinned memory behind the
     // APPLY work, one synchronisation (two blocking hipMemcpy cost ~40 us each at every step boundary)
     const size_t nc = c->contigs.size();
@@ -974,7 +983,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
     //  the exact values themselves)
     const uint32_t *dyn = g.d_dyn;
     const uint32_t n = (uint32_t)(dyn ? g.n_rec_cap : g.n_rec);
-    hipStream_t st = c->emit_stream;
+    hipStream_t st = g.apply_stream ? g.apply_stream : c->emit_stream;
     if (!g.ea0) {
         MSIM_HIP(c, hipEventCreate(&g.ea0));
         MSIM_HIP(c, hipEventCreate(&g.ea1));
@@ -1036,15 +1045,23 @@ int apply_contig_device(Ctx *c, Contig &g) {
     const uint32_t n_tiles = (uint32_t)((g.out_len + TILE - 1) / TILE);
     int32_t *d_first = nullptr;
     if (n_tiles) {
-        int rc = ensure_scratch(c, (size_t)(n_tiles + 1) * sizeof(int32_t) + 64);
-        if (rc) return rc;
-        d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
+        if (g.apply_stream) {
+            if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, hipStreamSynchronize(st));
+            int rc = dev_reserve(c, (void **)&g.d_first, &g.cap_first, (size_t)(n_tiles + 1) * sizeof(int32_t));
+            if (rc) return rc;
+            d_first = g.d_first;
+        } else {
+            int rc = ensure_scratch(c, (size_t)(n_tiles + 1) * sizeof(int32_t) + 64);
+            if (rc) return rc;
+            d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
+        }
         hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, st,
-                           d_off, g.d_recs, n, d_first, n_tiles + 1, dyn);
+                           d_off, g.d_recs, n, d_first, n_tiles + 1, dyn, d_err);
         MSIM_HIP(c, hipGetLastError());
+    } else {
+        MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
     }
     // ---- 3. rewrite
-    MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
     MSIM_HIP(c, hipEventRecord(g.ea1, st));
     if (n_tiles) {
         // small window: mean records per tile < 80 % of it (dyn: only the STRUCTURAL records take window slots, and their

@@ -29,6 +29,9 @@ struct Contig {
     uint64_t n_rec_cap = 0;           // candidates: the record table's allocation
     uint64_t out_cap_len = 0;         // 16-sigma bound of the mutated length: d_out's allocation and the APPLY grid
     uint64_t n_struct_est = 0;        // expected non-SNP candidates (selects the rewrite kernel's window)
+    hipStream_t apply_stream = nullptr;   // the stream its PLAN ran on: its APPLY follows there (null: the context's emit stream)
+    int32_t *d_first = nullptr;       // tile index of its own (contigs on different streams cannot share the context's scratch)
+    size_t cap_first = 0;
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD

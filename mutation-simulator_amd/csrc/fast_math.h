@@ -37,7 +37,7 @@ namespace fastrng {
 // philox counter = (x, y, contig ordinal, tag | hi << 8); one call = 128 random bits
 constexpr uint32_t TAG_SPLIT = 16;     // x = heap index of the tree node, y = attempt, hi = drawing range
 constexpr uint32_t TAG_POS = 17;       // x = draw index >> 1, y = leaf (numbered through the contig), hi = 0
-constexpr uint32_t TAG_CAND = 18;      // x = candidate ordinal, y = 0: type (53 bits) + length (64 bits); y = 1: SNP outcome
+constexpr uint32_t TAG_CAND = 18;      // x = candidate ordinal: low 64 bits -> type (53 bits), high 64 -> length, or the SNP's outcome
 constexpr uint32_t TAG_INS = 19;       // x = 64-base chunk of the insert, y = candidate ordinal
 constexpr int LG_LEAF_MIN = 10, LG_LEAF_MAX = 16;
 constexpr uint32_t LEAF_TARGET = 96;   // a leaf should hold about this many points or more (up to twice as many)
@@ -110,27 +110,42 @@ MSIM_FHD inline double d_log(double x) {
     const double t = (2.0 * s) * p;
     return (double)e * 0.6931471805599453 + t;
 }
-// log(1 + t), t > -1 (Kahan: the rounding error of u = 1 + t cancels in log(u) * t / (u - 1))
+// the series of d_log on s = t / (2 + t): log(1 + t) = 2 atanh(s).  One division; |s| < 0.1716 for t in (-0.29, 0.41),
+// outside (-0.25, 0.4) the rounding of 1 + t no longer matters and d_log takes over
 MSIM_FHD inline double d_log1p(double t) {
     MSIM_FP_STRICT
-    const double u = 1.0 + t;
-    if (u == 1.0) return t;
-    return d_log(u) * t / (u - 1.0);
+    if (!(t > -0.25 && t < 0.4)) return d_log(1.0 + t);
+    const double s = t / (2.0 + t);
+    const double z = s * s;
+    double p = 1.0 / 23.0;
+    p = p * z + 1.0 / 21.0;
+    p = p * z + 1.0 / 19.0;
+    p = p * z + 1.0 / 17.0;
+    p = p * z + 1.0 / 15.0;
+    p = p * z + 1.0 / 13.0;
+    p = p * z + 1.0 / 11.0;
+    p = p * z + 1.0 / 9.0;
+    p = p * z + 1.0 / 7.0;
+    p = p * z + 1.0 / 5.0;
+    p = p * z + 1.0 / 3.0;
+    p = p * z + 1.0;
+    return (2.0 * s) * p;
 }
-// square root of a positive normal double by Newton's iteration from 2^(e/2) (seed within a factor sqrt(2): 6 steps)
-MSIM_FHD inline double d_sqrt(double x) {
+// an upper bound of sqrt(x) within 3e-4 of it, x a positive normal double: four Newton steps from 2^floor(e/2) (every
+// Newton iterate after the first lies above the root).  The hat of the ratio-of-uniforms sampler only needs a bound.
+MSIM_FHD inline double d_sqrt_up(double x) {
     MSIM_FP_STRICT
     const uint64_t b = d_bits(x);
     const int e = (int)((b >> 52) & 0x7ff) - 1023;
     double y = d_from((uint64_t)(1023 + (e >> 1)) << 52);
 #pragma unroll
-    for (int i = 0; i < 7; i++) y = 0.5 * (y + x / y);
+    for (int i = 0; i < 4; i++) y = 0.5 * (y + x / y);
     return y;
 }
 // Stirling correction of lgamma(y): 1/(12 y) - 1/(360 y^3) + 1/(1260 y^5); y >= 32: the next term is below 2e-14
-MSIM_FHD inline double stirling_corr(double y) {
+MSIM_FHD inline double stirling_corr_inv(double iy) {
     MSIM_FP_STRICT
-    const double iy = 1.0 / y, iy2 = iy * iy;
+    const double iy2 = iy * iy;
     return iy * (1.0 / 12.0 - iy2 * (1.0 / 360.0 - iy2 * (1.0 / 1260.0)));
 }
 // log(x!)
@@ -142,76 +157,128 @@ MSIM_FHD inline double log_factorial(uint64_t x) {
         return d_log(p);
     }
     const double y = (double)(x + 1);
-    return (y - 0.5) * d_log(y) - y + 0.9189385332046727 + stirling_corr(y);
+    return (y - 0.5) * d_log(y) - y + 0.9189385332046727 + stirling_corr_inv(1.0 / y);
 }
-// log((a + d)!) - log(a!), a + d >= 0, without the cancellation of two huge logarithms
-MSIM_FHD inline double log_factorial_diff(uint64_t a, int64_t d) {
+// log((a + d)!) - log(a!) for a FIXED a and many d (a + d >= 0), without the cancellation of two huge logarithms:
+// what depends on a alone is prepared once
+struct LfBase { uint64_t a; double iy0, ly0m1, c0, lf; };           // 1 / (a + 1), log(a + 1) - 1, stirling_corr(a + 1), log(a!)
+MSIM_FHD inline LfBase lf_base(uint64_t a) {
+    MSIM_FP_STRICT
+    LfBase b;
+    b.a = a;
+    const double y0 = (double)(a + 1);
+    b.iy0 = 1.0 / y0;
+    b.ly0m1 = d_log(y0) - 1.0;
+    b.c0 = stirling_corr_inv(b.iy0);
+    b.lf = a + 1 >= 32 ? 0.0 : log_factorial(a);
+    return b;
+}
+MSIM_FHD inline double log_factorial_diff(const LfBase &b, int64_t d) {
     MSIM_FP_STRICT
     if (d == 0) return 0.0;
-    const uint64_t a1 = (uint64_t)((int64_t)a + d);
-    if (a + 1 >= 32 && a1 + 1 >= 32) {
-        const double y0 = (double)(a + 1), y1 = (double)(a1 + 1), dd = (double)d;
-        return (y1 - 0.5) * d_log1p(dd / y0) + dd * (d_log(y0) - 1.0) + (stirling_corr(y1) - stirling_corr(y0));
+    const uint64_t a1 = (uint64_t)((int64_t)b.a + d);
+    if (b.a + 1 >= 32 && a1 + 1 >= 32) {
+        const double y1 = (double)(a1 + 1), dd = (double)d;
+        return (y1 - 0.5) * d_log1p(dd * b.iy0) + dd * b.ly0m1 + (stirling_corr_inv(1.0 / y1) - b.c0);
     }
-    return log_factorial(a1) - log_factorial(a);
+    return log_factorial(a1) - (b.a + 1 >= 32 ? log_factorial(b.a) : b.lf);
 }
 
 // ---- Hypergeometric(good, bad, sample): how many of `sample` items drawn without replacement from good + bad are good ----
 // small samples: the urn itself; otherwise Stadlober's ratio-of-uniforms algorithm HRUA (Stadlober 1990, "The ratio of
 // uniforms approach for generating discrete random variates", J. Comput. Appl. Math. 31; the variant with the mode-centred
-// table mountain NumPy also uses).  Draws come from node counters (x = node, y = attempt).
+// table mountain NumPy also uses).  Draws come from node counters (x = node, y = attempt): attempt `att` is a pure function
+// of (node, att), the result is the outcome of the FIRST accepted attempt -- so a kernel may evaluate several attempts of
+// one node on neighbouring lanes at once (fast_kernels.h: hyp_group) and still land on the sequential answer.
+struct HypPrep {
+    int kind;                  // 0: z is the answer; 1: urn (m <= 10); 2: HRUA
+    uint64_t z;
+    uint64_t good, bad, sample, N, m, mingb, maxgb, mode;
+    double a, h, bnd;
+    LfBase t0, t1, t2, t3;     // mode, mingb - mode, m - mode, maxgb - m + mode
+};
+MSIM_FHD inline HypPrep hyp_prepare(uint64_t good, uint64_t bad, uint64_t sample) {
+    MSIM_FP_STRICT
+    HypPrep P;
+    P.kind = 0; P.z = 0;
+    P.good = good; P.bad = bad; P.sample = sample;
+    const uint64_t N = good + bad;
+    P.N = N;
+    P.m = P.mingb = P.maxgb = P.mode = 0;
+    P.a = P.h = P.bnd = 0.0;
+    P.t0 = P.t1 = P.t2 = P.t3 = LfBase{0, 0.0, 0.0, 0.0, 0.0};
+    if (sample == 0 || good == 0) return P;
+    if (bad == 0) { P.z = sample; return P; }
+    if (sample >= N) { P.z = good; return P; }
+    const uint64_t m = sample < N - sample ? sample : N - sample;
+    P.m = m;
+    if (m <= 10) { P.kind = 1; return P; }
+    P.kind = 2;
+    const uint64_t mingb = good < bad ? good : bad, maxgb = good < bad ? bad : good;
+    P.mingb = mingb; P.maxgb = maxgb;
+    const double p = (double)mingb / (double)N, q = 1.0 - p;
+    P.a = (double)m * p + 0.5;
+    const double var = (double)(N - m) * (double)m * p * q / (double)(N - 1);
+    const double c = d_sqrt_up(var + 0.5);
+    P.h = 1.7155277699214135 * c + 0.8989161620588988;     // 2 sqrt(2/e) c + 3 - 2 sqrt(3/e)
+    P.mode = (m + 1) * (mingb + 1) / (N + 2);
+    const double lim_a = (double)((m < mingb ? m : mingb) + 1);
+    double lim_b = P.a + 16.0 * c;
+    lim_b = (double)(uint64_t)lim_b;                       // floor of a positive number
+    P.bnd = lim_a < lim_b ? lim_a : lim_b;
+    P.t0 = lf_base(P.mode);
+    P.t1 = lf_base(mingb - P.mode);
+    P.t2 = lf_base(m - P.mode);
+    P.t3 = lf_base(maxgb - m + P.mode);
+    return P;
+}
+// one HRUA attempt: true = accepted, Z = how many of the m items are of the rarer kind
+MSIM_FHD inline bool hyp_attempt(const HypPrep &P, const Key &key, uint32_t node, uint32_t range, uint32_t att, uint64_t &Z) {
+    MSIM_FP_STRICT
+    const U4 v = draw4(key, node, att, TAG_SPLIT, range);
+    const double U = uni52(lo64(v)), V = uni52(hi64(v));
+    const double X = P.a + P.h * (V - 0.5) / U;
+    if (X < 0.0 || X >= P.bnd) return false;
+    Z = (uint64_t)X;
+    const int64_t dz = (int64_t)Z - (int64_t)P.mode;
+    const double T = -(log_factorial_diff(P.t0, dz) + log_factorial_diff(P.t1, -dz) + log_factorial_diff(P.t2, -dz) +
+                       log_factorial_diff(P.t3, dz));
+    if (U * (4.0 - U) - 3.0 <= T) return true;
+    if (U * (U - T) >= 1.0) return false;
+    return 2.0 * d_log(U) <= T;
+}
+MSIM_FHD inline uint64_t hyp_urn(const HypPrep &P, const Key &key, uint32_t node, uint32_t range) {   // the m items one by one
+    uint64_t g = P.good, n = P.N, cnt = 0;
+    U4 v{};
+    for (uint64_t i = 0; i < P.m; i++) {
+        if (!(i & 1)) v = draw4(key, node, (uint32_t)(i >> 1), TAG_SPLIT, range);
+        const uint64_t r = (i & 1) ? hi64(v) : lo64(v);
+        if (below(r, n) < g) { g--; cnt++; }
+        n--;
+    }
+    return cnt;                                            // good items among the m drawn
+}
+// kind 1: z = hyp_urn's count; kind 2: z = the accepted attempt's Z
+MSIM_FHD inline uint64_t hyp_finish(const HypPrep &P, uint64_t z) {
+    if (P.kind == 0) return P.z;
+    if (P.kind == 2) z = P.good > P.bad ? P.m - z : z;     // Z counted the rarer kind
+    return P.m < P.sample ? P.good - z : z;                // the m items were the ones left OUT
+}
+constexpr uint32_t HYP_MAX_ATTEMPTS = 4096;                // (an acceptance rate above 1/2 per attempt: never reached)
 MSIM_FHD inline uint64_t hypergeometric(uint64_t good, uint64_t bad, uint64_t sample, const Key &key, uint32_t node, uint32_t range,
                                        uint32_t *attempts_out = nullptr) {
-    MSIM_FP_STRICT
-    const uint64_t N = good + bad;
-    if (sample == 0 || good == 0) return 0;
-    if (bad == 0) return sample;
-    if (sample >= N) return good;
-    const uint64_t m = sample < N - sample ? sample : N - sample;
-    uint64_t z;
-    if (m <= 10) {                                         // draw the m items one by one
-        uint64_t g = good, n = N, cnt = 0;
-        U4 v{};
-        for (uint64_t i = 0; i < m; i++) {
-            if (!(i & 1)) v = draw4(key, node, (uint32_t)(i >> 1), TAG_SPLIT, range);
-            const uint64_t r = (i & 1) ? hi64(v) : lo64(v);
-            if (below(r, n) < g) { g--; cnt++; }
-            n--;
-        }
-        z = cnt;                                           // good items among m drawn
-        if (attempts_out) *attempts_out = 0;
-    } else {
-        const uint64_t mingb = good < bad ? good : bad, maxgb = good < bad ? bad : good;
-        const double p = (double)mingb / (double)N, q = 1.0 - p;
-        const double a = (double)m * p + 0.5;
-        const double var = (double)(N - m) * (double)m * p * q / (double)(N - 1);
-        const double c = d_sqrt(var + 0.5);
-        const double h = 1.7155277699214135 * c + 0.8989161620588988;      // 2 sqrt(2/e) c + 3 - 2 sqrt(3/e)
-        const uint64_t mode = (m + 1) * (mingb + 1) / (N + 2);
-        const double lim_a = (double)((m < mingb ? m : mingb) + 1);
-        double lim_b = a + 16.0 * c;
-        lim_b = (double)(uint64_t)lim_b;                   // floor of a positive number
-        const double bnd = lim_a < lim_b ? lim_a : lim_b;
-        uint32_t att = 0;
-        uint64_t Z = mode;
-        for (;; att++) {
-            if (att >= 4096) { Z = mode; break; }          // (an acceptance rate above 1/2 per attempt: never reached)
-            const U4 v = draw4(key, node, att, TAG_SPLIT, range);
-            const double U = uni52(lo64(v)), V = uni52(hi64(v));
-            const double X = a + h * (V - 0.5) / U;
-            if (X < 0.0 || X >= bnd) continue;
-            Z = (uint64_t)X;
-            const int64_t dz = (int64_t)Z - (int64_t)mode;
-            const double T = -(log_factorial_diff(mode, dz) + log_factorial_diff(mingb - mode, -dz) +
-                               log_factorial_diff(m - mode, -dz) + log_factorial_diff(maxgb - m + mode, dz));
-            if (U * (4.0 - U) - 3.0 <= T) break;
-            if (U * (U - T) >= 1.0) continue;
-            if (2.0 * d_log(U) <= T) break;
-        }
-        if (attempts_out) *attempts_out = att;
-        z = good > bad ? m - Z : Z;                        // Z counted the rarer kind
+    const HypPrep P = hyp_prepare(good, bad, sample);
+    uint64_t z = 0;
+    uint32_t att = 0;
+    if (P.kind == 1) z = hyp_urn(P, key, node, range);
+    else if (P.kind == 2) {
+        z = P.mode;
+        for (; att < HYP_MAX_ATTEMPTS; att++)
+            if (hyp_attempt(P, key, node, range, att, z)) break;
+        if (att >= HYP_MAX_ATTEMPTS) z = P.mode;
     }
-    return m < sample ? good - z : z;                      // the m items were the ones left OUT
+    if (attempts_out) *attempts_out = att;
+    return hyp_finish(P, z);
 }
 
 // ---- leaves ----------------------------------------------------------------------------------------------------------
@@ -238,10 +305,16 @@ struct Settings {
     uint32_t n_types;
     uint32_t rsv;
 };
+// candidate meta byte: bits 0-2 type, bits 3-4 SNP outcome (0 transition, 1 / 2 transversion column), then flags
 constexpr uint8_t CAND_DROPPED = 0x40;   // IV too close to the contig end (mutator.py:240-243): no record, blocks nothing
 constexpr uint8_t CAND_KEEP = 0x80;
 constexpr uint8_t CAND_VISIT = 0x20;
-struct Cand { uint32_t stop; uint32_t bend; uint8_t meta; };   // Mutation.stop, end of the blocked range it opens, type | flags
+constexpr int CAND_AUX_SHIFT = 3;
+struct Cand { uint32_t stop; uint32_t bend; uint8_t meta; };   // Mutation.stop, end of the blocked range it opens, type | aux | flags
+
+// SNP outcome from 64 random bits: transition iff the 53-bit sample is below ti_lim (mutator.py:436-438: p <= p_ti), else one
+// of the two transversion columns by the lowest bit (mutator.py:449-455)
+MSIM_FHD inline uint8_t snp_from(uint64_t r64, uint64_t ti_lim) { return (r64 >> 11) < ti_lim ? (uint8_t)0 : (uint8_t)(1 + (r64 & 1u)); }
 
 MSIM_FHD inline uint32_t sat_add32(uint32_t a, uint64_t b) {
     const uint64_t s = (uint64_t)a + b;
@@ -249,7 +322,7 @@ MSIM_FHD inline uint32_t sat_add32(uint32_t a, uint64_t b) {
 }
 // type, stop and blocked end of candidate `ord` at position pos (mutator.py:160-174, 184-265); block1[t] = block[t] + 1
 MSIM_FHD inline Cand cand_draw(const Key &key, uint32_t ord, uint32_t pos, uint64_t L, const Settings &s,
-                              const uint32_t *block1, uint32_t clip) {
+                              const uint32_t *block1, uint32_t clip, uint64_t ti_lim) {
     const U4 v = draw4(key, ord, 0, TAG_CAND);
     const uint64_t u53 = lo64(v) >> 11;
     uint32_t idx = 0;
@@ -259,6 +332,7 @@ MSIM_FHD inline Cand cand_draw(const Key &key, uint32_t ord, uint32_t pos, uint6
     Cand c;
     c.meta = (uint8_t)t;
     uint64_t stop = pos;
+    if (t == 1) c.meta |= (uint8_t)(snp_from(hi64(v), ti_lim) << CAND_AUX_SHIFT);      // an SNP draws no length: its outcome instead
     if (t != 1) {                                          // randint(start + min - 1, start + max - 1)
         stop = (uint64_t)pos + s.min_len[t] - 1 + below(hi64(v), s.width[t]);
         if (t == 5) {                                      // IV: dropped when it cannot fit (mutator.py:240-243)
@@ -276,10 +350,9 @@ MSIM_FHD inline Cand cand_draw(const Key &key, uint32_t ord, uint32_t pos, uint6
     if (c.bend <= pos) c.bend = pos + 1;
     return c;
 }
-// SNP outcome of candidate `ord`: 0 transition, 1 / 2 transversion column (mutator.py:428-455)
+// SNP outcome of candidate `ord` where every candidate is an SNP (the type draw is not looked at): the same bits cand_draw uses
 MSIM_FHD inline uint8_t snp_outcome(const Key &key, uint32_t ord, uint64_t ti_lim) {
-    const U4 v = draw4(key, ord, 1, TAG_CAND);
-    return (lo64(v) >> 11) < ti_lim ? (uint8_t)0 : (uint8_t)(1 + (v.z & 1u));
+    return snp_from(hi64(draw4(key, ord, 0, TAG_CAND)), ti_lim);
 }
 // base j of the insert of candidate `ord` (mutator.py:465-471): 64 bases per counter, 2 bits each
 MSIM_FHD inline uint8_t insert_base_of(const U4 &chunk, uint32_t j) {

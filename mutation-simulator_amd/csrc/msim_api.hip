@@ -136,7 +136,8 @@ static int free_contig(Ctx *c, Contig &g, bool keep_input) {
     if (g.d_pool) { MSIM_HIP(c, hipFree(g.d_pool)); g.d_pool = nullptr; }
     if (g.d_out) { MSIM_HIP(c, hipFree(g.d_out)); g.d_out = nullptr; }
     if (g.d_off) { MSIM_HIP(c, hipFree(g.d_off)); g.d_off = nullptr; }
-    g.cap_recs = g.cap_pool = g.cap_out = g.cap_off = 0;
+    if (g.d_first) { MSIM_HIP(c, hipFree(g.d_first)); g.d_first = nullptr; }
+    g.cap_recs = g.cap_pool = g.cap_out = g.cap_off = g.cap_first = 0;
     if (g.ea0) { (void)hipEventDestroy(g.ea0); (void)hipEventDestroy(g.ea1); (void)hipEventDestroy(g.ea2); g.ea0 = g.ea1 = g.ea2 = nullptr; }
     g.apply_pending = false;
     g.key_error = false;

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "ctx.h"
@@ -18,7 +19,7 @@ namespace msim {
 
 namespace {
 
-constexpr int F_SETS = 4;                                  // contigs in flight (one stream + one scratch set each)
+constexpr int F_SETS = 8;                                  // contigs in flight (one stream + one scratch set each)
 
 template <class T>
 struct DevBuf {
@@ -32,12 +33,11 @@ struct PinBuf {
 };
 
 struct FastSet {
-    DevBuf<FRange> ranges;
-    DevBuf<Settings> sets;
-    PinBuf<uint8_t> h_tab;                                 // pinned: FRange table + Settings table of the contig in flight
+    DevBuf<uint8_t> tab;                                   // FRange | Settings | SubDesc | big-range list: ONE copy per contig
+    PinBuf<uint8_t> h_tab;                                 // its pinned source
     DevBuf<LeafDesc> leaves;
-    DevBuf<uint32_t> leaf_m;
-    DevBuf<uint32_t> cand_pos, cand_stop, cand_bend, blk_out;
+    DevBuf<uint32_t> sub_k, sub_c0;                        // per subtree of 64 leaves: its points, its first candidate
+    DevBuf<uint32_t> cand_pos, cand_stop, cand_bend, cand_end2, blk_out;
     DevBuf<uint8_t> cand_meta;
     DevBuf<uint32_t> blk_u32;                              // S | indep | in | nrec | pool  (5 arrays of nb + 1)
     DevBuf<long long> blk_delta;
@@ -45,6 +45,25 @@ struct FastSet {
     hipEvent_t done = nullptr;
     bool pending = false;
 };
+
+struct Prep {
+    std::vector<FRange> fr;
+    std::vector<Settings> sets;
+    std::vector<SubDesc> subs;
+    std::vector<uint32_t> big;
+    uint64_t K = 0;
+    uint64_t n_leaves = 0;
+    uint32_t lgB_max = LG_LEAF_MIN;
+    bool snp_only = true;                                  // every candidate is an SNP that blocks nothing: records straight from the leaves
+    bool all_sn = true;                                    // every candidate is an SNP (no length change)
+    bool need_visit = false;                               // several ranges and a consuming type: the visit filter can drop records
+    uint32_t maxspan = 1, maxspan_visit = 1;
+    uint64_t pool_cap = 0, out_cap = 0, n_struct_est = 0;
+    Block1 block1{};
+    int64_t d = 1;
+};
+
+struct Replay { uint64_t key = 0; uint32_t seq = 0; Prep P; };
 
 }  // namespace
 
@@ -57,6 +76,8 @@ struct FastPlan {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool pending = false;                                  // work enqueued since the last collection
     std::vector<int> sized;                                // contigs whose sizes are still on the device only
+    std::map<int, Replay> replay;                          // per contig planned with device-side counts: its tables (see enqueue_plan)
+    uint64_t replays = 0;                                  // plans that had to be replayed with the orbit kernels
 };
 
 namespace {
@@ -73,21 +94,6 @@ int dev_grow(Ctx *c, FastPlan *f, DevBuf<T> &b, size_t want) {
     b.cap = n;
     return MSIM_OK;
 }
-
-struct Prep {
-    std::vector<FRange> fr;
-    std::vector<Settings> sets;
-    uint64_t K = 0;
-    uint64_t n_leaves = 0;
-    uint32_t lgB_max = LG_LEAF_MIN;
-    bool snp_only = true;                                  // every candidate is an SNP that blocks nothing: records straight from the leaves
-    bool all_sn = true;                                    // every candidate is an SNP (no length change)
-    bool need_visit = false;                               // several ranges and a consuming type: the visit filter can drop records
-    uint32_t maxspan = 1, maxspan_visit = 1;
-    uint64_t pool_cap = 0, out_cap = 0, n_struct_est = 0;
-    Block1 block1{};
-    int64_t d = 1;
-};
 
 bool type_drawable(const msim_range &r, int j) {
     const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
@@ -174,10 +180,15 @@ int prepare(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, Prep &P)
         f.lgB = leaf_lg((uint64_t)n, (uint64_t)r.k);
         f.clip = (uint32_t)std::min<int64_t>(r.stop + 1, 0xffffffffll);
         f.set = set;
+        f.sub_base = (uint32_t)P.subs.size();
+        f.rsv = 0;
+        const uint64_t T = ((uint64_t)n + (1ull << f.lgB) - 1) >> f.lgB;
+        if (T > (1u << LG_SUB)) P.big.push_back((uint32_t)P.fr.size());
+        for (uint64_t sidx = 0; sidx < (T + 63) >> LG_SUB; sidx++) P.subs.push_back(SubDesc{(uint32_t)P.fr.size(), (uint32_t)sidx});
         P.fr.push_back(f);
         P.lgB_max = std::max(P.lgB_max, f.lgB);
         P.K += (uint64_t)r.k;
-        P.n_leaves += ((uint64_t)n + (1ull << f.lgB) - 1) >> f.lgB;
+        P.n_leaves += T;
         n_draw++;
         if (P.K >= (1ull << 31) || P.n_leaves >= (1ull << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: 2^31 or more candidates on one contig");
     }
@@ -218,7 +229,7 @@ void fast_plan_destroy(Ctx *c) {
     if (!f) return;
     for (auto st : f->lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &s : f->set) {
-        void *bufs[] = {s.ranges.p, s.sets.p, s.leaves.p, s.leaf_m.p, s.cand_pos.p, s.cand_stop.p, s.cand_bend.p, s.blk_out.p,
+        void *bufs[] = {s.tab.p, s.leaves.p, s.sub_k.p, s.sub_c0.p, s.cand_pos.p, s.cand_stop.p, s.cand_bend.p, s.cand_end2.p, s.blk_out.p,
                         s.cand_meta.p, s.blk_u32.p, s.blk_delta.p, s.kept_any};
         for (void *p : bufs) if (p) (void)hipFree(p);
         if (s.h_tab.p) (void)hipHostFree(s.h_tab.p);
@@ -238,56 +249,107 @@ int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges) 
     return prepare(c, L, ranges, n_ranges, P);
 }
 
+namespace {
+struct HostProf {                                          // MSIM_FAST_PROF=1: where the host's time per contig goes (stderr at collection)
+    bool on = getenv("MSIM_FAST_PROF") != nullptr;
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    std::chrono::steady_clock::time_point last;
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        t[i] += std::chrono::duration<double, std::micro>(now - last).count();
+        last = now;
+    }
+    void report() {
+        if (!on || !n) return;
+        fprintf(stderr, "fast PLAN host us per contig (%llu contigs): prepare %.1f, wait-set %.1f, tables+grow %.1f, copy %.1f, split %.1f, leaf %.1f, "
+                        "keep+emit %.1f, events %.1f\n", (unsigned long long)n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n, t[7] / n);
+        for (double &x : t) x = 0;
+        n = 0;
+    }
+};
+HostProf g_prof;
+}  // namespace
+
+static int enqueue_plan(Ctx *c, Contig &ct, Prep &P, uint64_t key64, uint32_t seq, bool orbit_only);
+
 int fast_plan_collect(Ctx *c) {
     FastPlan *f = c->fast;
     if (!f || !f->pending) return MSIM_OK;
-    f->pending = false;
-    for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
-    MSIM_HIP(c, hipEventRecord(f->t1, f->lane[0]));
-    MSIM_HIP(c, hipStreamSynchronize(f->lane[0]));
-    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-    float ms = 0;
-    MSIM_HIP(c, hipEventElapsedTime(&ms, f->t0, f->t1));
-    c->t.plan_gpu_ms += ms;
-    for (auto &s : f->set) s.pending = false;
-    uint32_t flags = 0;
-    MSIM_HIP(c, hipMemcpy(&flags, f->d_flags, sizeof flags, hipMemcpyDeviceToHost));
-    if (!f->sized.empty()) {
-        int hi = 0;
-        for (int idx : f->sized) hi = std::max(hi, idx);
-        MSIM_HIP(c, hipMemcpy(f->h_dyn, f->d_dyn, sizeof(DynSizes) * (size_t)(hi + 1), hipMemcpyDeviceToHost));
-        for (int idx : f->sized) {
-            if ((size_t)idx >= c->contigs.size()) continue;
-            Contig &g = c->contigs[(size_t)idx];
-            if (!g.sizes_pending) continue;
-            const DynSizes s = f->h_dyn[idx];
-            flags |= s.flags & 0xffu;
-            g.sizes_pending = false;
-            g.d_dyn = nullptr;                             // host-known from here on (an APPLY in flight keeps its copy of the pointer)
-            g.n_rec = s.n_rec;
-            g.pool_len = s.pool_len;
-            g.plan_empty = !(s.flags & 0x100u);
-            if (!g.all_snp) {
-                g.known_delta = (long long)s.out_len - (long long)g.len;
-                g.delta_known = true;
-                if (g.applied) g.out_len = s.out_len;
+    g_prof.report();
+    for (int round = 0; f->pending && round < 3; round++) {
+        f->pending = false;
+        for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+        MSIM_HIP(c, hipEventRecord(f->t1, f->lane[0]));
+        MSIM_HIP(c, hipStreamSynchronize(f->lane[0]));
+        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        float ms = 0;
+        MSIM_HIP(c, hipEventElapsedTime(&ms, f->t0, f->t1));
+        c->t.plan_gpu_ms += ms;
+        for (auto &s : f->set) s.pending = false;
+        uint32_t flags = 0;
+        MSIM_HIP(c, hipMemcpy(&flags, f->d_flags, sizeof flags, hipMemcpyDeviceToHost));
+        std::vector<int> sized, redo;
+        sized.swap(f->sized);
+        if (!sized.empty()) {
+            int hi = 0;
+            for (int idx : sized) hi = std::max(hi, idx);
+            MSIM_HIP(c, hipMemcpy(f->h_dyn, f->d_dyn, sizeof(DynSizes) * (size_t)(hi + 1), hipMemcpyDeviceToHost));
+            for (int idx : sized) {
+                if ((size_t)idx >= c->contigs.size()) continue;
+                Contig &g = c->contigs[(size_t)idx];
+                if (!g.sizes_pending) continue;
+                const DynSizes s = f->h_dyn[idx];
+                if (s.flags & FF_NEED_ORBIT) { redo.push_back(idx); continue; }
+                flags |= s.flags & 0xffu;
+                g.sizes_pending = false;
+                g.d_dyn = nullptr;                         // host-known from here on (an APPLY in flight keeps its copy of the pointer)
+                g.n_rec = s.n_rec;
+                g.pool_len = s.pool_len;
+                g.plan_empty = !(s.flags & FF_KEPT_ANY);
+                if (!g.all_snp) {
+                    g.known_delta = (long long)s.out_len - (long long)g.len;
+                    g.delta_known = true;
+                    if (g.applied) g.out_len = s.out_len;
+                }
+                f->replay.erase(idx);
             }
         }
-        f->sized.clear();
-    }
-    if (flags) {
-        MSIM_HIP(c, hipMemset(f->d_flags, 0, 64));
-        if (flags & (FF_POOL_OVERFLOW | FF_OUT_OVERFLOW))
-            return fail(c, MSIM_ERR_HIP, "fast RNG sampler: the mutated length or the insert pool overflowed its 16-sigma allocation (results discarded)");
-        return fail(c, MSIM_ERR_HIP, "fast RNG sampler: internal error (flags " + std::to_string(flags) + "; results discarded)");
+        if (flags) {
+            MSIM_HIP(c, hipMemset(f->d_flags, 0, 64));
+            if (flags & (FF_POOL_OVERFLOW | FF_OUT_OVERFLOW))
+                return fail(c, MSIM_ERR_HIP, "fast RNG sampler: the mutated length or the insert pool overflowed its 16-sigma allocation (results discarded)");
+            return fail(c, MSIM_ERR_HIP, "fast RNG sampler: internal error (flags " + std::to_string(flags) + "; results discarded)");
+        }
+        // Contigs whose block-local boundary pass handed over (blocked ranges reaching over more than 64 candidates: long
+        // deletions at a high rate): planned again with the orbit kernels, and applied again where they already were -- the
+        // first plan left an empty record table, so the APPLY that ran was a plain copy.
+        for (int idx : redo) {
+            auto it = f->replay.find(idx);
+            if (it == f->replay.end()) return fail(c, MSIM_ERR_HIP, "fast RNG sampler: internal error (no tables to replay a plan from)");
+            Replay rp = std::move(it->second);
+            f->replay.erase(it);
+            Contig &g = c->contigs[(size_t)idx];
+            const bool was_applied = g.applied;
+            int rc = enqueue_plan(c, g, rp.P, rp.key, rp.seq, true);
+            if (rc) return rc;
+            f->replays++;
+            if (was_applied) {
+                g.apply_pending = false;                   // (its first APPLY has completed: everything was synchronised above)
+                g.dyn_applied = false;
+                if ((rc = apply_contig_device(c, g))) return rc;
+            }
+        }
     }
     return MSIM_OK;
 }
 
-int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key64, uint32_t seq) {
-    Prep P;
-    int rc = prepare(c, ct.len, ranges, n_ranges, P);
-    if (rc) return rc;
+// Enqueue PLAN of one contig.  orbit_only: the boundary pass / visit filter by the orbit kernels alone (the replay of a plan
+// whose block-local pass handed over, and the MSIM_FAST_FORCE_ORBIT test hook).
+static int enqueue_plan(Ctx *c, Contig &ct, Prep &P, uint64_t key64, uint32_t seq, bool orbit_only) {
+    int rc;
     const uint64_t K = P.K;
     ct.n_rec = P.snp_only ? K : 0;
     ct.n_rec_cap = K;
@@ -306,29 +368,37 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
     const uint32_t li = seq % F_SETS;
     FastSet &S = f->set[li];
     hipStream_t st = f->lane[li];
-    if (S.pending) {                                       // its last user's tables may still be in flight
-        MSIM_HIP(c, hipEventSynchronize(S.done));
+    g_prof.start();
+    if (S.pending) {                                       // its last user (8 contigs ago) may still be in flight on this stream
+        MSIM_HIP(c, hipStreamSynchronize(st));
         S.pending = false;
     }
+    g_prof.lap(1);
     if (!f->pending) MSIM_HIP(c, hipEventRecord(f->t0, st));
     f->pending = true;
     const Key key{(uint32_t)key64, (uint32_t)(key64 >> 32), seq};
     const uint32_t n_draw = (uint32_t)P.fr.size(), n_sets = (uint32_t)P.sets.size();
     const uint32_t n_leaves = (uint32_t)P.n_leaves;
     // ---- tables
-    const size_t tab_bytes = (size_t)n_draw * sizeof(FRange) + (size_t)n_sets * sizeof(Settings);
+    const uint32_t n_subs = (uint32_t)P.subs.size(), n_big = (uint32_t)P.big.size();
+    auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t off_sets = up16((size_t)n_draw * sizeof(FRange)), off_subs = up16(off_sets + (size_t)n_sets * sizeof(Settings)),
+                 off_big = up16(off_subs + (size_t)n_subs * sizeof(SubDesc));
+    const size_t tab_bytes = up16(off_big + (size_t)n_big * sizeof(uint32_t));
     if (S.h_tab.cap < tab_bytes) {
         if (S.h_tab.p) MSIM_HIP(c, hipHostFree(S.h_tab.p));
         S.h_tab.p = nullptr; S.h_tab.cap = 0;
         MSIM_HIP(c, hipHostMalloc(&S.h_tab.p, tab_bytes * 2 + 4096, hipHostMallocDefault));
         S.h_tab.cap = tab_bytes * 2 + 4096;
     }
-    if ((rc = dev_grow(c, f, S.ranges, n_draw))) return rc;
-    if ((rc = dev_grow(c, f, S.sets, n_sets))) return rc;
+    if ((rc = dev_grow(c, f, S.tab, tab_bytes))) return rc;
     if ((rc = dev_grow(c, f, S.leaves, n_leaves))) return rc;
-    if ((rc = dev_grow(c, f, S.leaf_m, (size_t)n_leaves + 1))) return rc;
+    if ((rc = dev_grow(c, f, S.sub_k, (size_t)n_subs + 1))) return rc;
+    if ((rc = dev_grow(c, f, S.sub_c0, (size_t)n_subs + 1))) return rc;
     memcpy(S.h_tab.p, P.fr.data(), (size_t)n_draw * sizeof(FRange));
-    memcpy(S.h_tab.p + (size_t)n_draw * sizeof(FRange), P.sets.data(), (size_t)n_sets * sizeof(Settings));
+    memcpy(S.h_tab.p + off_sets, P.sets.data(), (size_t)n_sets * sizeof(Settings));
+    memcpy(S.h_tab.p + off_subs, P.subs.data(), (size_t)n_subs * sizeof(SubDesc));
+    if (n_big) memcpy(S.h_tab.p + off_big, P.big.data(), (size_t)n_big * sizeof(uint32_t));
     {   // the record table (and what APPLY reads beside it) may still be in use by an earlier APPLY of this contig
         const size_t want = (size_t)K * sizeof(msim_record);
         const size_t want_pool = (size_t)P.pool_cap + 2 * PAD, want_off = P.all_sn ? 0 : (size_t)K * sizeof(uint32_t);
@@ -342,69 +412,119 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
         if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, want_pool))) return rc;
         if (want_off && (rc = dev_reserve(c, (void **)&ct.d_off, &ct.cap_off, want_off))) return rc;
     }
-    MSIM_HIP(c, hipMemcpyAsync(S.ranges.p, S.h_tab.p, (size_t)n_draw * sizeof(FRange), hipMemcpyHostToDevice, st));
-    if (!P.snp_only)
-        MSIM_HIP(c, hipMemcpyAsync(S.sets.p, S.h_tab.p + (size_t)n_draw * sizeof(FRange), (size_t)n_sets * sizeof(Settings),
-                                   hipMemcpyHostToDevice, st));
+    g_prof.lap(2);
+    MSIM_HIP(c, hipMemcpyAsync(S.tab.p, S.h_tab.p, tab_bytes, hipMemcpyHostToDevice, st));
+    g_prof.lap(3);
+    const FRange *d_ranges = reinterpret_cast<const FRange *>(S.tab.p);
+    const Settings *d_sets = reinterpret_cast<const Settings *>(S.tab.p + off_sets);
+    const SubDesc *d_subs = reinterpret_cast<const SubDesc *>(S.tab.p + off_subs);
+    const uint32_t *d_big = reinterpret_cast<const uint32_t *>(S.tab.p + off_big);
     // ---- positions
-    hipLaunchKernelGGL(k_fsplit, dim3(n_draw), dim3(256), 0, st, S.ranges.p, key, S.leaf_m.p, S.leaves.p, f->d_flags);
+    if (n_big)
+        hipLaunchKernelGGL(k_fsplit_top, dim3(n_big), dim3(1024), 0, st, d_ranges, d_big, key, S.sub_k.p, S.sub_c0.p, f->d_flags);
+    const uint32_t nb = (uint32_t)((K + OB_BLOCK - 1) / OB_BLOCK);
+    if (!P.snp_only && (rc = dev_grow(c, f, S.blk_u32, (size_t)7 * (nb + 1)))) return rc;
+    uint32_t *blk_max1 = P.snp_only ? nullptr : S.blk_u32.p + (size_t)5 * (nb + 1), *blk_max2 = P.snp_only ? nullptr : blk_max1 + (nb + 1);
+    hipLaunchKernelGGL(k_fsplit_sub, dim3((n_subs + 3) / 4), dim3(256), 0, st, d_ranges, d_subs, n_subs, key, S.sub_k.p, S.sub_c0.p,
+                       S.leaves.p, f->d_flags, blk_max1, P.snp_only ? 0u : 2 * (nb + 1), P.snp_only ? (uint32_t *)nullptr : S.kept_any);
+    g_prof.lap(4);
     const uint32_t bm_words = (1u << P.lgB_max) / 32 + 2;
-    const size_t lds = (size_t)4 * bm_words * sizeof(uint32_t);
+    const size_t lds = (size_t)4 * (bm_words + LEAF_LIST) * sizeof(uint32_t);
     const uint32_t leaf_blocks = (n_leaves + 3) / 4;
     if (P.snp_only) {
-        hipLaunchKernelGGL(k_fleaf<false>, dim3(leaf_blocks), dim3(256), lds, st, S.ranges.p, S.leaves.p, n_leaves, bm_words, key,
+        hipLaunchKernelGGL(k_fleaf<false>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, n_leaves, bm_words, key,
                            (uint32_t)P.d, ct.len, (const Settings *)nullptr, P.block1, (unsigned long long)c->params.ti_lim, ct.d_recs,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, f->d_flags);
+                           (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, f->d_flags);
         MSIM_HIP(c, hipGetLastError());
+        g_prof.lap(5);
     } else {
-        const uint32_t nb = (uint32_t)((K + OB_BLOCK - 1) / OB_BLOCK);
         if ((rc = dev_grow(c, f, S.cand_pos, K))) return rc;
         if ((rc = dev_grow(c, f, S.cand_stop, K))) return rc;
         if ((rc = dev_grow(c, f, S.cand_bend, K))) return rc;
         if ((rc = dev_grow(c, f, S.blk_out, K))) return rc;
+        if (P.need_visit && (rc = dev_grow(c, f, S.cand_end2, K))) return rc;
         if ((rc = dev_grow(c, f, S.cand_meta, K + 16))) return rc;
-        if ((rc = dev_grow(c, f, S.blk_u32, (size_t)5 * (nb + 1)))) return rc;
         if ((rc = dev_grow(c, f, S.blk_delta, (size_t)nb + 1))) return rc;
         uint32_t *blk_S = S.blk_u32.p, *blk_indep = blk_S + (nb + 1), *blk_in = blk_indep + (nb + 1), *blk_nrec = blk_in + (nb + 1),
                  *blk_pool = blk_nrec + (nb + 1);
-        hipLaunchKernelGGL(k_fleaf<true>, dim3(leaf_blocks), dim3(256), lds, st, S.ranges.p, S.leaves.p, n_leaves, bm_words, key,
-                           (uint32_t)P.d, ct.len, S.sets.p, P.block1, (unsigned long long)c->params.ti_lim, (msim_record *)nullptr,
-                           S.cand_pos.p, S.cand_stop.p, S.cand_bend.p, S.cand_meta.p, f->d_flags);
-        MSIM_HIP(c, hipMemsetAsync(S.kept_any, 0, 4, st));
+        hipLaunchKernelGGL(k_fleaf<true>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, n_leaves, bm_words, key,
+                           (uint32_t)P.d, ct.len, d_sets, P.block1, (unsigned long long)c->params.ti_lim, (msim_record *)nullptr,
+                           S.cand_pos.p, S.cand_stop.p, S.cand_bend.p, S.cand_meta.p, blk_max1, f->d_flags);
+        g_prof.lap(5);
+        uint32_t *fb1 = S.kept_any + 1, *fb2 = S.kept_any + 2;             // kept_any [0]; [1] / [2]: pass 1 / 2 handed over (zeroed by k_fsplit_sub)
+        // One pass = k_fkeep (block-local: free candidates + short cluster walks).  Where blocked ranges reach over more than its
+        // 64-candidate halo it raises *fb and the plan is replayed with the three orbit kernels when the sizes are collected
+        // (fast_plan_collect): nothing of the common path pays for them.
+        auto pass = [&](bool visit, bool final, const uint32_t *end_in, uint32_t *end2, uint32_t maxspan, uint32_t *fb) {
+#define MSIM_FK(V, F) hipLaunchKernelGGL((k_fkeep<V, F>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, \
+                                         (const uint32_t *)(visit ? blk_max2 : blk_max1), end2, blk_max2, S.cand_stop.p, \
+                                         S.cand_meta.p, (uint32_t)K, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any, fb)
+#define MSIM_FM(V, F) hipLaunchKernelGGL((k_forbit_mark<V, F>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, end2, S.cand_stop.p, \
+                                         S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any, \
+                                         (const uint32_t *)nullptr)
+            if (!orbit_only && nb <= 4096) {               // (beyond: every block would read thousands of block maxima)
+                if (!visit && final) MSIM_FK(false, true); else if (!visit) MSIM_FK(false, false); else MSIM_FK(true, true);
+            } else {
+                hipLaunchKernelGGL(k_forbit_local, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, (uint32_t)K, maxspan, S.blk_out.p,
+                                   blk_S, blk_indep, (const uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)K, nb,
+                                   blk_in, (const uint32_t *)nullptr);
+                if (!visit && final) MSIM_FM(false, true); else if (!visit) MSIM_FM(false, false); else MSIM_FM(true, true);
+            }
+#undef MSIM_FK
+#undef MSIM_FM
+            (void)fb;
+        };
         // ---- boundary pass (mutator.py:184-213)
-        hipLaunchKernelGGL(k_forbit_local, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, (uint32_t)K, P.maxspan,
-                           S.blk_out.p, blk_S, blk_indep);
-        hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)K, nb, blk_in);
         if (!P.need_visit) {
-            hipLaunchKernelGGL((k_forbit_mark<false, true>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, S.cand_stop.p,
-                               S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any);
+            pass(false, true, S.cand_bend.p, nullptr, P.maxspan, fb1);
         } else {
-            hipLaunchKernelGGL((k_forbit_mark<false, false>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, S.cand_stop.p,
-                               S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any);
-            // ---- visit filter (mutator.py:376,386,398): the same orbit over what the kept records consume
-            hipLaunchKernelGGL(k_forbit_local, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, (uint32_t)K, P.maxspan_visit,
-                               S.blk_out.p, blk_S, blk_indep);
-            hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)K, nb, blk_in);
-            hipLaunchKernelGGL((k_forbit_mark<true, true>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_bend.p, S.cand_stop.p,
-                               S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any);
+            pass(false, false, S.cand_bend.p, S.cand_end2.p, P.maxspan, fb1);
+            // ---- visit filter (mutator.py:376,386,398): the same pass over what the kept records consume
+            pass(true, true, S.cand_end2.p, nullptr, P.maxspan_visit, fb2);
         }
         DynSizes *dyn = f->d_dyn + ct.index;
-        hipLaunchKernelGGL(k_fscan, dim3(1), dim3(1024), 0, st, blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap,
-                           S.kept_any, f->d_flags, dyn);
-        hipLaunchKernelGGL(k_femit, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, (uint32_t)K, blk_nrec,
-                           blk_pool, S.blk_delta.p, dyn, key, (unsigned long long)c->params.ti_lim, ct.d_recs,
-                           P.all_sn ? S.blk_out.p : ct.d_off, ct.d_pool + PAD);
+        uint32_t *rec_off = P.all_sn ? S.blk_out.p : ct.d_off;
+        if (nb <= 4096) {
+            hipLaunchKernelGGL(k_femit<true>, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, (uint32_t)K,
+                               blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap, S.kept_any, f->d_flags, dyn, key,
+                               ct.d_recs, rec_off, ct.d_pool + PAD);
+        } else {
+            hipLaunchKernelGGL(k_fscan, dim3(1), dim3(1024), 0, st, blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap,
+                               S.kept_any, f->d_flags, dyn);
+            hipLaunchKernelGGL(k_femit<false>, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, (uint32_t)K,
+                               blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap, S.kept_any, f->d_flags, dyn, key,
+                               ct.d_recs, rec_off, ct.d_pool + PAD);
+        }
         MSIM_HIP(c, hipGetLastError());
         ct.d_dyn = reinterpret_cast<const uint32_t *>(dyn);
         ct.sizes_pending = true;
         ct.off_ready = !P.all_sn;
         f->sized.push_back(ct.index);
     }
-    // ---- whatever reads the records (APPLY, text) runs on the emit stream behind this contig's PLAN
-    MSIM_HIP(c, hipEventRecord(S.done, st));
-    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, S.done, 0));
+    g_prof.lap(6);
+    // ---- its APPLY follows on the same stream (apply.hip: Contig::apply_stream): no event, no cross-stream wait, and the rewrite
+    // kernels of different contigs overlap like everything else; whoever reads the records from another stream (text, fetches)
+    // drains first
+    ct.apply_stream = st;
     S.pending = true;
+    g_prof.lap(7);
+    g_prof.n++;
+    if (!P.snp_only && !orbit_only) {                      // what a replay needs, should the block-local pass hand over
+        Replay &rp = f->replay[ct.index];
+        rp.key = key64; rp.seq = seq;
+        rp.P = std::move(P);
+    }
     return MSIM_OK;
+}
+
+int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key64, uint32_t seq) {
+    Prep P;
+    g_prof.start();
+    const int rc = prepare(c, ct.len, ranges, n_ranges, P);
+    g_prof.lap(0);
+    if (rc) return rc;
+    return enqueue_plan(c, ct, P, key64, seq, getenv("MSIM_FAST_FORCE_ORBIT") != nullptr);
 }
 
 // ======================================================================================== host restatement (test support)
@@ -419,7 +539,7 @@ int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
     out.recs.clear();
     out.pool.clear();
     out.empty = true;
-    struct Kept { uint32_t pos, stop, ord; uint8_t type; };
+    struct Kept { uint32_t pos, stop, ord; uint8_t type, aux; };
     std::vector<Kept> kept;
     for (size_t ri = 0; ri < P.fr.size(); ri++) {
         const FRange &R = P.fr[ri];
@@ -457,13 +577,13 @@ int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
             for (uint32_t v = 0; v < len; v++) {
                 if ((seen[v] != 0) == inv) continue;
                 const uint32_t pos = R.start + v0 + v + (uint32_t)P.d * (ord - R.cand_base);
-                const Cand cd = cand_draw(key, ord, pos, L, P.sets[R.set], P.block1.v, R.clip);
+                const Cand cd = cand_draw(key, ord, pos, L, P.sets[R.set], P.block1.v, R.clip, c->params.ti_lim);
                 const uint32_t o = ord++;
                 if ((int64_t)pos < blocked_end) continue;                // mutator.py:190-192
                 if (cd.meta & CAND_DROPPED) continue;                    // mutator.py:199-201
                 const uint8_t ty = cd.meta & 7;
                 blocked_end = (ty == MSIM_SN || ty == MSIM_IN) ? (int64_t)pos + P.block1.v[ty] : (int64_t)cd.stop + P.block1.v[ty];
-                kept.push_back({pos, cd.stop, o, ty});
+                kept.push_back({pos, cd.stop, o, ty, (uint8_t)((cd.meta >> CAND_AUX_SHIFT) & 3)});
             }
         }
     }
@@ -473,7 +593,7 @@ int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_range
         if ((int64_t)q.pos <= cover) continue;                           // never visited   mutator.py:376,386,398
         msim_record rec;
         rec.pos = q.pos; rec.stop = q.stop; rec.extra = 0; rec.type = q.type; rec.aux = 0; rec.rsv = 0;
-        if (q.type == MSIM_SN) rec.aux = snp_outcome(key, q.ord, c->params.ti_lim);
+        if (q.type == MSIM_SN) rec.aux = q.aux;
         if (q.type == MSIM_IN) {
             rec.extra = (uint32_t)out.pool.size();
             const uint32_t len = q.stop - q.pos + 1;
@@ -502,16 +622,23 @@ int msim_dbg_fast_hypergeom(uint64_t good, uint64_t bad, uint64_t sample, uint64
     for (uint64_t i = 0; i < n; i++) out[i] = msim::fastrng::hypergeometric(good, bad, sample, k, node0 + (uint32_t)i, range);
     return MSIM_OK;
 }
+// plans of this context that were replayed with the orbit kernels (the block-local boundary pass handed over)
+int msim_dbg_fast_replays(msim_ctx *p, uint64_t *n) {
+    msim::Ctx *c = reinterpret_cast<msim::Ctx *>(p);
+    if (!c || !n) return MSIM_ERR_ARG;
+    *n = c->fast ? c->fast->replays : 0;
+    return MSIM_OK;
+}
 // op 0: d_log(x)  1: d_sqrt(x)  2: log_factorial((uint64) x)  3: d_log1p(x)  4: log_factorial_diff((uint64) x, (int64) y[i])
 int msim_dbg_fast_math(int op, const double *x, const double *y, uint64_t n, double *out) {
     if (!x || !out) return MSIM_ERR_ARG;
     for (uint64_t i = 0; i < n; i++) {
         switch (op) {
             case 0: out[i] = msim::fastrng::d_log(x[i]); break;
-            case 1: out[i] = msim::fastrng::d_sqrt(x[i]); break;
+            case 1: out[i] = msim::fastrng::d_sqrt_up(x[i]); break;
             case 2: out[i] = msim::fastrng::log_factorial((uint64_t)x[i]); break;
             case 3: out[i] = msim::fastrng::d_log1p(x[i]); break;
-            case 4: if (!y) return MSIM_ERR_ARG; out[i] = msim::fastrng::log_factorial_diff((uint64_t)x[i], (int64_t)y[i]); break;
+            case 4: if (!y) return MSIM_ERR_ARG; out[i] = msim::fastrng::log_factorial_diff(msim::fastrng::lf_base((uint64_t)x[i]), (int64_t)y[i]); break;
             default: return MSIM_ERR_ARG;
         }
     }

@@ -77,26 +77,35 @@ def d_log(x):
     return e.astype(np.float64) * 0.6931471805599453 + t
 
 
+def _atanh_series(s):
+    z = s * s
+    p = np.full(np.shape(s), 1.0 / 23.0)
+    for q in (21.0, 19.0, 17.0, 15.0, 13.0, 11.0, 9.0, 7.0, 5.0, 3.0):
+        p = p * z + 1.0 / q
+    p = p * z + 1.0
+    return (2.0 * s) * p
+
+
 def d_log1p(t):
     t = np.asarray(t, dtype=np.float64)
-    u = 1.0 + t
-    same = u == 1.0
-    us = np.where(same, 2.0, u)
-    return np.where(same, t, d_log(us) * t / (us - 1.0))
+    near = (t > -0.25) & (t < 0.4)
+    tn = np.where(near, t, 0.0)
+    series = _atanh_series(tn / (2.0 + tn))
+    far = d_log(np.where(near, 1.0, 1.0 + t))
+    return np.where(near, series, far)
 
 
-def d_sqrt(x):
+def d_sqrt_up(x):
     x = np.asarray(x, dtype=np.float64)
     b = x.view(np.uint64).reshape(x.shape)
     e = ((b >> U64(52)) & U64(0x7FF)).astype(np.int64) - 1023
     y = ((1023 + (e >> 1)).astype(np.uint64) << U64(52)).view(np.float64)
-    for _ in range(7):
+    for _ in range(4):
         y = 0.5 * (y + x / y)
     return y
 
 
-def stirling_corr(y):
-    iy = 1.0 / y
+def stirling_corr_inv(iy):
     iy2 = iy * iy
     return iy * (1.0 / 12.0 - iy2 * (1.0 / 360.0 - iy2 * (1.0 / 1260.0)))
 
@@ -108,7 +117,7 @@ def log_factorial(x):
     for i in range(2, 32):
         p = np.where(small & (x >= i), p * float(i), p)
     y = np.where(small, 33.0, (x + 1).astype(np.float64))
-    big = (y - 0.5) * d_log(y) - y + 0.9189385332046727 + stirling_corr(y)
+    big = (y - 0.5) * d_log(y) - y + 0.9189385332046727 + stirling_corr_inv(1.0 / y)
     return np.where(small, d_log(p), big)
 
 
@@ -121,7 +130,8 @@ def log_factorial_diff(a, d):
     y0 = np.where(stable, a + 1, 40).astype(np.float64)
     y1 = np.where(stable, a1 + 1, 40).astype(np.float64)
     dd = np.where(stable, d, 0).astype(np.float64)
-    st = (y1 - 0.5) * d_log1p(dd / y0) + dd * (d_log(y0) - 1.0) + (stirling_corr(y1) - stirling_corr(y0))
+    iy0 = 1.0 / y0
+    st = (y1 - 0.5) * d_log1p(dd * iy0) + dd * (d_log(y0) - 1.0) + (stirling_corr_inv(1.0 / y1) - stirling_corr_inv(iy0))
     plain = log_factorial(np.where(stable, 0, a1)) - log_factorial(np.where(stable, 0, a))
     return np.where(d == 0, 0.0, np.where(stable, st, plain))
 
@@ -165,7 +175,7 @@ def hypergeometric(good, bad, sample, key, seq, node, rng):
         q = 1.0 - p
         a = m_.astype(np.float64) * p + 0.5
         var = (N_ - m_).astype(np.float64) * m_.astype(np.float64) * p * q / (N_ - 1).astype(np.float64)
-        c = d_sqrt(var + 0.5)
+        c = d_sqrt_up(var + 0.5)
         h = 1.7155277699214135 * c + 0.8989161620588988
         mode = ((m_ + 1).astype(object) * (mingb + 1).astype(object) // (N_ + 2).astype(object)).astype(np.int64)
         lim_a = (np.minimum(m_, mingb) + 1).astype(np.float64)
@@ -341,9 +351,9 @@ def plan(L, ranges, block, ti_lim, key, seq):
     P, S, O, T = (np.array(c, dtype=np.int64) for c in zip(*vis))
     aux = np.zeros(len(P), dtype=np.int64)
     sn = T == SN
-    if sn.any():                                        # mutator.py:428-455
-        v = draw4(key, seq, O[sn], 1, TAG_CAND)
-        aux[sn] = np.where((lo64(v) >> U64(11)) < U64(ti_lim), 0, 1 + (v[2] & U64(1)).astype(np.int64))
+    if sn.any():                                        # mutator.py:428-455: the high 64 bits of the candidate's draw
+        r = hi64(draw4(key, seq, O[sn], 0, TAG_CAND))
+        aux[sn] = np.where((r >> U64(11)) < U64(ti_lim), 0, 1 + (r & U64(1)).astype(np.int64))
     extra = np.zeros(len(P), dtype=np.int64)
     ins = T == IN
     pool = np.zeros(0, dtype=np.uint8)

@@ -64,8 +64,9 @@ def test_log_sqrt_log_factorial_bit_identical_and_accurate():
     assert _same_bits(_math(0, x), ft.d_log(x))
     assert np.allclose(ft.d_log(x), np.log(x), rtol=4e-16, atol=2e-16)
     xs = np.exp(rng.uniform(-2, 60, 20000))
-    assert _same_bits(_math(1, xs), ft.d_sqrt(xs))
-    assert np.allclose(ft.d_sqrt(xs), np.sqrt(xs), rtol=3e-16)
+    assert _same_bits(_math(1, xs), ft.d_sqrt_up(xs))
+    up = ft.d_sqrt_up(xs) / np.sqrt(xs)                            # an upper bound within 3e-4 (the sampler's hat only needs that)
+    assert up.min() >= 1.0 - 1e-15 and up.max() < 1.0 + 3e-4
     n = np.concatenate((np.arange(0, 200), rng.randint(200, 2 ** 32, 5000))).astype(np.float64)
     assert _same_bits(_math(2, n), ft.log_factorial(n.astype(np.int64)))
     assert np.allclose(ft.log_factorial(n.astype(np.int64)), gammaln(n + 1.0), rtol=1e-14, atol=1e-12)

@@ -47,8 +47,13 @@ def _blocks(params):
     return {t: int(params.block[t]) for t in range(1, 8)}
 
 
+@pytest.mark.parametrize("orbit", [False, True], ids=["blocklocal", "orbit"])
 @pytest.mark.parametrize("name", sorted(SHAPES))
-def test_device_equals_numpy_restatement(name):
+def test_device_equals_numpy_restatement(name, orbit, monkeypatch):
+    """Both formulations of the boundary pass / visit filter: the block-local kernel (k_fkeep: free candidates + cluster walks;
+    the shape with 400 kb deletions makes it hand over to the orbit kernels by itself) and, forced, the orbit kernels alone."""
+    if orbit:
+        monkeypatch.setenv("MSIM_FAST_FORCE_ORBIT", "1")
     L, blocks, mk = SHAPES[name]
     params = _params({NAMES[t]: v for t, v in (blocks or {}).items()}, titv=2.0)
     ranges = mk(L)
@@ -63,6 +68,15 @@ def test_device_equals_numpy_restatement(name):
         assert_plan_equals_twin(recs, pool, empty, twin)
         eng.clear()
     assert eng.stats()["contigs_fast"] == 2
+    import ctypes as C
+    n = C.c_uint64()
+    assert eng.lib.msim_dbg_fast_replays(eng.h, C.byref(n)) == 0
+    # 400 kb deletions at rate 0.001 block ~100 candidates each: no free candidate in a 64-candidate halo -> the block-local
+    # kernel hands over and the plan is replayed with the orbit kernels.  Nothing else here comes near that.
+    if name == "long_deletions_dependent_blocks":
+        assert n.value == (0 if orbit else 2)
+    if orbit or name in ("svmix_one_range", "sn_block_7", "sn_block_svmix", "svmix_dense_end") or name.startswith("snp"):
+        assert n.value == 0
     eng.close()
 
 
