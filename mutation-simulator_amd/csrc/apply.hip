@@ -21,6 +21,7 @@
 //
 // Integer/byte work only -- no MFMA.  Roofline: HBM bandwidth.
 #include <algorithm>
+#include <vector>
 
 #include "ctx.h"
 
@@ -178,6 +179,32 @@ __global__ __launch_bounds__(THREADS) void k_tile_index(const uint32_t *__restri
         if ((uint64_t)o <= target) lo = mid + 1; else hi = mid;
     }
     first[t] = (int32_t)lo - 1;
+}
+
+// The same for up to 32 contigs in ONE launch (the counter-based engine applies a batch of contigs back to back: 24 launches
+// of 10 us each for a few thousand threads of work were a tenth of its step).  Jobs travel as kernel arguments.
+struct TileJob {
+    const uint32_t *off; const msim_record *recs; const uint32_t *dyn; int32_t *first; unsigned long long *err;
+    uint32_t n, n_entries, entry_base, rsv;
+};
+struct TileJobs { TileJob j[32]; uint32_t n_jobs, total; };
+__global__ __launch_bounds__(THREADS) void k_tile_index_batch(TileJobs J) {
+    const uint32_t g = blockIdx.x * THREADS + threadIdx.x;
+    if (g >= J.total) return;
+    uint32_t k = 0;
+    for (uint32_t q = 1; q < J.n_jobs; q++) if (J.j[q].entry_base <= g) k = q;
+    const TileJob &T = J.j[k];
+    const uint32_t t = g - T.entry_base;
+    if (t == 0) *T.err = ~0ull;
+    uint32_t n = T.dyn ? T.dyn[0] : T.n;
+    const uint64_t target = (uint64_t)t * TILE;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t o = T.off ? T.off[mid] : T.recs[mid].pos;
+        if ((uint64_t)o <= target) lo = mid + 1; else hi = mid;
+    }
+    T.first[t] = (int32_t)lo - 1;
 }
 
 // ------------------------------------------------------------------ 3. rewrite
@@ -977,6 +1004,49 @@ int apply_finish(Ctx *c) {
 // before the kernel can be launched); the KeyError word and the timings are collected by
 // apply_finish at the next synchronising call.  Tables with indels need the scanned total length to
 // size the output, so that path synchronises once.
+// APPLY of contigs the counter-based engine planned as one batch (plan_fast.hip): their tile indices in one launch, then the
+// rewrite kernels back to back on the batch's stream.
+int apply_batch_device(Ctx *c, const std::vector<int> &ids) {
+    TileJobs J;
+    J.n_jobs = 0; J.total = 0;
+    hipStream_t st = nullptr;
+    auto launch = [&]() {
+        if (J.n_jobs) hipLaunchKernelGGL(k_tile_index_batch, dim3((J.total + THREADS - 1) / THREADS), dim3(THREADS), 0, st, J);
+        J.n_jobs = 0; J.total = 0;
+    };
+    std::vector<int> marked;
+    for (int id : ids) {
+        Contig &g = c->contigs[(size_t)id];
+        const uint32_t *dyn = g.d_dyn;
+        const uint32_t n = (uint32_t)(dyn ? g.n_rec_cap : g.n_rec);
+        const uint64_t out_bound = g.all_snp ? g.len : (dyn ? g.out_cap_len : 0);
+        // (only what the engine plans itself: a device-sized table or an SNP-only one, on the batch's stream, not in flight)
+        if (!g.apply_stream || !n || !out_bound || g.apply_pending || (st && g.apply_stream != st)) continue;
+        st = g.apply_stream;
+        const uint32_t n_tiles = (uint32_t)((out_bound + TILE - 1) / TILE);
+        if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, hipStreamSynchronize(st));
+        int rc = dev_reserve(c, (void **)&g.d_first, &g.cap_first, (size_t)(n_tiles + 1) * sizeof(int32_t));
+        if (rc) return rc;
+        TileJob &T = J.j[J.n_jobs++];
+        T.off = g.all_snp ? nullptr : g.d_off; T.recs = g.d_recs; T.dyn = dyn; T.first = g.d_first; T.err = c->d_errs + g.index;
+        T.n = n; T.n_entries = n_tiles + 1; T.entry_base = J.total; T.rsv = 0;
+        J.total += n_tiles + 1;
+        g.tile_index_done = true;
+        marked.push_back(id);
+        if (J.n_jobs == 32) launch();
+    }
+    launch();
+    MSIM_HIP(c, hipGetLastError());
+    int rc = MSIM_OK;
+    for (int id : ids) {
+        Contig &g = c->contigs[(size_t)id];
+        if (!rc) rc = apply_contig_device(c, g);
+        g.tile_index_done = false;
+    }
+    for (int id : marked) c->contigs[(size_t)id].tile_index_done = false;
+    return rc;
+}
+
 int apply_contig_device(Ctx *c, Contig &g) {
     // (d_dyn: planned by the counter-based engine with types beyond SNPs -- the record count and the mutated length sit in
     //  device memory; `n` and the output length below are then the bounds the plan allocated for, and the kernels read
@@ -1055,9 +1125,11 @@ int apply_contig_device(Ctx *c, Contig &g) {
             if (rc) return rc;
             d_first = reinterpret_cast<int32_t *>(reinterpret_cast<uint8_t *>(c->d_scratch) + 64);
         }
-        hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, st,
-                           d_off, g.d_recs, n, d_first, n_tiles + 1, dyn, d_err);
-        MSIM_HIP(c, hipGetLastError());
+        if (!g.tile_index_done) {                          // (else: apply_batch_device did it for the whole batch)
+            hipLaunchKernelGGL(k_tile_index, dim3((n_tiles + 1 + THREADS - 1) / THREADS), dim3(THREADS), 0, st,
+                               d_off, g.d_recs, n, d_first, n_tiles + 1, dyn, d_err);
+            MSIM_HIP(c, hipGetLastError());
+        }
     } else {
         MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
     }

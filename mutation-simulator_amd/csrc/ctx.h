@@ -32,6 +32,7 @@ struct Contig {
     hipStream_t apply_stream = nullptr;   // the stream its PLAN ran on: its APPLY follows there (null: the context's emit stream)
     int32_t *d_first = nullptr;       // tile index of its own (contigs on different streams cannot share the context's scratch)
     size_t cap_first = 0;
+    bool tile_index_done = false;     // (transient) apply_batch_device has already launched this contig's tile index
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD
@@ -243,6 +244,10 @@ void fast_plan_destroy(Ctx *c);
 // MSIM_OK / MSIM_ERR_VALUE (the reference's ValueError: a sample larger than its population) / MSIM_ERR_UNSUPPORTED
 int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges);
 int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq);
+// plans queue up (plan_contig_fast) and go to the device as ONE batch: at the next entry point that needs a result
+int fast_plan_flush(Ctx *c);
+// is this contig's plan still queued?  mark_apply: its APPLY is enqueued right behind the batch (msim_apply_contig)
+bool fast_plan_queued(Ctx *c, int contig, bool mark_apply);
 // everything the engine enqueued has completed (the caller synchronised): sticky flags, sizes of the contigs planned with
 // device-side counts.  Idempotent.
 int fast_plan_collect(Ctx *c);
@@ -266,6 +271,7 @@ void comm_destroy(Ctx *c);
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);
+int apply_batch_device(Ctx *c, const std::vector<int> &ids);   // contigs of one batch of the counter-based engine
 int apply_finish(Ctx *c);             // collect results of asynchronous APPLYs (timing, KeyError words)
 constexpr int MAX_CONTIGS = 1 << 16;
 int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed);

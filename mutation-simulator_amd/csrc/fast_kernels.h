@@ -37,9 +37,35 @@ struct FRange {            // one drawing range (k > 0)
     uint32_t clip;         // stop + 1: blocked ends are clipped here (the blocked range is reset per range)
     uint32_t set;          // index into the Settings table
     uint32_t sub_base;     // number of its first subtree (64 leaves each)
-    uint32_t rsv;
+    uint32_t slot;         // the contig of the batch it belongs to
 };
-struct LeafDesc { uint32_t m, cand0, range, t; };          // points, ordinal of the first, its range, leaf number inside the range
+// One contig of a batch.  Every kernel below runs over ALL contigs of a batch at once (a genome = one launch per stage:
+// per-contig launches are latency-bound -- a 125 Mb contig is one round of workgroups -- and 24 of them on 8 streams still
+// left the device half idle).  Counters of the generator are per contig (ordinals, leaves, ranges restart at 0 with every
+// contig, `seq` tells the contigs apart), storage is concatenated: *_off says where the contig's part starts.
+struct FSlot {
+    uint64_t L;                // contig length
+    uint64_t out_cap, pool_cap;
+    msim_record *recs;         // the contig's own tables (ctx.h: Contig)
+    uint32_t *rec_off;
+    uint8_t *pool;
+    struct DynSizes *dyn;
+    uint32_t seq;              // contig ordinal of the generator
+    uint32_t K;                // candidates
+    uint32_t cand_off;         // first candidate in the candidate arrays (a multiple of OB_BLOCK)
+    uint32_t blk_off, nb;      // its blocks in the block arrays
+    uint32_t range_off, leaf_off, sub_off;
+};
+// A leaf, self-contained (k_fsplit_sub writes it, k_fleaf reads nothing else but its contig's slot and settings: the chain
+// leaf -> range -> slot -> settings was four dependent round trips at the head of every wave)
+struct LeafDesc {
+    uint32_t m, cand0;         // points; the contig's ordinal of the first one
+    uint32_t leaf_id;          // the generator's leaf number (per contig)
+    uint32_t len;              // values it spans (2^lgB, the range's last leaf fewer)
+    uint32_t pos0;             // position of value 0 of the leaf's candidate 0: pos = pos0 + value + d * ordinal  (mod 2^32)
+    uint32_t clip, set, slot;  // the range's stop + 1, its settings, its contig
+};
+struct Key2 { uint32_t k0, k1; };                          // the generator's key; the contig ordinal comes from the slot
 struct Block1 { uint32_t v[8]; };                          // block[t] + 1, saturated
 
 enum : uint32_t {
@@ -97,13 +123,19 @@ __device__ __forceinline__ uint32_t hyp_group(bool active, uint64_t good, uint64
     return active ? (uint32_t)hyp_finish(P, z) : 0u;
 }
 
-__global__ __launch_bounds__(1024) void k_fsplit_top(const FRange *__restrict__ ranges, const uint32_t *__restrict__ big, Key key,
+__global__ __launch_bounds__(1024) void k_fsplit_top(const FRange *__restrict__ ranges, const uint32_t *__restrict__ big,
+                                                     const FSlot *__restrict__ slots, Key2 key2,
                                                      uint32_t *__restrict__ sub_k, uint32_t *__restrict__ sub_c0,
                                                      uint32_t *__restrict__ flags) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
-    const uint32_t r = big[blockIdx.x];
-    const FRange R = ranges[r];
+    const uint32_t r_tab = big[blockIdx.x];
+    const FRange R = ranges[r_tab];
+    const FSlot &SL = slots[R.slot];
+    const Key key{key2.k0, key2.k1, SL.seq};
+    const uint32_t r = r_tab - SL.range_off;               // the generator counts ranges per contig
+    sub_k += SL.sub_off;
+    sub_c0 += SL.sub_off;
     const uint32_t lgB = R.lgB;
     const uint32_t T = (uint32_t)(((uint64_t)R.n + (1ull << lgB) - 1) >> lgB);
     uint32_t lgP = 0;
@@ -157,18 +189,27 @@ __global__ __launch_bounds__(1024) void k_fsplit_top(const FRange *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_fsplit_sub(const FRange *__restrict__ ranges, const SubDesc *__restrict__ subs, uint32_t n_subs,
-                                                    Key key, const uint32_t *__restrict__ sub_k, const uint32_t *__restrict__ sub_c0,
+                                                    const FSlot *__restrict__ slots, Key2 key2,
+                                                    const uint32_t *__restrict__ sub_k, const uint32_t *__restrict__ sub_c0,
                                                     LeafDesc *__restrict__ leaves, uint32_t *__restrict__ flags,
-                                                    uint32_t *__restrict__ zero_a, uint32_t n_zero_a, uint32_t *__restrict__ zero_b) {
+                                                    uint32_t *__restrict__ zero_a, uint32_t n_zero_a, uint32_t *__restrict__ zero_b,
+                                                    uint32_t n_zero_b, uint32_t d) {
     __shared__ uint32_t lds_m[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // (what the later kernels of this contig accumulate into starts at zero: the per-block maxima, the kept-any / hand-over words)
+    // (what the later kernels of this batch accumulate into starts at zero: the per-block maxima, the kept-any / hand-over words)
     for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < n_zero_a; q += gridDim.x * 256) zero_a[q] = 0;
-    if (zero_b && blockIdx.x == 0 && threadIdx.x < 4) zero_b[threadIdx.x] = 0;
+    for (uint32_t q = blockIdx.x * 256 + threadIdx.x; q < n_zero_b; q += gridDim.x * 256) zero_b[q] = 0;
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= n_subs) return;                               // (no workgroup barrier below)
-    const SubDesc D = subs[g];
-    const FRange R = ranges[D.range];
+    const SubDesc D0 = subs[g];
+    const FRange R = ranges[D0.range];
+    const FSlot &SL = slots[R.slot];
+    const Key key{key2.k0, key2.k1, SL.seq};
+    SubDesc D = D0;
+    D.range = D0.range - SL.range_off;                     // the generator counts ranges per contig
+    sub_k += SL.sub_off;
+    sub_c0 += SL.sub_off;
+    leaves += SL.leaf_off;
     const uint32_t lgB = R.lgB;
     const uint32_t T = (uint32_t)(((uint64_t)R.n + (1ull << lgB) - 1) >> lgB);
     uint32_t lgP = 0;
@@ -208,7 +249,11 @@ __global__ __launch_bounds__(256) void k_fsplit_sub(const FRange *__restrict__ r
     }
     if (t < T) {
         LeafDesc L;
-        L.m = v; L.cand0 = (has_top ? sub_c0[R.sub_base + D.s] : R.cand_base) + incl - v; L.range = D.range; L.t = t;
+        L.m = v; L.cand0 = (has_top ? sub_c0[R.sub_base + D.s] : R.cand_base) + incl - v;
+        L.leaf_id = R.leaf_base + t;
+        L.len = min(1u << lgB, R.n - (t << lgB));
+        L.pos0 = R.start + (t << lgB) - d * R.cand_base;
+        L.clip = R.clip; L.set = R.set; L.slot = R.slot;
         leaves[R.leaf_base + t] = L;
     }
 }
@@ -218,9 +263,9 @@ __global__ __launch_bounds__(256) void k_fsplit_sub(const FRange *__restrict__ r
 constexpr uint32_t LEAF_LIST = 1024;                       // values a leaf can stage for the balanced pass (a leaf holds ~100-200)
 template <bool SV>
 __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges, const LeafDesc *__restrict__ leaves,
-                                               uint32_t n_leaves, uint32_t bm_words, Key key, uint32_t d, uint64_t L,
-                                               const Settings *__restrict__ sets, Block1 block1, unsigned long long ti_lim,
-                                               msim_record *__restrict__ recs, uint32_t *__restrict__ cand_pos,
+                                               uint32_t n_leaves, uint32_t bm_words, const FSlot *__restrict__ slots, Key2 key2,
+                                               uint32_t d, const Settings *__restrict__ sets, Block1 block1, unsigned long long ti_lim,
+                                               uint32_t *__restrict__ cand_pos,
                                                uint32_t *__restrict__ cand_stop, uint32_t *__restrict__ cand_bend,
                                                uint8_t *__restrict__ cand_meta, uint32_t *__restrict__ blk_max,
                                                uint32_t *__restrict__ flags) {
@@ -232,9 +277,16 @@ __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges
     uint32_t *bm = lds_bm + (size_t)wave * (bm_words + LEAF_LIST);
     uint32_t *list = bm + bm_words;
     const LeafDesc D = leaves[g];
-    const FRange R = ranges[D.range];
-    const uint32_t v0 = D.t << R.lgB;
-    const uint32_t len = min(1u << R.lgB, R.n - v0);
+    const FSlot &SL = slots[D.slot];
+    const Key key{key2.k0, key2.k1, SL.seq};
+    const uint32_t leaf_id = D.leaf_id;                    // the generator counts leaves per contig
+    const uint64_t L = SL.L;
+    msim_record *recs = SL.recs;
+    if (SV) {                                              // storage of the batch is concatenated, ordinals are per contig
+        cand_pos += SL.cand_off; cand_stop += SL.cand_off; cand_bend += SL.cand_off; cand_meta += SL.cand_off;
+        blk_max += SL.blk_off;
+    }
+    const uint32_t len = D.len;
     const uint32_t m = D.m;
     if (m == 0) return;
     const uint32_t words32 = (len + 31) >> 5;
@@ -247,14 +299,23 @@ __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges
     const uint32_t need = inv ? len - m : m;
     uint32_t have = 0, done = 0;
     while (have < need) {
-        const uint32_t cnt = min(need - have, 64u);
-        bool fresh = false;
-        if ((uint32_t)lane < cnt) {
-            const uint32_t v = leaf_draw(key, g, done + lane, len);
-            const uint32_t bit = 1u << (v & 31);
-            fresh = !(atomicOr(&bm[v >> 5], bit) & bit);
+        // a counter yields two draws (fast_math.h: leaf_draw): lane l takes draws base + 2 l and base + 2 l + 1 of the sequence
+        const uint32_t base = done & ~1u, cnt = min(need - have, 128u - (done & 1u));
+        const uint32_t ja = base + 2 * lane, jb = ja + 1;
+        const bool va = ja >= done && ja < done + cnt, vb = jb >= done && jb < done + cnt;
+        bool fa = false, fb = false;
+        if (va || vb) {
+            const U4 r = draw4(key, ja >> 1, leaf_id, TAG_POS);
+            if (va) {
+                const uint32_t v = (uint32_t)below(lo64(r), len), bit = 1u << (v & 31);
+                fa = !(atomicOr(&bm[v >> 5], bit) & bit);
+            }
+            if (vb) {
+                const uint32_t v = (uint32_t)below(hi64(r), len), bit = 1u << (v & 31);
+                fb = !(atomicOr(&bm[v >> 5], bit) & bit);
+            }
         }
-        have += (uint32_t)__popcll(__ballot(fresh));
+        have += (uint32_t)__popcll(__ballot(fa)) + (uint32_t)__popcll(__ballot(fb));
         done += cnt;
         if (done > 64u * need + 65536u) {                  // (a geometric tail that long does not happen)
             if (lane == 0) atomicOr(flags, (uint32_t)FF_LEAF_GAVE_UP);
@@ -287,13 +348,13 @@ __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges
         if (lane == 0) atomicOr(flags, (uint32_t)FF_LEAF_MISMATCH);
         return;
     }
-    const uint32_t pos0 = R.start + v0 - d * R.cand_base;  // pos = start + v0 + v + d * (ord - cand_base)   (mod 2^32 throughout)
-    const Settings *S = SV ? sets + R.set : nullptr;
+    const uint32_t pos0 = D.pos0;                          // pos = start + v0 + v + d * (ord - cand_base)   (mod 2^32 throughout)
+    const Settings *S = SV ? sets + D.set : nullptr;
     // what one candidate is: its draws (one counter: type + length, or the SNP's outcome) and its stores
     auto emit = [&](uint32_t v, uint32_t ord) -> uint32_t {
         const uint32_t pos = pos0 + v + d * ord;
         if (SV) {
-            const Cand c = cand_draw(key, ord, pos, L, *S, block1.v, R.clip, ti_lim);
+            const Cand c = cand_draw(key, ord, pos, L, *S, block1.v, D.clip, ti_lim);
             cand_pos[ord] = pos;
             cand_stop[ord] = c.stop;
             cand_bend[ord] = c.bend;
@@ -566,15 +627,22 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
                                                       uint32_t *__restrict__ blk_max2, const uint32_t *__restrict__ cand_stop,
                                                       uint8_t *__restrict__ cand_meta, uint32_t K,
                                                       uint32_t *__restrict__ blk_nrec, uint32_t *__restrict__ blk_pool,
-                                                      long long *__restrict__ blk_delta, uint32_t *__restrict__ kept_any,
-                                                      uint32_t *__restrict__ fallback) {
+                                                      long long *__restrict__ blk_delta, uint32_t *__restrict__ kept_all,
+                                                      const FSlot *__restrict__ slots, const uint32_t *__restrict__ blk_slot) {
     __shared__ uint32_t pos_h[2 * OB_BLOCK + 1], E_h[2 * OB_BLOCK];
     __shared__ uint8_t onorb[OB_BLOCK];
     __shared__ uint32_t wmax[2][OB_THREADS / 64], wred[OB_THREADS / 64];
     __shared__ int32_t wanchor[OB_THREADS / 64];
     __shared__ uint32_t red_n[OB_THREADS / 64], red_p[OB_THREADS / 64];
     __shared__ long long red_d[OB_THREADS / 64];
-    const uint32_t b = blockIdx.x, base = b * OB_BLOCK, cnt = min((uint32_t)OB_BLOCK, K - base);
+    const uint32_t slot = blk_slot[blockIdx.x];             // which contig of the batch (one load: a search through the slot table
+    const FSlot &SL = slots[slot];                          //  was five dependent round trips at the head of every workgroup)
+    K = SL.K;
+    cand_pos += SL.cand_off; cand_end += SL.cand_off; cand_stop += SL.cand_off; cand_meta += SL.cand_off;
+    if (cand_end2) cand_end2 += SL.cand_off;
+    blk_max += SL.blk_off;
+    uint32_t *kept_any = kept_all + 4 * slot, *fallback = kept_any + (VISIT ? 2 : 1);
+    const uint32_t b = blockIdx.x - SL.blk_off, base = b * OB_BLOCK, cnt = min((uint32_t)OB_BLOCK, K - base);
     const bool prev = b > 0;                                // (the previous block is always a full one)
     uint32_t *pos = pos_h + OB_BLOCK, *E = E_h + OB_BLOCK;   // in-block index i; the previous block at i - 2048
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -779,20 +847,31 @@ __global__ __launch_bounds__(1024) void k_fscan(uint32_t *__restrict__ blk_nrec,
 // SCAN = false: the block arrays hold offsets (k_fscan ran).
 template <bool SCAN>
 __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict__ cand_pos, const uint32_t *__restrict__ cand_stop,
-                                                      const uint8_t *__restrict__ cand_meta, uint32_t K,
+                                                      const uint8_t *__restrict__ cand_meta,
                                                       const uint32_t *__restrict__ blk_nrec, const uint32_t *__restrict__ blk_pool,
-                                                      const long long *__restrict__ blk_delta, uint32_t nb, uint64_t L, uint64_t out_cap,
-                                                      uint64_t pool_cap, const uint32_t *__restrict__ kept_any, uint32_t *__restrict__ flags,
-                                                      DynSizes *__restrict__ dyn, Key key, msim_record *__restrict__ recs,
-                                                      uint32_t *__restrict__ rec_off, uint8_t *__restrict__ pool) {
+                                                      const long long *__restrict__ blk_delta, const uint32_t *__restrict__ kept_all,
+                                                      uint32_t *__restrict__ flags, const FSlot *__restrict__ slots,
+                                                      const uint32_t *__restrict__ blk_slot, Key2 key2) {
     __shared__ uint32_t wn[OB_THREADS / 64], wp[OB_THREADS / 64];
     __shared__ long long wd[OB_THREADS / 64];
     __shared__ uint32_t base_n, base_p;
     __shared__ long long base_d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t slot = blk_slot[blockIdx.x];             // which contig of the batch (see k_fkeep)
+    const FSlot &SL = slots[slot];
+    const Key key{key2.k0, key2.k1, SL.seq};
+    const uint32_t K = SL.K, nb = SL.nb, blk = blockIdx.x - SL.blk_off;
+    const uint64_t L = SL.L, out_cap = SL.out_cap, pool_cap = SL.pool_cap;
+    const uint32_t *kept_any = kept_all + 4 * slot;
+    DynSizes *dyn = SL.dyn;
+    msim_record *recs = SL.recs;
+    uint32_t *rec_off = SL.rec_off;
+    uint8_t *pool = SL.pool;
+    cand_pos += SL.cand_off; cand_stop += SL.cand_off; cand_meta += SL.cand_off;
+    blk_nrec += SL.blk_off; blk_pool += SL.blk_off; blk_delta += SL.blk_off;
     if (SCAN) {
         if (kept_any[1] | kept_any[2]) {                   // k_fkeep handed the pass over: this plan is replayed (plan_fast.hip)
-            if (blockIdx.x == nb - 1 && threadIdx.x == 0) {
+            if (blk == nb - 1 && threadIdx.x == 0) {
                 DynSizes s; s.n_rec = 0; s.out_len = (uint32_t)L; s.pool_len = 0; s.flags = FF_NEED_ORBIT;
                 *dyn = s;
             }
@@ -800,7 +879,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
         }
         uint32_t sn = 0, sp = 0;
         long long sd = 0;
-        for (uint32_t b2 = threadIdx.x; b2 < blockIdx.x; b2 += OB_THREADS) { sn += blk_nrec[b2]; sp += blk_pool[b2]; sd += blk_delta[b2]; }
+        for (uint32_t b2 = threadIdx.x; b2 < blk; b2 += OB_THREADS) { sn += blk_nrec[b2]; sp += blk_pool[b2]; sd += blk_delta[b2]; }
         for (int o = 32; o > 0; o >>= 1) { sn += __shfl_down(sn, o, 64); sp += __shfl_down(sp, o, 64); sd += __shfl_down(sd, o, 64); }
         if (lane == 0) { wn[wave] = sn; wp[wave] = sp; wd[wave] = sd; }
         __syncthreads();
@@ -809,7 +888,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
             long long td = 0;
             for (int w = 0; w < OB_THREADS / 64; w++) { tn += wn[w]; tp += wp[w]; td += wd[w]; }
             base_n = tn; base_p = tp; base_d = td;
-            if (blockIdx.x == nb - 1) {                    // totals = offsets of a block behind the last
+            if (blk == nb - 1) {                    // totals = offsets of a block behind the last
                 const unsigned long long pool_tot = (unsigned long long)tp + blk_pool[nb - 1];
                 const long long out_len = (long long)L + td + blk_delta[nb - 1];
                 uint32_t f = 0;
@@ -827,10 +906,10 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
         __syncthreads();
     } else {
         if (dyn->flags & (FF_POOL_OVERFLOW | FF_OUT_OVERFLOW | FF_NEED_ORBIT)) return;
-        if (threadIdx.x == 0) { base_n = blk_nrec[blockIdx.x]; base_p = blk_pool[blockIdx.x]; base_d = blk_delta[blockIdx.x]; }
+        if (threadIdx.x == 0) { base_n = blk_nrec[blk]; base_p = blk_pool[blk]; base_d = blk_delta[blk]; }
         __syncthreads();
     }
-    const uint32_t i0 = blockIdx.x * OB_BLOCK + threadIdx.x * OB_ITEMS;
+    const uint32_t i0 = blk * OB_BLOCK + threadIdx.x * OB_ITEMS;
     uint32_t pos[OB_ITEMS], stop[OB_ITEMS];
     uint8_t meta[OB_ITEMS];
     if (i0 + OB_ITEMS <= K) {                              // 8 consecutive candidates: 8 + 32 + 32 bytes in three / five loads
@@ -874,9 +953,14 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
     __syncthreads();                                       // (wn / wp / wd are reused)
     if (lane == 63) { wn[wave] = in; wp[wave] = ip; wd[wave] = id; }
     __syncthreads();
-    uint32_t r = base_n + in - nk, p = base_p + ip - np;
+    // records and offsets are staged in LDS and leave the workgroup as two contiguous runs (a lane's records sit ~100 bytes
+    // apart from its neighbour's: written straight from the lanes every store instruction touched 64 cache lines)
+    __shared__ __attribute__((aligned(16))) msim_record s_recs[OB_BLOCK];
+    __shared__ uint32_t s_off[OB_BLOCK];
+    uint32_t r = in - nk, p = base_p + ip - np;            // r: index among the workgroup's records
     long long shift = base_d + id - nd;
-    for (int w = 0; w < wave; w++) { r += wn[w]; p += wp[w]; shift += wd[w]; }
+    uint32_t n_blk = 0;
+    for (int w = 0; w < OB_THREADS / 64; w++) { if (w < wave) { r += wn[w]; p += wp[w]; shift += wd[w]; } n_blk += wn[w]; }
 #pragma unroll
     for (int q = 0; q < OB_ITEMS; q++) {
         if (!(meta[q] & CAND_VISIT)) continue;
@@ -904,9 +988,15 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
             }
             p += len;
         }
-        rec_off[r] = (uint32_t)((long long)pos[q] + shift);
+        s_off[r] = (uint32_t)((long long)pos[q] + shift);
         shift += cand_delta(t, pos[q], stop[q]);
-        recs[r++] = rec;
+        s_recs[r++] = rec;
+    }
+    __syncthreads();
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_recs);
+        uint4 *dst = reinterpret_cast<uint4 *>(recs + base_n);            // (record tables are 16-byte aligned: hipMalloc + 16 n)
+        for (uint32_t i = threadIdx.x; i < n_blk; i += OB_THREADS) { dst[i] = src[i]; rec_off[base_n + i] = s_off[i]; }
     }
 }
 

@@ -253,7 +253,8 @@ static Ctx *C(msim_ctx *p) { return reinterpret_cast<Ctx *>(p); }
 #define CTX_FLUSHED(c, p)                                   \
     Ctx *c = C(p);                                          \
     if (c) {                                                \
-        const int flush_rc_ = flush_deferred_apply(c);      \
+        int flush_rc_ = flush_deferred_apply(c);            \
+        if (!flush_rc_ && c->fast) flush_rc_ = fast_plan_flush(c);   /* (fast contexts: the plans queued so far, as one batch) */ \
         if (flush_rc_) return flush_rc_;                    \
     }
 #define NEED_GPU(c) do { if ((c)->host_only) return fail((c), MSIM_ERR_HIP, "host-only context: this call needs the GPU"); } while (0)
@@ -588,8 +589,15 @@ int msim_plan_was_empty(msim_ctx *p, int contig, int *empty) {
 }
 
 int msim_apply_contig(msim_ctx *p, int contig) {
-    CTX_FLUSHED(c, p)
+    Ctx *c = C(p);
     if (!c) return MSIM_ERR_ARG;
+    // fast contexts: a contig whose plan is still queued gets its APPLY enqueued right behind the batch (plan_fast.hip)
+    if (c->fast && fast_plan_queued(c, contig, true)) return MSIM_OK;
+    {
+        int rc = flush_deferred_apply(c);
+        if (!rc && c->fast) rc = fast_plan_flush(c);
+        if (rc) return rc;
+    }
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     NEED_GPU(c);

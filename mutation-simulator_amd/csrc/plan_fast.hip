@@ -19,7 +19,7 @@ namespace msim {
 
 namespace {
 
-constexpr int F_SETS = 8;                                  // contigs in flight (one stream + one scratch set each)
+constexpr int F_SETS = 3;                                  // batches in flight (one stream + one scratch set each)
 
 template <class T>
 struct DevBuf {
@@ -37,11 +37,11 @@ struct FastSet {
     PinBuf<uint8_t> h_tab;                                 // its pinned source
     DevBuf<LeafDesc> leaves;
     DevBuf<uint32_t> sub_k, sub_c0;                        // per subtree of 64 leaves: its points, its first candidate
-    DevBuf<uint32_t> cand_pos, cand_stop, cand_bend, cand_end2, blk_out;
+    DevBuf<uint32_t> cand_pos, cand_stop, cand_bend, cand_end2, blk_out, off_dummy;
+    DevBuf<uint32_t> kept;                                 // per contig of the batch: [0] kept any, [1] / [2] pass 1 / 2 handed over
     DevBuf<uint8_t> cand_meta;
     DevBuf<uint32_t> blk_u32;                              // S | indep | in | nrec | pool  (5 arrays of nb + 1)
     DevBuf<long long> blk_delta;
-    uint32_t *kept_any = nullptr;                          // one word
     hipEvent_t done = nullptr;
     bool pending = false;
 };
@@ -64,6 +64,7 @@ struct Prep {
 };
 
 struct Replay { uint64_t key = 0; uint32_t seq = 0; Prep P; };
+struct Pending { int contig = -1; bool apply = false; uint64_t key = 0; uint32_t seq = 0; Prep P; };   // planned, not enqueued yet
 
 }  // namespace
 
@@ -76,8 +77,10 @@ struct FastPlan {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     bool pending = false;                                  // work enqueued since the last collection
     std::vector<int> sized;                                // contigs whose sizes are still on the device only
-    std::map<int, Replay> replay;                          // per contig planned with device-side counts: its tables (see enqueue_plan)
+    std::map<int, Replay> replay;                          // per contig planned with device-side counts: its tables (see enqueue_batch)
     uint64_t replays = 0;                                  // plans that had to be replayed with the orbit kernels
+    std::vector<Pending> queue;                            // msim_plan_contig calls whose device work has not been enqueued
+    uint32_t next_set = 0;
 };
 
 namespace {
@@ -181,7 +184,7 @@ int prepare(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, Prep &P)
         f.clip = (uint32_t)std::min<int64_t>(r.stop + 1, 0xffffffffll);
         f.set = set;
         f.sub_base = (uint32_t)P.subs.size();
-        f.rsv = 0;
+        f.slot = 0;
         const uint64_t T = ((uint64_t)n + (1ull << f.lgB) - 1) >> f.lgB;
         if (T > (1u << LG_SUB)) P.big.push_back((uint32_t)P.fr.size());
         for (uint64_t sidx = 0; sidx < (T + 63) >> LG_SUB; sidx++) P.subs.push_back(SubDesc{(uint32_t)P.fr.size(), (uint32_t)sidx});
@@ -211,7 +214,6 @@ int ensure_plan(Ctx *c) {
     for (auto &st : f->lane) MSIM_HIP(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     for (auto &s : f->set) {
         MSIM_HIP(c, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        MSIM_HIP(c, hipMalloc(&s.kept_any, 64));
     }
     MSIM_HIP(c, hipMalloc(&f->d_flags, 64));
     MSIM_HIP(c, hipMemset(f->d_flags, 0, 64));
@@ -229,8 +231,8 @@ void fast_plan_destroy(Ctx *c) {
     if (!f) return;
     for (auto st : f->lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &s : f->set) {
-        void *bufs[] = {s.tab.p, s.leaves.p, s.sub_k.p, s.sub_c0.p, s.cand_pos.p, s.cand_stop.p, s.cand_bend.p, s.cand_end2.p, s.blk_out.p,
-                        s.cand_meta.p, s.blk_u32.p, s.blk_delta.p, s.kept_any};
+        void *bufs[] = {s.tab.p, s.leaves.p, s.sub_k.p, s.sub_c0.p, s.cand_pos.p, s.cand_stop.p, s.cand_bend.p, s.cand_end2.p, s.blk_out.p, s.off_dummy.p, s.kept.p,
+                        s.cand_meta.p, s.blk_u32.p, s.blk_delta.p};
         for (void *p : bufs) if (p) (void)hipFree(p);
         if (s.h_tab.p) (void)hipHostFree(s.h_tab.p);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -273,10 +275,14 @@ struct HostProf {                                          // MSIM_FAST_PROF=1: 
 HostProf g_prof;
 }  // namespace
 
-static int enqueue_plan(Ctx *c, Contig &ct, Prep &P, uint64_t key64, uint32_t seq, bool orbit_only);
+static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only);
 
 int fast_plan_collect(Ctx *c) {
     FastPlan *f = c->fast;
+    if (f && !f->queue.empty()) {
+        const int rc = fast_plan_flush(c);
+        if (rc) return rc;
+    }
     if (!f || !f->pending) return MSIM_OK;
     g_prof.report();
     for (int round = 0; f->pending && round < 3; round++) {
@@ -333,7 +339,9 @@ int fast_plan_collect(Ctx *c) {
             f->replay.erase(it);
             Contig &g = c->contigs[(size_t)idx];
             const bool was_applied = g.applied;
-            int rc = enqueue_plan(c, g, rp.P, rp.key, rp.seq, true);
+            std::vector<Pending> one(1);
+            one[0].contig = idx; one[0].key = rp.key; one[0].seq = rp.seq; one[0].P = std::move(rp.P);
+            int rc = enqueue_batch(c, one, true);
             if (rc) return rc;
             f->replays++;
             if (was_applied) {
@@ -346,45 +354,50 @@ int fast_plan_collect(Ctx *c) {
     return MSIM_OK;
 }
 
-// Enqueue PLAN of one contig.  orbit_only: the boundary pass / visit filter by the orbit kernels alone (the replay of a plan
-// whose block-local pass handed over, and the MSIM_FAST_FORCE_ORBIT test hook).
-static int enqueue_plan(Ctx *c, Contig &ct, Prep &P, uint64_t key64, uint32_t seq, bool orbit_only) {
+// Enqueue PLAN of a batch of contigs: one launch per stage over all of them (fast_kernels.h: FSlot).
+// orbit_only (batches of one): the boundary pass / visit filter by the orbit kernels alone -- the replay of a plan whose
+// block-local pass handed over, contigs of more than 4096 blocks, and the MSIM_FAST_FORCE_ORBIT test hook.
+static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
     int rc;
-    const uint64_t K = P.K;
-    ct.n_rec = P.snp_only ? K : 0;
-    ct.n_rec_cap = K;
-    ct.pool_len = 0;
-    ct.plan_empty = K == 0;
-    ct.all_snp = P.all_sn;
-    ct.d_dyn = nullptr;
-    ct.sizes_pending = false;
-    ct.out_cap_len = P.out_cap;
-    ct.n_struct_est = P.n_struct_est;
-    ct.planned = true;
-    if (!K) return MSIM_OK;
+    if (items.empty()) return MSIM_OK;
     if ((rc = ensure_plan(c))) return rc;
     FastPlan *f = c->fast;
-    // scratch set and stream by the contig's ordinal: a genome planned again finds every buffer at its size
-    const uint32_t li = seq % F_SETS;
+    const uint32_t li = f->next_set++ % F_SETS;
     FastSet &S = f->set[li];
     hipStream_t st = f->lane[li];
     g_prof.start();
-    if (S.pending) {                                       // its last user (8 contigs ago) may still be in flight on this stream
+    if (S.pending) {                                       // its last user (a few batches ago) may still be in flight on this stream
         MSIM_HIP(c, hipStreamSynchronize(st));
         S.pending = false;
     }
     g_prof.lap(1);
     if (!f->pending) MSIM_HIP(c, hipEventRecord(f->t0, st));
     f->pending = true;
-    const Key key{(uint32_t)key64, (uint32_t)(key64 >> 32), seq};
-    const uint32_t n_draw = (uint32_t)P.fr.size(), n_sets = (uint32_t)P.sets.size();
-    const uint32_t n_leaves = (uint32_t)P.n_leaves;
-    // ---- tables
-    const uint32_t n_subs = (uint32_t)P.subs.size(), n_big = (uint32_t)P.big.size();
+    const uint64_t key64 = items[0].key;
+    const Key2 key2{(uint32_t)key64, (uint32_t)(key64 >> 32)};
+    // ---- the batch's tables: ranges, settings, subtrees, big ranges and slots, concatenated
+    const uint32_t n_slots = (uint32_t)items.size();
+    size_t n_draw = 0, n_sets = 0, n_subs = 0, n_big = 0;
+    uint64_t n_leaves = 0, cand_total = 0, nb_total = 0;
+    bool snp_only = true, any_all_sn = false, need_visit = false;
+    uint32_t lgB_max = LG_LEAF_MIN;
+    for (auto &it : items) {
+        const Prep &P = it.P;
+        n_draw += P.fr.size(); n_sets += P.sets.size(); n_subs += P.subs.size(); n_big += P.big.size();
+        n_leaves += P.n_leaves;
+        const uint64_t nb = (P.K + OB_BLOCK - 1) / OB_BLOCK;
+        cand_total += nb * OB_BLOCK;
+        nb_total += nb;
+        snp_only = snp_only && P.snp_only;
+        any_all_sn = any_all_sn || P.all_sn;
+        need_visit = need_visit || P.need_visit;
+        lgB_max = std::max(lgB_max, P.lgB_max);
+    }
     auto up16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-    const size_t off_sets = up16((size_t)n_draw * sizeof(FRange)), off_subs = up16(off_sets + (size_t)n_sets * sizeof(Settings)),
-                 off_big = up16(off_subs + (size_t)n_subs * sizeof(SubDesc));
-    const size_t tab_bytes = up16(off_big + (size_t)n_big * sizeof(uint32_t));
+    const size_t off_sets = up16(n_draw * sizeof(FRange)), off_subs = up16(off_sets + n_sets * sizeof(Settings)),
+                 off_big = up16(off_subs + n_subs * sizeof(SubDesc)), off_slots = up16(off_big + n_big * sizeof(uint32_t)),
+                 off_bslot = up16(off_slots + (size_t)n_slots * sizeof(FSlot));
+    const size_t tab_bytes = up16(off_bslot + (snp_only ? 0 : (size_t)nb_total * sizeof(uint32_t)));
     if (S.h_tab.cap < tab_bytes) {
         if (S.h_tab.p) MSIM_HIP(c, hipHostFree(S.h_tab.p));
         S.h_tab.p = nullptr; S.h_tab.cap = 0;
@@ -393,24 +406,70 @@ static int enqueue_plan(Ctx *c, Contig &ct, Prep &P, uint64_t key64, uint32_t se
     }
     if ((rc = dev_grow(c, f, S.tab, tab_bytes))) return rc;
     if ((rc = dev_grow(c, f, S.leaves, n_leaves))) return rc;
-    if ((rc = dev_grow(c, f, S.sub_k, (size_t)n_subs + 1))) return rc;
-    if ((rc = dev_grow(c, f, S.sub_c0, (size_t)n_subs + 1))) return rc;
-    memcpy(S.h_tab.p, P.fr.data(), (size_t)n_draw * sizeof(FRange));
-    memcpy(S.h_tab.p + off_sets, P.sets.data(), (size_t)n_sets * sizeof(Settings));
-    memcpy(S.h_tab.p + off_subs, P.subs.data(), (size_t)n_subs * sizeof(SubDesc));
-    if (n_big) memcpy(S.h_tab.p + off_big, P.big.data(), (size_t)n_big * sizeof(uint32_t));
-    {   // the record table (and what APPLY reads beside it) may still be in use by an earlier APPLY of this contig
-        const size_t want = (size_t)K * sizeof(msim_record);
-        const size_t want_pool = (size_t)P.pool_cap + 2 * PAD, want_off = P.all_sn ? 0 : (size_t)K * sizeof(uint32_t);
-        if (ct.cap_recs < want || ct.cap_pool < want_pool || ct.cap_off < want_off) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-        } else if (ct.apply_pending && ct.ea2) {
-            MSIM_HIP(c, hipStreamWaitEvent(st, ct.ea2, 0));
+    if ((rc = dev_grow(c, f, S.sub_k, n_subs + 1))) return rc;
+    if ((rc = dev_grow(c, f, S.sub_c0, n_subs + 1))) return rc;
+    if ((rc = dev_grow(c, f, S.kept, (size_t)4 * n_slots))) return rc;
+    if (!snp_only) {
+        if ((rc = dev_grow(c, f, S.cand_pos, cand_total))) return rc;
+        if ((rc = dev_grow(c, f, S.cand_stop, cand_total))) return rc;
+        if ((rc = dev_grow(c, f, S.cand_bend, cand_total))) return rc;
+        if ((need_visit || orbit_only) && (rc = dev_grow(c, f, S.cand_end2, cand_total))) return rc;
+        if (orbit_only && (rc = dev_grow(c, f, S.blk_out, cand_total))) return rc;
+        if (any_all_sn && (rc = dev_grow(c, f, S.off_dummy, cand_total))) return rc;  // (SNP-only tables: offsets nobody reads)
+        if ((rc = dev_grow(c, f, S.cand_meta, cand_total + 16))) return rc;
+        if ((rc = dev_grow(c, f, S.blk_u32, (size_t)7 * (nb_total + 1)))) return rc;
+        if ((rc = dev_grow(c, f, S.blk_delta, nb_total + 1))) return rc;
+    }
+    FRange *h_fr = reinterpret_cast<FRange *>(S.h_tab.p);
+    Settings *h_sets = reinterpret_cast<Settings *>(S.h_tab.p + off_sets);
+    SubDesc *h_subs = reinterpret_cast<SubDesc *>(S.h_tab.p + off_subs);
+    uint32_t *h_big = reinterpret_cast<uint32_t *>(S.h_tab.p + off_big);
+    FSlot *h_slots = reinterpret_cast<FSlot *>(S.h_tab.p + off_slots);
+    uint32_t *h_bslot = reinterpret_cast<uint32_t *>(S.h_tab.p + off_bslot);
+    {
+        uint32_t r0 = 0, s0 = 0, sub0 = 0, big0 = 0, leaf0 = 0, cand0 = 0, blk0 = 0;
+        for (uint32_t si = 0; si < n_slots; si++) {
+            Pending &it = items[si];
+            const Prep &P = it.P;
+            Contig &ct = c->contigs[(size_t)it.contig];
+            {   // the record table (and what APPLY reads beside it) may still be in use by an earlier APPLY of this contig
+                const size_t want = (size_t)P.K * sizeof(msim_record);
+                const size_t want_pool = (size_t)P.pool_cap + 2 * PAD, want_off = P.all_sn ? 0 : (size_t)P.K * sizeof(uint32_t);
+                if (ct.cap_recs < want || ct.cap_pool < want_pool || ct.cap_off < want_off) {
+                    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+                    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+                    if (ct.apply_stream) MSIM_HIP(c, hipStreamSynchronize(ct.apply_stream));
+                } else if (ct.apply_pending && ct.ea2) {
+                    MSIM_HIP(c, hipStreamWaitEvent(st, ct.ea2, 0));
+                }
+                if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
+                if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, want_pool))) return rc;
+                if (want_off && (rc = dev_reserve(c, (void **)&ct.d_off, &ct.cap_off, want_off))) return rc;
+            }
+            const uint32_t nb = (uint32_t)((P.K + OB_BLOCK - 1) / OB_BLOCK);
+            for (size_t q = 0; q < P.fr.size(); q++) {
+                FRange fr = P.fr[q];
+                fr.slot = si;
+                fr.set += s0;
+                h_fr[r0 + q] = fr;
+            }
+            memcpy(h_sets + s0, P.sets.data(), P.sets.size() * sizeof(Settings));
+            for (size_t q = 0; q < P.subs.size(); q++) h_subs[sub0 + q] = SubDesc{P.subs[q].range + r0, P.subs[q].s};
+            for (size_t q = 0; q < P.big.size(); q++) h_big[big0 + q] = P.big[q] + r0;
+            FSlot sl;
+            memset(&sl, 0, sizeof sl);
+            sl.L = ct.len; sl.out_cap = P.out_cap; sl.pool_cap = P.pool_cap;
+            sl.recs = ct.d_recs;
+            sl.rec_off = P.all_sn ? (snp_only ? nullptr : S.off_dummy.p + cand0) : ct.d_off;
+            sl.pool = ct.d_pool + PAD;
+            sl.dyn = f->d_dyn + ct.index;
+            sl.seq = it.seq; sl.K = (uint32_t)P.K; sl.cand_off = cand0; sl.blk_off = blk0; sl.nb = nb;
+            sl.range_off = r0; sl.leaf_off = leaf0; sl.sub_off = sub0;
+            h_slots[si] = sl;
+            if (!snp_only) for (uint32_t q = 0; q < nb; q++) h_bslot[blk0 + q] = si;
+            r0 += (uint32_t)P.fr.size(); s0 += (uint32_t)P.sets.size(); sub0 += (uint32_t)P.subs.size(); big0 += (uint32_t)P.big.size();
+            leaf0 += (uint32_t)P.n_leaves; cand0 += nb * OB_BLOCK; blk0 += nb;
         }
-        if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
-        if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, want_pool))) return rc;
-        if (want_off && (rc = dev_reserve(c, (void **)&ct.d_off, &ct.cap_off, want_off))) return rc;
     }
     g_prof.lap(2);
     MSIM_HIP(c, hipMemcpyAsync(S.tab.p, S.h_tab.p, tab_bytes, hipMemcpyHostToDevice, st));
@@ -419,112 +478,184 @@ static int enqueue_plan(Ctx *c, Contig &ct, Prep &P, uint64_t key64, uint32_t se
     const Settings *d_sets = reinterpret_cast<const Settings *>(S.tab.p + off_sets);
     const SubDesc *d_subs = reinterpret_cast<const SubDesc *>(S.tab.p + off_subs);
     const uint32_t *d_big = reinterpret_cast<const uint32_t *>(S.tab.p + off_big);
+    const FSlot *d_slots = reinterpret_cast<const FSlot *>(S.tab.p + off_slots);
+    const uint32_t *d_bslot = reinterpret_cast<const uint32_t *>(S.tab.p + off_bslot);
+    const uint32_t nbt = (uint32_t)nb_total;
+    uint32_t *blk_S = S.blk_u32.p, *blk_indep = blk_S + (nbt + 1), *blk_in = blk_indep + (nbt + 1), *blk_nrec = blk_in + (nbt + 1),
+             *blk_pool = blk_nrec + (nbt + 1), *blk_max1 = blk_pool + (nbt + 1), *blk_max2 = blk_max1 + (nbt + 1);
     // ---- positions
     if (n_big)
-        hipLaunchKernelGGL(k_fsplit_top, dim3(n_big), dim3(1024), 0, st, d_ranges, d_big, key, S.sub_k.p, S.sub_c0.p, f->d_flags);
-    const uint32_t nb = (uint32_t)((K + OB_BLOCK - 1) / OB_BLOCK);
-    if (!P.snp_only && (rc = dev_grow(c, f, S.blk_u32, (size_t)7 * (nb + 1)))) return rc;
-    uint32_t *blk_max1 = P.snp_only ? nullptr : S.blk_u32.p + (size_t)5 * (nb + 1), *blk_max2 = P.snp_only ? nullptr : blk_max1 + (nb + 1);
-    hipLaunchKernelGGL(k_fsplit_sub, dim3((n_subs + 3) / 4), dim3(256), 0, st, d_ranges, d_subs, n_subs, key, S.sub_k.p, S.sub_c0.p,
-                       S.leaves.p, f->d_flags, blk_max1, P.snp_only ? 0u : 2 * (nb + 1), P.snp_only ? (uint32_t *)nullptr : S.kept_any);
+        hipLaunchKernelGGL(k_fsplit_top, dim3((uint32_t)n_big), dim3(1024), 0, st, d_ranges, d_big, d_slots, key2, S.sub_k.p, S.sub_c0.p,
+                           f->d_flags);
+    hipLaunchKernelGGL(k_fsplit_sub, dim3(((uint32_t)n_subs + 3) / 4), dim3(256), 0, st, d_ranges, d_subs, (uint32_t)n_subs, d_slots, key2,
+                       S.sub_k.p, S.sub_c0.p, S.leaves.p, f->d_flags, snp_only ? (uint32_t *)nullptr : blk_max1,
+                       snp_only ? 0u : 2 * (nbt + 1), S.kept.p, 4 * n_slots, (uint32_t)items[0].P.d);
     g_prof.lap(4);
-    const uint32_t bm_words = (1u << P.lgB_max) / 32 + 2;
+    const uint32_t bm_words = (1u << lgB_max) / 32 + 2;
     const size_t lds = (size_t)4 * (bm_words + LEAF_LIST) * sizeof(uint32_t);
-    const uint32_t leaf_blocks = (n_leaves + 3) / 4;
-    if (P.snp_only) {
-        hipLaunchKernelGGL(k_fleaf<false>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, n_leaves, bm_words, key,
-                           (uint32_t)P.d, ct.len, (const Settings *)nullptr, P.block1, (unsigned long long)c->params.ti_lim, ct.d_recs,
-                           (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, (uint32_t *)nullptr, f->d_flags);
+    const uint32_t leaf_blocks = ((uint32_t)n_leaves + 3) / 4;
+    const uint32_t d = (uint32_t)items[0].P.d;
+    const Block1 block1 = items[0].P.block1;
+    const unsigned long long ti_lim = (unsigned long long)c->params.ti_lim;
+    if (snp_only) {
+        hipLaunchKernelGGL(k_fleaf<false>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, (uint32_t)n_leaves, bm_words, d_slots,
+                           key2, d, (const Settings *)nullptr, block1, ti_lim, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                           (uint8_t *)nullptr, (uint32_t *)nullptr, f->d_flags);
         MSIM_HIP(c, hipGetLastError());
         g_prof.lap(5);
     } else {
-        if ((rc = dev_grow(c, f, S.cand_pos, K))) return rc;
-        if ((rc = dev_grow(c, f, S.cand_stop, K))) return rc;
-        if ((rc = dev_grow(c, f, S.cand_bend, K))) return rc;
-        if ((rc = dev_grow(c, f, S.blk_out, K))) return rc;
-        if (P.need_visit && (rc = dev_grow(c, f, S.cand_end2, K))) return rc;
-        if ((rc = dev_grow(c, f, S.cand_meta, K + 16))) return rc;
-        if ((rc = dev_grow(c, f, S.blk_delta, (size_t)nb + 1))) return rc;
-        uint32_t *blk_S = S.blk_u32.p, *blk_indep = blk_S + (nb + 1), *blk_in = blk_indep + (nb + 1), *blk_nrec = blk_in + (nb + 1),
-                 *blk_pool = blk_nrec + (nb + 1);
-        hipLaunchKernelGGL(k_fleaf<true>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, n_leaves, bm_words, key,
-                           (uint32_t)P.d, ct.len, d_sets, P.block1, (unsigned long long)c->params.ti_lim, (msim_record *)nullptr,
-                           S.cand_pos.p, S.cand_stop.p, S.cand_bend.p, S.cand_meta.p, blk_max1, f->d_flags);
+        hipLaunchKernelGGL(k_fleaf<true>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, (uint32_t)n_leaves, bm_words, d_slots,
+                           key2, d, d_sets, block1, ti_lim, S.cand_pos.p, S.cand_stop.p, S.cand_bend.p, S.cand_meta.p, blk_max1, f->d_flags);
         g_prof.lap(5);
-        uint32_t *fb1 = S.kept_any + 1, *fb2 = S.kept_any + 2;             // kept_any [0]; [1] / [2]: pass 1 / 2 handed over (zeroed by k_fsplit_sub)
-        // One pass = k_fkeep (block-local: free candidates + short cluster walks).  Where blocked ranges reach over more than its
-        // 64-candidate halo it raises *fb and the plan is replayed with the three orbit kernels when the sizes are collected
-        // (fast_plan_collect): nothing of the common path pays for them.
-        auto pass = [&](bool visit, bool final, const uint32_t *end_in, uint32_t *end2, uint32_t maxspan, uint32_t *fb) {
-#define MSIM_FK(V, F) hipLaunchKernelGGL((k_fkeep<V, F>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, \
+        // One pass = k_fkeep (block-local: free candidates + short cluster walks).  Where everything in front of a block is
+        // inside somebody's blocked range it raises the contig's hand-over word and that plan is replayed with the three orbit
+        // kernels when the sizes are collected (fast_plan_collect): nothing of the common path pays for them.
+        const Prep &P0 = items[0].P;
+        auto pass = [&](bool visit, bool final, const uint32_t *end_in, uint32_t *end2, uint32_t maxspan) {
+#define MSIM_FK(V, F) hipLaunchKernelGGL((k_fkeep<V, F>), dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, \
                                          (const uint32_t *)(visit ? blk_max2 : blk_max1), end2, blk_max2, S.cand_stop.p, \
-                                         S.cand_meta.p, (uint32_t)K, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any, fb)
-#define MSIM_FM(V, F) hipLaunchKernelGGL((k_forbit_mark<V, F>), dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, end2, S.cand_stop.p, \
-                                         S.cand_meta.p, (uint32_t)K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept_any, \
+                                         S.cand_meta.p, 0u, blk_nrec, blk_pool, S.blk_delta.p, S.kept.p, d_slots, d_bslot)
+#define MSIM_FM(V, F) hipLaunchKernelGGL((k_forbit_mark<V, F>), dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, end2, S.cand_stop.p, \
+                                         S.cand_meta.p, (uint32_t)P0.K, blk_in, blk_nrec, blk_pool, S.blk_delta.p, S.kept.p, \
                                          (const uint32_t *)nullptr)
-            if (!orbit_only && nb <= 4096) {               // (beyond: every block would read thousands of block maxima)
+            if (!orbit_only) {
                 if (!visit && final) MSIM_FK(false, true); else if (!visit) MSIM_FK(false, false); else MSIM_FK(true, true);
-            } else {
-                hipLaunchKernelGGL(k_forbit_local, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, (uint32_t)K, maxspan, S.blk_out.p,
-                                   blk_S, blk_indep, (const uint32_t *)nullptr);
-                hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)K, nb,
-                                   blk_in, (const uint32_t *)nullptr);
+            } else {                                       // (one contig: offsets are zero)
+                hipLaunchKernelGGL(k_forbit_local, dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, end_in, (uint32_t)P0.K, maxspan,
+                                   S.blk_out.p, blk_S, blk_indep, (const uint32_t *)nullptr);
+                hipLaunchKernelGGL(k_forbit_resolve, dim3(1), dim3(1024), 0, st, S.cand_pos.p, S.blk_out.p, blk_S, blk_indep, (uint32_t)P0.K,
+                                   nbt, blk_in, (const uint32_t *)nullptr);
                 if (!visit && final) MSIM_FM(false, true); else if (!visit) MSIM_FM(false, false); else MSIM_FM(true, true);
             }
 #undef MSIM_FK
 #undef MSIM_FM
-            (void)fb;
         };
-        // ---- boundary pass (mutator.py:184-213)
-        if (!P.need_visit) {
-            pass(false, true, S.cand_bend.p, nullptr, P.maxspan, fb1);
+        // ---- boundary pass (mutator.py:184-213); contigs of one range have no visit filter to fear, but in a batch with one that
+        //      has they run it too: it changes nothing for them
+        uint32_t maxspan = 1, maxspan_visit = 1;
+        for (auto &it : items) { maxspan = std::max(maxspan, it.P.maxspan); maxspan_visit = std::max(maxspan_visit, it.P.maxspan_visit); }
+        if (!need_visit) {
+            pass(false, true, S.cand_bend.p, nullptr, maxspan);
         } else {
-            pass(false, false, S.cand_bend.p, S.cand_end2.p, P.maxspan, fb1);
+            pass(false, false, S.cand_bend.p, S.cand_end2.p, maxspan);
             // ---- visit filter (mutator.py:376,386,398): the same pass over what the kept records consume
-            pass(true, true, S.cand_end2.p, nullptr, P.maxspan_visit, fb2);
+            pass(true, true, S.cand_end2.p, nullptr, maxspan_visit);
         }
-        DynSizes *dyn = f->d_dyn + ct.index;
-        uint32_t *rec_off = P.all_sn ? S.blk_out.p : ct.d_off;
-        if (nb <= 4096) {
-            hipLaunchKernelGGL(k_femit<true>, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, (uint32_t)K,
-                               blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap, S.kept_any, f->d_flags, dyn, key,
-                               ct.d_recs, rec_off, ct.d_pool + PAD);
+        if (!orbit_only || nbt <= 4096) {
+            hipLaunchKernelGGL(k_femit<true>, dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, blk_nrec, blk_pool,
+                               S.blk_delta.p, S.kept.p, f->d_flags, d_slots, d_bslot, key2);
         } else {
-            hipLaunchKernelGGL(k_fscan, dim3(1), dim3(1024), 0, st, blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap,
-                               S.kept_any, f->d_flags, dyn);
-            hipLaunchKernelGGL(k_femit<false>, dim3(nb), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, (uint32_t)K,
-                               blk_nrec, blk_pool, S.blk_delta.p, nb, ct.len, P.out_cap, P.pool_cap, S.kept_any, f->d_flags, dyn, key,
-                               ct.d_recs, rec_off, ct.d_pool + PAD);
+            hipLaunchKernelGGL(k_fscan, dim3(1), dim3(1024), 0, st, blk_nrec, blk_pool, S.blk_delta.p, nbt, c->contigs[(size_t)items[0].contig].len,
+                               P0.out_cap, P0.pool_cap, S.kept.p, f->d_flags, f->d_dyn + items[0].contig);
+            hipLaunchKernelGGL(k_femit<false>, dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, blk_nrec, blk_pool,
+                               S.blk_delta.p, S.kept.p, f->d_flags, d_slots, d_bslot, key2);
         }
         MSIM_HIP(c, hipGetLastError());
-        ct.d_dyn = reinterpret_cast<const uint32_t *>(dyn);
-        ct.sizes_pending = true;
-        ct.off_ready = !P.all_sn;
-        f->sized.push_back(ct.index);
     }
     g_prof.lap(6);
-    // ---- its APPLY follows on the same stream (apply.hip: Contig::apply_stream): no event, no cross-stream wait, and the rewrite
-    // kernels of different contigs overlap like everything else; whoever reads the records from another stream (text, fetches)
-    // drains first
-    ct.apply_stream = st;
+    // ---- per contig: what the host knows now; its APPLY follows on the same stream (apply.hip: Contig::apply_stream) -- no event,
+    // no cross-stream wait; whoever reads the records from another stream (text, fetches) drains first
+    for (auto &it : items) {
+        Contig &ct = c->contigs[(size_t)it.contig];
+        ct.apply_stream = st;
+        if (!it.P.snp_only) {
+            ct.d_dyn = reinterpret_cast<const uint32_t *>(f->d_dyn + ct.index);
+            ct.sizes_pending = true;
+            ct.off_ready = !it.P.all_sn;
+            f->sized.push_back(ct.index);
+            if (!orbit_only) {                             // what a replay needs, should the block-local pass hand over
+                Replay &rp = f->replay[ct.index];
+                rp.key = it.key; rp.seq = it.seq;
+                rp.P = std::move(it.P);
+            }
+        }
+    }
     S.pending = true;
     g_prof.lap(7);
-    g_prof.n++;
-    if (!P.snp_only && !orbit_only) {                      // what a replay needs, should the block-local pass hand over
-        Replay &rp = f->replay[ct.index];
-        rp.key = key64; rp.seq = seq;
-        rp.P = std::move(P);
-    }
+    g_prof.n += n_slots;
     return MSIM_OK;
 }
 
+// msim_plan_contig of a fast context: the contig's tables are prepared (what the reference refuses is refused here, now) and the
+// contig joins the queue; the device work of everything queued goes out in ONE batch at the next call that needs a result
+// (fast_plan_flush: every entry point but msim_plan_contig / msim_apply_contig).
 int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges, uint64_t key64, uint32_t seq) {
-    Prep P;
+    int rc;
+    if ((rc = ensure_plan(c))) return rc;
+    FastPlan *f = c->fast;
+    for (const Pending &q : f->queue)
+        if (q.contig == ct.index) { if ((rc = fast_plan_flush(c))) return rc; break; }      // planned again before anybody looked
+    Pending it;
     g_prof.start();
-    const int rc = prepare(c, ct.len, ranges, n_ranges, P);
+    rc = prepare(c, ct.len, ranges, n_ranges, it.P);
     g_prof.lap(0);
     if (rc) return rc;
-    return enqueue_plan(c, ct, P, key64, seq, getenv("MSIM_FAST_FORCE_ORBIT") != nullptr);
+    const Prep &P = it.P;
+    ct.n_rec = P.snp_only ? P.K : 0;
+    ct.n_rec_cap = P.K;
+    ct.pool_len = 0;
+    ct.plan_empty = P.K == 0;
+    ct.all_snp = P.all_sn;
+    ct.d_dyn = nullptr;
+    ct.sizes_pending = P.K != 0 && !P.snp_only;
+    ct.out_cap_len = P.out_cap;
+    ct.n_struct_est = P.n_struct_est;
+    ct.planned = true;
+    if (!P.K) return MSIM_OK;
+    it.contig = ct.index; it.key = key64; it.seq = seq; it.apply = false;
+    f->queue.push_back(std::move(it));
+    return MSIM_OK;
+}
+
+bool fast_plan_queued(Ctx *c, int contig, bool mark_apply) {
+    FastPlan *f = c->fast;
+    if (!f) return false;
+    for (Pending &q : f->queue)
+        if (q.contig == contig) { if (mark_apply) q.apply = true; return true; }
+    return false;
+}
+
+int fast_plan_flush(Ctx *c) {
+    FastPlan *f = c->fast;
+    if (!f || f->queue.empty()) return MSIM_OK;
+    std::vector<Pending> queue;
+    queue.swap(f->queue);
+    const bool force_orbit = getenv("MSIM_FAST_FORCE_ORBIT") != nullptr;
+    int rc = MSIM_OK;
+    std::vector<Pending> batch;
+    uint64_t cand = 0, leaves = 0;
+    auto go = [&](bool orbit) {
+        if (batch.empty()) return MSIM_OK;
+        std::vector<int> applies;
+        for (const Pending &q : batch) if (q.apply) applies.push_back(q.contig);
+        int r = enqueue_batch(c, batch, orbit);
+        batch.clear();
+        cand = leaves = 0;
+        if (!r && !applies.empty()) r = apply_batch_device(c, applies);
+        return r;
+    };
+    // A genome goes out in a few batches rather than one: the APPLYs of a batch (HBM-bound) then run beside the PLAN kernels of
+    // the next one (latency- and issue-bound) on another stream.  MSIM_FAST_BATCHES overrides the number (1 = everything at once).
+    uint64_t total = 0;
+    for (const Pending &q : queue) total += q.P.K;
+    static const int want_batches = getenv("MSIM_FAST_BATCHES") ? std::max(1, atoi(getenv("MSIM_FAST_BATCHES"))) : 2;
+    const uint64_t cut = queue.size() >= 6 && total >= (1u << 22) ? total / (uint64_t)want_batches + 1 : ~0ull;
+    uint64_t in_batch = 0;
+    for (Pending &q : queue) {
+        const uint64_t nb = (q.P.K + OB_BLOCK - 1) / OB_BLOCK;
+        const bool solo = !q.P.snp_only && (force_orbit || nb > 4096);      // (k_fkeep / k_femit<true> read all block words in front of a block)
+        if (solo || cand + nb * OB_BLOCK >= (1ull << 31) || leaves + q.P.n_leaves >= (1ull << 31) || batch.size() >= 4096 ||
+            (!batch.empty() && batch[0].key != q.key) || (!batch.empty() && in_batch + q.P.K / 2 > cut)) {
+            if ((rc = go(false))) return rc;
+            in_batch = 0;
+        }
+        in_batch += q.P.K;
+        cand += nb * OB_BLOCK;
+        leaves += q.P.n_leaves;
+        batch.push_back(std::move(q));
+        if (solo && (rc = go(true))) return rc;
+    }
+    return go(false);
 }
 
 // ======================================================================================== host restatement (test support)
