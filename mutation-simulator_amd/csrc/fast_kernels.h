@@ -78,6 +78,12 @@ enum : uint32_t {
     FF_NEED_ORBIT = 0x200u,    // (DynSizes only) the block-local pass handed over: the plan must be replayed with the orbit kernels
 };
 
+// a record as ONE 16-byte store (field by field the compiler stores pos / stop / extra, type, aux and rsv separately: four stores)
+__device__ __forceinline__ void store_record(msim_record *dst, uint32_t pos, uint32_t stop, uint32_t extra, uint32_t type, uint32_t aux) {
+    uint4 v;
+    v.x = pos; v.y = stop; v.z = extra; v.w = type | (aux << 8);
+    *reinterpret_cast<uint4 *>(dst) = v;                   // (tables are 16-byte aligned: hipMalloc + 16 n)
+}
 // ------------------------------------------------------------------------------------------------ splitting tree
 // A node's draw costs a few microseconds of dependent double-precision work, so the tree is cut at subtrees of 64 leaves:
 //   k_fsplit_top   one workgroup per range with more than 64 leaves: the levels above the subtrees (level l has 2^l nodes),
@@ -361,10 +367,7 @@ __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges
             cand_meta[ord] = c.meta;
             return c.bend;
         } else {
-            msim_record rec;
-            rec.pos = pos; rec.stop = pos; rec.extra = 0; rec.type = MSIM_SN;
-            rec.aux = snp_outcome(key, ord, ti_lim); rec.rsv = 0;
-            recs[ord] = rec;
+            store_record(recs + ord, pos, pos, 0u, MSIM_SN, snp_outcome(key, ord, ti_lim));
             return 0u;
         }
     };
@@ -651,13 +654,22 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
     uint32_t far = 0;
     if (b >= 2) for (uint32_t q = threadIdx.x; q + 1 < b; q += OB_THREADS) far = max(far, blk_max[q]);
     uint32_t my_p[OB_ITEMS], my_e[OB_ITEMS], pv_p[OB_ITEMS], pv_e[OB_ITEMS];
+    // (a thread's 8 consecutive words as two 16-byte loads: eight dword loads per array touch every cache line eight times)
+    auto load8 = [](const uint32_t *src, uint32_t *dst) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(src), b = *reinterpret_cast<const uint4 *>(src + 4);
+        dst[0] = a.x; dst[1] = a.y; dst[2] = a.z; dst[3] = a.w; dst[4] = b.x; dst[5] = b.y; dst[6] = b.z; dst[7] = b.w;
+    };
+    const bool full = cnt == (uint32_t)OB_BLOCK;            // (storage of a contig starts at a multiple of 2048: aligned)
+    if (full) { load8(cand_pos + base + i0, my_p); load8(cand_end + base + i0, my_e); }
+    if (prev) { load8(cand_pos + base - OB_BLOCK + i0, pv_p); load8(cand_end + base - OB_BLOCK + i0, pv_e); }
 #pragma unroll
     for (int q = 0; q < OB_ITEMS; q++) {
         const uint32_t i = i0 + q;
-        my_p[q] = i < cnt ? cand_pos[base + i] : 0xffffffffu;
-        my_e[q] = i < cnt ? cand_end[base + i] : 0u;
-        pv_p[q] = prev ? cand_pos[base - OB_BLOCK + i] : 0u;
-        pv_e[q] = prev ? cand_end[base - OB_BLOCK + i] : 0u;
+        if (!full) {
+            my_p[q] = i < cnt ? cand_pos[base + i] : 0xffffffffu;
+            my_e[q] = i < cnt ? cand_end[base + i] : 0u;
+        }
+        if (!prev) { pv_p[q] = 0u; pv_e[q] = 0u; }
         pos[i] = my_p[q]; E[i] = my_e[q];
         pos_h[i] = pv_p[q]; E_h[i] = pv_e[q];
     }
@@ -731,11 +743,27 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
     uint32_t n_rec = 0, n_pool = 0, max2 = 0;
     long long delta = 0;
     bool any = false;
+    uint32_t stops[OB_ITEMS];
+    uint8_t metas[OB_ITEMS];
+    if (full) {
+        load8(cand_stop + base + i0, stops);
+        const uint2 m8 = *reinterpret_cast<const uint2 *>(cand_meta + base + i0);
+#pragma unroll
+        for (int q = 0; q < OB_ITEMS; q++) metas[q] = (uint8_t)((q < 4 ? m8.x : m8.y) >> (8 * (q & 3)));
+    } else {
+#pragma unroll
+        for (int q = 0; q < OB_ITEMS; q++) {
+            stops[q] = i0 + q < cnt ? cand_stop[base + i0 + q] : 0u;
+            metas[q] = i0 + q < cnt ? cand_meta[base + i0 + q] : (uint8_t)0;
+        }
+    }
+    uint32_t e2s[OB_ITEMS];
 #pragma unroll
     for (int q = 0; q < OB_ITEMS; q++) {
         const uint32_t i = i0 + q;
+        e2s[q] = 0;
         if (i >= cnt) continue;
-        uint8_t meta = cand_meta[base + i];
+        uint8_t meta = metas[q];
         const uint32_t t = meta & 7u;
         const bool on = onorb[i] != 0;
         bool rec;
@@ -746,9 +774,9 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
             any = any || keep;
             rec = keep;
             if (!FINAL) {
-                const uint32_t stop = cand_stop[base + i];
+                const uint32_t stop = stops[q];
                 const uint32_t e2 = (keep && type_consumes(t)) ? (stop == 0xffffffffu ? stop : stop + 1) : my_p[q] + 1;
-                cand_end2[base + i] = e2;
+                e2s[q] = e2;
                 max2 = max(max2, e2);
             }
         } else {
@@ -757,12 +785,31 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
         }
         if (FINAL && rec) {
             meta |= CAND_VISIT;
-            const uint32_t stop = cand_stop[base + i];
+            const uint32_t stop = stops[q];
             n_rec++;
             if (t == MSIM_IN) n_pool += stop - my_p[q] + 1;
             delta += cand_delta(t, my_p[q], stop);
         }
-        cand_meta[base + i] = meta;
+        metas[q] = meta;
+    }
+    if (full) {
+        uint2 m8;
+        m8.x = metas[0] | (metas[1] << 8) | (metas[2] << 16) | ((uint32_t)metas[3] << 24);
+        m8.y = metas[4] | (metas[5] << 8) | (metas[6] << 16) | ((uint32_t)metas[7] << 24);
+        *reinterpret_cast<uint2 *>(cand_meta + base + i0) = m8;
+        if (!VISIT && !FINAL) {
+            uint4 a, b2;
+            a.x = e2s[0]; a.y = e2s[1]; a.z = e2s[2]; a.w = e2s[3]; b2.x = e2s[4]; b2.y = e2s[5]; b2.z = e2s[6]; b2.w = e2s[7];
+            *reinterpret_cast<uint4 *>(cand_end2 + base + i0) = a;
+            *reinterpret_cast<uint4 *>(cand_end2 + base + i0 + 4) = b2;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < OB_ITEMS; q++) {
+            if (i0 + q >= cnt) continue;
+            cand_meta[base + i0 + q] = metas[q];
+            if (!VISIT && !FINAL) cand_end2[base + i0 + q] = e2s[q];
+        }
     }
     if (!VISIT && any) *kept_any = 1u;
     if (FINAL) {
@@ -851,7 +898,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ blk_nrec, const uint32_t *__restrict__ blk_pool,
                                                       const long long *__restrict__ blk_delta, const uint32_t *__restrict__ kept_all,
                                                       uint32_t *__restrict__ flags, const FSlot *__restrict__ slots,
-                                                      const uint32_t *__restrict__ blk_slot, Key2 key2) {
+                                                      const uint32_t *__restrict__ blk_slot, Key2 key2, uint32_t abl) {
     __shared__ uint32_t wn[OB_THREADS / 64], wp[OB_THREADS / 64];
     __shared__ long long wd[OB_THREADS / 64];
     __shared__ uint32_t base_n, base_p;
@@ -879,7 +926,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
         }
         uint32_t sn = 0, sp = 0;
         long long sd = 0;
-        for (uint32_t b2 = threadIdx.x; b2 < blk; b2 += OB_THREADS) { sn += blk_nrec[b2]; sp += blk_pool[b2]; sd += blk_delta[b2]; }
+        if (!(abl & 4)) for (uint32_t b2 = threadIdx.x; b2 < blk; b2 += OB_THREADS) { sn += blk_nrec[b2]; sp += blk_pool[b2]; sd += blk_delta[b2]; }
         for (int o = 32; o > 0; o >>= 1) { sn += __shfl_down(sn, o, 64); sp += __shfl_down(sp, o, 64); sd += __shfl_down(sd, o, 64); }
         if (lane == 0) { wn[wave] = sn; wp[wave] = sp; wd[wave] = sd; }
         __syncthreads();
@@ -953,50 +1000,63 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
     __syncthreads();                                       // (wn / wp / wd are reused)
     if (lane == 63) { wn[wave] = in; wp[wave] = ip; wd[wave] = id; }
     __syncthreads();
-    // records and offsets are staged in LDS and leave the workgroup as two contiguous runs (a lane's records sit ~100 bytes
-    // apart from its neighbour's: written straight from the lanes every store instruction touched 64 cache lines)
-    __shared__ __attribute__((aligned(16))) msim_record s_recs[OB_BLOCK];
-    __shared__ uint32_t s_off[OB_BLOCK];
-    uint32_t r = in - nk, p = base_p + ip - np;            // r: index among the workgroup's records
+    uint32_t r = base_n + in - nk, p = base_p + ip - np;
     long long shift = base_d + id - nd;
-    uint32_t n_blk = 0;
-    for (int w = 0; w < OB_THREADS / 64; w++) { if (w < wave) { r += wn[w]; p += wp[w]; shift += wd[w]; } n_blk += wn[w]; }
+    for (int w = 0; w < wave; w++) { r += wn[w]; p += wp[w]; shift += wd[w]; }
+    // Insert bases (mutator.py:465-471) are NOT written from this loop: an insertion is one candidate in eight, so a lane-per-
+    // candidate loop would run its Philox call and a dozen stores in every one of its eight rounds for a handful of lanes
+    // (measured: 286 of the kernel's 426 us).  The workgroup's insertions go to an LDS list and are filled one lane each.
+    __shared__ uint32_t ins_ord[OB_BLOCK], ins_at[OB_BLOCK], ins_len[OB_BLOCK];
+    __shared__ uint32_t n_ins;
+    if (threadIdx.x == 0) n_ins = 0;
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < OB_ITEMS; q++) {
         if (!(meta[q] & CAND_VISIT)) continue;
         const uint32_t t = meta[q] & 7u, ord = i0 + q;
-        msim_record rec;
-        rec.pos = pos[q]; rec.stop = stop[q]; rec.extra = 0; rec.type = (uint8_t)t; rec.aux = 0; rec.rsv = 0;
-        if (t == MSIM_SN) rec.aux = (uint8_t)((meta[q] >> CAND_AUX_SHIFT) & 3u);     // (drawn with the candidate: k_fleaf)
+        uint32_t extra = 0;
+        const uint32_t aux = t == MSIM_SN ? (meta[q] >> CAND_AUX_SHIFT) & 3u : 0u;     // (drawn with the candidate: k_fleaf)
         if (t == MSIM_IN) {
-            rec.extra = p;
+            extra = p;
             const uint32_t len = stop[q] - pos[q] + 1;
-            if ((unsigned long long)p + len <= pool_cap) {                // (an overflowing plan: flagged by the last workgroup)
-                for (uint32_t c0 = 0; c0 < len; c0 += 64) {               // 64 bases per counter, 16 per word, stored 4 at a time
-                    const U4 ch = draw4(key, c0 >> 6, ord, TAG_INS);
-                    const uint32_t nbases = min(64u, len - c0);
-                    const uint32_t words[4] = {ch.x, ch.y, ch.z, ch.w};
-                    uint8_t *dst = pool + p + c0;
-                    for (uint32_t j = 0; j < nbases; j += 4) {
-                        const uint32_t bits = (words[j >> 4] >> (2 * (j & 15))) & 0xffu;          // four 2-bit codes
-                        const uint32_t codes = (bits & 3u) | ((bits & 12u) << 6) | ((bits & 48u) << 12) | ((bits & 192u) << 18);
-                        const uint32_t four = __builtin_amdgcn_perm(0u, 0x43475441u, codes);   // "ATGC"[code] per byte
-                        if (j + 4 <= nbases) __builtin_memcpy(dst + j, &four, 4);
-                        else for (uint32_t x = j; x < nbases; x++) dst[x] = (uint8_t)(four >> (8 * (x - j)));
-                    }
-                }
+            if ((unsigned long long)p + len <= pool_cap && !(abl & 1)) {  // (an overflowing plan: flagged by the last workgroup)
+                const uint32_t k = atomicAdd(&n_ins, 1u);
+                ins_ord[k] = ord; ins_at[k] = p; ins_len[k] = len;
             }
             p += len;
         }
-        s_off[r] = (uint32_t)((long long)pos[q] + shift);
+        rec_off[r] = (uint32_t)((long long)pos[q] + shift);
         shift += cand_delta(t, pos[q], stop[q]);
-        s_recs[r++] = rec;
+        store_record(recs + r, pos[q], stop[q], extra, t, aux);
+        r++;
     }
     __syncthreads();
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(s_recs);
-        uint4 *dst = reinterpret_cast<uint4 *>(recs + base_n);            // (record tables are 16-byte aligned: hipMalloc + 16 n)
-        for (uint32_t i = threadIdx.x; i < n_blk; i += OB_THREADS) { dst[i] = src[i]; rec_off[base_n + i] = s_off[i]; }
+    for (uint32_t k = threadIdx.x; k < n_ins; k += OB_THREADS) {
+        const uint32_t ord = ins_ord[k], len = ins_len[k];
+        uint8_t *dst0 = pool + ins_at[k];
+        for (uint32_t c0 = 0; c0 < len; c0 += 64) {                       // 64 bases per counter, 16 per word, stored 4 at a time
+            const U4 ch = draw4(key, c0 >> 6, ord, TAG_INS);
+            const uint32_t nbases = min(64u, len - c0);
+            uint8_t *dst = dst0 + c0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t word = w == 0 ? ch.x : w == 1 ? ch.y : w == 2 ? ch.z : ch.w;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const uint32_t j = 16u * w + 4u * g4;
+                    if (j >= nbases) break;
+                    const uint32_t bits = (word >> (8 * g4)) & 0xffu;                        // four 2-bit codes
+                    const uint32_t codes = (bits & 3u) | ((bits & 12u) << 6) | ((bits & 48u) << 12) | ((bits & 192u) << 18);
+                    const uint32_t four = __builtin_amdgcn_perm(0u, 0x43475441u, codes);     // "ATGC"[code] per byte
+                    if (j + 4 <= nbases) {
+                        typedef uint32_t u32_a1 __attribute__((aligned(1)));
+                        *reinterpret_cast<u32_a1 *>(dst + j) = four;
+                    } else {
+                        for (uint32_t x = j; x < nbases; x++) dst[x] = (uint8_t)(four >> (8 * (x - j)));
+                    }
+                }
+            }
+        }
     }
 }
 
