@@ -898,7 +898,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ blk_nrec, const uint32_t *__restrict__ blk_pool,
                                                       const long long *__restrict__ blk_delta, const uint32_t *__restrict__ kept_all,
                                                       uint32_t *__restrict__ flags, const FSlot *__restrict__ slots,
-                                                      const uint32_t *__restrict__ blk_slot, Key2 key2, uint32_t abl) {
+                                                      const uint32_t *__restrict__ blk_slot, Key2 key2) {
     __shared__ uint32_t wn[OB_THREADS / 64], wp[OB_THREADS / 64];
     __shared__ long long wd[OB_THREADS / 64];
     __shared__ uint32_t base_n, base_p;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
         }
         uint32_t sn = 0, sp = 0;
         long long sd = 0;
-        if (!(abl & 4)) for (uint32_t b2 = threadIdx.x; b2 < blk; b2 += OB_THREADS) { sn += blk_nrec[b2]; sp += blk_pool[b2]; sd += blk_delta[b2]; }
+        for (uint32_t b2 = threadIdx.x; b2 < blk; b2 += OB_THREADS) { sn += blk_nrec[b2]; sp += blk_pool[b2]; sd += blk_delta[b2]; }
         for (int o = 32; o > 0; o >>= 1) { sn += __shfl_down(sn, o, 64); sp += __shfl_down(sp, o, 64); sd += __shfl_down(sd, o, 64); }
         if (lane == 0) { wn[wave] = sn; wp[wave] = sp; wd[wave] = sd; }
         __syncthreads();
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
         if (t == MSIM_IN) {
             extra = p;
             const uint32_t len = stop[q] - pos[q] + 1;
-            if ((unsigned long long)p + len <= pool_cap && !(abl & 1)) {  // (an overflowing plan: flagged by the last workgroup)
+            if ((unsigned long long)p + len <= pool_cap) {                // (an overflowing plan: flagged by the last workgroup)
                 const uint32_t k = atomicAdd(&n_ins, 1u);
                 ins_ord[k] = ord; ins_at[k] = p; ins_len[k] = len;
             }

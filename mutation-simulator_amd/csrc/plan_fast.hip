@@ -543,12 +543,12 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
         }
         if (!orbit_only || nbt <= 4096) {
             hipLaunchKernelGGL(k_femit<true>, dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, blk_nrec, blk_pool,
-                               S.blk_delta.p, S.kept.p, f->d_flags, d_slots, d_bslot, key2, (uint32_t)(getenv("MSIM_FAST_ABL") ? atoi(getenv("MSIM_FAST_ABL")) : 0));
+                               S.blk_delta.p, S.kept.p, f->d_flags, d_slots, d_bslot, key2);
         } else {
             hipLaunchKernelGGL(k_fscan, dim3(1), dim3(1024), 0, st, blk_nrec, blk_pool, S.blk_delta.p, nbt, c->contigs[(size_t)items[0].contig].len,
                                P0.out_cap, P0.pool_cap, S.kept.p, f->d_flags, f->d_dyn + items[0].contig);
             hipLaunchKernelGGL(k_femit<false>, dim3(nbt), dim3(OB_THREADS), 0, st, S.cand_pos.p, S.cand_stop.p, S.cand_meta.p, blk_nrec, blk_pool,
-                               S.blk_delta.p, S.kept.p, f->d_flags, d_slots, d_bslot, key2, (uint32_t)(getenv("MSIM_FAST_ABL") ? atoi(getenv("MSIM_FAST_ABL")) : 0));
+                               S.blk_delta.p, S.kept.p, f->d_flags, d_slots, d_bslot, key2);
         }
         MSIM_HIP(c, hipGetLastError());
     }
