@@ -341,6 +341,45 @@ def fast_rng_steps(lengths, mm, steps=5, warmup=3):
     return out
 
 
+def fast_rng_sharded(lengths, owned, local_rank, barrier, max_over_ranks, mm, steps=5, warmup=2):
+    """ONE genome over the N GPUs with `--rng fast`: every rank holds, plans and applies only the contigs it owns
+    (msim_plan_chain for the others: their ordinal, nothing else).  value = 3 Gb / max-over-ranks step time."""
+    from mutation_simulator_amd import _ffi
+    eng = _ffi.Engine(int(os.environ.get("MSIM_BENCH_DEVICE", local_rank)), _ffi.RNG_FAST)
+    out = {"what": "NOT stream-compatible with the reference (counter-based draws, same construction and distributions); ONE genome, "
+                   "contigs sharded (LPT), no chain and no host work: a rank skips what it does not own; results left in HBM on the "
+                   "owning GPU", "steps": steps, "warmup": warmup, "scaling": "strong"}
+    try:
+        mine = set(owned)
+        cids = {i: eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths) if i in mine}
+        for w in ("c2", "c3"):
+            sim = build_settings(w, lengths)
+            tables = [mm.plan_table(ch) for ch in sim.chromosomes]
+            eng.set_params(mm.params_descriptor(sim))
+
+            def step():
+                eng.set_fast_key(42)
+                for ch, t in zip(sim.chromosomes, tables):
+                    if ch.number in mine:
+                        eng.plan_contig(cids[ch.number], t)
+                        eng.apply_contig(cids[ch.number])
+                    else:
+                        eng.plan_chain(lengths[ch.number], t)
+                eng.sync()
+            for _ in range(warmup):
+                step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            eng.sync()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            out[w] = {"value": round(sum(lengths) * steps / dt / 1e6, 3), "unit": "Mbases/s", "ms_per_step": round(dt / steps * 1e3, 3)}
+    finally:
+        eng.close()
+    return out
+
+
 def _snp_only_params():
     from mutation_simulator_amd import _ffi
     p = _ffi.Params()
@@ -433,12 +472,13 @@ def main():
     from mutation_simulator_amd.sharding import lpt_partition
 
     lengths = contig_lengths(a.total_bases)
-    # N > 1.  "weak" (default; the contract's definition: per-GPU work fixed): N genomes at once, one per GPU, each with
-    # its own seeded streams -- the cohort case, no exchange step, scales with N.  "strong": ONE genome, contigs sharded
-    # (LPT), the stream chain walked by every rank (msim_plan_chain for contigs it does not own), RCCL gather to rank 0 --
-    # BASELINE configs[4]'s shape, Amdahl-bound by the chain (amdahl_ceiling).  Whichever is the headline, the other one is
-    # measured too and rides in the same line (weak_replicas / one_genome_sharded).
-    scaling = a.scaling or "weak"
+    # N > 1.  "strong" (default since round 4: BASELINE's metric is "3 Gb synthetic genome ... 1 -> 8 GPUs" and configs[4] is ONE
+    # genome sharded): contigs sharded (LPT), the stream chain walked by every rank (msim_plan_chain for contigs it does not
+    # own), RCCL gather to rank 0 (streams + record tables + insert pools) -- Amdahl-bound by the chain in compatible mode
+    # (amdahl_ceiling), near-linear in fast mode, where nothing chains (one_genome_sharded_fast_rng).  "weak": N genomes at
+    # once, one per GPU, each with its own seeded streams -- the cohort case, no exchange step.  Whichever is the headline,
+    # the other one is measured too and rides in the same line (weak_replicas / one_genome_sharded).
+    scaling = a.scaling or ("strong" if world > 1 else "weak")      # N > 1: BASELINE's metric is ONE 3 Gb genome over the N GPUs
     strong = scaling == "strong" and world > 1
     parts = lpt_partition(lengths, world)               # ownership of the one-genome mode
     everything = list(range(len(lengths)))
@@ -550,6 +590,22 @@ def main():
             line["weak_replicas"] = {"value": round(sum(lengths) * world * a.steps / dtw / 1e6, 3), "unit": "Mbases/s",
                                      "ms_per_step": round(dtw / a.steps * 1e3, 3), "scaling": "weak",
                                      "what": f"{world} independent replicas, one whole genome per GPU, streams seeded 42+rank"}
+        if a.workload == "c2" and not a.no_secondary:
+            # BASELINE configs[4] as written: the full SV mix (c3) on ONE genome, contigs sharded over the N GPUs, RCCL gather
+            dt4, st4 = measure("c3", a.steps, 2, owned=parts[rank], step_seed=42)
+            sh4 = sharded_numbers(dt4, "c3")
+            if rank == 0:
+                sh4["metric"] = WORKLOADS["c3"]["metric"]
+                sh4["plan_engines_rank0"] = engines_of(st4, a.steps)
+                line["configs4_sv_mix_sharded"] = sh4
+            # the same genome in fast mode (--rng fast: counter-based draws, NOT the reference's numbers): nothing chains, a rank
+            # plans and applies its own contigs and skips the others -- the mode in which per-contig scaling can be near-linear
+            try:
+                fr = fast_rng_sharded(lengths, parts[rank], local_rank, barrier, max_over_ranks, mm)
+            except Exception as e:  # noqa: BLE001
+                fr = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                line["one_genome_sharded_fast_rng"] = fr
     elif world > 1:
         dts_, _ = measure(a.workload, a.steps, 1, owned=parts[rank], step_seed=42)
         sh = sharded_numbers(dts_)

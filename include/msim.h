@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 3
+#define MSIM_ABI_VERSION 4
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -54,12 +54,19 @@ extern "C" {
 #define MSIM_PLAN_AUTO   0u      /* per contig: a device PLAN engine where one applies, else the host planner */
 #define MSIM_PLAN_HOST   1u      /* force the sequential host planner (cross-check / debugging)               */
 #define MSIM_PLAN_GPU    2u      /* force a device engine; MSIM_ERR_UNSUPPORTED where none can run             */
-#define MSIM_RNG_FAST    4u      /* NOT stream-compatible with the reference: a counter-based generator (Philox4x32-10)
-                                    replaces the two MT19937 streams, so that no draw depends on another one and PLAN has no
-                                    sequential chain.  Same construction as the reference -- k = int(len * rate) positions per
-                                    range as a uniform k-subset with the minimum distance, transition with probability p_ti --
-                                    same distributions, different numbers.  SNP-only settings (MSIM_ERR_UNSUPPORTED otherwise);
-                                    msim_seed / msim_set_mt_state are ignored, msim_set_fast_key seeds it.                */
+#define MSIM_RNG_FAST    4u      /* NOT stream-compatible with the reference: a counter-based generator (Philox4x32-10) replaces
+                                    the two MT19937 streams, so that no draw depends on another one, PLAN has no sequential chain
+                                    and the host does nothing (csrc/plan_fast.hip, fast_math.h).  The CONSTRUCTION is the
+                                    reference's -- k = int(len * rate) candidates per range as a uniform k-subset with the minimum
+                                    distance (util.py:93-109), a type per candidate from the range's chances, a uniform length,
+                                    IV dropped / DU, DE clamped at the contig end, the boundary pass with its blocked ranges reset
+                                    per range (mutator.py:144-265), the rewrite's visit rule, transition with probability p_ti,
+                                    insert bases uniform in ATGC -- same distributions, different numbers.  SN / IN / DE / DU / IV
+                                    on any number of sorted, non-overlapping ranges; translocations and overlapping RMT ranges:
+                                    MSIM_ERR_UNSUPPORTED; a sample larger than its population: MSIM_ERR_VALUE like the reference.
+                                    msim_seed / msim_set_mt_state are ignored, msim_set_fast_key seeds it.  msim_plan_contig only
+                                    QUEUES the contig; everything queued goes to the device as one batch (one launch per stage over
+                                    all contigs) at the next call that needs a result -- plan a whole genome, then ask.        */
 /* Device PLAN engines: the device owns both MT19937 streams and does all per-record work;
  * SNP-only large ranges need nothing from the host, SV mixes hand the boundary chain over their non-SNP
  * candidates to the host, contigs with many small SNP ranges hand it the chain of sample() calls, contigs whose
@@ -313,18 +320,24 @@ int msim_comm_destroy(msim_ctx *ctx);
 /* Mutated length of a planned contig where PLAN alone fixes it (SNP-only tables, SV mixes planned on the device):
  * every rank then knows every contig's size without an exchange.  *known = 0: only the applying rank knows it. */
 int msim_planned_out_len(msim_ctx *ctx, int contig, uint64_t *out_len, int *known);
-/* Slot i = contig contig_ids[i] (this context's id), applied by rank owner[i], out_len[i] bytes.  Synchronises, then
- * moves every slot to `root`.  device_addrs[i] (optional) = where slot i now lives on this rank: the contig's own
- * buffer (owner), a receive buffer of the context (root), 0 elsewhere.  Valid until the next gather / clear.   */
-/* A failure of this call on ONE rank (a slot that rank has not applied, a length that disagrees with its result) is fatal
+/* Slot i = contig contig_ids[i] (this context's id), applied by rank owner[i].  A slot has three PARTS: 0 the mutated stream
+ * (out_len[i] bytes), 1 its record table (n_records[i] records of 16 bytes: the binary VCF, what __mutate_sequence hands the
+ * VcfWriter, mutator.py:334-421), 2 its insert pool (pool_len[i] bytes).  n_records / pool_len NULL: streams only.  Sizes of
+ * contigs a rank does not own come over the caller's control plane (msim_result_sizes on the owner).  Synchronises, then moves
+ * every part to `root`.  device_addrs[3 i + part] (optional) = where the part now lives on this rank: the contig's own buffer
+ * (owner), a receive buffer of the context (root), 0 elsewhere / for an empty part.  Valid until the next gather / clear.   */
+/* A failure of this call on ONE rank (a slot that rank has not applied, a size that disagrees with its result) is fatal
  * for the communicator: its peers have posted the matching transfers and wait for them.  Tear the communicator down
  * (msim_comm_destroy on every rank) -- agree on the slots over the control plane first, as gather.Communicator does.      */
 int msim_gather_to_root(msim_ctx *ctx, int n, const int *contig_ids, const int *owner, const uint64_t *out_len,
-                        int root, uint64_t *device_addrs);
-/* The transfers `rank` posts for that gather, without touching a GPU: ops[4k..] = kind (0 send, 1 recv, 2 already
- * local), slot, peer, bytes -- in posting order (slot order on both sides of every pair).                       */
-int msim_gather_plan(int n, const int *owner, const uint64_t *out_len, int rank, int world, int root,
-                     int64_t *ops, int *n_ops);
+                        const uint64_t *n_records, const uint64_t *pool_len, int root, uint64_t *device_addrs);
+/* The transfers `rank` posts for that gather, without touching a GPU: ops[5k..] = kind (0 send, 1 recv, 2 already
+ * local), slot, part, peer, bytes -- in posting order ((slot, part) order on both sides of every pair); capacity 3 n ops. */
+int msim_gather_plan(int n, const int *owner, const uint64_t *out_len, const uint64_t *n_records, const uint64_t *pool_len,
+                     int rank, int world, int root, int64_t *ops, int *n_ops);
+/* bytes at a device address msim_gather_to_root reported -> host (the root reading a remote contig's records / pool to
+ * render its VCF lines with msim_render_vcf).                                                                            */
+int msim_gather_fetch(msim_ctx *ctx, uint64_t device_addr, uint64_t bytes, void *dst);
 
 /* ---- stats -------------------------------------------------------------------------------------- */
 int msim_stats(msim_ctx *ctx, msim_timing *out);

@@ -128,12 +128,14 @@ int msim_comm_destroy(msim_ctx *p) {
 }
 
 // The bookkeeping of the gather, separated from the transport so that it can be checked without GPUs: which
-// transfers does `rank` post, in which order?  op = {kind (0 send, 1 recv, 2 local), slot, peer, bytes}.  The order
-// is the slot order on both sides of every pair, which is what makes grouped point-to-point calls match up.
-int msim_gather_plan(int n, const int *owner, const uint64_t *out_len, int rank, int world, int root,
-                     int64_t *ops /* 4 per op, capacity n */, int *n_ops) {
+// transfers does `rank` post, in which order?  A slot has three PARTS -- 0 the mutated stream, 1 its record table (16 bytes
+// per record: the binary VCF, mutator.py:334-421), 2 its insert pool -- and op = {kind (0 send, 1 recv, 2 local), slot, part,
+// peer, bytes}.  Empty parts are not transferred.  The order is (slot, part) on both sides of every pair, which is what makes
+// grouped point-to-point calls match up.  n_records / pool_len may be NULL: streams only.
+int msim_gather_plan(int n, const int *owner, const uint64_t *out_len, const uint64_t *n_records, const uint64_t *pool_len, int rank,
+                     int world, int root, int64_t *ops /* 5 per op, capacity 3 n */, int *n_ops) {
     if (n < 0 || (n && (!owner || !out_len)) || !ops || !n_ops || world < 1 || root < 0 || root >= world ||
-        rank < 0 || rank >= world)
+        rank < 0 || rank >= world || (!n_records) != (!pool_len))
         return MSIM_ERR_ARG;
     int k = 0;
     for (int i = 0; i < n; i++) {
@@ -142,17 +144,21 @@ int msim_gather_plan(int n, const int *owner, const uint64_t *out_len, int rank,
         if (rank == root) { kind = owner[i] == root ? 2 : 1; peer = owner[i]; }
         else if (owner[i] == rank) { kind = 0; peer = root; }
         if (kind < 0) continue;
-        ops[4 * k] = kind; ops[4 * k + 1] = i; ops[4 * k + 2] = peer; ops[4 * k + 3] = (int64_t)out_len[i];
-        k++;
+        const uint64_t bytes[3] = {out_len[i], n_records ? n_records[i] * sizeof(msim_record) : 0, pool_len ? pool_len[i] : 0};
+        for (int part = 0; part < 3; part++) {
+            if (part && !bytes[part]) continue;            // (the stream's op is always there: it carries the slot, even when empty)
+            ops[5 * k] = kind; ops[5 * k + 1] = i; ops[5 * k + 2] = part; ops[5 * k + 3] = peer; ops[5 * k + 4] = (int64_t)bytes[part];
+            k++;
+        }
     }
     *n_ops = k;
     return MSIM_OK;
 }
 
-int msim_gather_to_root(msim_ctx *p, int n, const int *contig_ids, const int *owner, const uint64_t *out_len, int root,
-                        uint64_t *device_addrs) {
+int msim_gather_to_root(msim_ctx *p, int n, const int *contig_ids, const int *owner, const uint64_t *out_len, const uint64_t *n_records,
+                        const uint64_t *pool_len, int root, uint64_t *device_addrs) {
     Ctx *c = reinterpret_cast<Ctx *>(p);
-    if (!c || n < 0 || (n && (!contig_ids || !owner || !out_len))) return MSIM_ERR_ARG;
+    if (!c || n < 0 || (n && (!contig_ids || !owner || !out_len)) || (!n_records) != (!pool_len)) return MSIM_ERR_ARG;
     if (c->host_only) return fail(c, MSIM_ERR_HIP, "host-only context: this call needs the GPU");
     Comm *m = c->comm;
     const int rank = m ? m->rank : 0, world = m ? m->world : 1;
@@ -161,52 +167,69 @@ int msim_gather_to_root(msim_ctx *p, int n, const int *contig_ids, const int *ow
             if (owner[i] != 0) return fail(c, MSIM_ERR_ARG, "msim_gather_to_root before msim_comm_init");
     }
     TraceRange tr("msim gather to root (RCCL)");
-    std::vector<int64_t> ops((size_t)4 * (n ? n : 1));
+    std::vector<int64_t> ops((size_t)15 * (n ? n : 1));
     int n_ops = 0;
-    int rc = msim_gather_plan(n, owner, out_len, rank, world, root, ops.data(), &n_ops);
+    int rc = msim_gather_plan(n, owner, out_len, n_records, pool_len, rank, world, root, ops.data(), &n_ops);
     if (rc) return fail(c, rc, "msim_gather_to_root: bad owner / root");
     // everything this rank produced has to exist before it is sent: collect the asynchronous APPLYs
     rc = msim_sync(p);
     if (rc) return rc;
-    if (device_addrs) for (int i = 0; i < n; i++) device_addrs[i] = 0;
-    if (m && rank == root && m->recv.size() < (size_t)n) { m->recv.resize((size_t)n, nullptr); m->cap.resize((size_t)n, 0); }
+    if (device_addrs) for (int i = 0; i < 3 * n; i++) device_addrs[i] = 0;
+    if (m && rank == root && m->recv.size() < (size_t)3 * n) { m->recv.resize((size_t)3 * n, nullptr); m->cap.resize((size_t)3 * n, 0); }
     bool any_remote = false;
+    auto local_ptr = [&](Contig &g, int part) -> uint8_t * {
+        return part == 0 ? g.d_out : part == 1 ? reinterpret_cast<uint8_t *>(g.d_recs) : g.d_pool + PAD;
+    };
     for (int k = 0; k < n_ops; k++) {                      // buffers first: no allocation inside the group
-        const int kind = (int)ops[4 * k], slot = (int)ops[4 * k + 1];
-        const uint64_t bytes = (uint64_t)ops[4 * k + 3];
+        const int kind = (int)ops[5 * k], slot = (int)ops[5 * k + 1], part = (int)ops[5 * k + 2];
+        const uint64_t bytes = (uint64_t)ops[5 * k + 4];
+        const size_t at = (size_t)3 * slot + part;
         if (kind == 1) {
             any_remote = true;
-            if (m->cap[(size_t)slot] < bytes + PAD) {
-                if (m->recv[(size_t)slot]) MSIM_HIP(c, hipFree(m->recv[(size_t)slot]));
-                m->recv[(size_t)slot] = nullptr; m->cap[(size_t)slot] = 0;
+            if (m->cap[at] < bytes + PAD) {
+                if (m->recv[at]) MSIM_HIP(c, hipFree(m->recv[at]));
+                m->recv[at] = nullptr; m->cap[at] = 0;
                 const size_t sz = bytes + (bytes >> 4) + PAD;
-                MSIM_HIP(c, hipMalloc(&m->recv[(size_t)slot], sz));
-                m->cap[(size_t)slot] = sz;
+                MSIM_HIP(c, hipMalloc(&m->recv[at], sz));
+                m->cap[at] = sz;
             }
-            if (device_addrs) device_addrs[slot] = (uint64_t)(uintptr_t)m->recv[(size_t)slot];
+            if (device_addrs) device_addrs[at] = (uint64_t)(uintptr_t)m->recv[at];
         } else {
             const int cid = contig_ids[slot];
             if (cid < 0 || (size_t)cid >= c->contigs.size()) return fail(c, MSIM_ERR_ARG, "no such contig");
             Contig &g = c->contigs[(size_t)cid];
             if (!g.applied) return fail(c, MSIM_ERR_ARG, "gather of a contig this rank has not applied");
-            if (g.out_len != bytes) return fail(c, MSIM_ERR_ARG, "gather: out_len disagrees with the applied contig");
+            if (part == 0 && g.out_len != bytes) return fail(c, MSIM_ERR_ARG, "gather: out_len disagrees with the applied contig");
+            if (part == 1 && g.n_rec * sizeof(msim_record) != bytes) return fail(c, MSIM_ERR_ARG, "gather: n_records disagrees with the contig's table");
+            if (part == 2 && g.pool_len != bytes) return fail(c, MSIM_ERR_ARG, "gather: pool_len disagrees with the contig's insert pool");
             if (kind == 0) any_remote = true;
-            if (device_addrs) device_addrs[slot] = (uint64_t)(uintptr_t)g.d_out;
+            if (device_addrs) device_addrs[at] = (uint64_t)(uintptr_t)local_ptr(g, part);
         }
     }
     if (!any_remote) return MSIM_OK;
     hipStream_t st = c->emit_stream;
     int nrc = g_rccl.GroupStart();
     for (int k = 0; k < n_ops && !nrc; k++) {
-        const int kind = (int)ops[4 * k], slot = (int)ops[4 * k + 1], peer = (int)ops[4 * k + 2];
-        const size_t bytes = (size_t)ops[4 * k + 3];
-        if (kind == 0) nrc = g_rccl.Send(c->contigs[(size_t)contig_ids[slot]].d_out, bytes, NCCL_UINT8, peer, m->comm, st);
-        else if (kind == 1) nrc = g_rccl.Recv(m->recv[(size_t)slot], bytes, NCCL_UINT8, peer, m->comm, st);
+        const int kind = (int)ops[5 * k], slot = (int)ops[5 * k + 1], part = (int)ops[5 * k + 2], peer = (int)ops[5 * k + 3];
+        const size_t bytes = (size_t)ops[5 * k + 4];
+        if (!bytes) continue;
+        if (kind == 0) nrc = g_rccl.Send(local_ptr(c->contigs[(size_t)contig_ids[slot]], part), bytes, NCCL_UINT8, peer, m->comm, st);
+        else if (kind == 1) nrc = g_rccl.Recv(m->recv[(size_t)3 * slot + part], bytes, NCCL_UINT8, peer, m->comm, st);
     }
     const int erc = g_rccl.GroupEnd();
     if (!nrc) nrc = erc;
     if (nrc) return fail(c, MSIM_ERR_HIP, std::string("RCCL gather: ") + g_rccl.GetErrorString(nrc));
     MSIM_HIP(c, hipStreamSynchronize(st));
+    return MSIM_OK;
+}
+
+// Copy `bytes` bytes at a device address msim_gather_to_root reported (a gathered part on the root, a contig's own buffer
+// elsewhere) to the host: how the root reads the record tables and insert pools of contigs it does not own.
+int msim_gather_fetch(msim_ctx *p, uint64_t device_addr, uint64_t bytes, void *dst) {
+    Ctx *c = reinterpret_cast<Ctx *>(p);
+    if (!c || (bytes && (!dst || !device_addr))) return MSIM_ERR_ARG;
+    if (c->host_only) return fail(c, MSIM_ERR_HIP, "host-only context: this call needs the GPU");
+    if (bytes) MSIM_HIP(c, hipMemcpy(dst, reinterpret_cast<const void *>((uintptr_t)device_addr), bytes, hipMemcpyDeviceToHost));
     return MSIM_OK;
 }
 

@@ -128,8 +128,9 @@ SYMBOLS = [
     ("msim_comm_init", C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     ("msim_comm_destroy", C.c_int, [_VP]),
     ("msim_planned_out_len", C.c_int, [_VP, C.c_int, _U64P, _IP]),
-    ("msim_gather_to_root", C.c_int, [_VP, C.c_int, _IP, _IP, _U64P, C.c_int, _U64P]),
-    ("msim_gather_plan", C.c_int, [C.c_int, _IP, _U64P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _IP]),
+    ("msim_gather_to_root", C.c_int, [_VP, C.c_int, _IP, _IP, _U64P, _U64P, _U64P, C.c_int, _U64P]),
+    ("msim_gather_plan", C.c_int, [C.c_int, _IP, _U64P, _U64P, _U64P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), _IP]),
+    ("msim_gather_fetch", C.c_int, [_VP, C.c_uint64, C.c_uint64, _VP]),
     ("msim_stats", C.c_int, [_VP, C.POINTER(Timing)]),
     ("msim_reset_stats", C.c_int, [_VP]),
 ]
@@ -158,7 +159,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msim_abi_version() != 3:
+        if lib.msim_abi_version() != 4:
             raise MsimError("libmsim ABI version mismatch")
         _lib = lib
     return _lib
@@ -542,15 +543,25 @@ class Engine:
         self._check(self.lib.msim_planned_out_len(self.h, contig, C.byref(n), C.byref(k)))
         return n.value, bool(k.value)
 
-    def gather_to_root(self, contig_ids, owner, out_len, root: int = 0):
-        """Moves every slot to ``root`` over RCCL; returns the device address of every slot on this rank."""
+    def gather_to_root(self, contig_ids, owner, out_len, n_records=None, pool_len=None, root: int = 0):
+        """Moves every slot -- mutated stream, and with ``n_records`` / ``pool_len`` its record table and insert pool -- to
+        ``root`` over RCCL; returns per slot the device addresses (stream, records, pool) on this rank (0: not here / empty)."""
         n = len(contig_ids)
         ids = (C.c_int * max(n, 1))(*contig_ids)
         own = (C.c_int * max(n, 1))(*owner)
         lens = (C.c_uint64 * max(n, 1))(*out_len)
-        addrs = (C.c_uint64 * max(n, 1))()
-        self._check(self.lib.msim_gather_to_root(self.h, n, ids, own, lens, root, addrs))
-        return list(addrs)[:n]
+        nrec = (C.c_uint64 * max(n, 1))(*n_records) if n_records is not None else None
+        pool = (C.c_uint64 * max(n, 1))(*pool_len) if pool_len is not None else None
+        addrs = (C.c_uint64 * (3 * max(n, 1)))()
+        self._check(self.lib.msim_gather_to_root(self.h, n, ids, own, lens, nrec, pool, root, addrs))
+        return [tuple(addrs[3 * i + j] for j in range(3)) for i in range(n)]
+
+    def gather_fetch(self, device_addr: int, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        """A gathered part (address from ``gather_to_root``) as a host array."""
+        out = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        if nbytes:
+            self._check(self.lib.msim_gather_fetch(self.h, device_addr, nbytes, C.c_void_p(out.ctypes.data)))
+        return out
 
     def release_result(self, contig: int):
         self._check(self.lib.msim_release_result(self.h, contig))
@@ -578,18 +589,21 @@ def comm_unique_id() -> bytes:
     return bytes(buf)
 
 
-def gather_plan(owner, out_len, rank: int, world: int, root: int = 0):
-    """The transfers ``rank`` posts for a gather: list of (kind, slot, peer, bytes); kind 0 send, 1 recv, 2 local."""
+def gather_plan(owner, out_len, rank: int, world: int, root: int = 0, n_records=None, pool_len=None):
+    """The transfers ``rank`` posts for a gather: list of (kind, slot, part, peer, bytes); kind 0 send, 1 recv, 2 local;
+    part 0 the mutated stream, 1 the record table, 2 the insert pool."""
     lib = load()
     n = len(owner)
     own = (C.c_int * max(n, 1))(*owner)
     lens = (C.c_uint64 * max(n, 1))(*out_len)
-    ops = (C.c_int64 * (4 * max(n, 1)))()
+    nrec = (C.c_uint64 * max(n, 1))(*n_records) if n_records is not None else None
+    pool = (C.c_uint64 * max(n, 1))(*pool_len) if pool_len is not None else None
+    ops = (C.c_int64 * (15 * max(n, 1)))()
     k = C.c_int()
-    rc = lib.msim_gather_plan(n, own, lens, rank, world, root, ops, C.byref(k))
+    rc = lib.msim_gather_plan(n, own, lens, nrec, pool, rank, world, root, ops, C.byref(k))
     if rc != OK:
         raise MsimError(f"msim_gather_plan failed ({rc})")
-    return [tuple(int(ops[4 * i + j]) for j in range(4)) for i in range(k.value)]
+    return [tuple(int(ops[5 * i + j]) for j in range(5)) for i in range(k.value)]
 
 
 def render_vcf(recs: np.ndarray, pool: np.ndarray, bases: np.ndarray, seq_name: str) -> bytes:

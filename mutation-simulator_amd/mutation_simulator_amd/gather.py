@@ -55,29 +55,28 @@ class Communicator:
         return ("libmsim RCCL communicator (dlopen librccl): grouped ncclSend/ncclRecv, every peer -> rank 0 over its own "
                 "xGMI link; ncclUniqueId bootstrapped over the gloo control plane")
 
-    def lengths(self, contig_ids, parts):
-        """Mutated length of every contig, on every rank.  PLAN is replayed everywhere, so lengths it fixes are
-        local knowledge; the rest is exchanged over the control plane by the owning rank."""
+    def sizes(self, contig_ids, parts):
+        """(owner, mutated length, records, insert pool bytes) of every contig, on every rank.  The owner knows them once it
+        has applied the contig; the others learn them over the control plane (in compatible mode a rank only walks the stream
+        chain through contigs it does not own -- msim_plan_chain leaves no table --, in fast mode it skips them altogether)."""
         owner = owners_of(parts, len(contig_ids))
-        lens, missing = [], []
-        for i, cid in enumerate(contig_ids):
-            n, known = self.eng.planned_out_len(cid)
-            if not known:
-                missing.append(i)
-                n = self.eng.result_sizes(cid)[0] if owner[i] == self.rank else 0
-            lens.append(n)
-        if missing and self.world > 1:
-            mine = {i: lens[i] for i in missing if owner[i] == self.rank}
+        mine = {i: self.eng.result_sizes(cid) for i, cid in enumerate(contig_ids) if owner[i] == self.rank}
+        every = [mine]
+        if self.world > 1:
             every = [None] * self.world
             self.dist.all_gather_object(every, mine)
-            for d in every:
-                for i, n in d.items():
-                    lens[i] = n
-        return owner, lens
+        lens, nrec, pool = [0] * len(contig_ids), [0] * len(contig_ids), [0] * len(contig_ids)
+        for d in every:
+            for i, (a, b, c) in d.items():
+                lens[i], nrec[i], pool[i] = int(a), int(b), int(c)
+        return owner, lens, nrec, pool
 
-    def gather_to_root(self, contig_ids, parts, root: int = 0):
-        owner, lens = self.lengths(contig_ids, parts)
-        return self.eng.gather_to_root(contig_ids, owner, lens, root), lens
+    def gather_to_root(self, contig_ids, parts, root: int = 0, records: bool = True):
+        """Every contig's mutated stream (and, ``records``, its record table + insert pool: the binary VCF) on ``root``.
+        Returns (per slot the device addresses (stream, records, pool) on this rank, lengths, record counts, pool bytes)."""
+        owner, lens, nrec, pool = self.sizes(contig_ids, parts)
+        addrs = self.eng.gather_to_root(contig_ids, owner, lens, nrec if records else None, pool if records else None, root)
+        return addrs, lens, nrec, pool
 
     def close(self):
         if self.live:
@@ -92,23 +91,37 @@ class HostTransport:
     def __init__(self, rank: int, world: int, dist):
         self.rank, self.world, self.dist = rank, world, dist
 
-    def gather_to_root(self, payload: dict, owner, out_len, root: int = 0):
-        """payload: slot -> uint8 numpy array for the slots this rank owns.  Returns slot -> array on root."""
+    def gather_to_root(self, payload: dict, owner, out_len, root: int = 0, n_records=None, pool_len=None):
+        """payload: slot -> uint8 array (the stream), or slot -> (stream, record bytes, pool bytes) when ``n_records`` /
+        ``pool_len`` are given, for the slots this rank owns.  Returns the same on root (parts as uint8 arrays)."""
         import torch
-        ops = _ffi.gather_plan(owner, out_len, self.rank, self.world, root)
+        three = n_records is not None
+        ops = _ffi.gather_plan(owner, out_len, self.rank, self.world, root, n_records, pool_len)
         out, reqs, keep = {}, [], []
-        for kind, slot, peer, nbytes in ops:
+
+        def part_of(slot, part):
+            v = payload[slot]
+            return np.ascontiguousarray(v[part] if three else v).view(np.uint8).reshape(-1)
+        for kind, slot, part, peer, nbytes in ops:
             if kind == 2:
-                out[slot] = payload[slot]
+                out[(slot, part)] = part_of(slot, part)
             elif kind == 0:
-                t = torch.from_numpy(np.ascontiguousarray(payload[slot]))
+                t = torch.from_numpy(part_of(slot, part).copy())
                 assert t.numel() == nbytes
                 keep.append(t)
-                reqs.append(self.dist.isend(t, peer, tag=slot))
+                reqs.append(self.dist.isend(t, peer, tag=3 * slot + part))
             else:
                 t = torch.empty(nbytes, dtype=torch.uint8)
-                out[slot] = t
-                reqs.append(self.dist.irecv(t, peer, tag=slot))
+                out[(slot, part)] = t
+                reqs.append(self.dist.irecv(t, peer, tag=3 * slot + part))
         for r in reqs:
             r.wait()
-        return {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in out.items()}
+        got = {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in out.items()}
+        if not three:
+            return {slot: v for (slot, part), v in got.items()}
+        res = {}
+        for (slot, part), v in got.items():
+            res.setdefault(slot, [np.zeros(0, np.uint8)] * 3)
+            res[slot] = list(res[slot])
+            res[slot][part] = v
+        return {slot: tuple(v) for slot, v in res.items()}

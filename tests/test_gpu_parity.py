@@ -292,8 +292,11 @@ def test_gather_single_rank_and_rccl_loopback(engine):
     cid = _plan_apply_snp_contig(engine)
     want = engine.fetch_sequence(cid)
     comm = Communicator(engine, 0, 1, None)
-    addrs, lens = comm.gather_to_root([cid], [[0]])
-    assert lens == [len(want)] and addrs[0] == engine.result_device_ptr(cid)[0]
+    addrs, lens, nrec, pool = comm.gather_to_root([cid], [[0]])
+    assert lens == [len(want)] and addrs[0][0] == engine.result_device_ptr(cid)[0]
+    recs, _ = engine.fetch_records(cid)
+    assert nrec == [len(recs)] and pool == [0] and addrs[0][2] == 0
+    assert np.array_equal(engine.gather_fetch(addrs[0][1], 16 * nrec[0], _ffi.RECORD_DTYPE).view(np.uint8), recs.view(np.uint8))
     engine.comm_init(_ffi.comm_unique_id(), 0, 1)
     lib = _ffi.load()
     lib.msim_dbg_comm_loopback.restype = C.c_int
@@ -333,21 +336,27 @@ def _two_gpu_worker(rank, world, port, out_dir):
         cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
         comm = Communicator(eng, rank, world, dist)
         bench.one_step(eng, sim, cids, parts[rank], 42)
-        addrs, lens = comm.gather_to_root(cids, parts)
+        addrs, lens, nrec, pool = comm.gather_to_root(cids, parts)
         if rank == 0:
-            sums = []
+            import hashlib
+            sums, tabs = [], []
             lib = ffi.load()
             import ctypes as C
             lib.msim_dbg_checksum_device.restype = C.c_int
             lib.msim_dbg_checksum_device.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
-            for a, n in zip(addrs, lens):
+            for (a, ra, pa), n, nr, pl in zip(addrs, lens, nrec, pool):
                 s = C.c_uint64()
                 assert lib.msim_dbg_checksum_device(eng.h, a, n, C.byref(s)) == 0
                 sums.append(s.value)
+                tabs.append(hashlib.sha256(eng.gather_fetch(ra, 16 * nr).tobytes() + eng.gather_fetch(pa, pl).tobytes()).hexdigest())
             # the 1-GPU answer: apply everything here
             bench.one_step(eng, sim, cids, list(range(len(lengths))), 42)
             want = [eng.result_checksum(c) for c in cids]
-            Path(out_dir, "two_gpu.json").write_text(json.dumps({"ok": sums == want, "n": len(sums)}))
+            want_tabs = []
+            for c in cids:
+                recs, pl = eng.fetch_records(c)
+                want_tabs.append(hashlib.sha256(recs.tobytes() + pl.tobytes()).hexdigest())
+            Path(out_dir, "two_gpu.json").write_text(json.dumps({"ok": sums == want and tabs == want_tabs, "n": len(sums)}))
         dist.barrier()
         comm.close()
         eng.close()
