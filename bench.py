@@ -312,13 +312,12 @@ def fast_rng_steps(lengths, mm, steps=5, warmup=3):
         cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
         for w in ("c2", "c3", "c4", "c4sv"):
             sim = build_settings(w, lengths)
-            tables = [mm.plan_table(ch) for ch in sim.chromosomes]
             eng.set_params(mm.params_descriptor(sim))
 
             def step():
                 eng.set_fast_key(42)
-                for ch, t in zip(sim.chromosomes, tables):
-                    eng.plan_contig(cids[ch.number], t)
+                for ch in sim.chromosomes:
+                    eng.plan_contig(cids[ch.number], mm.plan_table(ch))      # (the range tables are made inside the step)
                     eng.apply_contig(cids[ch.number])
                 eng.sync()
             for _ in range(warmup):
@@ -512,15 +511,17 @@ def main():
         owned = mine if owned is None else owned
         step_seed = seed if step_seed is None else step_seed
         sim = build_settings(workload, lengths)
-        # msim_range table per contig: settings -> integers ONCE, outside the timed steps (the settings do not change
-        # between steps; the CLI pays this once per run).  What that costs is reported next to the value
-        # ("descriptor_marshalling_ms": the msim_range table of every contig, mutator.plan_table).
-        t_m = time.perf_counter()
-        descs = {chrom.number: mm.plan_table(chrom) for chrom in sim.chromosomes}
-        marshal_ms[workload] = round((time.perf_counter() - t_m) * 1e3, 3)
+        # msim_range table per contig: settings -> integers INSIDE every timed step since round 4 (mutator.plan_table ->
+        # msim_build_ranges: the reference's int((stop - start + 1) * rate), cdf and setsize per range are part of its hot path,
+        # mutator.py:160-174,225).  "descriptor_marshalling_ms" = what that is per step (it is inside ms_per_step).  The walk
+        # over the settings tree's RangeDefinition objects happens once, at the first table (warm-up): mutator._range_triples.
+        marsh = [0.0]
 
         def plan_descs(chrom):
-            return descs[chrom.number]
+            t_m = time.perf_counter()
+            d = mm.plan_table(chrom)
+            marsh[0] += time.perf_counter() - t_m
+            return d
         eng.set_params(mm.params_descriptor(sim))
 
         def step():
@@ -528,15 +529,17 @@ def main():
             if gather:
                 comm.gather_to_root(cids, parts)
 
-        for _ in range(warmup):
+        for _ in range(max(warmup, 1)):                 # (at least one: the first table of a settings tree walks its objects)
             step()
         eng.reset_stats()
         barrier()
+        marsh[0] = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
+        marshal_ms[workload] = round(marsh[0] / steps * 1e3, 3)
         return dt, eng.stats()
 
     dt, st = measure(a.workload, a.steps, a.warmup)
@@ -557,7 +560,7 @@ def main():
                                        if strong else f"{world} independent replica(s): one whole genome per GPU, "
                                        f"streams seeded 42+rank, results left in HBM")},
             "stages_ms_per_step": stages_of(st, a.steps),
-            "descriptor_marshalling_ms": marshal_ms[a.workload],      # once per run, NOT in the timed steps
+            "descriptor_marshalling_ms": marshal_ms[a.workload],      # per step, INSIDE ms_per_step (msim_build_ranges)
             "plan_engines": engines_of(st, a.steps),
             "records_per_step": st["records"] // a.steps,
             "roofline": roofline_of(st, a.workload, a.steps),

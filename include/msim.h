@@ -189,6 +189,26 @@ int msim_plan_chain(msim_ctx *ctx, uint64_t len, const msim_range *ranges, int n
 /* 1 if the last plan of this contig left `muts` empty (warning at mutator.py:125-129).             */
 int msim_plan_was_empty(msim_ctx *ctx, int contig, int *empty);
 
+/* ---- settings -> msim_range tables, natively ------------------------------------------------------ */
+/* One MutationSettings object (rmt.py:79-163) as the reference holds it: floats stay floats until here.  */
+typedef struct msim_settings_desc {
+    double   rate_sum;        /* sum(mut_rates.values()) -- Python's left-to-right float sum, evaluated by the caller (one number) */
+    int32_t  n_types;         /* len(mut_chances), dict order                                       */
+    int32_t  types[8];        /* MSIM_* ids in that order                                            */
+    double   chances[8];      /* mut_chances.values()                                                */
+    int64_t  min_len[8];      /* mut_lengs["min"/"max"], indexed by MSIM_* id                        */
+    int64_t  max_len[8];
+} msim_settings_desc;
+/* The msim_range table of a contig from its ranges' (start, stop, settings index) triples: what mutator.py:157-174,225 and
+ * CPython's sample() derive per range, with the same IEEE operations --
+ *   k        = (int64) ((double)(stop - start + 1) * rate_sum)                  int(((stop - start) + 1) * sum(rates))
+ *   setsize  = 21 + 4^ceil(log4(3 k)) for k > 5, else 21, in integers (3 k is never a power of 4; exact for k < 2^33)
+ *   cdf_thr  = ceil(cdf_j * 2^53), cdf = cumsum(chances) / cumsum(chances)[-1]  numpy.random.choice(p=...)
+ * An RMT file in the style of the reference's examples gives a genome 35 000 ranges over three settings objects: this is
+ * their marshalling, off the Python interpreter.  Pure host code, no context.  MSIM_ERR_ARG: a settings index out of range.  */
+int msim_build_ranges(const msim_settings_desc *sets, int n_sets, const int64_t *start, const int64_t *stop,
+                      const int32_t *set_id, int64_t n, msim_range *out);
+
 /* ---- APPLY: Mutator.__mutate_sequence (mutator.py:318-426) -------------------------------------- */
 /* Execution model: msim_plan_contig (SNP sampler engine) and msim_apply_contig (device-planned tables) only
  * ENQUEUE work -- the chain that fixes stream positions on one HIP stream, record emission and the rewrite

@@ -1411,3 +1411,53 @@ int plan_contig_host(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges,
 }
 
 }  // namespace msim
+
+// ---- settings -> msim_range tables (include/msim.h: msim_build_ranges) ---------------------------------------------------
+// The float expressions are the reference's (mutator.py:160-174, 225) evaluated with the same IEEE operations: a double
+// multiply and a truncation for k, numpy's cumsum (sequential adds) and one division per threshold, an exact ceil of
+// cdf * 2^53 (a multiplication by a power of two is exact).  tests/test_cabi_host.py holds it against
+// mutator.plan_descriptors on a million random ranges and on the settings goldens.
+extern "C" int msim_build_ranges(const msim_settings_desc *sets, int n_sets, const int64_t *start, const int64_t *stop,
+                                 const int32_t *set_id, int64_t n, msim_range *out) {
+    if (n < 0 || n_sets < 0 || (n && (!sets || !start || !stop || !set_id || !out))) return MSIM_ERR_ARG;
+    std::vector<msim_range> tmpl((size_t)n_sets);
+    for (int s = 0; s < n_sets; s++) {
+        const msim_settings_desc &d = sets[s];
+        if (d.n_types < 0 || d.n_types > 8) return MSIM_ERR_ARG;
+        msim_range &t = tmpl[(size_t)s];
+        memset(&t, 0, sizeof t);
+        t.n_types = d.n_types;
+        double cdf[8], run = 0.0;
+        for (int j = 0; j < d.n_types; j++) { run += d.chances[j]; cdf[j] = run; }           // numpy.cumsum
+        for (int j = 0; j < d.n_types; j++) {
+            t.types[j] = d.types[j];
+            const double c = cdf[j] / cdf[d.n_types - 1];                                     // cdf /= cdf[-1]
+            double x = c * 9007199254740992.0;                                                // exact
+            if (!(x > 0.0)) t.cdf_thr[j] = 0;                                                 // (0, negative or NaN: nothing below it)
+            else { x = std::ceil(x); t.cdf_thr[j] = x >= 18446744073709551616.0 ? ~0ull : (uint64_t)x; }
+        }
+        for (int q = 0; q < 8; q++) { t.min_len[q] = d.min_len[q]; t.max_len[q] = d.max_len[q]; }
+    }
+    for (int64_t i = 0; i < n; i++) {
+        if (set_id[i] < 0 || set_id[i] >= n_sets) return MSIM_ERR_ARG;
+        msim_range r = tmpl[(size_t)set_id[i]];
+        r.start = start[i];
+        r.stop = stop[i];
+        const double span = (double)((stop[i] - start[i]) + 1);                                // (exact below 2^53)
+        const double kf = span * sets[set_id[i]].rate_sum;
+        int64_t k = kf >= 9.2e18 ? INT64_MAX : kf <= -9.2e18 ? INT64_MIN : (int64_t)kf;       // int(): towards zero
+        r.k = k;
+        int64_t setsize = 21;
+        if (k > 5) {
+            const unsigned __int128 x = (unsigned __int128)3 * (uint64_t)k - 1;                // smallest m with 4^m > 3 k
+            int bits = 0;
+            for (unsigned __int128 y = x; y; y >>= 1) bits++;
+            const int m = (bits + 1) / 2;
+            setsize = m >= 31 ? INT64_MAX : 21 + ((int64_t)1 << (2 * m));
+        }
+        r.setsize = setsize;
+        out[i] = r;
+    }
+    return MSIM_OK;
+}
+

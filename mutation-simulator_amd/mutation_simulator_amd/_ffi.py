@@ -41,6 +41,11 @@ class Range(C.Structure):            # msim_range
                 ("cdf_thr", C.c_uint64 * 8), ("min_len", C.c_int64 * 8), ("max_len", C.c_int64 * 8)]
 
 
+class SettingsDesc(C.Structure):     # msim_settings_desc
+    _fields_ = [("rate_sum", C.c_double), ("n_types", C.c_int32), ("types", C.c_int32 * 8), ("chances", C.c_double * 8),
+                ("min_len", C.c_int64 * 8), ("max_len", C.c_int64 * 8)]
+
+
 class Params(C.Structure):           # msim_params
     _fields_ = [("block", C.c_int64 * 8), ("ti_lim", C.c_uint64)]
 
@@ -124,6 +129,7 @@ SYMBOLS = [
     ("msim_batch_view", C.c_int, [_VP, C.POINTER(C.c_void_p), _U64P, C.POINTER(C.c_void_p), _U64P, _U64P]),
     ("msim_batch_key_contig", C.c_int, [_VP, _IP]),
     ("msim_fasta_index", C.c_int, [_VP, C.c_uint64, _VP, C.c_uint64, _U64P]),
+    ("msim_build_ranges", C.c_int, [_VP, C.c_int, _VP, _VP, _VP, C.c_int64, _VP]),
     ("msim_comm_unique_id", C.c_int, [_VP]),
     ("msim_comm_init", C.c_int, [_VP, _VP, C.c_int, C.c_int]),
     ("msim_comm_destroy", C.c_int, [_VP]),

@@ -158,11 +158,91 @@ def plan_descriptors(chrom) -> list:
             if rd.mutation_settings.has_mutations]
 
 
+def _range_triples(chrom):
+    """(start, stop, settings index) arrays of the contig's ranges with mutations + the distinct settings objects: the contig's
+    range list in the form ``msim_build_ranges`` takes.  Walking 35 000 ``RangeDefinition`` objects is 20 ms of interpreter
+    time per genome, so the arrays are made once per settings tree and kept on the chromosome object (a list that is replaced
+    or changes its length is walked again; ranges edited IN PLACE after their first use are not noticed -- nothing in the
+    product does that).  The settings' VALUES are read on every call."""
+    rds = chrom.range_definitions
+    stamp = (id(rds), len(rds))
+    cached = getattr(chrom, "_msim_triples", None)
+    if cached is not None and cached[0] == stamp:
+        return cached[1:]
+    keep = [rd for rd in rds if rd.mutation_settings.has_mutations]
+    n = len(keep)
+    start = np.fromiter((rd.start for rd in keep), dtype=np.int64, count=n)
+    stop = np.fromiter((rd.stop for rd in keep), dtype=np.int64, count=n)
+    ids = np.fromiter((id(rd.mutation_settings) for rd in keep), dtype=np.int64, count=n)
+    uniq, first, inv = np.unique(ids, return_index=True, return_inverse=True) if n else (ids, ids, ids)
+    # an RMT parser makes one settings object per range line: 35 000 objects, three distinct VALUES -- ranges are grouped by value
+    by_value, of_object, settings = {}, np.empty(len(uniq), dtype=np.int32), []
+    for q, f in enumerate(first.tolist()):
+        ms = keep[f].mutation_settings
+        key = _settings_key(ms)
+        if key not in by_value:
+            by_value[key] = len(settings)
+            settings.append(ms)
+        of_object[q] = by_value[key]
+    sid = of_object[inv] if n else np.zeros(0, dtype=np.int32)
+    out = (np.ascontiguousarray(start), np.ascontiguousarray(stop), np.ascontiguousarray(sid, dtype=np.int32), settings)
+    try:
+        chrom._msim_triples = (stamp,) + out
+    except AttributeError:
+        pass
+    return out
+
+
+def _settings_descs(settings):
+    descs = (_ffi.SettingsDesc * max(len(settings), 1))()
+    for d, ms in zip(descs, settings):
+        d.rate_sum = sum(ms.mut_rates.values())                          # mutator.py:160 (Python's own left-to-right sum)
+        chances = ms.mut_chances                                         # mutator.py:172-173
+        d.n_types = len(chances)
+        for j, (ty, p) in enumerate(chances.items()):
+            d.types[j] = ty.value
+            d.chances[j] = p
+        if ms.mut_lengs:
+            for ty, v in ms.mut_lengs["min"].items():
+                d.min_len[ty.value] = v
+            for ty, v in ms.mut_lengs["max"].items():
+                d.max_len[ty.value] = v
+    return descs
+
+
 def plan_table(chrom) -> np.ndarray:
-    """``plan_descriptors`` as ONE ``msim_range`` table (numpy, ``_ffi.RANGE_DTYPE``), built with array operations: an RMT
-    file in the style of the reference's examples gives a contig thousands of ranges that share a handful of settings
-    objects -- the per-settings part is copied in bulk, ``k`` and ``setsize`` come from the same float / integer
-    expressions as ``range_descriptor`` (checked against it in the tests)."""
+    """``plan_descriptors`` as ONE ``msim_range`` table (numpy, ``_ffi.RANGE_DTYPE``), built natively: the contig's ranges as
+    (start, stop, settings index) arrays and its few distinct settings go to ``msim_build_ranges`` (csrc/plan_host.cpp), which
+    evaluates the reference's float expressions (``int(((stop - start) + 1) * sum(rates))``, ``cumsum(p) / cumsum(p)[-1]``) with
+    the same IEEE operations.  Checked against ``range_descriptor`` range by range in the tests (a million random ranges)."""
+    rds = chrom.range_definitions
+    if len(rds) <= 2:                                   # ARGS mode: one range per contig -- nothing to amortise, no arrays to build
+        few = [range_descriptor(rd) for rd in rds if rd.mutation_settings.has_mutations]
+        return np.frombuffer(b"".join(bytes(r) for r in few), dtype=_ffi.RANGE_DTYPE) if few else np.zeros(0, dtype=_ffi.RANGE_DTYPE)
+    start, stop, sid, settings = _range_triples(chrom)
+    n = len(start)
+    if n == 0:
+        return np.zeros(0, dtype=_ffi.RANGE_DTYPE)
+    out = np.empty(n, dtype=_ffi.RANGE_DTYPE)           # (msim_build_ranges writes every byte of every entry, padding included)
+    if len(settings) > 8 or any(len(ms.mut_chances) > 8 for ms in settings):
+        return _plan_table_python(chrom)
+    descs = _settings_descs(settings)
+    rc = _ffi.load().msim_build_ranges(descs, len(settings), start.ctypes.data, stop.ctypes.data, sid.ctypes.data, n, out.ctypes.data)
+    if rc != _ffi.OK:
+        raise _ffi.MsimError(f"msim_build_ranges failed ({rc})")
+    k = out["k"]
+    big = (((stop - start) + 1) >= (1 << 53)) | (k >= (1 << 33)) | (k < 0)
+    if big.any():                                                        # (outside the integer setsize formula's domain)
+        rds = [rd for rd in chrom.range_definitions if rd.mutation_settings.has_mutations]
+        for i in np.flatnonzero(big).tolist():
+            r = range_descriptor(rds[i])
+            out["k"][i], out["setsize"][i] = r.k, r.setsize
+    return out
+
+
+def _plan_table_python(chrom) -> np.ndarray:
+    """The same table by numpy array operations (kept as the cross-check of ``msim_build_ranges`` and for contigs with more
+    than 8 distinct settings objects)."""
     rds = [rd for rd in chrom.range_definitions if rd.mutation_settings.has_mutations]
     n = len(rds)
     out = np.zeros(n, dtype=_ffi.RANGE_DTYPE)

@@ -236,3 +236,59 @@ def test_plan_table_equals_plan_descriptors(tmp_path):
         masked["_pad"] = 0
         assert masked.tobytes() == raw
     assert sum(len(mm.plan_descriptors(c)) for c in sim.chromosomes) > 300
+
+
+def test_native_range_tables_equal_python_on_a_million_random_ranges():
+    """``msim_build_ranges`` (C: the reference's float expressions with the same IEEE operations) against
+    ``mutator.range_descriptor`` (the Python expressions themselves): one million random ranges over random settings -- rates
+    from 1e-9 to 0.5 incl. sums that round differently in other orders, chances that do not sum to one, spans from 1 to 2^31 --
+    k, setsize and every cdf threshold bit for bit; then the array formulation (``_plan_table_python``) on the same ranges."""
+    import numpy as np
+    from mutation_simulator_amd import _ffi, mutator as mm
+    from mutation_simulator_amd.mut_types import MutType
+    rs = np.random.RandomState(11)
+    types = list(MutType)
+
+    class MS:
+        has_mutations = True
+
+    class RD:
+        pass
+
+    class Chrom:
+        pass
+    sets = []
+    for _ in range(8):
+        ms = MS()
+        picked = [types[i] for i in rs.permutation(len(types))[:int(rs.randint(1, 8))]]
+        ms.mut_rates = {t: float(10 ** rs.uniform(-9, -0.7)) * float(rs.rand() < 0.9) for t in picked}
+        tot = sum(ms.mut_rates.values()) or 1.0
+        ms.mut_chances = {t: r / tot if rs.rand() < 0.7 else float(rs.rand()) for t, r in ms.mut_rates.items()}
+        if not any(ms.mut_chances.values()):
+            ms.mut_chances[picked[0]] = 1.0
+        ms.mut_lengs = {"min": {t: int(rs.randint(1, 60)) for t in picked}, "max": {t: int(rs.randint(60, 10_000)) for t in picked}}
+        sets.append(ms)
+    n = 1_000_000
+    span = np.where(rs.rand(n) < 0.5, rs.randint(1, 5_000, n), (2.0 ** rs.uniform(0, 31, n)).astype(np.int64))
+    start = rs.randint(0, 1 << 30, n).astype(np.int64)
+    sid = rs.randint(0, len(sets), n)
+    chrom = Chrom()
+    chrom.range_definitions = []
+    for a, w, q in zip(start.tolist(), span.tolist(), sid.tolist()):
+        rd = RD()
+        rd.start, rd.stop, rd.mutation_settings = a, a + w - 1, sets[q]
+        chrom.range_definitions.append(rd)
+    got = mm.plan_table(chrom)
+    assert got.shape[0] == n
+    alt = mm._plan_table_python(chrom)
+    g2, a2 = got.copy(), alt.copy()
+    g2["_pad"] = 0
+    a2["_pad"] = 0
+    assert g2.tobytes() == a2.tobytes()
+    for i in rs.randint(0, n, 20_000).tolist() + list(range(2000)):        # the Python expressions themselves, range by range
+        r = mm.range_descriptor(chrom.range_definitions[i])
+        row = got[i]
+        assert (row["start"], row["stop"], row["k"], row["setsize"], row["n_types"]) == (r.start, r.stop, r.k, r.setsize, r.n_types)
+        assert row["cdf_thr"].tolist() == list(r.cdf_thr) and row["types"].tolist() == list(r.types)
+        assert row["min_len"].tolist() == list(r.min_len) and row["max_len"].tolist() == list(r.max_len)
+
