@@ -388,13 +388,22 @@ def _snp_only_params():
     return p
 
 
+LIVE_PMC = [False]            # set by main(): the headline's roofline.traffic is measured in child rocprofv3 passes
+
+
 def roofline_of(st, workload, steps):
     launches = max(st["apply_launches"], 1)
     alg_bytes = st["bytes_in"] + st["bytes_out"] + 16 * st["records"]
     k_ms = st["apply_kernel_ms"]
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic, source = None, None   # HBM bytes per launch: NOT measured in this run -- read from the committed rocprofv3 --pmc passes
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    traffic, source = None, None
+    live = live_traffic(workload, WORKLOADS[workload]["kernel"]) if LIVE_PMC[0] else None
+    if live is not None:
+        traffic = live["traffic"]
+        source = ("measured during this run: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of "
+                  f"`bench.py --workload {workload} --steps 1`, per launch of the kernel; FETCH_SIZE x 2 (gfx950) = {live['fetch_bytes_x2']} "
+                  f"+ WRITE_SIZE {live['write_bytes']} bytes")
+    for name in (() if live is not None else ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
         tf = ROOT / "profiles" / name
         if tf.exists():
             try:
@@ -407,6 +416,45 @@ def roofline_of(st, workload, steps):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
             "kernel": WORKLOADS[workload]["kernel"], "algorithmic_bytes_per_launch": alg_bytes // launches,
             "avg_launch_ms": round(k_ms / launches, 4), "launches": launches}
+
+
+def live_traffic(workload, kernel):
+    """HBM bytes per launch of the rewrite kernel, measured NOW: two child runs of this file under `rocprofv3 --pmc` (FETCH_SIZE
+    and WRITE_SIZE in passes of their own, never with a trace domain -- MI355X_MICROARCH.md, HBM section), one step each of the
+    same workload; FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of a wide coalesced stream at 64 bytes).  None when
+    rocprofv3 is not there or a pass fails (the line then says where the number comes from instead)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None or os.environ.get("MSIM_BENCH_NO_PMC"):
+        return None
+    per = {}
+    td = tempfile.mkdtemp(prefix="msim_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(td, ctr)
+            env = dict(os.environ, TMPDIR="/tmp", MSIM_BENCH_NO_PMC="1")
+            cmd = [prof, "--pmc", ctr, "-d", out, "-o", "p", "--", sys.executable, str(ROOT / "bench.py"), "--workload", workload,
+                   "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None
+            c = sqlite3.connect(dbs[0])
+            row = c.execute("select count(*), sum(value) from counters_collection where counter_name = ? and kernel_name like ?",
+                            (ctr, f"%{kernel.split('::')[-1].split('<')[0]}%")).fetchone()
+            c.close()
+            if not row or not row[0]:
+                return None
+            per[ctr] = row[1] / row[0] * 1024.0                # KB per dispatch -> bytes
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return {"traffic": int(2.0 * per["FETCH_SIZE"] + per["WRITE_SIZE"]), "fetch_bytes_x2": int(2.0 * per["FETCH_SIZE"]),
+            "write_bytes": int(per["WRITE_SIZE"])}
 
 
 def step_roofline(st, dt):
@@ -544,6 +592,7 @@ def main():
 
     dt, st = measure(a.workload, a.steps, a.warmup)
     line = None
+    LIVE_PMC[0] = world == 1 and not a.no_secondary and not os.environ.get("MSIM_BENCH_NO_PMC")
     if rank == 0:
         total = sum(lengths) * (1 if strong else world)      # weak: every rank mutated a whole genome
         W = WORKLOADS[a.workload]
@@ -567,6 +616,7 @@ def main():
         }
         if world == 1:
             line["step_roofline"] = step_roofline(st, dt)
+    LIVE_PMC[0] = False                                 # (the secondary workloads: profiles/r04_traffic.json)
     gather_jobs = []                                    # (workload, its dict in the line): measured in the gather phase
 
     def sharded_numbers(dt_sharded, workload=None):

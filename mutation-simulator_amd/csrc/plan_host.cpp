@@ -157,6 +157,19 @@ inline uint64_t randbelow(HostMT &g, uint64_t n) {      // n < 2^32 on this path
     while (r >= n) r = g.next() >> sh;
     return r;
 }
+// getrandbits(k), 32 < k <= 64 (CPython _randommodule.c: the low word first, the LAST word shifted down to the bits that are
+// left) and _randbelow over it: ranges of 2^32 positions and more
+inline uint64_t getrandbits_wide(HostMT &g, int k) {
+    const uint64_t lo = g.next();
+    const uint64_t hi = g.next() >> (64 - k);
+    return lo | (hi << 32);
+}
+inline uint64_t randbelow_wide(HostMT &g, uint64_t n) { // 2^32 <= n < 2^64
+    const int k = bit_length64(n);
+    uint64_t r = getrandbits_wide(g, k);
+    while (r >= n) r = getrandbits_wide(g, k);
+    return r;
+}
 inline int64_t randint(HostMT &g, int64_t a, int64_t b) { return a + (int64_t)randbelow(g, (uint64_t)(b - a + 1)); }
 
 // sample(range(n), k) as a SORTED list of the selected values.  Only the set matters downstream
@@ -167,9 +180,27 @@ int sample_sorted(Ctx *c, HostMT &g, int64_t n, int64_t k, int64_t setsize, std:
     if (k < 0 || k > n)
         return fail(c, MSIM_ERR_VALUE, "Sample larger than population or is negative");
     if (k == 0) return MSIM_OK;
-    if ((uint64_t)n >= (1ull << 32))
-        return fail(c, MSIM_ERR_UNSUPPORTED, "sampling range of 2^32 or more positions (multi-word getrandbits)");
     out.reserve((size_t)k);
+    if ((uint64_t)n >= (1ull << 32)) {
+        // 2^32 positions and more (no contig of this build is that long -- records hold 32-bit positions -- but the host sampler
+        // is also the IT pass's breakpoint sampler, msim_sample_min_distance): CPython's set path over two-word getrandbits.
+        // n > setsize always here (setsize <= 21 + 4^ceil(log4(3 k)) with k < 2^31 allocatable entries).
+        if (n <= setsize) return fail(c, MSIM_ERR_UNSUPPORTED, "pool-path sample over 2^32 or more positions");
+        std::vector<uint64_t> seen, fresh, merged;
+        int64_t need = k;
+        while (need > 0) {
+            fresh.clear();
+            for (int64_t i = 0; i < need; i++) fresh.push_back(randbelow_wide(g, (uint64_t)n));   // each consumed whatever it is
+            std::sort(fresh.begin(), fresh.end());
+            fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+            merged.clear();
+            std::set_union(seen.begin(), seen.end(), fresh.begin(), fresh.end(), std::back_inserter(merged));
+            need = k - (int64_t)merged.size();
+            seen.swap(merged);
+        }
+        for (uint64_t v : seen) out.push_back((int64_t)v);
+        return MSIM_OK;
+    }
     if (n <= setsize) {                                 // pool path: partial Fisher-Yates
         std::vector<int64_t> pool((size_t)n);
         for (int64_t i = 0; i < n; i++) pool[(size_t)i] = i;

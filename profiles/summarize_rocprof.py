@@ -36,5 +36,29 @@ def pmc(db):
         print(f"{short:50s} {ctr:12s} dispatches={n:4d} sum={total:16.1f} total_ns={dur}")
 
 
+def text(db, wall_line=""):
+    """Kernel stats of a CLI run plus achieved GB/s of the text kernels: bytes in + out per kernel over
+    its total duration.  Sizes come from the run's own output line ("CLI wall ... outputs: out_ms.fa N MB, out_ms.vcf M MB")
+    and the input size (--mb): k_gather reads the FASTA body text and writes the bases, k_frame reads the mutated bases and
+    writes the wrapped body, k_vcf_lines<true> reads 16-byte records + REF/ALT sources (~ the text it writes) and writes the
+    VCF text, k_vcf_lines<false> (line lengths) reads the same sources without writing text."""
+    import re
+    stats(db)
+    m = re.search(r"out_ms\.fa (\d+) MB, out_ms\.vcf (\d+) MB", wall_line)
+    if not m:
+        return
+    fa_mb, vcf_mb = float(m.group(1)), float(m.group(2))
+    bases_mb = fa_mb * 60.0 / 61.0
+    c = sqlite3.connect(db)
+    print("\n# text kernels: bytes moved (in + out, MB, whole run) / total duration -> achieved GB/s (HBM peak 8000)")
+    for pat, mb, what in (("%k_gather%", fa_mb + bases_mb, "file text in, bases out"),
+                          ("%k_frame%", bases_mb + fa_mb, "mutated bases in, wrapped text out"),
+                          ("%k_vcf_lines<true>%", 2.0 * vcf_mb, "records + REF/ALT sources in (~ text size), text out"),
+                          ("%k_vcf_lines<false>%", vcf_mb, "records + REF/ALT sources in (line lengths only)")):
+        row = c.execute("select sum(total_calls), sum(total_duration) from top_kernels where name like ?", (pat,)).fetchone()
+        if row and row[1]:
+            print(f"{pat.strip('%'):24s} calls={int(row[0]):4d} total_us={row[1]:10.1f} {mb:9.1f} MB -> {mb * 1e6 / (row[1] * 1e-6) / 1e9:8.1f} GB/s  ({what})")
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "text": text}[sys.argv[1]](*sys.argv[2:])

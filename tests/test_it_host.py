@@ -204,6 +204,31 @@ def test_native_breakpoint_sampler_equals_cpython(start, stop, k, d, monkeypatch
     assert random.getstate() == before               # nothing was drawn
 
 
+@pytest.mark.parametrize("start,stop,k,d", [(1, (1 << 32) + 12_345, 700, 1), (5, 3 * (1 << 33) + 7, 4_000, 3),
+                                            ((1 << 40), (1 << 40) + (1 << 35), 1_000, 2)])
+def test_native_sampler_over_ranges_of_2_to_the_32_and_more(start, stop, k, d):
+    """random.sample over range(n) with n >= 2**32 takes CPython's multi-word getrandbits (low word first, the last
+    word shifted).  libmsim's host sampler -- msim_sample_min_distance, the IT pass's breakpoint sampler -- does the same:
+    positions and the generator's position afterwards equal CPython's own ``sample_with_minimum_distance``."""
+    import numpy as np
+    from mutation_simulator_amd import _ffi, mutator as mm
+
+    def reference(start, stop, k, d):                      # util.py:93-109
+        sampl = random.sample(range(start, stop - (k - 1) * d), k)
+        return [s + d * r for r, s in enumerate(sorted(sampl))]
+    random.seed(77 + k)
+    want = reference(start, stop, k, d)
+    after = [random.getrandbits(32) for _ in range(4)]
+    random.seed(77 + k)
+    eng = _ffi.Engine(device=-1)
+    mm.export_python_streams(eng)
+    got = eng.sample_min_distance(start, stop, k, d, mm.sample_setsize(k))
+    mm.import_python_streams(eng)
+    eng.close()
+    assert np.asarray(got).tolist() == want
+    assert after == [random.getrandbits(32) for _ in range(4)]
+
+
 def test_partner_walk_equals_the_references_list_walk():
     """``_assign_partners`` keeps the reference's semantics -- a walk over the very list it removes from
     (it_mutator.py:59-71) -- without its quadratic ``list.remove``: same pairs in the same dict order, same one-per-pair list
