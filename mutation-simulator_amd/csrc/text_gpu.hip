@@ -4,7 +4,8 @@
 // The record table and the mutated stream live in HBM; for an SV mix the VCF text is as large as the
 // genome, so rendering it on the host means one core pushing gigabytes through a
 // byte-wise formatter.  Here:
-//   VCF    k_vcf_lines<false> : one wave per record -> length of its line (0 = suppressed, REF == ALT)
+//   VCF    k_vcf_lines<false> : a wave per 64 records (SNP lines one lane each, every other record by the whole wave)
+//                               -> length of every line (0 = suppressed, REF == ALT)
 //          k_len_* / k_scan_u64: exclusive u64 scan -> byte offset of every line
 //          k_vcf_lines<true>  : same walk, writing: lane 0 emits the scalar fields, all 64 lanes copy
 //                               REF / ALT (raw, ambiguity-converted, or reverse-complemented) coalesced
@@ -120,16 +121,54 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
     for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
     __syncthreads();
-    const uint32_t i = blockIdx.x * TX_WAVES + (threadIdx.x >> 6);
-    if (i >= n_rec) return;
-    const msim_record r = recs[i];
+    // A wave takes 64 consecutive records.  SNP lines are ~25 bytes: one LANE each formats its own (a wave per SNP line -- round 1 --
+    // spent ~15 instructions of 64 lanes on 25 bytes: 135 GB/s, 1.7 % of HBM, and a twelfth of a CLI run with -sn 0.01); every other
+    // record (REF / ALT of up to thousands of bases) is taken by the whole wave, one after the other, its fields broadcast.
+    const uint32_t lane_id = threadIdx.x & 63;
+    const uint32_t base_rec = (blockIdx.x * TX_WAVES + (threadIdx.x >> 6)) * 64;
+    if (base_rec >= n_rec) return;
+    const uint32_t mine = base_rec + lane_id;
+    const bool valid = mine < n_rec;
+    msim_record my{};
+    if (valid) my = recs[mine];
+    if (valid && my.type == MSIM_SN) {                                   // mutator.py:334-341
+        const uint8_t x = in[my.pos];
+        const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];          // ti / tv column of conv(x)
+        const unsigned long long start = (unsigned long long)my.pos + 1;
+        const int nd = ndigits(start);
+        const uint32_t len = ref == alt ? 0u : name_len + (uint32_t)nd + 19u;               // vcf_writer.py:123: REF == ALT suppressed
+        if (!WRITE) len_out[mine] = len;
+        else if (len) {
+            char *p = text + off[mine];
+            for (uint32_t q = 0; q < name_len; q++) p[q] = (char)name[q];
+            p += name_len;
+            *p++ = '\t';
+            unsigned long long v = start;
+            for (int q = nd - 1; q >= 0; q--) { p[q] = (char)('0' + (int)(v % 10)); v /= 10; }
+            p += nd;
+            const char tail[18] = {'\t', '.', '\t', (char)ref, '\t', (char)alt, '\t', '.', '\t', '.', '\t', '.', '\t', 'G', 'T', '\t', '1', '\n'};
+#pragma unroll
+            for (int q = 0; q < 18; q++) p[q] = tail[q];
+        }
+    }
+    unsigned long long todo = __ballot(valid && my.type != MSIM_SN);
+    while (todo) {
+    const int src_lane = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const uint32_t i = base_rec + (uint32_t)src_lane;
+    msim_record r;
+    r.pos = (uint32_t)__shfl((int)my.pos, src_lane, 64);
+    r.stop = (uint32_t)__shfl((int)my.stop, src_lane, 64);
+    r.extra = (uint32_t)__shfl((int)my.extra, src_lane, 64);
+    const uint32_t ta = (uint32_t)__shfl((int)((uint32_t)my.type | ((uint32_t)my.aux << 8)), src_lane, 64);
+    r.type = (uint8_t)ta; r.aux = (uint8_t)(ta >> 8); r.rsv = 0;
     WSink<WRITE> s;
-    s.lane = threadIdx.x & 63;
+    s.lane = lane_id;
     s.n = 0;
     s.p = WRITE ? text + off[i] : nullptr;
     const unsigned long long pos = r.pos, stop = r.stop;
     switch (r.type) {
-        case MSIM_SN: {                                                  // mutator.py:334-341
+        case MSIM_SN: {                                                  // (taken by its own lane above)
             const uint8_t x = in[pos];
             const uint8_t ref = lut[768 + x];
             const uint8_t alt = lut[(uint32_t)r.aux * 256 + x];          // ti / tv column of conv(x)
@@ -208,6 +247,7 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         default: break;
     }
     if (!WRITE && s.lane == 0) len_out[i] = (uint32_t)s.n;
+    }
 }
 
 // ---- exclusive u64 scan of u32 lengths (2048 per workgroup)
@@ -289,6 +329,26 @@ __global__ __launch_bounds__(TX_THREADS) void k_frame(const uint8_t *__restrict_
     const uint32_t stride = bpl + 1;
     unsigned long long line = t0 / stride;
     uint32_t col = (uint32_t)(t0 % stride);
+    if (bpl >= 16 && t0 + 16 <= text_len) {
+        // Lines of 16 bases or more: at most ONE newline falls into these 16 bytes, at k = bpl - col.  Bytes before it are source
+        // bytes s0 .. (16 at the output's source offset), bytes behind it the same stream one byte later in the output: two
+        // 16-byte loads and a mask (round 1's byte-by-byte walk ran at 2.0 TB/s: 16 byte loads per thread).
+        const unsigned long long s0 = t0 - line;           // source index of output byte t0 (of the byte after a leading '\n')
+        const uint32_t k = bpl - col;                      // col <= bpl
+        unsigned __int128 a, out;
+        __builtin_memcpy(&a, seq + s0, 16);
+        if (k >= 16) out = a;
+        else {
+            unsigned __int128 cshift = 0;
+            if (s0) __builtin_memcpy(&cshift, seq + s0 - 1, 16);      // cshift[q] = seq[s0 + q - 1]
+            const unsigned __int128 ones = ~(unsigned __int128)0;
+            const unsigned __int128 low = k ? ones >> (128 - 8 * k) : 0;              // bytes [0, k)
+            const unsigned __int128 upto = k == 15 ? ones : ones >> (128 - 8 * (k + 1));   // bytes [0, k]
+            out = (a & low) | ((unsigned __int128)'\n' << (8 * k)) | (cshift & ~upto);
+        }
+        __builtin_memcpy(text + t0, &out, 16);
+        return;
+    }
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -351,6 +411,34 @@ __global__ __launch_bounds__(TX_THREADS) void k_gather(const uint8_t *__restrict
     if (i0 >= n_bases) return;
     unsigned long long line = i0 / lenc;
     uint32_t col = (uint32_t)(i0 % lenc);
+    if (lenc >= 16 && i0 + 16 <= n_bases) {
+        // Lines of 16 bases or more: these 16 bases cross at most one line terminator (lenb - lenc bytes), after kk = lenc - col
+        // of them: the bases before it sit at the text offset, the ones behind it lenb - lenc bytes further -- two 16-byte
+        // loads and a mask, upper-casing on all 16 bytes at once.
+        const unsigned long long b0 = line * lenb + col;
+        const uint32_t kk = lenc - col;
+        unsigned __int128 a, x;
+        __builtin_memcpy(&a, body + b0, 16);
+        if (kk >= 16) x = a;
+        else {
+            unsigned __int128 b;
+            __builtin_memcpy(&b, body + b0 + (lenb - lenc), 16);      // (the body's buffer carries 64 bytes of slack behind the text)
+            const unsigned __int128 low = (~(unsigned __int128)0) >> (128 - 8 * kk);   // kk >= 1
+            x = (a & low) | (b & ~low);
+        }
+        // a-z -> A-Z per byte: bit 7 of (c + 0x1f) says c >= 'a', of (c + 0x05) c > 'z' (7-bit part: no carry into a neighbour)
+        unsigned long long h[2] = {(unsigned long long)x, (unsigned long long)(x >> 64)};
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const unsigned long long v = h[q], lo7 = v & 0x7f7f7f7f7f7f7f7full;
+            const unsigned long long is_lower = (lo7 + 0x1f1f1f1f1f1f1f1full) & ~(lo7 + 0x0505050505050505ull) & ~v & 0x8080808080808080ull;
+            h[q] = v - (is_lower >> 2);
+        }
+        uint4 o;
+        o.x = (uint32_t)h[0]; o.y = (uint32_t)(h[0] >> 32); o.z = (uint32_t)h[1]; o.w = (uint32_t)(h[1] >> 32);
+        *reinterpret_cast<uint4 *>(dst + i0) = o;
+        return;
+    }
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < 16; q++) {
@@ -394,7 +482,7 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes) 
     MSIM_HIP(c, hipMemcpyAsync(d_name, seq_name, name_len, hipMemcpyHostToDevice, st));
     const uint8_t *in = g.d_in + PAD;
     const uint8_t *pool = g.d_pool ? g.d_pool + PAD : nullptr;
-    const dim3 grid((n + TX_WAVES - 1) / TX_WAVES);
+    const dim3 grid((n + 64 * TX_WAVES - 1) / (64 * TX_WAVES));           // a wave takes 64 consecutive records
     hipLaunchKernelGGL(k_vcf_lines<false>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
                        d_name, (uint32_t)name_len, ctx_lut(c), d_len, (const unsigned long long *)nullptr, (char *)nullptr);
     hipLaunchKernelGGL(k_len_reduce, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums);
