@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 4
+#define MSIM_ABI_VERSION 5
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -40,6 +40,7 @@ extern "C" {
                                      A,G,T,C,N -- mutator.py:449-455; see msim_key_error()         */
 #define MSIM_ERR_UNSUPPORTED  5   /* valid for the reference, outside this build (contigs >= 4 GiB)  */
 #define MSIM_ERR_NOMEM        6
+#define MSIM_ERR_IO           7   /* a write queued by the *_file entry points failed (msim_last_error)   */
 
 /* ---- mutation types: numerically identical to mut_types.py:6-12 --------------------------------- */
 #define MSIM_SN  1
@@ -252,6 +253,18 @@ int msim_render_vcf_device(msim_ctx *ctx, int contig, const char *seq_name, char
  * Same two-call protocol.                                                                             */
 int msim_fetch_sequence_framed(msim_ctx *ctx, int contig, uint32_t bpl, uint8_t *out, uint64_t cap,
                                uint64_t *needed);
+/* The same two texts written into an open output file, off the calling thread: bytes [offset, offset + *written) of `fd`
+ * (a regular file; libmsim keeps its own duplicate of the descriptor) receive what FastaWriter / VcfWriter would write()
+ * there (fasta_writer.py:40-58, vcf_writer.py:118-126).  The call renders on the device, reports the size and QUEUES the
+ * transfer on the output channel of that file kind (file_io.hip: a thread, a HIP stream and a pinned ring per channel --
+ * device -> ring -> pwrite in 8 MiB pieces); it returns while the bytes are on their way, so that the caller's next contig
+ * (ingest, PLAN, APPLY) overlaps them.  msim_file_wait (also msim_sync, msim_destroy) returns once everything queued is in
+ * its file -- call it before the files are read, truncated or closed for good -- and reports the first failure of a queued
+ * transfer (MSIM_ERR_IO: no space ...; MSIM_ERR_HIP).  MSIM_ERR_UNSUPPORTED: `fd` is no regular file (a pipe ...): use the
+ * buffer calls above and write().  At most two transfers per channel are in flight: a third call waits for the oldest.     */
+int msim_render_vcf_device_file(msim_ctx *ctx, int contig, const char *seq_name, int fd, uint64_t offset, uint64_t *written);
+int msim_fetch_sequence_framed_file(msim_ctx *ctx, int contig, uint32_t bpl, int fd, uint64_t offset, uint64_t *written);
+int msim_file_wait(msim_ctx *ctx);
 /* Ingest one FASTA record straight from file text: `body` = the bytes after the header line, n_bases bases
  * in lines of `lenc` bases every `lenb` bytes (the .fai columns; uniform line width is what pyfaidx
  * requires, util.py:77-91).  Line terminators are skipped and a-z upper-cased on the device

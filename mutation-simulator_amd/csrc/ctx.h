@@ -61,6 +61,7 @@ struct GpuPlan;
 struct FastPlan;                      // plan_fast.hip: the counter-based PLAN engine's streams + scratch
 struct Comm;                          // comm.cpp: RCCL communicator + receive buffers of the gather
 struct Batch;                         // msim_api.hip: state of msim_batch_run
+struct FileIo;                        // file_io.hip: the output channels (thread + stream + pinned ring per output file)
 
 struct Ctx {
     int device = 0;
@@ -76,6 +77,7 @@ struct Ctx {
     GpuPlan *gpu = nullptr;           // device representation of the streams + sampler scratch
     Comm *comm = nullptr;             // multi-GPU: set by msim_comm_init
     Batch *batch = nullptr;           // last batch of small contigs (host buffers)
+    FileIo *file_io = nullptr;        // file_io.hip (made on first use)
     msim_params params{};
     bool have_params = false;
     std::vector<Contig> contigs;
@@ -255,12 +257,20 @@ int fast_plan_collect(Ctx *c);
 int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq, HostPlan &out);
 
 // text_gpu.hip
-int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes);
-int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes);
+// (buf / cap: render there instead of into the context's text buffer -- an output channel's; text_len is then left alone)
+int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, uint8_t **buf = nullptr, size_t *cap = nullptr);
+int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes, uint8_t **buf = nullptr, size_t *cap = nullptr);
 int splice_device(Ctx *c, const Contig &a, const Contig *b, const uint32_t *seg_out, const uint32_t *seg_src, uint32_t n_seg,
                   Contig &dst);
 int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,
                         uint32_t lenb, uint8_t *d_dst);
+
+// file_io.hip: device text -> output files on the channels' own threads (0 the Fasta, 1 the VCF)
+int file_check(Ctx *c, int fd);
+int file_text_buffer(Ctx *c, int ch, int *slot, uint8_t ***buf, size_t **cap);
+int file_enqueue(Ctx *c, int ch, int slot, uint64_t n, int fd, uint64_t offset);
+int file_wait(Ctx *c);
+void file_io_destroy(Ctx *c);
 
 // render.cpp
 uint64_t render_vcf_unchecked(const msim_record *recs, uint64_t n_records, const uint8_t *insert_pool, const uint8_t *bases,

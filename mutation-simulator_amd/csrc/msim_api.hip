@@ -269,6 +269,7 @@ void msim_destroy(msim_ctx *p) {
     double ph[6] = {0, 0, 0, 0, 0, 0};
     auto lap = [&](int i) { const auto n = std::chrono::steady_clock::now(); ph[i] += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
     (void)hipSetDevice(c->device);
+    file_io_destroy(c);                                    // (finishes what is queued for the output files first)
     (void)hipStreamSynchronize(c->stream);
     (void)hipStreamSynchronize(c->emit_stream);
     lap(0);
@@ -315,7 +316,7 @@ int msim_sync(msim_ctx *p) {
     if (rc) return rc;
     for (auto &g : c->contigs)                             // deferred KeyError of an asynchronous APPLY
         if (g.key_error && !g.key_reported) return key_error_of(c, g);
-    return MSIM_OK;
+    return file_wait(c);                                   // ... and what was queued for the output files is there
 }
 
 int msim_seed(msim_ctx *p, const uint32_t *py_key, int n_key, uint32_t np_seed) {
@@ -759,24 +760,48 @@ static int text_copy_out(Ctx *c, uint8_t *out, uint64_t cap, uint64_t *needed) {
     return MSIM_OK;
 }
 
+// render (unless the preceding size call left the text in d_text)
+static int vcf_text_ready(Ctx *c, int contig, const char *seq_name, bool reuse) {
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    if (reuse && c->text_kind == 1 && c->text_contig == contig) return MSIM_OK;
+    int rc = drain(c);                                                   // record aux bytes come from the emit stream
+    if (rc) return rc;
+    c->text_kind = 0;
+    uint64_t bytes = 0;
+    rc = vcf_render_device(c, *g, seq_name, &bytes);
+    if (rc) return rc;
+    c->text_kind = 1;
+    c->text_contig = contig;
+    return MSIM_OK;
+}
+
+static int framed_text_ready(Ctx *c, int contig, uint32_t bpl, bool reuse) {
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
+    if (reuse && c->text_kind == 2 && c->text_contig == contig && c->text_bpl == bpl) return MSIM_OK;
+    int rc = drain(c);
+    if (rc) return rc;
+    if (g->key_error) return key_error_of(c, *g);
+    c->text_kind = 0;
+    uint64_t bytes = 0;
+    rc = fasta_frame_device(c, *g, bpl, &bytes);
+    if (rc) return rc;
+    c->text_kind = 2;
+    c->text_contig = contig;
+    c->text_bpl = bpl;
+    return MSIM_OK;
+}
+
 int msim_render_vcf_device(msim_ctx *p, int contig, const char *seq_name, char *out, uint64_t cap, uint64_t *needed) {
     CTX_FLUSHED(c, p)
     if (!c || !seq_name || !needed) return MSIM_ERR_ARG;
     NEED_GPU(c);
-    Contig *g = get_contig(c, contig);
-    if (!g) return MSIM_ERR_ARG;
-    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
     TraceRange tr("msim text: VCF lines");
-    if (!(out && c->text_kind == 1 && c->text_contig == contig)) {      // not cached by a preceding size call
-        int rc = drain(c);                                               // record aux bytes come from the emit stream
-        if (rc) return rc;
-        c->text_kind = 0;
-        uint64_t bytes = 0;
-        rc = vcf_render_device(c, *g, seq_name, &bytes);
-        if (rc) return rc;
-        c->text_kind = 1;
-        c->text_contig = contig;
-    }
+    int rc = vcf_text_ready(c, contig, seq_name, out != nullptr);        // (a size call always renders)
+    if (rc) return rc;
     return text_copy_out(c, reinterpret_cast<uint8_t *>(out), cap, needed);
 }
 
@@ -784,23 +809,67 @@ int msim_fetch_sequence_framed(msim_ctx *p, int contig, uint32_t bpl, uint8_t *o
     CTX_FLUSHED(c, p)
     if (!c || !needed || bpl == 0) return MSIM_ERR_ARG;
     NEED_GPU(c);
+    TraceRange tr("msim text: framed FASTA");
+    int rc = framed_text_ready(c, contig, bpl, out != nullptr);
+    if (rc) return rc;
+    return text_copy_out(c, out, cap, needed);
+}
+
+// The two texts queued for an output file (file_io.hip).  Rendering runs on the context's stream into a buffer of the output
+// channel; the channel's thread copies and writes it while the caller goes on.
+int msim_render_vcf_device_file(msim_ctx *p, int contig, const char *seq_name, int fd, uint64_t offset, uint64_t *written) {
+    CTX_FLUSHED(c, p)
+    if (!c || !seq_name || !written || fd < 0) return MSIM_ERR_ARG;
+    NEED_GPU(c);
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    if (!g->planned) return fail(c, MSIM_ERR_ARG, "contig has not been planned");
+    TraceRange tr("msim text: VCF lines -> file");
+    int rc = file_check(c, fd);
+    if (rc) return rc;
+    rc = drain(c);                                                       // record aux bytes come from the emit stream
+    if (rc) return rc;
+    int slot;
+    uint8_t **buf;
+    size_t *cap;
+    rc = file_text_buffer(c, 1, &slot, &buf, &cap);
+    if (rc) return rc;
+    uint64_t bytes = 0;
+    rc = vcf_render_device(c, *g, seq_name, &bytes, buf, cap);
+    if (rc) return rc;
+    *written = bytes;
+    return file_enqueue(c, 1, slot, bytes, fd, offset);
+}
+
+int msim_fetch_sequence_framed_file(msim_ctx *p, int contig, uint32_t bpl, int fd, uint64_t offset, uint64_t *written) {
+    CTX_FLUSHED(c, p)
+    if (!c || !written || bpl == 0 || fd < 0) return MSIM_ERR_ARG;
+    NEED_GPU(c);
     Contig *g = get_contig(c, contig);
     if (!g) return MSIM_ERR_ARG;
     if (!g->applied) return fail(c, MSIM_ERR_ARG, "contig has not been applied");
-    TraceRange tr("msim text: framed FASTA");
-    if (!(out && c->text_kind == 2 && c->text_contig == contig && c->text_bpl == bpl)) {
-        int rc = drain(c);
-        if (rc) return rc;
-        if (g->key_error) return key_error_of(c, *g);
-        c->text_kind = 0;
-        uint64_t bytes = 0;
-        rc = fasta_frame_device(c, *g, bpl, &bytes);
-        if (rc) return rc;
-        c->text_kind = 2;
-        c->text_contig = contig;
-        c->text_bpl = bpl;
-    }
-    return text_copy_out(c, out, cap, needed);
+    TraceRange tr("msim text: framed FASTA -> file");
+    int rc = file_check(c, fd);
+    if (rc) return rc;
+    rc = drain(c);
+    if (rc) return rc;
+    if (g->key_error) return key_error_of(c, *g);
+    int slot;
+    uint8_t **buf;
+    size_t *cap;
+    rc = file_text_buffer(c, 0, &slot, &buf, &cap);
+    if (rc) return rc;
+    uint64_t bytes = 0;
+    rc = fasta_frame_device(c, *g, bpl, &bytes, buf, cap);
+    if (rc) return rc;
+    *written = bytes;
+    return file_enqueue(c, 0, slot, bytes, fd, offset);
+}
+
+int msim_file_wait(msim_ctx *p) {
+    Ctx *c = C(p);
+    if (!c) return MSIM_ERR_ARG;
+    return file_wait(c);
 }
 
 int msim_add_contig_text(msim_ctx *p, const uint8_t *body, uint64_t body_bytes, uint64_t n_bases, uint32_t lenc,

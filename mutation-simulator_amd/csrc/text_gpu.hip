@@ -36,13 +36,17 @@ __device__ __forceinline__ int ndigits(unsigned long long v) {
     return k;
 }
 
-// Wave-uniform sink: every lane carries the same offset n; small fields are written by the low lanes,
-// bulk copies by all 64.
+// Two sinks with one interface.  WSink: wave-uniform -- every lane carries the same offset n; small fields are written by
+// the low lanes, bulk copies by all 64 (4 bytes per lane while 256 are left).  LSink: one lane formats its own line
+// sequentially -- for records whose REF / ALT are a few bases (the reference's default SV lengths are 1..3, defaults.py:29-32).
 template <bool WRITE>
 struct WSink {
     char *p;
     unsigned long long n;
     uint32_t lane;
+    __device__ __forceinline__ uint32_t first() const { return lane; }
+    __device__ __forceinline__ uint32_t step() const { return 64; }
+    __device__ __forceinline__ bool any(bool d) const { return __ballot(d) != 0ull; }
     __device__ __forceinline__ void put(char c) {
         if (WRITE && lane == 0) p[n] = c;
         n++;
@@ -65,7 +69,24 @@ struct WSink {
     __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode,
                                          const uint8_t *lut) {
         if (WRITE) {
-            for (unsigned long long i = lane; i < len; i += 64) {
+            unsigned long long i = 0;
+            for (; i + 256 <= len; i += 256) {                           // unaligned dword per lane (gfx950 global accesses may be)
+                const unsigned long long k = i + 4ull * lane;
+                uint32_t w;
+                if (mode == 2) {
+                    uint32_t v;
+                    __builtin_memcpy(&v, src - k - 3, 4);
+                    w = (uint32_t)lut[1024 + (v >> 24)] | ((uint32_t)lut[1024 + ((v >> 16) & 255)] << 8) |
+                        ((uint32_t)lut[1024 + ((v >> 8) & 255)] << 16) | ((uint32_t)lut[1024 + (v & 255)] << 24);
+                } else {
+                    __builtin_memcpy(&w, src + k, 4);
+                    if (mode == 1)
+                        w = (uint32_t)lut[768 + (w & 255)] | ((uint32_t)lut[768 + ((w >> 8) & 255)] << 8) |
+                            ((uint32_t)lut[768 + ((w >> 16) & 255)] << 16) | ((uint32_t)lut[768 + (w >> 24)] << 24);
+                }
+                __builtin_memcpy(p + n + k, &w, 4);
+            }
+            for (i += lane; i < len; i += 64) {
                 uint8_t c;
                 if (mode == 0) c = src[i];
                 else if (mode == 1) c = lut[768 + src[i]];
@@ -78,15 +99,55 @@ struct WSink {
 };
 
 template <bool WRITE>
-__device__ __forceinline__ void line_head(WSink<WRITE> &s, const uint8_t *name, uint32_t name_len, unsigned long long start) {
+struct LSink {
+    char *p;
+    unsigned long long n;
+    __device__ __forceinline__ uint32_t first() const { return 0; }
+    __device__ __forceinline__ uint32_t step() const { return 1; }
+    __device__ __forceinline__ bool any(bool d) const { return d; }
+    __device__ __forceinline__ void put(char c) {
+        if (WRITE) p[n] = c;
+        n++;
+    }
+    template <int N>
+    __device__ __forceinline__ void lit(const char (&s)[N]) {
+        if (WRITE) {
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) p[n + i] = s[i];
+        }
+        n += N - 1;
+    }
+    __device__ __forceinline__ void num(unsigned long long v) {
+        const int k = ndigits(v);
+        if (WRITE)
+            for (int q = k - 1; q >= 0; q--) { p[n + q] = (char)('0' + (int)(v % 10)); v /= 10; }
+        n += (unsigned)k;
+    }
+    __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode,
+                                         const uint8_t *lut) {
+        if (WRITE) {
+            for (unsigned long long i = 0; i < len; i++) {
+                uint8_t c;
+                if (mode == 0) c = src[i];
+                else if (mode == 1) c = lut[768 + src[i]];
+                else c = lut[1024 + *(src - i)];
+                p[n + i] = (char)c;
+            }
+        }
+        n += len;
+    }
+};
+
+template <class S>
+__device__ __forceinline__ void line_head(S &s, const uint8_t *name, uint32_t name_len, unsigned long long start) {
     s.bulk(name, name_len, 0, nullptr);
     s.put('\t');
     s.num(start);
     s.lit("\t.\t");
 }
 // svtype: 0 none (SNP), 1 INS, 2 DEL, 3 INV, 4 DUP, 5 INS:ME, 6 DEL:ME
-template <bool WRITE>
-__device__ __forceinline__ void line_tail(WSink<WRITE> &s, int svtype, unsigned long long end, unsigned long long len) {
+template <class S>
+__device__ __forceinline__ void line_tail(S &s, int svtype, unsigned long long end, unsigned long long len) {
     s.lit("\t.\t.\t");
     if (svtype) {
         s.lit("SVTYPE=");
@@ -108,67 +169,14 @@ __device__ __forceinline__ void line_tail(WSink<WRITE> &s, int svtype, unsigned 
     s.lit("\tGT\t1\n");
 }
 
-template <bool WRITE>
-__global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
-                                                          const uint8_t *__restrict__ pool,
-                                                          const uint8_t *__restrict__ in, unsigned long long L,
-                                                          const uint8_t *__restrict__ name, uint32_t name_len,
-                                                          const uint8_t *__restrict__ lut_g,
-                                                          uint32_t *__restrict__ len_out,
-                                                          const unsigned long long *__restrict__ off,
-                                                          char *__restrict__ text) {
-    __shared__ uint8_t lut[1280];
-    for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
-        reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
-    __syncthreads();
-    // A wave takes 64 consecutive records.  SNP lines are ~25 bytes: one LANE each formats its own (a wave per SNP line -- round 1 --
-    // spent ~15 instructions of 64 lanes on 25 bytes: 135 GB/s, 1.7 % of HBM, and a twelfth of a CLI run with -sn 0.01); every other
-    // record (REF / ALT of up to thousands of bases) is taken by the whole wave, one after the other, its fields broadcast.
-    const uint32_t lane_id = threadIdx.x & 63;
-    const uint32_t base_rec = (blockIdx.x * TX_WAVES + (threadIdx.x >> 6)) * 64;
-    if (base_rec >= n_rec) return;
-    const uint32_t mine = base_rec + lane_id;
-    const bool valid = mine < n_rec;
-    msim_record my{};
-    if (valid) my = recs[mine];
-    if (valid && my.type == MSIM_SN) {                                   // mutator.py:334-341
-        const uint8_t x = in[my.pos];
-        const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];          // ti / tv column of conv(x)
-        const unsigned long long start = (unsigned long long)my.pos + 1;
-        const int nd = ndigits(start);
-        const uint32_t len = ref == alt ? 0u : name_len + (uint32_t)nd + 19u;               // vcf_writer.py:123: REF == ALT suppressed
-        if (!WRITE) len_out[mine] = len;
-        else if (len) {
-            char *p = text + off[mine];
-            for (uint32_t q = 0; q < name_len; q++) p[q] = (char)name[q];
-            p += name_len;
-            *p++ = '\t';
-            unsigned long long v = start;
-            for (int q = nd - 1; q >= 0; q--) { p[q] = (char)('0' + (int)(v % 10)); v /= 10; }
-            p += nd;
-            const char tail[18] = {'\t', '.', '\t', (char)ref, '\t', (char)alt, '\t', '.', '\t', '.', '\t', '.', '\t', 'G', 'T', '\t', '1', '\n'};
-#pragma unroll
-            for (int q = 0; q < 18; q++) p[q] = tail[q];
-        }
-    }
-    unsigned long long todo = __ballot(valid && my.type != MSIM_SN);
-    while (todo) {
-    const int src_lane = __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const uint32_t i = base_rec + (uint32_t)src_lane;
-    msim_record r;
-    r.pos = (uint32_t)__shfl((int)my.pos, src_lane, 64);
-    r.stop = (uint32_t)__shfl((int)my.stop, src_lane, 64);
-    r.extra = (uint32_t)__shfl((int)my.extra, src_lane, 64);
-    const uint32_t ta = (uint32_t)__shfl((int)((uint32_t)my.type | ((uint32_t)my.aux << 8)), src_lane, 64);
-    r.type = (uint8_t)ta; r.aux = (uint8_t)(ta >> 8); r.rsv = 0;
-    WSink<WRITE> s;
-    s.lane = lane_id;
-    s.n = 0;
-    s.p = WRITE ? text + off[i] : nullptr;
+// One record's line into a sink (mutator.py:334-421 builds the record, vcf_writer.py:118-126 the line).
+template <class S>
+__device__ __forceinline__ void format_record(S &s, const msim_record &r, const uint8_t *__restrict__ pool,
+                                              const uint8_t *__restrict__ in, unsigned long long L,
+                                              const uint8_t *__restrict__ name, uint32_t name_len, const uint8_t *lut) {
     const unsigned long long pos = r.pos, stop = r.stop;
     switch (r.type) {
-        case MSIM_SN: {                                                  // (taken by its own lane above)
+        case MSIM_SN: {                                                  // mutator.py:334-341
             const uint8_t x = in[pos];
             const uint8_t ref = lut[768 + x];
             const uint8_t alt = lut[(uint32_t)r.aux * 256 + x];          // ti / tv column of conv(x)
@@ -226,9 +234,9 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         case MSIM_IV: {                                                  // mutator.py:379-387
             const unsigned long long len = stop - pos + 1;
             bool diff = false;                                           // REF == ALT (palindrome): suppressed
-            for (unsigned long long q = s.lane; q < len; q += 64)
+            for (unsigned long long q = s.first(); q < len; q += s.step())
                 diff |= lut[768 + in[pos + q]] != lut[1024 + in[stop - q]];
-            if (__ballot(diff) == 0ull) break;
+            if (!s.any(diff)) break;
             line_head(s, name, name_len, pos + 1);
             s.bulk(in + pos, len, 1, lut);
             s.put('\t');
@@ -246,7 +254,85 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         }
         default: break;
     }
-    if (!WRITE && s.lane == 0) len_out[i] = (uint32_t)s.n;
+}
+
+constexpr uint32_t VCF_LANE_SPAN = 24;        // records spanning at most this many bases are formatted by one lane
+
+template <bool WRITE>
+__global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
+                                                          const uint8_t *__restrict__ pool,
+                                                          const uint8_t *__restrict__ in, unsigned long long L,
+                                                          const uint8_t *__restrict__ name, uint32_t name_len,
+                                                          const uint8_t *__restrict__ lut_g,
+                                                          uint32_t *__restrict__ len_out,
+                                                          const unsigned long long *__restrict__ off,
+                                                          char *__restrict__ text) {
+    __shared__ uint8_t lut[1280];
+    for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
+        reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
+    __syncthreads();
+    // A wave takes 64 consecutive records.  Short lines -- every SNP (~25 bytes) and every record of a few bases -- are formatted by
+    // one LANE each (a wave per such line -- round 1 -- spent ~15 instructions of 64 lanes on 25 bytes: 135 GB/s, 1.7 % of HBM, and
+    // a twelfth of a CLI run with -sn 0.01); records with a long REF / ALT are taken by the whole wave, one after the other, their
+    // fields broadcast.
+    const uint32_t lane_id = threadIdx.x & 63;
+    const uint32_t base_rec = (blockIdx.x * TX_WAVES + (threadIdx.x >> 6)) * 64;
+    if (base_rec >= n_rec) return;
+    const uint32_t mine = base_rec + lane_id;
+    const bool valid = mine < n_rec;
+    msim_record my{};
+    if (valid) my = recs[mine];
+    bool by_lane = false;
+    if (valid && my.type == MSIM_SN) {                                   // mutator.py:334-341
+        by_lane = true;
+        const uint8_t x = in[my.pos];
+        const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];          // ti / tv column of conv(x)
+        const unsigned long long start = (unsigned long long)my.pos + 1;
+        const int nd = ndigits(start);
+        const uint32_t len = ref == alt ? 0u : name_len + (uint32_t)nd + 19u;               // vcf_writer.py:123: REF == ALT suppressed
+        if (!WRITE) len_out[mine] = len;
+        else if (len) {
+            char *p = text + off[mine];
+            for (uint32_t q = 0; q < name_len; q++) p[q] = (char)name[q];
+            p += name_len;
+            *p++ = '\t';
+            unsigned long long v = start;
+            for (int q = nd - 1; q >= 0; q--) { p[q] = (char)('0' + (int)(v % 10)); v /= 10; }
+            p += nd;
+            const char tail[18] = {'\t', '.', '\t', (char)ref, '\t', (char)alt, '\t', '.', '\t', '.', '\t', '.', '\t', 'G', 'T', '\t', '1', '\n'};
+#pragma unroll
+            for (int q = 0; q < 18; q++) p[q] = tail[q];
+        }
+    } else if (valid) {
+        const unsigned long long hi = (unsigned long long)my.stop + 1 < L ? (unsigned long long)my.stop + 1 : L;
+        const unsigned long long span = my.type == MSIM_TLI ? (hi > my.extra ? hi - my.extra : 0)
+                                                            : (unsigned long long)my.stop - my.pos + 1;
+        if (span <= VCF_LANE_SPAN) {
+            by_lane = true;
+            LSink<WRITE> s;
+            s.n = 0;
+            s.p = WRITE ? text + off[mine] : nullptr;
+            format_record(s, my, pool, in, L, name, name_len, lut);
+            if (!WRITE) len_out[mine] = (uint32_t)s.n;
+        }
+    }
+    unsigned long long todo = __ballot(valid && !by_lane);
+    while (todo) {
+        const int src_lane = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t i = base_rec + (uint32_t)src_lane;
+        msim_record r;
+        r.pos = (uint32_t)__shfl((int)my.pos, src_lane, 64);
+        r.stop = (uint32_t)__shfl((int)my.stop, src_lane, 64);
+        r.extra = (uint32_t)__shfl((int)my.extra, src_lane, 64);
+        const uint32_t ta = (uint32_t)__shfl((int)((uint32_t)my.type | ((uint32_t)my.aux << 8)), src_lane, 64);
+        r.type = (uint8_t)ta; r.aux = (uint8_t)(ta >> 8); r.rsv = 0;
+        WSink<WRITE> s;
+        s.lane = lane_id;
+        s.n = 0;
+        s.p = WRITE ? text + off[i] : nullptr;
+        format_record(s, r, pool, in, L, name, name_len, lut);
+        if (!WRITE && s.lane == 0) len_out[i] = (uint32_t)s.n;
     }
 }
 
@@ -461,10 +547,12 @@ __global__ __launch_bounds__(TX_THREADS) void k_gather(const uint8_t *__restrict
 }  // namespace
 
 // VCF text of one contig into the context's text buffer; returns its size.
-int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes) {
+int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, uint8_t **buf, size_t *cap) {
     const uint32_t n = (uint32_t)g.n_rec;
     *bytes = 0;
-    if (!n) { c->text_len = 0; return MSIM_OK; }
+    const bool own = buf == nullptr;
+    if (own) { buf = &c->d_text; cap = &c->cap_text; }
+    if (!n) { if (own) c->text_len = 0; return MSIM_OK; }
     hipStream_t st = c->stream;
     const size_t name_len = strlen(seq_name);
     const uint32_t nb = (n + LS_BLOCK - 1) / LS_BLOCK;
@@ -491,30 +579,30 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes) 
     MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipStreamSynchronize(st));
     const uint64_t total = *c->h_mail;
-    rc = dev_reserve(c, (void **)&c->d_text, &c->cap_text, total + 64);
+    rc = dev_reserve(c, (void **)buf, cap, total + 64);
     if (rc) return rc;
     if (total) {
         hipLaunchKernelGGL(k_vcf_lines<true>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                           d_name, (uint32_t)name_len, ctx_lut(c), (uint32_t *)nullptr, d_off, reinterpret_cast<char *>(c->d_text));
+                           d_name, (uint32_t)name_len, ctx_lut(c), (uint32_t *)nullptr, d_off, reinterpret_cast<char *>(*buf));
         MSIM_HIP(c, hipGetLastError());
     }
-    c->text_len = total;
+    if (own) c->text_len = total;
     *bytes = total;
     return MSIM_OK;
 }
 
 // Mutated stream of one contig as FASTA body text into the context's text buffer.
-int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes) {
+int fasta_frame_device(Ctx *c, Contig &g, uint32_t bpl, uint64_t *bytes, uint8_t **buf, size_t *cap) {
     const uint64_t L = g.out_len;
     const uint64_t total = L + L / bpl;
     *bytes = total;
-    c->text_len = total;
+    if (!buf) { buf = &c->d_text; cap = &c->cap_text; c->text_len = total; }
     if (!total) return MSIM_OK;
-    int rc = dev_reserve(c, (void **)&c->d_text, &c->cap_text, total + 64);
+    int rc = dev_reserve(c, (void **)buf, cap, total + 64);
     if (rc) return rc;
     const uint64_t groups = (total + 15) / 16;
     hipLaunchKernelGGL(k_frame, dim3((uint32_t)((groups + TX_THREADS - 1) / TX_THREADS)), dim3(TX_THREADS), 0, c->stream,
-                       g.d_out, (unsigned long long)L, bpl, (unsigned long long)total, c->d_text);
+                       g.d_out, (unsigned long long)L, bpl, (unsigned long long)total, *buf);
     MSIM_HIP(c, hipGetLastError());
     return MSIM_OK;
 }

@@ -16,8 +16,13 @@ _INIT_ERRORS = (FileNotFoundError, ITNotEnoughAvailChromsError, RatesTooHighErro
                 MinimumLengthHigherThanMaximumError)
 
 
+STAGES: dict = {}          # wall seconds of the last run's stages (--bench-json: cli_s)
+
+
 def initialize(argv=None):
+    t0 = timer()
     args = get_args(argv)
+    STAGES["parse_args"] = timer() - t0
     if (args.gpus or 1) <= 1:
         try:                       # the GPU comes up while the FASTA is read and indexed (never in the parent of --gpus N)
             from ._ffi import warm_up_async
@@ -25,7 +30,9 @@ def initialize(argv=None):
         except Exception:  # noqa: BLE001  (no library: Mutator reports it properly)
             pass
     try:
+        t0 = timer()
         fasta = load_fasta(args.infile)
+        STAGES["load_index"] = timer() - t0
         if args.mode == "args":
             sim = SimulationSettings.from_args(args, fasta, args.ignore_warnings)
         elif args.mode == "it":
@@ -56,17 +63,22 @@ def main(argv=None):
         numpy.random.seed(args.seed)
     if sim.has_mutations:
         try:
+            t0 = timer()
             mutator = Mutator(args, fasta, sim)
+            t1 = timer()
             try:
                 mutator.mutate()
             finally:
+                t2 = timer()
                 mutator.close()            # (also on the reference's KeyError / ValueError: the files are complete as far as they go)
             fasta.close()
             if args.bench_json:
                 stats = dict(mutator.stats)
                 from . import mutator as _m
                 stats["replanned_contigs"] = _m.REPLANNED_CONTIGS     # device window overflows recovered on the host (expected: 0)
-                stats["cli_s"] = {"load_index_settings": round(loaded - start, 4), "mutate_and_write": round(timer() - loaded, 4)}
+                stats["cli_s"] = {"load_index_settings": round(loaded - start, 4), "mutate_and_write": round(timer() - loaded, 4),
+                                  "parse_args": round(STAGES.get("parse_args", 0.0), 4), "load_index": round(STAGES.get("load_index", 0.0), 4),
+                                  "open_writers": round(t1 - t0, 4), "mutate": round(t2 - t1, 4), "close": round(timer() - t2, 4)}
                 args.bench_json.write_text(json.dumps(stats, indent=1) + "\n")
         except (FastaWriterError, VcfWriterError, MsimError) as e:
             exit_with_error(e, args.no_color)

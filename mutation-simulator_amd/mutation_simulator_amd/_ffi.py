@@ -13,7 +13,7 @@ import numpy as np
 PKG_DIR = Path(__file__).resolve().parent
 LIB_CANDIDATES = [PKG_DIR.parent / "lib" / "libmsim.so"]
 
-OK, ERR_ARG, ERR_HIP, ERR_VALUE, ERR_KEY, ERR_UNSUPPORTED, ERR_NOMEM = range(7)
+OK, ERR_ARG, ERR_HIP, ERR_VALUE, ERR_KEY, ERR_UNSUPPORTED, ERR_NOMEM, ERR_IO = range(8)
 PLAN_AUTO, PLAN_HOST, PLAN_GPU = 0, 1, 2
 RNG_FAST = 4           # Engine flag: counter-based generator, NOT stream-compatible with the reference (msim.h: MSIM_RNG_FAST)
 
@@ -117,6 +117,9 @@ SYMBOLS = [
                                   C.c_uint64, _U64P]),
     ("msim_render_vcf_device", C.c_int, [_VP, C.c_int, C.c_char_p, _VP, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed", C.c_int, [_VP, C.c_int, C.c_uint32, _VP, C.c_uint64, _U64P]),
+    ("msim_render_vcf_device_file", C.c_int, [_VP, C.c_int, C.c_char_p, C.c_int, C.c_uint64, _U64P]),
+    ("msim_fetch_sequence_framed_file", C.c_int, [_VP, C.c_int, C.c_uint32, C.c_int, C.c_uint64, _U64P]),
+    ("msim_file_wait", C.c_int, [_VP]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
     ("msim_splice_contigs", C.c_int, [_VP, C.c_int, C.c_int, C.c_uint64, _U64P, _U64P, _IP]),
     ("msim_set_fast_key", C.c_int, [_VP, C.c_uint64]),
@@ -165,7 +168,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msim_abi_version() != 4:
+        if lib.msim_abi_version() != 5:
             raise MsimError("libmsim ABI version mismatch")
         _lib = lib
     return _lib
@@ -446,6 +449,25 @@ class Engine:
         need = C.c_uint64()
         self._check(self.lib.msim_fetch_sequence_framed(self.h, contig, bpl, _ptr(out), out.shape[0], C.byref(need)), contig)
         return need.value
+
+    def file_wait(self):
+        """Everything queued by the ``..._to_file`` calls is in its file (raises the first failure of a queued write)."""
+        self._check(self.lib.msim_file_wait(self.h))
+
+    def fetch_sequence_framed_to_file(self, contig: int, bpl: int, fd: int, offset: int) -> int:
+        """The framed body QUEUED for bytes [offset, offset + n) of the open regular file ``fd`` (libmsim's output channel
+        writes it while the caller goes on; ``file_wait`` / ``sync`` / ``close`` join); returns n.  ``MsimUnsupported``:
+        ``fd`` is no regular file -- use ``..._into`` + write()."""
+        n = C.c_uint64()
+        self._check(self.lib.msim_fetch_sequence_framed_file(self.h, contig, bpl, int(fd), int(offset), C.byref(n)), contig)
+        return n.value
+
+    def render_vcf_device_to_file(self, contig: int, seq_name: str, fd: int, offset: int) -> int:
+        """The contig's VCF record lines into bytes [offset, offset + n) of the open file ``fd``; returns n."""
+        n = C.c_uint64()
+        self._check(self.lib.msim_render_vcf_device_file(self.h, contig, seq_name.encode("utf-8", "replace"), int(fd),
+                                                         int(offset), C.byref(n)), contig)
+        return n.value
 
     def fetch_sequence_framed(self, contig: int, bpl: int, guess_len: int | None = None) -> np.ndarray:
         """The mutated contig as FASTA body text (newline after every ``bpl`` bases).  With ``guess_len`` (e.g. the

@@ -238,6 +238,19 @@ class FastaWriter:
         if region.nbytes:
             self._written = n_bases % self._bpl
 
+    def native_span(self):
+        """(fd, position) where the next framed record body goes, for a writer outside Python (libmsim's
+        ``msim_fetch_sequence_framed_file``); must start a line.  ``commit_native(pos, nbytes, n_bases)`` finishes it."""
+        if self._written != 0:
+            raise FastaWriterError("native_span needs to start at the beginning of a line")
+        self._out.flush()
+        return self._out.fileno(), self._out.tell()
+
+    def commit_native(self, pos: int, nbytes: int, n_bases: int):
+        self._out.seek(pos + nbytes)
+        if nbytes:
+            self._written = n_bases % self._bpl
+
     def write_records(self, text: np.ndarray, bpl: int, last_line_bases: int):
         """Append a run of complete records -- header lines and wrapped bodies, exactly the bytes ``write_header`` +
         ``write_framed`` would produce for each (``Engine.batch_run``).  ``bpl`` / ``last_line_bases``: line width of the

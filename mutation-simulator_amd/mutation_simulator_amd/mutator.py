@@ -298,6 +298,7 @@ BATCH_SPARSE_MAX_CANDIDATES = 8_000              #     a contig on its own costs
                                                  #     host planner ~40 ns per candidate (measured, -sn 0.01: 300 kb contigs 480 -> 1150 Mbases/s
                                                  #     in batches, 1 Mb contigs the same either way, 3 Mb contigs 1300 vs 960)
 BATCH_MAX_BASES = 256 << 20      # bases per batch
+NATIVE_FILE_EGRESS = os.environ.get("MSIM_PY_EGRESS") != "1"   # (diagnosis: 1 = map the output spans here, copy with one thread)
 BATCH_MAX_CONTIGS = 16384
 
 
@@ -312,9 +313,6 @@ class Mutator:
         self._vcf_writer = VcfWriter(args.outvcf)
         self._vcf_writer.write_header(args.infile.name, fasta, sim.assembly_name, sim.species_name,
                                       sim.sample_name)
-        total = int(getattr(fasta, "text_bytes", 0) or 0)   # the output is about as large as the input: allocate it meanwhile
-        if int(getattr(args, "gpus", 1) or 1) <= 1 and total > (64 << 20):
-            self._fasta_writer.preallocate(total)
         self._engine = engine
         self._own_engine = engine is None
         self._t = {"ingest_s": 0.0, "plan_apply_s": 0.0, "fasta_egress_s": 0.0, "vcf_egress_s": 0.0}
@@ -485,12 +483,6 @@ class Mutator:
         t1 = time.perf_counter()
         t["ingest_s"] += t1 - t0
         table = plan_table(chrom)
-        # the VCF span this contig will fill, estimated from its candidate count and the bytes per candidate seen so far
-        # (first contig: a generous guess), is allocated and mapped in the background while the device plans
-        n_cand = int(table["k"].sum()) if len(table) else 0
-        rate = getattr(self, "_vcf_bytes_per_candidate", None) or (len(rec.name.encode("utf-8", "replace")) + 64.0)
-        if n_cand * rate >= (8 << 20):
-            self._vcf_writer.expect(int(n_cand * rate * 1.04) + 65536)
         eng.plan_contig(cid, table)
         if eng.plan_was_empty(cid) and "warned" not in done:
             self._warn_empty(chrom)
@@ -501,19 +493,30 @@ class Mutator:
             self._fasta_writer.write_header(rec.long_name)
             done.add("header")
         eng.apply_contig(cid)
-        # Egress.  Line framing and VCF text are rendered on the device; the copies land DIRECTLY in the output files'
-        # page cache (the writers map the next region of their file): no intermediate buffer, no write() pass -- a
-        # write() of a 200 Mb contig into tmpfs costs 40-50 ms of one core, the D2H copy into the mapping 9-14.
+        # Egress.  Line framing and VCF text are rendered on the device and libmsim's output channels write them into the
+        # files' next spans (csrc/file_io.hip: device -> pinned ring -> pwrite on a thread per file) while this thread goes on
+        # with the next contig; mutate() joins them (file_wait) before the writers are closed.
         if bpl > 0:
-            n_text = eng.fetch_sequence_framed_size(cid, bpl)          # (synchronises: PLAN + APPLY are done here)
+            n_text = eng.fetch_sequence_framed_size(cid, bpl) if not NATIVE_FILE_EGRESS else None
+            if n_text is None:
+                out_len = eng.result_sizes(cid)[0]                     # (synchronises: PLAN + APPLY are done here)
+                n_text = out_len + out_len // bpl
             t2 = time.perf_counter()
             t["plan_apply_s"] += t2 - t1
-            region = self._fasta_writer.map_region(n_text)
+            q, r = divmod(n_text, bpl + 1)              # text = L + L // bpl bytes  ->  L
+            fd, pos = self._fasta_writer.native_span()
             try:
-                eng.fetch_sequence_framed_into(cid, bpl, region.view)
-            finally:
-                q, r = divmod(n_text, bpl + 1)          # text = L + L // bpl bytes  ->  L
-                self._fasta_writer.commit_region(region, q * bpl + r)
+                n_done = eng.fetch_sequence_framed_to_file(cid, bpl, fd, pos) if NATIVE_FILE_EGRESS else None
+            except _ffi.MsimUnsupported:                # the file cannot be mapped there: through a mapping made here
+                n_done = None
+            if n_done is not None:
+                self._fasta_writer.commit_native(pos, n_done, q * bpl + r)
+            else:
+                region = self._fasta_writer.map_region(n_text)
+                try:
+                    eng.fetch_sequence_framed_into(cid, bpl, region.view)
+                finally:
+                    self._fasta_writer.commit_region(region, q * bpl + r)
         else:
             text = eng.fetch_sequence(cid)
             t2 = time.perf_counter()
@@ -521,15 +524,21 @@ class Mutator:
             self._fasta_writer.write_array(text)
         t3 = time.perf_counter()
         t["fasta_egress_s"] += t3 - t2
-        n_vcf = eng.render_vcf_device_size(cid, rec.name)
-        if n_cand:
-            self._vcf_bytes_per_candidate = n_vcf / n_cand
-        region = self._vcf_writer.map_region(n_vcf)
+        fd, pos = self._vcf_writer.native_span()
         try:
-            if n_vcf:
-                eng.render_vcf_device_into(cid, rec.name, region.view)
-        finally:
-            self._vcf_writer.commit_region(region)
+            n_done = eng.render_vcf_device_to_file(cid, rec.name, fd, pos) if NATIVE_FILE_EGRESS else None
+        except _ffi.MsimUnsupported:
+            n_done = None
+        if n_done is not None:
+            self._vcf_writer.commit_native(pos, n_done)
+        else:
+            n_vcf = eng.render_vcf_device_size(cid, rec.name)
+            region = self._vcf_writer.map_region(n_vcf)
+            try:
+                if n_vcf:
+                    eng.render_vcf_device_into(cid, rec.name, region.view)
+            finally:
+                self._vcf_writer.commit_region(region)
         t["vcf_egress_s"] += time.perf_counter() - t3
         eng.clear()
 
@@ -610,6 +619,9 @@ class Mutator:
             chroms = self._chromosomes()
             for i, j in self._units(chroms):
                 self._process_unit(eng, chroms, i, j)
+            t0 = time.perf_counter()
+            eng.file_wait()                            # what the output channels still hold goes out
+            self._t["egress_wait_s"] = time.perf_counter() - t0
         finally:
             if not self._fast_rng:
                 import_python_streams(eng)

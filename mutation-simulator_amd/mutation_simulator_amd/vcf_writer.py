@@ -113,6 +113,15 @@ class VcfWriter:
     def commit_region(self, region):
         region.close(self._out)
 
+    def native_span(self):
+        """(fd, position) where the next record lines go, for a writer outside Python (``msim_render_vcf_device_file``);
+        ``commit_native(pos, nbytes)`` finishes it."""
+        self._out.flush()
+        return self._out.fileno(), self._out.tell()
+
+    def commit_native(self, pos: int, nbytes: int):
+        self._out.seek(pos + nbytes)
+
     def tell(self) -> int:
         self._out.flush()
         return self._out.tell()

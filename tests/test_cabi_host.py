@@ -24,7 +24,7 @@ def test_header_symbols_exported_and_bound():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.msim_abi_version() == 4
+    assert lib.msim_abi_version() == 5
 
 
 def test_struct_layouts_match_header():

@@ -58,6 +58,26 @@ def test_vcf_device_equals_host_renderer(L, rate, seed, deco):
     eng.close()
 
 
+@pytest.mark.parametrize("lens,seed", [({2: (200, 900), 3: (250, 1500), 4: (256, 700), 5: (300, 1100), 6: (260, 2000)}, 21),
+                                       ({2: (20, 300), 3: (24, 26), 4: (25, 257), 5: (1, 600), 6: (23, 258)}, 22)])
+def test_vcf_device_long_records_take_the_wave_path(lens, seed):
+    """REF / ALT of hundreds of bases: the wave-cooperative sink with its 4-bytes-per-lane copies (raw, converted, reverse-
+    complemented) and the byte tail; the second mix straddles the lane / wave threshold."""
+    L = 2_000_000
+    bases = decorate(random_bases(L, seed), seed + 1, n_runs=4, iupac=300, lower=0)
+    bases[bases == ord("U")] = ord("A")
+    eng = _ffi.Engine(0)
+    eng.seed(seed, seed + 10)
+    eng.set_params(_params(titv=1.0))
+    mix = {2: 0.2, 3: 0.2, 4: 0.2, 5: 0.2, 6: 0.1, 7: 0.1}
+    cid = _plan_apply(eng, bases, [_sv_range(0, L - 1, 1500, mix, lens)])
+    recs, pool = eng.fetch_records(cid)
+    want = _ffi.render_vcf(recs, pool, bases, "chrLong")
+    got = eng.render_vcf_device(cid, "chrLong").tobytes()
+    assert got == want and len(want) > 300_000
+    eng.close()
+
+
 def test_vcf_device_tiny_contigs_cover_position_zero_and_contig_end():
     """Thousands of 12-40 base contigs under a dense SV + translocation mix: mutations at position 0
     (IN / DE / TLI special cases, mutator.py:346-358, 362-371, 404-413), deletions clamped at the end."""
@@ -189,3 +209,81 @@ def test_splice_contigs_equals_numpy(la, lb, n_bp, seed):
     with pytest.raises(_ffi.MsimError):
         eng.splice_contigs(a, b, np.array([1], np.uint64), np.array([lb + 1], np.uint64))
     eng.close()
+
+
+@pytest.mark.parametrize("L,head", [(40_000_003, 37), (9_000_000, 4096), (300_000, 5), (0, 11)])
+def test_text_written_into_the_output_file_equals_the_fetched_text(tmp_path, L, head):
+    """msim_fetch_sequence_framed_file / msim_render_vcf_device_file (file_io.hip): the span behind what the file already
+    holds receives exactly the bytes the buffer calls return; what was there before and what the caller writes behind the
+    span meanwhile stay.  40 Mb is several pieces of the channel's ring, 300 kb less than one."""
+    eng = _ffi.Engine(0)
+    eng.seed(7, 8)
+    eng.set_params(_params(titv=1.0))
+    bases = random_bases(L, 31)
+    cid = _plan_apply(eng, bases, [_sv_range(0, L - 1, L // 50, ALL_SV, LENS)] if L else [])
+    want_fa = eng.fetch_sequence_framed(cid, 60).tobytes() if L else b""
+    want_vcf = eng.render_vcf_device(cid, "chrF").tobytes()
+    prefix = bytes(range(256)) * 17
+    for name, want, call in (("o.fa", want_fa, lambda fd, off: eng.fetch_sequence_framed_to_file(cid, 60, fd, off)),
+                             ("o.vcf", want_vcf, lambda fd, off: eng.render_vcf_device_to_file(cid, "chrF", fd, off))):
+        if not L and name == "o.fa":
+            continue
+        with open(tmp_path / name, "w+b") as f:
+            f.write(prefix[:head])
+            f.flush()
+            n = call(f.fileno(), head)
+            assert n == len(want)
+            f.seek(head + n)
+            f.write(b"tail")                          # (the caller goes on behind the span while the channel fills it)
+            f.flush()
+            eng.file_wait()
+        got = (tmp_path / name).read_bytes()
+        assert got[:head] == prefix[:head] and got[head:head + len(want)] == want and got[head + len(want):] == b"tail"
+    eng.close()
+
+
+def test_text_into_a_file_that_cannot_be_mapped_is_reported_not_attempted():
+    import os
+    eng = _ffi.Engine(0)
+    eng.seed(1, 1)
+    eng.set_params(_params())
+    cid = _plan_apply(eng, random_bases(100_000, 2), [])
+    r, w = os.pipe()
+    try:
+        with pytest.raises(_ffi.MsimUnsupported):
+            eng.fetch_sequence_framed_to_file(cid, 60, w, 0)
+    finally:
+        os.close(r)
+        os.close(w)
+    eng.close()
+
+
+def test_queued_file_writes_of_many_contigs_land_in_order(tmp_path):
+    """Six contigs queued back to back on both channels (a third job waits for the channel's older buffer): the files hold
+    every contig's text at its offset once file_wait returns; a write that fails (descriptor opened read-only) is reported by
+    file_wait, not lost."""
+    eng = _ffi.Engine(0)
+    eng.seed(3, 4)
+    eng.set_params(_params(titv=1.0))
+    wants = []
+    with open(tmp_path / "all.fa", "w+b") as fa, open(tmp_path / "all.vcf", "w+b") as vc:
+        pos_f = pos_v = 0
+        for i in range(6):
+            L = 9_000_000 + 1000 * i
+            cid = _plan_apply(eng, random_bases(L, 40 + i), [_sv_range(0, L - 1, L // 80, ALL_SV, LENS)])
+            wants.append((eng.fetch_sequence_framed(cid, 60).tobytes(), eng.render_vcf_device(cid, f"c{i}").tobytes()))
+            pos_f += eng.fetch_sequence_framed_to_file(cid, 60, fa.fileno(), pos_f)
+            pos_v += eng.render_vcf_device_to_file(cid, f"c{i}", vc.fileno(), pos_v)
+            eng.clear()
+        eng.file_wait()
+    assert (tmp_path / "all.fa").read_bytes() == b"".join(w[0] for w in wants)
+    assert (tmp_path / "all.vcf").read_bytes() == b"".join(w[1] for w in wants)
+    cid = _plan_apply(eng, random_bases(100_000, 1), [])
+    with open(tmp_path / "all.fa", "rb") as ro:
+        eng.fetch_sequence_framed_to_file(cid, 60, ro.fileno(), 0)
+        with pytest.raises(_ffi.MsimError, match="pwrite"):
+            eng.file_wait()
+    eng.file_wait()                                   # (reported once)
+    eng.close()
+
+
