@@ -317,6 +317,11 @@ int msim_batch_run(msim_ctx *ctx, const msim_batch_contig *contigs, int n);
 int msim_batch_sizes(msim_ctx *ctx, int n, uint64_t *fasta_bytes, uint64_t *vcf_bytes, int32_t *empty, uint64_t *n_records);
 /* the framed bodies / the VCF lines of all contigs of the batch, back to back in contig order (either may be NULL)       */
 int msim_batch_fetch(msim_ctx *ctx, uint8_t *fasta_text, uint64_t fasta_cap, char *vcf_text, uint64_t vcf_cap);
+/* The last batch's two texts queued for their output files (see msim_fetch_sequence_framed_file: same channels, same
+ * msim_file_wait): the FASTA text is framed into libmsim's buffer by its host threads and written from there, the VCF text
+ * as it was rendered; either descriptor may be -1 (not wanted).  The texts' sizes: msim_batch_view (fasta_text == NULL).
+ * The next msim_batch_run waits, where it overwrites them, until the channel has let go of the buffers.                  */
+int msim_batch_fetch_file(msim_ctx *ctx, int fasta_fd, uint64_t fasta_offset, int vcf_fd, uint64_t vcf_offset);
 /* the same texts in place (valid until the next batch / destroy): no copy of a few hundred MB.  *last_line_bases: bases on
  * the partial last line of the FASTA text (what FastaWriter needs to know to continue after it)                           */
 int msim_batch_view(msim_ctx *ctx, const uint8_t **fasta_text, uint64_t *fasta_bytes, const char **vcf_text,

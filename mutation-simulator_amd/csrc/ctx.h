@@ -269,6 +269,8 @@ int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64
 int file_check(Ctx *c, int fd);
 int file_text_buffer(Ctx *c, int ch, int *slot, uint8_t ***buf, size_t **cap);
 int file_enqueue(Ctx *c, int ch, int slot, uint64_t n, int fd, uint64_t offset);
+int file_enqueue_host(Ctx *c, int ch, const uint8_t *src, uint64_t n, int fd, uint64_t offset);
+void file_channel_idle(Ctx *c, int ch);
 int file_wait(Ctx *c);
 void file_io_destroy(Ctx *c);
 

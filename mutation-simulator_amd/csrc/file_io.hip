@@ -36,7 +36,8 @@ constexpr size_t FILE_CHUNK = 8u << 20;
 constexpr int FILE_SLOTS = 3;
 
 struct FileJob {
-    const uint8_t *d_src;
+    const uint8_t *d_src;                  // device text (a buffer of the channel) ...
+    const uint8_t *h_src;                  // ... or host text the caller keeps untouched until the channel is idle
     int buf;
     uint64_t n;
     int fd;                                // a dup() of the caller's descriptor: closed when the job is done
@@ -94,6 +95,13 @@ void run_job(FileChannel &ch, const FileJob &job) {
     bool failed;
     { std::lock_guard<std::mutex> lk(ch.mu); failed = ch.err != 0; }
     hipError_t e = hipSuccess;
+    if (!failed && job.h_src) {                             // host text (a batch of small contigs, framed on the host)
+        const auto tb = std::chrono::steady_clock::now();
+        std::string why;
+        if (!pwrite_all(job.fd, job.h_src, job.n, job.offset, why)) set_err(ch, MSIM_ERR_IO, why);
+        if (prof) write_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+        failed = true;                                      // (nothing left to do below)
+    }
     if (!failed && !ch.st) {
         e = hipSetDevice(ch.device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&ch.st, hipStreamNonBlocking);
@@ -159,7 +167,7 @@ void channel_main(FileChannel *chp) {
         {
             std::lock_guard<std::mutex> lk(ch.mu);
             ch.running = false;
-            ch.in_flight[job.buf] = false;
+            if (job.buf >= 0) ch.in_flight[job.buf] = false;
         }
         ch.cv_done.notify_all();
     }
@@ -225,10 +233,42 @@ int file_enqueue(Ctx *c, int ch_id, int slot, uint64_t n, int fd, uint64_t offse
             ch.started = true;
         }
         ch.in_flight[slot] = true;
-        ch.q.push_back(FileJob{ch.d_buf[slot], slot, n, own, offset});
+        ch.q.push_back(FileJob{ch.d_buf[slot], nullptr, slot, n, own, offset});
     }
     ch.cv_job.notify_one();
     return MSIM_OK;
+}
+
+// Host text [src, src + n) -> bytes [offset, offset + n) of `fd` on the channel's thread.  The caller leaves the text alone
+// until file_channel_idle(ch) / file_wait() has returned.
+int file_enqueue_host(Ctx *c, int ch_id, const uint8_t *src, uint64_t n, int fd, uint64_t offset) {
+    if (!n) return MSIM_OK;
+    FileChannel &ch = io_get(c)->ch[ch_id];
+    const int own = dup(fd);
+    if (own < 0) return fail(c, MSIM_ERR_IO, std::string("dup: ") + strerror(errno));
+    {
+        std::lock_guard<std::mutex> lk(ch.mu);
+        if (!ch.started) {
+            try {
+                ch.th = std::thread(channel_main, &ch);
+            } catch (const std::system_error &e) {
+                (void)close(own);
+                return fail(c, MSIM_ERR_NOMEM, std::string("output channel thread: ") + e.what());
+            }
+            ch.started = true;
+        }
+        ch.q.push_back(FileJob{nullptr, src, -1, n, own, offset});
+    }
+    ch.cv_job.notify_one();
+    return MSIM_OK;
+}
+
+// The channel has nothing queued or running (a failure stays recorded for file_wait).
+void file_channel_idle(Ctx *c, int ch_id) {
+    if (!c->file_io) return;
+    FileChannel &ch = c->file_io->ch[ch_id];
+    std::unique_lock<std::mutex> lk(ch.mu);
+    ch.cv_done.wait(lk, [&] { return ch.q.empty() && !ch.running; });
 }
 
 // Everything queued is in its file (or failed: the first failure is reported, once).

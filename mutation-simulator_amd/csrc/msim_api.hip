@@ -263,7 +263,7 @@ void msim_destroy(msim_ctx *p) {
     if (!p) return;
     CtxFull *c = static_cast<CtxFull *>(C(p));
     c->deferred_apply = -1;                                // nobody will ask for its result
-    if (c->host_only) { delete c; return; }
+    if (c->host_only) { file_io_destroy(c); batch_free(c); delete c; return; }
     static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
     auto tp = std::chrono::steady_clock::now();
     double ph[6] = {0, 0, 0, 0, 0, 0};
@@ -1128,6 +1128,8 @@ struct Batch {
 
 static void batch_free(Ctx *c) {
     if (!c->batch) return;
+    file_channel_idle(c, 0);                               // (an output channel may still be writing the batch's texts)
+    file_channel_idle(c, 1);
     static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) { const auto n = std::chrono::steady_clock::now(); if (prof) fprintf(stderr, "  batch_free %s %.1f ms\n", what, std::chrono::duration<double, std::milli>(n - tp).count()); tp = n; };
@@ -1422,6 +1424,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
         std::sort(order.begin(), order.end(), [&](int x, int y) { return part_first[(size_t)x] < part_first[(size_t)y]; });
         uint64_t total_vcf = 0;
         for (int t : order) total_vcf += part_len[(size_t)t];
+        file_channel_idle(c, 1);                            // (the previous batch's VCF text may still be on its way to the file)
         if (!raw_reserve(&B.vcf, &B.vcf_cap, (size_t)total_vcf + 1)) { free_parts(); vcf_rc = MSIM_ERR_NOMEM; vcf_msg = "batch VCF text"; return; }
         uint64_t at = 0;
         for (size_t k = 0; k < order.size(); k++) {
@@ -1517,6 +1520,31 @@ int msim_batch_fetch(msim_ctx *p, uint8_t *fasta_text, uint64_t fasta_cap, char 
     if (vcf_text) {
         if (vcf_cap < B.vcf_len) return fail(c, MSIM_ERR_ARG, "vcf buffer too small");
         if (B.vcf_len) memcpy(vcf_text, B.vcf, B.vcf_len);
+    }
+    return MSIM_OK;
+}
+
+int msim_batch_fetch_file(msim_ctx *p, int fasta_fd, uint64_t fasta_offset, int vcf_fd, uint64_t vcf_offset) {
+    CTX_FLUSHED(c, p)
+    if (!c || !c->batch) return MSIM_ERR_ARG;
+    Batch &B = *c->batch;
+    if (fasta_fd >= 0) {
+        int rc = file_check(c, fasta_fd);
+        if (rc) return rc;
+        file_channel_idle(c, 0);                           // (the previous batch's text may still be read from B.fasta)
+        if (!B.framed) {
+            if (!raw_reserve(&B.fasta, &B.fasta_cap, B.fasta_len + 1)) return fail(c, MSIM_ERR_NOMEM, "batch FASTA text");
+            if (B.fasta_len) batch_frame_into(B, B.fasta);
+            B.framed = true;
+        }
+        rc = file_enqueue_host(c, 0, B.fasta, B.fasta_len, fasta_fd, fasta_offset);
+        if (rc) return rc;
+    }
+    if (vcf_fd >= 0) {
+        int rc = file_check(c, vcf_fd);
+        if (rc) return rc;
+        rc = file_enqueue_host(c, 1, reinterpret_cast<const uint8_t *>(B.vcf), B.vcf_len, vcf_fd, vcf_offset);
+        if (rc) return rc;
     }
     return MSIM_OK;
 }

@@ -120,6 +120,7 @@ SYMBOLS = [
     ("msim_render_vcf_device_file", C.c_int, [_VP, C.c_int, C.c_char_p, C.c_int, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed_file", C.c_int, [_VP, C.c_int, C.c_uint32, C.c_int, C.c_uint64, _U64P]),
     ("msim_file_wait", C.c_int, [_VP]),
+    ("msim_batch_fetch_file", C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, C.c_uint64]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
     ("msim_splice_contigs", C.c_int, [_VP, C.c_int, C.c_int, C.c_uint64, _U64P, _U64P, _IP]),
     ("msim_set_fast_key", C.c_int, [_VP, C.c_uint64]),
@@ -542,6 +543,11 @@ class Engine:
         if dst.dtype != np.uint8 or not dst.flags.c_contiguous or not dst.flags.writeable:
             raise ValueError("batch_fetch_fasta needs a writable contiguous uint8 array")
         self._check(self.lib.msim_batch_fetch(self.h, C.c_void_p(dst.ctypes.data), dst.shape[0], None, 0))
+
+    def batch_fetch_to_files(self, fasta_fd: int, fasta_offset: int, vcf_fd: int, vcf_offset: int):
+        """Queue the last batch's FASTA text (framed by libmsim's host threads) and VCF text for their files' spans at the
+        given offsets (-1: not that one); ``file_wait`` joins."""
+        self._check(self.lib.msim_batch_fetch_file(self.h, int(fasta_fd), int(fasta_offset), int(vcf_fd), int(vcf_offset)))
 
     def _batch_result(self, n: int, defer_fasta: bool = False):
         em = (C.c_int32 * n)()

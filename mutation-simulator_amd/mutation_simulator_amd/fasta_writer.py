@@ -251,6 +251,21 @@ class FastaWriter:
         if nbytes:
             self._written = n_bases % self._bpl
 
+    def native_records_span(self, nbytes: int):
+        """(fd, position) for a run of complete records of ``nbytes`` bytes written outside Python (see ``write_records``;
+        the newline a partial previous line is owed is written here); ``commit_native_records`` finishes it."""
+        if nbytes and self._written != 0:
+            self._out.write(b"\n")
+            self._written = 0
+        self._out.flush()
+        return self._out.fileno(), self._out.tell()
+
+    def commit_native_records(self, pos: int, nbytes: int, bpl: int, last_line_bases: int):
+        self._out.seek(pos + nbytes)
+        if nbytes:
+            self._bpl = bpl
+            self._written = int(last_line_bases)
+
     def write_records(self, text: np.ndarray, bpl: int, last_line_bases: int):
         """Append a run of complete records -- header lines and wrapped bodies, exactly the bytes ``write_header`` +
         ``write_framed`` would produce for each (``Engine.batch_run``).  ``bpl`` / ``last_line_bases``: line width of the

@@ -391,6 +391,17 @@ class Mutator:
             bpl_last = self._fasta.faidx.index[last.name].lenc
         for k in np.flatnonzero(empty):
             self._warn_empty(chroms[i + int(k)])
+        if isinstance(fasta, int) and NATIVE_FILE_EGRESS:
+            # both texts go out on libmsim's output channels while the next batch is planned (csrc/file_io.hip)
+            try:
+                fd_f, pos_f = self._fasta_writer.native_records_span(fasta)
+                fd_v, pos_v = self._vcf_writer.native_span()
+                eng.batch_fetch_to_files(fd_f if fasta else -1, pos_f, fd_v if len(vcf) else -1, pos_v)
+                self._fasta_writer.commit_native_records(pos_f, fasta, bpl_last, last_line)
+                self._vcf_writer.commit_native(pos_v, len(vcf))
+                return
+            except _ffi.MsimUnsupported:               # no regular files: through a mapping / write() made here
+                pass
         if isinstance(fasta, int):
             region = self._fasta_writer.map_records(fasta)
             try:
