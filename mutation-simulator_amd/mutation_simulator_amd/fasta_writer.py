@@ -11,7 +11,6 @@ import ctypes
 import errno
 import mmap
 import os
-import time
 
 import numpy as np
 
@@ -45,17 +44,16 @@ def fallocate_native(fd: int, offset: int, nbytes: int) -> bool:
 class MappedRegion:
     """The next ``nbytes`` of an output file as a writable uint8 array (``view``): the file is extended and that span
     mapped, so whoever fills it -- a device-to-host copy -- writes straight into the page cache.  ``close`` unmaps.
-    ``ahead``: the writer's ``Preallocator``; a span inside one of its arenas is a slice of that mapping."""
+    The fallback of libmsim's output channels (csrc/file_io.hip), which write the same spans with pwrite() from threads of
+    their own: building and tearing down the page tables of a mapping costs more than the copy (measured there)."""
     __slots__ = ("pos", "nbytes", "view", "_map")
 
-    def __init__(self, fileobj, nbytes: int, ahead=None):
+    def __init__(self, fileobj, nbytes: int):
         fileobj.flush()
         self.pos = fileobj.tell()
         self.nbytes = int(nbytes)
         self._map = None
-        self.view = ahead.view(self.pos, self.nbytes) if (ahead is not None and self.nbytes) else None
-        if self.view is not None:
-            return
+        self.view = None
         if self.nbytes:
             fd = fileobj.fileno()
             if os.fstat(fd).st_size < self.pos + self.nbytes:
@@ -78,97 +76,6 @@ class MappedRegion:
         fileobj.seek(self.pos + self.nbytes)
 
 
-_MADV_POPULATE_WRITE = 23          # Linux >= 5.14: allocate + map the pages of a range now
-
-
-class Preallocator:
-    """Background allocation of spans of an output file ahead of the copies that will land there: ``request(start, end)``
-    queues file bytes [start, end) -- an estimate of what is about to be written -- and a worker thread allocates them
-    (fallocate: bulk page allocation), maps them as one arena and populates the mapping's page tables chunk by chunk.  A
-    device-to-host copy into a populated mapping runs at the link's speed (4 ms per 200 MB), into fresh file pages at a
-    tenth of it.  Estimates may overlap and may be wrong: a span no arena covers is mapped by ``MappedRegion`` itself, and
-    ``finish`` cuts the file to what was written."""
-
-    def __init__(self, fileobj):
-        import queue
-        self._fd = fileobj.fileno()
-        self._arenas = []                       # (start, length, mmap), appended by the worker
-        self._q = queue.SimpleQueue()
-        self._thread = None
-        self._stop = False
-        self._requested = 0                     # requests queued (written by the requesting thread only)
-        self._mapped = 0                        # requests whose arena is mapped, or that failed (written by the worker only)
-
-    def request(self, start: int, end: int):
-        import threading
-        start -= start % mmap.ALLOCATIONGRANULARITY
-        if end <= start or self._stop:
-            return
-        self._requested += 1
-        self._q.put((int(start), int(end)))
-        if self._thread is None:
-            self._thread = threading.Thread(target=self._work, name="msim-fallocate", daemon=True)
-            self._thread.start()
-
-    def _work(self):
-        while True:
-            job = self._q.get()
-            if job is None:
-                return
-            start, end = job
-            arena = None
-            try:
-                if not self._stop:
-                    if not fallocate_native(self._fd, start, end - start):
-                        # no native fallocate here: no allocation ahead of the writers at all (an emulated one would race
-                        # with them); MappedRegion extends the file by ftruncate and the copies fault their pages in
-                        self._stop = True
-                        raise OSError(errno.EOPNOTSUPP, "fallocate not supported")
-                    arena = mmap.mmap(self._fd, end - start, access=mmap.ACCESS_WRITE, offset=start)
-                    self._arenas.append((start, end - start, arena))
-            except (OSError, ValueError):
-                arena = None
-            self._mapped += 1
-            step = 64 << 20
-            for a in range(0, end - start if arena is not None else 0, step):
-                if self._stop:
-                    break
-                try:
-                    arena.madvise(_MADV_POPULATE_WRITE, a, min(step, end - start - a))
-                except (OSError, ValueError):
-                    break                       # older kernel: the copies fault the pages in themselves
-
-    def view(self, pos: int, nbytes: int):
-        """[pos, pos + nbytes) as a slice of an arena, or None.  (An arena that is requested but not mapped yet is waited
-        for: the fallocate + mmap at its start take a few ms per 100 MB; its population may still be running behind --
-        a page it has not reached simply faults in.)"""
-        for _ in range(4000):
-            for start, length, arena in reversed(self._arenas):
-                if start <= pos and pos + nbytes <= start + length:
-                    return np.frombuffer(arena, dtype=np.uint8, count=nbytes, offset=pos - start)
-            if self._mapped >= self._requested or self._thread is None or not self._thread.is_alive():
-                return None
-            time.sleep(0.0005)
-        return None
-
-    def finish(self, fileobj):
-        """Stop the worker, drop the arenas and cut the file to what was written."""
-        self._stop = True
-        if self._thread is not None:
-            self._q.put(None)
-            self._thread.join()
-            self._thread = None
-        for _, _, arena in self._arenas:
-            try:
-                arena.close()
-            except BufferError:                 # (a view of it is still alive somewhere: the mapping goes with it)
-                pass
-        self._arenas = []
-        fileobj.flush()
-        if os.fstat(fileobj.fileno()).st_size > fileobj.tell():
-            os.ftruncate(fileobj.fileno(), fileobj.tell())
-
-
 class FastaWriterError(Exception):
     """Raised when the writer can not write to a file."""
 
@@ -188,17 +95,7 @@ class FastaWriter:
     def close(self):
         out = getattr(self, "_out", None)
         if out is not None and not out.closed:
-            ahead, self._ahead = getattr(self, "_ahead", None), None
-            if ahead is not None:
-                ahead.finish(out)
             out.close()
-
-    def preallocate(self, nbytes: int):
-        """Allocate the file's first ``nbytes`` in the background (a size estimate: the file is cut to what was really
-        written at ``close``).  Mapped regions inside it then cost no page allocation."""
-        if getattr(self, "_ahead", None) is None and nbytes > 0:
-            self._ahead = Preallocator(self._out)
-            self._ahead.request(0, int(nbytes))
 
     def set_bpl(self, bpl: int):
         self._bpl = bpl
@@ -231,7 +128,7 @@ class FastaWriter:
         start a line).  ``commit_region(region, n_bases)`` finishes it."""
         if self._written != 0:
             raise FastaWriterError("map_region needs to start at the beginning of a line")
-        return MappedRegion(self._out, nbytes, getattr(self, "_ahead", None))
+        return MappedRegion(self._out, nbytes)
 
     def commit_region(self, region: MappedRegion, n_bases: int):
         region.close(self._out)
@@ -284,7 +181,7 @@ class FastaWriter:
         if nbytes and self._written != 0:
             self._out.write(b"\n")
             self._written = 0
-        return MappedRegion(self._out, nbytes, getattr(self, "_ahead", None))
+        return MappedRegion(self._out, nbytes)
 
     def commit_records(self, region: MappedRegion, bpl: int, last_line_bases: int):
         region.close(self._out)

@@ -8,6 +8,7 @@ go up as file text, ``msim_splice_contigs`` (csrc/text_gpu.hip: ``k_splice``) cu
 the segments alternately, the framing kernel wraps the result, and the copy lands in the mapped output file."""
 from __future__ import annotations
 
+import os
 import random
 
 import numpy as np
@@ -19,6 +20,10 @@ from .fasta_writer import FastaWriter
 from .util import print_warning
 
 
+NATIVE_FILE_EGRESS = os.environ.get("MSIM_PY_EGRESS") != "1"   # (diagnosis: 1 = map the output spans here, copy with one thread)
+_SAMPLER = None                   # libmsim host-only context of sample_with_minimum_distance (made on first use)
+RESIDENT_MAX_BYTES = 64 << 30     # inputs kept in HBM for their partner's turn (a human genome is 3 GB; the GPU holds 288)
+RESIDENT_MAX_CONTIGS = 30000      # ... and contig slots of the context (libmsim: 65536; every splice result takes one)
 NATIVE_SAMPLE_FROM = 512          # breakpoints per contig from which libmsim's sampler takes over (same draws, ~100x faster)
 
 
@@ -36,15 +41,15 @@ def sample_with_minimum_distance(start: int, stop: int, k: int, d: int) -> np.nd
         out = np.sort(np.asarray(picked, dtype=np.int64))
         return out + d * np.arange(k, dtype=np.int64)
     from .mutator import sample_setsize
+    global _SAMPLER
     st = random.getstate()
-    eng = _HostEngine(device=-1)
-    try:
-        eng.set_mt_state(0, np.array(st[1][:624], dtype=np.uint32), st[1][624])
-        out = eng.sample_min_distance(start, stop, k, d, sample_setsize(k))      # (ValueError: nothing was drawn)
-        mt, pos = eng.get_mt_state(0)
-    finally:
-        eng.close()
-    random.setstate((st[0], tuple(int(x) for x in mt) + (int(pos),), st[2]))
+    if _SAMPLER is None:                               # one host-only context for every call of the run
+        _SAMPLER = _HostEngine(device=-1)
+    eng = _SAMPLER
+    eng.set_mt_state(0, np.array(st[1][:624], dtype=np.uint32), st[1][624])
+    out = eng.sample_min_distance(start, stop, k, d, sample_setsize(k))          # (ValueError: nothing was drawn)
+    mt, pos = eng.get_mt_state(0)
+    random.setstate((st[0], tuple(mt.tolist()) + (int(pos),), st[2]))
     return out
 
 
@@ -55,10 +60,11 @@ class ITMutator:
         self._sim = sim
         self._fasta_writer = FastaWriter(args.outfastait)
         self._bedpe_writer = BedpeWriter(args.outbedpe)
-        total = int(getattr(fasta, "text_bytes", 0) or 0)   # segments only change places: the output is as large as the input
-        if total > (64 << 20):
-            self._fasta_writer.preallocate(total + (total >> 6))
         self._eng = None
+        self._turns_left: set = set()
+        self._resident: dict = {}                      # contig number -> libmsim contig id of its input, while in HBM
+        self._resident_bytes = 0
+        self._slots = 0                                # contig slots of the context in use
         self._assign_partners(self._available())
 
     def __del__(self):
@@ -160,10 +166,26 @@ class ITMutator:
             self._eng = _ffi.Engine(getattr(self._args, "device", 0) or 0)
         return self._eng
 
-    def _ingest(self, eng, rec) -> int:
+    def _ingest(self, eng, rec, number=None) -> int:
+        """The contig's input in HBM.  A contig with a partner is read twice -- at its own turn and at its partner's: it is
+        uploaded once and stays resident in between (``number``: its key; ``_forget`` drops everything)."""
+        if number is not None and number in self._resident:
+            return self._resident[number]
         if getattr(rec, "uniform", False):            # file text -> HBM: strip + upper-case on the device
-            return eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
-        return eng.add_contig(rec.bases)
+            cid = eng.add_contig_text(rec.body, len(rec), rec.lenc, rec.lenb)
+        else:
+            cid = eng.add_contig(rec.bases)
+        self._slots += 1
+        if number is not None:
+            self._resident[number] = cid
+            self._resident_bytes += len(rec)
+        return cid
+
+    def _forget(self, eng):
+        eng.clear()
+        self._resident = {}
+        self._resident_bytes = 0
+        self._slots = 0
 
     def _untouched_runs(self, n: int, breakpoints: dict) -> list:
         """[a, b) spans of >= 2 consecutive contigs that keep their sequence and are small: an assembly's thousands of
@@ -213,13 +235,24 @@ class ITMutator:
         t["name"] = t["header"]                        # (no VCF lines: the name is never read, it only must not be NULL)
         t["name_len"] = 1
         eng.set_params(params_descriptor(self._sim))
+        self._forget(eng)                              # (a batch takes the context's contig table for itself)
         n_text, _, _, last_line = eng.batch_run_table(t, keep=(blob, text), defer_fasta=True)
-        region = self._fasta_writer.map_records(n_text)
-        try:
-            if n_text:
-                eng.batch_fetch_fasta(region.view)
-        finally:
-            self._fasta_writer.commit_records(region, int(tab["lenc"][-1]), last_line)
+        done = False
+        if NATIVE_FILE_EGRESS:
+            try:                                       # framed by libmsim's host threads, written by its output channel
+                fd, pos = self._fasta_writer.native_records_span(n_text)
+                eng.batch_fetch_to_files(fd if n_text else -1, pos, -1, 0)
+                self._fasta_writer.commit_native_records(pos, n_text, int(tab["lenc"][-1]), last_line)
+                done = True
+            except _ffi.MsimUnsupported:
+                pass
+        if not done:
+            region = self._fasta_writer.map_records(n_text)
+            try:
+                if n_text:
+                    eng.batch_fetch_fasta(region.view)
+            finally:
+                self._fasta_writer.commit_records(region, int(tab["lenc"][-1]), last_line)
         del blob
 
     def _mutate_sequence(self, breakpoints: dict):
@@ -242,28 +275,54 @@ class ITMutator:
         bpl = self._fasta.faidx.index[rec.name].lenc
         self._fasta_writer.set_bpl(bpl)
         self._fasta_writer.write_header(rec.long_name)
-        a = self._ingest(eng, rec)
-        if chrom.number in breakpoints:
-            partner = self._fasta[self._partners[chrom.number]]
+        paired = chrom.number in breakpoints
+        a = self._ingest(eng, rec, chrom.number if paired else None)
+        if paired:
+            p = self._partners[chrom.number]
+            partner = self._fasta[p]
             own, other = breakpoints[chrom.number]
-            cid = eng.splice_contigs(a, self._ingest(eng, partner), own.astype(np.uint64), other.astype(np.uint64))
+            cid = eng.splice_contigs(a, self._ingest(eng, partner, p), own.astype(np.uint64), other.astype(np.uint64))
             self._bedpe_writer.write(rec.name, own, len(rec), partner.name, other, len(partner))
+            self._turns_left.discard(chrom.number)
         else:
             # (the reference's __write_chrom_full writes the header again, it_mutator.py:148-156 after :199-202: a contig
             #  without breakpoints carries its defline twice.  Kept: the files are compared byte by byte)
             self._fasta_writer.write_header(rec.long_name)
             cid = eng.splice_contigs(a, -1, none, none)
         if bpl > 0:
-            n_text = eng.fetch_sequence_framed_size(cid, bpl)
-            region = self._fasta_writer.map_region(n_text)
-            try:
-                eng.fetch_sequence_framed_into(cid, bpl, region.view)
-            finally:
-                q, r = divmod(n_text, bpl + 1)
-                self._fasta_writer.commit_region(region, q * bpl + r)
+            n_done = None
+            if NATIVE_FILE_EGRESS:
+                fd, pos = self._fasta_writer.native_span()
+                try:                                   # queued on libmsim's output channel (csrc/file_io.hip); mutate() joins
+                    n_done = eng.fetch_sequence_framed_to_file(cid, bpl, fd, pos)
+                except _ffi.MsimUnsupported:
+                    n_done = None
+            if n_done is not None:
+                q, r = divmod(n_done, bpl + 1)
+                self._fasta_writer.commit_native(pos, n_done, q * bpl + r)
+            else:
+                n_text = eng.fetch_sequence_framed_size(cid, bpl)
+                region = self._fasta_writer.map_region(n_text)
+                try:
+                    eng.fetch_sequence_framed_into(cid, bpl, region.view)
+                finally:
+                    q, r = divmod(n_text, bpl + 1)
+                    self._fasta_writer.commit_region(region, q * bpl + r)
         else:
             self._fasta_writer.write_array(eng.fetch_sequence(cid))
-        eng.clear()
+        # the result has left for the file (or sits in the channel's own buffer); the inputs stay while a partner's turn
+        # is still to come
+        self._slots += 1
+        left = self._turns_left
+        waiting = any(k in left or self._partners.get(k) in left for k in self._resident)
+        if not waiting or self._resident_bytes > RESIDENT_MAX_BYTES or self._slots > RESIDENT_MAX_CONTIGS:
+            self._forget(eng)
+        else:
+            eng.release_result(cid)
 
     def mutate(self):
-        self._mutate_sequence(self._generate_all_breakpoints())
+        breakpoints = self._generate_all_breakpoints()
+        self._turns_left = set(breakpoints)            # paired contigs whose own turn is still to come
+        self._mutate_sequence(breakpoints)
+        if self._eng is not None:
+            self._eng.file_wait()                      # what the output channel still holds goes out

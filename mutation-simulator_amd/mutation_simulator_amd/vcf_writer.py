@@ -59,9 +59,6 @@ class VcfWriter:
     def close(self):
         out = getattr(self, "_out", None)
         if out is not None and not out.closed:
-            ahead, self._ahead = getattr(self, "_ahead", None), None
-            if ahead is not None:
-                ahead.finish(out)
             out.flush()
             if os.fstat(out.fileno()).st_size > out.tell():     # (a mapped region that was cut short)
                 os.ftruncate(out.fileno(), out.tell())
@@ -93,22 +90,10 @@ class VcfWriter:
     def write_raw(self, text: bytes):
         self._out.write(text)
 
-    def expect(self, nbytes: int):
-        """About ``nbytes`` of record lines are on their way (an estimate, made before the contig is planned): the file's
-        next span is allocated, mapped and populated in the background while the device works (``Preallocator``)."""
-        from .fasta_writer import Preallocator
-        if nbytes <= 0:
-            return
-        if getattr(self, "_ahead", None) is None:
-            self._ahead = Preallocator(self._out)
-        self._out.flush()
-        pos = self._out.tell()
-        self._ahead.request(pos, pos + int(nbytes))
-
     def map_region(self, nbytes: int):
         """The next ``nbytes`` of the file mapped for writing (record lines rendered elsewhere land there directly)."""
         from .fasta_writer import MappedRegion
-        return MappedRegion(self._out, nbytes, getattr(self, "_ahead", None))
+        return MappedRegion(self._out, nbytes)
 
     def commit_region(self, region):
         region.close(self._out)

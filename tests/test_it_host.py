@@ -123,6 +123,26 @@ class NumpyEngine:
     def batch_fetch_fasta(self, dst):
         dst[:len(self._batch_text)] = np.frombuffer(self._batch_text, dtype=np.uint8)
 
+    # the *_to_file calls (libmsim: queued on an output channel; here: written at once)
+    def fetch_sequence_framed_to_file(self, cid, bpl, fd, offset):
+        import os
+        buf = np.empty(self.fetch_sequence_framed_size(cid, bpl), dtype=np.uint8)
+        self.fetch_sequence_framed_into(cid, bpl, buf)
+        os.pwrite(fd, buf.tobytes(), offset)
+        return len(buf)
+
+    def batch_fetch_to_files(self, fasta_fd, fasta_offset, vcf_fd, vcf_offset):
+        import os
+        assert vcf_fd == -1
+        if fasta_fd >= 0:
+            os.pwrite(fasta_fd, self._batch_text, fasta_offset)
+
+    def file_wait(self):
+        pass
+
+    def release_result(self, cid):
+        self.contigs[cid] = None
+
     def clear(self):
         self.contigs = []
 
