@@ -534,8 +534,12 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS, CAP> &A, in
 
 
 // ---- LDS path (the tile's records fit the window) --------------------------------------------------------
-// k_rewrite is VALU-issue bound on SV mixes (PMC: ~1000 VALU instructions per wave, VALU pipes ~70 % busy
-// with the first version of this routine), so everything here is about instruction count:
+// The FIRST version of this routine was VALU-issue bound on SV mixes (round-1 PMC: ~1000 VALU instructions per wave, VALU
+// pipes ~70 % busy), so everything here is about instruction count.  What it bought, measured on the round-3/4 kernel
+// (profiles/r04_pmc_sq_k_rewrite.txt, k_rewrite<140> on a 240 Mb contig of the c3 mix): 564 VALU instructions per wave; of
+// the waves' cycles 62.5 % wait for memory (SQ_WAIT_ANY), 19.8 % wait to issue (SQ_WAIT_INST_ANY), 17.7 % execute
+// (SQ_ACTIVE_INST_ANY; VALU 9 %, LDS 1.5 % with a bank conflict in 13 % of its cycles) -- the kernel now waits for HBM
+// like k_rewrite_snp does (85 % SQ_WAIT_ANY), it no longer issues instructions against it.  The means:
 //   * governing record of every 16-B group from an INDEX TABLE (one LDS atomicMax per record + a max-scan,
 //     aliased onto the tile buffer) instead of a binary search per group
 //   * SNPs do not break a copy run (the run after an SNP continues the same source stream), so only the

@@ -8,6 +8,7 @@ O=gpurun_out/r4ev; mkdir -p $O
 for w in c2 c3 c4 c4sv; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/ks_$w -o ks -- python3 bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > $O/ks_$w.log 2>&1
   python3 profiles/summarize_rocprof.py stats $O/ks_$w/ks_results.db > $O/kernel_stats_$w.txt 2>&1
+  [ $w = c2 ] && python3 profiles/summarize_rocprof.py timeline $O/ks_$w/ks_results.db -4 330 2 > $O/timeline_c2.txt 2>&1
   rm -rf $O/ks_$w
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/kf_$w -o ks -- python3 mutation-simulator_amd/tools/fast_steps.py $w 3 > $O/kf_$w.log 2>&1
   (grep "plan+apply\|plan only\|host enqueue" $O/kf_$w.log; python3 profiles/summarize_rocprof.py stats $O/kf_$w/ks_results.db) > $O/kernel_stats_fast_$w.txt 2>&1
@@ -44,5 +45,11 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 12 > $O/cli_profile.txt 2>&1
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- args -sn 0.005 -in 0.001 -inmin 1 -inmax 50 -de 0.001 -demin 1 -demax 50 -du 0.0005 -dumin 50 -dumax 500 -iv 0.0005 -ivmin 50 -ivmax 500 >> $O/cli_profile.txt 2>&1
 python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- --rng fast args -sn 0.005 -in 0.001 -inmin 1 -inmax 50 -de 0.001 -demin 1 -demax 50 -du 0.0005 -dumin 50 -dumax 500 -iv 0.0005 -ivmin 50 -ivmax 500 >> $O/cli_profile.txt 2>&1
+python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 20000 --top 6 >> $O/cli_profile.txt 2>&1
+python3 mutation-simulator_amd/tools/cli_profile.py --mb 1200 --contigs 6 --top 6 -- it 0.000001 >> $O/cli_profile.txt 2>&1
+MSIM_IO_PROF=1 python3 mutation-simulator_amd/tools/cli_profile.py --dir /dev/shm --mb 1200 --contigs 6 --top 2 2>&1 | grep "msim io\|CLI wall" > $O/file_channels.txt
 timeout 100 python3 mutation-simulator_amd/tools/apply_microbench.py 10 > $O/apply_microbench.txt 2>&1
+# ---- 6. why the output channels write() instead of mapping the files (csrc/file_io.hip)
+g++ -O2 -pthread -o /tmp/iobench mutation-simulator_amd/tools/iobench.cpp 2>/dev/null
+(echo "== /dev/shm (tmpfs)"; /tmp/iobench /dev/shm | tail -17; echo "== /tmp"; /tmp/iobench /tmp | tail -17) > $O/iobench.txt 2>&1
 head -12 $O/kernel_stats_fast_c3.txt

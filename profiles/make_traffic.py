@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""profiles/rNN_traffic.json from the PMC passes' summaries (profiles/summarize_rocprof.py pmc): per launch of each workload's
+rewrite kernel the HBM bytes FETCH_SIZE x 2 (the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md: the counter
+ticks in 32-byte units where rocprofv3 documents 64) + WRITE_SIZE, both in KB, beside the algorithmic bytes bench.py prices.
+
+    python3 profiles/make_traffic.py gpurun_out/r4ev profiles/r04_bench_default.json > profiles/r04_traffic.json
+"""
+import json
+import re
+import sys
+from pathlib import Path
+
+KERNEL = {"c2": "k_rewrite_snp", "c3": "k_rewrite<140>", "c4": "k_rewrite_snp", "c4sv": "k_rewrite<140>"}
+
+
+def per_launch(path: Path, kernel: str, counter: str) -> float:
+    for line in path.read_text().splitlines():
+        if kernel in line and counter in line:
+            m = re.search(r"dispatches=\s*(\d+)\s+sum=\s*([0-9.]+)", line)
+            return float(m.group(2)) / int(m.group(1))
+    raise SystemExit(f"{path}: no {counter} line for {kernel}")
+
+
+def main(src: str, bench_json: str):
+    src = Path(src)
+    bench = json.loads(Path(bench_json).read_text())
+    alg = {"c2": bench["roofline"]["algorithmic_bytes_per_launch"]}
+    for w in ("c3", "c4", "c4sv"):
+        alg[w] = bench["secondary"][w]["roofline"]["algorithmic_bytes_per_launch"]
+    out = {}
+    for w, k in KERNEL.items():
+        f = per_launch(src / f"pmc_fetch_{w}.txt", k, "FETCH_SIZE")
+        wr = per_launch(src / f"pmc_write_{w}.txt", k, "WRITE_SIZE")
+        traffic = int(round((2.0 * f + wr) * 1024))
+        out[w] = {"kernel": "msim::" + k, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": wr, "fetch_correction": 2.0,
+                  "traffic_bytes_per_launch": traffic, "algorithmic_bytes_per_launch": alg[w],
+                  "traffic_over_algorithmic": round(traffic / alg[w], 4)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:3])

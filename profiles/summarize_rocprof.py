@@ -60,5 +60,42 @@ def text(db, wall_line=""):
             print(f"{pat.strip('%'):24s} calls={int(row[0]):4d} total_us={row[1]:10.1f} {mb:9.1f} MB -> {mb * 1e6 / (row[1] * 1e-6) / 1e9:8.1f} GB/s  ({what})")
 
 
+def timeline(db, which="-1", max_rows="400", groups="1", marker="k_state_init"):
+    """Kernel dispatches of ONE step in start order: offset from the step's first kernel, duration, queue, name -- and per
+    queue the busy time and the gaps between consecutive kernels (what a latency-bound chain is made of).  `which`: index of
+    the k_state_init group the step starts with (negative: from the end); `groups`: how many such groups make one step (compatible
+    mode reseeds the second stream lazily at the end of a step: 2)."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = list(c.execute(f"select start, end, {qcol}, name, grid_x from kernels order by start"))
+    short = lambda n: n.replace("msim::(anonymous namespace)::", "").replace("msim::", "").split("(")[0]
+    # a step starts with the stream kernels of the first contig's reseed: k_state_init
+    starts = [i for i, r in enumerate(rows) if marker in r[3]]
+    firsts = [starts[i] for i in range(len(starts)) if i == 0 or rows[starts[i]][0] - rows[starts[i - 1]][0] > 1_000_000]
+    if not firsts:
+        print("no", marker, "found"); return
+    k = int(which)
+    if k < 0:
+        k = len(firsts) - 1 + k                      # (the last step may be cut off by the end of the run: take the one before)
+    lo = firsts[max(k, 0)]
+    hi = firsts[k + int(groups)] if k + int(groups) < len(firsts) else len(rows)
+    step = rows[lo:hi]
+    t0 = step[0][0]
+    print(f"# step {k}: {len(step)} dispatches, {(max(r[1] for r in step) - t0) / 1e3:.1f} us from first start to last end")
+    per_q = {}
+    for st, en, q, name, grid in step:
+        per_q.setdefault(q, []).append((st, en, short(name)))
+    for q, lst in sorted(per_q.items(), key=lambda kv: kv[1][0][0]):
+        busy = sum(e - s for s, e, _ in lst)
+        gaps = [lst[i + 1][0] - lst[i][1] for i in range(len(lst) - 1)]
+        pos = [g for g in gaps if g > 0]
+        print(f"# queue {q}: {len(lst)} kernels, busy {busy / 1e3:.1f} us, first at {(lst[0][0] - t0) / 1e3:.1f}, last end {(lst[-1][1] - t0) / 1e3:.1f}, "
+              f"positive gaps {len(pos)} sum {sum(pos) / 1e3:.1f} us")
+    print(f"{'start_us':>10s} {'dur_us':>8s} {'queue':>6s}  kernel (grid)")
+    for st, en, q, name, grid in step[:int(max_rows)]:
+        print(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:8.1f} {q!s:>6s}  {short(name)} ({grid})")
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc, "text": text}[sys.argv[1]](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "text": text, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])
