@@ -145,6 +145,7 @@ class ShardWorker(Mutator):
                 segments.append((u, f0, self._fasta_writer.tell(), v0, self._vcf_writer.tell()))
                 if error:
                     break
+            eng.file_wait()                            # the part files hold everything queued for them (or: MsimError)
         finally:
             if error is None and not self._fast_rng:
                 import_python_streams(eng)

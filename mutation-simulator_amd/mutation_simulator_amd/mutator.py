@@ -320,6 +320,12 @@ class Mutator:
 
     def close(self):
         # the context's teardown (device buffers, registered staging memory) beside the writers' (unmapping the output files)
+        pending = None
+        if getattr(self._engine, "h", None):           # (also on the reference's KeyError / ValueError: what was queued for the
+            try:                                       #  files before it is part of what the reference had written by then)
+                self._engine.file_wait()
+            except _ffi.MsimError as e:
+                pending = e
         eng, self._engine = (self._engine if self._own_engine else None), None
         side = None
         if eng is not None and os.environ.get("MSIM_SERIAL_CLOSE") != "1":
@@ -334,6 +340,8 @@ class Mutator:
                 side.join()
             elif eng is not None:
                 eng.close()
+        if pending is not None:
+            raise pending
 
     def __del__(self):
         try:
