@@ -80,6 +80,11 @@ struct FastPlan {
     std::map<int, Replay> replay;                          // per contig planned with device-side counts: its tables (see enqueue_batch)
     uint64_t replays = 0;                                  // plans that had to be replayed with the orbit kernels
     std::vector<Pending> queue;                            // msim_plan_contig calls whose device work has not been enqueued
+    // A run of plans between two synchronising calls is a cycle (a genome in bench.py, a contig in the CLI).  Its first half
+    // goes to the device as soon as it is queued -- judged by the previous cycle's size -- so that the device works while the
+    // host still prepares the tables of the second half (35 k ranges: 0.8 ms of host work in front of a 2.5 ms step otherwise).
+    uint64_t queued_K = 0, cycle_K = 0, last_cycle_K = 0;
+    bool early_done = false;
     uint32_t next_set = 0;
 };
 
@@ -284,6 +289,9 @@ int fast_plan_collect(Ctx *c) {
         if (rc) return rc;
     }
     if (!f || !f->pending) return MSIM_OK;
+    if (f->cycle_K) f->last_cycle_K = f->cycle_K;          // a cycle ends here (see FastPlan::queued_K)
+    f->cycle_K = 0;
+    f->early_done = false;
     g_prof.report();
     for (int round = 0; f->pending && round < 3; round++) {
         f->pending = false;
@@ -585,6 +593,12 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
     FastPlan *f = c->fast;
     for (const Pending &q : f->queue)
         if (q.contig == ct.index) { if ((rc = fast_plan_flush(c))) return rc; break; }      // planned again before anybody looked
+    static const bool no_early = getenv("MSIM_FAST_NO_EARLY_FLUSH") != nullptr;
+    // (halves: thirds and quarters measured slower on every bench shape -- more batches, more fixed latency)
+    if (!no_early && !f->early_done && f->queue.size() >= 3 && f->queued_K >= std::max<uint64_t>(1u << 22, f->last_cycle_K / 2)) {
+        f->early_done = true;                              // (the contigs queued so far have had their msim_apply_contig)
+        if ((rc = fast_plan_flush(c))) return rc;
+    }
     Pending it;
     g_prof.start();
     rc = prepare(c, ct.len, ranges, n_ranges, it.P);
@@ -603,6 +617,8 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
     ct.planned = true;
     if (!P.K) return MSIM_OK;
     it.contig = ct.index; it.key = key64; it.seq = seq; it.apply = false;
+    f->queued_K += P.K;
+    f->cycle_K += P.K;
     f->queue.push_back(std::move(it));
     return MSIM_OK;
 }
@@ -638,7 +654,9 @@ int fast_plan_flush(Ctx *c) {
     // the next one (latency- and issue-bound) on another stream.  MSIM_FAST_BATCHES overrides the number (1 = everything at once).
     uint64_t total = 0;
     for (const Pending &q : queue) total += q.P.K;
-    static const int want_batches = getenv("MSIM_FAST_BATCHES") ? std::max(1, atoi(getenv("MSIM_FAST_BATCHES"))) : 2;
+    f->queued_K = 0;
+    static const int env_batches = getenv("MSIM_FAST_BATCHES") ? std::max(1, atoi(getenv("MSIM_FAST_BATCHES"))) : 2;
+    const int want_batches = f->early_done ? 1 : env_batches;   // (a cycle whose first half went out early: each flush is one batch)
     const uint64_t cut = queue.size() >= 6 && total >= (1u << 22) ? total / (uint64_t)want_batches + 1 : ~0ull;
     uint64_t in_batch = 0;
     for (Pending &q : queue) {
