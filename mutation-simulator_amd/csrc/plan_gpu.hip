@@ -54,6 +54,8 @@ struct GpuStream {
     bool live = false;                  // device copy is the authoritative stream
     // generation runs on its own HIP stream; batch b covers chunks [.., ready_hi[b]) and signals ready_ev[b]
     std::vector<uint32_t> ready_hi;
+    std::vector<hipEvent_t> words_ev;   // ... and words_ev[b] as soon as its words are there (the SNP maps of the batch follow)
+    uint32_t waited_words = 0;          // the plan stream already waited for the WORDS of chunks below this
     std::vector<hipEvent_t> ready_ev;
     uint32_t waited_chunks = 0;         // the plan stream already waited for chunks below this
 };
@@ -204,6 +206,7 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (s.d_z) (void)hipFree(s.d_z);
         if (s.d_maps) (void)hipFree(s.d_maps);
         for (auto e : s.ready_ev) (void)hipEventDestroy(e);
+        for (auto e : s.words_ev) if (e) (void)hipEventDestroy(e);
     }
     for (auto e : g->ev_pool) (void)hipEventDestroy(e);
     for (auto &t : g->sample) {
@@ -277,7 +280,9 @@ static int ensure_side_streams(Ctx *c, GpuPlan *g) {
 // stream only waits for the batch that covers what it is about to read.  With the sizing hint the
 // whole session is enqueued at the first call, so the cascade overlaps the planning of the first
 // contigs instead of preceding it.
-static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
+// maps = false: the caller reads the words only (a sample's chain) -- it need not wait for the batch's SNP maps, which the first
+// batch of a step delivers ~110 us behind its words
+static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = true) {
     GpuStream &s = g->s[si];
     {
         int rc0 = ensure_side_streams(c, g);
@@ -361,9 +366,16 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                 MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, st_ev, 0));
                 s.ready_ev.push_back(st_ev);                // recycled with the batch events at the next reseed
                 s.ready_hi.push_back(0);
+                s.words_ev.push_back(nullptr);
                 hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(GEN_THREADS), 0, g->gen_stream, s.d_states,
                                    s.d_raw, s.n_chunks);
                 MSIM_HIP(c, hipGetLastError());
+                hipEvent_t wev = nullptr;
+                if (si == 0) {
+                    rc = take_event(wev);
+                    if (rc) return rc;
+                    MSIM_HIP(c, hipEventRecord(wev, g->gen_stream));
+                }
                 if (si == 0) {                              // SNP transducer maps of every block the batch completed
                     const uint32_t n_words = (uint32_t)(MT_N + (uint64_t)hi * MT_CHUNK_WORDS);
                     const uint32_t complete = n_words / SNP_BLOCK2;
@@ -380,6 +392,7 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
                 MSIM_HIP(c, hipEventRecord(ev, g->gen_stream));
                 s.ready_hi.push_back(hi);
                 s.ready_ev.push_back(ev);
+                s.words_ev.push_back(wev);
                 s.n_chunks = hi;
             }
             if (s.n_chunks < need_chunks) {                // extend the cascade (mixed radix, one launch per level)
@@ -416,11 +429,13 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto) {
     // the plan stream waits for the batch that covers `upto`
     if (upto > MT_N) {
         const uint32_t need = (uint32_t)((upto - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
-        if (need > s.waited_chunks) {
+        if (need > (maps ? s.waited_chunks : s.waited_words)) {
             for (size_t b = 0; b < s.ready_hi.size(); b++) {
                 if (s.ready_hi[b] >= need) {
-                    MSIM_HIP(c, hipStreamWaitEvent(c->stream, s.ready_ev[b], 0));
-                    s.waited_chunks = s.ready_hi[b];
+                    const bool words_only = !maps && s.words_ev[b];
+                    MSIM_HIP(c, hipStreamWaitEvent(c->stream, words_only ? s.words_ev[b] : s.ready_ev[b], 0));
+                    s.waited_words = std::max(s.waited_words, s.ready_hi[b]);
+                    if (!words_only) s.waited_chunks = s.ready_hi[b];
                     break;
                 }
             }
@@ -464,7 +479,10 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     for (auto e : s.ready_ev) g->ev_pool.push_back(e);
     s.ready_ev.clear();
     s.ready_hi.clear();
+    for (auto e : s.words_ev) if (e) g->ev_pool.push_back(e);
+    s.words_ev.clear();
     s.waited_chunks = 0;
+    s.waited_words = 0;
     s.n_states = 1;
     s.lvl = 0; s.n_src = 1; s.m_done = 0;
     s.z_lvl = -1;
@@ -616,7 +634,7 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, bm_words64 * 8, &grew))) return rc;
     if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
     if (!raw_other) {
-        if ((rc = ensure_words(c, g, 0, pos_hi + W + 1))) return rc;
+        if ((rc = ensure_words(c, g, 0, pos_hi + W + 1, false))) return rc;
         raw = g->s[0].d_raw;                               // (may have been reallocated)
     }
     // ---- chain (plan stream): where does this sample end?
