@@ -4,15 +4,19 @@
 // The record table and the mutated stream live in HBM; for an SV mix the VCF text is as large as the
 // genome, so rendering it on the host means one core pushing gigabytes through a
 // byte-wise formatter.  Here:
-//   VCF    k_vcf_lines<false> : a wave per 64 records (SNP lines one lane each, every other record by the whole wave)
+//   VCF    k_vcf_lines<false> : a wave per 64 consecutive records.  Short lines -- every SNP, every record spanning <= 24
+//                               bases -- are formatted by ONE lane each (LSink), long REF / ALT by the whole wave, one
+//                               record after the other (WSink: scalar fields by the low lanes, copies 4 bytes per lane)
 //                               -> length of every line (0 = suppressed, REF == ALT)
 //          k_len_* / k_scan_u64: exclusive u64 scan -> byte offset of every line
-//          k_vcf_lines<true>  : same walk, writing: lane 0 emits the scalar fields, all 64 lanes copy
-//                               REF / ALT (raw, ambiguity-converted, or reverse-complemented) coalesced
+//          k_vcf_lines<true>  : same walk, writing (raw, ambiguity-converted, or reverse-complemented REF / ALT)
 //          follows mutator.py:334-421 (record construction) and vcf_writer.py:44-52,118-126 (the line)
-//   FASTA  k_frame  : mutated stream -> text with '\n' after every `bpl` bases (fasta_writer.py:40-58)
+//   FASTA  k_frame  : mutated stream -> text with '\n' after every `bpl` bases (fasta_writer.py:40-58); 16 output bytes
+//                     per lane from two unaligned 16-byte loads, the newline shifted in
 //          k_gather : FASTA body text (uniform line width, as pyfaidx requires) -> upper-cased uint8 bases
-//                     (what pyfaidx hands the reference with sequence_always_upper=True, util.py:84-88)
+//                     (what pyfaidx hands the reference with sequence_always_upper=True, util.py:84-88); 16 bases per lane,
+//                     the one line terminator a group can straddle squeezed out
+//   (round 4, profiles/r04_kernel_stats_cli_*.txt: k_gather / k_frame 4.8-5.4 TB/s, k_vcf_lines 1.3-1.8 TB/s on SNP tables)
 //   IT     k_splice : interchromosomal translocation of one contig -- segments of two contigs taken alternately
 //                     (it_mutator.py:121-146 __write_with_bp)
 // Byte/integer work, HBM-bound; no MFMA.

@@ -12,6 +12,7 @@ for w in c2 c3 c4 c4sv; do
   rm -rf $O/ks_$w
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/kf_$w -o ks -- python3 mutation-simulator_amd/tools/fast_steps.py $w 3 > $O/kf_$w.log 2>&1
   (grep "plan+apply\|plan only\|host enqueue" $O/kf_$w.log; python3 profiles/summarize_rocprof.py stats $O/kf_$w/ks_results.db) > $O/kernel_stats_fast_$w.txt 2>&1
+  [ $w = c3 ] && python3 profiles/summarize_rocprof.py timeline $O/kf_$w/ks_results.db -6 120 2 k_fsplit_top > $O/timeline_fast_c3.txt 2>&1
   rm -rf $O/kf_$w
 done
 # ---- 2. HBM traffic of the rewrite kernels (FETCH_SIZE / WRITE_SIZE, separate passes)
