@@ -658,7 +658,7 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, raw, ps, W,
                        (uint32_t)(32 - bits), (uint32_t)n, S.cnt, ps, binned ? S.cursors : nullptr,
                        binned ? n_bins * BIN_SUBS : 0u);
-    hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->stream, S.cnt, nb);
+    hipLaunchKernelGGL(k_scan_u32_w4, dim3(1), dim3(256), 0, c->stream, S.cnt, nb);   // (four waves: see the kernel)
     if (binned) {
         hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, c->stream, raw, ps, W,
                            (uint32_t)(32 - bits), (uint32_t)n, k, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc,

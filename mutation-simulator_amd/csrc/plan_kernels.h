@@ -170,11 +170,11 @@ __global__ __launch_bounds__(GEN_THREADS) void k_mt_generate(const uint32_t *__r
 // path, so: wave scan by shuffles, two barriers per round; a round covers 4096 items, or 16384 when more than
 // one round of 4096 would be needed -- the loads of a round are independent, so the longer round costs one
 // memory latency, not four)
-template <int ITEMS>
+template <int ITEMS, int WAVES = 16>
 __device__ __forceinline__ void scan_rounds(uint32_t *__restrict__ a, uint32_t n, uint32_t *wsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
-    for (uint32_t base = 0; base < n; base += 1024 * ITEMS) {
+    for (uint32_t base = 0; base < n; base += 64 * WAVES * ITEMS) {
         const uint32_t i0 = base + threadIdx.x * ITEMS;
         uint32_t v[ITEMS];
         uint32_t mine = 0;
@@ -190,7 +190,7 @@ __device__ __forceinline__ void scan_rounds(uint32_t *__restrict__ a, uint32_t n
         __syncthreads();
         uint32_t pre = carry, total = 0;
 #pragma unroll
-        for (int w = 0; w < 16; w++) {
+        for (int w = 0; w < WAVES; w++) {
             const uint32_t t = wsum[w];
             if (w < wave) pre += t;
             total += t;
@@ -211,6 +211,12 @@ __global__ __launch_bounds__(1024) void k_scan_u32(uint32_t *__restrict__ a, uin
     __shared__ uint32_t wsum[16];
     if (n <= 4096) scan_rounds<4>(a, n, wsum);
     else scan_rounds<16>(a, n, wsum);
+}
+// The same with four waves: a workgroup of 16 needs half a CU's wave slots at once, and next to a rewrite kernel that fills
+// every slot it waits until four of that kernel's workgroups on ONE CU have ended with no refill in between
+__global__ __launch_bounds__(256) void k_scan_u32_w4(uint32_t *__restrict__ a, uint32_t n) {
+    __shared__ uint32_t wsum[4];
+    scan_rounds<16, 4>(a, n, wsum);
 }
 
 // ------------------------------------------------------------------ 2. accepted draws, in order
