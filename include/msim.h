@@ -137,6 +137,11 @@ int  msim_abi_version(void);
 /* Initialise the HIP runtime for `device_id` (idempotent, thread-safe, no context): the first HIP call of a process costs
  * ~0.2 s; a caller with host work of its own to do first (reading and indexing the FASTA) runs this beside it.        */
 int  msim_warm_up(int device_id);
+/* The CPUs of the NUMA node the device hangs on, as a Linux cpulist ("64-127,192-255"; "" when the host has one node or sysfs
+ * does not tell).  On a two-socket host a run whose host threads stay on the GPU's socket moves its bytes once across the
+ * inter-socket links instead of twice (CLI end to end: 0.30 -> 0.25-0.27 s); libmsim pins its own output channels' threads
+ * there (MSIM_IO_CPUS=none / a cpulist overrides), the caller decides about its own.  Initialises the HIP runtime.        */
+int  msim_device_host_cpus(int device_id, char *cpulist, int cap);
 int  msim_create(int device_id, uint32_t flags, msim_ctx **out);     /* Mutator.__init__ mutator.py:79 */
 void msim_destroy(msim_ctx *ctx);                                     /* Mutator.close    mutator.py:95 */
 const char *msim_last_error(const msim_ctx *ctx);                     /* "" when none; ctx may be NULL  */

@@ -273,6 +273,7 @@ int file_enqueue_host(Ctx *c, int ch, const uint8_t *src, uint64_t n, int fd, ui
 void file_channel_idle(Ctx *c, int ch);
 int file_wait(Ctx *c);
 void file_io_destroy(Ctx *c);
+void device_host_cpus(int device, char *buf, size_t cap);   // cpulist of the device's NUMA node ("" if unknown)
 
 // render.cpp
 uint64_t render_vcf_unchecked(const msim_record *recs, uint64_t n_records, const uint8_t *insert_pool, const uint8_t *bases,

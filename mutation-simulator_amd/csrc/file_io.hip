@@ -13,6 +13,7 @@
 // channel's thread copies it device -> pinned ring in 8 MiB pieces (the copy of piece k + 1 runs while piece k is written)
 // and pwrite()s the pieces to the file.  The calling thread goes on with the next contig's ingest / PLAN / APPLY meanwhile;
 // file_wait() joins.  Writes to ONE file serialise on its inode in the kernel anyway -- one thread per file is all there is.
+#include <cctype>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -23,6 +24,8 @@
 #include <thread>
 
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -151,8 +154,61 @@ void run_job(FileChannel &ch, const FileJob &job) {
                 wait_ms, write_ms, write_ms > 0 ? job.n / 1e6 / write_ms : 0.0);
 }
 
+// A channel's thread runs on the CPUs of the NUMA node its GPU hangs on (sysfs: the PCI device's numa_node, the node's
+// cpulist): the ring the DMA engine fills, the thread that reads it and the file pages it writes then share a socket -- on the
+// two-socket hosts of the pool a CLI run pinned to the GPU's node took 0.31 s where the unpinned one took 0.40.
+// MSIM_IO_CPUS overrides: a cpulist ("64-127,192-255"), or "none".
+bool parse_cpulist(const char *s, cpu_set_t *set) {
+    CPU_ZERO(set);
+    bool any = false;
+    while (*s) {
+        char *end;
+        long a = strtol(s, &end, 10);
+        if (end == s) return false;
+        long b = a;
+        if (*end == '-') { s = end + 1; b = strtol(s, &end, 10); if (end == s) return false; }
+        for (long q = a; q <= b && q < CPU_SETSIZE; q++) { CPU_SET((int)q, set); any = true; }
+        s = end;
+        while (*s == ',' || *s == ' ' || *s == '\n') s++;
+    }
+    return any;
+}
+
+bool read_line(const std::string &path, char *buf, size_t cap) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const bool ok = fgets(buf, (int)cap, f) != nullptr;
+    fclose(f);
+    return ok;
+}
+
+// cpulist of the NUMA node the device hangs on ("" when sysfs does not tell or the host has one node)
+void gpu_node_cpulist(int device, char *buf, size_t cap) {
+    buf[0] = 0;
+    char bus[64] = {0}, tmp[64];
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *q = bus; *q; q++) *q = (char)tolower((unsigned char)*q);
+    if (!read_line(std::string("/sys/bus/pci/devices/") + bus + "/numa_node", tmp, sizeof tmp)) return;
+    const int node = atoi(tmp);
+    if (node < 0) return;                                   // (a one-node host says -1)
+    if (!read_line("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", buf, cap)) buf[0] = 0;
+    for (char *q = buf; *q; q++) if (*q == '\n') *q = 0;
+}
+
+void pin_to_gpu_node(int device) {
+    cpu_set_t set;
+    char buf[4096];
+    if (const char *e = getenv("MSIM_IO_CPUS")) {
+        if (strcmp(e, "none") != 0 && parse_cpulist(e, &set)) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);
+        return;
+    }
+    gpu_node_cpulist(device, buf, sizeof buf);
+    if (buf[0] && parse_cpulist(buf, &set)) (void)pthread_setaffinity_np(pthread_self(), sizeof set, &set);   // (refused in a narrower cpuset: stays put)
+}
+
 void channel_main(FileChannel *chp) {
     FileChannel &ch = *chp;
+    pin_to_gpu_node(ch.device);
     for (;;) {
         FileJob job;
         {
@@ -189,6 +245,8 @@ FileIo *io_get(Ctx *c) {
 }
 
 }  // namespace
+
+void device_host_cpus(int device, char *buf, size_t cap) { gpu_node_cpulist(device, buf, cap); }
 
 // `fd` must be something pwrite() can address: a regular file.  MSIM_ERR_UNSUPPORTED otherwise (a pipe, a terminal): the
 // caller fetches the text into a buffer and write()s it.

@@ -184,6 +184,16 @@ int msim_warm_up(int device_id) {
     return hipFree(nullptr) == hipSuccess ? MSIM_OK : MSIM_ERR_HIP;     // forces the runtime + device context up
 }
 
+int msim_device_host_cpus(int device_id, char *cpulist, int cap) {
+    if (!cpulist || cap <= 0) return MSIM_ERR_ARG;
+    cpulist[0] = 0;
+    if (device_id < 0) return MSIM_OK;
+    char buf[4096];
+    device_host_cpus(device_id, buf, sizeof buf);
+    snprintf(cpulist, (size_t)cap, "%s", buf);
+    return MSIM_OK;
+}
+
 int msim_create(int device_id, uint32_t flags, msim_ctx **out) {
     if (!out) return MSIM_ERR_ARG;
     *out = nullptr;

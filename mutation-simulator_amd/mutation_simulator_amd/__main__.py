@@ -26,7 +26,7 @@ def initialize(argv=None):
     if (args.gpus or 1) <= 1:
         try:                       # the GPU comes up while the FASTA is read and indexed (never in the parent of --gpus N)
             from ._ffi import warm_up_async
-            warm_up_async(args.device or 0)
+            warm_up_async(args.device or 0, pin=True)
         except Exception:  # noqa: BLE001  (no library: Mutator reports it properly)
             pass
     try:

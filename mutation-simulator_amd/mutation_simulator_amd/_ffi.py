@@ -120,6 +120,7 @@ SYMBOLS = [
     ("msim_render_vcf_device_file", C.c_int, [_VP, C.c_int, C.c_char_p, C.c_int, C.c_uint64, _U64P]),
     ("msim_fetch_sequence_framed_file", C.c_int, [_VP, C.c_int, C.c_uint32, C.c_int, C.c_uint64, _U64P]),
     ("msim_file_wait", C.c_int, [_VP]),
+    ("msim_device_host_cpus", C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     ("msim_batch_fetch_file", C.c_int, [_VP, C.c_int, C.c_uint64, C.c_int, C.c_uint64]),
     ("msim_add_contig_text", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, _IP]),
     ("msim_splice_contigs", C.c_int, [_VP, C.c_int, C.c_int, C.c_uint64, _U64P, _U64P, _IP]),
@@ -175,12 +176,41 @@ def load():
     return _lib
 
 
-def warm_up_async(device: int = 0):
+def parse_cpulist(text: str) -> set:
+    """A Linux cpulist ("0-63,128-191") as a set of ints."""
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def warm_up_async(device: int = 0, pin: bool = False):
     """Start the HIP runtime on a helper thread (the first HIP call of a process costs ~0.2 s) while the caller reads and
-    indexes its input; returns the thread (join it, or just create the Engine: HIP initialisation is serialised inside)."""
+    indexes its input; returns the thread (join it, or just create the Engine: HIP initialisation is serialised inside).
+    ``pin``: once the runtime is up, move the CALLING thread onto the CPUs of the GPU's NUMA node (what the CLI does:
+    on a two-socket host the copies to and from the GPU then cross the inter-socket links once; ``MSIM_NO_PIN=1`` or a
+    cpuset that does not contain those CPUs leaves it where it is)."""
     import threading
     lib = load()
-    t = threading.Thread(target=lib.msim_warm_up, args=(int(device),), name="msim-warm-up", daemon=True)
+    caller = threading.get_native_id()
+
+    def work():
+        lib.msim_warm_up(int(device))
+        if not pin or os.environ.get("MSIM_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+            return
+        try:
+            buf = C.create_string_buffer(4096)
+            if lib.msim_device_host_cpus(int(device), buf, 4096) != OK or not buf.value:
+                return
+            cpus = parse_cpulist(buf.value.decode()) & os.sched_getaffinity(caller)
+            if cpus:
+                os.sched_setaffinity(caller, cpus)
+        except (OSError, ValueError):
+            pass
+    t = threading.Thread(target=work, name="msim-warm-up", daemon=True)
     t.start()
     return t
 

@@ -156,7 +156,7 @@ def test_it_mode_cli_host_side_matches_reference_golden(name, tmp_path, monkeypa
     breakpoints, the doubled defline of untouched contigs, BEDPE lines, warnings, the generator's position."""
     from mutation_simulator_amd import _ffi
     monkeypatch.setattr(_ffi, "Engine", NumpyEngine)
-    monkeypatch.setattr(_ffi, "warm_up_async", lambda device=0: None)
+    monkeypatch.setattr(_ffi, "warm_up_async", lambda device=0, pin=False: None)
     meta = case_meta(name)
     res = run_product_case(meta, tmp_path)
     assert res["exception"] is None and res["exit_code"] is None, (res["exception"], res["stderr"])
