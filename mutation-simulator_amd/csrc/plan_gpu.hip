@@ -42,6 +42,7 @@ struct GpuStream {
     uint32_t n_states = 0;              // valid states = n_src * (m_done + 1)
     uint32_t lvl = 0, n_src = 1, m_done = 0;   // cascade position: level, states at its start, multipliers done
     SnpMap *d_maps = nullptr;           // CPython stream only: SNP transducer maps of the absolute 8192-word blocks
+    SnpLane *d_lanes = nullptr;         //   ... and per lane of every block its masks + map (plan_kernels.h: SnpLane), maps_cap blocks
     size_t maps_cap = 0;                //   (entries)
     uint32_t mapped_blocks = 0;         //   blocks [0, mapped_blocks) are mapped (enqueued on the generation stream)
     unsigned long long maps_ti_lim = 0; //   with this transition threshold
@@ -205,6 +206,7 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (s.d_states) (void)hipFree(s.d_states);
         if (s.d_z) (void)hipFree(s.d_z);
         if (s.d_maps) (void)hipFree(s.d_maps);
+        if (s.d_lanes) (void)hipFree(s.d_lanes);
         for (auto e : s.ready_ev) (void)hipEventDestroy(e);
         for (auto e : s.words_ev) if (e) (void)hipEventDestroy(e);
     }
@@ -327,13 +329,18 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
             }
             if (si == 0 && want_cap / SNP_BLOCK2 + 2 > s.maps_cap) {
                 SnpMap *nm = nullptr;
+                SnpLane *nl = nullptr;
                 const size_t cap = (size_t)(want_cap / SNP_BLOCK2 + 2) * 5 / 4;
                 MSIM_HIP(c, hipMalloc(&nm, cap * sizeof(SnpMap)));
+                MSIM_HIP(c, hipMalloc(&nl, cap * SNP_THREADS * sizeof(SnpLane)));
                 if (s.d_maps) {
                     MSIM_HIP(c, hipMemcpy(nm, s.d_maps, (size_t)s.mapped_blocks * sizeof(SnpMap), hipMemcpyDeviceToDevice));
+                    MSIM_HIP(c, hipMemcpy(nl, s.d_lanes, (size_t)s.mapped_blocks * SNP_THREADS * sizeof(SnpLane), hipMemcpyDeviceToDevice));
                     MSIM_HIP(c, hipFree(s.d_maps));
+                    MSIM_HIP(c, hipFree(s.d_lanes));
                 }
                 s.d_maps = nm;
+                s.d_lanes = nl;
                 s.maps_cap = cap;
             }
             if (want_cap > s.cap) {
@@ -381,7 +388,7 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
                     const uint32_t complete = n_words / SNP_BLOCK2;
                     if (complete > s.mapped_blocks) {
                         hipLaunchKernelGGL(k_snp_maps_abs, dim3(complete - s.mapped_blocks), dim3(SNP_THREADS), 0, g->gen_stream,
-                                           s.d_raw, n_words, (unsigned long long)c->params.ti_lim, s.mapped_blocks, s.d_maps);
+                                           s.d_raw, n_words, (unsigned long long)c->params.ti_lim, s.mapped_blocks, s.d_maps, s.d_lanes);
                         MSIM_HIP(c, hipGetLastError());
                         s.mapped_blocks = complete;
                     }
@@ -703,18 +710,18 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
         if (!py.ready_ev.empty()) MSIM_HIP(c, hipStreamWaitEvent(c->stream, py.ready_ev.back(), 0));
         if (py.mapped_blocks)
             hipLaunchKernelGGL(k_snp_maps_abs, dim3(py.mapped_blocks), dim3(SNP_THREADS), 0, c->stream, py.d_raw,
-                               (uint32_t)(MT_N + (uint64_t)py.n_chunks * MT_CHUNK_WORDS), (unsigned long long)P.ti_lim, 0u, py.d_maps);
+                               (uint32_t)(MT_N + (uint64_t)py.n_chunks * MT_CHUNK_WORDS), (unsigned long long)P.ti_lim, 0u, py.d_maps, py.d_lanes);
         py.maps_ti_lim = P.ti_lim;
     }
-    hipLaunchKernelGGL(k_snp_scan_cut_abs, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_raw, g->d_ps, W2,
-                       (unsigned long long)P.ti_lim, py.d_maps, T.maps, nb2, (uint32_t)K, T.base);
+    hipLaunchKernelGGL(k_snp_scan_cut_abs, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_lanes, g->d_ps, W2,
+                       py.d_maps, T.maps, nb2, (uint32_t)K, T.base);
     MSIM_HIP(c, hipGetLastError());
     if (!c->chain_only) {                                 // (chain only: where the draws END is all that is wanted)
         hipEvent_t ce = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(ce, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
-        hipLaunchKernelGGL(k_snp_emit_abs, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_raw, T.base, W2,
-                           (unsigned long long)P.ti_lim, T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index);
+        hipLaunchKernelGGL(k_snp_emit_abs, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_lanes, T.base, W2,
+                           T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index);
         MSIM_HIP(c, hipGetLastError());
         MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
         T.pending = true;

@@ -703,6 +703,35 @@ __device__ __forceinline__ SnpBits snp_stage(const uint32_t *__restrict__ raw, u
     return m;
 }
 
+// What k_snp_maps_abs leaves behind per lane of every absolute block, besides the block's map: the lane's three masks and its
+// own map (counts <= 32 and end states, packed).  Masks and maps depend on the words and on ti_lim only, so the kernels that
+// follow -- k_snp_scan_cut_abs ON the chain, k_snp_emit_abs beside it -- load 16 bytes per lane instead of staging the lane's
+// 32 words through LDS, tempering them and rebuilding the masks (round 4: the emit pass was the heaviest thing running beside
+// the chain; without it a c2 step took 4.45 ms instead of 4.98).  Only where a window starts or ends inside a lane is the
+// lane's map recomputed from its masks (bit operations, no loads).
+struct SnpLane { uint32_t A, B, T, pm; };
+__device__ __forceinline__ uint32_t snp_pack_map(const SnpMap &m) {
+    return (m.c[0] & 63u) | ((m.c[1] & 63u) << 6) | ((m.c[2] & 63u) << 12) | ((m.e & 63u) << 18);
+}
+__device__ __forceinline__ SnpMap snp_unpack_map(uint32_t pm) {
+    SnpMap r;
+    r.c[0] = pm & 63u; r.c[1] = (pm >> 6) & 63u; r.c[2] = (pm >> 12) & 63u; r.e = (pm >> 18) & 63u;
+    return r;
+}
+// the lane's masks with the live range of a window: block words [start_off, ..) and absolute words below W
+__device__ __forceinline__ SnpBits snp_bits_of(const SnpLane &L, uint32_t base, uint32_t W, uint32_t start_off) {
+    SnpBits m;
+    m.A = L.A; m.B = L.B; m.T = L.T;
+    const uint32_t first = base + threadIdx.x * SNP_ITEMS2;
+    m.E = first >= W ? 0 : (int)min((uint32_t)SNP_ITEMS2, W - first);
+    const uint32_t lane0 = threadIdx.x * SNP_ITEMS2;
+    m.S = start_off <= lane0 ? 0 : (int)min((uint32_t)SNP_ITEMS2, start_off - lane0);
+    return m;
+}
+__device__ __forceinline__ SnpMap snp_lane_map_of(const SnpLane &L, const SnpBits &m) {
+    return (m.S == 0 && m.E == SNP_ITEMS2) ? snp_unpack_map(L.pm) : snp_lane_map(m);
+}
+
 // exclusive prefix of the lanes' maps across the workgroup (shuffles inside a wave, LDS across waves)
 __device__ __forceinline__ SnpMap snp_shfl_up(const SnpMap &v, int o) {
     SnpMap r;
@@ -739,13 +768,15 @@ __device__ __forceinline__ SnpMap snp_block_scan2(const SnpMap &mine, SnpMap *wa
 // of ~200 per contig).
 __global__ __launch_bounds__(SNP_THREADS) void k_snp_maps_abs(const uint32_t *__restrict__ raw, uint32_t n_words,
                                                               unsigned long long ti_lim, uint32_t first_block,
-                                                              SnpMap *__restrict__ abs_maps) {
+                                                              SnpMap *__restrict__ abs_maps, SnpLane *__restrict__ lanes) {
     __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     const uint32_t b = first_block + blockIdx.x;
     const SnpBits m = snp_stage(raw, 0ull, b * SNP_BLOCK2, n_words, ti_lim, sw);
+    const SnpMap lm = snp_lane_map(m);
+    lanes[(size_t)b * SNP_THREADS + threadIdx.x] = SnpLane{m.A, m.B, m.T, snp_pack_map(lm)};   // (only complete blocks are mapped)
     SnpMap total;
-    (void)snp_block_scan2(snp_lane_map(m), wave_tot, total);
+    (void)snp_block_scan2(lm, wave_tot, total);
     if (threadIdx.x == 0) abs_maps[b] = total;
 }
 
@@ -754,12 +785,11 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_maps_abs(const uint32_t *__
 // of window block j when the stream starts in state 0 (c[0] = count, e = state) -- what k_snp_emit_abs needs -- and
 // the block in which the K-th SNP completes has been re-walked: the word on which it completes + 1 is the new
 // stream position.  Also saves the start position for the emit pass.
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
-                                                                  uint32_t W, unsigned long long ti_lim,
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const SnpLane *__restrict__ lanes, PlanState *__restrict__ ps,
+                                                                  uint32_t W,
                                                                   const SnpMap *__restrict__ abs_maps,
                                                                   SnpMap *__restrict__ win_maps, uint32_t nb_max, uint32_t K,
                                                                   unsigned long long *__restrict__ base_out) {
-    __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     __shared__ SnpMap s_first;
     __shared__ uint32_t s_blk, s_bs, s_bc;
@@ -770,9 +800,10 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const uint32_t
     const uint32_t w_end = (uint32_t)min<unsigned long long>(p0 + W, 0xffffffffull);       // words beyond the window are not live
     if (threadIdx.x == 0) { s_blk = 0xffffffffu; *base_out = p0; }
     {   // the partial first block, mapped here
-        const SnpBits m0 = snp_stage(raw, 0ull, b0 * SNP_BLOCK2, w_end, ti_lim, sw, off);
+        const SnpLane L0 = lanes[(size_t)b0 * SNP_THREADS + threadIdx.x];
+        const SnpBits m0 = snp_bits_of(L0, b0 * SNP_BLOCK2, w_end, off);
         SnpMap total;
-        (void)snp_block_scan2(snp_lane_map(m0), wave_tot, total);
+        (void)snp_block_scan2(snp_lane_map_of(L0, m0), wave_tot, total);
         if (threadIdx.x == 0) s_first = total;
     }
     __syncthreads();
@@ -826,9 +857,10 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const uint32_t
     if (c_count < K) return;                              // uniform
     const uint32_t b = s_blk, bs = s_bs, bc = s_bc;
     const uint32_t wbase = (b0 + b) * SNP_BLOCK2;         // absolute
-    const SnpBits m = snp_stage(raw, 0ull, wbase, w_end, ti_lim, sw, b == 0 ? off : 0u);
+    const SnpLane Lb = lanes[(size_t)(b0 + b) * SNP_THREADS + threadIdx.x];
+    const SnpBits m = snp_bits_of(Lb, wbase, w_end, b == 0 ? off : 0u);
     SnpMap tot2;
-    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, tot2);
+    const SnpMap ex = snp_block_scan2(snp_lane_map_of(Lb, m), wave_tot, tot2);
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
     const uint32_t idx = bc + ex.c[bs];                   // SNPs completed before this lane's words
     uint32_t emits, from2;
@@ -843,13 +875,11 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const uint32_t
 }
 
 // aux of every SNP record (off the critical path; runs on the emit stream).  Window block j = absolute block b0 + j.
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const uint32_t *__restrict__ raw,
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const SnpLane *__restrict__ lanes,
                                                               const unsigned long long *__restrict__ base_in, uint32_t W,
-                                                              unsigned long long ti_lim,
                                                               const SnpMap *__restrict__ win_maps, uint32_t nb_max,
                                                               msim_record *__restrict__ recs, uint32_t K,
                                                               const uint32_t *__restrict__ sn_index) {
-    __shared__ uint32_t sw[SNP_LDS_WORDS];
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     if (blockIdx.x >= win_maps[nb_max].c[1]) return;      // beyond the window (uniform)
     const uint32_t bc = win_maps[blockIdx.x].c[0];
@@ -857,9 +887,10 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const uint32_t *__
     const unsigned long long p0 = *base_in;
     const uint32_t b0 = (uint32_t)(p0 / SNP_BLOCK2), off = (uint32_t)(p0 % SNP_BLOCK2);
     const uint32_t w_end = (uint32_t)min<unsigned long long>(p0 + W, 0xffffffffull);
-    const SnpBits m = snp_stage(raw, 0ull, (b0 + blockIdx.x) * SNP_BLOCK2, w_end, ti_lim, sw, blockIdx.x == 0 ? off : 0u);
+    const SnpLane Lm = lanes[(size_t)(b0 + blockIdx.x) * SNP_THREADS + threadIdx.x];
+    const SnpBits m = snp_bits_of(Lm, (b0 + blockIdx.x) * SNP_BLOCK2, w_end, blockIdx.x == 0 ? off : 0u);
     SnpMap total;
-    const SnpMap ex = snp_block_scan2(snp_lane_map(m), wave_tot, total);
+    const SnpMap ex = snp_block_scan2(snp_lane_map_of(Lm, m), wave_tot, total);
     const uint32_t bs = win_maps[blockIdx.x].e;
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
     uint32_t idx = bc + ex.c[bs];
