@@ -77,6 +77,7 @@ struct SampleSet {                       // scratch of one sampled range
 };
 struct SnpSet {                          // scratch of one contig's SNP draws
     SnpMap *maps = nullptr; size_t cap = 0;
+    uint8_t *aux8 = nullptr; size_t aux_cap = 0;          // one-range contigs: the outcomes by rank (folded into the records by k_bitmap_expand)
     unsigned long long *base = nullptr;                   // device word: stream position the draws start at
     hipEvent_t emit_done = nullptr;
     bool pending = false;
@@ -222,6 +223,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     }
     for (auto &t : g->snp) {
         if (t.maps) (void)hipFree(t.maps);
+        if (t.aux8) (void)hipFree(t.aux8);
         if (t.base) (void)hipFree(t.base);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
@@ -690,7 +692,10 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
 // SNP draws of a contig's K (kept) SNPs in position order, starting at the device position (ps->snp_base): the chain
 // part (k_snp_scan_cut_abs: exact end of the draws) on the plan stream, the aux bytes (k_snp_emit_abs) on the emit
 // stream.  pos_hi: upper bound of the start position on entry, of the end position on return.
-static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const uint32_t *sn_index, uint64_t &pos_hi, bool &grew) {
+// aux8_out (SNP sampler, one drawing range): the outcomes go to a compact byte array by rank instead of into the records; the
+// caller launches the bitmap expansion behind this stage and hands it that array (*aux8_out).
+static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const uint32_t *sn_index, uint64_t &pos_hi, bool &grew,
+                             uint8_t **aux8_out = nullptr) {
     const msim_params &P = c->params;
     GpuStream &py = g->s[0];
     int rc;
@@ -702,6 +707,10 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
     SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
     if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
     if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
+    if (aux8_out) {
+        if ((rc = grow(c, (void **)&T.aux8, &T.aux_cap, (size_t)K + 64, &grew))) return rc;
+        *aux8_out = T.aux8;
+    }
     if (!T.base) MSIM_HIP(c, hipMalloc(&T.base, 64));
     if (!T.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&T.emit_done, hipEventDisableTiming));
     // words AND absolute maps up to the end of the last window block
@@ -721,10 +730,12 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
         MSIM_HIP(c, hipEventRecord(ce, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
         hipLaunchKernelGGL(k_snp_emit_abs, dim3(nb2), dim3(SNP_THREADS), 0, c->emit_stream, py.d_lanes, T.base, W2,
-                           T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index);
+                           T.maps, nb2, ct.d_recs, (uint32_t)K, sn_index, aux8_out ? T.aux8 : (uint8_t *)nullptr);
         MSIM_HIP(c, hipGetLastError());
-        MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
-        T.pending = true;
+        if (!aux8_out) {                                  // (else: the caller records it behind the expansion that reads aux8)
+            MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+            T.pending = true;
+        }
     }
     pos_hi += W2;
     return MSIM_OK;
@@ -769,6 +780,14 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     }
     uint64_t pos_hi = py.pos;                             // upper bound of the device position
     uint64_t rec_base = 0;
+    // One drawing range (ARGS mode): the SNP outcomes are folded into the records by the expansion, which then runs behind
+    // the SNP stage.  Several ranges keep the order expansion -> outcomes patched in (their bitmaps rotate through N_SETS
+    // scratch sets and cannot all wait for the contig's one SNP stage).
+    int n_draw = 0;
+    for (int i = 0; i < n_ranges; i++) n_draw += ranges[i].k != 0;
+    static const bool no_fold = getenv("MSIM_NO_AUX_FOLD") != nullptr;
+    const bool fold_aux = n_draw == 1 && !c->chain_only && !no_fold;
+    struct { SampleSet *S; uint32_t bmw, bnb, start; } late = {nullptr, 0, 0, 0};
     for (int i = 0; i < n_ranges; i++) {
         const msim_range &r = ranges[i];
         if (r.k == 0) continue;
@@ -785,18 +804,35 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
                                reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2);
             hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, S.cnt2, bnb);
-            hipLaunchKernelGGL(k_bitmap_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
-                               reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
-                               ct.d_recs + rec_base);
-            MSIM_HIP(c, hipGetLastError());
-            MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
-            S.pending = true;
+            if (fold_aux) {                               // the expansion follows the SNP stage (below): it writes complete records
+                late = {&S, bmw, bnb, (uint32_t)r.start};
+            } else {
+                hipLaunchKernelGGL(k_bitmap_expand, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                                   reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2, (uint32_t)r.start, (uint32_t)d,
+                                   ct.d_recs + rec_base, (const uint8_t *)nullptr);
+                MSIM_HIP(c, hipGetLastError());
+                MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
+                S.pending = true;
+            }
         }
         pos_hi += W;
         rec_base += k;
     }
     if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
-        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew))) return rc;
+        uint8_t *aux8 = nullptr;
+        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr))) return rc;
+        if (late.S) {
+            SampleSet &S = *late.S;
+            SnpSet &T = g->snp[(g->snp_unit - 1) % N_SETS];        // (the set enqueue_snp_stage just took)
+            hipLaunchKernelGGL(k_bitmap_expand, dim3(late.bnb), dim3(BM_THREADS), 0, c->emit_stream,
+                               reinterpret_cast<const uint64_t *>(S.bitmap), late.bmw, S.cnt2, late.start, (uint32_t)d,
+                               ct.d_recs, (const uint8_t *)aux8);
+            MSIM_HIP(c, hipGetLastError());
+            MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
+            S.pending = true;
+            MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+            T.pending = true;
+        }
     }
     py.pos = pos_hi;                                       // bound until gpu_plan_finish reads the exact value
     g->s[1].pos += 2 * K;                                  // numpy.random.choice(size=k): 2 words per candidate

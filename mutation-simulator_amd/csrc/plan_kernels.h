@@ -561,7 +561,10 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_count(const uint64_t *__r
 __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__restrict__ bm, uint32_t n_words,
                                                               const uint32_t *__restrict__ block_off,
                                                               uint32_t start, uint32_t d,
-                                                              msim_record *__restrict__ recs) {
+                                                              msim_record *__restrict__ recs,
+                                                              const uint8_t *__restrict__ aux8 = nullptr) {
+    // aux8 (one-range contigs): the SNP outcomes by rank, left there by k_snp_emit_abs -- the records are then written once,
+    // complete, instead of being patched a byte each by the emit pass (a read-modify-write of every record's cache line)
     __shared__ uint32_t part[BM_THREADS];
     const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
     uint64_t w = i < n_words ? bm[i] : 0;
@@ -580,7 +583,7 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__
         w &= w - 1;
         const uint32_t pos = start + (i * 64 + bit) + d * rank;
         msim_record r;
-        r.pos = pos; r.stop = pos; r.extra = 0; r.type = MSIM_SN; r.aux = 0; r.rsv = 0;
+        r.pos = pos; r.stop = pos; r.extra = 0; r.type = MSIM_SN; r.aux = aux8 ? aux8[rank] : (uint8_t)0; r.rsv = 0;
         recs[rank] = r;
         rank++;
     }
@@ -879,7 +882,8 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const SnpLane *__r
                                                               const unsigned long long *__restrict__ base_in, uint32_t W,
                                                               const SnpMap *__restrict__ win_maps, uint32_t nb_max,
                                                               msim_record *__restrict__ recs, uint32_t K,
-                                                              const uint32_t *__restrict__ sn_index) {
+                                                              const uint32_t *__restrict__ sn_index,
+                                                              uint8_t *__restrict__ aux8 = nullptr) {
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     if (blockIdx.x >= win_maps[nb_max].c[1]) return;      // beyond the window (uniform)
     const uint32_t bc = win_maps[blockIdx.x].c[0];
@@ -899,7 +903,9 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const SnpLane *__r
     while (emits && idx < K) {                            // aux: 0 transition, 1/2 transversion column (bit 30)
         const uint32_t i = (uint32_t)__builtin_ctz(emits);
         emits &= emits - 1;
-        recs[sn_index ? sn_index[idx] : idx].aux = (uint8_t)(((from2 >> i) & 1u) ? 1u + ((m.T >> i) & 1u) : 0u);
+        const uint8_t val = (uint8_t)(((from2 >> i) & 1u) ? 1u + ((m.T >> i) & 1u) : 0u);
+        if (aux8) aux8[idx] = val;                        // (compact, by rank: k_bitmap_expand folds it into the record it writes)
+        else recs[sn_index ? sn_index[idx] : idx].aux = val;
         idx++;
     }
 }
