@@ -803,7 +803,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
             hipLaunchKernelGGL(k_bitmap_count, dim3(bnb), dim3(BM_THREADS), 0, c->emit_stream,
                                reinterpret_cast<const uint64_t *>(S.bitmap), bmw, S.cnt2);
-            hipLaunchKernelGGL(k_scan_u32, dim3(1), dim3(1024), 0, c->emit_stream, S.cnt2, bnb);
+            hipLaunchKernelGGL(k_scan_u32_w4, dim3(1), dim3(256), 0, c->emit_stream, S.cnt2, bnb);
             if (fold_aux) {                               // the expansion follows the SNP stage (below): it writes complete records
                 late = {&S, bmw, bnb, (uint32_t)r.start};
             } else {

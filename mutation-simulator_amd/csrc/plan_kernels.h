@@ -565,19 +565,20 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__
                                                               const uint8_t *__restrict__ aux8 = nullptr) {
     // aux8 (one-range contigs): the SNP outcomes by rank, left there by k_snp_emit_abs -- the records are then written once,
     // complete, instead of being patched a byte each by the emit pass (a read-modify-write of every record's cache line)
-    __shared__ uint32_t part[BM_THREADS];
+    __shared__ uint32_t wsum[BM_THREADS / 64];
     const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
     uint64_t w = i < n_words ? bm[i] : 0;
     const uint32_t c = (uint32_t)__popcll(w);
-    part[threadIdx.x] = c;
-    __syncthreads();
-    for (int o = 1; o < BM_THREADS; o <<= 1) {
-        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
+    uint32_t incl = c;                                    // inclusive prefix: shuffles inside the wave, one barrier across waves
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= (unsigned)o) incl += t;
     }
-    uint32_t rank = block_off[blockIdx.x] + part[threadIdx.x] - c;
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    for (uint32_t q = 0; q < (threadIdx.x >> 6); q++) incl += wsum[q];
+    uint32_t rank = block_off[blockIdx.x] + incl - c;
     while (w) {
         const uint32_t bit = (uint32_t)__builtin_ctzll(w);
         w &= w - 1;
