@@ -265,6 +265,7 @@ static Ctx *C(msim_ctx *p) { return reinterpret_cast<Ctx *>(p); }
     if (c) {                                                \
         int flush_rc_ = flush_deferred_apply(c);            \
         if (!flush_rc_ && c->fast) flush_rc_ = fast_plan_flush(c);   /* (fast contexts: the plans queued so far, as one batch) */ \
+        if (!flush_rc_ && c->gpu) flush_rc_ = gpu_emit_flush(c);     /* (SNP sampler: the emission group that is still waiting) */ \
         if (flush_rc_) return flush_rc_;                    \
     }
 #define NEED_GPU(c) do { if ((c)->host_only) return fail((c), MSIM_ERR_HIP, "host-only context: this call needs the GPU"); } while (0)
@@ -489,6 +490,7 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
     // A deferred APPLY of the previous contig (msim_apply_contig) is enqueued when this plan's host chain starts --
     // by the engine itself -- so that it fills the device's idle time instead of competing with this contig's
     // latency-bound chain kernels.  Every other route enqueues it now.
+    if (c->gpu && (!gpu_ok || gpu_emit_pending(c, contig, false)) && (rc = gpu_emit_flush(c))) return rc;   // (another engine / planned again)
     const bool host_chain = mixed_ok || hs_ok || mm_ok;
     const bool engine_flushes = host_chain && c->deferred_apply != contig;
     if (!engine_flushes && (rc = flush_deferred_apply(c))) return rc;
@@ -604,6 +606,8 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     if (!c) return MSIM_ERR_ARG;
     // fast contexts: a contig whose plan is still queued gets its APPLY enqueued right behind the batch (plan_fast.hip)
     if (c->fast && fast_plan_queued(c, contig, true)) return MSIM_OK;
+    // SNP sampler: a contig whose emission still waits for its group is applied right behind that group (plan_gpu.hip)
+    if (c->gpu && gpu_emit_pending(c, contig, true)) return MSIM_OK;
     {
         int rc = flush_deferred_apply(c);
         if (!rc && c->fast) rc = fast_plan_flush(c);

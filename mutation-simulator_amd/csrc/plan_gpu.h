@@ -31,6 +31,11 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
 // words, accept tables and candidate types
 bool gpu_plan_multimix_eligible(const Ctx *c, GpuPlan *g, uint64_t L, const msim_range *ranges, int n_ranges);
 int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, int n_ranges);
+// SNP sampler: contigs with one drawing range queue their emission (records, SNP outcomes) and go through its stages in groups;
+// gpu_emit_flush sends what is queued (every entry point that needs a result does), gpu_emit_pending tells whether a contig is
+// still queued (mark_apply: its APPLY follows its group's emission -- msim_apply_contig)
+int gpu_emit_flush(Ctx *c);
+bool gpu_emit_pending(Ctx *c, int contig, bool mark_apply);
 int gpu_plan_force_overflow(Ctx *c, GpuPlan *g);          // test support
 
 void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]);

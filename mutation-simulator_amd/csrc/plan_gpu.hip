@@ -83,6 +83,10 @@ struct SnpSet {                          // scratch of one contig's SNP draws
     bool pending = false;
 };
 
+struct SnpDefer { SnpSet *T; uint32_t W2, nb2; };           // what a deferred emit pass needs (enqueue_snp_stage)
+// A contig whose chain is enqueued and whose emission waits for its group (plan_kernels.h: EmitJobs)
+struct EmitItem { int contig; SampleSet *S; SnpSet *T; uint32_t bmw, bnb, start, K, W2, nb2; msim_record *recs; bool apply; };
+
 struct MixedSet {                        // scratch of one SV-mix range (section 6)
     uint32_t *cand_pos = nullptr; size_t cap_pos = 0;     // candidates in position order
     uint8_t *cand_type = nullptr; size_t cap_type = 0;    // MSIM_* id | KEEP_BIT
@@ -146,6 +150,8 @@ struct GpuPlan {
     hipEvent_t t0 = nullptr, t1 = nullptr;   // chain-time span since the last finish
     bool ps_valid = false;              // device PlanState carries the current session's position
     bool unverified = false;            // work enqueued since the last finish (flags / exact position unknown)
+    std::vector<EmitItem> emit_items;   // SNP sampler: contigs waiting for their emission group (gpu_emit_flush)
+    uint32_t emit_d = 1;                //   ... and the sampling distance they share
     uint64_t verified_pos = 0;          // exact position at the last finish
     uint64_t reserve_words[2] = {0, 0};
 };
@@ -561,6 +567,10 @@ bool gpu_plan_eligible(const Ctx *c, const msim_range *ranges, int n_ranges) {
 
 // Everything enqueued so far has completed: collect the sticky flags and the exact stream position.
 int gpu_plan_finish(Ctx *c, GpuPlan *g) {
+    {
+        const int rc = gpu_emit_flush(c);                  // (a group that is still waiting goes out now)
+        if (rc) return rc;
+    }
     if (!g->unverified) return MSIM_OK;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
     MSIM_HIP(c, hipGetLastError());
@@ -694,8 +704,9 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
 // stream.  pos_hi: upper bound of the start position on entry, of the end position on return.
 // aux8_out (SNP sampler, one drawing range): the outcomes go to a compact byte array by rank instead of into the records; the
 // caller launches the bitmap expansion behind this stage and hands it that array (*aux8_out).
+// defer (with aux8_out): the emit pass is not launched here at all -- the caller queues it for the contig's emission group.
 static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const uint32_t *sn_index, uint64_t &pos_hi, bool &grew,
-                             uint8_t **aux8_out = nullptr) {
+                             uint8_t **aux8_out = nullptr, SnpDefer *defer = nullptr) {
     const msim_params &P = c->params;
     GpuStream &py = g->s[0];
     int rc;
@@ -725,7 +736,8 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
     hipLaunchKernelGGL(k_snp_scan_cut_abs, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_lanes, g->d_ps, W2,
                        py.d_maps, T.maps, nb2, (uint32_t)K, T.base);
     MSIM_HIP(c, hipGetLastError());
-    if (!c->chain_only) {                                 // (chain only: where the draws END is all that is wanted)
+    if (defer) { defer->T = &T; defer->W2 = W2; defer->nb2 = nb2; }
+    if (!c->chain_only && !defer) {                       // (chain only: where the draws END is all that is wanted)
         hipEvent_t ce = next_chain_event(g);
         MSIM_HIP(c, hipEventRecord(ce, c->stream));
         MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, ce, 0));
@@ -739,6 +751,59 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
     }
     pos_hi += W2;
     return MSIM_OK;
+}
+
+// The emission group: count, scan, SNP outcomes and expansion of every queued contig in one launch per stage on the emission
+// stream, behind the chain of the last one; then the APPLYs msim_apply_contig marked (one tile-index launch for all of them,
+// apply.hip: apply_batch_device), the rewrite kernels back to back.
+int gpu_emit_flush(Ctx *c) {
+    GpuPlan *g = c->gpu;
+    if (!g || g->emit_items.empty()) return MSIM_OK;
+    std::vector<EmitItem> items;
+    items.swap(g->emit_items);
+    EmitJobs J;
+    memset(&J, 0, sizeof J);
+    J.n = (uint32_t)items.size();
+    J.d = g->emit_d;
+    uint32_t blk = 0, eblk = 0;
+    for (uint32_t i = 0; i < J.n; i++) {
+        const EmitItem &it = items[i];
+        EmitJob &T = J.j[i];
+        T.bm = reinterpret_cast<const uint64_t *>(it.S->bitmap); T.cnt2 = it.S->cnt2; T.recs = it.recs; T.aux8 = it.T->aux8;
+        T.base = it.T->base; T.win_maps = it.T->maps;
+        T.bmw = it.bmw; T.bnb = it.bnb; T.start = it.start; T.K = it.K; T.W2 = it.W2; T.nb2 = it.nb2; T.blk0 = blk; T.eblk0 = eblk;
+        blk += it.bnb; eblk += it.nb2;
+    }
+    J.total_blk = blk; J.total_eblk = eblk;
+    hipStream_t es = c->emit_stream;
+    hipEvent_t ce = next_chain_event(g);
+    MSIM_HIP(c, hipEventRecord(ce, c->stream));
+    MSIM_HIP(c, hipStreamWaitEvent(es, ce, 0));
+    hipLaunchKernelGGL(k_bitmap_count_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
+    hipLaunchKernelGGL(k_scan_u32_b, dim3(J.n), dim3(256), 0, es, J);
+    hipLaunchKernelGGL(k_snp_emit_abs_b, dim3(eblk), dim3(SNP_THREADS), 0, es, g->s[0].d_lanes, J);
+    hipLaunchKernelGGL(k_bitmap_expand_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
+    MSIM_HIP(c, hipGetLastError());
+    std::vector<int> applies;
+    for (const EmitItem &it : items) {
+        MSIM_HIP(c, hipEventRecord(it.S->emit_done, es));
+        it.S->pending = true;
+        MSIM_HIP(c, hipEventRecord(it.T->emit_done, es));
+        it.T->pending = true;
+        if (it.apply && (size_t)it.contig < c->contigs.size()) {
+            c->contigs[(size_t)it.contig].apply_stream = es;      // (apply_batch_device takes contigs with a stream of their own)
+            applies.push_back(it.contig);
+        }
+    }
+    return applies.empty() ? MSIM_OK : apply_batch_device(c, applies);
+}
+
+bool gpu_emit_pending(Ctx *c, int contig, bool mark_apply) {
+    GpuPlan *g = c->gpu;
+    if (!g) return false;
+    for (EmitItem &it : g->emit_items)
+        if (it.contig == contig) { if (mark_apply) it.apply = true; return true; }
+    return false;
 }
 
 // Asynchronous: enqueues the contig's chain (stream positions) on the plan stream and its emit work
@@ -787,6 +852,11 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     for (int i = 0; i < n_ranges; i++) n_draw += ranges[i].k != 0;
     static const bool no_fold = getenv("MSIM_NO_AUX_FOLD") != nullptr;
     const bool fold_aux = n_draw == 1 && !c->chain_only && !no_fold;
+    // ... and such contigs go through the emission stages in groups of EMIT_G (gpu_emit_flush), one launch per stage
+    static const bool no_group = getenv("MSIM_NO_EMIT_GROUP") != nullptr;
+    const bool grouped = fold_aux && !no_group;
+    if (grouped && !g->emit_items.empty() && g->emit_d != (uint32_t)d)
+        if ((rc = gpu_emit_flush(c))) return rc;
     struct { SampleSet *S; uint32_t bmw, bnb, start; } late = {nullptr, 0, 0, 0};
     for (int i = 0; i < n_ranges; i++) {
         const msim_range &r = ranges[i];
@@ -796,7 +866,9 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if ((rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl))) return rc;
         SampleSet &S = *sl.S;
         const uint32_t W = sl.W, bmw = sl.bmw, bnb = sl.bnb;
-        if (!c->chain_only) {
+        if (grouped) {
+            late = {&S, bmw, bnb, (uint32_t)r.start};
+        } else if (!c->chain_only) {
             hipEvent_t ce = next_chain_event(g);
             MSIM_HIP(c, hipEventRecord(ce, c->stream));
             // ---- emit (emit stream): the bitmap is the sorted sample -> records
@@ -820,8 +892,17 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     }
     if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
         uint8_t *aux8 = nullptr;
-        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr))) return rc;
-        if (late.S) {
+        SnpDefer df{nullptr, 0, 0};
+        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr, grouped ? &df : nullptr))) return rc;
+        if (grouped) {
+            g->emit_d = (uint32_t)d;
+            g->emit_items.push_back(EmitItem{ct.index, late.S, df.T, late.bmw, late.bnb, late.start, (uint32_t)K, df.W2, df.nb2,
+                                             ct.d_recs, false});
+            // (pairs: 4.29-4.33 ms per c2 step; threes 4.29-4.45, fours 4.27-4.51, eights 4.55 -- larger groups bunch the rewrite
+            //  kernels and lengthen what is left to do behind the last chain; one per group = the ungrouped 4.6-5.1)
+            static const int group = getenv("MSIM_EMIT_GROUP") ? std::min(EMIT_G, std::max(1, atoi(getenv("MSIM_EMIT_GROUP")))) : 2;
+            if (g->emit_items.size() >= (size_t)group && (rc = gpu_emit_flush(c))) return rc;
+        } else if (late.S) {
             SampleSet &S = *late.S;
             SnpSet &T = g->snp[(g->snp_unit - 1) % N_SETS];        // (the set enqueue_snp_stage just took)
             hipLaunchKernelGGL(k_bitmap_expand, dim3(late.bnb), dim3(BM_THREADS), 0, c->emit_stream,

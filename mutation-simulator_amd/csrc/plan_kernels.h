@@ -546,27 +546,56 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
 }
 
 // ------------------------------------------------------------------ 4. bitmap -> sorted positions
-__global__ __launch_bounds__(BM_THREADS) void k_bitmap_count(const uint64_t *__restrict__ bm, uint32_t n_words,
-                                                             uint32_t *__restrict__ block_cnt) {
-    __shared__ uint32_t red[BM_THREADS / 64];
-    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+__device__ __forceinline__ void bitmap_count_body(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                  uint32_t *__restrict__ block_cnt, uint32_t blk, uint32_t *red) {
+    const uint32_t i = blk * BM_THREADS + threadIdx.x;
     uint32_t c = i < n_words ? (uint32_t)__popcll(bm[i]) : 0;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) block_cnt[blk] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_count(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                             uint32_t *__restrict__ block_cnt) {
+    __shared__ uint32_t red[BM_THREADS / 64];
+    bitmap_count_body(bm, n_words, block_cnt, blockIdx.x, red);
+}
+
+// ---- the emission of several contigs in ONE launch per stage (SNP sampler, one drawing range per contig).  A contig's emission
+// is a train of five small kernels (count, scan, outcomes, expansion, tile index) in front of its rewrite kernel; per contig they
+// cost as much in launch gaps as in work, and that train -- not the chain -- bounded a c2 step.  The contigs whose chains have
+// completed wait for each other in groups of EMIT_G and go through each stage together; jobs travel as kernel arguments.
+constexpr int EMIT_G = 8;                                // jobs a launch can carry (the group size is chosen at run time)
+struct SnpMap;
+struct EmitJob {
+    const uint64_t *bm; uint32_t *cnt2; msim_record *recs; uint8_t *aux8;
+    const unsigned long long *base; const SnpMap *win_maps;
+    uint32_t bmw, bnb, start, K, W2, nb2, blk0, eblk0;       // blk0 / eblk0: the job's first block in the bitmap / the emit grids
+};
+struct EmitJobs { EmitJob j[EMIT_G]; uint32_t n, d, total_blk, total_eblk; };
+__device__ __forceinline__ uint32_t emit_job_of(const EmitJobs &J, uint32_t blk, bool emit_grid) {
+    uint32_t k = 0;
+    for (uint32_t q = 1; q < J.n; q++) if ((emit_grid ? J.j[q].eblk0 : J.j[q].blk0) <= blk) k = q;
+    return k;
+}
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_count_b(EmitJobs J) {
+    __shared__ uint32_t red[BM_THREADS / 64];
+    const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, false)];
+    bitmap_count_body(T.bm, T.bmw, T.cnt2, blockIdx.x - T.blk0, red);
+}
+__global__ __launch_bounds__(256) void k_scan_u32_b(EmitJobs J) {           // one workgroup per job
+    __shared__ uint32_t wsum[4];
+    scan_rounds<16, 4>(J.j[blockIdx.x].cnt2, J.j[blockIdx.x].bnb, wsum);
 }
 
 // record i of the range: pos = start + value + d * rank (util.py:104-109), type SN, stop = pos
-__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__restrict__ bm, uint32_t n_words,
-                                                              const uint32_t *__restrict__ block_off,
-                                                              uint32_t start, uint32_t d,
-                                                              msim_record *__restrict__ recs,
-                                                              const uint8_t *__restrict__ aux8 = nullptr) {
-    // aux8 (one-range contigs): the SNP outcomes by rank, left there by k_snp_emit_abs -- the records are then written once,
-    // complete, instead of being patched a byte each by the emit pass (a read-modify-write of every record's cache line)
-    __shared__ uint32_t wsum[BM_THREADS / 64];
-    const uint32_t i = blockIdx.x * BM_THREADS + threadIdx.x;
+// aux8 (one-range contigs): the SNP outcomes by rank, left there by k_snp_emit_abs -- the records are then written once,
+// complete, instead of being patched a byte each by the emit pass (a read-modify-write of every record's cache line)
+__device__ __forceinline__ void bitmap_expand_body(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                   const uint32_t *__restrict__ block_off, uint32_t start, uint32_t d,
+                                                   msim_record *__restrict__ recs, const uint8_t *__restrict__ aux8,
+                                                   uint32_t blk, uint32_t *wsum) {
+    const uint32_t i = blk * BM_THREADS + threadIdx.x;
     uint64_t w = i < n_words ? bm[i] : 0;
     const uint32_t c = (uint32_t)__popcll(w);
     uint32_t incl = c;                                    // inclusive prefix: shuffles inside the wave, one barrier across waves
@@ -578,7 +607,7 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__
     if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
     __syncthreads();
     for (uint32_t q = 0; q < (threadIdx.x >> 6); q++) incl += wsum[q];
-    uint32_t rank = block_off[blockIdx.x] + incl - c;
+    uint32_t rank = block_off[blk] + incl - c;
     while (w) {
         const uint32_t bit = (uint32_t)__builtin_ctzll(w);
         w &= w - 1;
@@ -588,6 +617,19 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__
         recs[rank] = r;
         rank++;
     }
+}
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                              const uint32_t *__restrict__ block_off,
+                                                              uint32_t start, uint32_t d,
+                                                              msim_record *__restrict__ recs,
+                                                              const uint8_t *__restrict__ aux8 = nullptr) {
+    __shared__ uint32_t wsum[BM_THREADS / 64];
+    bitmap_expand_body(bm, n_words, block_off, start, d, recs, aux8, blockIdx.x, wsum);
+}
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand_b(EmitJobs J) {
+    __shared__ uint32_t wsum[BM_THREADS / 64];
+    const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, false)];
+    bitmap_expand_body(T.bm, T.bmw, T.cnt2, T.start, J.d, T.recs, T.aux8, blockIdx.x - T.blk0, wsum);
 }
 
 // ------------------------------------------------------------------ 5. SNP ti/tv transducer
@@ -879,24 +921,21 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const SnpLane 
 }
 
 // aux of every SNP record (off the critical path; runs on the emit stream).  Window block j = absolute block b0 + j.
-__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const SnpLane *__restrict__ lanes,
-                                                              const unsigned long long *__restrict__ base_in, uint32_t W,
-                                                              const SnpMap *__restrict__ win_maps, uint32_t nb_max,
-                                                              msim_record *__restrict__ recs, uint32_t K,
-                                                              const uint32_t *__restrict__ sn_index,
-                                                              uint8_t *__restrict__ aux8 = nullptr) {
-    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
-    if (blockIdx.x >= win_maps[nb_max].c[1]) return;      // beyond the window (uniform)
-    const uint32_t bc = win_maps[blockIdx.x].c[0];
+__device__ __forceinline__ void snp_emit_body(const SnpLane *__restrict__ lanes, const unsigned long long *__restrict__ base_in,
+                                              uint32_t W, const SnpMap *__restrict__ win_maps, uint32_t nb_max,
+                                              msim_record *__restrict__ recs, uint32_t K, const uint32_t *__restrict__ sn_index,
+                                              uint8_t *__restrict__ aux8, uint32_t blk, SnpMap *wave_tot) {
+    if (blk >= win_maps[nb_max].c[1]) return;             // beyond the window (uniform)
+    const uint32_t bc = win_maps[blk].c[0];
     if (bc >= K) return;                                  // window slack beyond the last SNP (uniform)
     const unsigned long long p0 = *base_in;
     const uint32_t b0 = (uint32_t)(p0 / SNP_BLOCK2), off = (uint32_t)(p0 % SNP_BLOCK2);
     const uint32_t w_end = (uint32_t)min<unsigned long long>(p0 + W, 0xffffffffull);
-    const SnpLane Lm = lanes[(size_t)(b0 + blockIdx.x) * SNP_THREADS + threadIdx.x];
-    const SnpBits m = snp_bits_of(Lm, (b0 + blockIdx.x) * SNP_BLOCK2, w_end, blockIdx.x == 0 ? off : 0u);
+    const SnpLane Lm = lanes[(size_t)(b0 + blk) * SNP_THREADS + threadIdx.x];
+    const SnpBits m = snp_bits_of(Lm, (b0 + blk) * SNP_BLOCK2, w_end, blk == 0 ? off : 0u);
     SnpMap total;
     const SnpMap ex = snp_block_scan2(snp_lane_map_of(Lm, m), wave_tot, total);
-    const uint32_t bs = win_maps[blockIdx.x].e;
+    const uint32_t bs = win_maps[blk].e;
     const uint32_t st = (ex.e >> (2 * bs)) & 3;
     uint32_t idx = bc + ex.c[bs];
     uint32_t emits, from2;
@@ -909,6 +948,20 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const SnpLane *__r
         else recs[sn_index ? sn_index[idx] : idx].aux = val;
         idx++;
     }
+}
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs(const SnpLane *__restrict__ lanes,
+                                                              const unsigned long long *__restrict__ base_in, uint32_t W,
+                                                              const SnpMap *__restrict__ win_maps, uint32_t nb_max,
+                                                              msim_record *__restrict__ recs, uint32_t K,
+                                                              const uint32_t *__restrict__ sn_index,
+                                                              uint8_t *__restrict__ aux8 = nullptr) {
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    snp_emit_body(lanes, base_in, W, win_maps, nb_max, recs, K, sn_index, aux8, blockIdx.x, wave_tot);
+}
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs_b(const SnpLane *__restrict__ lanes, EmitJobs J) {
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, true)];
+    snp_emit_body(lanes, T.base, T.W2, T.win_maps, T.nb2, T.recs, T.K, nullptr, T.aux8, blockIdx.x - T.eblk0, wave_tot);
 }
 
 // ------------------------------------------------------------------ 6. SV mixes: candidates, types, filter
