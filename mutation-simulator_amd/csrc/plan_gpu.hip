@@ -855,7 +855,12 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     // ... and such contigs go through the emission stages in groups of EMIT_G (gpu_emit_flush), one launch per stage
     static const bool no_group = getenv("MSIM_NO_EMIT_GROUP") != nullptr;
     const bool grouped = fold_aux && !no_group;
-    if (grouped && !g->emit_items.empty() && g->emit_d != (uint32_t)d)
+    // A full group goes out when the NEXT contig is planned, in front of its chain: by then msim_apply_contig has marked the
+    // group's last contig too, so all of its APPLYs share the group's tile-index launch.
+    // (threes: 4.24-4.30 ms per c2 step; pairs 4.26-4.5, fours 4.45-4.5, eights 4.55 -- larger groups bunch the rewrite
+    //  kernels and lengthen what is left to do behind the last chain; one per group = the ungrouped 4.6-5.1)
+    static const int group = getenv("MSIM_EMIT_GROUP") ? std::min(EMIT_G, std::max(1, atoi(getenv("MSIM_EMIT_GROUP")))) : 3;
+    if (!g->emit_items.empty() && (!grouped || g->emit_d != (uint32_t)d || g->emit_items.size() >= (size_t)group))
         if ((rc = gpu_emit_flush(c))) return rc;
     struct { SampleSet *S; uint32_t bmw, bnb, start; } late = {nullptr, 0, 0, 0};
     for (int i = 0; i < n_ranges; i++) {
@@ -898,10 +903,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             g->emit_d = (uint32_t)d;
             g->emit_items.push_back(EmitItem{ct.index, late.S, df.T, late.bmw, late.bnb, late.start, (uint32_t)K, df.W2, df.nb2,
                                              ct.d_recs, false});
-            // (pairs: 4.29-4.33 ms per c2 step; threes 4.29-4.45, fours 4.27-4.51, eights 4.55 -- larger groups bunch the rewrite
-            //  kernels and lengthen what is left to do behind the last chain; one per group = the ungrouped 4.6-5.1)
-            static const int group = getenv("MSIM_EMIT_GROUP") ? std::min(EMIT_G, std::max(1, atoi(getenv("MSIM_EMIT_GROUP")))) : 2;
-            if (g->emit_items.size() >= (size_t)group && (rc = gpu_emit_flush(c))) return rc;
+            if (g->emit_items.size() >= (size_t)EMIT_G && (rc = gpu_emit_flush(c))) return rc;   // (the launch's job table is full)
         } else if (late.S) {
             SampleSet &S = *late.S;
             SnpSet &T = g->snp[(g->snp_unit - 1) % N_SETS];        // (the set enqueue_snp_stage just took)
