@@ -221,7 +221,11 @@ int msim_build_ranges(const msim_settings_desc *sets, int n_sets, const int64_t 
  * kernel on another, overlapping the next contig's chain.  (The SV-mix and host-cut engines wait inside
  * msim_plan_contig for the device data their host chain reads -- the boundary walk, the stream cuts.)  Deferred outcomes (the reference's KeyError, an
  * internal window overflow) are reported by the next call that synchronises: msim_sync,
- * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats, the text calls. */
+ * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats, the text calls.
+ * Enqueued does not mean launched at once: contigs the SNP sampler planned from ONE drawing range (ARGS mode) gather in groups
+ * of three whose emission stages and tile index go to the device as one launch each, their rewrite kernels behind them --
+ * when the next msim_plan_contig arrives or at any other entry point, whichever comes first (plan + apply a whole genome,
+ * then ask: that is the fast order; asking after every contig is as correct and launches per contig).                  */
 int msim_apply_contig(msim_ctx *ctx, int contig);
 /* If apply hit the reference's KeyError: the offending (ambiguity-converted) base and position.
  * contig == -1: the first contig (in index order) that hit it.                                    */
