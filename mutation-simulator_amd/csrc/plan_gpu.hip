@@ -677,15 +677,19 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     hipLaunchKernelGGL(k_accept_count, dim3(nb), dim3(ACC_THREADS), 0, c->stream, raw, ps, W,
                        (uint32_t)(32 - bits), (uint32_t)n, S.cnt, ps, binned ? S.cursors : nullptr,
                        binned ? n_bins * BIN_SUBS : 0u);
-    hipLaunchKernelGGL(k_scan_u32_w4, dim3(1), dim3(256), 0, c->stream, S.cnt, nb);   // (four waves: see the kernel)
+    // the counts' prefix sums: made by their two consumers themselves where the tail kernel can hold them in LDS (every real
+    // contig) -- a launch less on the chain; else by a scan of their own
+    static const bool no_fold_scan = getenv("MSIM_NO_SCAN_FOLD") != nullptr;
+    const uint32_t raw_counts = (binned && nb < (uint32_t)TAIL_LDS_OFFS && !no_fold_scan) ? 1u : 0u;
+    if (!raw_counts) hipLaunchKernelGGL(k_scan_u32_w4, dim3(1), dim3(256), 0, c->stream, S.cnt, nb);   // (four waves: see the kernel)
     if (binned) {
         hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, c->stream, raw, ps, W,
                            (uint32_t)(32 - bits), (uint32_t)n, k, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc,
-                           ps);
+                           ps, raw_counts);
         hipLaunchKernelGGL(k_bin_dedupe, dim3(n_bins), dim3(512), 0, c->stream, S.bins, S.cursors, bin_cap, S.bitmap,
                            ps);
         hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, raw, S.acc, k, S.cnt, nb, W,
-                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, ps);
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, ps, raw_counts);
     } else {
         MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
         hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, raw, ps, W,

@@ -305,6 +305,22 @@ __global__ __launch_bounds__(256) void k_bitmap_insert(const uint32_t *__restric
 }
 
 // ---- locality-friendly de-dup: bins of 2^20 values, each de-duplicated in a 128 KB LDS bitmap ----
+// inclusive prefix sum over the workgroup: shuffles inside a wave, one barrier across the waves (wsum: one word per wave; the
+// caller puts a barrier between two uses of the same wsum)
+__device__ __forceinline__ uint32_t wg_scan_incl(uint32_t v, uint32_t *wsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) incl += wsum[w];
+    return incl;
+}
+
 constexpr int BIN_SHIFT = 20;
 constexpr int BIN_VALUES = 1 << BIN_SHIFT;
 constexpr int BIN_WORDS = BIN_VALUES / 32;               // 32768 x u32 = 128 KB
@@ -325,9 +341,12 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_scatter(const uint32_t *__r
                                                              const uint32_t *__restrict__ block_off, uint32_t n_bins,
                                                              uint32_t bin_cap, uint32_t *__restrict__ cursors,
                                                              uint32_t *__restrict__ bins, uint32_t *__restrict__ tail,
-                                                             PlanState *ps_rw) {
+                                                             PlanState *ps_rw, uint32_t raw_counts) {
+    // raw_counts: block_off holds k_accept_count's COUNTS, not their prefix sums -- every workgroup adds up the counts in front
+    // of its first block itself (a few loads per lane), which takes the scan kernel and its launch off the chain
     __shared__ uint32_t stage[SPL_LDS];
-    __shared__ uint32_t part[ACC_THREADS];
+    __shared__ uint32_t wsum[ACC_THREADS / 64], wsum2[ACC_THREADS / 64], wsum3[ACC_THREADS / 64];
+    __shared__ uint32_t s_total;
     __shared__ uint32_t lhist[MAX_BINS];
     __shared__ uint32_t lbase[MAX_BINS + 1];
     __shared__ uint32_t gbase[MAX_BINS];
@@ -357,15 +376,18 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_scatter(const uint32_t *__r
         vals[q] = stage[threadIdx.x * 33 + q];
         c += vals[q] != 0xffffffffu ? 1u : 0u;
     }
-    part[threadIdx.x] = c;
-    __syncthreads();
-    for (int o = 1; o < ACC_THREADS; o <<= 1) {
-        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+    uint32_t before;                                      // accepted draws in front of this workgroup's words
+    if (raw_counts) {
+        uint32_t t = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x * (SPL_BLOCK / ACC_BLOCK); i += ACC_THREADS) t += block_off[i];
+        const uint32_t incl = wg_scan_incl(t, wsum3);
+        if (threadIdx.x == ACC_THREADS - 1) s_total = incl;
         __syncthreads();
-        part[threadIdx.x] += t;
-        __syncthreads();
+        before = s_total;
+    } else {
+        before = block_off[blockIdx.x * (SPL_BLOCK / ACC_BLOCK)];
     }
-    uint32_t a = block_off[blockIdx.x * (SPL_BLOCK / ACC_BLOCK)] + part[threadIdx.x] - c;   // accepted index
+    uint32_t a = before + wg_scan_incl(c, wsum) - c;      // accepted index
     uint32_t slot[SPL_ITEMS];
 #pragma unroll
     for (int q = 0; q < SPL_ITEMS; q++) {
@@ -386,15 +408,8 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_scatter(const uint32_t *__r
             h[q] = b < n_bins ? lhist[b] : 0;
             sum += h[q];
         }
-        part[threadIdx.x] = sum;
-        __syncthreads();
-        for (int o = 1; o < ACC_THREADS; o <<= 1) {
-            const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
-            __syncthreads();
-            part[threadIdx.x] += t;
-            __syncthreads();
-        }
-        uint32_t run = part[threadIdx.x] - sum;
+        const uint32_t incl_h = wg_scan_incl(sum, wsum2);
+        uint32_t run = incl_h - sum;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t b = threadIdx.x * 4 + q;
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(ACC_THREADS) void k_bin_scatter(const uint32_t *__r
             }
             run += h[q];
         }
-        if (threadIdx.x == ACC_THREADS - 1) lbase[MAX_BINS] = part[ACC_THREADS - 1];   // total placed
+        if (threadIdx.x == ACC_THREADS - 1) lbase[MAX_BINS] = incl_h;   // total placed
     }
     __syncthreads();
 #pragma unroll
@@ -464,14 +479,37 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
                                                       uint32_t acc_first,
                                                       const uint32_t *__restrict__ block_off, uint32_t n_blocks,
                                                       uint32_t W, uint32_t shift, uint32_t n, uint32_t k,
-                                                      uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps) {
+                                                      uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps,
+                                                      uint32_t raw_counts = 0) {
+    // raw_counts (n_blocks <= TAIL_LDS_OFFS): block_off holds k_accept_count's counts; their prefix sums are made here, in LDS
     __shared__ uint32_t red[16];
-    __shared__ uint32_t s_need, s_pos, s_blk;
+    __shared__ uint32_t s_need, s_pos, s_blk, s_total;
     __shared__ uint32_t loff[TAIL_LDS_OFFS + 1];
     const bool offs_in_lds = n_blocks <= TAIL_LDS_OFFS;
-    if (offs_in_lds)
-        for (uint32_t i = threadIdx.x; i <= n_blocks; i += 1024) loff[i] = block_off[i];
-    const uint32_t total_acc = block_off[n_blocks];
+    uint32_t total_acc;
+    if (raw_counts) {                                      // eight consecutive counts per lane, one workgroup scan
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = threadIdx.x * 8 + q;
+            v[q] = i < n_blocks ? block_off[i] : 0;
+            sum += v[q];
+        }
+        uint32_t run = wg_scan_incl(sum, red) - sum;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = threadIdx.x * 8 + q;
+            if (i <= n_blocks) loff[i] = run;              // (entry n_blocks: the total)
+            run += v[q];
+        }
+        if (threadIdx.x == 1023) s_total = run;
+        __syncthreads();
+        total_acc = s_total;
+    } else {
+        if (offs_in_lds)
+            for (uint32_t i = threadIdx.x; i <= n_blocks; i += 1024) loff[i] = block_off[i];
+        total_acc = block_off[n_blocks];
+    }
     if (threadIdx.x == 0) { s_pos = k; s_need = ps->dups; }
     __syncthreads();
     if (total_acc < k) {                                  // window too small even for the first k
