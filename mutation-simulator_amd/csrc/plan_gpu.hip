@@ -57,6 +57,11 @@ struct GpuStream {
     std::vector<uint32_t> ready_hi;
     std::vector<hipEvent_t> words_ev;   // ... and words_ev[b] as soon as its words are there (the SNP maps of the batch follow)
     uint32_t waited_words = 0;          // the plan stream already waited for the WORDS of chunks below this
+    // A session's first two cascade levels and its first generation batch run ON the plan stream (nothing else is there yet and
+    // the first contig's chain waits for exactly them): every hand-over between streams costs 50-80 us of idle queue, three of
+    // them sat in front of the first chain kernel.  casc_ev: behind the last such launch, for the jump stream to wait on.
+    hipEvent_t casc_ev = nullptr;
+    bool casc_pending = false;
     std::vector<hipEvent_t> ready_ev;
     uint32_t waited_chunks = 0;         // the plan stream already waited for chunks below this
 };
@@ -216,6 +221,7 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (s.d_lanes) (void)hipFree(s.d_lanes);
         for (auto e : s.ready_ev) (void)hipEventDestroy(e);
         for (auto e : s.words_ev) if (e) (void)hipEventDestroy(e);
+        if (s.casc_ev) (void)hipEventDestroy(s.casc_ev);
     }
     for (auto e : g->ev_pool) (void)hipEventDestroy(e);
     for (auto &t : g->sample) {
@@ -362,6 +368,14 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
                 s.cap = want_cap;
             }
         }
+        static const bool lead_on_plan = getenv("MSIM_NO_LEAD_ON_PLAN") == nullptr;
+        auto join_plan_cascade = [&]() -> int {             // the jump stream continues behind what the plan stream did of the cascade
+            if (s.casc_pending) {
+                MSIM_HIP(c, hipStreamWaitEvent(g->jump_stream, s.casc_ev, 0));
+                s.casc_pending = false;
+            }
+            return MSIM_OK;
+        };
         auto take_event = [&](hipEvent_t &ev) -> int {
             if (!g->ev_pool.empty()) { ev = g->ev_pool.back(); g->ev_pool.pop_back(); }
             else MSIM_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -373,23 +387,34 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
             // cascade level is ~10-30 us: the first batch waits for the second level (256 chunks) instead of
             // going out with the 16 states of the first
             if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, (uint32_t)(MT_JUMP_RADIX[0] * MT_JUMP_RADIX[1]))) {
-                // states [n_chunks, hi) are complete on the jump stream: generate those chunks
-                hipEvent_t st_ev;
-                int rc = take_event(st_ev);
-                if (rc) return rc;
-                MSIM_HIP(c, hipEventRecord(st_ev, g->jump_stream));
-                MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, st_ev, 0));
-                s.ready_ev.push_back(st_ev);                // recycled with the batch events at the next reseed
-                s.ready_hi.push_back(0);
-                s.words_ev.push_back(nullptr);
-                hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(GEN_THREADS), 0, g->gen_stream, s.d_states,
+                // states [n_chunks, hi) are complete: generate those chunks (the session's first batch on the plan stream itself,
+                // right behind the cascade levels that ran there; later ones on the generation stream behind the jump stream)
+                const bool first = lead_on_plan && s.n_chunks == 0 && s.casc_pending;
+                hipStream_t gs = first ? c->stream : g->gen_stream;
+                int rc = MSIM_OK;
+                if (!first) {
+                    if ((rc = join_plan_cascade())) return rc;
+                    hipEvent_t st_ev;
+                    rc = take_event(st_ev);
+                    if (rc) return rc;
+                    MSIM_HIP(c, hipEventRecord(st_ev, g->jump_stream));
+                    MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, st_ev, 0));
+                    s.ready_ev.push_back(st_ev);            // recycled with the batch events at the next reseed
+                    s.ready_hi.push_back(0);
+                    s.words_ev.push_back(nullptr);
+                }
+                hipLaunchKernelGGL(k_mt_generate, dim3(hi - s.n_chunks), dim3(GEN_THREADS), 0, gs, s.d_states,
                                    s.d_raw, s.n_chunks);
                 MSIM_HIP(c, hipGetLastError());
                 hipEvent_t wev = nullptr;
-                if (si == 0) {
+                if (si == 0 || first) {
                     rc = take_event(wev);
                     if (rc) return rc;
-                    MSIM_HIP(c, hipEventRecord(wev, g->gen_stream));
+                    MSIM_HIP(c, hipEventRecord(wev, gs));
+                    if (first) {                            // the map pass (and whatever follows there) stays on the generation stream
+                        MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, wev, 0));
+                        s.waited_words = hi;                // (the plan stream made these words itself)
+                    }
                 }
                 if (si == 0) {                              // SNP transducer maps of every block the batch completed
                     const uint32_t n_words = (uint32_t)(MT_N + (uint64_t)hi * MT_CHUNK_WORDS);
@@ -420,22 +445,31 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
                 const uint32_t m_need = std::min<uint32_t>(R - 1, (need_chunks + s.n_src - 1) / s.n_src - 1);
                 uint32_t level_base = 0;
                 for (uint32_t l = 0; l < s.lvl; l++) level_base += (uint32_t)MT_JUMP_RADIX[l] - 1;
+                const bool on_plan = lead_on_plan && s.lvl <= 1 && s.n_chunks == 0;
+                hipStream_t js = on_plan ? c->stream : g->jump_stream;
+                if (!on_plan) { const int rcj = join_plan_cascade(); if (rcj) return rcj; }
                 if (s.z_lvl != (int)s.lvl) {               // extend this level's source states once
                     if (s.z_cap < s.n_src) {
                         MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));   // the old buffer may still be read
+                        MSIM_HIP(c, hipStreamSynchronize(c->stream));
                         if (s.d_z) MSIM_HIP(c, hipFree(s.d_z));
                         s.d_z = nullptr; s.z_cap = 0;
                         MSIM_HIP(c, hipMalloc(&s.d_z, (size_t)s.n_src * JUMP_ZP * sizeof(uint32_t)));
                         s.z_cap = s.n_src;
                     }
-                    hipLaunchKernelGGL(k_mt_extend, dim3(s.n_src), dim3(GEN_THREADS), 0, g->jump_stream, s.d_states, s.d_z);
+                    hipLaunchKernelGGL(k_mt_extend, dim3(s.n_src), dim3(GEN_THREADS), 0, js, s.d_states, s.d_z);
                     MSIM_HIP(c, hipGetLastError());
                     s.z_lvl = (int)s.lvl;
                 }
                 hipLaunchKernelGGL(k_mt_jump, dim3(s.n_src * (m_need - s.m_done)), dim3(JUMP_THREADS), 0,
-                                   g->jump_stream, s.d_states, s.d_z, s.n_src,
+                                   js, s.d_states, s.d_z, s.n_src,
                                    g->d_poly + (size_t)level_base * MT_POLY_WORDS, s.m_done + 1);
                 MSIM_HIP(c, hipGetLastError());
+                if (on_plan) {
+                    if (!s.casc_ev) MSIM_HIP(c, hipEventCreateWithFlags(&s.casc_ev, hipEventDisableTiming));
+                    MSIM_HIP(c, hipEventRecord(s.casc_ev, c->stream));
+                    s.casc_pending = true;
+                }
                 s.m_done = m_need;
                 s.n_states = s.n_src * (s.m_done + 1);
             }
@@ -498,6 +532,7 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     s.words_ev.clear();
     s.waited_chunks = 0;
     s.waited_words = 0;
+    s.casc_pending = false;
     s.n_states = 1;
     s.lvl = 0; s.n_src = 1; s.m_done = 0;
     s.z_lvl = -1;
