@@ -669,3 +669,58 @@ def test_five_and_eight_randint_classes_vs_host():
               _rate_range(2_000_000, L - 1, 0.01, {1: 0.5, 2: 0.5}, {2: (1, 30)})]
     st = _compare([(L, ranges)], _params({"DE": 3, "TL": 4}, titv=1.0), seed=(5, 6), host_chain=True)
     assert st["contigs_hostchain"] == 1
+
+
+@pytest.mark.parametrize("n_contigs", [1, 3, 7, 8])
+def test_plan_and_apply_a_whole_genome_then_ask_equals_contig_by_contig(n_contigs):
+    """The fast order of the C-ABI -- plan + apply every contig, only then read -- lets the SNP sampler gather emission and
+    APPLY in groups (gpu_emit_flush: one launch per stage for three contigs, the last group partial, flushed by the first
+    reader).  Records, insert-free mutated streams and both stream positions must equal the contig-by-contig order through
+    the sequential host planner."""
+    import hashlib
+    rs = np.random.RandomState(100 + n_contigs)
+    lengths = [int(x) for x in rs.randint(3_000_000, 9_000_000, size=n_contigs)]
+    params = _params(titv=2.0)
+
+    def ranges(L):
+        return [_snp_range(0, L - 1, int(L * 0.01))]
+
+    # contig by contig, host planner
+    want = []
+    eng = _ffi.Engine(0, _ffi.PLAN_HOST)
+    eng.seed(7, 9)
+    eng.set_params(params)
+    for i, L in enumerate(lengths):
+        cid = eng.add_contig_synthetic(L, 50 + i)
+        eng.plan_contig(cid, ranges(L))
+        eng.apply_contig(cid)
+        recs, _ = eng.fetch_records(cid)
+        want.append((hashlib.sha256(recs.tobytes()).hexdigest(), eng.result_checksum(cid)))
+        eng.clear()
+    want_states = [eng.get_mt_state(0), eng.get_mt_state(1)]
+    eng.close()
+    # everything enqueued first, on the device engines
+    eng = _ffi.Engine(0, _ffi.PLAN_GPU)
+    eng.seed(7, 9)
+    eng.set_params(params)
+    cids = [eng.add_contig_synthetic(L, 50 + i) for i, L in enumerate(lengths)]
+    for cid, L in zip(cids, lengths):
+        eng.plan_contig(cid, ranges(L))
+        eng.apply_contig(cid)
+    got = []
+    for cid in cids:
+        recs, _ = eng.fetch_records(cid)
+        got.append((hashlib.sha256(recs.tobytes()).hexdigest(), eng.result_checksum(cid)))
+    assert got == want
+    assert eng.stats()["contigs_snp"] == n_contigs
+    for (hm, hp), (gm, gp) in zip(want_states, [eng.get_mt_state(0), eng.get_mt_state(1)]):
+        assert _next_words(hm, hp, 8) == _next_words(gm, gp, 8)
+    # ... and once more with one contig planned again in between (its group goes out first)
+    eng.seed(7, 9)
+    for j, (cid, L) in enumerate(zip(cids, lengths)):
+        eng.plan_contig(cid, ranges(L))
+        eng.apply_contig(cid)
+        if j == 1:
+            assert hashlib.sha256(eng.fetch_records(cid)[0].tobytes()).hexdigest() == want[1][0]
+    assert [eng.result_checksum(cid) for cid in cids] == [w[1] for w in want]
+    eng.close()
