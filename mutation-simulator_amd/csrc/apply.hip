@@ -701,25 +701,24 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
     }
 }
 
+// One tile of one contig (blk of nwg: the workgroup's place in its contig's grid).
 template <int CAP>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? MSIM_WPE : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                     const msim_record *__restrict__ recs,
-                                                     const uint32_t *__restrict__ off,
-                                                     const int32_t *__restrict__ first, uint32_t n_rec,
-                                                     uint64_t L_out, const uint8_t *__restrict__ pool,
-                                                     const uint8_t *__restrict__ lut_g,
-                                                     unsigned long long *err, const uint32_t *__restrict__ dyn) {
+__device__ __forceinline__ void rewrite_one_tile(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                 const msim_record *__restrict__ recs, const uint32_t *__restrict__ off,
+                                                 const int32_t *__restrict__ first, uint32_t n_rec, uint64_t L_out,
+                                                 const uint8_t *__restrict__ pool, const uint8_t *__restrict__ lut_g,
+                                                 unsigned long long *err, const uint32_t *__restrict__ dyn, uint32_t blk, uint32_t nwg) {
     if (dyn) {                                             // sizes from the device (see k_tile_index); surplus tiles leave
         n_rec = dyn[0];
         L_out = dyn[1];
-        if ((uint64_t)blockIdx.x * TILE >= L_out) return;
+        if ((uint64_t)blk * TILE >= L_out) return;
     }
     __shared__ RecWin<CAP> win;
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
-    uint32_t t = blockIdx.x;
+    uint32_t t = blk;
     if (MSIM_ABL & 16) {                                   // XCD x gets a contiguous range of tiles (bijective for any grid)
-        const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = t % 8, k8 = t / 8;
+        const uint32_t q8 = nwg / 8, r8 = nwg % 8, xcd = t % 8, k8 = t / 8;
         t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
     }
     const uint64_t tile0 = (uint64_t)t * TILE;
@@ -779,20 +778,54 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 
         rewrite_tile<false, CAP>(A, r_hi, any_rec, cnt, tile, in, out, recs, n_rec, pool, lut, tile0, L_out, err);
     }
 }
+template <int CAP>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? MSIM_WPE : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                     const msim_record *__restrict__ recs,
+                                                     const uint32_t *__restrict__ off,
+                                                     const int32_t *__restrict__ first, uint32_t n_rec,
+                                                     uint64_t L_out, const uint8_t *__restrict__ pool,
+                                                     const uint8_t *__restrict__ lut_g,
+                                                     unsigned long long *err, const uint32_t *__restrict__ dyn) {
+    rewrite_one_tile<CAP>(in, out, recs, off, first, n_rec, L_out, pool, lut_g, err, dyn, blockIdx.x, gridDim.x);
+}
+
+// The rewrite of several contigs in ONE launch: a batch of the counter-based engine (or an emission group of the SNP sampler)
+// applies its contigs back to back, and every launch boundary between two rewrite kernels is 5-10 us in which an HBM-bound
+// machine moves nothing (24 of them per genome: a seventh of the APPLY phase).  Jobs travel as kernel arguments; a workgroup
+// finds its contig by its index (constant indices and scalar selects: no copy of the table, no LDS).
+struct RwJob {
+    const uint8_t *in; uint8_t *out; const msim_record *recs; const uint32_t *off; const int32_t *first; const uint8_t *pool;
+    unsigned long long *err; const uint32_t *dyn; uint64_t L_out; uint32_t n_rec, n_tiles, tile_base, rsv;
+};
+constexpr int RW_JOBS = 16;
+struct RwJobs { RwJob j[RW_JOBS]; uint32_t n, total; };
+__device__ __forceinline__ RwJob rw_job_of(const RwJobs &J, uint32_t blk) {
+    RwJob T = J.j[0];
+#pragma unroll
+    for (int q = 1; q < RW_JOBS; q++)
+        if ((uint32_t)q < J.n && J.j[q].tile_base <= blk) T = J.j[q];
+    return T;
+}
+template <int CAP>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? MSIM_WPE : 4, 8))) void k_rewrite_b(RwJobs J, const uint8_t *__restrict__ lut_g) {
+    const RwJob T = rw_job_of(J, blockIdx.x);
+    const uint32_t blk = blockIdx.x - T.tile_base;
+    if (blk >= T.n_tiles) return;
+    rewrite_one_tile<CAP>(T.in, T.out, T.recs, T.off, T.first, T.n_rec, T.L_out, T.pool, lut_g, T.err, T.dyn, blk, T.n_tiles);
+}
 
 // ------------------------------------------------------------------ 3b. rewrite, SNP-only tables
 // No length change: output offset == input position.  The tile is staged in LDS (aligned 16-B loads,
 // ds_write_b128), then ONE LANE PER RECORD patches its byte through the LDS LUT -- no per-lane record
 // search -- and the tile streams out with aligned 16-B stores.  Any number of records per tile.
-__global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
-                                                         const msim_record *__restrict__ recs,
-                                                         const int32_t *__restrict__ first, uint32_t n_rec,
-                                                         uint64_t L, const uint8_t *__restrict__ lut_g,
-                                                         unsigned long long *err, const uint32_t *__restrict__ dyn) {
+__device__ __forceinline__ void rewrite_snp_one_tile(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                     const msim_record *__restrict__ recs, const int32_t *__restrict__ first,
+                                                     uint32_t n_rec, uint64_t L, const uint8_t *__restrict__ lut_g,
+                                                     unsigned long long *err, const uint32_t *__restrict__ dyn, uint32_t blk) {
     if (dyn) n_rec = dyn[0];
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[1024];
-    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    const uint64_t tile0 = (uint64_t)blk * TILE;
     u32x4 v[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
@@ -806,7 +839,7 @@ __global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restri
         const uint32_t o = it * (THREADS * GROUP) + threadIdx.x * GROUP;
         *reinterpret_cast<u32x4 *>(tile + o) = v[it];
     }
-    const int32_t f0 = first[blockIdx.x], f1 = first[blockIdx.x + 1];
+    const int32_t f0 = first[blk], f1 = first[blk + 1];
     __syncthreads();
     // records with tile0 <= pos < tile0 + TILE are (f0 or f0+1) .. f1
     if (f1 >= 0 && n_rec) {
@@ -829,6 +862,19 @@ __global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restri
         if (tile0 + o < L)
             __builtin_nontemporal_store(*reinterpret_cast<const u32x4 *>(tile + o), reinterpret_cast<u32x4 *>(out + tile0 + o));
     }
+}
+__global__ __launch_bounds__(THREADS) void k_rewrite_snp(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+                                                         const msim_record *__restrict__ recs,
+                                                         const int32_t *__restrict__ first, uint32_t n_rec,
+                                                         uint64_t L, const uint8_t *__restrict__ lut_g,
+                                                         unsigned long long *err, const uint32_t *__restrict__ dyn) {
+    rewrite_snp_one_tile(in, out, recs, first, n_rec, L, lut_g, err, dyn, blockIdx.x);
+}
+__global__ __launch_bounds__(THREADS) void k_rewrite_snp_b(RwJobs J, const uint8_t *__restrict__ lut_g) {
+    const RwJob T = rw_job_of(J, blockIdx.x);
+    const uint32_t blk = blockIdx.x - T.tile_base;
+    if (blk >= T.n_tiles) return;
+    rewrite_snp_one_tile(T.in, T.out, T.recs, T.first, T.n_rec, T.L_out, lut_g, T.err, T.dyn, blk);
 }
 
 // single-lane epilogue: small results go to the pinned host mailbox (no blit-kernel D2H copy)
@@ -988,11 +1034,14 @@ int apply_finish(Ctx *c) {
             c->t.bytes_out += g.out_len;
             c->t.records += g.n_rec;
         }
-        float ms_all = 0, ms_k = 0;
-        MSIM_HIP(c, hipEventElapsedTime(&ms_all, g.ea0, g.ea2));
-        MSIM_HIP(c, hipEventElapsedTime(&ms_k, g.ea1, g.ea2));
-        c->t.apply_ms += ms_all;
-        c->t.apply_kernel_ms += ms_k;
+        if (!g.timing_shared) {                            // (else: its rewrite ran inside another contig's batched launch)
+            float ms_all = 0, ms_k = 0;
+            MSIM_HIP(c, hipEventElapsedTime(&ms_all, g.ea0, g.ea2));
+            MSIM_HIP(c, hipEventElapsedTime(&ms_k, g.ea1, g.ea2));
+            c->t.apply_ms += ms_all;
+            c->t.apply_kernel_ms += ms_k;
+        }
+        g.timing_shared = false;
         const unsigned long long h_err = errs[(size_t)idx];
         g.key_error = h_err != ~0ull;
         if (g.key_error) { g.key_pos = h_err >> 8; g.key_base = (uint8_t)(h_err & 0xff); g.key_reported = false; }
@@ -1010,7 +1059,12 @@ int apply_finish(Ctx *c) {
 // size the output, so that path synchronises once.
 // APPLY of contigs the counter-based engine planned as one batch (plan_fast.hip): their tile indices in one launch, then the
 // rewrite kernels back to back on the batch's stream.
-int apply_batch_device(Ctx *c, const std::vector<int> &ids) {
+// While apply_batch_device applies its contigs, apply_contig_device hands their rewrite launches over instead of making them
+// (variant: 0 SNP-only, 1 small window, 2 large window): they go out as ONE launch per variant.
+struct RwPending { RwJob job; int variant; int contig; };
+static std::vector<RwPending> *g_rw_collect = nullptr;
+
+int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites) {
     TileJobs J;
     J.n_jobs = 0; J.total = 0;
     hipStream_t st = nullptr;
@@ -1042,13 +1096,48 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids) {
     launch();
     MSIM_HIP(c, hipGetLastError());
     int rc = MSIM_OK;
+    std::vector<RwPending> rw;
+    static const bool no_rw_batch = getenv("MSIM_NO_REWRITE_BATCH") != nullptr;
+    g_rw_collect = (no_rw_batch || !batch_rewrites) ? nullptr : &rw;
     for (int id : ids) {
         Contig &g = c->contigs[(size_t)id];
         if (!rc) rc = apply_contig_device(c, g);
         g.tile_index_done = false;
     }
+    g_rw_collect = nullptr;
     for (int id : marked) c->contigs[(size_t)id].tile_index_done = false;
-    return rc;
+    if (rc) return rc;
+    // ---- the collected rewrites: one launch per kernel variant and RW_JOBS contigs; the first contig's events time the launch
+    for (int variant = 0; variant < 3; variant++) {
+        RwJobs R;
+        R.n = 0; R.total = 0;
+        int leader = -1;
+        auto go = [&]() -> int {
+            if (!R.n) return MSIM_OK;
+            Contig &L = c->contigs[(size_t)leader];
+            MSIM_HIP(c, hipEventRecord(L.ea1, st));
+            if (variant == 0) hipLaunchKernelGGL(k_rewrite_snp_b, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
+            else if (variant == 1) hipLaunchKernelGGL(k_rewrite_b<REC_CAP_SMALL>, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
+            else hipLaunchKernelGGL(k_rewrite_b<REC_CAP>, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
+            MSIM_HIP(c, hipGetLastError());
+            MSIM_HIP(c, hipEventRecord(L.ea2, st));
+            L.timing_shared = false;
+            c->t.apply_launches += 1;
+            R.n = 0; R.total = 0; leader = -1;
+            return MSIM_OK;
+        };
+        for (const RwPending &p : rw) {
+            if (p.variant != variant) continue;
+            if (leader < 0) leader = p.contig;
+            RwJob &T = R.j[R.n++];
+            T = p.job;
+            T.tile_base = R.total;
+            R.total += T.n_tiles;
+            if (R.n == RW_JOBS && (rc = go())) return rc;
+        }
+        if ((rc = go())) return rc;
+    }
+    return MSIM_OK;
 }
 
 int apply_contig_device(Ctx *c, Contig &g) {
@@ -1138,8 +1227,21 @@ int apply_contig_device(Ctx *c, Contig &g) {
         MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
     }
     // ---- 3. rewrite
-    MSIM_HIP(c, hipEventRecord(g.ea1, st));
-    if (n_tiles) {
+    const bool hand_over = g_rw_collect && g.tile_index_done && n_tiles;     // (apply_batch_device launches it with its batch)
+    g.timing_shared = hand_over;
+    if (!hand_over) MSIM_HIP(c, hipEventRecord(g.ea1, st));
+    if (hand_over) {
+        const bool small_win = dyn ? g.n_struct_est * 2 < (uint64_t)n_tiles * REC_CAP_SMALL
+                                   : (uint64_t)n * 5 + 64 * 4 < (uint64_t)n_tiles * REC_CAP_SMALL * 4;
+        RwPending p;
+        memset(&p, 0, sizeof p);
+        p.job.in = g.d_in + PAD; p.job.out = g.d_out; p.job.recs = g.d_recs; p.job.off = d_off;
+        p.job.first = d_first; p.job.pool = g.d_pool ? g.d_pool + PAD : nullptr; p.job.err = d_err; p.job.dyn = dyn;
+        p.job.L_out = g.out_len; p.job.n_rec = n; p.job.n_tiles = n_tiles;
+        p.variant = g.all_snp ? 0 : (small_win ? 1 : 2);
+        p.contig = g.index;
+        g_rw_collect->push_back(p);
+    } else if (n_tiles) {
         // small window: mean records per tile < 80 % of it (dyn: only the STRUCTURAL records take window slots, and their
         // expected number is what the host knows -- mean structural candidates per tile below half the window)
         const bool small_win = dyn ? g.n_struct_est * 2 < (uint64_t)n_tiles * REC_CAP_SMALL
@@ -1155,8 +1257,10 @@ int apply_contig_device(Ctx *c, Contig &g) {
                                d_off, d_first, n, g.out_len, g.d_pool + PAD, ctx_lut(c), d_err, dyn);
         MSIM_HIP(c, hipGetLastError());
     }
-    MSIM_HIP(c, hipEventRecord(g.ea2, st));
-    c->t.apply_launches += n_tiles ? 1 : 0;
+    if (!hand_over) {
+        MSIM_HIP(c, hipEventRecord(g.ea2, st));
+        c->t.apply_launches += n_tiles ? 1 : 0;
+    }
     c->t.bytes_in += g.len;
     if (!dyn) {                                            // (dyn: counted when the sizes are collected, apply_finish)
         c->t.bytes_out += g.out_len;

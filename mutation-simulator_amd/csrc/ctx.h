@@ -33,6 +33,7 @@ struct Contig {
     int32_t *d_first = nullptr;       // tile index of its own (contigs on different streams cannot share the context's scratch)
     size_t cap_first = 0;
     bool tile_index_done = false;     // (transient) apply_batch_device has already launched this contig's tile index
+    bool timing_shared = false;       // its rewrite ran inside another contig's batched launch: that contig's events time it
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
     uint8_t *d_pool = nullptr;        // allocation; insert bases start at d_pool + PAD
@@ -284,7 +285,11 @@ void comm_destroy(Ctx *c);
 
 // apply.hip
 int apply_contig_device(Ctx *c, Contig &g);
-int apply_batch_device(Ctx *c, const std::vector<int> &ids);   // contigs of one batch of the counter-based engine
+// contigs of one batch of the counter-based engine / one emission group of the SNP sampler: ONE tile-index launch for all of them;
+// batch_rewrites: their rewrite kernels as one launch per kernel variant too (the counter-based engine: 1.84 -> 1.63 ms per c2
+// step, 2.87 -> 2.55 for c3; the SNP sampler's groups keep one launch per contig -- a three-contig rewrite kernel runs at 0.76 of
+// the HBM peak instead of 0.67, but it holds the machine for 150 us at a stretch and the chain beside it loses more than that)
+int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites);
 int apply_finish(Ctx *c);             // collect results of asynchronous APPLYs (timing, KeyError words)
 constexpr int MAX_CONTIGS = 1 << 16;
 int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed);

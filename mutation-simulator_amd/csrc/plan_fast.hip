@@ -647,7 +647,7 @@ int fast_plan_flush(Ctx *c) {
         int r = enqueue_batch(c, batch, orbit);
         batch.clear();
         cand = leaves = 0;
-        if (!r && !applies.empty()) r = apply_batch_device(c, applies);
+        if (!r && !applies.empty()) r = apply_batch_device(c, applies, true);
         return r;
     };
     // A genome goes out in a few batches rather than one: the APPLYs of a batch (HBM-bound) then run beside the PLAN kernels of
