@@ -287,8 +287,8 @@ void comm_destroy(Ctx *c);
 int apply_contig_device(Ctx *c, Contig &g);
 // contigs of one batch of the counter-based engine / one emission group of the SNP sampler: ONE tile-index launch for all of them;
 // batch_rewrites: their rewrite kernels as one launch per kernel variant too (the counter-based engine: 1.84 -> 1.63 ms per c2
-// step, 2.87 -> 2.55 for c3; the SNP sampler's groups keep one launch per contig -- a three-contig rewrite kernel runs at 0.76 of
-// the HBM peak instead of 0.67, but it holds the machine for 150 us at a stretch and the chain beside it loses more than that)
+// step, 2.87 -> 2.55 for c3; the SNP sampler's groups of three: the same step time within the noise, 4.19-4.24 vs 4.23-4.39 ms,
+// and the three-contig rewrite kernel runs at 0.76 of the HBM peak inside the pipeline instead of 0.67 -- fewer ramps and tails)
 int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites);
 int apply_finish(Ctx *c);             // collect results of asynchronous APPLYs (timing, KeyError words)
 constexpr int MAX_CONTIGS = 1 << 16;

@@ -834,7 +834,7 @@ int gpu_emit_flush(Ctx *c) {
             applies.push_back(it.contig);
         }
     }
-    return applies.empty() ? MSIM_OK : apply_batch_device(c, applies, false);
+    return applies.empty() ? MSIM_OK : apply_batch_device(c, applies, true);
 }
 
 bool gpu_emit_pending(Ctx *c, int contig, bool mark_apply) {
