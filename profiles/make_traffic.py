@@ -10,7 +10,7 @@ import re
 import sys
 from pathlib import Path
 
-KERNEL = {"c2": "k_rewrite_snp", "c3": "k_rewrite<140>", "c4": "k_rewrite_snp", "c4sv": "k_rewrite<140>"}
+KERNEL = {"c2": "k_rewrite_snp_b", "c3": "k_rewrite<140>", "c4": "k_rewrite_snp", "c4sv": "k_rewrite<140>"}
 
 
 def per_launch(path: Path, kernel: str, counter: str) -> float:
