@@ -7,6 +7,8 @@
 // memory (Contig::d_dyn), the host collects them at the next synchronising call.
 #include <algorithm>
 #include <chrono>
+#include <climits>
+#include <cstddef>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -74,7 +76,7 @@ struct FastPlan {
     uint32_t *d_flags = nullptr;                           // sticky FF_* flags of everything since the last collection
     DynSizes *d_dyn = nullptr;                             // one per contig of the context
     DynSizes *h_dyn = nullptr;                             // pinned copy (collection)
-    hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t t0 = nullptr, t1[F_SETS] = {};
     bool pending = false;                                  // work enqueued since the last collection
     std::vector<int> sized;                                // contigs whose sizes are still on the device only
     std::map<int, Replay> replay;                          // per contig planned with device-side counts: its tables (see enqueue_batch)
@@ -85,7 +87,14 @@ struct FastPlan {
     // host still prepares the tables of the second half (35 k ranges: 0.8 ms of host work in front of a 2.5 ms step otherwise).
     uint64_t queued_K = 0, cycle_K = 0, last_cycle_K = 0;
     bool early_done = false;
-    uint32_t next_set = 0;
+    // The batches of a cycle take the lanes in turn, from lane 0.  (Measured and not kept, round 4: the later batches on
+    // high-priority lanes, and/or their kernels gated behind the PLAN kernels of the batch before -- so that the first batch plans
+    // alone and the second one's short kernels do not starve behind the first one's rewrite.  c3 2.58 ms vs 2.44 without: the
+    // PLAN kernels are latency-bound and two batches planning side by side fill each other's bubbles.)
+    uint32_t cycle_batches = 0;
+    uint32_t *h_flags = nullptr;                           // pinned: [lane] flags word, then [lane][MAX_CONTIGS] DynSizes (collection)
+    DynSizes *h_dyn_lane[F_SETS] = {};
+    std::vector<uint8_t> lane_of;                          // per contig: the lane that planned it last
 };
 
 namespace {
@@ -126,6 +135,21 @@ int prepare(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, Prep &P)
     double pool_mean = 0, pool_var = 0, grow_mean = 0, grow_var = 0, max_piece = 0, struct_est = 0;
     bool consuming = false;
     uint32_t n_draw = 0;
+    // A table of tens of thousands of ranges repeats a few MutationSettings (rmt.py:79-163: the std line between two gene blocks,
+    // the hot and the cold spots): what a range's settings come to -- its Settings entry, the checks, the terms of the size
+    // estimates -- is worked out when they differ from the drawing range before, and replayed (same additions, same order) when
+    // they do not.  45 -> 14 ns per range: the tables of c4sv's 35 k ranges were 0.8 ms of host work in front of a 2.7 ms step.
+    struct Term { double p; double hi; uint8_t t; };
+    struct Derived {
+        const msim_range *of = nullptr;
+        uint32_t set = 0;
+        bool sn_only = true;
+        int n_terms = 0;
+        Term term[8];
+    } D;
+    constexpr size_t SET_OFF = offsetof(msim_range, n_types), SET_BYTES = sizeof(msim_range) - SET_OFF;
+    P.fr.reserve((size_t)n_ranges);
+    P.subs.reserve((size_t)n_ranges + 64);
     for (int i = 0; i < n_ranges; i++) {
         const msim_range &r = ranges[i];
         if (r.k == 0) continue;
@@ -138,47 +162,58 @@ int prepare(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, Prep &P)
             return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: overlapping or unsorted ranges (the reference's dict semantics) are not covered");
         if ((uint64_t)r.stop >= L) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: range beyond the contig end");
         prev_stop = r.stop;
-        if (r.n_types < 1 || r.n_types > 8) return fail(c, MSIM_ERR_ARG, "range with no or more than 8 mutation types");
-        Settings s;
-        memset(&s, 0, sizeof s);
-        s.n_types = (uint32_t)r.n_types;
-        bool sn_only = true;
-        for (int j = 0; j < r.n_types; j++) {
-            s.thr[j] = r.cdf_thr[j];
-            s.type[j] = (uint8_t)r.types[j];
-            if (!type_drawable(r, j)) continue;
-            const int t = r.types[j];
-            const double p = (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - (j ? r.cdf_thr[j - 1] : 0)) / 9007199254740992.0;
-            if (t == MSIM_SN) continue;
-            sn_only = false;
-            if (t == MSIM_TL || t == MSIM_TLI)
-                return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: translocations (-tl) are not covered; use --rng compat");
-            if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return fail(c, MSIM_ERR_ARG, "unknown mutation type");
-            const int64_t lo = r.min_len[t], hi = r.max_len[t];
-            if (lo < 1 || hi < lo || hi >= (1ll << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: mutation lengths outside 1 .. 2^31");
-            struct_est += (double)r.k * p;
-            if (t == MSIM_IN) { pool_mean += (double)r.k * p * hi; pool_var += (double)r.k * p * hi * hi; }
-            if (t == MSIM_IN || t == MSIM_DU) { grow_mean += (double)r.k * p * hi; grow_var += (double)r.k * p * hi * hi; max_piece = std::max(max_piece, (double)hi); }
-            if (t == MSIM_DE || t == MSIM_DU || t == MSIM_IV) {
-                consuming = true;
-                P.maxspan_visit = std::max<uint64_t>(P.maxspan_visit, (uint64_t)hi);
-                P.maxspan = (uint32_t)std::min<uint64_t>(0xffffffffull, std::max<uint64_t>(P.maxspan, (uint64_t)hi - 1 + P.block1.v[t]));
-            } else {
-                P.maxspan = std::max(P.maxspan, P.block1.v[t]);
+        if (!D.of || memcmp(reinterpret_cast<const char *>(D.of) + SET_OFF, reinterpret_cast<const char *>(&r) + SET_OFF, SET_BYTES)) {
+            if (r.n_types < 1 || r.n_types > 8) return fail(c, MSIM_ERR_ARG, "range with no or more than 8 mutation types");
+            Settings s;
+            memset(&s, 0, sizeof s);
+            s.n_types = (uint32_t)r.n_types;
+            D.sn_only = true;
+            D.n_terms = 0;
+            for (int j = 0; j < r.n_types; j++) {
+                s.thr[j] = r.cdf_thr[j];
+                s.type[j] = (uint8_t)r.types[j];
+                if (!type_drawable(r, j)) continue;
+                const int t = r.types[j];
+                const double p = (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - (j ? r.cdf_thr[j - 1] : 0)) / 9007199254740992.0;
+                if (t == MSIM_SN) continue;
+                D.sn_only = false;
+                if (t == MSIM_TL || t == MSIM_TLI)
+                    return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: translocations (-tl) are not covered; use --rng compat");
+                if (t != MSIM_IN && t != MSIM_DE && t != MSIM_DU && t != MSIM_IV) return fail(c, MSIM_ERR_ARG, "unknown mutation type");
+                const int64_t lo = r.min_len[t], hi = r.max_len[t];
+                if (lo < 1 || hi < lo || hi >= (1ll << 31)) return fail(c, MSIM_ERR_UNSUPPORTED, "fast RNG mode: mutation lengths outside 1 .. 2^31");
+                D.term[D.n_terms++] = Term{p, (double)hi, (uint8_t)t};
+                if (t == MSIM_IN || t == MSIM_DU) max_piece = std::max(max_piece, (double)hi);
+                if (t == MSIM_DE || t == MSIM_DU || t == MSIM_IV) {
+                    consuming = true;
+                    P.maxspan_visit = std::max<uint64_t>(P.maxspan_visit, (uint64_t)hi);
+                    P.maxspan = (uint32_t)std::min<uint64_t>(0xffffffffull, std::max<uint64_t>(P.maxspan, (uint64_t)hi - 1 + P.block1.v[t]));
+                } else {
+                    P.maxspan = std::max(P.maxspan, P.block1.v[t]);
+                }
             }
+            P.maxspan = std::max(P.maxspan, P.block1.v[MSIM_SN]);
+            for (int t = 0; t < 8; t++) {
+                const int64_t lo = std::max<int64_t>(r.min_len[t], 0), hi = std::max<int64_t>(r.max_len[t], lo);
+                s.min_len[t] = (uint32_t)std::min<int64_t>(lo, 0x7fffffff);
+                s.max_len[t] = (uint32_t)std::min<int64_t>(hi, 0x7fffffff);
+                s.width[t] = s.max_len[t] - s.min_len[t] + 1;
+            }
+            if (!D.sn_only) { P.all_sn = false; P.snp_only = false; }
+            if (sn_blocks) P.snp_only = false;
+            uint32_t set = 0;
+            for (; set < P.sets.size(); set++) if (!memcmp(&P.sets[set], &s, sizeof s)) break;
+            if (set == P.sets.size()) P.sets.push_back(s);
+            D.set = set;
+            D.of = &r;
         }
-        P.maxspan = std::max(P.maxspan, P.block1.v[MSIM_SN]);
-        for (int t = 0; t < 8; t++) {
-            const int64_t lo = std::max<int64_t>(r.min_len[t], 0), hi = std::max<int64_t>(r.max_len[t], lo);
-            s.min_len[t] = (uint32_t)std::min<int64_t>(lo, 0x7fffffff);
-            s.max_len[t] = (uint32_t)std::min<int64_t>(hi, 0x7fffffff);
-            s.width[t] = s.max_len[t] - s.min_len[t] + 1;
+        const double kd = (double)r.k;
+        for (int q = 0; q < D.n_terms; q++) {
+            const Term &tm = D.term[q];
+            struct_est += kd * tm.p;
+            if (tm.t == MSIM_IN) { pool_mean += kd * tm.p * tm.hi; pool_var += kd * tm.p * tm.hi * tm.hi; }
+            if (tm.t == MSIM_IN || tm.t == MSIM_DU) { grow_mean += kd * tm.p * tm.hi; grow_var += kd * tm.p * tm.hi * tm.hi; }
         }
-        if (!sn_only) { P.all_sn = false; P.snp_only = false; }
-        if (sn_blocks) P.snp_only = false;
-        uint32_t set = 0;
-        for (; set < P.sets.size(); set++) if (!memcmp(&P.sets[set], &s, sizeof s)) break;
-        if (set == P.sets.size()) P.sets.push_back(s);
         FRange f;
         f.start = (uint32_t)r.start;
         f.n = (uint32_t)n;
@@ -187,7 +222,7 @@ int prepare(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, Prep &P)
         f.leaf_base = (uint32_t)P.n_leaves;
         f.lgB = leaf_lg((uint64_t)n, (uint64_t)r.k);
         f.clip = (uint32_t)std::min<int64_t>(r.stop + 1, 0xffffffffll);
-        f.set = set;
+        f.set = D.set;
         f.sub_base = (uint32_t)P.subs.size();
         f.slot = 0;
         const uint64_t T = ((uint64_t)n + (1ull << f.lgB) - 1) >> f.lgB;
@@ -223,9 +258,11 @@ int ensure_plan(Ctx *c) {
     MSIM_HIP(c, hipMalloc(&f->d_flags, 64));
     MSIM_HIP(c, hipMemset(f->d_flags, 0, 64));
     MSIM_HIP(c, hipMalloc(&f->d_dyn, sizeof(DynSizes) * MAX_CONTIGS));
-    MSIM_HIP(c, hipHostMalloc(&f->h_dyn, sizeof(DynSizes) * MAX_CONTIGS + 64, hipHostMallocDefault));
+    MSIM_HIP(c, hipHostMalloc(&f->h_dyn, sizeof(DynSizes) * MAX_CONTIGS * F_SETS + 256, hipHostMallocDefault));
+    for (int i = 0; i < F_SETS; i++) f->h_dyn_lane[i] = f->h_dyn + (size_t)i * MAX_CONTIGS;
+    f->h_flags = reinterpret_cast<uint32_t *>(f->h_dyn + (size_t)F_SETS * MAX_CONTIGS);
     MSIM_HIP(c, hipEventCreate(&f->t0));
-    MSIM_HIP(c, hipEventCreate(&f->t1));
+    for (auto &e : f->t1) MSIM_HIP(c, hipEventCreate(&e));
     return MSIM_OK;
 }
 
@@ -246,7 +283,7 @@ void fast_plan_destroy(Ctx *c) {
     if (f->d_dyn) (void)hipFree(f->d_dyn);
     if (f->h_dyn) (void)hipHostFree(f->h_dyn);
     if (f->t0) (void)hipEventDestroy(f->t0);
-    if (f->t1) (void)hipEventDestroy(f->t1);
+    for (auto e : f->t1) if (e) (void)hipEventDestroy(e);
     delete f;
     c->fast = nullptr;
 }
@@ -295,27 +332,45 @@ int fast_plan_collect(Ctx *c) {
     g_prof.report();
     for (int round = 0; f->pending && round < 3; round++) {
         f->pending = false;
-        for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
-        MSIM_HIP(c, hipEventRecord(f->t1, f->lane[0]));
-        MSIM_HIP(c, hipStreamSynchronize(f->lane[0]));
-        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-        float ms = 0;
-        MSIM_HIP(c, hipEventElapsedTime(&ms, f->t0, f->t1));
-        c->t.plan_gpu_ms += ms;
-        for (auto &s : f->set) s.pending = false;
-        uint32_t flags = 0;
-        MSIM_HIP(c, hipMemcpy(&flags, f->d_flags, sizeof flags, hipMemcpyDeviceToHost));
+        f->cycle_batches = 0;
+        // Flags and sizes come back by asynchronous copies into pinned memory behind each lane's work (a blocking hipMemcpy
+        // costs ~30 us at every step boundary): a contig's sizes are read from the copy of the lane that planned it.
         std::vector<int> sized, redo;
         sized.swap(f->sized);
-        if (!sized.empty()) {
-            int hi = 0;
-            for (int idx : sized) hi = std::max(hi, idx);
-            MSIM_HIP(c, hipMemcpy(f->h_dyn, f->d_dyn, sizeof(DynSizes) * (size_t)(hi + 1), hipMemcpyDeviceToHost));
+        int lo_idx[F_SETS], hi_idx[F_SETS];
+        for (int i = 0; i < F_SETS; i++) { lo_idx[i] = INT_MAX; hi_idx[i] = -1; }
+        for (int idx : sized) {
+            if ((size_t)idx >= f->lane_of.size()) continue;
+            const int li = f->lane_of[(size_t)idx];
+            lo_idx[li] = std::min(lo_idx[li], idx); hi_idx[li] = std::max(hi_idx[li], idx);
+        }
+        for (int i = 0; i < F_SETS; i++) {
+            if (!f->set[i].pending) { f->h_flags[i] = 0; continue; }
+            if (hi_idx[i] >= 0)
+                MSIM_HIP(c, hipMemcpyAsync(f->h_dyn_lane[i] + lo_idx[i], f->d_dyn + lo_idx[i], sizeof(DynSizes) * (size_t)(hi_idx[i] - lo_idx[i] + 1),
+                                           hipMemcpyDeviceToHost, f->lane[i]));
+            MSIM_HIP(c, hipMemcpyAsync(f->h_flags + i, f->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, f->lane[i]));
+            MSIM_HIP(c, hipEventRecord(f->t1[i], f->lane[i]));
+        }
+        for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        float ms = 0;
+        for (int i = 0; i < F_SETS; i++) {                 // (first batch's start to the end of the lane that finished last)
+            if (!f->set[i].pending) continue;
+            float m = 0;
+            MSIM_HIP(c, hipEventElapsedTime(&m, f->t0, f->t1[i]));
+            ms = std::max(ms, m);
+        }
+        c->t.plan_gpu_ms += ms;
+        uint32_t flags = 0;
+        for (int i = 0; i < F_SETS; i++) flags |= f->h_flags[i];
+        for (auto &s : f->set) s.pending = false;
+        {
             for (int idx : sized) {
-                if ((size_t)idx >= c->contigs.size()) continue;
+                if ((size_t)idx >= c->contigs.size() || (size_t)idx >= f->lane_of.size()) continue;
                 Contig &g = c->contigs[(size_t)idx];
                 if (!g.sizes_pending) continue;
-                const DynSizes s = f->h_dyn[idx];
+                const DynSizes s = f->h_dyn_lane[f->lane_of[(size_t)idx]][idx];
                 if (s.flags & FF_NEED_ORBIT) { redo.push_back(idx); continue; }
                 flags |= s.flags & 0xffu;
                 g.sizes_pending = false;
@@ -370,7 +425,7 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
     if (items.empty()) return MSIM_OK;
     if ((rc = ensure_plan(c))) return rc;
     FastPlan *f = c->fast;
-    const uint32_t li = f->next_set++ % F_SETS;
+    const uint32_t li = f->cycle_batches++ % F_SETS;
     FastSet &S = f->set[li];
     hipStream_t st = f->lane[li];
     g_prof.start();
@@ -561,6 +616,8 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
         MSIM_HIP(c, hipGetLastError());
     }
     g_prof.lap(6);
+    if (f->lane_of.size() < c->contigs.size()) f->lane_of.resize(c->contigs.size(), 0);
+    for (auto &it : items) f->lane_of[(size_t)it.contig] = (uint8_t)li;
     // ---- per contig: what the host knows now; its APPLY follows on the same stream (apply.hip: Contig::apply_stream) -- no event,
     // no cross-stream wait; whoever reads the records from another stream (text, fetches) drains first
     for (auto &it : items) {
