@@ -117,8 +117,9 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     double plan_host_ms;      /* host planner wall time (sequential RNG chain)                      */
     double plan_gpu_ms;       /* GPU sampler kernels                                                */
     double upload_ms;         /* record table H2D                                                   */
-    double apply_ms;          /* APPLY kernels (scan + tile index + rewrite)                        */
-    double apply_kernel_ms;   /* the rewrite kernel alone (roofline kernel)                         */
+    double apply_ms;          /* APPLY kernels (scan + tile index + rewrite): the time during which */
+    double apply_kernel_ms;   /* at least one was in flight; the rewrite kernel alone (roofline     */
+                              /* kernel), likewise -- launches on different streams may overlap     */
     uint64_t apply_launches;  /* rewrite-kernel launches accumulated since msim_reset_stats         */
     uint64_t bytes_in, bytes_out, records;   /* algorithmic traffic of those launches               */
     uint64_t py_words, np_words;             /* MT19937 words consumed from each stream             */

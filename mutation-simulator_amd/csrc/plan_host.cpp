@@ -1471,23 +1471,23 @@ extern "C" int msim_build_ranges(const msim_settings_desc *sets, int n_sets, con
     }
     for (int64_t i = 0; i < n; i++) {
         if (set_id[i] < 0 || set_id[i] >= n_sets) return MSIM_ERR_ARG;
-        msim_range r = tmpl[(size_t)set_id[i]];
+        msim_range &r = out[i];
+        r = tmpl[(size_t)set_id[i]];
         r.start = start[i];
         r.stop = stop[i];
         const double span = (double)((stop[i] - start[i]) + 1);                                // (exact below 2^53)
         const double kf = span * sets[set_id[i]].rate_sum;
-        int64_t k = kf >= 9.2e18 ? INT64_MAX : kf <= -9.2e18 ? INT64_MIN : (int64_t)kf;       // int(): towards zero
+        const int64_t k = kf >= 9.2e18 ? INT64_MAX : kf <= -9.2e18 ? INT64_MIN : (int64_t)kf; // int(): towards zero
         r.k = k;
         int64_t setsize = 21;
         if (k > 5) {
             const unsigned __int128 x = (unsigned __int128)3 * (uint64_t)k - 1;                // smallest m with 4^m > 3 k
-            int bits = 0;
-            for (unsigned __int128 y = x; y; y >>= 1) bits++;
+            const uint64_t hi = (uint64_t)(x >> 64), lo = (uint64_t)x;
+            const int bits = hi ? 128 - __builtin_clzll(hi) : 64 - __builtin_clzll(lo);         // (x >= 17)
             const int m = (bits + 1) / 2;
             setsize = m >= 31 ? INT64_MAX : 21 + ((int64_t)1 << (2 * m));
         }
         r.setsize = setsize;
-        out[i] = r;
     }
     return MSIM_OK;
 }

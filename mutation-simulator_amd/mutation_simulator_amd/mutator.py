@@ -185,7 +185,10 @@ def _range_triples(chrom):
             settings.append(ms)
         of_object[q] = by_value[key]
     sid = of_object[inv] if n else np.zeros(0, dtype=np.int32)
-    out = (np.ascontiguousarray(start), np.ascontiguousarray(stop), np.ascontiguousarray(sid, dtype=np.int32), settings)
+    # (the widest range, as Python's int: decides whether any k can leave the integer formulas' domain -- plan_table)
+    # (a negative-length filler of overlapping RMT ranges, rmt.py:243-255, makes k negative: then nothing is skipped)
+    widest = int((stop - start).max()) + 1 if n and int((stop - start).min()) + 1 >= 0 else (0 if not n else 1 << 62)
+    out = (np.ascontiguousarray(start), np.ascontiguousarray(stop), np.ascontiguousarray(sid, dtype=np.int32), settings, widest)
     try:
         chrom._msim_triples = (stamp,) + out
     except AttributeError:
@@ -200,13 +203,13 @@ def _settings_descs(settings):
         chances = ms.mut_chances                                         # mutator.py:172-173
         d.n_types = len(chances)
         for j, (ty, p) in enumerate(chances.items()):
-            d.types[j] = ty.value
+            d.types[j] = ty._value_                                      # (`.value` is a descriptor call; this runs per contig per step)
             d.chances[j] = p
         if ms.mut_lengs:
             for ty, v in ms.mut_lengs["min"].items():
-                d.min_len[ty.value] = v
+                d.min_len[ty._value_] = v
             for ty, v in ms.mut_lengs["max"].items():
-                d.max_len[ty.value] = v
+                d.max_len[ty._value_] = v
     return descs
 
 
@@ -219,7 +222,7 @@ def plan_table(chrom) -> np.ndarray:
     if len(rds) <= 2:                                   # ARGS mode: one range per contig -- nothing to amortise, no arrays to build
         few = [range_descriptor(rd) for rd in rds if rd.mutation_settings.has_mutations]
         return np.frombuffer(b"".join(bytes(r) for r in few), dtype=_ffi.RANGE_DTYPE) if few else np.zeros(0, dtype=_ffi.RANGE_DTYPE)
-    start, stop, sid, settings = _range_triples(chrom)
+    start, stop, sid, settings, widest = _range_triples(chrom)
     n = len(start)
     if n == 0:
         return np.zeros(0, dtype=_ffi.RANGE_DTYPE)
@@ -230,6 +233,10 @@ def plan_table(chrom) -> np.ndarray:
     rc = _ffi.load().msim_build_ranges(descs, len(settings), start.ctypes.data, stop.ctypes.data, sid.ctypes.data, n, out.ctypes.data)
     if rc != _ffi.OK:
         raise _ffi.MsimError(f"msim_build_ranges failed ({rc})")
+    # k = int(span * rate_sum) <= widest * max(rate_sum): nothing can leave the domain of the integer formulas (span < 2^53,
+    # 0 <= k < 2^33) when the widest range times the largest rate stays below 2^33 and no rate sum is negative or NaN
+    if widest < (1 << 53) and all(0.0 <= d.rate_sum and widest * d.rate_sum < float(1 << 33) for d in descs[:len(settings)]):
+        return out
     k = out["k"]
     big = (((stop - start) + 1) >= (1 << 53)) | (k >= (1 << 33)) | (k < 0)
     if big.any():                                                        # (outside the integer setsize formula's domain)
