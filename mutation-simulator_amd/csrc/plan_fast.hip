@@ -85,8 +85,12 @@ struct FastPlan {
     // A run of plans between two synchronising calls is a cycle (a genome in bench.py, a contig in the CLI).  Its first half
     // goes to the device as soon as it is queued -- judged by the previous cycle's size -- so that the device works while the
     // host still prepares the tables of the second half (35 k ranges: 0.8 ms of host work in front of a 2.5 ms step otherwise).
+    // Where the tables themselves are the host's work (an RMT file: thousands of ranges per contig, 20-40 us of `prepare` each),
+    // a first, smaller part goes out before that: once 100 us of preparation are queued (`queued_host_us`) -- the device then
+    // starts on the three largest contigs while the host is a fifth into the genome, not half.
     uint64_t queued_K = 0, cycle_K = 0, last_cycle_K = 0;
-    bool early_done = false;
+    double queued_host_us = 0;
+    bool early_done = false, half_done = false;
     // The batches of a cycle take the lanes in turn, from lane 0.  (Measured and not kept, round 4: the later batches on
     // high-priority lanes, and/or their kernels gated behind the PLAN kernels of the batch before -- so that the first batch plans
     // alone and the second one's short kernels do not starve behind the first one's rewrite.  c3 2.58 ms vs 2.44 without: the
@@ -328,7 +332,8 @@ int fast_plan_collect(Ctx *c) {
     if (!f || !f->pending) return MSIM_OK;
     if (f->cycle_K) f->last_cycle_K = f->cycle_K;          // a cycle ends here (see FastPlan::queued_K)
     f->cycle_K = 0;
-    f->early_done = false;
+    f->queued_host_us = 0;
+    f->early_done = f->half_done = false;
     g_prof.report();
     for (int round = 0; f->pending && round < 3; round++) {
         f->pending = false;
@@ -652,13 +657,19 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
         if (q.contig == ct.index) { if ((rc = fast_plan_flush(c))) return rc; break; }      // planned again before anybody looked
     static const bool no_early = getenv("MSIM_FAST_NO_EARLY_FLUSH") != nullptr;
     // (halves: thirds and quarters measured slower on every bench shape -- more batches, more fixed latency)
-    if (!no_early && !f->early_done && f->queue.size() >= 3 && f->queued_K >= std::max<uint64_t>(1u << 22, f->last_cycle_K / 2)) {
+    static const bool no_head = getenv("MSIM_FAST_NO_HEAD_FLUSH") != nullptr;
+    const bool half = !f->half_done && f->cycle_K >= std::max<uint64_t>(1u << 22, f->last_cycle_K / 2);
+    const bool head = !no_head && !f->early_done && f->queued_host_us >= 100.0 && f->queued_K >= std::max<uint64_t>(1u << 21, f->last_cycle_K / 6);
+    if (!no_early && f->queue.size() >= 3 && (half || head)) {
         f->early_done = true;                              // (the contigs queued so far have had their msim_apply_contig)
+        if (half) f->half_done = true;
         if ((rc = fast_plan_flush(c))) return rc;
     }
     Pending it;
     g_prof.start();
+    const auto tp0 = std::chrono::steady_clock::now();
     rc = prepare(c, ct.len, ranges, n_ranges, it.P);
+    f->queued_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count();
     g_prof.lap(0);
     if (rc) return rc;
     const Prep &P = it.P;
@@ -712,6 +723,7 @@ int fast_plan_flush(Ctx *c) {
     uint64_t total = 0;
     for (const Pending &q : queue) total += q.P.K;
     f->queued_K = 0;
+    f->queued_host_us = 0;
     static const int env_batches = getenv("MSIM_FAST_BATCHES") ? std::max(1, atoi(getenv("MSIM_FAST_BATCHES"))) : 2;
     const int want_batches = f->early_done ? 1 : env_batches;   // (a cycle whose first half went out early: each flush is one batch)
     const uint64_t cut = queue.size() >= 6 && total >= (1u << 22) ? total / (uint64_t)want_batches + 1 : ~0ull;

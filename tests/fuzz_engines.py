@@ -112,6 +112,8 @@ def rmt_settings_round3(rs, lengths):
     for ci, L in enumerate(lengths):
         if rs.rand() < 0.25:
             continue
+        if L < 8:                                          # (a contig of a few bases: no room for a range line; std settings)
+            continue
         rows.append(f"chr {ci + 1}")
         n_blocks = int(rs.choice([3, 20, 150]))
         cuts = np.sort(rs.choice(np.arange(2, L - 2), size=min(2 * n_blocks, (L - 4) // 2 * 2), replace=False))
