@@ -659,6 +659,7 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
     // (halves: thirds and quarters measured slower on every bench shape -- more batches, more fixed latency)
     static const bool no_head = getenv("MSIM_FAST_NO_HEAD_FLUSH") != nullptr;
     const bool half = !f->half_done && f->cycle_K >= std::max<uint64_t>(1u << 22, f->last_cycle_K / 2);
+    // (100 us and a sixth of the last cycle: 60 us / an eighth, 40 / a twelfth, 150 / a fifth, 100 / a quarter measured the same or slower)
     const bool head = !no_head && !f->early_done && f->queued_host_us >= 100.0 && f->queued_K >= std::max<uint64_t>(1u << 21, f->last_cycle_K / 6);
     if (!no_early && f->queue.size() >= 3 && (half || head)) {
         f->early_done = true;                              // (the contigs queued so far have had their msim_apply_contig)
