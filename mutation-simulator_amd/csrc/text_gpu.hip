@@ -16,7 +16,10 @@
 //          k_gather : FASTA body text (uniform line width, as pyfaidx requires) -> upper-cased uint8 bases
 //                     (what pyfaidx hands the reference with sequence_always_upper=True, util.py:84-88); 16 bases per lane,
 //                     the one line terminator a group can straddle squeezed out
-//   (round 4, profiles/r04_kernel_stats_cli_*.txt: k_gather / k_frame 4.8-5.4 TB/s, k_vcf_lines 1.3-1.8 TB/s on SNP tables)
+//                               the write pass formats a wave's lines into LDS where all 64 are short and stores the stretch
+//                               16 aligned bytes per lane; REF / ALT of SNP records come from the length pass (no second gather)
+//   (round 4, profiles/r04_kernel_stats_cli_*.txt: k_gather / k_frame 4.8-5.2 TB/s; k_vcf_lines' write pass on SNP tables
+//    2.5 TB/s [1.26 with a lane's own byte stores], its length pass 1.4 TB/s -- it gathers one base per record from the contig)
 //   IT     k_splice : interchromosomal translocation of one contig -- segments of two contigs taken alternately
 //                     (it_mutator.py:121-146 __write_with_bp)
 // Byte/integer work, HBM-bound; no MFMA.
@@ -261,17 +264,37 @@ __device__ __forceinline__ void format_record(S &s, const msim_record &r, const 
 }
 
 constexpr uint32_t VCF_LANE_SPAN = 24;        // records spanning at most this many bases are formatted by one lane
+constexpr uint32_t VCF_STAGE = 4096;          // LDS per wave for the lines of its 64 records (write pass)
 
+// the line of an SNP record (mutator.py:334-341, vcf_writer.py:118-126) at p: name \t POS \t . \t REF \t ALT \t . \t . \t . \t GT \t 1 \n
+template <class P>
+__device__ __forceinline__ void snp_line(P p, const uint8_t *__restrict__ name, uint32_t name_len, unsigned long long start, int nd,
+                                         uint8_t ref, uint8_t alt) {
+    for (uint32_t q = 0; q < name_len; q++) p[q] = (char)name[q];
+    p += name_len;
+    *p++ = '\t';
+    unsigned long long v = start;
+    for (int q = nd - 1; q >= 0; q--) { p[q] = (char)('0' + (int)(v % 10)); v /= 10; }
+    p += nd;
+    const char tail[18] = {'\t', '.', '\t', (char)ref, '\t', (char)alt, '\t', '.', '\t', '.', '\t', '.', '\t', 'G', 'T', '\t', '1', '\n'};
+#pragma unroll
+    for (int q = 0; q < 18; q++) p[q] = tail[q];
+}
+
+// len_io: the lines' lengths -- written by the length pass, read by the write pass.  ra: REF | ALT << 8 of every SNP record, left
+// by the length pass (which has to look at the base anyway: REF == ALT is suppressed) so that the write pass does not gather
+// the contig's bases at 2 M scattered positions a second time.
 template <bool WRITE>
 __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
                                                           const uint8_t *__restrict__ pool,
                                                           const uint8_t *__restrict__ in, unsigned long long L,
                                                           const uint8_t *__restrict__ name, uint32_t name_len,
                                                           const uint8_t *__restrict__ lut_g,
-                                                          uint32_t *__restrict__ len_out,
+                                                          uint32_t *__restrict__ len_io, uint16_t *__restrict__ ra,
                                                           const unsigned long long *__restrict__ off,
                                                           char *__restrict__ text) {
     __shared__ uint8_t lut[1280];
+    __shared__ __attribute__((aligned(16))) char stage[WRITE ? TX_WAVES : 1][WRITE ? VCF_STAGE : 16];
     for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
     __syncthreads();
@@ -279,46 +302,72 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
     // one LANE each (a wave per such line -- round 1 -- spent ~15 instructions of 64 lanes on 25 bytes: 135 GB/s, 1.7 % of HBM, and
     // a twelfth of a CLI run with -sn 0.01); records with a long REF / ALT are taken by the whole wave, one after the other, their
     // fields broadcast.
-    const uint32_t lane_id = threadIdx.x & 63;
-    const uint32_t base_rec = (blockIdx.x * TX_WAVES + (threadIdx.x >> 6)) * 64;
+    // Write pass: the lines of a wave's records are adjacent in the text.  Where all of them are short, the lanes format into
+    // LDS and the wave stores the stretch 16 aligned bytes per lane (a lane's own 25-byte line goes out as 25 one-byte stores
+    // otherwise: 64 bytes per store instruction instead of 1024).
+    const uint32_t lane_id = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base_rec = (blockIdx.x * TX_WAVES + wave) * 64;
     if (base_rec >= n_rec) return;
     const uint32_t mine = base_rec + lane_id;
     const bool valid = mine < n_rec;
     msim_record my{};
     if (valid) my = recs[mine];
     bool by_lane = false;
-    if (valid && my.type == MSIM_SN) {                                   // mutator.py:334-341
+    if (valid && my.type == MSIM_SN) {
         by_lane = true;
-        const uint8_t x = in[my.pos];
-        const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];          // ti / tv column of conv(x)
-        const unsigned long long start = (unsigned long long)my.pos + 1;
-        const int nd = ndigits(start);
-        const uint32_t len = ref == alt ? 0u : name_len + (uint32_t)nd + 19u;               // vcf_writer.py:123: REF == ALT suppressed
-        if (!WRITE) len_out[mine] = len;
-        else if (len) {
-            char *p = text + off[mine];
-            for (uint32_t q = 0; q < name_len; q++) p[q] = (char)name[q];
-            p += name_len;
-            *p++ = '\t';
-            unsigned long long v = start;
-            for (int q = nd - 1; q >= 0; q--) { p[q] = (char)('0' + (int)(v % 10)); v /= 10; }
-            p += nd;
-            const char tail[18] = {'\t', '.', '\t', (char)ref, '\t', (char)alt, '\t', '.', '\t', '.', '\t', '.', '\t', 'G', 'T', '\t', '1', '\n'};
-#pragma unroll
-            for (int q = 0; q < 18; q++) p[q] = tail[q];
-        }
     } else if (valid) {
         const unsigned long long hi = (unsigned long long)my.stop + 1 < L ? (unsigned long long)my.stop + 1 : L;
         const unsigned long long span = my.type == MSIM_TLI ? (hi > my.extra ? hi - my.extra : 0)
                                                             : (unsigned long long)my.stop - my.pos + 1;
-        if (span <= VCF_LANE_SPAN) {
-            by_lane = true;
-            LSink<WRITE> s;
-            s.n = 0;
-            s.p = WRITE ? text + off[mine] : nullptr;
-            format_record(s, my, pool, in, L, name, name_len, lut);
-            if (!WRITE) len_out[mine] = (uint32_t)s.n;
+        by_lane = span <= VCF_LANE_SPAN;
+    }
+    unsigned long long my_off = 0, start0 = 0;
+    uint32_t my_len = 0, stretch = 0, phase = 0;
+    bool staged = false;
+    if (WRITE) {
+        if (valid) { my_off = off[mine]; my_len = len_io[mine]; }
+        const uint32_t last = min(63u, n_rec - 1 - base_rec);
+        start0 = __shfl(my_off, 0, 64);
+        const unsigned long long end = __shfl(my_off + my_len, (int)last, 64);
+        stretch = (uint32_t)min(end - start0, (unsigned long long)(2 * VCF_STAGE));
+        phase = (uint32_t)(start0 & 15);
+        staged = __ballot(valid && !by_lane) == 0ull && phase + stretch <= VCF_STAGE;
+    }
+    if (valid && my.type == MSIM_SN) {                                   // mutator.py:334-341
+        const unsigned long long start = (unsigned long long)my.pos + 1;
+        const int nd = ndigits(start);
+        if (!WRITE) {
+            const uint8_t x = in[my.pos];
+            const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];      // ti / tv column of conv(x)
+            len_io[mine] = ref == alt ? 0u : name_len + (uint32_t)nd + 19u;                 // vcf_writer.py:123: REF == ALT suppressed
+            ra[mine] = (uint16_t)((uint32_t)ref | ((uint32_t)alt << 8));
+        } else if (my_len) {
+            const uint32_t r2 = ra[mine];
+            if (staged) snp_line(&stage[wave][phase + (uint32_t)(my_off - start0)], name, name_len, start, nd, (uint8_t)r2, (uint8_t)(r2 >> 8));
+            else snp_line(text + my_off, name, name_len, start, nd, (uint8_t)r2, (uint8_t)(r2 >> 8));
         }
+    } else if (valid && by_lane) {
+        LSink<WRITE> s;
+        s.n = 0;
+        s.p = !WRITE ? nullptr : staged ? &stage[wave][phase + (uint32_t)(my_off - start0)] : text + my_off;
+        format_record(s, my, pool, in, L, name, name_len, lut);
+        if (!WRITE) len_io[mine] = (uint32_t)s.n;
+    }
+    if (WRITE && staged) {                                               // (wave-uniform)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (flat stores into LDS complete out of order with ds reads: wait for both)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        char *g0 = text + (start0 - phase);                              // 16-byte aligned (the text buffer is)
+        const uint32_t lim = phase + stretch;
+        for (uint32_t k = lane_id * 16; k < lim; k += 64 * 16) {
+            if (k >= phase && k + 16 <= lim) {
+                *reinterpret_cast<uint4 *>(g0 + k) = *reinterpret_cast<const uint4 *>(&stage[wave][k]);
+            } else {
+                const uint32_t lo = max(k, phase), hi = min(k + 16, lim);
+                for (uint32_t q = lo; q < hi; q++) g0[q] = stage[wave][q];
+            }
+        }
+        return;
     }
     unsigned long long todo = __ballot(valid && !by_lane);
     while (todo) {
@@ -334,9 +383,9 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         WSink<WRITE> s;
         s.lane = lane_id;
         s.n = 0;
-        s.p = WRITE ? text + off[i] : nullptr;
+        s.p = WRITE ? text + __shfl(my_off, src_lane, 64) : nullptr;
         format_record(s, r, pool, in, L, name, name_len, lut);
-        if (!WRITE && s.lane == 0) len_out[i] = (uint32_t)s.n;
+        if (!WRITE && s.lane == 0) len_io[i] = (uint32_t)s.n;
     }
 }
 
@@ -560,23 +609,25 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     hipStream_t st = c->stream;
     const size_t name_len = strlen(seq_name);
     const uint32_t nb = (n + LS_BLOCK - 1) / LS_BLOCK;
-    // scratch: name | lens u32[n] | sums u64[nb+1] | off u64[n]
+    // scratch: name | lens u32[n] | sums u64[nb+1] | off u64[n] | REF/ALT of the SNP records u16[n]
     const size_t o_len = (name_len + 255) & ~(size_t)255;
     const size_t o_sums = o_len + (((size_t)n * 4 + 255) & ~(size_t)255);
     const size_t o_off = o_sums + (((size_t)(nb + 1) * 8 + 255) & ~(size_t)255);
-    int rc = dev_reserve(c, (void **)&c->d_text_scratch, &c->cap_text_scratch, o_off + (size_t)n * 8);
+    const size_t o_ra = o_off + (((size_t)n * 8 + 255) & ~(size_t)255);
+    int rc = dev_reserve(c, (void **)&c->d_text_scratch, &c->cap_text_scratch, o_ra + (size_t)n * 2);
     if (rc) return rc;
     uint8_t *base = c->d_text_scratch;
     uint8_t *d_name = base;
     uint32_t *d_len = reinterpret_cast<uint32_t *>(base + o_len);
     unsigned long long *d_sums = reinterpret_cast<unsigned long long *>(base + o_sums);
     unsigned long long *d_off = reinterpret_cast<unsigned long long *>(base + o_off);
+    uint16_t *d_ra = reinterpret_cast<uint16_t *>(base + o_ra);
     MSIM_HIP(c, hipMemcpyAsync(d_name, seq_name, name_len, hipMemcpyHostToDevice, st));
     const uint8_t *in = g.d_in + PAD;
     const uint8_t *pool = g.d_pool ? g.d_pool + PAD : nullptr;
     const dim3 grid((n + 64 * TX_WAVES - 1) / (64 * TX_WAVES));           // a wave takes 64 consecutive records
     hipLaunchKernelGGL(k_vcf_lines<false>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, (const unsigned long long *)nullptr, (char *)nullptr);
+                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, (const unsigned long long *)nullptr, (char *)nullptr);
     hipLaunchKernelGGL(k_len_reduce, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, d_sums, nb, c->h_mail);
     hipLaunchKernelGGL(k_len_offsets, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums, d_off);
@@ -587,7 +638,7 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     if (rc) return rc;
     if (total) {
         hipLaunchKernelGGL(k_vcf_lines<true>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                           d_name, (uint32_t)name_len, ctx_lut(c), (uint32_t *)nullptr, d_off, reinterpret_cast<char *>(*buf));
+                           d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf));
         MSIM_HIP(c, hipGetLastError());
     }
     if (own) c->text_len = total;
