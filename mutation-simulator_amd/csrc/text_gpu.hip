@@ -19,7 +19,8 @@
 //                               the write pass formats a wave's lines into LDS where all 64 are short and stores the stretch
 //                               16 aligned bytes per lane; REF / ALT of SNP records come from the length pass (no second gather)
 //   (round 4, profiles/r04_kernel_stats_cli_*.txt: k_gather / k_frame 4.8-5.2 TB/s; k_vcf_lines' write pass on SNP tables
-//    2.5 TB/s [1.26 with a lane's own byte stores], its length pass 1.4 TB/s -- it gathers one base per record from the contig)
+//    4.0 TB/s [1.26 with a lane's own byte stores and the general kernel's registers], its length pass 1.4 TB/s -- it gathers
+//    one base per record from the contig)
 //   IT     k_splice : interchromosomal translocation of one contig -- segments of two contigs taken alternately
 //                     (it_mutator.py:121-146 __write_with_bp)
 // Byte/integer work, HBM-bound; no MFMA.
@@ -284,7 +285,9 @@ __device__ __forceinline__ void snp_line(P p, const uint8_t *__restrict__ name, 
 // len_io: the lines' lengths -- written by the length pass, read by the write pass.  ra: REF | ALT << 8 of every SNP record, left
 // by the length pass (which has to look at the base anyway: REF == ALT is suppressed) so that the write pass does not gather
 // the contig's bases at 2 M scattered positions a second time.
-template <bool WRITE>
+// ALL_SNP (Contig::all_snp: the table holds SNP records only -- the SNP sampler's, `-sn` alone): the kernel without the other
+// types' formatter -- 52 registers instead of 139, eight waves per SIMD instead of three.
+template <bool WRITE, bool ALL_SNP>
 __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
                                                           const uint8_t *__restrict__ pool,
                                                           const uint8_t *__restrict__ in, unsigned long long L,
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
     msim_record my{};
     if (valid) my = recs[mine];
     bool by_lane = false;
-    if (valid && my.type == MSIM_SN) {
+    if (valid && (ALL_SNP || my.type == MSIM_SN)) {
         by_lane = true;
     } else if (valid) {
         const unsigned long long hi = (unsigned long long)my.stop + 1 < L ? (unsigned long long)my.stop + 1 : L;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         phase = (uint32_t)(start0 & 15);
         staged = __ballot(valid && !by_lane) == 0ull && phase + stretch <= VCF_STAGE;
     }
-    if (valid && my.type == MSIM_SN) {                                   // mutator.py:334-341
+    if (valid && (ALL_SNP || my.type == MSIM_SN)) {                      // mutator.py:334-341
         const unsigned long long start = (unsigned long long)my.pos + 1;
         const int nd = ndigits(start);
         if (!WRITE) {
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
             if (staged) snp_line(&stage[wave][phase + (uint32_t)(my_off - start0)], name, name_len, start, nd, (uint8_t)r2, (uint8_t)(r2 >> 8));
             else snp_line(text + my_off, name, name_len, start, nd, (uint8_t)r2, (uint8_t)(r2 >> 8));
         }
-    } else if (valid && by_lane) {
+    } else if (!ALL_SNP && valid && by_lane) {
         LSink<WRITE> s;
         s.n = 0;
         s.p = !WRITE ? nullptr : staged ? &stage[wave][phase + (uint32_t)(my_off - start0)] : text + my_off;
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         }
         return;
     }
+    if (ALL_SNP) return;
     unsigned long long todo = __ballot(valid && !by_lane);
     while (todo) {
         const int src_lane = __builtin_ctzll(todo);
@@ -626,8 +630,10 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     const uint8_t *in = g.d_in + PAD;
     const uint8_t *pool = g.d_pool ? g.d_pool + PAD : nullptr;
     const dim3 grid((n + 64 * TX_WAVES - 1) / (64 * TX_WAVES));           // a wave takes 64 consecutive records
-    hipLaunchKernelGGL(k_vcf_lines<false>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, (const unsigned long long *)nullptr, (char *)nullptr);
+#define MSIM_VCF_LINES(W, ...) do { if (g.all_snp) hipLaunchKernelGGL((k_vcf_lines<W, true>), __VA_ARGS__); \
+                                    else hipLaunchKernelGGL((k_vcf_lines<W, false>), __VA_ARGS__); } while (0)
+    MSIM_VCF_LINES(false, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
+                   d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, (const unsigned long long *)nullptr, (char *)nullptr);
     hipLaunchKernelGGL(k_len_reduce, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, d_sums, nb, c->h_mail);
     hipLaunchKernelGGL(k_len_offsets, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums, d_off);
@@ -637,8 +643,9 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     rc = dev_reserve(c, (void **)buf, cap, total + 64);
     if (rc) return rc;
     if (total) {
-        hipLaunchKernelGGL(k_vcf_lines<true>, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                           d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf));
+        MSIM_VCF_LINES(true, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
+                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf));
+#undef MSIM_VCF_LINES
         MSIM_HIP(c, hipGetLastError());
     }
     if (own) c->text_len = total;

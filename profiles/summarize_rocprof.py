@@ -53,8 +53,8 @@ def text(db, wall_line=""):
     print("\n# text kernels: bytes moved (in + out, MB, whole run) / total duration -> achieved GB/s (HBM peak 8000)")
     for pat, mb, what in (("%k_gather%", fa_mb + bases_mb, "file text in, bases out"),
                           ("%k_frame%", bases_mb + fa_mb, "mutated bases in, wrapped text out"),
-                          ("%k_vcf_lines<true>%", 2.0 * vcf_mb, "records + REF/ALT sources in (~ text size), text out"),
-                          ("%k_vcf_lines<false>%", vcf_mb, "records + REF/ALT sources in (line lengths only)")):
+                          ("%k_vcf_lines<true%", 2.0 * vcf_mb, "records + REF/ALT sources in (~ text size), text out"),
+                          ("%k_vcf_lines<false%", vcf_mb, "records + REF/ALT sources in (line lengths only)")):
         row = c.execute("select sum(total_calls), sum(total_duration) from top_kernels where name like ?", (pat,)).fetchone()
         if row and row[1]:
             print(f"{pat.strip('%'):24s} calls={int(row[0]):4d} total_us={row[1]:10.1f} {mb:9.1f} MB -> {mb * 1e6 / (row[1] * 1e-6) / 1e9:8.1f} GB/s  ({what})")
