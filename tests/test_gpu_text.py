@@ -119,6 +119,27 @@ def test_vcf_device_snp_only_table_from_gpu_sampler():
     eng.close()
 
 
+@pytest.mark.parametrize("name_len", [1, 36, 37, 38, 39, 40, 41, 150])
+def test_vcf_device_snp_lines_at_the_staging_limit(name_len):
+    """The write pass formats the 64 lines of a wave into 4 KB of LDS when they fit (k_vcf_lines, VCF_STAGE) and writes them
+    one lane each when they do not: names around the limit (64 lines of name + 7 digits + 19 bytes, plus the stretch's phase),
+    a name far beyond it, suppressed lines in between -- on an SNP-only table (its own kernel) and on a mix of short records."""
+    L = 2_500_000
+    name = ("chr" + "x" * 200)[:name_len]
+    bases = random_bases(L, 31 + name_len)
+    bases[5000:5400] = ord("N")                          # REF == ALT: suppressed lines inside staged stretches
+    for types, lens, k in (({1: 1.0}, {}, 40_000), ({1: 0.6, 2: 0.2, 3: 0.2}, {2: (1, 3), 3: (1, 3)}, 20_000)):
+        eng = _ffi.Engine(0)
+        eng.seed(7, 8)
+        eng.set_params(_params(titv=2.0))
+        cid = _plan_apply(eng, bases, [_sv_range(0, L - 1, k, types, lens)])
+        recs, pool = eng.fetch_records(cid)
+        want = _ffi.render_vcf(recs, pool, bases, name)
+        assert eng.render_vcf_device(cid, name).tobytes() == want
+        assert len(want) > 15 * len(recs)
+        eng.close()
+
+
 @pytest.mark.parametrize("bpl", [1, 7, 60, 61, 4096])
 def test_framed_fetch_equals_fasta_writer_rule(bpl):
     L = 123_457
