@@ -538,7 +538,13 @@ def main():
     seed = 42 if strong else 42 + rank       # replicas: every GPU mutates its own genome
 
     # (MSIM_BENCH_DEVICE: put every rank on one GPU -- lets the N > 1 control flow run on a 1-GPU box)
-    eng = _ffi.Engine(int(os.environ.get("MSIM_BENCH_DEVICE", local_rank)))
+    device = int(os.environ.get("MSIM_BENCH_DEVICE", local_rank))
+    # The calling thread moves onto the CPUs of its GPU's NUMA node, as the CLI's does (_ffi.warm_up_async: sysfs numa_node of
+    # the PCI device; MSIM_NO_PIN=1 leaves it where the scheduler put it).  A c2 step is ~160 dependent launches: from the
+    # other socket of the pool's two-socket hosts it takes 4.37-4.45 ms, from the GPU's own 4.18-4.26 -- unpinned, a
+    # process lands on either (the two "modes" of the round-3 and round-4 notes).
+    _ffi.warm_up_async(device, pin=True).join()
+    eng = _ffi.Engine(device)
     # genome resident in HBM before the timed region (3 GB; every rank holds every contig so that
     # contig numbering is global -- 288 GB of HBM make the replica free)
     cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
@@ -609,6 +615,9 @@ def main():
             "config": {"workload": f"{W['mode']} mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), {W['what']}"
                                    ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
                        "total_bases": total, "contigs": len(lengths),
+                       "host_thread": (f"on the CPUs of the GPU's NUMA node ({len(os.sched_getaffinity(0))} of {os.cpu_count()})"
+                                       if hasattr(os, "sched_getaffinity") and len(os.sched_getaffinity(0)) < (os.cpu_count() or 0)
+                                       else "where the scheduler put it"),
                        "parallelism": (f"one genome, contigs sharded over {world} GPUs (LPT), stream chain walked per rank, "
                                        "results left in HBM on the owning GPU ('with_gather' adds the RCCL gather to rank 0)"
                                        if strong else f"{world} independent replica(s): one whole genome per GPU, "

@@ -20,6 +20,7 @@ def main():
     total = int(float(sys.argv[3])) if len(sys.argv) > 3 else 3_000_000_000
     lengths = bench.contig_lengths(total)
     sim = bench.build_settings(w, lengths)
+    _ffi.warm_up_async(0, pin=True).join()              # (as the CLI and bench.py: the calling thread on the GPU's NUMA node)
     eng = _ffi.Engine(0, _ffi.RNG_FAST)
     cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
     tables = [mm.plan_table(ch) for ch in sim.chromosomes]
