@@ -175,7 +175,7 @@ C3_FLAGS = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-dem
 README_FLAGS = ["-in", "0.01", "-de", "0.01", "-du", "0.01", "-iv", "0.01", "-tl", "0.01"]     # + -sn 0.01: README.md:430-446
 
 WORKLOADS = {
-    "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp_b",   # (three contigs per launch)
+    "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp_b",   # (two contigs per launch)
            "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01"},
     "c3": {"mode": "ARGS", "what": "full SV mix (BASELINE configs[2]): -sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500",
            "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},
@@ -485,8 +485,8 @@ def stages_of(st, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)             # (the driver's own: --steps 20 --warmup 5)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--total-bases", type=int, default=3_000_000_000)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")

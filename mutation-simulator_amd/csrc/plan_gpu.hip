@@ -896,9 +896,12 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     const bool grouped = fold_aux && !no_group;
     // A full group goes out when the NEXT contig is planned, in front of its chain: by then msim_apply_contig has marked the
     // group's last contig too, so all of its APPLYs share the group's tile-index launch.
-    // (threes: 4.24-4.30 ms per c2 step; pairs 4.26-4.5, fours 4.45-4.5, eights 4.55 -- larger groups bunch the rewrite
-    //  kernels and lengthen what is left to do behind the last chain; one per group = the ungrouped 4.6-5.1)
-    static const int group = getenv("MSIM_EMIT_GROUP") ? std::min(EMIT_G, std::max(1, atoi(getenv("MSIM_EMIT_GROUP")))) : 3;
+    // (pairs.  Measured with the calling thread on the GPU's NUMA node, where runs repeat within 0.05 ms: pairs 4.10-4.21 ms per
+    //  c2 step with the rewrite launches at 0.72-0.74 of the HBM peak, threes 4.22-4.31 at 0.75-0.77, fours 4.29-4.32 at 0.78,
+    //  sixes 4.36-4.38 at 0.79 -- a larger group is a better rewrite launch and a longer stretch in which the chain's kernels
+    //  crawl beside it, plus more left to do behind the last chain; groups cut by their bases instead of their count, 250-400 Mb
+    //  with at most 4-6 contigs, were no better than threes; one per group = the ungrouped 4.6-5.1)
+    static const int group = getenv("MSIM_EMIT_GROUP") ? std::min(EMIT_G, std::max(1, atoi(getenv("MSIM_EMIT_GROUP")))) : 2;
     if (!g->emit_items.empty() && (!grouped || g->emit_d != (uint32_t)d || g->emit_items.size() >= (size_t)group))
         if ((rc = gpu_emit_flush(c))) return rc;
     struct { SampleSet *S; uint32_t bmw, bnb, start; } late = {nullptr, 0, 0, 0};
