@@ -214,29 +214,51 @@ def host_info():
     return model, os.cpu_count()
 
 
-def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4):
+def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4, device=None):
     """CPU oracle (single-threaded C restatement of the reference path) on a bounded sample of the same
     workload: `n_contigs` contigs totalling `sample_total` bases with the workload's settings, seeds 42/42.
     The reference itself cannot travel to the GPU box; its wall time measured in the build container
-    (tests/golden/reference_timing.json, written by `make_goldens.py timing`) is carried along."""
+    (tests/golden/reference_timing.json, written by `make_goldens.py timing`) is carried along.
+
+    `device` given: the same sample genome then goes through `one_step` -- the function the timed steps run: plan + apply
+    every contig, ONE synchronisation, reads afterwards (emission groups, batched rewrite launches) -- on that GPU, and
+    `matches_gpu` says whether every contig's framed Fasta body and VCF text equal the oracle's (SHA-256 per contig) and
+    whether both MT19937 streams end where the oracle's do.  The oracle stays the checker: nothing of it is inside `value`."""
+    import hashlib
+
     from oracle import oracle as orc
     from test_gpu_parity import synth_host  # same generator as the device kernel
     from test_host_settings import dump_sim
     lengths = [sample_total // n_contigs] * n_contigs
     sim = build_settings(workload, lengths)
-    contigs = [{"name": f"chr{i+1}", "long_name": f"chr{i+1} synthetic", "lenc": 60,
-                "bases": synth_host(L, 1000 + i)} for i, L in enumerate(lengths)]
+    dump = dump_sim(sim)
+    by_number = {ch["number"]: ch for ch in dump["chromosomes"]}
     o = orc.Oracle()
     o.seed(42, 42)
-    t0 = time.perf_counter()
-    o.run_genome(contigs, dump_sim(sim), "synthetic.fa")
-    dt = time.perf_counter() - t0
+    o.configure(dump)
+    dt = 0.0
+    want = {}
+    for chrom in sim.chromosomes:                      # mutate()'s contig loop, mutator.py:111-141
+        i = chrom.number
+        name = f"chr{i+1}"
+        bases = synth_host(lengths[i], 1000 + i)
+        t0 = time.perf_counter()
+        fa, vcf, _ = o.mutate_contig_stream(bases, name, f"{name} synthetic", 60, by_number[i]["ranges"])
+        dt += time.perf_counter() - t0
+        head = len(f">{name} synthetic\n")
+        want[i] = (hashlib.sha256(memoryview(fa)[head:]).hexdigest(), hashlib.sha256(vcf).hexdigest(), vcf.count(b"\n"))
+        del bases, fa, vcf
     total = sum(lengths)
     model, cores = host_info()
     out = {"value": round(total / dt / 1e6, 3), "unit": "Mbases/s", "cores": 1, "kind": "port",
            "cpu_model": model, "node_cores": cores,
            "sample": f"{n_contigs} contigs x {lengths[0]/1e6:.0f} Mb, {WORKLOADS[workload]['what']}, seeds 42/42, "
                      f"Fasta framing + VCF text included ({dt:.1f} s of CPU work)"}
+    if device is not None:
+        try:
+            out["matches_gpu"], out["matches_gpu_detail"] = gpu_matches_oracle(device, sim, lengths, want, o)
+        except Exception as e:  # noqa: BLE001
+            out["matches_gpu"], out["matches_gpu_detail"] = False, {"error": f"{type(e).__name__}: {e}"}
     rt = ROOT / "tests" / "golden" / "reference_timing.json"
     if rt.exists():
         try:
@@ -247,6 +269,53 @@ def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4):
         except Exception:  # noqa: BLE001
             pass
     return out
+
+
+def gpu_matches_oracle(device, sim, lengths, want, oracle):
+    """The cpu_baseline sample genome through `one_step` (the timed function, in the timed order) on the GPU; per contig the
+    SHA-256 of the framed Fasta body and of the device-rendered VCF lines against the oracle's (`want`), line counts, and the
+    final positions of both MT19937 streams."""
+    import hashlib
+    import random
+
+    from mutation_simulator_amd import _ffi
+    from mutation_simulator_amd import mutator as mm
+    eng = _ffi.Engine(device)
+    try:
+        cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
+        eng.set_params(mm.params_descriptor(sim))
+        eng.reset_stats()
+        one_step(eng, sim, cids, list(range(len(lengths))), 42, mm.plan_table)
+        st = eng.stats()
+        bad = []
+        lines = 0
+        for chrom in sim.chromosomes:
+            i = chrom.number
+            name = f"chr{i+1}"
+            text = eng.fetch_sequence_framed(cids[i], 60, guess_len=lengths[i])
+            _, n_rec, _ = eng.result_sizes(cids[i], applied=False)
+            vcf = eng.render_vcf_device(cids[i], name, guess=n_rec * 48 + 256)
+            got = (hashlib.sha256(memoryview(text)).hexdigest(), hashlib.sha256(memoryview(vcf)).hexdigest(), bytes(vcf).count(b"\n"))
+            lines += got[2]
+            if got != want[i]:
+                bad.append(name)
+            del text, vcf
+        streams_ok = True
+        for stream in (0, 1):
+            mt, pos = eng.get_mt_state(stream)
+            omt, opos = oracle.get_state(stream)
+            a, b = random.Random(), random.Random()
+            a.setstate((3, tuple(int(x) for x in mt) + (int(pos),), None))
+            b.setstate((3, tuple(omt) + (opos,), None))
+            streams_ok = streams_ok and [a.getrandbits(32) for _ in range(8)] == [b.getrandbits(32) for _ in range(8)]
+        detail = {"what": "the sample genome through bench.one_step (plan + apply all contigs, one sync, then reads) on the GPU: "
+                          "SHA-256 of each contig's framed Fasta body and device VCF text == the oracle's, both MT19937 streams "
+                          "end where the oracle's do",
+                  "contigs": len(lengths), "contigs_differing": bad, "vcf_lines": lines, "streams_end_equal": streams_ok,
+                  "apply_launches": st["apply_launches"], "plan_engines": engines_of(st, 1)}
+        return (not bad) and streams_ok, detail
+    finally:
+        eng.close()
 
 
 def e2e_cli(eng, total_bases=1_200_000_000, n_contigs=6, where="tmpfs"):
@@ -496,10 +565,10 @@ def main():
                          "c4 = configs[3], RMT mode with ~40 k blocked ranges + hot/cold spots; c4sv = the c4 file with the "
                          "c3 SV mix as its std line")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
-                    help="N > 1: 'weak' (default) = N independent genomes, one per GPU with its own seeded streams (per-GPU work "
-                         "fixed); 'strong' = BASELINE configs[4]'s shape: ONE genome, contigs sharded (LPT), the MT19937 stream "
-                         "chain walked on every rank, RCCL gather to rank 0.  The other mode is measured too and reported in the "
-                         "same line")
+                    help="N > 1: 'strong' (default) = BASELINE configs[4]'s shape: ONE genome, contigs sharded (LPT), the MT19937 "
+                         "stream chain walked on every rank, RCCL gather to rank 0 (Amdahl-bound by the chain: amdahl_ceiling); "
+                         "'weak' = N independent genomes, one per GPU with its own seeded streams (per-GPU work fixed; scales "
+                         "linearly).  The other mode is measured too and reported in the same line")
     ap.add_argument("--gather", action="store_true", help="(kept for compatibility: the gather is always measured for N > 1, strong)")
     a = ap.parse_args()
 
@@ -723,7 +792,7 @@ def main():
                 sec[key] = {"error": f"{type(e).__name__}: {e}"}
         line["secondary"] = sec
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload)      # bounded sample: ~6-10 s of CPU work
+        line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload, device=device)      # bounded sample: ~6-10 s of CPU work
     printed = [False]
 
     def emit_line():

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 5
+#define MSIM_ABI_VERSION 6
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -38,7 +38,10 @@ extern "C" {
                                      is negative") -- util.py:104 via random.sample                */
 #define MSIM_ERR_KEY          4   /* reference raises KeyError(base): transversion of a base outside
                                      A,G,T,C,N -- mutator.py:449-455; see msim_key_error()         */
-#define MSIM_ERR_UNSUPPORTED  5   /* valid for the reference, outside this build (contigs >= 4 GiB)  */
+#define MSIM_ERR_UNSUPPORTED  5   /* valid for the reference, outside this build: contigs (or their mutated
+                                     form) of 4 GiB and more, 2^31 mutations on one contig, an output file
+                                     that cannot be written at an offset, MSIM_PLAN_GPU forced on a contig
+                                     no device engine takes (README "Limits")                          */
 #define MSIM_ERR_NOMEM        6
 #define MSIM_ERR_IO           7   /* a write queued by the *_file entry points failed (msim_last_error)   */
 
@@ -131,6 +134,9 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     uint64_t contigs_host;       /* sequential host planner (translocations, overlapping ranges, tiny contigs)         */
     uint64_t contigs_batch;      /* contigs that went through msim_batch_run (host planner, one APPLY per batch)       */
     uint64_t contigs_fast;       /* MSIM_RNG_FAST contexts: contigs planned with the counter-based generator            */
+    uint64_t stream_rebases;     /* device MT19937 sessions re-based: the jump tables span 8192 chunks (1.31 G words) from a
+                                    session's origin; before a contig that would not fit, the state at the streams' exact
+                                    positions becomes the next session's origin (no limit on a run's stream length)     */
 } msim_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

@@ -483,10 +483,15 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
         return rc;
     }
     const bool dev = !c->host_only && c->gpu && !(c->flags & MSIM_PLAN_HOST);
-    const bool gpu_ok = dev && gpu_plan_eligible(c, ranges, n_ranges);
-    const bool mixed_ok = dev && !gpu_ok && gpu_plan_mixed_eligible(c, ranges, n_ranges);
-    const bool hs_ok = dev && !gpu_ok && !mixed_ok && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
-    const bool mm_ok = dev && !gpu_ok && !mixed_ok && !hs_ok && gpu_plan_multimix_eligible(c, c->gpu, g->len, ranges, n_ranges);
+    bool gpu_ok = dev && gpu_plan_eligible(c, ranges, n_ranges);
+    bool mixed_ok = dev && !gpu_ok && gpu_plan_mixed_eligible(c, ranges, n_ranges);
+    bool hs_ok = dev && !gpu_ok && !mixed_ok && gpu_plan_hostsample_eligible(c, ranges, n_ranges);
+    bool mm_ok = dev && !gpu_ok && !mixed_ok && !hs_ok && gpu_plan_multimix_eligible(c, c->gpu, g->len, ranges, n_ranges);
+    if (gpu_ok || mixed_ok || hs_ok || mm_ok) {            // the device streams' sessions span 1.31 G words: re-base where this contig
+        bool fits = true;                                  // would not fit; a contig no span holds is the host planner's
+        if ((rc = gpu_plan_make_room(c, c->gpu, ranges, n_ranges, &fits))) return rc;
+        if (!fits) gpu_ok = mixed_ok = hs_ok = mm_ok = false;
+    }
     // A deferred APPLY of the previous contig (msim_apply_contig) is enqueued when this plan's host chain starts --
     // by the engine itself -- so that it fills the device's idle time instead of competing with this contig's
     // latency-bound chain kernels.  Every other route enqueues it now.

@@ -159,6 +159,10 @@ struct GpuPlan {
     uint32_t emit_d = 1;                //   ... and the sampling distance they share
     uint64_t verified_pos = 0;          // exact position at the last finish
     uint64_t reserve_words[2] = {0, 0};
+    // per context, read when it is created (tests run several group sizes / stream spans in one process):
+    int emit_group = 2;                 //   contigs per emission group (MSIM_EMIT_GROUP; see plan_contig_gpu)
+    uint32_t max_chunks = MT_JUMP_MAX_CHUNKS;   //   chunks one (re)seeded session may span (MSIM_DBG_JUMP_MAX_CHUNKS lowers it)
+    uint32_t rebases = 0;               //   sessions ended because the next contig would not fit into the span
 };
 
 static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
@@ -176,7 +180,13 @@ static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
     return MSIM_OK;
 }
 
-GpuPlan *gpu_plan_create() { return new GpuPlan(); }
+GpuPlan *gpu_plan_create() {
+    GpuPlan *g = new GpuPlan();
+    if (const char *e = getenv("MSIM_EMIT_GROUP")) g->emit_group = std::min(EMIT_G, std::max(1, atoi(e)));
+    if (const char *e = getenv("MSIM_DBG_JUMP_MAX_CHUNKS"))
+        g->max_chunks = (uint32_t)std::min<long>(MT_JUMP_MAX_CHUNKS, std::max<long>(2, atol(e)));
+    return g;
+}
 
 // Page-locked staging buffers of the engines with a host chain (grow_host): plain 2 MB-aligned memory on huge pages,
 // registered with the runtime.  Measured on the bench box per GiB: hipHostMalloc 182 ms + 90 ms to free; aligned_alloc +
@@ -275,6 +285,86 @@ void gpu_plan_invalidate(GpuPlan *g) {
 }
 void gpu_plan_reserve(GpuPlan *g, uint64_t py_words, uint64_t np_words) { g->reserve_words[0] = py_words; g->reserve_words[1] = np_words; }
 
+// Words one (re)seeded session can address: the jump polynomials (mt_jump_table.h) reach MT_JUMP_MAX_CHUNKS chunks from its origin.
+static inline uint64_t span_words(const GpuPlan *g) { return (uint64_t)MT_N + (uint64_t)g->max_chunks * MT_CHUNK_WORDS; }
+
+// The reference's generators have no length limit (mutator.py:105-142 draws from the two global streams for as long as the genome
+// lasts; util.py:104), the jump tables have: 8192 chunks = 1.31 G words from a session's origin (-sn 0.01: ~20 Gb of genome).
+// Before a contig is handed to a device engine: will its windows fit into what is left of the span?  If not, the session is
+// RE-BASED -- everything in flight is finished, the 624-word window at each stream's exact position goes to the host generators
+// (gpu_plan_sync_to_host: any such window is a valid state) and the engine's stream_to_device makes it the origin of a new
+// session; a synchronisation and a fresh cascade every 1.3 G words.  *fits = false: not even an empty span holds this contig
+// (hundreds of millions of candidates on one contig) -- AUTO plans it on the host, which has no such limit.
+// The need is an upper bound built from the engines' own window formulas (enqueue_sample_chain, enqueue_snp_stage, window_of,
+// mixed_link_translocations), summed as if every stage started at the end of the previous one's window.
+int gpu_plan_make_room(Ctx *c, GpuPlan *g, const msim_range *ranges, int n_ranges, bool *fits) {
+    const msim_params &P = c->params;
+    int64_t d = P.block[1];
+    for (int t = 2; t <= 7; t++) d = std::min(d, P.block[t]);
+    double py = 0, np = 0, K = 0, K_chain = 0, pool_mean = 0, pool_var = 0, e_small = 0, var_small = 0;
+    bool has_tl = false, bad = false;
+    int n_big = 0;
+    for (int i = 0; i < n_ranges; i++) {
+        const msim_range &r = ranges[i];
+        if (r.k <= 0) continue;
+        const double k = (double)r.k;
+        const double n = (double)((r.stop - (r.k - 1) * d) - r.start);
+        K += k;
+        if (n < k) bad = true;                                           // ValueError: whoever plans it raises it
+        else if (n <= (double)r.setsize) { e_small += 2.0 * k; var_small += 2.0 * k; }    // pool path: < 2 words per draw
+        else if (n >= 4294967296.0) bad = true;                          // (multi-word getrandbits: no device engine takes it)
+        else {                                                           // set path: the first k distinct accepted draws
+            const double p_acc = n / (double)(1ull << bit_length64((uint64_t)n));
+            const double need = k >= n ? 64.0 * k : -n * std::log1p(-k / n);             // coupon collector
+            if (r.k >= 4096) {                                           // a window of its own (enqueue_sample_chain)
+                const double target = need + 16.0 * std::sqrt(need) + 4096.0;
+                py += target / p_acc + 16.0 * std::sqrt(target) / p_acc + 8192.0;
+                n_big++;
+            } else {                                                     // small ranges share one window (host-cut / host-chain engines)
+                e_small += need / p_acc;
+                var_small += need * (1.0 - p_acc) / (p_acc * p_acc) + 4.0 * (need - k) / (p_acc * p_acc) + need / p_acc;
+            }
+        }
+        bool chain = P.block[MSIM_SN] != d;                              // an SNP that blocks rides the chain too
+        for (int j = 0; j < r.n_types; j++) {
+            const uint64_t lo = j ? r.cdf_thr[j - 1] : 0;
+            if (!(r.cdf_thr[j] > lo && lo < (1ull << 53))) continue;
+            const int t = r.types[j];
+            if (t == MSIM_SN) continue;
+            chain = true;
+            if (t == MSIM_TL || t == MSIM_TLI) has_tl = true;
+            if (t == MSIM_IN) {
+                const double q = (double)(std::min<uint64_t>(r.cdf_thr[j], 1ull << 53) - lo) / 9007199254740992.0;
+                const double mx = (double)std::max<int64_t>(r.max_len[t], 1);
+                pool_mean += k * q * mx;                                 // (every insert at its longest: a bound, not an estimate)
+                pool_var += k * q * mx * mx;
+            }
+        }
+        if (chain) K_chain += k;
+    }
+    py += e_small + 16.0 * std::sqrt(var_small);
+    if (K_chain > 0) py += 2.0 * K_chain + 32.0 * std::sqrt(K_chain) + 4096.0;              // randint windows (acceptance >= 1/2)
+    if (has_tl) py += 6.0 * K_chain + 16.0 * std::sqrt(25.0 * K_chain + 1.0) + 4096.0;      // __link_tls
+    py += 4.0 * K + 16.0 * std::sqrt(4.0 * K) + 16384.0 + 3.0 * SNP_BLOCK2;                 // SNP draws (<= 4 words each, expected)
+    py += 2.0 * 65536.0 + 8192.0 * n_big;
+    np = 2.0 * K + pool_mean + 16.0 * std::sqrt(pool_var) + 4096.0;
+    const double span = (double)(span_words(g) - MT_N);
+    *fits = true;
+    if (bad) return MSIM_OK;                                             // (the engines' eligibility refuses these themselves)
+    *fits = std::isfinite(py) && py < span && np < span;
+    if (!*fits) return MSIM_OK;
+    const GpuStream &s0 = g->s[0], &s1 = g->s[1];
+    const bool live = s0.live || s1.live;
+    const double at0 = s0.live ? (double)s0.pos : (double)MT_N, at1 = s1.live ? (double)s1.pos : (double)MT_N;
+    if (live && (at0 + py > (double)span_words(g) || at1 + np > (double)span_words(g))) {
+        const int rc = gpu_plan_sync_to_host(c, g);          // both streams: exact positions -> host states; the next engine reseeds
+        if (rc) return rc;
+        g->rebases++;
+        c->t.stream_rebases++;
+    }
+    return MSIM_OK;
+}
+
 // Side streams of the stream machinery: the jump cascade and chunk generation run beside the plan chain.
 static int ensure_side_streams(Ctx *c, GpuPlan *g) {
     if (g->gen_stream) return MSIM_OK;
@@ -309,11 +399,15 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
         // batch the extension: an explicit hint, or what the previous session on this context needed
         // A generation batch costs ~300 us of latency whatever its size, so never extend piecemeal: take
         // what the previous session on this context went through, else at least double the stream.
+        const uint64_t span = span_words(g);               // what the jump tables reach from this session's origin
+        // (gpu_plan_make_room re-bases the session between contigs so that a plan never gets here; should a window estimate
+        //  ever fall short, the caller's recovery for overflowed windows applies: mutator.py re-plans through the host planner)
+        if (upto > span) return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its session's jump-table span (results discarded)");
         uint64_t want = std::max<uint64_t>(upto, s.pos + g->reserve_words[si]);
         want = std::max<uint64_t>(want, std::min<uint64_t>(s.last_session_words, want * 64));
-        if (s.n_chunks) want = std::max<uint64_t>(want, std::min<uint64_t>(2 * have, (uint64_t)MT_N + (uint64_t)MT_JUMP_MAX_CHUNKS * MT_CHUNK_WORDS));
+        if (s.n_chunks) want = std::max<uint64_t>(want, 2 * have);
+        want = std::min<uint64_t>(want, span);             // hints never reach beyond the span
         const uint32_t need_chunks = (uint32_t)((want - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
-        if (need_chunks > (uint32_t)MT_JUMP_MAX_CHUNKS) return fail(c, MSIM_ERR_UNSUPPORTED, "random stream longer than the jump table covers");
         // states the cascade will hold once it covers need_chunks: whole levels, then part of one
         uint32_t want_states = 1;
         for (int l = 0; l < MT_JUMP_LEVELS && want_states < need_chunks; l++) {
@@ -901,7 +995,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     //  sixes 4.36-4.38 at 0.79 -- a larger group is a better rewrite launch and a longer stretch in which the chain's kernels
     //  crawl beside it, plus more left to do behind the last chain; groups cut by their bases instead of their count, 250-400 Mb
     //  with at most 4-6 contigs, were no better than threes; one per group = the ungrouped 4.6-5.1)
-    static const int group = getenv("MSIM_EMIT_GROUP") ? std::min(EMIT_G, std::max(1, atoi(getenv("MSIM_EMIT_GROUP")))) : 2;
+    const int group = g->emit_group;
     if (!g->emit_items.empty() && (!grouped || g->emit_d != (uint32_t)d || g->emit_items.size() >= (size_t)group))
         if ((rc = gpu_emit_flush(c))) return rc;
     struct { SampleSet *S; uint32_t bmw, bnb, start; } late = {nullptr, 0, 0, 0};

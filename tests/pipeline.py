@@ -71,9 +71,10 @@ def plan_only_vcf(meta: dict, tmp: Path):
     return mask_vcf((tmp / "plan_only.vcf").read_bytes()), empty, eng
 
 
-def run_product_case(meta: dict, tmp: Path):
-    """Whole CLI on the GPU.  Returns dict(exit_code, exception, stdout, stderr, fasta, vcf)."""
-    argv = prepare(meta, tmp)
+def run_product_case(meta: dict, tmp: Path, extra_argv=()):
+    """Whole CLI on the GPU.  Returns dict(exit_code, exception, stdout, stderr, fasta, vcf).  ``extra_argv``: options of this
+    package's own (``--bench-json path``, ``--rng fast`` ...) in front of the reference's argv."""
+    argv = list(extra_argv) + prepare(meta, tmp)
     out, err = io.StringIO(), io.StringIO()
     code, exc = None, None
     random.seed(meta["seed_py"])
