@@ -44,103 +44,65 @@ __device__ __forceinline__ int ndigits(unsigned long long v) {
     return k;
 }
 
-// Two sinks with one interface.  WSink: wave-uniform -- every lane carries the same offset n; small fields are written by
-// the low lanes, bulk copies by all 64 (4 bytes per lane while 256 are left).  LSink: one lane formats its own line
-// sequentially -- for records whose REF / ALT are a few bases (the reference's default SV lengths are 1..3, defaults.py:29-32).
-template <bool WRITE>
-struct WSink {
-    char *p;
+// Two sinks with one interface, both used by ONE lane for its own record.  CSink counts (the length pass); PSink writes the
+// line's short fields -- name, numbers, separators, INFO -- itself and turns every REF / ALT copy longer than VCF_INLINE bytes
+// into a PIECE (destination offset, source, length, mode) in the wave's LDS list: the wave copies all pieces of its 64 records
+// together afterwards, 16 destination-aligned bytes per lane and step (vcf_copy_pieces).
+constexpr uint32_t VCF_INLINE = 25;           // copies up to this length are made by the formatting lane (a DE of span 24 reads 25)
+constexpr uint32_t VCF_LANE_SPAN = 24;        // records spanning at most this many bases have no piece ("short": candidates for staging)
+constexpr uint32_t VCF_STAGE = 4096;          // LDS per wave for the lines of its 64 records where all of them are short
+constexpr int VCF_SLOTS = 4;                  // pieces a record can have: a long name, REF, ALT (twice for a duplication)
+
+struct VcfPiece { unsigned long long dst; const uint8_t *src; uint32_t len, mode; };      // mode: see bulk()
+
+struct CSink {
     unsigned long long n;
-    uint32_t lane;
-    __device__ __forceinline__ uint32_t first() const { return lane; }
-    __device__ __forceinline__ uint32_t step() const { return 64; }
-    __device__ __forceinline__ bool any(bool d) const { return __ballot(d) != 0ull; }
-    __device__ __forceinline__ void put(char c) {
-        if (WRITE && lane == 0) p[n] = c;
-        n++;
-    }
+    __device__ __forceinline__ void put(char) { n++; }
     template <int N>
-    __device__ __forceinline__ void lit(const char (&s)[N]) {            // N - 1 characters
-        if (WRITE && lane < (uint32_t)(N - 1)) p[n + lane] = s[lane];
-        n += N - 1;
+    __device__ __forceinline__ void lit(const char (&)[N]) { n += N - 1; }
+    __device__ __forceinline__ void num(unsigned long long v) { n += (unsigned)ndigits(v); }
+    __device__ __forceinline__ void bulk(const uint8_t *, unsigned long long len, int, const uint8_t *) { n += len; }
+};
+
+struct PSink {
+    char *text;                           // the contig's VCF text
+    unsigned long long n;                 // absolute offset of the next byte
+    VcfPiece *slots;                      // this lane's VCF_SLOTS entries of the wave's piece list (len == 0: unused)
+    uint32_t np;
+    __device__ __forceinline__ void put(char c) { text[n++] = c; }
+    template <int N>
+    __device__ __forceinline__ void lit(const char (&s)[N]) {            // N - 1 characters, four per store where there are four
+        constexpr int M = N - 1;
+        char *q = text + n;
+#pragma unroll
+        for (int i = 0; i + 4 <= M; i += 4) {
+            const uint32_t w = (uint32_t)(uint8_t)s[i] | ((uint32_t)(uint8_t)s[i + 1] << 8) | ((uint32_t)(uint8_t)s[i + 2] << 16) |
+                               ((uint32_t)(uint8_t)s[i + 3] << 24);
+            __builtin_memcpy(q + i, &w, 4);                              // (unaligned dword store)
+        }
+#pragma unroll
+        for (int i = M & ~3; i < M; i++) q[i] = s[i];
+        n += M;
     }
     __device__ __forceinline__ void num(unsigned long long v) {
         const int k = ndigits(v);
-        if (WRITE && lane < (uint32_t)k) {
-            unsigned long long q = v;
-            for (int i = 0; i < k - 1 - (int)lane; i++) q /= 10;
-            p[n + lane] = (char)('0' + (int)(q % 10));
-        }
+        for (int q = k - 1; q >= 0; q--) { text[n + q] = (char)('0' + (int)(v % 10)); v /= 10; }
         n += (unsigned)k;
     }
     // mode 0 raw, 1 conv(x), 2 comp(conv(x)) read BACKWARDS from src (src points at the LAST source byte)
-    __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode,
-                                         const uint8_t *lut) {
-        if (WRITE) {
-            unsigned long long i = 0;
-            for (; i + 256 <= len; i += 256) {                           // unaligned dword per lane (gfx950 global accesses may be)
-                const unsigned long long k = i + 4ull * lane;
-                uint32_t w;
-                if (mode == 2) {
-                    uint32_t v;
-                    __builtin_memcpy(&v, src - k - 3, 4);
-                    w = (uint32_t)lut[1024 + (v >> 24)] | ((uint32_t)lut[1024 + ((v >> 16) & 255)] << 8) |
-                        ((uint32_t)lut[1024 + ((v >> 8) & 255)] << 16) | ((uint32_t)lut[1024 + (v & 255)] << 24);
-                } else {
-                    __builtin_memcpy(&w, src + k, 4);
-                    if (mode == 1)
-                        w = (uint32_t)lut[768 + (w & 255)] | ((uint32_t)lut[768 + ((w >> 8) & 255)] << 8) |
-                            ((uint32_t)lut[768 + ((w >> 16) & 255)] << 16) | ((uint32_t)lut[768 + (w >> 24)] << 24);
-                }
-                __builtin_memcpy(p + n + k, &w, 4);
-            }
-            for (i += lane; i < len; i += 64) {
-                uint8_t c;
-                if (mode == 0) c = src[i];
-                else if (mode == 1) c = lut[768 + src[i]];
-                else c = lut[1024 + *(src - i)];
-                p[n + i] = (char)c;
-            }
-        }
-        n += len;
-    }
-};
-
-template <bool WRITE>
-struct LSink {
-    char *p;
-    unsigned long long n;
-    __device__ __forceinline__ uint32_t first() const { return 0; }
-    __device__ __forceinline__ uint32_t step() const { return 1; }
-    __device__ __forceinline__ bool any(bool d) const { return d; }
-    __device__ __forceinline__ void put(char c) {
-        if (WRITE) p[n] = c;
-        n++;
-    }
-    template <int N>
-    __device__ __forceinline__ void lit(const char (&s)[N]) {
-        if (WRITE) {
-#pragma unroll
-            for (int i = 0; i < N - 1; i++) p[n + i] = s[i];
-        }
-        n += N - 1;
-    }
-    __device__ __forceinline__ void num(unsigned long long v) {
-        const int k = ndigits(v);
-        if (WRITE)
-            for (int q = k - 1; q >= 0; q--) { p[n + q] = (char)('0' + (int)(v % 10)); v /= 10; }
-        n += (unsigned)k;
-    }
-    __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode,
-                                         const uint8_t *lut) {
-        if (WRITE) {
+    __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode, const uint8_t *lut) {
+        if (len <= VCF_INLINE || np >= (uint32_t)VCF_SLOTS || len >= (1ull << 32)) {
             for (unsigned long long i = 0; i < len; i++) {
                 uint8_t c;
                 if (mode == 0) c = src[i];
                 else if (mode == 1) c = lut[768 + src[i]];
                 else c = lut[1024 + *(src - i)];
-                p[n + i] = (char)c;
+                text[n + i] = (char)c;
             }
+        } else {
+            VcfPiece pc;
+            pc.dst = n; pc.src = src; pc.len = (uint32_t)len; pc.mode = (uint32_t)mode;
+            slots[np++] = pc;
         }
         n += len;
     }
@@ -178,7 +140,9 @@ __device__ __forceinline__ void line_tail(S &s, int svtype, unsigned long long e
 }
 
 // One record's line into a sink (mutator.py:334-421 builds the record, vcf_writer.py:118-126 the line).
-template <class S>
+// CHECK: evaluate the suppression rules (REF == ALT, vcf_writer.py:123) -- the length pass does, the write pass skips the
+// records whose length came out 0.
+template <bool CHECK, class S>
 __device__ __forceinline__ void format_record(S &s, const msim_record &r, const uint8_t *__restrict__ pool,
                                               const uint8_t *__restrict__ in, unsigned long long L,
                                               const uint8_t *__restrict__ name, uint32_t name_len, const uint8_t *lut) {
@@ -241,10 +205,12 @@ __device__ __forceinline__ void format_record(S &s, const msim_record &r, const 
         }
         case MSIM_IV: {                                                  // mutator.py:379-387
             const unsigned long long len = stop - pos + 1;
-            bool diff = false;                                           // REF == ALT (palindrome): suppressed
-            for (unsigned long long q = s.first(); q < len; q += s.step())
-                diff |= lut[768 + in[pos + q]] != lut[1024 + in[stop - q]];
-            if (!s.any(diff)) break;
+            if (CHECK) {                                                 // REF == ALT (a reverse-complement palindrome): suppressed
+                bool diff = false;                                       // (three of four random pairs differ: ~1.3 steps)
+                for (unsigned long long q = 0; q < len && !diff; q++)
+                    diff = lut[768 + in[pos + q]] != lut[1024 + in[stop - q]];
+                if (!diff) break;
+            }
             line_head(s, name, name_len, pos + 1);
             s.bulk(in + pos, len, 1, lut);
             s.put('\t');
@@ -264,8 +230,63 @@ __device__ __forceinline__ void format_record(S &s, const msim_record &r, const 
     }
 }
 
-constexpr uint32_t VCF_LANE_SPAN = 24;        // records spanning at most this many bases are formatted by one lane
-constexpr uint32_t VCF_STAGE = 4096;          // LDS per wave for the lines of its 64 records (write pass)
+// 16 source bytes through a 256-entry LDS table
+__device__ __forceinline__ uint4 lut16(uint4 w, const uint8_t *t) {
+    uint32_t v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+        v[d] = (uint32_t)t[v[d] & 255] | ((uint32_t)t[(v[d] >> 8) & 255] << 8) | ((uint32_t)t[(v[d] >> 16) & 255] << 16) |
+               ((uint32_t)t[v[d] >> 24] << 24);
+    return uint4{v[0], v[1], v[2], v[3]};
+}
+// ... and the same with the byte order reversed (reverse complement: the piece is read backwards)
+__device__ __forceinline__ uint4 lut16_rev(uint4 w, const uint8_t *t) {
+    uint32_t v[4] = {w.w, w.z, w.y, w.x};
+#pragma unroll
+    for (int d = 0; d < 4; d++)
+        v[d] = (uint32_t)t[v[d] >> 24] | ((uint32_t)t[(v[d] >> 16) & 255] << 8) | ((uint32_t)t[(v[d] >> 8) & 255] << 16) |
+               ((uint32_t)t[v[d] & 255] << 24);
+    return uint4{v[0], v[1], v[2], v[3]};
+}
+
+// The pieces of a wave's records, copied by the whole wave: a UNIT is 16 destination-aligned bytes of one piece (its first and
+// last unit may be partial).  pre[s] = units in front of slot s (pre[64 * VCF_SLOTS] = all of them); a lane takes units lane,
+// lane + 64, ... and finds each one's slot by binary search.  Two units per lane are in flight (their loads are issued together).
+// Round 4 took the long records one after the other, every copy a dependent load -> table -> store chain of the whole wave:
+// latency-bound at 0.2 TB/s of text on the SV mix (DU / IV of 50-500 bases: 85 % of the bytes).
+struct VcfUnit { unsigned long long dst; const uint8_t *src; uint32_t lo, hi, mode; uint4 w; };      // bytes [lo, hi) of the unit at dst
+
+__device__ __forceinline__ void vcf_unit_load(VcfUnit &u, uint32_t idx, uint32_t n_units, const VcfPiece *pcs, const uint32_t *pre) {
+    u.hi = 0;
+    if (idx >= n_units) return;
+    uint32_t s = 0;
+#pragma unroll
+    for (int step = 32 * VCF_SLOTS; step; step >>= 1) if (pre[s + step] <= idx) s += step;
+    const VcfPiece pc = pcs[s];
+    const unsigned long long a0 = pc.dst & ~15ull, at = a0 + 16ull * (idx - pre[s]);
+    const unsigned long long lo = at > pc.dst ? at : pc.dst, hi = at + 16 < pc.dst + pc.len ? at + 16 : pc.dst + pc.len;
+    u.dst = at; u.lo = (uint32_t)(lo - at); u.hi = (uint32_t)(hi - at); u.mode = pc.mode;
+    const unsigned long long k = lo - pc.dst;                            // piece offset of the unit's first byte
+    u.src = pc.mode == 2 ? pc.src - k : pc.src + k;                      // source of that byte
+    if (u.hi - u.lo == 16) {                                             // a whole unit: one unaligned 16-byte load
+        if (pc.mode == 2) __builtin_memcpy(&u.w, u.src - 15, 16);
+        else __builtin_memcpy(&u.w, u.src, 16);
+    }
+}
+
+__device__ __forceinline__ void vcf_unit_store(const VcfUnit &u, char *__restrict__ text, const uint8_t *lut) {
+    if (u.hi == 0) return;
+    if (u.hi - u.lo == 16) {
+        const uint4 o = u.mode == 0 ? u.w : u.mode == 1 ? lut16(u.w, lut + 768) : lut16_rev(u.w, lut + 1024);
+        *reinterpret_cast<uint4 *>(text + u.dst) = o;
+    } else {
+        for (uint32_t q = u.lo; q < u.hi; q++) {
+            const uint32_t i = q - u.lo;
+            const uint8_t c = u.mode == 0 ? u.src[i] : u.mode == 1 ? lut[768 + u.src[i]] : lut[1024 + *(u.src - i)];
+            text[u.dst + q] = (char)c;
+        }
+    }
+}
 
 // the line of an SNP record (mutator.py:334-341, vcf_writer.py:118-126) at p: name \t POS \t . \t REF \t ALT \t . \t . \t . \t GT \t 1 \n
 template <class P>
@@ -287,6 +308,13 @@ __device__ __forceinline__ void snp_line(P p, const uint8_t *__restrict__ name, 
 // the contig's bases at 2 M scattered positions a second time.
 // ALL_SNP (Contig::all_snp: the table holds SNP records only -- the SNP sampler's, `-sn` alone): the kernel without the other
 // types' formatter -- 52 registers instead of 139, eight waves per SIMD instead of three.
+// A wave takes 64 consecutive records, a LANE formats its own record's line (round 1 gave every line a wave: ~15 instructions of
+// 64 lanes for 25 bytes, 135 GB/s).  Length pass: nothing but the record, one base per SNP and the ends of an inversion are read --
+// every length follows from (type, pos, stop).  Write pass: the lines of a wave's records are adjacent in the text.  Where all of
+// them are short, the lanes format into LDS and the wave stores the stretch 16 aligned bytes per lane; else a lane writes its
+// line's short fields to the text itself and the long REF / ALT copies of all 64 records go through vcf_unit_*.
+constexpr uint32_t VCF_WAVE_LDS = 64 * VCF_SLOTS * sizeof(VcfPiece) + (64 * VCF_SLOTS + 4) * sizeof(uint32_t);   // piece list + unit prefix
+
 template <bool WRITE, bool ALL_SNP>
 __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
                                                           const uint8_t *__restrict__ pool,
@@ -297,17 +325,11 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
                                                           const unsigned long long *__restrict__ off,
                                                           char *__restrict__ text) {
     __shared__ uint8_t lut[1280];
-    __shared__ __attribute__((aligned(16))) char stage[WRITE ? TX_WAVES : 1][WRITE ? VCF_STAGE : 16];
+    constexpr uint32_t WB = !WRITE ? 16 : ALL_SNP ? VCF_STAGE : (VCF_WAVE_LDS > VCF_STAGE ? VCF_WAVE_LDS : VCF_STAGE);
+    __shared__ __attribute__((aligned(16))) char wbuf[WRITE ? TX_WAVES : 1][WB];
     for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
     __syncthreads();
-    // A wave takes 64 consecutive records.  Short lines -- every SNP (~25 bytes) and every record of a few bases -- are formatted by
-    // one LANE each (a wave per such line -- round 1 -- spent ~15 instructions of 64 lanes on 25 bytes: 135 GB/s, 1.7 % of HBM, and
-    // a twelfth of a CLI run with -sn 0.01); records with a long REF / ALT are taken by the whole wave, one after the other, their
-    // fields broadcast.
-    // Write pass: the lines of a wave's records are adjacent in the text.  Where all of them are short, the lanes format into
-    // LDS and the wave stores the stretch 16 aligned bytes per lane (a lane's own 25-byte line goes out as 25 one-byte stores
-    // otherwise: 64 bytes per store instruction instead of 1024).
     const uint32_t lane_id = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t base_rec = (blockIdx.x * TX_WAVES + wave) * 64;
     if (base_rec >= n_rec) return;
@@ -315,48 +337,54 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
     const bool valid = mine < n_rec;
     msim_record my{};
     if (valid) my = recs[mine];
-    bool by_lane = false;
-    if (valid && (ALL_SNP || my.type == MSIM_SN)) {
-        by_lane = true;
-    } else if (valid) {
+    const bool is_snp = ALL_SNP || my.type == MSIM_SN;
+    if (!WRITE) {                                                        // ---- length pass
+        if (!valid) return;
+        if (is_snp) {                                                    // mutator.py:334-341
+            const unsigned long long start = (unsigned long long)my.pos + 1;
+            const uint8_t x = in[my.pos];
+            const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];      // ti / tv column of conv(x)
+            len_io[mine] = ref == alt ? 0u : name_len + (uint32_t)ndigits(start) + 19u;   // vcf_writer.py:123: REF == ALT suppressed
+            ra[mine] = (uint16_t)((uint32_t)ref | ((uint32_t)alt << 8));
+        } else if (!ALL_SNP) {
+            CSink s;
+            s.n = 0;
+            format_record<true>(s, my, pool, in, L, name, name_len, lut);
+            len_io[mine] = (uint32_t)s.n;
+        }
+        return;
+    }
+    // ---- write pass
+    char *stage = wbuf[WRITE ? wave : 0];
+    bool is_short = is_snp;
+    if (!ALL_SNP && valid && !is_snp) {
         const unsigned long long hi = (unsigned long long)my.stop + 1 < L ? (unsigned long long)my.stop + 1 : L;
         const unsigned long long span = my.type == MSIM_TLI ? (hi > my.extra ? hi - my.extra : 0)
                                                             : (unsigned long long)my.stop - my.pos + 1;
-        by_lane = span <= VCF_LANE_SPAN;
+        is_short = span <= VCF_LANE_SPAN;
     }
-    unsigned long long my_off = 0, start0 = 0;
-    uint32_t my_len = 0, stretch = 0, phase = 0;
-    bool staged = false;
-    if (WRITE) {
-        if (valid) { my_off = off[mine]; my_len = len_io[mine]; }
-        const uint32_t last = min(63u, n_rec - 1 - base_rec);
-        start0 = __shfl(my_off, 0, 64);
-        const unsigned long long end = __shfl(my_off + my_len, (int)last, 64);
-        stretch = (uint32_t)min(end - start0, (unsigned long long)(2 * VCF_STAGE));
-        phase = (uint32_t)(start0 & 15);
-        staged = __ballot(valid && !by_lane) == 0ull && phase + stretch <= VCF_STAGE;
-    }
-    if (valid && (ALL_SNP || my.type == MSIM_SN)) {                      // mutator.py:334-341
-        const unsigned long long start = (unsigned long long)my.pos + 1;
-        const int nd = ndigits(start);
-        if (!WRITE) {
-            const uint8_t x = in[my.pos];
-            const uint8_t ref = lut[768 + x], alt = lut[(uint32_t)my.aux * 256 + x];      // ti / tv column of conv(x)
-            len_io[mine] = ref == alt ? 0u : name_len + (uint32_t)nd + 19u;                 // vcf_writer.py:123: REF == ALT suppressed
-            ra[mine] = (uint16_t)((uint32_t)ref | ((uint32_t)alt << 8));
-        } else if (my_len) {
-            const uint32_t r2 = ra[mine];
-            if (staged) snp_line(&stage[wave][phase + (uint32_t)(my_off - start0)], name, name_len, start, nd, (uint8_t)r2, (uint8_t)(r2 >> 8));
-            else snp_line(text + my_off, name, name_len, start, nd, (uint8_t)r2, (uint8_t)(r2 >> 8));
+    unsigned long long my_off = 0;
+    uint32_t my_len = 0;
+    if (valid) { my_off = off[mine]; my_len = len_io[mine]; }
+    const uint32_t last = min(63u, n_rec - 1 - base_rec);
+    const unsigned long long start0 = __shfl(my_off, 0, 64);
+    const unsigned long long end = __shfl(my_off + my_len, (int)last, 64);
+    const uint32_t stretch = (uint32_t)min(end - start0, (unsigned long long)(2 * VCF_STAGE));
+    const uint32_t phase = (uint32_t)(start0 & 15);
+    const bool staged = __ballot(valid && !is_short) == 0ull && phase + stretch <= VCF_STAGE && (ALL_SNP || name_len <= VCF_INLINE);
+    if (staged) {                                                        // (wave-uniform) every line is short: through LDS
+        if (valid && my_len) {
+            char *p = &stage[phase + (uint32_t)(my_off - start0)];
+            if (is_snp) {
+                const uint32_t r2 = ra[mine];
+                const unsigned long long start = (unsigned long long)my.pos + 1;
+                snp_line(p, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
+            } else if (!ALL_SNP) {
+                PSink s;
+                s.text = p; s.n = 0; s.slots = nullptr; s.np = VCF_SLOTS;   // (no piece can arise: every copy is <= VCF_INLINE)
+                format_record<false>(s, my, pool, in, L, name, name_len, lut);
+            }
         }
-    } else if (!ALL_SNP && valid && by_lane) {
-        LSink<WRITE> s;
-        s.n = 0;
-        s.p = !WRITE ? nullptr : staged ? &stage[wave][phase + (uint32_t)(my_off - start0)] : text + my_off;
-        format_record(s, my, pool, in, L, name, name_len, lut);
-        if (!WRITE) len_io[mine] = (uint32_t)s.n;
-    }
-    if (WRITE && staged) {                                               // (wave-uniform)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (flat stores into LDS complete out of order with ds reads: wait for both)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -364,32 +392,67 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
         const uint32_t lim = phase + stretch;
         for (uint32_t k = lane_id * 16; k < lim; k += 64 * 16) {
             if (k >= phase && k + 16 <= lim) {
-                *reinterpret_cast<uint4 *>(g0 + k) = *reinterpret_cast<const uint4 *>(&stage[wave][k]);
+                *reinterpret_cast<uint4 *>(g0 + k) = *reinterpret_cast<const uint4 *>(&stage[k]);
             } else {
                 const uint32_t lo = max(k, phase), hi = min(k + 16, lim);
-                for (uint32_t q = lo; q < hi; q++) g0[q] = stage[wave][q];
+                for (uint32_t q = lo; q < hi; q++) g0[q] = stage[q];
             }
         }
         return;
     }
-    if (ALL_SNP) return;
-    unsigned long long todo = __ballot(valid && !by_lane);
-    while (todo) {
-        const int src_lane = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const uint32_t i = base_rec + (uint32_t)src_lane;
-        msim_record r;
-        r.pos = (uint32_t)__shfl((int)my.pos, src_lane, 64);
-        r.stop = (uint32_t)__shfl((int)my.stop, src_lane, 64);
-        r.extra = (uint32_t)__shfl((int)my.extra, src_lane, 64);
-        const uint32_t ta = (uint32_t)__shfl((int)((uint32_t)my.type | ((uint32_t)my.aux << 8)), src_lane, 64);
-        r.type = (uint8_t)ta; r.aux = (uint8_t)(ta >> 8); r.rsv = 0;
-        WSink<WRITE> s;
-        s.lane = lane_id;
-        s.n = 0;
-        s.p = WRITE ? text + __shfl(my_off, src_lane, 64) : nullptr;
-        format_record(s, r, pool, in, L, name, name_len, lut);
-        if (!WRITE && s.lane == 0) len_io[i] = (uint32_t)s.n;
+    if (ALL_SNP) {                                                       // (a stretch that does not fit the stage: long names)
+        if (valid && my_len) {
+            const uint32_t r2 = ra[mine];
+            const unsigned long long start = (unsigned long long)my.pos + 1;
+            snp_line(text + my_off, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
+        }
+        return;
+    }
+    VcfPiece *pcs = reinterpret_cast<VcfPiece *>(stage);
+    uint32_t *pre = reinterpret_cast<uint32_t *>(stage + 64 * VCF_SLOTS * sizeof(VcfPiece));
+    PSink s;
+    s.text = text; s.n = my_off; s.slots = pcs + lane_id * VCF_SLOTS; s.np = 0;
+    if (valid && my_len) {
+        if (is_snp) {
+            const uint32_t r2 = ra[mine];
+            const unsigned long long start = (unsigned long long)my.pos + 1;
+            snp_line(text + my_off, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
+        } else {
+            format_record<false>(s, my, pool, in, L, name, name_len, lut);
+        }
+    }
+    // units of this lane's pieces, their prefix over the wave
+    uint32_t cnt[VCF_SLOTS], tot = 0;
+#pragma unroll
+    for (int q = 0; q < VCF_SLOTS; q++) {
+        cnt[q] = 0;
+        if ((uint32_t)q < s.np) {
+            const VcfPiece pc = s.slots[q];
+            cnt[q] = (uint32_t)((((pc.dst + pc.len + 15) & ~15ull) - (pc.dst & ~15ull)) >> 4);
+        }
+        tot += cnt[q];
+    }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane_id >= (uint32_t)o) incl += t;
+    }
+    const uint32_t n_units = (uint32_t)__shfl((int)incl, 63, 64);
+    if (n_units == 0) return;
+    uint32_t run = incl - tot;
+#pragma unroll
+    for (int q = 0; q < VCF_SLOTS; q++) { pre[lane_id * VCF_SLOTS + q] = run; run += cnt[q]; }
+    if (lane_id == 63) pre[64 * VCF_SLOTS] = n_units;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (uint32_t u0 = 0; u0 < n_units; u0 += 128) {
+        VcfUnit a, b;
+        vcf_unit_load(a, u0 + lane_id, n_units, pcs, pre);
+        vcf_unit_load(b, u0 + 64 + lane_id, n_units, pcs, pre);
+        vcf_unit_store(a, text, lut);
+        vcf_unit_store(b, text, lut);
     }
 }
 
