@@ -517,8 +517,14 @@ def live_traffic(workload, kernel):
             if r.returncode != 0 or not dbs:
                 return None
             c = sqlite3.connect(dbs[0])
+            # (the exact kernel: "k_rewrite<140>" must not average over k_rewrite_snp / k_rewrite_b launches of the same run)
+            short = kernel.split("::")[-1]
+            pat = f"%{short}%" if "<" in short else f"%{short}(%"
             row = c.execute("select count(*), sum(value) from counters_collection where counter_name = ? and kernel_name like ?",
-                            (ctr, f"%{kernel.split('::')[-1].split('<')[0]}%")).fetchone()
+                            (ctr, pat)).fetchone()
+            if (not row or not row[0]) and "<" not in short:     # (kernel names without their argument list in this rocprofv3)
+                row = c.execute("select count(*), sum(value) from counters_collection where counter_name = ? and "
+                                "(kernel_name = ? or kernel_name like ?)", (ctr, kernel, f"%::{short}")).fetchone()
             c.close()
             if not row or not row[0]:
                 return None

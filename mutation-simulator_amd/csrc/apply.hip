@@ -708,11 +708,6 @@ __device__ __forceinline__ void rewrite_one_tile(const uint8_t *__restrict__ in,
                                                  const int32_t *__restrict__ first, uint32_t n_rec, uint64_t L_out,
                                                  const uint8_t *__restrict__ pool, const uint8_t *__restrict__ lut_g,
                                                  unsigned long long *err, const uint32_t *__restrict__ dyn, uint32_t blk, uint32_t nwg) {
-    if (dyn) {                                             // sizes from the device (see k_tile_index); surplus tiles leave
-        n_rec = dyn[0];
-        L_out = dyn[1];
-        if ((uint64_t)blk * TILE >= L_out) return;
-    }
     __shared__ RecWin<CAP> win;
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE];
     __shared__ __attribute__((aligned(16))) uint8_t lut[LUT_BYTES];
@@ -720,6 +715,11 @@ __device__ __forceinline__ void rewrite_one_tile(const uint8_t *__restrict__ in,
     if (MSIM_ABL & 16) {                                   // XCD x gets a contiguous range of tiles (bijective for any grid)
         const uint32_t q8 = nwg / 8, r8 = nwg % 8, xcd = t % 8, k8 = t / 8;
         t = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + k8;
+    }
+    if (dyn) {                                             // sizes from the device (see k_tile_index); surplus TILES leave (the
+        n_rec = dyn[0];                                    // tile a workgroup maps to decides, not its place in the grid)
+        L_out = dyn[1];
+        if ((uint64_t)t * TILE >= L_out) return;
     }
     const uint64_t tile0 = (uint64_t)t * TILE;
     for (int i = threadIdx.x; i < LUT_BYTES / 4; i += THREADS)
@@ -1083,8 +1083,8 @@ int apply_finish(Ctx *c) {
 // rewrite kernels back to back on the batch's stream.
 // While apply_batch_device applies its contigs, apply_contig_device hands their rewrite launches over instead of making them
 // (variant: 0 SNP-only, 1 small window, 2 large window): they go out as ONE launch per variant.
+// (the collector hangs on the context -- Ctx::rw_collect -- so that two contexts driven from two threads never see each other's)
 struct RwPending { RwJob job; int variant; int contig; };
-static std::vector<RwPending> *g_rw_collect = nullptr;
 
 int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites) {
     TileJobs J;
@@ -1120,13 +1120,13 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
     int rc = MSIM_OK;
     std::vector<RwPending> rw;
     static const bool no_rw_batch = getenv("MSIM_NO_REWRITE_BATCH") != nullptr;
-    g_rw_collect = (no_rw_batch || !batch_rewrites) ? nullptr : &rw;
+    c->rw_collect = (no_rw_batch || !batch_rewrites) ? nullptr : &rw;
     for (int id : ids) {
         Contig &g = c->contigs[(size_t)id];
         if (!rc) rc = apply_contig_device(c, g);
         g.tile_index_done = false;
     }
-    g_rw_collect = nullptr;
+    c->rw_collect = nullptr;
     for (int id : marked) c->contigs[(size_t)id].tile_index_done = false;
     if (rc) return rc;
     // ---- the collected rewrites: one launch per kernel variant and RW_JOBS contigs; the first contig's events time the launch
@@ -1249,7 +1249,8 @@ int apply_contig_device(Ctx *c, Contig &g) {
         MSIM_HIP(c, hipMemsetAsync(d_err, 0xff, 8, st));
     }
     // ---- 3. rewrite
-    const bool hand_over = g_rw_collect && g.tile_index_done && n_tiles;     // (apply_batch_device launches it with its batch)
+    std::vector<RwPending> *collect = static_cast<std::vector<RwPending> *>(c->rw_collect);
+    const bool hand_over = collect && g.tile_index_done && n_tiles;     // (apply_batch_device launches it with its batch)
     g.timing_shared = hand_over;
     if (!hand_over) MSIM_HIP(c, hipEventRecord(g.ea1, st));
     if (hand_over) {
@@ -1262,7 +1263,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
         p.job.L_out = g.out_len; p.job.n_rec = n; p.job.n_tiles = n_tiles;
         p.variant = g.all_snp ? 0 : (small_win ? 1 : 2);
         p.contig = g.index;
-        g_rw_collect->push_back(p);
+        collect->push_back(p);
     } else if (n_tiles) {
         // small window: mean records per tile < 80 % of it (dyn: only the STRUCTURAL records take window slots, and their
         // expected number is what the host knows -- mean structural candidates per tile below half the window)

@@ -77,6 +77,7 @@ struct Ctx {
     HostMT py, np;                    // stream states, host representation
     GpuPlan *gpu = nullptr;           // device representation of the streams + sampler scratch
     Comm *comm = nullptr;             // multi-GPU: set by msim_comm_init
+    void *rw_collect = nullptr;       // apply.hip: where apply_contig_device hands rewrite launches over while apply_batch_device runs
     Batch *batch = nullptr;           // last batch of small contigs (host buffers)
     FileIo *file_io = nullptr;        // file_io.hip (made on first use)
     msim_params params{};

@@ -1574,6 +1574,7 @@ int msim_batch_view(msim_ctx *p, const uint8_t **fasta_text, uint64_t *fasta_byt
     if (!c || !c->batch) return MSIM_ERR_ARG;
     Batch &B = *c->batch;
     if (fasta_text && !B.framed) {
+        file_channel_idle(c, 0);                           // (the previous batch's text may still be read from B.fasta)
         if (!raw_reserve(&B.fasta, &B.fasta_cap, B.fasta_len + 1)) return fail(c, MSIM_ERR_NOMEM, "batch FASTA text");
         if (B.fasta_len) batch_frame_into(B, B.fasta);
         B.framed = true;

@@ -70,7 +70,29 @@ struct Pending { int contig = -1; bool apply = false; uint64_t key = 0; uint32_t
 
 }  // namespace
 
+struct HostProf {                                          // MSIM_FAST_PROF=1: where the host's time per contig goes (stderr at collection)
+    bool on = getenv("MSIM_FAST_PROF") != nullptr;
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n = 0;
+    std::chrono::steady_clock::time_point last;
+    void start() { if (on) last = std::chrono::steady_clock::now(); }
+    void lap(int i) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        t[i] += std::chrono::duration<double, std::micro>(now - last).count();
+        last = now;
+    }
+    void report() {
+        if (!on || !n) return;
+        fprintf(stderr, "fast PLAN host us per contig (%llu contigs): prepare %.1f, wait-set %.1f, tables+grow %.1f, copy %.1f, split %.1f, leaf %.1f, "
+                        "keep+emit %.1f, events %.1f\n", (unsigned long long)n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n, t[7] / n);
+        for (double &x : t) x = 0;
+        n = 0;
+    }
+};
+
 struct FastPlan {
+    HostProf prof;                                         // (per context: two contexts may plan from two threads)
     hipStream_t lane[F_SETS] = {};
     FastSet set[F_SETS];
     uint32_t *d_flags = nullptr;                           // sticky FF_* flags of everything since the last collection
@@ -297,29 +319,6 @@ int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges) 
     return prepare(c, L, ranges, n_ranges, P);
 }
 
-namespace {
-struct HostProf {                                          // MSIM_FAST_PROF=1: where the host's time per contig goes (stderr at collection)
-    bool on = getenv("MSIM_FAST_PROF") != nullptr;
-    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t n = 0;
-    std::chrono::steady_clock::time_point last;
-    void start() { if (on) last = std::chrono::steady_clock::now(); }
-    void lap(int i) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        t[i] += std::chrono::duration<double, std::micro>(now - last).count();
-        last = now;
-    }
-    void report() {
-        if (!on || !n) return;
-        fprintf(stderr, "fast PLAN host us per contig (%llu contigs): prepare %.1f, wait-set %.1f, tables+grow %.1f, copy %.1f, split %.1f, leaf %.1f, "
-                        "keep+emit %.1f, events %.1f\n", (unsigned long long)n, t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, t[6] / n, t[7] / n);
-        for (double &x : t) x = 0;
-        n = 0;
-    }
-};
-HostProf g_prof;
-}  // namespace
 
 static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only);
 
@@ -334,7 +333,7 @@ int fast_plan_collect(Ctx *c) {
     f->cycle_K = 0;
     f->queued_host_us = 0;
     f->early_done = f->half_done = false;
-    g_prof.report();
+    c->fast->prof.report();
     for (int round = 0; f->pending && round < 3; round++) {
         f->pending = false;
         f->cycle_batches = 0;
@@ -433,12 +432,12 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
     const uint32_t li = f->cycle_batches++ % F_SETS;
     FastSet &S = f->set[li];
     hipStream_t st = f->lane[li];
-    g_prof.start();
+    c->fast->prof.start();
     if (S.pending) {                                       // its last user (a few batches ago) may still be in flight on this stream
         MSIM_HIP(c, hipStreamSynchronize(st));
         S.pending = false;
     }
-    g_prof.lap(1);
+    c->fast->prof.lap(1);
     if (!f->pending) MSIM_HIP(c, hipEventRecord(f->t0, st));
     f->pending = true;
     const uint64_t key64 = items[0].key;
@@ -539,9 +538,9 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
             leaf0 += (uint32_t)P.n_leaves; cand0 += nb * OB_BLOCK; blk0 += nb;
         }
     }
-    g_prof.lap(2);
+    c->fast->prof.lap(2);
     MSIM_HIP(c, hipMemcpyAsync(S.tab.p, S.h_tab.p, tab_bytes, hipMemcpyHostToDevice, st));
-    g_prof.lap(3);
+    c->fast->prof.lap(3);
     const FRange *d_ranges = reinterpret_cast<const FRange *>(S.tab.p);
     const Settings *d_sets = reinterpret_cast<const Settings *>(S.tab.p + off_sets);
     const SubDesc *d_subs = reinterpret_cast<const SubDesc *>(S.tab.p + off_subs);
@@ -558,7 +557,7 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
     hipLaunchKernelGGL(k_fsplit_sub, dim3(((uint32_t)n_subs + 3) / 4), dim3(256), 0, st, d_ranges, d_subs, (uint32_t)n_subs, d_slots, key2,
                        S.sub_k.p, S.sub_c0.p, S.leaves.p, f->d_flags, snp_only ? (uint32_t *)nullptr : blk_max1,
                        snp_only ? 0u : 2 * (nbt + 1), S.kept.p, 4 * n_slots, (uint32_t)items[0].P.d);
-    g_prof.lap(4);
+    c->fast->prof.lap(4);
     const uint32_t bm_words = (1u << lgB_max) / 32 + 2;
     const size_t lds = (size_t)4 * (bm_words + LEAF_LIST) * sizeof(uint32_t);
     const uint32_t leaf_blocks = ((uint32_t)n_leaves + 3) / 4;
@@ -570,11 +569,11 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
                            key2, d, (const Settings *)nullptr, block1, ti_lim, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                            (uint8_t *)nullptr, (uint32_t *)nullptr, f->d_flags);
         MSIM_HIP(c, hipGetLastError());
-        g_prof.lap(5);
+        c->fast->prof.lap(5);
     } else {
         hipLaunchKernelGGL(k_fleaf<true>, dim3(leaf_blocks), dim3(256), lds, st, d_ranges, S.leaves.p, (uint32_t)n_leaves, bm_words, d_slots,
                            key2, d, d_sets, block1, ti_lim, S.cand_pos.p, S.cand_stop.p, S.cand_bend.p, S.cand_meta.p, blk_max1, f->d_flags);
-        g_prof.lap(5);
+        c->fast->prof.lap(5);
         // One pass = k_fkeep (block-local: free candidates + short cluster walks).  Where everything in front of a block is
         // inside somebody's blocked range it raises the contig's hand-over word and that plan is replayed with the three orbit
         // kernels when the sizes are collected (fast_plan_collect): nothing of the common path pays for them.
@@ -620,7 +619,7 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
         }
         MSIM_HIP(c, hipGetLastError());
     }
-    g_prof.lap(6);
+    c->fast->prof.lap(6);
     if (f->lane_of.size() < c->contigs.size()) f->lane_of.resize(c->contigs.size(), 0);
     for (auto &it : items) f->lane_of[(size_t)it.contig] = (uint8_t)li;
     // ---- per contig: what the host knows now; its APPLY follows on the same stream (apply.hip: Contig::apply_stream) -- no event,
@@ -641,8 +640,8 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
         }
     }
     S.pending = true;
-    g_prof.lap(7);
-    g_prof.n += n_slots;
+    c->fast->prof.lap(7);
+    c->fast->prof.n += n_slots;
     return MSIM_OK;
 }
 
@@ -667,11 +666,11 @@ int plan_contig_fast(Ctx *c, Contig &ct, const msim_range *ranges, int n_ranges,
         if ((rc = fast_plan_flush(c))) return rc;
     }
     Pending it;
-    g_prof.start();
+    c->fast->prof.start();
     const auto tp0 = std::chrono::steady_clock::now();
     rc = prepare(c, ct.len, ranges, n_ranges, it.P);
     f->queued_host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp0).count();
-    g_prof.lap(0);
+    c->fast->prof.lap(0);
     if (rc) return rc;
     const Prep &P = it.P;
     ct.n_rec = P.snp_only ? P.K : 0;

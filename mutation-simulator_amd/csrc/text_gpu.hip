@@ -24,6 +24,7 @@
 //   IT     k_splice : interchromosomal translocation of one contig -- segments of two contigs taken alternately
 //                     (it_mutator.py:121-146 __write_with_bp)
 // Byte/integer work, HBM-bound; no MFMA.
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.h"
@@ -38,140 +39,218 @@ constexpr int TX_THREADS = 256;
 constexpr int TX_WAVES = TX_THREADS / 64;
 
 __device__ __forceinline__ int ndigits(unsigned long long v) {
-    int k = 1;
-    unsigned long long p = 10;
+    if ((v >> 32) == 0) {                                                // (every position of a contig below 4 GiB)
+        const uint32_t x = (uint32_t)v;
+        return 1 + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) + (x >= 10000000u) +
+               (x >= 100000000u) + (x >= 1000000000u);
+    }
+    int k = 10;
+    unsigned long long p = 10000000000ull;
     while (v >= p && k < 20) { p *= 10; k++; }
     return k;
 }
 
-// Two sinks with one interface, both used by ONE lane for its own record.  CSink counts (the length pass); PSink writes the
-// line's short fields -- name, numbers, separators, INFO -- itself and turns every REF / ALT copy longer than VCF_INLINE bytes
-// into a PIECE (destination offset, source, length, mode) in the wave's LDS list: the wave copies all pieces of its 64 records
-// together afterwards, 16 destination-aligned bytes per lane and step (vcf_copy_pieces).
-constexpr uint32_t VCF_INLINE = 25;           // copies up to this length are made by the formatting lane (a DE of span 24 reads 25)
-constexpr uint32_t VCF_LANE_SPAN = 24;        // records spanning at most this many bases have no piece ("short": candidates for staging)
-constexpr uint32_t VCF_STAGE = 4096;          // LDS per wave for the lines of its 64 records where all of them are short
-constexpr int VCF_SLOTS = 4;                  // pieces a record can have: a long name, REF, ALT (twice for a duplication)
+// Two sinks with one interface, each used by ONE lane for its own record.
+//   CSink  counts (the length pass).
+//   (vcf_line_gaps measures a line's GAPS: a REF / ALT copy longer than VCF_INLINE bytes is not formatted by its lane -- its
+//          16-byte-aligned interior (in text coordinates) becomes a PIECE that the whole wave copies -- and is missing from
+//          the wave's LDS stage, which holds everything else of the wave's lines back to back ("compact" coordinates: text
+//          offset minus the gaps in front of it; gaps are multiples of 16, so alignment survives).)
+//   SSink  writes: short fields, inline copies and the edges of the pieces (the < 16 bytes in front of and behind a piece's
+//          aligned interior) into the stage; pieces into the wave's LDS list; gs[u] += units of the gap that opens in front of
+//          stage unit u.
+constexpr uint32_t VCF_INLINE = 25;           // copies up to this length are made by the formatting lane
+constexpr uint32_t VCF_STAGE = 4096;          // LDS per wave: the compact text of (a group of) its 64 records
+constexpr uint32_t VCF_UNITS = VCF_STAGE / 16;
+constexpr int VCF_SLOTS = 3;                  // pieces a record can have: REF, ALT (twice for a duplication)
 
-struct VcfPiece { unsigned long long dst; const uint8_t *src; uint32_t len, mode; };      // mode: see bulk()
+// One REF / ALT copy of a line: its first byte's text offset (relative to the stage's text origin, which is 16-byte aligned), its
+// length, and source | stage position of its first byte << 48 | mode << 62.
+struct VcfPiece { uint32_t n_rel, len; unsigned long long src_ws_mode; };
+
+// The 16-byte-aligned interior [ia, ib) of a copy of `len` bytes at text offset n -- the part that goes source -> text without
+// touching the stage -- if it is worth having (copies up to VCF_INLINE bytes stay whole in the stage).
+__device__ __forceinline__ bool vcf_piece_of(unsigned long long n, unsigned long long len, unsigned long long &ia, unsigned long long &ib) {
+    if (len <= VCF_INLINE) return false;
+    ia = (n + 15) & ~15ull;
+    ib = (n + len) & ~15ull;
+    return ib > ia;
+}
 
 struct CSink {
     unsigned long long n;
+    __device__ __forceinline__ void chars(uint32_t, uint32_t k) { n += k; }
+    __device__ __forceinline__ void chars64(unsigned long long, uint32_t k) { n += k; }
     __device__ __forceinline__ void put(char) { n++; }
     template <int N>
     __device__ __forceinline__ void lit(const char (&)[N]) { n += N - 1; }
     __device__ __forceinline__ void num(unsigned long long v) { n += (unsigned)ndigits(v); }
-    __device__ __forceinline__ void bulk(const uint8_t *, unsigned long long len, int, const uint8_t *) { n += len; }
+    __device__ __forceinline__ void name(const uint8_t *, uint32_t len) { n += len; }
+    template <class D> __device__ __forceinline__ void begin(const D &) {}
+    __device__ __forceinline__ void bulk(int, const uint8_t *, unsigned long long len, int, const uint8_t *) { n += len; }
 };
 
-struct PSink {
-    char *text;                           // the contig's VCF text
-    unsigned long long n;                 // absolute offset of the next byte
-    VcfPiece *slots;                      // this lane's VCF_SLOTS entries of the wave's piece list (len == 0: unused)
+struct SSink {
+    char *stage;                          // the wave's compact stage (LDS)
+    uint32_t w;                           // next byte in it
+    unsigned long long n, origin;         // absolute text offset of the next byte; text offset of the stage's first unit
+    VcfPiece *slots;                      // this lane's VCF_SLOTS entries of the wave's piece list
+    uint32_t *gs;
     uint32_t np;
-    __device__ __forceinline__ void put(char c) { text[n++] = c; }
+    __device__ __forceinline__ void put(char c) { stage[w++] = c; n++; }
+    __device__ __forceinline__ void chars(uint32_t v, uint32_t k) {
+        for (uint32_t i = 0; i < k; i++) { stage[w + i] = (char)v; v >>= 8; }
+        w += k; n += k;
+    }
+    __device__ __forceinline__ void chars64(unsigned long long v, uint32_t k) {
+        for (uint32_t i = 0; i < k; i++) { stage[w + i] = (char)v; v >>= 8; }
+        w += k; n += k;
+    }
+    // literals go out eight, four, two characters per LDS store (gfx950 takes unaligned ds_write_b64 / b32 / b16): a byte per
+    // store kept one register per character of "\t.\t.\tSVTYPE=" ... alive -- a hundred registers for the formatter
     template <int N>
-    __device__ __forceinline__ void lit(const char (&s)[N]) {            // N - 1 characters, four per store where there are four
+    __device__ __forceinline__ void lit(const char (&s)[N]) {
         constexpr int M = N - 1;
-        char *q = text + n;
+        char *q = stage + w;
+        int i = 0;
 #pragma unroll
-        for (int i = 0; i + 4 <= M; i += 4) {
-            const uint32_t w = (uint32_t)(uint8_t)s[i] | ((uint32_t)(uint8_t)s[i + 1] << 8) | ((uint32_t)(uint8_t)s[i + 2] << 16) |
-                               ((uint32_t)(uint8_t)s[i + 3] << 24);
-            __builtin_memcpy(q + i, &w, 4);                              // (unaligned dword store)
+        for (; i + 8 <= M; i += 8) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) v |= (unsigned long long)(uint8_t)s[i + j] << (8 * j);
+            __builtin_memcpy(q + i, &v, 8);
         }
+        if (i + 4 <= M) {
+            const uint32_t v = (uint32_t)(uint8_t)s[i] | ((uint32_t)(uint8_t)s[i + 1] << 8) | ((uint32_t)(uint8_t)s[i + 2] << 16) |
+                               ((uint32_t)(uint8_t)s[i + 3] << 24);
+            __builtin_memcpy(q + i, &v, 4);
+            i += 4;
+        }
+        if (i + 2 <= M) {
+            const uint16_t v = (uint16_t)((uint32_t)(uint8_t)s[i] | ((uint32_t)(uint8_t)s[i + 1] << 8));
+            __builtin_memcpy(q + i, &v, 2);
+            i += 2;
+        }
+        if (i < M) q[i] = s[i];
+        w += M; n += M;
+    }
+    __device__ __forceinline__ void num(unsigned long long v) {         // (v < 5e9: positions of a contig below 4 GiB, + 1)
+        const int k = ndigits(v);
+        uint32_t x = v >= 4000000000ull ? (uint32_t)(v - 4000000000ull) : (uint32_t)v;    // no 64-bit division (20 registers of it)
+        const int low = v >= 4000000000ull ? 9 : k;
+        for (int q = k - 1; q >= k - low; q--) { stage[w + q] = (char)('0' + x % 10u); x /= 10u; }
+        if (low != k) stage[w] = '4';
+        w += (unsigned)k; n += (unsigned)k;
+    }
+    __device__ __forceinline__ void name(const uint8_t *src, uint32_t len) {          // (src: the workgroup's LDS copy)
+        for (uint32_t i = 0; i < len; i++) stage[w + i] = (char)src[i];
+        w += len; n += len;
+    }
+    template <class D> __device__ __forceinline__ void begin(const D &) {}
+    // mode 0 raw, 1 conv(x), 2 comp(conv(x)) read BACKWARDS from src (src points at the LAST source byte).
+    // The lane copies nothing itself: it notes the copy as a piece, leaves room in the stage for what of it does not belong to
+    // the aligned interior, and opens the gap.  (A byte-by-byte loop here was a chain of dependent global loads.)
+    __device__ __forceinline__ void bulk(int, const uint8_t *__restrict__ src, unsigned long long len, int mode, const uint8_t *) {
+        if (len == 0) return;
+        unsigned long long ia, ib;                                       // (the wave checked: len, n - origin < 2^32, src < 2^48 -- vcf_fits)
+        const bool interior = vcf_piece_of(n, len, ia, ib);
+        VcfPiece pc;
+        pc.n_rel = (uint32_t)(n - origin);
+        pc.len = (uint32_t)len;
+        pc.src_ws_mode = (unsigned long long)(uintptr_t)src | ((unsigned long long)w << 48) | ((unsigned long long)mode << 62);
+        slots[np++] = pc;
+        if (interior) {
+            atomicAdd(&gs[(w + (uint32_t)(ia - n)) >> 4], (uint32_t)((ib - ia) >> 4));   // (a unit boundary: compact keeps text's alignment)
+            w += (uint32_t)(len - (ib - ia));
+        } else {
+            w += (uint32_t)len;
+        }
+        n += len;
+    }
+};
+
+// ... and the plain one for waves the stage scheme cannot describe (a wave whose 64 lines span 4 GiB of text and more -- a
+// duplication of 1.4 Gb has such a line --, source addresses beyond 2^48): every lane writes its own line byte by byte.
+struct DSink {
+    char *text;
+    unsigned long long n;
+    __device__ __forceinline__ void put(char c) { text[n++] = c; }
+    __device__ __forceinline__ void chars(uint32_t v, uint32_t k) { for (uint32_t i = 0; i < k; i++) { text[n++] = (char)v; v >>= 8; } }
+    __device__ __forceinline__ void chars64(unsigned long long v, uint32_t k) { for (uint32_t i = 0; i < k; i++) { text[n++] = (char)v; v >>= 8; } }
+    template <int N>
+    __device__ __forceinline__ void lit(const char (&s)[N]) {
 #pragma unroll
-        for (int i = M & ~3; i < M; i++) q[i] = s[i];
-        n += M;
+        for (int i = 0; i < N - 1; i++) text[n + i] = s[i];
+        n += N - 1;
     }
     __device__ __forceinline__ void num(unsigned long long v) {
         const int k = ndigits(v);
         for (int q = k - 1; q >= 0; q--) { text[n + q] = (char)('0' + (int)(v % 10)); v /= 10; }
         n += (unsigned)k;
     }
-    // mode 0 raw, 1 conv(x), 2 comp(conv(x)) read BACKWARDS from src (src points at the LAST source byte)
-    __device__ __forceinline__ void bulk(const uint8_t *__restrict__ src, unsigned long long len, int mode, const uint8_t *lut) {
-        if (len <= VCF_INLINE || np >= (uint32_t)VCF_SLOTS || len >= (1ull << 32)) {
-            for (unsigned long long i = 0; i < len; i++) {
-                uint8_t c;
-                if (mode == 0) c = src[i];
-                else if (mode == 1) c = lut[768 + src[i]];
-                else c = lut[1024 + *(src - i)];
-                text[n + i] = (char)c;
-            }
-        } else {
-            VcfPiece pc;
-            pc.dst = n; pc.src = src; pc.len = (uint32_t)len; pc.mode = (uint32_t)mode;
-            slots[np++] = pc;
+    __device__ __forceinline__ void name(const uint8_t *src, uint32_t len) { for (uint32_t i = 0; i < len; i++) text[n++] = (char)src[i]; }
+    template <class D> __device__ __forceinline__ void begin(const D &) {}
+    __device__ __forceinline__ void bulk(int, const uint8_t *__restrict__ src, unsigned long long len, int mode, const uint8_t *lut) {
+#pragma unroll 1
+        for (unsigned long long k = 0; k < len; k++) {
+            const uint8_t x = mode == 2 ? *(src - k) : src[k];
+            text[n + k] = (char)(mode == 0 ? x : mode == 1 ? lut[768 + x] : lut[1024 + x]);
         }
         n += len;
     }
 };
 
-template <class S>
-__device__ __forceinline__ void line_head(S &s, const uint8_t *name, uint32_t name_len, unsigned long long start) {
-    s.bulk(name, name_len, 0, nullptr);
-    s.put('\t');
-    s.num(start);
-    s.lit("\t.\t");
-}
-// svtype: 0 none (SNP), 1 INS, 2 DEL, 3 INV, 4 DUP, 5 INS:ME, 6 DEL:ME
-template <class S>
-__device__ __forceinline__ void line_tail(S &s, int svtype, unsigned long long end, unsigned long long len) {
-    s.lit("\t.\t.\t");
-    if (svtype) {
-        s.lit("SVTYPE=");
-        switch (svtype) {
-            case 1: s.lit("INS"); break;
-            case 2: s.lit("DEL"); break;
-            case 3: s.lit("INV"); break;
-            case 4: s.lit("DUP"); break;
-            case 5: s.lit("INS:ME"); break;
-            default: s.lit("DEL:ME"); break;
-        }
-        s.lit(";END=");
-        s.num(end);
-        s.lit(";SVLEN=");
-        s.num(len);
-    } else {
-        s.put('.');
-    }
-    s.lit("\tGT\t1\n");
-}
+// One record's line (mutator.py:334-421 builds the record, vcf_writer.py:44-52,118-126 the line) as a DESCRIPTION that every
+// type shares, so that the 64 lanes of a wave -- records of six types -- run ONE formatter instead of six one after the other:
+//   name \t POS \t . \t  pre  copy0  mid  copy1  copy2  \t.\t.\t INFO \tGT\t1\n
+// pre / mid: up to three / two literal characters (the anchor base of an insertion, the tab between REF and ALT, a deletion's ALT);
+// copy: (source, length, mode) -- mode 0 raw, 1 conv(x), 2 comp(conv(x)) read BACKWARDS from the source (the LAST source byte).
+//   SN   pre "R\tA"                                   INFO .
+//   IN   pre "r\tr" copy0 ins            (pos 0: pre "r\t" copy0 ins mid "r")
+//   TLI  like IN, copy0 = the linked span (reversed: mode 2)
+//   DE / TL   copy0 REF, mid "\ta"
+//   IV   copy0 REF, mid "\t", copy1 = REF reverse-complemented
+//   DU   copy0 REF (raw), mid "\t", copy1 = copy2 = REF
+struct VcfLine {
+    unsigned long long start, end, svlen;            // POS; END / SVLEN of INFO
+    const uint8_t *src[3];
+    unsigned long long len[3];
+    uint32_t mode;                                   // 2 bits per copy
+    uint32_t pre, mid;                               // characters, first one in the low byte
+    uint32_t n_pre, n_mid, svtype;                   // svtype: 0 none (SNP), 1 INS, 2 DEL, 3 INV, 4 DUP, 5 INS:ME, 6 DEL:ME
+    bool none;                                       // REF == ALT: no line (vcf_writer.py:123)
+};
 
-// One record's line into a sink (mutator.py:334-421 builds the record, vcf_writer.py:118-126 the line).
-// CHECK: evaluate the suppression rules (REF == ALT, vcf_writer.py:123) -- the length pass does, the write pass skips the
-// records whose length came out 0.
-template <bool CHECK, class S>
-__device__ __forceinline__ void format_record(S &s, const msim_record &r, const uint8_t *__restrict__ pool,
-                                              const uint8_t *__restrict__ in, unsigned long long L,
-                                              const uint8_t *__restrict__ name, uint32_t name_len, const uint8_t *lut) {
+// CHECK: evaluate the suppression rules that need bases -- the length pass does, the write pass skips records of length 0.
+// snp_ra: REF | ALT << 8 of an SNP record where the caller has them already (the write pass: from the length pass), else 0.
+template <bool CHECK>
+__device__ __forceinline__ VcfLine vcf_describe(const msim_record &r, const uint8_t *__restrict__ pool, const uint8_t *__restrict__ in,
+                                                unsigned long long L, const uint8_t *lut, uint32_t snp_ra) {
+    VcfLine d;
     const unsigned long long pos = r.pos, stop = r.stop;
+    d.start = pos + 1; d.end = 0; d.svlen = 0;
+    d.src[0] = d.src[1] = d.src[2] = in;
+    d.len[0] = d.len[1] = d.len[2] = 0;
+    d.mode = 0; d.pre = 0; d.mid = 0; d.n_pre = 0; d.n_mid = 0; d.svtype = 0; d.none = false;
     switch (r.type) {
         case MSIM_SN: {                                                  // mutator.py:334-341
-            const uint8_t x = in[pos];
-            const uint8_t ref = lut[768 + x];
-            const uint8_t alt = lut[(uint32_t)r.aux * 256 + x];          // ti / tv column of conv(x)
-            if (ref == alt) break;                                       // vcf_writer.py:123
-            line_head(s, name, name_len, pos + 1);
-            s.put((char)ref); s.put('\t'); s.put((char)alt);
-            line_tail(s, 0, 0, 0);
+            uint32_t ref = snp_ra & 255, alt = snp_ra >> 8;
+            if (CHECK) {
+                const uint8_t x = in[pos];
+                ref = lut[768 + x];
+                alt = lut[(uint32_t)r.aux * 256 + x];                    // ti / tv column of conv(x)
+            }
+            d.none = ref == alt;
+            d.pre = ref | ((uint32_t)'\t' << 8) | (alt << 16); d.n_pre = 3;
             break;
         }
         case MSIM_IN: {                                                  // mutator.py:343-358
-            const unsigned long long len = stop + 1 - pos;
-            const uint8_t *ins = pool + r.extra;
-            if (pos > 0) {
-                const char ref = (char)lut[768 + in[pos - 1]];
-                line_head(s, name, name_len, pos);
-                s.put(ref); s.put('\t'); s.put(ref); s.bulk(ins, len, 0, lut);
-                line_tail(s, 1, pos, len);
-            } else {
-                const char ref = (char)lut[768 + in[0]];
-                line_head(s, name, name_len, 1);
-                s.put(ref); s.put('\t'); s.bulk(ins, len, 0, lut); s.put(ref);
-                line_tail(s, 1, 1, len);
-            }
+            const uint32_t ref = lut[768 + in[pos > 0 ? pos - 1 : 0]];
+            d.src[0] = pool + r.extra; d.len[0] = stop + 1 - pos;
+            d.svtype = 1; d.svlen = d.len[0];
+            if (pos > 0) { d.start = pos; d.pre = ref | ((uint32_t)'\t' << 8) | (ref << 16); d.n_pre = 3; }
+            else { d.start = 1; d.pre = ref | ((uint32_t)'\t' << 8); d.n_pre = 2; d.mid = ref; d.n_mid = 1; }
+            d.end = d.start;
             break;
         }
         case MSIM_TLI: {                                                 // mutator.py:401-421
@@ -179,28 +258,24 @@ __device__ __forceinline__ void format_record(S &s, const msim_record &r, const 
             const unsigned long long hi = stop + 1 < L ? stop + 1 : L;
             const unsigned long long ilen = hi > src ? hi - src : 0;
             const bool rev = r.aux & 1, after = r.aux & 2;
-            if (ilen == 0) break;                                        // REF == ALT: suppressed
-            const unsigned long long start = after ? pos : pos + 1;
-            const char ref = (char)lut[768 + in[after ? pos - 1 : pos]];
-            line_head(s, name, name_len, start);
-            s.put(ref); s.put('\t');
-            if (after) s.put(ref);
-            if (rev) s.bulk(in + hi - 1, ilen, 2, lut);
-            else s.bulk(in + src, ilen, 1, lut);
-            if (!after) s.put(ref);
-            line_tail(s, 5, start, ilen);
+            d.none = ilen == 0;                                          // REF == ALT: suppressed
+            const uint32_t ref = lut[768 + in[after ? pos - 1 : pos]];
+            d.start = after ? pos : pos + 1;
+            if (after) { d.pre = ref | ((uint32_t)'\t' << 8) | (ref << 16); d.n_pre = 3; }
+            else { d.pre = ref | ((uint32_t)'\t' << 8); d.n_pre = 2; d.mid = ref; d.n_mid = 1; }
+            d.src[0] = rev ? in + hi - 1 : in + src; d.len[0] = ilen; d.mode = rev ? 2u : 1u;
+            d.svtype = 5; d.end = d.start; d.svlen = ilen;
             break;
         }
         case MSIM_TL:
         case MSIM_DE: {                                                  // mutator.py:360-377
-            unsigned long long start = pos, end = stop + 1, lo = pos - 1;
-            if (pos == 0) { start = 1; end = stop + 2; lo = 0; }
+            unsigned long long end = stop + 1, lo = pos - 1;
+            d.start = pos;
+            if (pos == 0) { d.start = 1; end = stop + 2; lo = 0; }
             const unsigned long long hi = end < L ? end : L;             // slice clamps at len(sequence)
-            line_head(s, name, name_len, start);
-            s.bulk(in + lo, hi - lo, 1, lut);
-            s.put('\t');
-            s.put((char)lut[768 + in[pos > 0 ? lo : hi - 1]]);           // REF[0] / REF[-1]
-            line_tail(s, r.type == MSIM_DE ? 2 : 6, end, stop - pos + 1);
+            d.src[0] = in + lo; d.len[0] = hi - lo; d.mode = 1u;
+            d.mid = (uint32_t)'\t' | ((uint32_t)lut[768 + in[pos > 0 ? lo : hi - 1]] << 8); d.n_mid = 2;     // REF[0] / REF[-1]
+            d.svtype = r.type == MSIM_DE ? 2 : 6; d.end = end; d.svlen = stop - pos + 1;
             break;
         }
         case MSIM_IV: {                                                  // mutator.py:379-387
@@ -209,25 +284,78 @@ __device__ __forceinline__ void format_record(S &s, const msim_record &r, const 
                 bool diff = false;                                       // (three of four random pairs differ: ~1.3 steps)
                 for (unsigned long long q = 0; q < len && !diff; q++)
                     diff = lut[768 + in[pos + q]] != lut[1024 + in[stop - q]];
-                if (!diff) break;
+                d.none = !diff;
             }
-            line_head(s, name, name_len, pos + 1);
-            s.bulk(in + pos, len, 1, lut);
-            s.put('\t');
-            s.bulk(in + stop, len, 2, lut);
-            line_tail(s, 3, stop + 1, 0);
+            d.src[0] = in + pos; d.len[0] = len; d.src[1] = in + stop; d.len[1] = len; d.mode = 1u | (2u << 2);
+            d.mid = (uint32_t)'\t'; d.n_mid = 1;
+            d.svtype = 3; d.end = stop + 1; d.svlen = 0;
             break;
         }
         case MSIM_DU: {                                                  // mutator.py:389-399 (REF not converted)
             const unsigned long long len = stop - pos + 1;
-            line_head(s, name, name_len, pos + 1);
-            s.bulk(in + pos, len, 0, lut); s.put('\t');
-            s.bulk(in + pos, len, 0, lut); s.bulk(in + pos, len, 0, lut);
-            line_tail(s, 4, pos + len, len);
+            d.src[0] = d.src[1] = d.src[2] = in + pos; d.len[0] = d.len[1] = d.len[2] = len;
+            d.mid = (uint32_t)'\t'; d.n_mid = 1;
+            d.svtype = 4; d.end = pos + len; d.svlen = len;
             break;
         }
-        default: break;
+        default: d.none = true; break;
     }
+    return d;
+}
+
+// the six SVTYPE names, eight bytes each (first character in the low byte) and their lengths
+__device__ __forceinline__ unsigned long long vcf_svname(uint32_t t, uint32_t &n) {
+    constexpr unsigned long long INS = 0x534e49ull, DEL = 0x4c4544ull, INV = 0x564e49ull, DUP = 0x505544ull,
+                                 INSME = 0x454d3a534e49ull, DELME = 0x454d3a4c4544ull;
+    n = t >= 5 ? 6u : 3u;
+    return t == 1 ? INS : t == 2 ? DEL : t == 3 ? INV : t == 4 ? DUP : t == 5 ? INSME : DELME;
+}
+
+template <class S>
+__device__ __forceinline__ void vcf_emit(S &s, const VcfLine &d, const uint8_t *name, uint32_t name_len, const uint8_t *lut) {
+    s.begin(d);
+    s.name(name, name_len);
+    s.put('\t');
+    s.num(d.start);
+    s.lit("\t.\t");
+    s.chars(d.pre, d.n_pre);
+    s.bulk(0, d.src[0], d.len[0], (int)(d.mode & 3), lut);
+    s.chars(d.mid, d.n_mid);
+    s.bulk(1, d.src[1], d.len[1], (int)((d.mode >> 2) & 3), lut);
+    s.bulk(2, d.src[2], d.len[2], (int)((d.mode >> 4) & 3), lut);
+    s.lit("\t.\t.\t");
+    if (d.svtype) {
+        s.lit("SVTYPE=");
+        uint32_t k;
+        const unsigned long long nm = vcf_svname(d.svtype, k);
+        s.chars64(nm, k);
+        s.lit(";END=");
+        s.num(d.end);
+        s.lit(";SVLEN=");
+        s.num(d.svlen);
+    } else {
+        s.put('.');
+    }
+    s.lit("\tGT\t1\n");
+}
+
+// Which waves the stage scheme cannot describe (wave-uniform): 64 lines spanning 4 GiB of text, source addresses beyond 2^48 (the
+// pieces pack them), or the test hook.  k_vcf_lines<true, false> leaves them alone, k_vcf_plain writes them.
+__device__ __forceinline__ bool vcf_wave_is_plain(unsigned long long first, unsigned long long end, const uint8_t *in, unsigned long long L,
+                                                  const uint8_t *pool, uint32_t plain) {
+    const unsigned long long top = (unsigned long long)(uintptr_t)(in + L) | (unsigned long long)(uintptr_t)(pool + (1ull << 32));
+    return end - first >= (1ull << 32) - 16 || (top >> 48) != 0 || plain != 0;
+}
+
+// the gaps of a line written at text offset `off` (what SSink::bulk will open)
+__device__ __forceinline__ unsigned long long vcf_line_gaps(const VcfLine &d, unsigned long long off, uint32_t name_len) {
+    unsigned long long n = off + name_len + 1 + (unsigned)ndigits(d.start) + 3 + d.n_pre, gaps = 0, ia, ib;
+    if (vcf_piece_of(n, d.len[0], ia, ib)) gaps += ib - ia;
+    n += d.len[0] + d.n_mid;
+    if (vcf_piece_of(n, d.len[1], ia, ib)) gaps += ib - ia;
+    n += d.len[1];
+    if (vcf_piece_of(n, d.len[2], ia, ib)) gaps += ib - ia;
+    return gaps;
 }
 
 // 16 source bytes through a 256-entry LDS table
@@ -239,51 +367,61 @@ __device__ __forceinline__ uint4 lut16(uint4 w, const uint8_t *t) {
                ((uint32_t)t[v[d] >> 24] << 24);
     return uint4{v[0], v[1], v[2], v[3]};
 }
-// ... and the same with the byte order reversed (reverse complement: the piece is read backwards)
-__device__ __forceinline__ uint4 lut16_rev(uint4 w, const uint8_t *t) {
-    uint32_t v[4] = {w.w, w.z, w.y, w.x};
-#pragma unroll
-    for (int d = 0; d < 4; d++)
-        v[d] = (uint32_t)t[v[d] >> 24] | ((uint32_t)t[(v[d] >> 16) & 255] << 8) | ((uint32_t)t[(v[d] >> 8) & 255] << 16) |
-               ((uint32_t)t[v[d] & 255] << 24);
-    return uint4{v[0], v[1], v[2], v[3]};
-}
-
-// The pieces of a wave's records, copied by the whole wave: a UNIT is 16 destination-aligned bytes of one piece (its first and
-// last unit may be partial).  pre[s] = units in front of slot s (pre[64 * VCF_SLOTS] = all of them); a lane takes units lane,
-// lane + 64, ... and finds each one's slot by binary search.  Two units per lane are in flight (their loads are issued together).
+// The copies of a wave's records, made by the whole wave: a UNIT is what of a copy falls into one aligned 16-byte unit of the
+// text.  A whole unit inside a copy's interior goes source -> text (one unaligned 16-byte load, one aligned store); the others --
+// a short copy's units, the edges in front of and behind an interior -- go byte by byte into the stage, where the lane left
+// room for them.  pre[s] = units in front of slot s (pre[64 * VCF_SLOTS] = all of them); a lane takes units lane, lane + 64, ...
+// and finds each one's slot by binary search; two units per lane are in flight (their loads are issued together).
 // Round 4 took the long records one after the other, every copy a dependent load -> table -> store chain of the whole wave:
 // latency-bound at 0.2 TB/s of text on the SV mix (DU / IV of 50-500 bases: 85 % of the bytes).
-struct VcfUnit { unsigned long long dst; const uint8_t *src; uint32_t lo, hi, mode; uint4 w; };      // bytes [lo, hi) of the unit at dst
+struct VcfUnit { unsigned long long dst; uint32_t mode, cnt, spos; uint4 w; };       // cnt: 0 nothing, 16 a whole interior unit (dst),
+                                                                                      // else cnt bytes at stage position spos
+__device__ __forceinline__ uint32_t vcf_piece_units(const VcfPiece &pc) {
+    return ((pc.n_rel + pc.len - 1) >> 4) - (pc.n_rel >> 4) + 1;                     // (len >= 1)
+}
 
-__device__ __forceinline__ void vcf_unit_load(VcfUnit &u, uint32_t idx, uint32_t n_units, const VcfPiece *pcs, const uint32_t *pre) {
-    u.hi = 0;
+__device__ __forceinline__ void vcf_unit_load(VcfUnit &u, uint32_t idx, uint32_t n_units, const VcfPiece *pcs, const uint32_t *pre,
+                                              unsigned long long origin) {
+    u.cnt = 0;
     if (idx >= n_units) return;
     uint32_t s = 0;
 #pragma unroll
-    for (int step = 32 * VCF_SLOTS; step; step >>= 1) if (pre[s + step] <= idx) s += step;
+    for (int step = 128; step; step >>= 1) if (s + step <= 64 * VCF_SLOTS && pre[s + step] <= idx) s += step;
     const VcfPiece pc = pcs[s];
-    const unsigned long long a0 = pc.dst & ~15ull, at = a0 + 16ull * (idx - pre[s]);
-    const unsigned long long lo = at > pc.dst ? at : pc.dst, hi = at + 16 < pc.dst + pc.len ? at + 16 : pc.dst + pc.len;
-    u.dst = at; u.lo = (uint32_t)(lo - at); u.hi = (uint32_t)(hi - at); u.mode = pc.mode;
-    const unsigned long long k = lo - pc.dst;                            // piece offset of the unit's first byte
-    u.src = pc.mode == 2 ? pc.src - k : pc.src + k;                      // source of that byte
-    if (u.hi - u.lo == 16) {                                             // a whole unit: one unaligned 16-byte load
-        if (pc.mode == 2) __builtin_memcpy(&u.w, u.src - 15, 16);
-        else __builtin_memcpy(&u.w, u.src, 16);
+    const uint32_t tu = (pc.n_rel >> 4) + (idx - pre[s]);                // text unit, counted from the origin
+    const uint32_t lo = max(pc.n_rel, tu << 4), hi = min(pc.n_rel + pc.len, (tu + 1) << 4);      // (a wave's stretch stays below 4 GiB)
+    const uint32_t k0 = lo - pc.n_rel;                                   // copy offset of the unit's first byte
+    u.mode = (uint32_t)(pc.src_ws_mode >> 62);
+    const uint8_t *src = reinterpret_cast<const uint8_t *>((uintptr_t)(pc.src_ws_mode & ((1ull << 48) - 1)));
+    const uint32_t ws = (uint32_t)(pc.src_ws_mode >> 48) & 4095u;
+    if (u.mode == 2) __builtin_memcpy(&u.w, src - k0 - 15, 16);          // one unaligned 16-byte load (slack on both sides of the
+    else __builtin_memcpy(&u.w, src + k0, 16);                           //  buffers -- ctx.h: PAD -- keeps a partial unit's inside)
+    u.cnt = hi - lo;
+    const unsigned long long n = origin + pc.n_rel;
+    unsigned long long ia, ib;
+    const bool interior = vcf_piece_of(n, pc.len, ia, ib);
+    if (u.cnt == 16 && interior && origin + lo >= ia && origin + hi <= ib) {
+        u.dst = origin + lo;
+    } else {                                                             // stage position: the copy's offset, minus its gap behind it
+        u.cnt |= 32u;
+        u.spos = ws + k0 - (interior && origin + lo >= ib ? (uint32_t)(ib - ia) : 0u);
     }
 }
 
-__device__ __forceinline__ void vcf_unit_store(const VcfUnit &u, char *__restrict__ text, const uint8_t *lut) {
-    if (u.hi == 0) return;
-    if (u.hi - u.lo == 16) {
-        const uint4 o = u.mode == 0 ? u.w : u.mode == 1 ? lut16(u.w, lut + 768) : lut16_rev(u.w, lut + 1024);
-        *reinterpret_cast<uint4 *>(text + u.dst) = o;
+__device__ __forceinline__ void vcf_unit_store(const VcfUnit &u, char *__restrict__ text, char *stage, const uint8_t *lut) {
+    if (u.cnt == 0) return;
+    uint4 v = u.w;
+    if (u.mode == 2) v = uint4{__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x)};   // read backwards
+    if (u.mode) v = lut16(v, lut + (u.mode == 1 ? 768 : 1024));          // conv / comp(conv)
+    if (u.cnt == 16) {
+        *reinterpret_cast<uint4 *>(text + u.dst) = v;
     } else {
-        for (uint32_t q = u.lo; q < u.hi; q++) {
-            const uint32_t i = q - u.lo;
-            const uint8_t c = u.mode == 0 ? u.src[i] : u.mode == 1 ? lut[768 + u.src[i]] : lut[1024 + *(u.src - i)];
-            text[u.dst + q] = (char)c;
+        const uint32_t c = u.cnt & 31u;
+        unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32), hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+        for (uint32_t i = 0; i < c; i++) {
+            stage[u.spos + i] = (char)lo;
+            lo = (lo >> 8) | (hi << 56);
+            hi >>= 8;
         }
     }
 }
@@ -307,13 +445,22 @@ __device__ __forceinline__ void snp_line(P p, const uint8_t *__restrict__ name, 
 // by the length pass (which has to look at the base anyway: REF == ALT is suppressed) so that the write pass does not gather
 // the contig's bases at 2 M scattered positions a second time.
 // ALL_SNP (Contig::all_snp: the table holds SNP records only -- the SNP sampler's, `-sn` alone): the kernel without the other
-// types' formatter -- 52 registers instead of 139, eight waves per SIMD instead of three.
+// types' formatter.
 // A wave takes 64 consecutive records, a LANE formats its own record's line (round 1 gave every line a wave: ~15 instructions of
-// 64 lanes for 25 bytes, 135 GB/s).  Length pass: nothing but the record, one base per SNP and the ends of an inversion are read --
-// every length follows from (type, pos, stop).  Write pass: the lines of a wave's records are adjacent in the text.  Where all of
-// them are short, the lanes format into LDS and the wave stores the stretch 16 aligned bytes per lane; else a lane writes its
-// line's short fields to the text itself and the long REF / ALT copies of all 64 records go through vcf_unit_*.
-constexpr uint32_t VCF_WAVE_LDS = 64 * VCF_SLOTS * sizeof(VcfPiece) + (64 * VCF_SLOTS + 4) * sizeof(uint32_t);   // piece list + unit prefix
+// 64 lanes for 25 bytes, 135 GB/s).
+// Length pass: nothing but the record, one base per SNP and the ends of an inversion are read -- every length follows from
+// (type, pos, stop).
+// Write pass: the lines of a wave's records are adjacent in the text, so the wave builds them in LDS and stores 16 aligned bytes
+// per lane -- minus the long REF / ALT copies (a duplication of 275 bases is a line of 885 bytes; 64 such lines do not fit any
+// stage): their aligned interiors are gaps of the stage, copied source -> text by the whole wave (vcf_unit_*), and the flush
+// shifts every stage unit by the gaps in front of it.  No byte of text is stored other than as part of an aligned 16-byte store
+// (the first and the last unit of a wave's stretch excepted).  Records whose compact text does not fit the stage together go
+// in groups (consecutive lanes).  Round 4 let a lane store its line byte by byte unless ALL 64 lines were short, and took long
+// records one after the other, every copy a dependent load -> table -> store chain: 0.2 TB/s of text on the SV mix.
+constexpr uint32_t VCF_O_GS = VCF_STAGE;                                                // u32[VCF_UNITS]: gap units in front of a stage unit
+constexpr uint32_t VCF_O_PCS = VCF_O_GS + VCF_UNITS * 4;                               // VcfPiece[64 * VCF_SLOTS]
+constexpr uint32_t VCF_O_PRE = VCF_O_PCS + 64 * VCF_SLOTS * sizeof(VcfPiece);          // u32[64 * VCF_SLOTS + 1] (+ pad)
+constexpr uint32_t VCF_WAVE_LDS = VCF_O_PRE + (64 * VCF_SLOTS + 4) * 4;
 
 template <bool WRITE, bool ALL_SNP>
 __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__restrict__ recs, uint32_t n_rec,
@@ -323,13 +470,16 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
                                                           const uint8_t *__restrict__ lut_g,
                                                           uint32_t *__restrict__ len_io, uint16_t *__restrict__ ra,
                                                           const unsigned long long *__restrict__ off,
-                                                          char *__restrict__ text) {
+                                                          char *__restrict__ text, uint32_t plain) {
     __shared__ uint8_t lut[1280];
-    constexpr uint32_t WB = !WRITE ? 16 : ALL_SNP ? VCF_STAGE : (VCF_WAVE_LDS > VCF_STAGE ? VCF_WAVE_LDS : VCF_STAGE);
+    __shared__ uint8_t lname[64];                                        // the sequence name (every line starts with it)
+    constexpr uint32_t WB = !WRITE ? 16 : ALL_SNP ? VCF_STAGE : VCF_WAVE_LDS;
     __shared__ __attribute__((aligned(16))) char wbuf[WRITE ? TX_WAVES : 1][WB];
     for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
         reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
+    if (threadIdx.x < 64 && threadIdx.x < name_len) lname[threadIdx.x] = name[threadIdx.x];
     __syncthreads();
+    const uint8_t *nm = name_len <= 64 ? lname : name;
     const uint32_t lane_id = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t base_rec = (blockIdx.x * TX_WAVES + wave) * 64;
     if (base_rec >= n_rec) return;
@@ -347,44 +497,33 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
             len_io[mine] = ref == alt ? 0u : name_len + (uint32_t)ndigits(start) + 19u;   // vcf_writer.py:123: REF == ALT suppressed
             ra[mine] = (uint16_t)((uint32_t)ref | ((uint32_t)alt << 8));
         } else if (!ALL_SNP) {
+            const VcfLine d = vcf_describe<true>(my, pool, in, L, lut, 0);
             CSink s;
             s.n = 0;
-            format_record<true>(s, my, pool, in, L, name, name_len, lut);
+            if (!d.none) vcf_emit(s, d, name, name_len, lut);
             len_io[mine] = (uint32_t)s.n;
         }
         return;
     }
     // ---- write pass
     char *stage = wbuf[WRITE ? wave : 0];
-    bool is_short = is_snp;
-    if (!ALL_SNP && valid && !is_snp) {
-        const unsigned long long hi = (unsigned long long)my.stop + 1 < L ? (unsigned long long)my.stop + 1 : L;
-        const unsigned long long span = my.type == MSIM_TLI ? (hi > my.extra ? hi - my.extra : 0)
-                                                            : (unsigned long long)my.stop - my.pos + 1;
-        is_short = span <= VCF_LANE_SPAN;
-    }
     unsigned long long my_off = 0;
     uint32_t my_len = 0;
     if (valid) { my_off = off[mine]; my_len = len_io[mine]; }
     const uint32_t last = min(63u, n_rec - 1 - base_rec);
-    const unsigned long long start0 = __shfl(my_off, 0, 64);
-    const unsigned long long end = __shfl(my_off + my_len, (int)last, 64);
-    const uint32_t stretch = (uint32_t)min(end - start0, (unsigned long long)(2 * VCF_STAGE));
-    const uint32_t phase = (uint32_t)(start0 & 15);
-    const bool staged = __ballot(valid && !is_short) == 0ull && phase + stretch <= VCF_STAGE && (ALL_SNP || name_len <= VCF_INLINE);
-    if (staged) {                                                        // (wave-uniform) every line is short: through LDS
+    if (ALL_SNP) {
+        const unsigned long long start0 = __shfl(my_off, 0, 64);
+        const unsigned long long end = __shfl(my_off + my_len, (int)last, 64);
+        const uint32_t stretch = (uint32_t)min(end - start0, (unsigned long long)(2 * VCF_STAGE));
+        const uint32_t phase = (uint32_t)(start0 & 15);
+        const bool staged = phase + stretch <= VCF_STAGE;                 // (wave-uniform; else: long names)
         if (valid && my_len) {
-            char *p = &stage[phase + (uint32_t)(my_off - start0)];
-            if (is_snp) {
-                const uint32_t r2 = ra[mine];
-                const unsigned long long start = (unsigned long long)my.pos + 1;
-                snp_line(p, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
-            } else if (!ALL_SNP) {
-                PSink s;
-                s.text = p; s.n = 0; s.slots = nullptr; s.np = VCF_SLOTS;   // (no piece can arise: every copy is <= VCF_INLINE)
-                format_record<false>(s, my, pool, in, L, name, name_len, lut);
-            }
+            const uint32_t r2 = ra[mine];
+            const unsigned long long start = (unsigned long long)my.pos + 1;
+            if (staged) snp_line(&stage[phase + (uint32_t)(my_off - start0)], name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
+            else snp_line(text + my_off, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
         }
+        if (!staged) return;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // (flat stores into LDS complete out of order with ds reads: wait for both)
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -399,61 +538,129 @@ __global__ __launch_bounds__(TX_THREADS) void k_vcf_lines(const msim_record *__r
             }
         }
         return;
-    }
-    if (ALL_SNP) {                                                       // (a stretch that does not fit the stage: long names)
-        if (valid && my_len) {
-            const uint32_t r2 = ra[mine];
-            const unsigned long long start = (unsigned long long)my.pos + 1;
-            snp_line(text + my_off, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
-        }
-        return;
-    }
-    VcfPiece *pcs = reinterpret_cast<VcfPiece *>(stage);
-    uint32_t *pre = reinterpret_cast<uint32_t *>(stage + 64 * VCF_SLOTS * sizeof(VcfPiece));
-    PSink s;
-    s.text = text; s.n = my_off; s.slots = pcs + lane_id * VCF_SLOTS; s.np = 0;
-    if (valid && my_len) {
-        if (is_snp) {
-            const uint32_t r2 = ra[mine];
-            const unsigned long long start = (unsigned long long)my.pos + 1;
-            snp_line(text + my_off, name, name_len, start, ndigits(start), (uint8_t)r2, (uint8_t)(r2 >> 8));
-        } else {
-            format_record<false>(s, my, pool, in, L, name, name_len, lut);
-        }
-    }
-    // units of this lane's pieces, their prefix over the wave
-    uint32_t cnt[VCF_SLOTS], tot = 0;
+    } else {
+        uint32_t *gs = reinterpret_cast<uint32_t *>(stage + VCF_O_GS);
+        VcfPiece *pcs = reinterpret_cast<VcfPiece *>(stage + VCF_O_PCS);
+        uint32_t *pre = reinterpret_cast<uint32_t *>(stage + VCF_O_PRE);
+        auto wave_sync = []() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        // this lane's line, and its gaps (text coordinates are needed: a piece's interior is aligned in the text)
+        const bool live = valid && my_len != 0;
+        VcfLine d = vcf_describe<false>(my, pool, in, L, lut, live && is_snp ? (uint32_t)ra[mine] : 0u);
+        if (vcf_wave_is_plain(__shfl(my_off, 0, 64), __shfl(my_off + my_len, (int)last, 64), in, L, pool, plain)) return;   // k_vcf_plain's
+        const unsigned long long my_gap = live ? vcf_line_gaps(d, my_off, name_len) : 0ull;
+        // compact size of the lines up to and including this lane's
+        unsigned long long cp = (unsigned long long)my_len - my_gap;
 #pragma unroll
-    for (int q = 0; q < VCF_SLOTS; q++) {
-        cnt[q] = 0;
-        if ((uint32_t)q < s.np) {
-            const VcfPiece pc = s.slots[q];
-            cnt[q] = (uint32_t)((((pc.dst + pc.len + 15) & ~15ull) - (pc.dst & ~15ull)) >> 4);
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(cp, o, 64);
+            if (lane_id >= (uint32_t)o) cp += t;
         }
-        tot += cnt[q];
-    }
-    uint32_t incl = tot;
+        const unsigned long long cp_excl = cp - ((unsigned long long)my_len - my_gap);
+        for (uint32_t lo = 0; lo <= last;) {                             // groups of consecutive lanes that fit the stage together
+            const unsigned long long off_lo = __shfl(my_off, (int)lo, 64), cp_lo = __shfl(cp_excl, (int)lo, 64);
+            const unsigned long long origin = off_lo & ~15ull;
+            const uint32_t phase = (uint32_t)(off_lo & 15);
+            const unsigned long long fits = __ballot(lane_id >= lo && lane_id <= last && cp - cp_lo + phase <= VCF_STAGE);
+            const unsigned long long rest = ~(fits >> lo);               // first lane from lo on that does not fit
+            uint32_t hi = lo + (rest ? (uint32_t)__builtin_ctzll(rest) : 64u - lo);
+            hi = min(hi, last + 1);
+            if (hi == lo) hi = lo + 1;                                   // (cannot happen: one line's compact text is a few hundred bytes)
+            const uint32_t csize = (uint32_t)(__shfl(cp, (int)(hi - 1), 64) - cp_lo) + phase;      // compact bytes incl. the phase
+            const uint32_t units = (csize + 15) >> 4;
+            reinterpret_cast<uint4 *>(gs)[lane_id] = uint4{0, 0, 0, 0};  // (VCF_UNITS == 256 == 64 lanes x 4)
+            wave_sync();
+            SSink s;
+            s.stage = stage; s.gs = gs; s.slots = pcs + lane_id * VCF_SLOTS; s.np = 0; s.origin = origin;
+            const bool in_group = lane_id >= lo && lane_id < hi;
+            if (in_group && live) {
+                s.w = phase + (uint32_t)(cp_excl - cp_lo);
+                s.n = my_off;
+                vcf_emit(s, d, nm, name_len, lut);
+            }
+            // ---- the pieces' interiors: source -> text
+            uint32_t cnt[VCF_SLOTS], tot = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-        if (lane_id >= (uint32_t)o) incl += t;
-    }
-    const uint32_t n_units = (uint32_t)__shfl((int)incl, 63, 64);
-    if (n_units == 0) return;
-    uint32_t run = incl - tot;
+            for (int q = 0; q < VCF_SLOTS; q++) {
+                cnt[q] = (uint32_t)q < s.np ? vcf_piece_units(s.slots[q]) : 0u;
+                tot += cnt[q];
+            }
+            uint32_t incl = tot;
 #pragma unroll
-    for (int q = 0; q < VCF_SLOTS; q++) { pre[lane_id * VCF_SLOTS + q] = run; run += cnt[q]; }
-    if (lane_id == 63) pre[64 * VCF_SLOTS] = n_units;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    for (uint32_t u0 = 0; u0 < n_units; u0 += 128) {
-        VcfUnit a, b;
-        vcf_unit_load(a, u0 + lane_id, n_units, pcs, pre);
-        vcf_unit_load(b, u0 + 64 + lane_id, n_units, pcs, pre);
-        vcf_unit_store(a, text, lut);
-        vcf_unit_store(b, text, lut);
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+                if (lane_id >= (uint32_t)o) incl += t;
+            }
+            const uint32_t n_units = (uint32_t)__shfl((int)incl, 63, 64);
+            uint32_t run = incl - tot;
+#pragma unroll
+            for (int q = 0; q < VCF_SLOTS; q++) { pre[lane_id * VCF_SLOTS + q] = run; run += cnt[q]; }
+            if (lane_id == 63) pre[64 * VCF_SLOTS] = n_units;
+            wave_sync();
+            for (uint32_t u0 = 0; u0 < n_units; u0 += 128) {
+                VcfUnit a, b;
+                vcf_unit_load(a, u0 + lane_id, n_units, pcs, pre, origin);
+                vcf_unit_load(b, u0 + 64 + lane_id, n_units, pcs, pre, origin);
+                vcf_unit_store(a, text, stage, lut);
+                vcf_unit_store(b, text, stage, lut);
+            }
+            // ---- the stage: unit x goes to text unit x + (gap units in front of it)
+            {
+                uint4 v = reinterpret_cast<const uint4 *>(gs)[lane_id];
+                v.y += v.x; v.z += v.y; v.w += v.z;
+                uint32_t inc2 = v.w;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)inc2, o, 64);
+                    if (lane_id >= (uint32_t)o) inc2 += t;
+                }
+                const uint32_t before = inc2 - v.w;
+                v.x += before; v.y += before; v.z += before; v.w += before;
+                reinterpret_cast<uint4 *>(gs)[lane_id] = v;
+            }
+            wave_sync();
+            for (uint32_t x = lane_id; x < units; x += 64) {
+                char *g0 = text + origin + 16ull * ((unsigned long long)x + gs[x]);
+                const uint32_t b0 = x == 0 ? phase : 0u, b1 = x + 1 == units ? csize - 16 * x : 16u;
+                if (b0 == 0 && b1 == 16) *reinterpret_cast<uint4 *>(g0) = *reinterpret_cast<const uint4 *>(&stage[16 * x]);
+                else for (uint32_t q = b0; q < b1; q++) g0[q] = stage[16 * x + q];
+            }
+            wave_sync();                                                 // (the next group reuses the stage)
+            lo = hi;
+        }
     }
+}
+
+// The waves k_vcf_lines<true, false> left alone: every lane writes its own line byte by byte.
+__global__ __launch_bounds__(TX_THREADS) void k_vcf_plain(const msim_record *__restrict__ recs, uint32_t n_rec,
+                                                          const uint8_t *__restrict__ pool, const uint8_t *__restrict__ in,
+                                                          unsigned long long L, const uint8_t *__restrict__ name, uint32_t name_len,
+                                                          const uint8_t *__restrict__ lut_g, const uint32_t *__restrict__ len_io,
+                                                          const uint16_t *__restrict__ ra, const unsigned long long *__restrict__ off,
+                                                          char *__restrict__ text, uint32_t plain) {
+    __shared__ uint8_t lut[1280];
+    for (int i = threadIdx.x; i < 1280 / 4; i += TX_THREADS)
+        reinterpret_cast<uint32_t *>(lut)[i] = reinterpret_cast<const uint32_t *>(lut_g)[i];
+    __syncthreads();
+    const uint32_t lane_id = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t base_rec = (blockIdx.x * TX_WAVES + wave) * 64;
+    if (base_rec >= n_rec) return;
+    const uint32_t mine = base_rec + lane_id;
+    const bool valid = mine < n_rec;
+    msim_record my{};
+    unsigned long long my_off = 0;
+    uint32_t my_len = 0;
+    if (valid) { my = recs[mine]; my_off = off[mine]; my_len = len_io[mine]; }
+    const uint32_t last = min(63u, n_rec - 1 - base_rec);
+    if (!vcf_wave_is_plain(__shfl(my_off, 0, 64), __shfl(my_off + my_len, (int)last, 64), in, L, pool, plain)) return;
+    if (!valid || my_len == 0) return;
+    const VcfLine d = vcf_describe<false>(my, pool, in, L, lut, my.type == MSIM_SN ? (uint32_t)ra[mine] : 0u);
+    DSink s;
+    s.text = text; s.n = my_off;
+    vcf_emit(s, d, name, name_len, lut);
 }
 
 // ---- exclusive u64 scan of u32 lengths (2048 per workgroup)
@@ -696,7 +903,7 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
 #define MSIM_VCF_LINES(W, ...) do { if (g.all_snp) hipLaunchKernelGGL((k_vcf_lines<W, true>), __VA_ARGS__); \
                                     else hipLaunchKernelGGL((k_vcf_lines<W, false>), __VA_ARGS__); } while (0)
     MSIM_VCF_LINES(false, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                   d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, (const unsigned long long *)nullptr, (char *)nullptr);
+                   d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, (const unsigned long long *)nullptr, (char *)nullptr, 0u);
     hipLaunchKernelGGL(k_len_reduce, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums);
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, d_sums, nb, c->h_mail);
     hipLaunchKernelGGL(k_len_offsets, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums, d_off);
@@ -707,8 +914,15 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     if (rc) return rc;
     if (total) {
         MSIM_VCF_LINES(true, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
-                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf));
+                       d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf),
+                       getenv("MSIM_DBG_VCF_PLAIN") ? 1u : 0u);      // (test hook: the plain path of waves the stage scheme cannot describe)
 #undef MSIM_VCF_LINES
+        // waves the stage scheme cannot describe (vcf_wave_is_plain): only a text of 4 GiB and more can hold one
+        const uint32_t plain = getenv("MSIM_DBG_VCF_PLAIN") ? 1u : 0u;
+        const bool far = (((uintptr_t)(in + g.len) | (uintptr_t)(pool + (1ull << 32))) >> 48) != 0;
+        if (!g.all_snp && (plain || far || total >= (1ull << 32) - 16))
+            hipLaunchKernelGGL(k_vcf_plain, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len, d_name,
+                               (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf), plain);
         MSIM_HIP(c, hipGetLastError());
     }
     if (own) c->text_len = total;

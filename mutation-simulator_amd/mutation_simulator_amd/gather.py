@@ -60,15 +60,22 @@ class Communicator:
         has applied the contig; the others learn them over the control plane (in compatible mode a rank only walks the stream
         chain through contigs it does not own -- msim_plan_chain leaves no table --, in fast mode it skips them altogether)."""
         owner = owners_of(parts, len(contig_ids))
-        mine = {i: self.eng.result_sizes(cid) for i, cid in enumerate(contig_ids) if owner[i] == self.rank}
-        every = [mine]
+        n = len(contig_ids)
         if self.world > 1:
-            every = [None] * self.world
-            self.dist.all_gather_object(every, mine)
-        lens, nrec, pool = [0] * len(contig_ids), [0] * len(contig_ids), [0] * len(contig_ids)
-        for d in every:
-            for i, (a, b, c) in d.items():
-                lens[i], nrec[i], pool[i] = int(a), int(b), int(c)
+            # one packed int64 tensor, summed over the ranks (every contig has exactly one owner): no pickling on the control
+            # plane inside a timed step (an all_gather_object of dicts was 0.3-1 ms per call)
+            import torch
+            t = torch.zeros(3 * n, dtype=torch.int64)
+            for i, cid in enumerate(contig_ids):
+                if owner[i] == self.rank:
+                    a, b, c = self.eng.result_sizes(cid)
+                    t[i], t[n + i], t[2 * n + i] = int(a), int(b), int(c)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            v = t.tolist()
+            return owner, v[:n], v[n:2 * n], v[2 * n:]
+        lens, nrec, pool = [0] * n, [0] * n, [0] * n
+        for i, cid in enumerate(contig_ids):
+            lens[i], nrec[i], pool[i] = (int(x) for x in self.eng.result_sizes(cid))
         return owner, lens, nrec, pool
 
     def gather_to_root(self, contig_ids, parts, root: int = 0, records: bool = True):

@@ -68,15 +68,30 @@ class ITMutator:
         self._assign_partners(self._available())
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
     def close(self):
-        for w in (getattr(self, "_fasta_writer", None), getattr(self, "_bedpe_writer", None)):
-            if w is not None:
-                w.close()
+        # what the pass queued for the Fasta (libmsim's output channel) is joined BEFORE the writers close -- also when mutate()
+        # raised half-way: a write that failed (ENOSPC ...) is reported, after the teardown, like Mutator.close() does
         eng, self._eng = getattr(self, "_eng", None), None
-        if eng is not None:
-            eng.close()
+        pending = None
+        if eng is not None and getattr(eng, "h", None):
+            try:
+                eng.file_wait()
+            except Exception as e:  # noqa: BLE001
+                pending = e
+        try:
+            for w in (getattr(self, "_fasta_writer", None), getattr(self, "_bedpe_writer", None)):
+                if w is not None:
+                    w.close()
+        finally:
+            if eng is not None:
+                eng.close()
+        if pending is not None:
+            raise pending
 
     # ------------------------------------------------------------------ who with whom (it_mutator.py:50-83)
     def _available(self) -> list:

@@ -163,12 +163,14 @@ def _range_triples(chrom):
     range list in the form ``msim_build_ranges`` takes.  Walking 35 000 ``RangeDefinition`` objects is 20 ms of interpreter
     time per genome, so the arrays are made once per settings tree and kept on the chromosome object (a list that is replaced
     or changes its length is walked again; ranges edited IN PLACE after their first use are not noticed -- nothing in the
-    product does that).  The settings' VALUES are read on every call."""
+    product does that).  The cache holds the list itself, so its identity cannot be reused by a later list; the grouping of the
+    ranges BY SETTINGS VALUE is fixed at the first use, the values themselves (rates, lengths) are read on every call
+    (``_settings_descs``) -- settings objects edited in place so that two of them stop being equal are not noticed either."""
     rds = chrom.range_definitions
-    stamp = (id(rds), len(rds))
     cached = getattr(chrom, "_msim_triples", None)
-    if cached is not None and cached[0] == stamp:
+    if cached is not None and cached[0][0] is rds and cached[0][1] == len(rds):
         return cached[1:]
+    stamp = (rds, len(rds))
     keep = [rd for rd in rds if rd.mutation_settings.has_mutations]
     n = len(keep)
     start = np.fromiter((rd.start for rd in keep), dtype=np.int64, count=n)

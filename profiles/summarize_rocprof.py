@@ -41,7 +41,9 @@ def text(db, wall_line=""):
     its total duration.  Sizes come from the run's own output line ("CLI wall ... outputs: out_ms.fa N MB, out_ms.vcf M MB")
     and the input size (--mb): k_gather reads the FASTA body text and writes the bases, k_frame reads the mutated bases and
     writes the wrapped body, k_vcf_lines<true> reads 16-byte records + REF/ALT sources (~ the text it writes) and writes the
-    VCF text, k_vcf_lines<false> (line lengths) reads the same sources without writing text."""
+    VCF text.  k_vcf_lines<false> (line lengths): up to round 4 it read the same sources without writing; since round 5 it
+    reads the record, one base per SNP and the ends of an inversion only -- its line keeps round 4's NOMINAL accounting (the
+    text's size) so that rounds compare, and says so."""
     import re
     stats(db)
     m = re.search(r"out_ms\.fa (\d+) MB, out_ms\.vcf (\d+) MB", wall_line)
@@ -54,7 +56,8 @@ def text(db, wall_line=""):
     for pat, mb, what in (("%k_gather%", fa_mb + bases_mb, "file text in, bases out"),
                           ("%k_frame%", bases_mb + fa_mb, "mutated bases in, wrapped text out"),
                           ("%k_vcf_lines<true%", 2.0 * vcf_mb, "records + REF/ALT sources in (~ text size), text out"),
-                          ("%k_vcf_lines<false%", vcf_mb, "records + REF/ALT sources in (line lengths only)")):
+                          ("%k_vcf_lines<false%", vcf_mb, "line lengths only; NOMINAL bytes = the text's size (round 4's accounting: it "
+                                                          "read the REF/ALT sources; now 16-byte records + one base per SNP)")):
         row = c.execute("select sum(total_calls), sum(total_duration) from top_kernels where name like ?", (pat,)).fetchone()
         if row and row[1]:
             print(f"{pat.strip('%'):24s} calls={int(row[0]):4d} total_us={row[1]:10.1f} {mb:9.1f} MB -> {mb * 1e6 / (row[1] * 1e-6) / 1e9:8.1f} GB/s  ({what})")

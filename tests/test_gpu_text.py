@@ -60,9 +60,14 @@ def test_vcf_device_equals_host_renderer(L, rate, seed, deco):
 
 @pytest.mark.parametrize("lens,seed", [({2: (200, 900), 3: (250, 1500), 4: (256, 700), 5: (300, 1100), 6: (260, 2000)}, 21),
                                        ({2: (20, 300), 3: (24, 26), 4: (25, 257), 5: (1, 600), 6: (23, 258)}, 22)])
-def test_vcf_device_long_records_take_the_wave_path(lens, seed):
-    """REF / ALT of hundreds of bases: the wave-cooperative sink with its 4-bytes-per-lane copies (raw, converted, reverse-
-    complemented) and the byte tail; the second mix straddles the lane / wave threshold."""
+@pytest.mark.parametrize("plain", [False, True], ids=["stage", "plain"])
+def test_vcf_device_long_records_take_the_wave_path(lens, seed, plain, monkeypatch):
+    """REF / ALT of hundreds of bases: their aligned interiors are copied source -> text by the whole wave, 16 bytes per lane
+    (raw, converted, reverse-complemented), their edges and the short copies go through the wave's LDS stage, which the flush
+    shifts by the gaps; the second mix straddles the inline threshold.  plain: the byte-by-byte path of waves the stage scheme
+    cannot describe (4 GiB of text in one wave's 64 lines), forced by the test hook."""
+    if plain:
+        monkeypatch.setenv("MSIM_DBG_VCF_PLAIN", "1")
     L = 2_000_000
     bases = decorate(random_bases(L, seed), seed + 1, n_runs=4, iupac=300, lower=0)
     bases[bases == ord("U")] = ord("A")
