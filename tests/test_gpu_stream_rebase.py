@@ -28,7 +28,7 @@ pytestmark = pytest.mark.gpu
     ("c2", "contigs_snp", 4, 10, 3_000_000, 5_000_000),            # 40 Mb of -sn 0.01 -titv 2.0: the SNP sampler
     ("c3", "contigs_svmix", 3, 12, 2_000_000, 4_000_000),           # the SV mix: boundary windows, insert pool (NumPy stream)
     ("c4", "contigs_hostcut", 3, 12, 4_000_000, 6_000_000),        # RMT gene blocks: one window per contig, host cuts
-    ("c4sv", "contigs_hostchain", 3, 12, 4_000_000, 6_000_000),    # RMT + SV std line: samples + chains in one window
+    ("c4sv", "contigs_hostchain", 4, 14, 4_000_000, 6_000_000),    # RMT + SV std line: samples + chains in one window
 ])
 def test_small_span_rebases_vs_oracle(workload, engine, chunks, n, lo, hi, monkeypatch):
     """Every device engine across >= 3 re-bases, in the bench's order (nothing read between contigs): Fasta body + VCF text of
