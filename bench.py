@@ -178,15 +178,15 @@ WORKLOADS = {
     "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp_b",   # (two contigs per launch)
            "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01"},
     "c3": {"mode": "ARGS", "what": "full SV mix (BASELINE configs[2]): -sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500",
-           "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},
+           "kernel": "msim::k_rewrite_b<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},   # (pairs)
     "c4": {"mode": "RMT", "what": "RMT mode, gene-blocking file with hot/cold spots (BASELINE configs[3])",
-           "kernel": "msim::k_rewrite_snp", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT hot/cold/blocked ranges"},
+           "kernel": "msim::k_rewrite_snp_b", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT hot/cold/blocked ranges"},
     "c4sv": {"mode": "RMT", "what": "RMT mode, the configs[3] gene-blocking file with the configs[2] SV mix as its std line "
                                     "(every gap between two blocked genes draws SN/IN/DE/DU/IV; hot/cold ranges keep their own settings)",
-             "kernel": "msim::k_rewrite<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT gene blocks + SV std line"},
+             "kernel": "msim::k_rewrite_b<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT gene blocks + SV std line"},
     "readme": {"mode": "ARGS", "what": "the reference README's benchmark flags: -sn -in -de -du -iv -tl 0.01 each, default lengths "
                                        "(180 M candidates per 3 Gb, translocations linked per contig)",
-               "kernel": "msim::k_rewrite<140|1024>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS every type at 0.01"},
+               "kernel": "msim::k_rewrite_b<140|1024>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS every type at 0.01"},
 }
 
 

@@ -1099,8 +1099,10 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         Contig &g = c->contigs[(size_t)id];
         const uint32_t *dyn = g.d_dyn;
         const uint32_t n = (uint32_t)(dyn ? g.n_rec_cap : g.n_rec);
-        const uint64_t out_bound = g.all_snp ? g.len : (dyn ? g.out_cap_len : 0);
-        // (only what the engine plans itself: a device-sized table or an SNP-only one, on the batch's stream, not in flight)
+        const uint64_t out_bound = g.all_snp ? g.len : dyn ? g.out_cap_len
+                                   : (g.off_ready && g.delta_known) ? (uint64_t)((long long)g.len + g.known_delta) : 0;
+        // (only what a device engine planned: a device-sized table, an SNP-only one, or one that came with its offsets and its
+        //  length -- the host-chain engines' --, on the batch's stream, not in flight)
         if (!g.apply_stream || !n || !out_bound || g.apply_pending || (st && g.apply_stream != st)) continue;
         st = g.apply_stream;
         const uint32_t n_tiles = (uint32_t)((out_bound + TILE - 1) / TILE);

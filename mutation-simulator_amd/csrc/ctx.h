@@ -84,6 +84,9 @@ struct Ctx {
     bool have_params = false;
     std::vector<Contig> contigs;
     int deferred_apply = -1;              // contig whose APPLY msim_apply_contig deferred (msim_api.hip), -1: none
+    int deferred_prev = -1;               //   ... and the one deferred before it: host-chain contigs are applied in PAIRS (one
+                                          //   tile-index launch, one rewrite launch: a 60 us kernel's ramp, tail and the gap to
+                                          //   the next launch are a tenth of it); only_pairs leaves a single one waiting
     uint64_t fast_key = 0x9E3779B97F4A7C15ull;   // MSIM_RNG_FAST: Philox key (msim_set_fast_key) ...
     uint32_t fast_seq = 0;                //   ... and the ordinal of the next contig planned or walked past
     FastPlan *fast = nullptr;             //   ... and the engine's streams + scratch (plan_fast.hip)
@@ -127,7 +130,7 @@ int hip_fail(Ctx *c, hipError_t e, const char *what);
 
 // msim_api.hip: enqueue the APPLY that msim_apply_contig deferred, if any (the engines with a host chain call it when
 // their chain starts)
-int flush_deferred_apply(Ctx *c);
+int flush_deferred_apply(Ctx *c, bool only_pairs = false);
 
 // plan_host.cpp
 struct HostPlan {

@@ -72,12 +72,25 @@ static int drain(Ctx *c) {
     MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
     return MSIM_OK;
 }
-int flush_deferred_apply(Ctx *c) {
+// The APPLYs msim_apply_contig deferred.  only_pairs (the engines' flush point at the start of a host walk): a single waiting
+// contig keeps waiting for its successor -- two go out together through apply_batch_device.
+int flush_deferred_apply(Ctx *c, bool only_pairs) {
     if (c->deferred_apply < 0) return MSIM_OK;
-    const int idx = c->deferred_apply;
-    c->deferred_apply = -1;
-    if (idx >= (int)c->contigs.size()) return MSIM_OK;
-    return apply_contig_device(c, c->contigs[(size_t)idx]);
+    static const bool no_pairs = getenv("MSIM_NO_DEFER_PAIRS") != nullptr;
+    if (only_pairs && c->deferred_prev < 0 && !no_pairs) return MSIM_OK;
+    std::vector<int> ids;
+    for (int idx : {c->deferred_prev, c->deferred_apply})
+        if (idx >= 0 && idx < (int)c->contigs.size()) ids.push_back(idx);
+    c->deferred_apply = c->deferred_prev = -1;
+    if (ids.size() == 2) {
+        for (int idx : ids) c->contigs[(size_t)idx].apply_stream = c->emit_stream;   // (apply_batch_device: contigs with a stream of their own)
+        return apply_batch_device(c, ids, true);
+    }
+    for (int idx : ids) {
+        const int rc = apply_contig_device(c, c->contigs[(size_t)idx]);
+        if (rc) return rc;
+    }
+    return MSIM_OK;
 }
 static int key_error_of(Ctx *c, Contig &g) {
     g.key_reported = true;
@@ -273,7 +286,7 @@ static Ctx *C(msim_ctx *p) { return reinterpret_cast<Ctx *>(p); }
 void msim_destroy(msim_ctx *p) {
     if (!p) return;
     CtxFull *c = static_cast<CtxFull *>(C(p));
-    c->deferred_apply = -1;                                // nobody will ask for its result
+    c->deferred_apply = c->deferred_prev = -1;             // nobody will ask for its result
     if (c->host_only) { file_io_destroy(c); batch_free(c); delete c; return; }
     static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
     auto tp = std::chrono::steady_clock::now();
@@ -497,7 +510,7 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
     // latency-bound chain kernels.  Every other route enqueues it now.
     if (c->gpu && (!gpu_ok || gpu_emit_pending(c, contig, false)) && (rc = gpu_emit_flush(c))) return rc;   // (another engine / planned again)
     const bool host_chain = mixed_ok || hs_ok || mm_ok;
-    const bool engine_flushes = host_chain && c->deferred_apply != contig;
+    const bool engine_flushes = host_chain && c->deferred_apply != contig && c->deferred_prev != contig;
     if (!engine_flushes && (rc = flush_deferred_apply(c))) return rc;
     reset_contig(*g);
     c->text_kind = 0;
@@ -521,7 +534,8 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
         static const int force_at = getenv("MSIM_DBG_FORCE_OVERFLOW") ? atoi(getenv("MSIM_DBG_FORCE_OVERFLOW")) : 0;
         static int device_plans = 0;
         if (!rc && force_at && ++device_plans == force_at) rc = gpu_plan_force_overflow(c, c->gpu);
-        const int frc = flush_deferred_apply(c);           // (an engine that returned early never reached its flush point)
+        const int frc = flush_deferred_apply(c, rc == MSIM_OK);   // (an engine that failed never reached its flush point; a single
+                                                                   //  contig left waiting by design stays for its successor)
         g->defer_apply = !rc && host_chain && !c->chain_only;
         if (c->chain_only) g->planned = false;              // nothing to apply or fetch
         return rc ? rc : frc;
@@ -613,13 +627,15 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     if (c->fast && fast_plan_queued(c, contig, true)) return MSIM_OK;
     // SNP sampler: a contig whose emission still waits for its group is applied right behind that group (plan_gpu.hip)
     if (c->gpu && gpu_emit_pending(c, contig, true)) return MSIM_OK;
-    {
-        int rc = flush_deferred_apply(c);
+    Contig *g = get_contig(c, contig);
+    if (!g) return MSIM_ERR_ARG;
+    static const bool no_defer = getenv("MSIM_NO_DEFER") != nullptr;
+    const bool defer = g->planned && g->defer_apply && !no_defer && !c->host_only;
+    {   // (a contig that will wait itself pairs up with the one already waiting; anything else sends what waits first)
+        int rc = (defer && c->deferred_prev < 0 && c->deferred_apply != contig) ? MSIM_OK : flush_deferred_apply(c);
         if (!rc && c->fast) rc = fast_plan_flush(c);
         if (rc) return rc;
     }
-    Contig *g = get_contig(c, contig);
-    if (!g) return MSIM_ERR_ARG;
     NEED_GPU(c);
     if (!g->planned) return fail(c, MSIM_ERR_ARG, "msim_apply_contig before msim_plan_contig");
     TraceRange tr("msim APPLY contig");
@@ -627,8 +643,8 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     // Contigs of the engines with a host chain: the next contig's plan starts with latency-bound device kernels and
     // then leaves the device idle for a millisecond while the host walks -- that is where this APPLY belongs.  It is
     // enqueued by the next entry point, whichever it is (the next plan at the start of its host chain).
-    static const bool no_defer = getenv("MSIM_NO_DEFER") != nullptr;
-    if (g->defer_apply && !no_defer) {
+    if (defer) {
+        c->deferred_prev = c->deferred_apply;              // (-1, or the contig this one pairs up with)
         c->deferred_apply = contig;
         return MSIM_OK;
     }

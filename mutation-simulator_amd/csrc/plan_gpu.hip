@@ -1223,7 +1223,7 @@ static int span_close(Ctx *c, GpuPlan *g) {
 // with k_accept_tables and the D2H copies of the window (c3: 1.54 -> 1.92 ms of rewrite kernel per step).
 static int flush_deferred_apply_behind(Ctx *c, hipEvent_t last_copy) {
     if (c->deferred_apply >= 0) MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, last_copy, 0));
-    return flush_deferred_apply(c);
+    return flush_deferred_apply(c, true);                  // (pairs: a single waiting contig stays for its successor)
 }
 
 // M.cnt: five u32 counter arrays of nbk + 2 entries, then (8-byte aligned) one 64-bit array of the same length
@@ -1580,7 +1580,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             MSIM_HIP(c, hipGetLastError());
             MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, words_bytes, hipMemcpyDeviceToHost, c->stream));
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-            if ((rc = flush_deferred_apply(c))) return rc;
+            if ((rc = flush_deferred_apply(c, true))) return rc;
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
             MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
             if ((rc = span_close(c, g))) return rc;
