@@ -232,7 +232,8 @@ int msim_build_ranges(const msim_settings_desc *sets, int n_sets, const int64_t 
  * internal window overflow) are reported by the next call that synchronises: msim_sync,
  * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats, the text calls.
  * Enqueued does not mean launched at once: contigs the SNP sampler planned from ONE drawing range (ARGS mode) gather in groups
- * of three whose emission stages and tile index go to the device as one launch each, their rewrite kernels behind them --
+ * (pairs by default) whose emission stages, tile index and rewrite go to the device as one launch each; the APPLYs of contigs
+ * planned by an engine with a host chain wait for the walks of the contigs behind them and go out three at a time --
  * when the next msim_plan_contig arrives or at any other entry point, whichever comes first (plan + apply a whole genome,
  * then ask: that is the fast order; asking after every contig is as correct and launches per contig).                  */
 int msim_apply_contig(msim_ctx *ctx, int contig);

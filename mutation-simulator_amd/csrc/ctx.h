@@ -83,10 +83,10 @@ struct Ctx {
     msim_params params{};
     bool have_params = false;
     std::vector<Contig> contigs;
-    int deferred_apply = -1;              // contig whose APPLY msim_apply_contig deferred (msim_api.hip), -1: none
-    int deferred_prev = -1;               //   ... and the one deferred before it: host-chain contigs are applied in PAIRS (one
-                                          //   tile-index launch, one rewrite launch: a 60 us kernel's ramp, tail and the gap to
-                                          //   the next launch are a tenth of it); only_pairs leaves a single one waiting
+    int deferred_apply = -1;              // the contig whose APPLY msim_apply_contig deferred last (msim_api.hip), -1: none
+    int deferred_more[3] = {-1, -1, -1};  //   ... and those deferred before it, oldest first: host-chain contigs are applied in
+    int n_deferred_more = 0;              //   GROUPS (one tile-index launch, one rewrite launch: a 60 us kernel's ramp, tail and
+                                          //   the gap to the next launch are a tenth of it); only_groups leaves an incomplete one waiting
     uint64_t fast_key = 0x9E3779B97F4A7C15ull;   // MSIM_RNG_FAST: Philox key (msim_set_fast_key) ...
     uint32_t fast_seq = 0;                //   ... and the ordinal of the next contig planned or walked past
     FastPlan *fast = nullptr;             //   ... and the engine's streams + scratch (plan_fast.hip)
@@ -130,7 +130,8 @@ int hip_fail(Ctx *c, hipError_t e, const char *what);
 
 // msim_api.hip: enqueue the APPLY that msim_apply_contig deferred, if any (the engines with a host chain call it when
 // their chain starts)
-int flush_deferred_apply(Ctx *c, bool only_pairs = false);
+int flush_deferred_apply(Ctx *c, bool only_groups = false);
+bool deferred_apply_holds(const Ctx *c, int contig);
 
 // plan_host.cpp
 struct HostPlan {

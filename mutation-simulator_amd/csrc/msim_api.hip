@@ -72,17 +72,27 @@ static int drain(Ctx *c) {
     MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
     return MSIM_OK;
 }
-// The APPLYs msim_apply_contig deferred.  only_pairs (the engines' flush point at the start of a host walk): a single waiting
-// contig keeps waiting for its successor -- two go out together through apply_batch_device.
-int flush_deferred_apply(Ctx *c, bool only_pairs) {
+// The APPLYs msim_apply_contig deferred.  only_groups (the engines' flush point at the start of a host walk): an incomplete group
+// keeps waiting for its successors -- a full one goes out together through apply_batch_device.
+static int defer_group_size() {
+    static const int n = getenv("MSIM_NO_DEFER_PAIRS") ? 1 : getenv("MSIM_DEFER_GROUP") ? std::min(4, std::max(1, atoi(getenv("MSIM_DEFER_GROUP")))) : 3;
+    return n;
+}
+bool deferred_apply_holds(const Ctx *c, int contig) {
+    if (c->deferred_apply == contig) return contig >= 0;
+    for (int q = 0; q < c->n_deferred_more; q++) if (c->deferred_more[q] == contig) return true;
+    return false;
+}
+int flush_deferred_apply(Ctx *c, bool only_groups) {
     if (c->deferred_apply < 0) return MSIM_OK;
-    static const bool no_pairs = getenv("MSIM_NO_DEFER_PAIRS") != nullptr;
-    if (only_pairs && c->deferred_prev < 0 && !no_pairs) return MSIM_OK;
+    if (only_groups && c->n_deferred_more + 1 < defer_group_size()) return MSIM_OK;
     std::vector<int> ids;
-    for (int idx : {c->deferred_prev, c->deferred_apply})
-        if (idx >= 0 && idx < (int)c->contigs.size()) ids.push_back(idx);
-    c->deferred_apply = c->deferred_prev = -1;
-    if (ids.size() == 2) {
+    for (int q = 0; q < c->n_deferred_more; q++) ids.push_back(c->deferred_more[q]);
+    ids.push_back(c->deferred_apply);
+    c->deferred_apply = -1;
+    c->n_deferred_more = 0;
+    ids.erase(std::remove_if(ids.begin(), ids.end(), [&](int idx) { return idx < 0 || idx >= (int)c->contigs.size(); }), ids.end());
+    if (ids.size() >= 2) {
         for (int idx : ids) c->contigs[(size_t)idx].apply_stream = c->emit_stream;   // (apply_batch_device: contigs with a stream of their own)
         return apply_batch_device(c, ids, true);
     }
@@ -286,7 +296,8 @@ static Ctx *C(msim_ctx *p) { return reinterpret_cast<Ctx *>(p); }
 void msim_destroy(msim_ctx *p) {
     if (!p) return;
     CtxFull *c = static_cast<CtxFull *>(C(p));
-    c->deferred_apply = c->deferred_prev = -1;             // nobody will ask for its result
+    c->deferred_apply = -1;                                // nobody will ask for their results
+    c->n_deferred_more = 0;
     if (c->host_only) { file_io_destroy(c); batch_free(c); delete c; return; }
     static const bool prof = getenv("MSIM_BATCH_PROF") != nullptr;
     auto tp = std::chrono::steady_clock::now();
@@ -510,7 +521,7 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
     // latency-bound chain kernels.  Every other route enqueues it now.
     if (c->gpu && (!gpu_ok || gpu_emit_pending(c, contig, false)) && (rc = gpu_emit_flush(c))) return rc;   // (another engine / planned again)
     const bool host_chain = mixed_ok || hs_ok || mm_ok;
-    const bool engine_flushes = host_chain && c->deferred_apply != contig && c->deferred_prev != contig;
+    const bool engine_flushes = host_chain && !deferred_apply_holds(c, contig);
     if (!engine_flushes && (rc = flush_deferred_apply(c))) return rc;
     reset_contig(*g);
     c->text_kind = 0;
@@ -632,7 +643,7 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     static const bool no_defer = getenv("MSIM_NO_DEFER") != nullptr;
     const bool defer = g->planned && g->defer_apply && !no_defer && !c->host_only;
     {   // (a contig that will wait itself pairs up with the one already waiting; anything else sends what waits first)
-        int rc = (defer && c->deferred_prev < 0 && c->deferred_apply != contig) ? MSIM_OK : flush_deferred_apply(c);
+        int rc = (defer && c->n_deferred_more + 1 < defer_group_size() && !deferred_apply_holds(c, contig)) ? MSIM_OK : flush_deferred_apply(c);
         if (!rc && c->fast) rc = fast_plan_flush(c);
         if (rc) return rc;
     }
@@ -644,7 +655,7 @@ int msim_apply_contig(msim_ctx *p, int contig) {
     // then leaves the device idle for a millisecond while the host walks -- that is where this APPLY belongs.  It is
     // enqueued by the next entry point, whichever it is (the next plan at the start of its host chain).
     if (defer) {
-        c->deferred_prev = c->deferred_apply;              // (-1, or the contig this one pairs up with)
+        if (c->deferred_apply >= 0) c->deferred_more[c->n_deferred_more++] = c->deferred_apply;   // (the group this one joins)
         c->deferred_apply = contig;
         return MSIM_OK;
     }

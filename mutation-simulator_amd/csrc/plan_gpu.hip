@@ -1223,7 +1223,7 @@ static int span_close(Ctx *c, GpuPlan *g) {
 // with k_accept_tables and the D2H copies of the window (c3: 1.54 -> 1.92 ms of rewrite kernel per step).
 static int flush_deferred_apply_behind(Ctx *c, hipEvent_t last_copy) {
     if (c->deferred_apply >= 0) MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, last_copy, 0));
-    return flush_deferred_apply(c, true);                  // (pairs: a single waiting contig stays for its successor)
+    return flush_deferred_apply(c, true);                  // (groups: an incomplete one stays for its successors)
 }
 
 // M.cnt: five u32 counter arrays of nbk + 2 entries, then (8-byte aligned) one 64-bit array of the same length

@@ -106,9 +106,9 @@ def test_config2_bench_order_full_genome_vs_oracle():
                                               ("c4sv", {"contigs_hostchain": 24})])
 def test_secondary_workloads_bench_order_full_genome_vs_oracle(workload, engines):
     """The secondary lines of the bench (configs[2], configs[3] and the RMT + SV shape) in the bench's order: every APPLY of
-    these engines is deferred into a later contig's host walk and goes out in PAIRS (one tile-index launch, one
-    ``k_rewrite_b<140>`` / ``k_rewrite_snp_b`` launch for two contigs), the last pair flushed by the synchronisation."""
-    _bench_order_vs_oracle(workload, bench.contig_lengths(3_000_000_000), engines, launches=12)
+    these engines is deferred into a later contig's host walk and goes out in GROUPS OF THREE (one tile-index launch, one
+    ``k_rewrite_b<140>`` / ``k_rewrite_snp_b`` launch for three contigs), the last group flushed by the synchronisation."""
+    _bench_order_vs_oracle(workload, bench.contig_lengths(3_000_000_000), engines, launches=8)
 
 
 @pytest.mark.parametrize("group", [1, 2, 3, 4])

@@ -674,7 +674,7 @@ def test_five_and_eight_randint_classes_vs_host():
 @pytest.mark.parametrize("n_contigs", [1, 3, 7, 8])
 def test_plan_and_apply_a_whole_genome_then_ask_equals_contig_by_contig(n_contigs):
     """The fast order of the C-ABI -- plan + apply every contig, only then read -- lets the SNP sampler gather emission and
-    APPLY in groups (gpu_emit_flush: one launch per stage for three contigs, the last group partial, flushed by the first
+    APPLY in groups (gpu_emit_flush: one launch per stage for a pair of contigs, the last group partial, flushed by the first
     reader).  Records, insert-free mutated streams and both stream positions must equal the contig-by-contig order through
     the sequential host planner."""
     import hashlib
