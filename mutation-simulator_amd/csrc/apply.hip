@@ -420,20 +420,14 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS, CAP> &A, in
     // record: segment, copy run) owns the bytes from the piece start to the end of its 16-B group.  All sources
     // are resolved first (LDS searches), then ALL loads are issued together -- the fix-up loads do not wait for
     // a second HBM round trip behind a barrier.
-    PieceSrc src[ITERS];
-    uint32_t patch[ITERS];                               // SNP on the group's first byte: mj | pos handled below
-    uint32_t ppos[ITERS];
-    bool live[ITERS];
-#pragma unroll
+    // (This is the rare path -- a tile with more structural records than the LDS window holds: one group at a time, no arrays of
+    //  sources and loads in flight.  Unrolled four-fold like the LDS path it needed 47 spilled registers, and a kernel with ANY
+    //  scratch pays for it at every dispatch -- the queue's scratch is set up before the launch.)
+#pragma unroll 1
     for (int it = 0; it < ITERS; it++) {
         const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
         const uint32_t O = tile0 + g;
-        live[it] = O < tile_end;
-        patch[it] = 0;
-        ppos[it] = 0;
-        src[it].ptr = in;
-        src[it].mode = 0;
-        if (!live[it]) continue;
+        if (O >= tile_end) continue;
         int32_t j = r_lo - 1;
         if (any_rec) {
             int32_t lo = r_lo, hi = r_hi + 1;
@@ -448,11 +442,15 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS, CAP> &A, in
         if (has) A.all(j, oj, ej, sj, mj);
         const bool in_seg = has && O < ej;
         if (in_seg) xj = A.ext(j);
-        src[it] = piece_src(O, has, in_seg, oj, ej, sj, mj, xj, in, pool);
-        if (!in_seg && has && (mj & 0xff) == MSIM_SN && oj == O) { patch[it] = mj | 0x80000000u; ppos[it] = sj; }
+        const PieceSrc ps = piece_src(O, has, in_seg, oj, ej, sj, mj, xj, in, pool);
+        u32x4 pv = piece_finish(piece_load(ps), ps.mode, lut);
+        if (!in_seg && has && (mj & 0xff) == MSIM_SN && oj == O)        // the group starts on an SNP byte
+            pv.x = (pv.x & ~0xffu) | snp_patch(pv.x & 0xff, mj, sj, lut, err);
+        *reinterpret_cast<u32x4 *>(tile + g) = pv;
     }
-    // (B) fix-up pieces owned by this lane: FIX per pass over the piece list (one pass unless the tile is dense)
-    constexpr int FIX = 2;
+    __syncthreads();
+    // (B) fix-up pieces: one lane per PIECE (2 per record: segment, copy run) owns the bytes from the piece start to the end
+    // of its 16-B group and overwrites them
     struct Fix { PieceSrc ps; uint32_t p, end, mj, sj; bool on; };
     auto resolve_fix = [&](int32_t q2, Fix &f) {
         f.on = false;
@@ -494,29 +492,8 @@ __device__ __forceinline__ void rewrite_tile(const RecAccess<IN_LDS, CAP> &A, in
         }
         fix_bytes(tile, tile0, f.p, f.end, pv, pidx, pval);
     };
-    Fix fx[FIX];
-#pragma unroll
-    for (int u = 0; u < FIX; u++) resolve_fix((int32_t)threadIdx.x + u * THREADS, fx[u]);
-    // ---- all loads in flight together
-    Raw5 raw[ITERS], fraw[FIX];
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) raw[it] = piece_load(src[it]);
-#pragma unroll
-    for (int u = 0; u < FIX; u++) fraw[u] = piece_load(fx[u].ps);
-#pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        if (!live[it]) continue;
-        const uint32_t g = it * (THREADS * GROUP) + threadIdx.x * GROUP;
-        u32x4 pv = piece_finish(raw[it], src[it].mode, lut);
-        if (patch[it])                                   // the group starts on an SNP byte
-            pv.x = (pv.x & ~0xffu) | snp_patch(pv.x & 0xff, patch[it] & 0x7fffffffu, ppos[it], lut, err);
-        *reinterpret_cast<u32x4 *>(tile + g) = pv;
-    }
-    __syncthreads();
-    // ---- pass B: piece starts inside a group overwrite the bytes up to the group's end
-#pragma unroll
-    for (int u = 0; u < FIX; u++) apply_fix(fx[u], fraw[u]);
-    for (int32_t q2 = (int32_t)threadIdx.x + FIX * THREADS; q2 < 2 * cnt; q2 += THREADS) {   // dense tiles
+#pragma unroll 1
+    for (int32_t q2 = (int32_t)threadIdx.x; q2 < 2 * cnt; q2 += THREADS) {
         Fix f;
         resolve_fix(q2, f);
         if (f.on) apply_fix(f, piece_load(f.ps));
