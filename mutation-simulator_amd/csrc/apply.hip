@@ -973,22 +973,8 @@ int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum) {
 // LUT upload lives with the ctx (msim_api.hip); declared here
 extern uint8_t *ctx_lut(Ctx *c);
 
-int apply_finish(Ctx *c) {
-    {   // sizes the counter-based engine left on the device (synchronises its streams; no-op when nothing is pending)
-        const int rc = fast_plan_collect(c);
-        if (rc) { c->pending_apply.clear(); for (auto &g : c->contigs) g.apply_pending = g.dyn_applied = false; return rc; }
-    }
-    if (c->pending_apply.empty()) return MSIM_OK;
-    {   // APPLYs that ran on a stream of their own (counter-based engine)
-        hipStream_t last = nullptr;
-        for (int idx : c->pending_apply) {
-            if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
-            hipStream_t s = c->contigs[(size_t)idx].apply_stream;
-            if (s && s != last) { MSIM_HIP(c, hipStreamSynchronize(s)); last = s; }
-        }
-    }
-    // KeyError words + length-check words of every contig: two asynchronous copies into pinned memory behind the
-    // APPLY work, one synchronisation (two blocking hipMemcpy cost ~40 us each at every step boundary)
+// KeyError words + length-check words of every contig: two asynchronous copies into pinned memory on the emit stream
+static int enqueue_err_copies(Ctx *c) {
     const size_t nc = c->contigs.size();
     if (c->cap_h_errs < 2 * nc) {
         if (c->h_errs) MSIM_HIP(c, hipHostFree(c->h_errs));
@@ -996,10 +982,37 @@ int apply_finish(Ctx *c) {
         MSIM_HIP(c, hipHostMalloc(&c->h_errs, (2 * nc + 64) * sizeof(unsigned long long), hipHostMallocDefault));
         c->cap_h_errs = 2 * nc + 64;
     }
+    MSIM_HIP(c, hipMemcpyAsync(c->h_errs, c->d_errs, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->emit_stream));
+    MSIM_HIP(c, hipMemcpyAsync(c->h_errs + nc, c->d_errs + MAX_CONTIGS, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->emit_stream));
+    return MSIM_OK;
+}
+
+int apply_finish(Ctx *c) {
+    bool have_errs = false;
+    {   // sizes the counter-based engine left on the device (synchronises its streams; no-op when nothing is pending).  The
+        // KeyError words ride behind its lanes' work, under the same host wait.
+        int state = 0;
+        const bool ride = c->fast && !c->pending_apply.empty();
+        const int rc = fast_plan_collect(c, ride ? enqueue_err_copies : nullptr, &state);
+        if (rc) { c->pending_apply.clear(); for (auto &g : c->contigs) g.apply_pending = g.dyn_applied = false; return rc; }
+        have_errs = state == 1;
+    }
+    if (c->pending_apply.empty()) return MSIM_OK;
+    {   // APPLYs that ran on a stream of their own (counter-based engine)
+        hipStream_t last = nullptr;
+        for (int idx : c->pending_apply) {
+            if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
+            hipStream_t s = c->contigs[(size_t)idx].apply_stream;
+            if (s && s != last && s != c->emit_stream) { MSIM_HIP(c, hipStreamSynchronize(s)); last = s; }
+        }
+    }
+    const size_t nc = c->contigs.size();
+    if (!have_errs) {                                      // (two blocking hipMemcpy cost ~40 us each at every step boundary)
+        const int rc = enqueue_err_copies(c);
+        if (rc) return rc;
+        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    }
     unsigned long long *errs = c->h_errs, *deltas = c->h_errs + nc;
-    MSIM_HIP(c, hipMemcpyAsync(errs, c->d_errs, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->emit_stream));
-    MSIM_HIP(c, hipMemcpyAsync(deltas, c->d_errs + MAX_CONTIGS, nc * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->emit_stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
     bool delta_mismatch = false;
     hipEvent_t origin = nullptr;
     std::vector<std::pair<float, float>> spans_all, spans_k;
@@ -1072,6 +1085,7 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         J.n_jobs = 0; J.total = 0;
     };
     std::vector<int> marked;
+    int batch_first = -1;
     for (int id : ids) {
         Contig &g = c->contigs[(size_t)id];
         const uint32_t *dyn = g.d_dyn;
@@ -1086,6 +1100,14 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, hipStreamSynchronize(st));
         int rc = dev_reserve(c, (void **)&g.d_first, &g.cap_first, (size_t)(n_tiles + 1) * sizeof(int32_t));
         if (rc) return rc;
+        if (!g.ea0) {
+            MSIM_HIP(c, hipEventCreate(&g.ea0));
+            MSIM_HIP(c, hipEventCreate(&g.ea1));
+            MSIM_HIP(c, hipEventCreate(&g.ea2));
+        }
+        // ONE start event for the batch (on its first contig, in front of the tile index): an event per contig is a packet per
+        // contig on the queue -- twelve of them stood between a batch's tile index and its rewrite launch, 50 us of an idle device
+        if (marked.empty()) { MSIM_HIP(c, hipEventRecord(g.ea0, st)); batch_first = id; }
         TileJob &T = J.j[J.n_jobs++];
         T.off = g.all_snp ? nullptr : g.d_off; T.recs = g.d_recs; T.dyn = dyn; T.first = g.d_first; T.err = c->d_errs + g.index;
         T.n = n; T.n_entries = n_tiles + 1; T.entry_base = J.total; T.rsv = 0;
@@ -1116,6 +1138,7 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         auto go = [&]() -> int {
             if (!R.n) return MSIM_OK;
             Contig &L = c->contigs[(size_t)leader];
+            if (leader != batch_first) MSIM_HIP(c, hipEventRecord(L.ea0, st));   // (a second kernel variant's launch: its own span)
             MSIM_HIP(c, hipEventRecord(L.ea1, st));
             if (variant == 0) hipLaunchKernelGGL(k_rewrite_snp_b, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
             else if (variant == 1) hipLaunchKernelGGL(k_rewrite_b<REC_CAP_SMALL>, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
@@ -1158,7 +1181,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
         if (rc) return rc;
     }
     unsigned long long *d_err = c->d_errs + g.index;
-    MSIM_HIP(c, hipEventRecord(g.ea0, st));
+    if (!(c->rw_collect && g.tile_index_done)) MSIM_HIP(c, hipEventRecord(g.ea0, st));   // (batched: apply_batch_device recorded the batch's)
     // ---- 1. output offsets (skipped for an SNP-only table: no length change, offset == position)
     long long total_delta = 0;
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;

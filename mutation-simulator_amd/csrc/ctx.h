@@ -258,7 +258,11 @@ int fast_plan_flush(Ctx *c);
 bool fast_plan_queued(Ctx *c, int contig, bool mark_apply);
 // everything the engine enqueued has completed (the caller synchronised): sticky flags, sizes of the contigs planned with
 // device-side counts.  Idempotent.
-int fast_plan_collect(Ctx *c);
+// behind (optional): device work of the caller's that belongs behind everything the lanes have in flight -- enqueued on the
+// emit stream once that stream waits for the lanes, so that ONE host wait covers both (apply_finish: the KeyError words).
+// *behind_state: 0 it did not run (nothing was pending), 1 it ran and what it copied is complete, 2 it ran, but a plan was
+// replayed (and applied again) afterwards -- stale
+int fast_plan_collect(Ctx *c, int (*behind)(Ctx *) = nullptr, int *behind_state = nullptr);
 // test support (msim_dbg_fast_plan): the engine restated sequentially on the host over the same arithmetic (fast_math.h)
 int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq, HostPlan &out);
 

@@ -322,8 +322,9 @@ int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges) 
 
 static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only);
 
-int fast_plan_collect(Ctx *c) {
+int fast_plan_collect(Ctx *c, int (*behind)(Ctx *), int *behind_state) {
     FastPlan *f = c->fast;
+    if (behind_state) *behind_state = 0;
     if (f && !f->queue.empty()) {
         const int rc = fast_plan_flush(c);
         if (rc) return rc;
@@ -356,8 +357,18 @@ int fast_plan_collect(Ctx *c) {
             MSIM_HIP(c, hipMemcpyAsync(f->h_flags + i, f->d_flags, sizeof(uint32_t), hipMemcpyDeviceToHost, f->lane[i]));
             MSIM_HIP(c, hipEventRecord(f->t1[i], f->lane[i]));
         }
-        for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+        // one host wait: the emit stream joins the lanes (their t1 events), takes the caller's copies, and is waited for --
+        // a hipStreamSynchronize per lane and another round trip for the caller's copies were ~100 us of every step boundary
+        for (int i = 0; i < F_SETS; i++)
+            if (f->set[i].pending) MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, f->t1[i], 0));
+        if (behind && round == 0) {
+            const int brc = behind(c);
+            if (brc) return brc;
+            if (behind_state) *behind_state = 1;
+        }
         MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        for (int i = 0; i < F_SETS; i++)                   // (done by now: the emit stream waited for them)
+            if (f->set[i].pending) MSIM_HIP(c, hipEventSynchronize(f->t1[i]));
         float ms = 0;
         for (int i = 0; i < F_SETS; i++) {                 // (first batch's start to the end of the lane that finished last)
             if (!f->set[i].pending) continue;
@@ -411,6 +422,7 @@ int fast_plan_collect(Ctx *c) {
             int rc = enqueue_batch(c, one, true);
             if (rc) return rc;
             f->replays++;
+            if (behind_state && *behind_state) *behind_state = 2;
             if (was_applied) {
                 g.apply_pending = false;                   // (its first APPLY has completed: everything was synchronised above)
                 g.dyn_applied = false;
