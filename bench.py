@@ -477,7 +477,7 @@ def roofline_of(st, workload, steps):
         source = ("measured during this run: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of "
                   f"`bench.py --workload {workload} --steps 1`, per launch of the kernel; FETCH_SIZE x 2 (gfx950) = {live['fetch_bytes_x2']} "
                   f"+ WRITE_SIZE {live['write_bytes']} bytes")
-    for name in (() if live is not None else ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
+    for name in (() if live is not None else ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
         tf = ROOT / "profiles" / name
         if tf.exists():
             try:
@@ -705,7 +705,7 @@ def main():
         }
         if world == 1:
             line["step_roofline"] = step_roofline(st, dt)
-    LIVE_PMC[0] = False                                 # (the secondary workloads: profiles/r04_traffic.json)
+    LIVE_PMC[0] = False                                 # (the secondary workloads: profiles/r05_traffic.json)
     gather_jobs = []                                    # (workload, its dict in the line): measured in the gather phase
 
     def sharded_numbers(dt_sharded, workload=None):
