@@ -344,8 +344,9 @@ __device__ __forceinline__ void vcf_emit(S &s, const VcfLine &d, const uint8_t *
 __device__ __forceinline__ bool vcf_wave_is_plain(unsigned long long first, unsigned long long end, const uint8_t *in, unsigned long long L,
                                                   const uint8_t *pool, uint32_t plain) {
     const unsigned long long top = (unsigned long long)(uintptr_t)(in + L) | (unsigned long long)(uintptr_t)(pool + (1ull << 32));
-    return end - first >= (1ull << 32) - 16 || (top >> 48) != 0 || plain != 0;
+    return end - first >= (1ull << 32) - 16 || (top >> 48) != 0 || plain != 0;    // (plain: the test hook, or a name beyond VCF_MAX_NAME)
 }
+constexpr uint32_t VCF_MAX_NAME = 1024;       // one line's compact text (name + < 300 bytes) must fit the stage
 
 // the gaps of a line written at text offset `off` (what SSink::bulk will open)
 __device__ __forceinline__ unsigned long long vcf_line_gaps(const VcfLine &d, unsigned long long off, uint32_t name_len) {
@@ -915,10 +916,10 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     if (total) {
         MSIM_VCF_LINES(true, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len,
                        d_name, (uint32_t)name_len, ctx_lut(c), d_len, d_ra, d_off, reinterpret_cast<char *>(*buf),
-                       getenv("MSIM_DBG_VCF_PLAIN") ? 1u : 0u);      // (test hook: the plain path of waves the stage scheme cannot describe)
+                       (getenv("MSIM_DBG_VCF_PLAIN") || name_len > VCF_MAX_NAME) ? 1u : 0u);      // (the plain path: test hook, huge names)
 #undef MSIM_VCF_LINES
         // waves the stage scheme cannot describe (vcf_wave_is_plain): only a text of 4 GiB and more can hold one
-        const uint32_t plain = getenv("MSIM_DBG_VCF_PLAIN") ? 1u : 0u;
+        const uint32_t plain = (getenv("MSIM_DBG_VCF_PLAIN") || name_len > VCF_MAX_NAME) ? 1u : 0u;
         const bool far = (((uintptr_t)(in + g.len) | (uintptr_t)(pool + (1ull << 32))) >> 48) != 0;
         if (!g.all_snp && (plain || far || total >= (1ull << 32) - 16))
             hipLaunchKernelGGL(k_vcf_plain, grid, dim3(TX_THREADS), 0, st, g.d_recs, n, pool, in, (unsigned long long)g.len, d_name,

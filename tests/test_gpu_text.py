@@ -124,13 +124,13 @@ def test_vcf_device_snp_only_table_from_gpu_sampler():
     eng.close()
 
 
-@pytest.mark.parametrize("name_len", [1, 36, 37, 38, 39, 40, 41, 150])
+@pytest.mark.parametrize("name_len", [1, 36, 37, 38, 39, 40, 41, 150, 1500])
 def test_vcf_device_snp_lines_at_the_staging_limit(name_len):
     """The write pass formats the 64 lines of a wave into 4 KB of LDS when they fit (k_vcf_lines, VCF_STAGE) and writes them
     one lane each when they do not: names around the limit (64 lines of name + 7 digits + 19 bytes, plus the stretch's phase),
     a name far beyond it, suppressed lines in between -- on an SNP-only table (its own kernel) and on a mix of short records."""
     L = 2_500_000
-    name = ("chr" + "x" * 200)[:name_len]
+    name = ("chr" + "x" * 2000)[:name_len]
     bases = random_bases(L, 31 + name_len)
     bases[5000:5400] = ord("N")                          # REF == ALT: suppressed lines inside staged stretches
     for types, lens, k in (({1: 1.0}, {}, 40_000), ({1: 0.6, 2: 0.2, 3: 0.2}, {2: (1, 3), 3: (1, 3)}, 20_000)):
