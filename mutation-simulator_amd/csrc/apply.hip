@@ -39,10 +39,13 @@ namespace {
 
 constexpr int THREADS = 256;
 constexpr int GROUP = 16;                              // output bytes per lane per iteration
-constexpr int ITERS = 4;
+#ifndef MSIM_ITERS
+#define MSIM_ITERS 4                                   // (A/B builds: 8 = 32 KiB tiles, four per CU -- see the Makefile's `ablate`)
+#endif
+constexpr int ITERS = MSIM_ITERS;
 constexpr int TILE = THREADS * GROUP * ITERS;          // 16384 output bytes per workgroup
 constexpr int REC_CAP = 1024;                          // records staged in LDS per tile (dense tables)
-constexpr int REC_CAP_SMALL = 140;                     // sparse tables: window + tile + LUT = 20 KB of LDS -> 8 tiles per CU
+constexpr int REC_CAP_SMALL = 35 * ITERS;              // sparse tables: window (140 entries) + tile + LUT = 20 KB of LDS -> 8 tiles per CU
 constexpr int SCAN_ITEMS = 4;
 constexpr int SCAN_BLOCK = THREADS * SCAN_ITEMS;
 
@@ -558,9 +561,7 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // ---- index table: idx[g] = 1 + window index of the last record whose output offset is <= the start of
     // group g (0: none).  Aliases the tile buffer, which is not written before the barrier below.
-    uint32_t *idx = reinterpret_cast<uint32_t *>(tile);
-    *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x) = u32x4{0, 0, 0, 0};
-    __syncthreads();
+    uint32_t *idx = reinterpret_cast<uint32_t *>(tile);      // (zeroed by the caller, in front of the barrier behind the window fill)
     for (int32_t q = threadIdx.x; q < n_win; q += THREADS) {
         const uint32_t o = win.o[q];
         const uint32_t g = o <= tile0 ? 0u : (o - tile0 + 15u) >> 4;
@@ -568,9 +569,15 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
     }
     __syncthreads();
     {
-        u32x4 v = *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x);
-        v.y = max(v.y, v.x); v.z = max(v.z, v.y); v.w = max(v.w, v.z);
-        uint32_t incl = v.w;
+        uint32_t v[ITERS];                                 // this thread's ITERS consecutive entries
+#pragma unroll
+        for (int q = 0; q < ITERS; q += 4) {
+            const u32x4 w = *reinterpret_cast<u32x4 *>(idx + ITERS * threadIdx.x + q);
+            v[q] = w.x; v[q + 1] = w.y; v[q + 2] = w.z; v[q + 3] = w.w;
+        }
+#pragma unroll
+        for (int q = 1; q < ITERS; q++) v[q] = max(v[q], v[q - 1]);
+        uint32_t incl = v[ITERS - 1];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t t = __shfl_up(incl, o, 64);
@@ -581,8 +588,9 @@ __device__ __forceinline__ void rewrite_tile_lds(const RecWin<CAP> &win, int32_t
         if (lane == 63) wtmp[wave] = incl;
         __syncthreads();
         for (int w = 0; w < wave; w++) ex = max(ex, wtmp[w]);
-        v.x = max(v.x, ex); v.y = max(v.y, ex); v.z = max(v.z, ex); v.w = max(v.w, ex);
-        *reinterpret_cast<u32x4 *>(idx + 4 * threadIdx.x) = v;
+#pragma unroll
+        for (int q = 0; q < ITERS; q += 4)
+            *reinterpret_cast<u32x4 *>(idx + ITERS * threadIdx.x + q) = u32x4{max(v[q], ex), max(v[q + 1], ex), max(v[q + 2], ex), max(v[q + 3], ex)};
         __syncthreads();
     }
     // ---- resolve: (A) every group from the piece that covers its first byte
@@ -741,11 +749,14 @@ __device__ __forceinline__ void rewrite_one_tile(const uint8_t *__restrict__ in,
                 win.m[k] = (uint32_t)r.type | ((uint32_t)r.aux << 8);
                 win.x[k] = (r.type == MSIM_TLI && (r.aux & 1)) ? r.stop : r.extra;
             }
-            __syncthreads();
             n_win += (int32_t)total;
+            if (q0 + THREADS < cnt) __syncthreads();         // (wtmp is reused by the next round -- a tile with more than 256 records)
         }
     }
     const bool in_lds = n_win <= CAP;
+#pragma unroll
+    for (int q = 0; q < ITERS; q += 4)                       // the LDS path's index table (aliases the tile buffer)
+        *reinterpret_cast<u32x4 *>(tile + 4 * (ITERS * threadIdx.x + q)) = u32x4{0, 0, 0, 0};
     __syncthreads();
     if (in_lds) {
         rewrite_tile_lds<CAP>(win, n_win, tile, wtmp, in, out, pool, lut, tile0, L_out, err, recs, off, r_lo, r_hi,
@@ -756,7 +767,7 @@ __device__ __forceinline__ void rewrite_one_tile(const uint8_t *__restrict__ in,
     }
 }
 template <int CAP>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? MSIM_WPE : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 512 ? MSIM_WPE : 4, 8))) void k_rewrite(const uint8_t *__restrict__ in, uint8_t *__restrict__ out,
                                                      const msim_record *__restrict__ recs,
                                                      const uint32_t *__restrict__ off,
                                                      const int32_t *__restrict__ first, uint32_t n_rec,
@@ -784,7 +795,7 @@ __device__ __forceinline__ RwJob rw_job_of(const RwJobs &J, uint32_t blk) {
     return T;
 }
 template <int CAP>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 256 ? MSIM_WPE : 4, 8))) void k_rewrite_b(RwJobs J, const uint8_t *__restrict__ lut_g) {
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(CAP <= 512 ? MSIM_WPE : 4, 8))) void k_rewrite_b(RwJobs J, const uint8_t *__restrict__ lut_g) {
     const RwJob T = rw_job_of(J, blockIdx.x);
     const uint32_t blk = blockIdx.x - T.tile_base;
     if (blk >= T.n_tiles) return;
