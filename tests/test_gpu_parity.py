@@ -445,13 +445,26 @@ def _sharded_worker(rank, world, port, out_dir, transport, one_device):
 
 
 def _run_sharded(tmp_path, transport, one_device):
+    """Two worker interpreters, started as plain subprocesses: this process must NOT import torch -- the PyTorch-ROCm wheel
+    brings a HIP runtime of its own, and a second runtime beside the one libmsim has already loaded here ends the test run
+    with a double free at interpreter exit (the workers import torch first, as bench.py does)."""
     import json
     import socket
-    import torch.multiprocessing as mp
+    import subprocess
+    import sys
+    from pathlib import Path
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path), transport, one_device), nprocs=2, join=True)
+    here = str(Path(__file__).resolve().parent)
+    code = ("import sys; sys.path.insert(0, {here!r}); import conftest  # noqa: F401 (sys.path of the test tree)\n"
+            "from test_gpu_parity import _sharded_worker\n"
+            "_sharded_worker({rank}, 2, {port}, {out!r}, {transport!r}, {one!r})\n")
+    procs = [subprocess.Popen([sys.executable, "-c", code.format(here=here, rank=r, port=port, out=str(tmp_path), transport=transport,
+                                                                  one=one_device)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=540)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     res = json.loads((tmp_path / "sharded.json").read_text())
     bad = [c for c in res["checked"] if not c[3]]
     assert res["ok"] and not bad, bad
