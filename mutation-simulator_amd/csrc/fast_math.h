@@ -40,7 +40,7 @@ constexpr uint32_t TAG_POS = 17;       // x = draw index >> 1, y = leaf (numbere
 constexpr uint32_t TAG_CAND = 18;      // x = candidate ordinal: low 64 bits -> type (53 bits), high 64 -> length, or the SNP's outcome
 constexpr uint32_t TAG_INS = 19;       // x = 64-base chunk of the insert, y = candidate ordinal
 constexpr int LG_LEAF_MIN = 10, LG_LEAF_MAX = 16;
-constexpr uint32_t LEAF_TARGET = 96;   // a leaf should hold about this many points or more (up to twice as many)
+constexpr uint32_t LEAF_TARGET = 224;  // a leaf should hold about this many points or more (up to twice as many): 96 -> 224 in round 5 (A/B on one box, interleaved: c4 -5 %, c4sv -4 %, c3 -1 %, c2 +-0; 320: c3 +4 %)
 
 struct U4 { uint32_t x, y, z, w; };
 

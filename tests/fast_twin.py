@@ -13,7 +13,7 @@ import numpy as np
 U64 = np.uint64
 M32 = U64(0xFFFFFFFF)
 TAG_SPLIT, TAG_POS, TAG_CAND, TAG_INS = 16, 17, 18, 19
-LG_MIN, LG_MAX, LEAF_TARGET = 10, 16, 96
+LG_MIN, LG_MAX, LEAF_TARGET = 10, 16, 224
 SN, IN, DE, DU, IV = 1, 2, 3, 4, 5
 
 
