@@ -266,7 +266,10 @@ __global__ __launch_bounds__(256) void k_fsplit_sub(const FRange *__restrict__ r
 
 // ------------------------------------------------------------------------------------------------ leaves
 // one wave per leaf; dynamic LDS per wave: a bitmap of 2^lgBmax bits, then the list of the leaf's values
-constexpr uint32_t LEAF_LIST = 1024;                       // values a leaf can stage for the balanced pass (a leaf holds ~100-200)
+constexpr uint32_t LEAF_LIST = 512;                        // values a leaf can stage for the balanced pass (a leaf holds 224-448; fuller
+                                                           // ones -- 3 sigma and more above the densest mean -- take the unbalanced
+                                                           // loop), 16 bits each (a value lies below 2^16: LG_LEAF_MAX): 1 KB beside
+                                                           // the 4 KB bitmap of a 2^15-value leaf -> eight workgroups per CU
 template <bool SV>
 __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges, const LeafDesc *__restrict__ leaves,
                                                uint32_t n_leaves, uint32_t bm_words, const FSlot *__restrict__ slots, Key2 key2,
@@ -280,8 +283,8 @@ __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t g = blockIdx.x * 4 + wave;
     if (g >= n_leaves) return;                             // (no workgroup barrier below: waves are on their own)
-    uint32_t *bm = lds_bm + (size_t)wave * (bm_words + LEAF_LIST);
-    uint32_t *list = bm + bm_words;
+    uint32_t *bm = lds_bm + (size_t)wave * (bm_words + LEAF_LIST / 2);
+    uint16_t *list = reinterpret_cast<uint16_t *>(bm + bm_words);
     const LeafDesc D = leaves[g];
     const FSlot &SL = slots[D.slot];
     const Key key{key2.k0, key2.k1, SL.seq};
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void k_fleaf(const FRange *__restrict__ ranges
             const uint32_t wi = lane * W + q;
             unsigned long long w = word_at(wi);
             while (w) {
-                list[lr++] = wi * 64 + (uint32_t)__builtin_ctzll(w);
+                list[lr++] = (uint16_t)(wi * 64 + (uint32_t)__builtin_ctzll(w));
                 w &= w - 1;
             }
         }

@@ -571,7 +571,7 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
                        snp_only ? 0u : 2 * (nbt + 1), S.kept.p, 4 * n_slots, (uint32_t)items[0].P.d);
     c->fast->prof.lap(4);
     const uint32_t bm_words = (1u << lgB_max) / 32 + 2;
-    const size_t lds = (size_t)4 * (bm_words + LEAF_LIST) * sizeof(uint32_t);
+    const size_t lds = (size_t)4 * (bm_words + LEAF_LIST / 2) * sizeof(uint32_t);
     const uint32_t leaf_blocks = ((uint32_t)n_leaves + 3) / 4;
     const uint32_t d = (uint32_t)items[0].P.d;
     const Block1 block1 = items[0].P.block1;
