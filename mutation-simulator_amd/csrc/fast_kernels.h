@@ -1006,37 +1006,17 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
     uint32_t r = base_n + in - nk, p = base_p + ip - np;
     long long shift = base_d + id - nd;
     for (int w = 0; w < wave; w++) { r += wn[w]; p += wp[w]; shift += wd[w]; }
+    const uint32_t p_first = p;                            // (pool offset of this lane's first insertion)
     // Insert bases (mutator.py:465-471) are NOT written from this loop: an insertion is one candidate in eight, so a lane-per-
     // candidate loop would run its Philox call and a dozen stores in every one of its eight rounds for a handful of lanes
     // (measured: 286 of the kernel's 426 us).  The workgroup's insertions go to an LDS list and are filled one lane each.
-    __shared__ uint32_t ins_ord[OB_BLOCK], ins_at[OB_BLOCK], ins_len[OB_BLOCK];
+    // (half a block's worth of list -- 12 KB, eight workgroups per CU; a block with more insertions than that, i.e. settings that
+    //  draw mostly insertions, fills the rest from the emitting lanes themselves)
+    constexpr uint32_t INS_LIST = OB_BLOCK / 2;
+    __shared__ uint32_t ins_ord[INS_LIST], ins_at[INS_LIST], ins_len[INS_LIST];
     __shared__ uint32_t n_ins;
-    if (threadIdx.x == 0) n_ins = 0;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < OB_ITEMS; q++) {
-        if (!(meta[q] & CAND_VISIT)) continue;
-        const uint32_t t = meta[q] & 7u, ord = i0 + q;
-        uint32_t extra = 0;
-        const uint32_t aux = t == MSIM_SN ? (meta[q] >> CAND_AUX_SHIFT) & 3u : 0u;     // (drawn with the candidate: k_fleaf)
-        if (t == MSIM_IN) {
-            extra = p;
-            const uint32_t len = stop[q] - pos[q] + 1;
-            if ((unsigned long long)p + len <= pool_cap) {                // (an overflowing plan: flagged by the last workgroup)
-                const uint32_t k = atomicAdd(&n_ins, 1u);
-                ins_ord[k] = ord; ins_at[k] = p; ins_len[k] = len;
-            }
-            p += len;
-        }
-        rec_off[r] = (uint32_t)((long long)pos[q] + shift);
-        shift += cand_delta(t, pos[q], stop[q]);
-        store_record(recs + r, pos[q], stop[q], extra, t, aux);
-        r++;
-    }
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < n_ins; k += OB_THREADS) {
-        const uint32_t ord = ins_ord[k], len = ins_len[k];
-        uint8_t *dst0 = pool + ins_at[k];
+    auto fill_insert = [&](uint32_t ord, uint32_t at, uint32_t len) {
+        uint8_t *dst0 = pool + at;
         for (uint32_t c0 = 0; c0 < len; c0 += 64) {                       // 64 bases per counter, 16 per word, stored 4 at a time
             const U4 ch = draw4(key, c0 >> 6, ord, TAG_INS);
             const uint32_t nbases = min(64u, len - c0);
@@ -1059,6 +1039,41 @@ __global__ __launch_bounds__(OB_THREADS) void k_femit(const uint32_t *__restrict
                     }
                 }
             }
+        }
+    };
+    if (threadIdx.x == 0) n_ins = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < OB_ITEMS; q++) {
+        if (!(meta[q] & CAND_VISIT)) continue;
+        const uint32_t t = meta[q] & 7u, ord = i0 + q;
+        uint32_t extra = 0;
+        const uint32_t aux = t == MSIM_SN ? (meta[q] >> CAND_AUX_SHIFT) & 3u : 0u;     // (drawn with the candidate: k_fleaf)
+        if (t == MSIM_IN) {
+            extra = p;
+            const uint32_t len = stop[q] - pos[q] + 1;
+            if ((unsigned long long)p + len <= pool_cap) {                // (an overflowing plan: flagged by the last workgroup)
+                const uint32_t k = atomicAdd(&n_ins, 1u);
+                if (k < INS_LIST) { ins_ord[k] = ord; ins_at[k] = p; ins_len[k] = len; }
+            }
+            p += len;
+        }
+        rec_off[r] = (uint32_t)((long long)pos[q] + shift);
+        shift += cand_delta(t, pos[q], stop[q]);
+        store_record(recs + r, pos[q], stop[q], extra, t, aux);
+        r++;
+    }
+    __syncthreads();
+    if (n_ins <= INS_LIST) {
+        for (uint32_t k = threadIdx.x; k < n_ins; k += OB_THREADS) fill_insert(ins_ord[k], ins_at[k], ins_len[k]);
+    } else {                                               // (the list overflowed: every lane fills its own, the list is ignored)
+        uint32_t at = p_first;
+#pragma unroll 1
+        for (int q = 0; q < OB_ITEMS; q++) {
+            if (!(meta[q] & CAND_VISIT) || (meta[q] & 7u) != MSIM_IN) continue;
+            const uint32_t len = stop[q] - pos[q] + 1;
+            if ((unsigned long long)at + len <= pool_cap) fill_insert(i0 + q, at, len);
+            at += len;
         }
     }
 }

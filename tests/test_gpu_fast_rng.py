@@ -94,6 +94,22 @@ def test_big_contig_equals_numpy_restatement():
         eng.close()
 
 
+def test_insert_heavy_blocks_equal_numpy_restatement():
+    """Nine candidates in ten are insertions: k_femit's LDS list of a block's insertions (half a block's worth) overflows and
+    every lane fills its own insert bases instead -- pools and records still equal the twin's."""
+    params = _params(titv=2.0)
+    L, key = 3_000_000, 1234
+    ranges = [_sv_range(0, L - 1, 30_000, {1: 0.1, 2: 0.9}, {2: (1, 30)})]
+    eng = _ffi.Engine(0, _ffi.RNG_FAST)
+    eng.set_params(params)
+    eng.set_fast_key(key)
+    cid, recs, pool = _plan(eng, L, ranges)
+    assert (recs["type"] == 2).sum() > 0.6 * len(recs) and len(pool) > 100_000
+    twin = ft.plan(L, _twin_ranges(ranges), _blocks(params), _ti_lim(params), key, 0)
+    assert_plan_equals_twin(recs, pool, eng.plan_was_empty(cid), twin)
+    eng.close()
+
+
 def test_properties_at_scale():
     L = 60_000_000
     blocks = {t: 3 for t in ("SN", "IN", "DE", "IV", "DU", "TL", "TLI")}          # min distance d = 3
