@@ -95,10 +95,10 @@ def _settings_key(ms):
     """By VALUE: a settings object changed in place after its first descriptor (tests, callers adjusting rates) must not
     meet its stale template."""
     lengs = ms.mut_lengs or {}
-    return (tuple((t.value, r) for t, r in (ms.mut_rates or {}).items()),
-            tuple((t.value, c) for t, c in (ms.mut_chances or {}).items()),
-            tuple((t.value, v) for t, v in (lengs.get("min") or {}).items()),
-            tuple((t.value, v) for t, v in (lengs.get("max") or {}).items()))
+    # (dict items as they are -- MutType members hash and compare by identity: 1 us instead of 6 for four generator
+    #  expressions over `.value`, per contig and step in front of every plan)
+    return (tuple((ms.mut_rates or {}).items()), tuple((ms.mut_chances or {}).items()),
+            tuple((lengs.get("min") or {}).items()), tuple((lengs.get("max") or {}).items()))
 
 
 def range_descriptor(rd) -> "_ffi.Range":
