@@ -635,7 +635,12 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
                                                       uint32_t *__restrict__ blk_nrec, uint32_t *__restrict__ blk_pool,
                                                       long long *__restrict__ blk_delta, uint32_t *__restrict__ kept_all,
                                                       const FSlot *__restrict__ slots, const uint32_t *__restrict__ blk_slot) {
-    __shared__ uint32_t pos_h[2 * OB_BLOCK + 1], E_h[2 * OB_BLOCK];
+    // (of the previous block only its last KEEP_HALO candidates sit in LDS -- the walk that enters this block starts at the
+    //  previous block's last free candidate, a few candidates from its end; the running maxima over the whole previous block
+    //  come from registers.  22 KB instead of 34: seven workgroups per CU instead of four.  An anchor further back than the
+    //  halo is treated like no anchor at all: the orbit kernels replay the plan.)
+    constexpr int KEEP_HALO = 512;
+    __shared__ uint32_t pos_h[KEEP_HALO + OB_BLOCK + 1], E_h[KEEP_HALO + OB_BLOCK];
     __shared__ uint8_t onorb[OB_BLOCK];
     __shared__ uint32_t wmax[2][OB_THREADS / 64], wred[OB_THREADS / 64];
     __shared__ int32_t wanchor[OB_THREADS / 64];
@@ -650,7 +655,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
     uint32_t *kept_any = kept_all + 4 * slot, *fallback = kept_any + (VISIT ? 2 : 1);
     const uint32_t b = blockIdx.x - SL.blk_off, base = b * OB_BLOCK, cnt = min((uint32_t)OB_BLOCK, K - base);
     const bool prev = b > 0;                                // (the previous block is always a full one)
-    uint32_t *pos = pos_h + OB_BLOCK, *E = E_h + OB_BLOCK;   // in-block index i; the previous block at i - 2048
+    uint32_t *pos = pos_h + KEEP_HALO, *E = E_h + KEEP_HALO;   // in-block index i; the previous block's tail at i - 2048 >= -KEEP_HALO
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t i0 = threadIdx.x * OB_ITEMS;             // a thread owns 8 consecutive candidates of each block
     // ---- loads; maximum of the ends over everything before the previous block
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
         }
         if (!prev) { pv_p[q] = 0u; pv_e[q] = 0u; }
         pos[i] = my_p[q]; E[i] = my_e[q];
-        pos_h[i] = pv_p[q]; E_h[i] = pv_e[q];
+        if (i >= (uint32_t)(OB_BLOCK - KEEP_HALO)) { pos_h[i - (OB_BLOCK - KEEP_HALO)] = pv_p[q]; E_h[i - (OB_BLOCK - KEEP_HALO)] = pv_e[q]; }
     }
     for (int o = 32; o > 0; o >>= 1) far = max(far, (uint32_t)__shfl_down((int)far, o, 64));
     uint32_t rp = 0, rm = 0;                               // this thread's maxima of the ends: previous block, this block
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(OB_THREADS) void k_fkeep(const uint32_t *__restrict
     if (prev) {
         anchor = -1;
         for (int w = 0; w < OB_THREADS / 64; w++) anchor = max(anchor, wanchor[w]);
-        if (anchor < 0) {                                  // (uniform) the orbit kernels take over
+        if (anchor < OB_BLOCK - KEEP_HALO) {               // (uniform; none at all: -1) the orbit kernels take over
             if (threadIdx.x == 0) atomicOr(fallback, 1u);
             return;
         }
