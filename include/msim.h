@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 6
+#define MSIM_ABI_VERSION 7
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -137,6 +137,10 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     uint64_t stream_rebases;     /* device MT19937 sessions re-based: the jump tables span 8192 chunks (1.31 G words) from a
                                     session's origin; before a contig that would not fit, the state at the streams' exact
                                     positions becomes the next session's origin (no limit on a run's stream length)     */
+    uint64_t snp_samples_ahead;  /* SNP sampler, on a rank of a sharded step (msim_plan_chain in use): samples -- of owned contigs
+                                    and of contigs walked for their stream positions alike -- whose count / scatter / de-dup
+                                    ran off the stream-position chain, on a window anchored at the host's bound of the start
+                                                                                                     */
 } msim_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */
@@ -158,7 +162,8 @@ int  msim_device_name(const msim_ctx *ctx, char *dst, int cap);
 int  msim_sync(msim_ctx *ctx);
 /* Change the PLAN mode of a live context (0 = AUTO, MSIM_PLAN_HOST, MSIM_PLAN_GPU).  The host package uses it to
  * re-plan a contig through the sequential host planner when a device engine reports that a stream window
- * overflowed its 16-sigma margin (the streams are put back with msim_set_mt_state first).                    */
+ * overflowed its margin -- 16 sigma; 8 for the interval in which a sample planned ahead of the stream-position chain
+ * (msim_timing.snp_samples_ahead) expects its start -- (the streams are put back with msim_set_mt_state first). */
 int  msim_set_plan_mode(msim_ctx *ctx, uint32_t mode);
 
 /* ---- the two global RNGs the reference draws from ---------------------------------------------- */

@@ -77,6 +77,14 @@ struct SampleSet {                       // scratch of one sampled range
     uint32_t *cnt2 = nullptr; size_t cnt2_cap = 0;        // per-workgroup popcounts / ranks
     uint32_t *bins = nullptr; size_t bins_cap = 0;        // first-k draws grouped by value bin
     uint32_t *cursors = nullptr; size_t cursors_cap = 0;  // per-bin fill counters
+    // anchored windows (enqueue_sample_ahead): bookkeeping of the core window and of the head interval, the accepted draws of
+    // the head interval with their per-block offsets, and the event behind the set's off-chain work
+    uint8_t *ahead = nullptr;                             // PlanState core | PlanState head | SpecHdr
+    uint32_t *hcnt = nullptr; size_t hcnt_cap = 0;
+    uint32_t *hacc = nullptr; size_t hacc_cap = 0;
+    hipEvent_t prep_done = nullptr;
+    hipEvent_t chain_done = nullptr;                      // behind the set's last kernel on the plan stream (anchored windows)
+    uint8_t last_user = 0;                                // since the last finish: 1 a sample on the chain, 2 an anchored window
     hipEvent_t emit_done = nullptr;
     bool pending = false;
 };
@@ -163,11 +171,30 @@ struct GpuPlan {
     int emit_group = 2;                 //   contigs per emission group (MSIM_EMIT_GROUP; see plan_contig_gpu)
     uint32_t max_chunks = MT_JUMP_MAX_CHUNKS;   //   chunks one (re)seeded session may span (MSIM_DBG_JUMP_MAX_CHUNKS lowers it)
     uint32_t rebases = 0;               //   sessions ended because the next contig would not fit into the span
+    // anchored windows: the CPython stream's position as the host knows it between two exact readings -- mean and variance of
+    // the words consumed since (the sampler's rejections and duplicates, the SNP draws' transversion loops), a hard lower bound
+    hipStream_t prep_stream = nullptr;  //   the off-chain part of the samples: the stream of the sample being enqueued,
+    hipStream_t prep_streams[8] = {};   //   one of these in turn (contigs' off-chain parts are independent of each other)
+    int n_prep = 4, prep_i = 0, prep_prio = -1;   //   (at the chain's priority: 2.3-2.6 ms for a chain-only rank at either, 2.75 against 3.2 owning three)
+    double ahead_sigma = 8.0;
+    uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
+    // Measured (c2, 3 Gb, tools/compat_steps.py): a rank that owns every contig is bound by its emission + APPLY train either way
+    // and the extra off-chain launches only slow that train (4.1 ms on the chain, 4.2-4.7 ahead); a rank of a sharded step, which
+    // walks the other ranks' contigs for their stream positions only, is bound by the chain: 2.9 -> 2.3 ms owning none of 24,
+    // 3.4 -> 2.75 owning three.  So: ahead on a context that has been asked for msim_plan_chain in this pass or the last one.
+    int ahead = 1;                      //   0 never (MSIM_NO_AHEAD), 1 sharded ranks, 2 always (MSIM_AHEAD=2)
+    uint32_t pass_chain_only = 0;       //   msim_plan_chain calls in this pass
+    bool sharded_rank = false;          //   ... there were some in this pass or in the one before
+    bool est_ok = false;
+    double est_e = 0, est_v = 0;
+    uint64_t est_lo = 0;
+    uint32_t ahead_contigs = 0;         //   contigs planned this way (tests)
 };
 
 static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
     if (*cap >= want_bytes) return MSIM_OK;
     if (!*grew) {                         // a buffer is about to be replaced: nothing may be in flight
+        if (c->gpu) for (auto st : c->gpu->prep_streams) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
         MSIM_HIP(c, hipStreamSynchronize(c->stream));
         MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
         *grew = true;
@@ -185,6 +212,11 @@ GpuPlan *gpu_plan_create() {
     if (const char *e = getenv("MSIM_EMIT_GROUP")) g->emit_group = std::min(EMIT_G, std::max(1, atoi(e)));
     if (const char *e = getenv("MSIM_DBG_JUMP_MAX_CHUNKS"))
         g->max_chunks = (uint32_t)std::min<long>(MT_JUMP_MAX_CHUNKS, std::max<long>(2, atol(e)));
+    if (getenv("MSIM_NO_AHEAD")) g->ahead = 0;
+    else if (const char *e = getenv("MSIM_AHEAD")) g->ahead = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("MSIM_PREP_STREAMS")) g->n_prep = std::min(8, std::max(1, atoi(e)));
+    if (const char *e = getenv("MSIM_PREP_PRIO")) g->prep_prio = atoi(e);
+    if (const char *e = getenv("MSIM_AHEAD_SIGMA")) g->ahead_sigma = std::min(16.0, std::max(0.0, atof(e)));
     return g;
 }
 
@@ -223,6 +255,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     if (!g) return;
     if (g->jump_stream) { (void)hipStreamSynchronize(g->jump_stream); (void)hipStreamDestroy(g->jump_stream); }
     if (g->gen_stream) { (void)hipStreamSynchronize(g->gen_stream); (void)hipStreamDestroy(g->gen_stream); }
+    for (auto st : g->prep_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     for (auto &s : g->s) {
         if (s.d_raw) (void)hipFree(s.d_raw);
         if (s.d_states) (void)hipFree(s.d_states);
@@ -241,6 +274,11 @@ void gpu_plan_destroy(GpuPlan *g) {
         if (t.cnt2) (void)hipFree(t.cnt2);
         if (t.bins) (void)hipFree(t.bins);
         if (t.cursors) (void)hipFree(t.cursors);
+        if (t.ahead) (void)hipFree(t.ahead);
+        if (t.hcnt) (void)hipFree(t.hcnt);
+        if (t.hacc) (void)hipFree(t.hacc);
+        if (t.prep_done) (void)hipEventDestroy(t.prep_done);
+        if (t.chain_done) (void)hipEventDestroy(t.chain_done);
         if (t.emit_done) (void)hipEventDestroy(t.emit_done);
     }
     for (auto &t : g->snp) {
@@ -278,6 +316,8 @@ void gpu_plan_destroy(GpuPlan *g) {
 
 void gpu_plan_invalidate(GpuPlan *g) {
     g->unit = g->snp_unit = g->mixed_unit = 0;            // a new pass: contig i meets scratch set i again (sizes fit)
+    g->sharded_rank = g->pass_chain_only > 0;
+    g->pass_chain_only = 0;
     for (auto &s : g->s) {
         if (s.live) s.last_session_words = std::max<uint64_t>(s.pos, MT_N + (uint64_t)s.n_chunks * MT_CHUNK_WORDS);
         s.live = false;
@@ -423,6 +463,7 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
         if (want_states > s.states_cap || want_cap > s.cap) {      // grow (rare): quiesce every stream first
             MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));
             MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
+            for (auto st : g->prep_streams) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
             MSIM_HIP(c, hipStreamSynchronize(c->stream));
             MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));     // record emission reads the word arrays too
             if (want_states > s.states_cap) {
@@ -606,6 +647,7 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     }
     MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));     // nothing of the old session in flight
     MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
+    for (auto st : g->prep_streams) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
     // the state goes through a pinned staging slot (one per stream), so the copies need no host synchronisation:
     // h.mt may change right after; the slot is rewritten only once the copies that read it are known to be done,
     // and the side streams are ordered behind the copies by the same event
@@ -619,6 +661,7 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     MSIM_HIP(c, hipEventRecord(g->seed_ev[si], c->stream));
     MSIM_HIP(c, hipStreamWaitEvent(g->jump_stream, g->seed_ev[si], 0));
     MSIM_HIP(c, hipStreamWaitEvent(g->gen_stream, g->seed_ev[si], 0));
+    if (si == 0) for (auto st : g->prep_streams) if (st) MSIM_HIP(c, hipStreamWaitEvent(st, g->seed_ev[si], 0));
     for (auto e : s.ready_ev) g->ev_pool.push_back(e);
     s.ready_ev.clear();
     s.ready_hi.clear();
@@ -626,6 +669,7 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
     s.words_ev.clear();
     s.waited_chunks = 0;
     s.waited_words = 0;
+    if (si == 0) for (auto &w : g->prep_waited) w = 0;
     s.casc_pending = false;
     s.n_states = 1;
     s.lvl = 0; s.n_src = 1; s.m_done = 0;
@@ -710,14 +754,14 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
     MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
     c->t.plan_gpu_ms += ms;
     g->unverified = false;
-    for (auto &t : g->sample) t.pending = false;
+    for (auto &t : g->sample) { t.pending = false; t.last_user = 0; }
     for (auto &t : g->snp) t.pending = false;
     for (auto &t : g->mixed) t.pending = false;
     const PlanState h = *g->h_mail;
     if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
         g->s[0].live = g->s[1].live = false;
         for (auto &t : g->mixed) t.wbits_dirty = true;
-        return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its 16-sigma margin (results discarded)");
+        return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its margin (16 sigma; 8 for the start of a sample planned ahead of the chain; results discarded)");
     }
     c->t.py_words += h.pos - g->verified_pos;
     g->verified_pos = h.pos;
@@ -771,6 +815,7 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
     const uint32_t W = (uint32_t)wd;
     SampleSet &S = g->sample[g->unit++ % N_SETS];
+    S.last_user = 1;
     if ((rc = wait_if_pending(c, S.pending, S.emit_done))) return rc;          // its last emit may still read it
     const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
     const size_t bm_words64 = (size_t)((n + 63) / 64);
@@ -829,6 +874,119 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     }
     MSIM_HIP(c, hipGetLastError());
     out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
+    return MSIM_OK;
+}
+
+// ---- anchored windows: the same sample with its heavy part OFF the chain (plan_kernels.h: k_ahead_fringe has the argument).
+// The host knows the sample's start to within [lo, H]; count, scatter and de-dup of the first k_core accepted draws from H and
+// the compaction of the accepted draws of [lo, H) run on the prep stream as soon as the words exist; the chain keeps the
+// fringe pass (needs the exact start), the tail rounds and the cut.  e_limit: the cut may not lie beyond it (what the caller
+// will have made sure exists for the stage that follows).
+static int prep_wait_words(Ctx *c, GpuPlan *g, uint64_t upto) {
+    GpuStream &s = g->s[0];
+    if (upto <= MT_N) return MSIM_OK;
+    const uint32_t need = (uint32_t)((upto - MT_N + MT_CHUNK_WORDS - 1) / MT_CHUNK_WORDS);
+    uint32_t &waited = g->prep_waited[g->prep_i];
+    if (need <= waited) return MSIM_OK;
+    for (size_t b = 0; b < s.ready_hi.size(); b++) {
+        if (s.ready_hi[b] >= need) {
+            MSIM_HIP(c, hipStreamWaitEvent(g->prep_stream, s.words_ev[b] ? s.words_ev[b] : s.ready_ev[b], 0));
+            waited = s.ready_hi[b];
+            break;
+        }
+    }
+    return MSIM_OK;
+}
+
+static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t d, uint64_t lo, uint64_t H, uint64_t e_limit,
+                                bool &grew, SampleLaunch &out, bool &took) {
+    int rc;
+    const uint32_t K = (uint32_t)r.k;
+    const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
+    const int bits = bit_length64(n);
+    const double p_acc = (double)n / (double)(1ull << bits);
+    const double need_acc = -(double)n * std::log1p(-(double)K / (double)n);
+    const double target = need_acc + 16.0 * std::sqrt(need_acc) + 4096.0;
+    const double wd = target / p_acc + 16.0 * std::sqrt(target) / p_acc + 8192.0;
+    if (wd >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "sample window beyond 2^32 words");
+    const uint32_t W = (uint32_t)wd;                       // (sized for all K draws from H: the core needs fewer)
+    const uint32_t F = (uint32_t)(H - lo);
+    took = (W + ACC_BLOCK - 1) / ACC_BLOCK < (uint32_t)TAIL_LDS_OFFS && (F + ACC_BLOCK - 1) / ACC_BLOCK <= (uint32_t)AHEAD_MAX_HEAD_BLOCKS;
+    if (!took) return MSIM_OK;                             // (counts beyond what the chain's kernels hold in LDS: the caller's other path)
+    const uint32_t a_max = F ? (uint32_t)std::min<double>((double)F, (double)F * p_acc + 16.0 * std::sqrt((double)F * p_acc * (1.0 - p_acc)) + 64.0) : 0u;
+    const uint32_t k_core = K - a_max;
+    g->prep_i = (g->prep_i + 1) % g->n_prep;
+    if (!g->prep_streams[g->prep_i]) {
+        int plo = 0, phi = 0;
+        MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&plo, &phi));
+        const int prio = g->prep_prio > 0 ? plo : g->prep_prio < 0 ? phi : 0;
+        MSIM_HIP(c, hipStreamCreateWithPriority(&g->prep_streams[g->prep_i], hipStreamNonBlocking, prio));
+        if (g->seed_ev[0]) MSIM_HIP(c, hipStreamWaitEvent(g->prep_streams[g->prep_i], g->seed_ev[0], 0));   // (the session's first 624 words are a copy)
+    }
+    g->prep_stream = g->prep_streams[g->prep_i];
+    hipStream_t ps_ = g->prep_stream;
+    SampleSet &S = g->sample[g->unit++ % N_SETS];
+    const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
+    const uint32_t nbh = (F + ACC_BLOCK - 1) / ACC_BLOCK;
+    const size_t bm_words64 = (size_t)((n + 63) / 64);
+    const uint32_t bmw = (uint32_t)bm_words64;
+    const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
+    const uint32_t n_bins = (uint32_t)((n + BIN_VALUES - 1) >> BIN_SHIFT);
+    const uint32_t nbk = (uint32_t)((double)K / p_acc / SPL_BLOCK) + 3;
+    const double mean = (double)((nbk + BIN_SUBS - 1) / BIN_SUBS) * SPL_BLOCK * p_acc * std::min(1.0, (double)BIN_VALUES / (double)n);
+    const uint32_t bin_cap = (uint32_t)std::min<double>((double)K + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
+    if ((rc = grow(c, (void **)&S.cnt, &S.cnt_cap, (size_t)(nb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.acc, &S.acc_cap, (size_t)W * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.bins, &S.bins_cap, (size_t)n_bins * BIN_SUBS * bin_cap * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.cursors, &S.cursors_cap, (size_t)MAX_BINS * BIN_SUBS * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, std::max(bm_words64 * 8, (size_t)n_bins * BIN_WORDS * 4), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.hcnt, &S.hcnt_cap, (size_t)(nbh + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.hacc, &S.hacc_cap, ((size_t)nbh * ACC_BLOCK + 64) * sizeof(uint32_t), &grew))) return rc;
+    if (!S.ahead) MSIM_HIP(c, hipMalloc(&S.ahead, 2 * sizeof(PlanState) + sizeof(SpecHdr)));
+    if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
+    if (!S.prep_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.prep_done, hipEventDisableTiming));
+    PlanState *ps_core = reinterpret_cast<PlanState *>(S.ahead), *ps_head = ps_core + 1;
+    SpecHdr *hdr = reinterpret_cast<SpecHdr *>(ps_head + 1);
+    if ((rc = ensure_words(c, g, 0, H + W + 1, false))) return rc;
+    const uint32_t *raw = g->s[0].d_raw;
+    if ((rc = prep_wait_words(c, g, H + W + 1))) return rc;
+    if (S.pending) {                                       // the set's last emission may still read it
+        if (hipEventQuery(S.emit_done) == hipSuccess) S.pending = false;
+        else { (void)hipGetLastError(); MSIM_HIP(c, hipStreamWaitEvent(ps_, S.emit_done, 0)); }
+    }
+    // ... and so may the chain of the contig that had the set N_SETS contigs ago (the host may be that far ahead of the device):
+    // an anchored window left an event behind its last chain kernel; behind a sample on the chain, whatever the plan stream holds
+    if (!S.chain_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.chain_done, hipEventDisableTiming));
+    if (S.last_user == 1) MSIM_HIP(c, hipEventRecord(S.chain_done, c->stream));
+    if (S.last_user && hipEventQuery(S.chain_done) != hipSuccess) {
+        (void)hipGetLastError();
+        MSIM_HIP(c, hipStreamWaitEvent(ps_, S.chain_done, 0));
+    }
+    S.last_user = 2;
+    // ---- off the chain
+    const uint32_t shift = (uint32_t)(32 - bits);
+    hipLaunchKernelGGL(k_ahead_count, dim3(nb + nbh), dim3(ACC_THREADS), 0, ps_, raw, ps_core, ps_head, hdr, (unsigned long long)H,
+                       (unsigned long long)lo, W, F, nb, shift, (uint32_t)n, S.cnt, S.cursors, n_bins * BIN_SUBS, S.hcnt, S.hacc);
+    hipLaunchKernelGGL(k_bin_scatter, dim3((W + SPL_BLOCK - 1) / SPL_BLOCK), dim3(ACC_THREADS), 0, ps_, raw, ps_core, W, shift,
+                       (uint32_t)n, k_core, S.cnt, n_bins, bin_cap, S.cursors, S.bins, S.acc, ps_core, 1u);
+    hipLaunchKernelGGL(k_bin_dedupe, dim3(n_bins), dim3(512), 0, ps_, S.bins, S.cursors, bin_cap, S.bitmap, ps_core);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipEventRecord(S.prep_done, ps_));
+    // ---- on the chain: fringe (exact start), tail rounds, cut
+    MSIM_HIP(c, hipStreamWaitEvent(c->stream, S.prep_done, 0));
+    const double dups_est = (double)K * (double)K / (2.0 * (double)n);
+    const uint32_t items_est = a_max + (uint32_t)(dups_est + 16.0 * std::sqrt(dups_est) + 64.0);
+    const uint32_t G = std::max(1u, std::min(256u, (items_est + ACC_THREADS * FRINGE_ITEMS - 1) / (ACC_THREADS * FRINGE_ITEMS)));
+    hipLaunchKernelGGL(k_ahead_fringe, dim3(G), dim3(ACC_THREADS), 0, c->stream, raw, g->d_ps, ps_core, ps_head, hdr,
+                       (unsigned long long)lo, F, S.hcnt, nbh, S.hacc, S.acc, K, k_core, shift, (uint32_t)n, S.bitmap);
+    hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, raw, S.acc, k_core, S.cnt, nb, W, shift, (uint32_t)n,
+                       k_core, S.bitmap, g->d_ps, 1u, ps_core, hdr, (unsigned long long)e_limit);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, hipEventRecord(S.chain_done, c->stream));
+    out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
+    g->ahead_contigs++;
+    c->t.snp_samples_ahead++;
     return MSIM_OK;
 }
 
@@ -978,6 +1136,17 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     }
     uint64_t pos_hi = py.pos;                             // upper bound of the device position
     uint64_t rec_base = 0;
+    if (c->chain_only) { g->pass_chain_only++; g->sharded_rank = true; }
+    if (!g->unverified) {                                 // py.pos is exact: the estimate of the position starts here
+        g->est_ok = true;
+        g->est_e = (double)py.pos; g->est_v = 0.0; g->est_lo = py.pos;
+    }
+    // mean + 16 sigma of the position (est_*), never beyond the sum of the windows
+    auto est_hi = [&](uint64_t bound) -> uint64_t {
+        if (!g->est_ok) return bound;
+        const double m = g->est_v > 0.0 ? 16.0 * std::sqrt(1.1 * g->est_v) + 256.0 : 0.0;
+        return std::min<uint64_t>(bound, (uint64_t)std::ceil(g->est_e + m));
+    };
     // One drawing range (ARGS mode): the SNP outcomes are folded into the records by the expansion, which then runs behind
     // the SNP stage.  Several ranges keep the order expansion -> outcomes patched in (their bitmaps rotate through N_SETS
     // scratch sets and cannot all wait for the contig's one SNP stage).
@@ -1004,7 +1173,34 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if (r.k == 0) continue;
         const uint32_t k = (uint32_t)r.k;
         SampleLaunch sl;
-        if ((rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl))) return rc;
+        // moments of the words this sample consumes: A accepted draws until k distinct values (duplicates: a coupon collector's
+        // first k), each after a geometric number of rejected words (_randbelow)
+        const double n_d = (double)((r.stop - (r.k - 1) * d) - r.start);
+        const double p_acc = n_d / (double)(1ull << bit_length64((uint64_t)n_d));
+        const double l1p = std::log1p(-(double)k / n_d);
+        const double EA = -n_d * l1p, VA = std::max(0.0, n_d * ((double)k / (n_d - (double)k) + l1p));
+        const double e_samp = EA / p_acc, v_samp = EA * (1.0 - p_acc) / (p_acc * p_acc) + VA / (p_acc * p_acc);
+        bool ahead = false;
+        uint64_t lo = 0, H = 0;
+        if ((g->ahead == 2 || (g->ahead == 1 && g->sharded_rank)) && (grouped || (c->chain_only && n_draw == 1)) && g->est_ok && (uint64_t)n_d <= ((uint64_t)MAX_BINS << BIN_SHIFT) && 4.0 * (double)k <= n_d) {
+            // the interval costs what it holds (its accepted draws go through the fringe pass on the chain): g->ahead_sigma
+            // (8) standard deviations instead of the windows' 16 -- a start outside it is reported like an overflowed window
+            const double m = g->est_v > 0.0 ? g->ahead_sigma * std::sqrt(1.1 * g->est_v) + 256.0 : 0.0;
+            lo = std::max<uint64_t>(g->est_lo, (uint64_t)std::max(0.0, std::floor(g->est_e - m)));
+            H = std::max<uint64_t>(lo, std::min<uint64_t>(pos_hi, (uint64_t)std::ceil(g->est_e + m)));
+            // (a sample smaller than the uncertainty of its start stays on the chain; so does one whose start is known exactly --
+            //  behind a synchronisation the chain is empty and nothing is gained by making it wait for the prep stream)
+            static const bool ahead_first = getenv("MSIM_AHEAD_FIRST") != nullptr;
+            ahead = 2 * (H - lo) <= (uint64_t)k && (g->est_v > 0.0 || ahead_first);
+        }
+        if (g->est_ok) { g->est_e += e_samp; g->est_v += v_samp; g->est_lo += k; }
+        if (ahead) {
+            // the sample ends at or in front of e_lim (and inside its window): what the SNP stage's windows are laid out from
+            const uint64_t e_lim = est_hi(~0ull);
+            if ((rc = enqueue_sample_ahead(c, g, r, d, lo, H, e_lim, grew, sl, ahead))) return rc;
+            if (ahead) pos_hi = std::min<uint64_t>(H + sl.W, e_lim) - sl.W;      // (+ W below)
+        }
+        if (!ahead && (rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl))) return rc;
         SampleSet &S = *sl.S;
         const uint32_t W = sl.W, bmw = sl.bmw, bnb = sl.bnb;
         if (grouped) {
@@ -1029,12 +1225,20 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             }
         }
         pos_hi += W;
+        if (!ahead) pos_hi = est_hi(pos_hi);
         rec_base += k;
     }
     if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
         uint8_t *aux8 = nullptr;
         SnpDefer df{nullptr, 0, 0};
         if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr, grouped ? &df : nullptr))) return rc;
+        if (g->est_ok) {                              // a uniform() = 2 words, a transversion's randbelow(2) = a geometric(1/2) loop
+            const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
+            g->est_e += (double)K * (2.0 + 2.0 * p_tv);
+            g->est_v += (double)K * (2.0 * p_tv + 4.0 * p_tv * (1.0 - p_tv));
+            g->est_lo += 2 * K;
+            pos_hi = est_hi(pos_hi);
+        }
         if (grouped) {
             g->emit_d = (uint32_t)d;
             g->emit_items.push_back(EmitItem{ct.index, late.S, df.T, late.bmw, late.bnb, late.start, (uint32_t)K, df.W2, df.nb2,
@@ -1196,7 +1400,7 @@ static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h, F &&behind_mailbox) {
     if (h.flags & (FLAG_SAMPLE_OVERFLOW | FLAG_SNP_OVERFLOW)) {
         g->s[0].live = g->s[1].live = false;
         g->unverified = false;
-        return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its 16-sigma margin (results discarded)");
+        return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its margin (16 sigma; 8 for the start of a sample planned ahead of the chain; results discarded)");
     }
     c->t.py_words += h.pos - g->verified_pos;
     g->verified_pos = h.pos;
@@ -1300,6 +1504,7 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     M.pending = true;
     py.pos = pos_hi;                                       // bound until the next sync reads the exact value
     g->unverified = true;
+    g->est_ok = false;                                    // (the SNP sampler's estimate of the position ends here)
     ct.planned = true;
     return MSIM_OK;
 }
@@ -1356,6 +1561,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         g->ps_valid = true;
     }
     g->unverified = true;
+    g->est_ok = false;                                    // (the SNP sampler's estimate of the position ends here)
     bool grew = false;
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
     if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;          // its last emit may still read it
@@ -1668,6 +1874,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
         g->ps_valid = true;
     }
     g->unverified = true;
+    g->est_ok = false;                                    // (the SNP sampler's estimate of the position ends here)
     // word window: expected consumption of every sample + 16 sigma of the total
     uint64_t K = 0, K_pool = 0;
     uint32_t n_draw = 0;
@@ -1871,6 +2078,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
         g->ps_valid = true;
     }
     g->unverified = true;
+    g->est_ok = false;                                    // (the SNP sampler's estimate of the position ends here)
     // ---- sizes: the word window (every sample + every randint, 16 sigma of the total) and the chain length
     double e_words = 0, var = 0, e_ch = 0, var_ch = 0;
     std::vector<double> q_nsn(n_sets, 0.0), acc_min(n_sets, 1.0), q_tl(n_sets, 0.0);

@@ -472,6 +472,170 @@ __global__ __launch_bounds__(512) void k_bin_dedupe(const uint32_t *__restrict__
     for (int i = threadIdx.x; i < BIN_WORDS / 4; i += 512) g4[i] = l4[i];
 }
 
+// ---- anchored windows (plan_gpu.hip: enqueue_sample_ahead).  Where a contig's sample STARTS is known exactly only when the
+// chain of the contig before it has ended -- but the host knows it to within a few standard deviations of the words consumed
+// since the last exact position: s in [lo, H].  So the heavy part of a sample (count, scatter, de-dup) runs OFF the chain on a
+// window anchored at H, for the first k_core = K - a_max accepted draws from there (a_max bounds the accepted draws in [lo, H):
+// whatever s turns out to be, those k_core draws are consumed), and the accepted draws of [lo, H) are compacted beside it.
+// On the chain, once s is there: the accepted draws of [s, H) (h_acc of them) and the first need0 = K - D_core - h_acc draws of
+// the ordered tail list are all consumed whatever their order (each adds at most one new value), so they go into the bitmap in
+// parallel (k_ahead_fringe); the d1 values among them that were there already are what k_sample_tail's rounds still have to find.
+struct SpecHdr { uint32_t need0, d1, rsv0, rsv1; };
+constexpr int AHEAD_MAX_HEAD_BLOCKS = 1024;              // [lo, H) of at most 2 M words
+// Off the chain, launch 1 of 3 (then k_bin_scatter with raw counts, k_bin_dedupe): blocks [0, nb) count the accepted draws of the
+// core window's 2048-word blocks (k_accept_count, the window's origin as an argument); blocks [nb, nb + nbh) compact the accepted
+// draws of the head interval's blocks, in order, each into its own 2048-entry segment.  Block 0 also resets the bookkeeping.
+__global__ __launch_bounds__(ACC_THREADS) void k_ahead_count(const uint32_t *__restrict__ raw, PlanState *ps_core, PlanState *ps_head,
+                                                             SpecHdr *hdr, unsigned long long H, unsigned long long lo, uint32_t W,
+                                                             uint32_t F, uint32_t nb, uint32_t shift, uint32_t n,
+                                                             uint32_t *__restrict__ block_cnt, uint32_t *__restrict__ cursors,
+                                                             uint32_t n_cursors, uint32_t *__restrict__ hcnt,
+                                                             uint32_t *__restrict__ hacc) {
+    __shared__ uint32_t red[ACC_THREADS / 64];
+    __shared__ uint32_t part[ACC_THREADS];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ps_core->pos = H; ps_core->snp_base = H; ps_core->flags = 0; ps_core->dups = 0; ps_core->accepted_used = 0;
+        ps_head->pos = lo; ps_head->snp_base = lo; ps_head->flags = 0; ps_head->dups = 0; ps_head->accepted_used = 0;
+        hdr->need0 = 0; hdr->d1 = 0;
+    }
+    if (blockIdx.x < nb) {
+        for (uint32_t i = blockIdx.x * ACC_THREADS + threadIdx.x; i < n_cursors; i += nb * ACC_THREADS) cursors[i] = 0;
+        const uint32_t i0 = blockIdx.x * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < ACC_ITEMS; q++) {
+            uint32_t v;
+            if (i0 + q < W && accepted(raw, H + i0 + q, shift, n, v)) c++;
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) block_cnt[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        return;
+    }
+    const uint32_t hb = blockIdx.x - nb;
+    const uint32_t i0 = hb * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
+    uint32_t vals[ACC_ITEMS];
+    uint32_t mask = 0, c = 0;
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; q++) {
+        uint32_t v = 0;
+        const bool ok = i0 + q < F && accepted(raw, lo + i0 + q, shift, n, v);
+        vals[q] = v;
+        if (ok) { mask |= 1u << q; c++; }
+    }
+    part[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 1; o < ACC_THREADS; o <<= 1) {
+        const uint32_t t = threadIdx.x >= (unsigned)o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t w = hb * ACC_BLOCK + part[threadIdx.x] - c;
+#pragma unroll
+    for (int q = 0; q < ACC_ITEMS; q++)
+        if (mask & (1u << q)) hacc[w++] = vals[q];
+    if (threadIdx.x == ACC_THREADS - 1) hcnt[hb] = part[threadIdx.x];
+}
+
+constexpr int FRINGE_ITEMS = 4;
+__global__ __launch_bounds__(ACC_THREADS) void k_ahead_fringe(const uint32_t *__restrict__ raw, PlanState *__restrict__ ps,
+                                                              const PlanState *__restrict__ ps_core,
+                                                              const PlanState *__restrict__ ps_head, SpecHdr *__restrict__ hdr,
+                                                              unsigned long long lo, uint32_t F,
+                                                              const uint32_t *__restrict__ hcnt, uint32_t nbh,
+                                                              const uint32_t *__restrict__ hacc, const uint32_t *__restrict__ tail,
+                                                              uint32_t K, uint32_t k_core, uint32_t shift, uint32_t n,
+                                                              uint32_t *__restrict__ bitmap) {
+    __shared__ uint32_t red[ACC_THREADS / 64];
+    __shared__ uint32_t hoff[AHEAD_MAX_HEAD_BLOCKS + 1];   // accepted draws of [s, H) in front of head block b
+    __shared__ uint32_t wsum[ACC_THREADS / 64];
+    const unsigned long long s = ps->pos;
+    if (s < lo || s > lo + F) {                            // (uniform) the start fell outside the interval the host planned for
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
+        return;
+    }
+    const uint32_t rel = (uint32_t)(s - lo);
+    const uint32_t blk = min(rel / ACC_BLOCK, nbh);         // head block that holds s (nbh: s == H on a block border)
+    uint32_t h_acc = 0, skip = 0;
+    if (nbh) {
+        // accepted draws of [block start, s): the entries of block blk's segment that do not belong to the sample
+        {
+            const uint32_t i0 = blk * ACC_BLOCK + threadIdx.x * ACC_ITEMS;
+            uint32_t c = 0;
+#pragma unroll
+            for (int q = 0; q < ACC_ITEMS; q++) {
+                uint32_t v;
+                if (i0 + q < rel && accepted(raw, lo + i0 + q, shift, n, v)) c++;
+            }
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+            __syncthreads();
+            skip = red[0] + red[1] + red[2] + red[3];
+        }
+        // offsets of the blocks from blk on (four consecutive blocks per lane)
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            v[q] = (b >= blk && b < nbh) ? hcnt[b] - (b == blk ? skip : 0u) : 0u;
+            sum += v[q];
+        }
+        uint32_t run = wg_scan_incl(sum, wsum) - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t b = threadIdx.x * 4 + q;
+            if (b <= AHEAD_MAX_HEAD_BLOCKS) hoff[b] = run;
+            run += v[q];
+        }
+        if (threadIdx.x == ACC_THREADS - 1) hoff[AHEAD_MAX_HEAD_BLOCKS] = run;
+        __syncthreads();
+        h_acc = hoff[AHEAD_MAX_HEAD_BLOCKS];
+    }
+    const uint32_t items = K - k_core + ps_core->dups;     // = h_acc + need0
+    if (h_acc > items) {                                   // (uniform) more accepted draws in front of the anchor than a_max
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
+        return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr->need0 = items - h_acc;
+        const uint32_t fl = ps_core->flags | ps_head->flags;
+        if (fl) atomicOr(&ps->flags, fl);
+    }
+    uint32_t d = 0;
+    const uint32_t stride = gridDim.x * ACC_THREADS;
+    for (uint32_t base = blockIdx.x * ACC_THREADS + threadIdx.x; base < items; base += FRINGE_ITEMS * stride) {
+        uint32_t old[FRINGE_ITEMS], bit[FRINGE_ITEMS];
+#pragma unroll
+        for (int q = 0; q < FRINGE_ITEMS; q++) {           // the atomics back to back, then their answers
+            const uint32_t i = base + q * stride;
+            old[q] = 0; bit[q] = 0;
+            if (i < items) {
+                uint32_t v;
+                if (i < h_acc) {                           // head entry i: last block b >= blk with hoff[b] <= i
+                    uint32_t lo_b = blk, hi_b = nbh;
+                    while (hi_b - lo_b > 1) {
+                        const uint32_t mid = (lo_b + hi_b) >> 1;
+                        if (hoff[mid] <= i) lo_b = mid; else hi_b = mid;
+                    }
+                    v = hacc[lo_b * ACC_BLOCK + (i - hoff[lo_b]) + (lo_b == blk ? skip : 0u)];
+                } else {
+                    v = tail[i - h_acc];
+                }
+                if (v < n) {                               // (a list entry nobody wrote: the tail pass reports the short window)
+                    bit[q] = 1u << (v & 31);
+                    old[q] = atomicOr(&bitmap[v >> 5], bit[q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < FRINGE_ITEMS; q++) d += (old[q] & bit[q]) ? 1u : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_down(d, o, 64);
+    if ((threadIdx.x & 63) == 0 && d) atomicAdd(&hdr->d1, d);
+}
+
 // Tail rounds + exact cut.  One workgroup.  `total_acc` = accepted draws available in the window.
 // `acc` holds the accepted draws from accepted-index `acc_first` on (0: the whole list, k: tail only).
 constexpr int TAIL_LDS_OFFS = 8192;
@@ -480,8 +644,12 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ block_off, uint32_t n_blocks,
                                                       uint32_t W, uint32_t shift, uint32_t n, uint32_t k,
                                                       uint32_t *__restrict__ bitmap, PlanState *__restrict__ ps,
-                                                      uint32_t raw_counts = 0) {
+                                                      uint32_t raw_counts = 0, const PlanState *__restrict__ ps_win = nullptr,
+                                                      const SpecHdr *__restrict__ hdr = nullptr,
+                                                      unsigned long long pos_limit = ~0ull) {
     // raw_counts (n_blocks <= TAIL_LDS_OFFS): block_off holds k_accept_count's counts; their prefix sums are made here, in LDS
+    // ps_win / hdr (anchored windows, see k_ahead_fringe): the window starts at ps_win->pos, not at the chain's position; `k`
+    // is the core's share of the sample, the fringe pass has consumed hdr->need0 more accepted draws and left hdr->d1 to find
     __shared__ uint32_t red[16];
     __shared__ uint32_t s_need, s_pos, s_blk, s_total;
     __shared__ uint32_t loff[TAIL_LDS_OFFS + 1];
@@ -510,9 +678,9 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
             for (uint32_t i = threadIdx.x; i <= n_blocks; i += 1024) loff[i] = block_off[i];
         total_acc = block_off[n_blocks];
     }
-    if (threadIdx.x == 0) { s_pos = k; s_need = ps->dups; }
+    if (threadIdx.x == 0) { s_pos = hdr ? k + hdr->need0 : k; s_need = hdr ? hdr->d1 : ps->dups; }
     __syncthreads();
-    if (total_acc < k) {                                  // window too small even for the first k
+    if (total_acc < s_pos) {                              // window too small even for the first k
         if (threadIdx.x == 0) atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW);
         return;
     }
@@ -555,7 +723,7 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
     __syncthreads();
     const uint32_t b = s_blk;
     const uint32_t want = A - (offs_in_lds ? loff[b] : block_off[b]);   // 1-based rank inside block b
-    const unsigned long long p0 = ps->pos;
+    const unsigned long long p0 = ps_win ? ps_win->pos : ps->pos;
     // 1024 threads x 2 words cover the block's 2048 words in stream order
     uint32_t f[2], v;
     const uint32_t i0 = b * ACC_BLOCK + threadIdx.x * 2;
@@ -577,8 +745,10 @@ __global__ __launch_bounds__(1024) void k_sample_tail(const uint32_t *__restrict
     const uint32_t excl = incl - mine;
     if (excl < want && want <= incl) {
         const uint32_t idx = (f[0] && excl + 1 == want) ? i0 : i0 + 1;
-        ps->pos = p0 + idx + 1;
-        ps->snp_base = p0 + idx + 1;
+        unsigned long long cut = p0 + idx + 1;
+        if (cut > pos_limit) { cut = pos_limit; atomicOr(&ps->flags, FLAG_SAMPLE_OVERFLOW); }   // (beyond what the host made sure exists)
+        ps->pos = cut;
+        ps->snp_base = cut;
         ps->accepted_used = A;
     }
 }
