@@ -175,7 +175,11 @@ struct GpuPlan {
     // the words consumed since (the sampler's rejections and duplicates, the SNP draws' transversion loops), a hard lower bound
     hipStream_t prep_stream = nullptr;  //   the off-chain part of the samples: the stream of the sample being enqueued,
     hipStream_t prep_streams[8] = {};   //   one of these in turn (contigs' off-chain parts are independent of each other)
-    int n_prep = 4, prep_i = 0, prep_prio = -1;   //   (at the chain's priority: 2.3-2.6 ms for a chain-only rank at either, 2.75 against 3.2 owning three)
+    // (at the chain's priority.  A rank that owns 3 of 24 contigs: 2.8 ms per step against 3.1-3.2 with these streams at normal
+    //  priority, where the off-chain kernels fall behind beside the rank's own emission + APPLY; a rank that owns nothing would
+    //  do 2.3 instead of 2.6 at normal priority, but a second set of streams for that case left some of them sharing hardware
+    //  queues with other streams of the context: 3.9 ms -- one set, one priority)
+    int n_prep = 4, prep_i = 0, prep_prio = -1;
     double ahead_sigma = 8.0;
     uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
     // Measured (c2, 3 Gb, tools/compat_steps.py): a rank that owns every contig is bound by its emission + APPLY train either way
@@ -987,6 +991,8 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
     g->ahead_contigs++;
     c->t.snp_samples_ahead++;
+    static const bool log_ahead = getenv("MSIM_DBG_AHEAD_LOG") != nullptr;
+    if (log_ahead) fprintf(stderr, "msim: sample ahead of the chain: K %u, start in [%llu, %llu], core %u draws\n", K, (unsigned long long)lo, (unsigned long long)H, k_core);
     return MSIM_OK;
 }
 
