@@ -522,10 +522,17 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
         };
         while (s.n_chunks < need_chunks) {
             const uint32_t hi = std::min<uint32_t>(need_chunks, s.n_states);
-            // a generation batch costs ~80 us of latency whatever its size and batches queue in order, while a
-            // cascade level is ~10-30 us: the first batch waits for the second level (256 chunks) instead of
-            // going out with the 16 states of the first
-            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, (uint32_t)(MT_JUMP_RADIX[0] * MT_JUMP_RADIX[1]))) {
+            // A generation batch costs ~110-140 us of latency whatever its size and batches queue in order; a cascade level costs an
+            // extension (50 us) and its jumps, 256 of them at a time (one 88 KB workgroup per CU): ~100 us per round.  Radices
+            // 256 x 4 x 8 (round 5; 16 x 16 x 16 x 2 before): the 689 jumps of a 3 Gb -sn 0.01 session are three rounds in two
+            // launches, both on the plan stream, and ONE generation batch + ONE map pass follow -- the first chain kernel starts
+            // later than it did (0.52 ms against 0.44) but nothing of the cascade runs beside the first contigs' chains any more,
+            // which used to stretch them to 2-3 x their time: c2 4.04-4.16 -> 3.92-3.95 ms per step, a chain-only rank 2.60 -> 2.43.
+            // MSIM_GEN_FIRST_LEVELS=1: the first batch behind the first level already (256 chunks, 41 M words: the first four
+            // contigs), the second level beside their chains -- 3.96-4.01.
+            static const uint32_t first_levels = getenv("MSIM_GEN_FIRST_LEVELS") ? (uint32_t)std::max(1, atoi(getenv("MSIM_GEN_FIRST_LEVELS"))) : 2u;
+            const uint32_t first_states = first_levels >= 2 ? (uint32_t)(MT_JUMP_RADIX[0] * MT_JUMP_RADIX[1]) : (uint32_t)MT_JUMP_RADIX[0];
+            if (hi > s.n_chunks && hi >= std::min<uint32_t>(need_chunks, first_states)) {
                 // states [n_chunks, hi) are complete: generate those chunks (the session's first batch on the plan stream itself,
                 // right behind the cascade levels that ran there; later ones on the generation stream behind the jump stream)
                 const bool first = lead_on_plan && s.n_chunks == 0 && s.casc_pending;

@@ -28,7 +28,11 @@ N, M = 624, 397
 DEG = 19937
 CHUNK_BLOCKS = 256                 # one stream chunk = 256 regenerations = 159 744 words
 CHUNK = N * CHUNK_BLOCKS
-RADIX = [16, 16, 16, 2]             # 8192 chunks = 1.3 G words per cascade, 4 dependent launches
+# 8192 chunks = 1.3 G words per cascade, 3 dependent launches.  The first level is the wide one: a jump is one 88 KB workgroup, a
+# CU holds one, so 255 jumps are ONE round of the device (~65 us) -- and the 689 jumps of a 3 Gb -sn 0.01 session (255 + 2 x 256)
+# three rounds in two launches (rounds 1-4: [16, 16, 16, 2] -- 15 + 240 + 512 jumps in three launches, the last one beside the
+# first contigs' chains).  Sessions of up to 41 M words need the first level only.
+RADIX = [256, 4, 8]
 
 
 def twist(a, b, c):
