@@ -20,7 +20,7 @@ timed call order -- on the GPU, gives the oracle's bytes).
 What N > 1 means here.  The reference draws from two global generators contig after contig
 (mutator.py:111-141), so in this bit-identical mode ONE genome over N GPUs is Amdahl-bound: every rank
 walks the whole stream chain (msim_plan_chain for contigs it does not own) and only emission + APPLY are
-divided -- at most 1.6x for this workload, ~1.05x for the SV mix, whatever N ("amdahl_ceiling",
+divided -- at most 1.66x for this workload, ~1.05x for the SV mix, whatever N ("amdahl_ceiling",
 measured).  That strong-scaling number is the N > 1 headline ("one genome", BASELINE's metric); the line
 also carries what does scale: "weak_replicas" (N genomes at once, one per GPU, own seeds: linear) and
 "one_genome_sharded_fast_rng" (--rng fast: counter-based draws, NOT the reference's numbers; nothing
