@@ -1115,6 +1115,14 @@ int msim_dbg_fast_plan(msim_ctx *p, uint64_t L, const msim_range *ranges, int n_
     return MSIM_OK;
 }
 
+// test support (tests/test_ahead_moments.py, CPU tier): the moments the anchored windows are laid out from; needs no context
+int msim_dbg_stream_moments(uint64_t n, uint64_t k, uint64_t K, uint64_t ti_lim, double out[4]) {
+    if (!out || !n || k >= n) return MSIM_ERR_ARG;
+    const StreamMoments a = sample_words_moments(n, k), b = snp_words_moments(K, (unsigned long long)ti_lim);
+    out[0] = a.e; out[1] = a.v; out[2] = b.e; out[3] = b.v;
+    return MSIM_OK;
+}
+
 int msim_dbg_stream_status(msim_ctx *p, int out[8]) {
     CTX_FLUSHED(c, p)
     if (!c || !out || c->host_only || !c->gpu) return MSIM_ERR_ARG;

@@ -43,4 +43,16 @@ int gpu_plan_make_room(Ctx *c, GpuPlan *g, const msim_range *ranges, int n_range
 
 void gpu_plan_stream_status(Ctx *c, GpuPlan *g, int out[8]);
 
+// Mean and variance of the CPython stream's words one stage consumes -- what the SNP sampler's anchored windows lay out the
+// interval of a sample's start from (plan_gpu.hip: plan_contig_gpu; checked against simulation in tests/test_ahead_moments.py).
+//   sample: random.sample(range(n), k) by the set path draws until k DISTINCT values are there -- A accepted draws, a coupon
+//     collector's first k: E A = sum n/(n-i) = -n ln(1 - k/n), Var A = sum (i/n)/(1-i/n)^2 = n (k/(n-k) + ln(1 - k/n)) --,
+//     each after a geometric number of getrandbits(bits) words with success p = n / 2^bits (_randbelow's rejection):
+//     E = E A / p, Var = E A (1-p)/p^2 + Var A / p^2
+//   SNP draws of K SNPs (mutator.py:428-463): uniform() = 2 words; with probability p_tv a transversion's randint(0, 1) =
+//     _randbelow(2) = getrandbits(2) until < 2, a geometric(1/2) loop: E = K (2 + 2 p_tv), Var = K (2 p_tv + 4 p_tv (1 - p_tv))
+struct StreamMoments { double e, v; };
+StreamMoments sample_words_moments(uint64_t n, uint64_t k);
+StreamMoments snp_words_moments(uint64_t K, unsigned long long ti_lim);
+
 }  // namespace msim

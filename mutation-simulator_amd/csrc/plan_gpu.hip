@@ -1116,6 +1116,18 @@ bool gpu_emit_pending(Ctx *c, int contig, bool mark_apply) {
     return false;
 }
 
+StreamMoments sample_words_moments(uint64_t n, uint64_t k) {
+    const double n_d = (double)n, k_d = (double)k;
+    const double p_acc = n_d / (double)(1ull << bit_length64(n));
+    const double l1p = std::log1p(-k_d / n_d);
+    const double EA = -n_d * l1p, VA = std::max(0.0, n_d * (k_d / (n_d - k_d) + l1p));
+    return StreamMoments{EA / p_acc, EA * (1.0 - p_acc) / (p_acc * p_acc) + VA / (p_acc * p_acc)};
+}
+StreamMoments snp_words_moments(uint64_t K, unsigned long long ti_lim) {
+    const double p_tv = 1.0 - std::min(1.0, (double)ti_lim / 9007199254740992.0);
+    return StreamMoments{(double)K * (2.0 + 2.0 * p_tv), (double)K * (2.0 * p_tv + 4.0 * p_tv * (1.0 - p_tv))};
+}
+
 // Asynchronous: enqueues the contig's chain (stream positions) on the plan stream and its emit work
 // (records) on the emit stream; nothing is waited for.  Flags and the exact position are collected
 // by gpu_plan_finish at the next synchronising call.
@@ -1195,10 +1207,8 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         // moments of the words this sample consumes: A accepted draws until k distinct values (duplicates: a coupon collector's
         // first k), each after a geometric number of rejected words (_randbelow)
         const double n_d = (double)((r.stop - (r.k - 1) * d) - r.start);
-        const double p_acc = n_d / (double)(1ull << bit_length64((uint64_t)n_d));
-        const double l1p = std::log1p(-(double)k / n_d);
-        const double EA = -n_d * l1p, VA = std::max(0.0, n_d * ((double)k / (n_d - (double)k) + l1p));
-        const double e_samp = EA / p_acc, v_samp = EA * (1.0 - p_acc) / (p_acc * p_acc) + VA / (p_acc * p_acc);
+        const StreamMoments ms = sample_words_moments((uint64_t)n_d, (uint64_t)k);
+        const double e_samp = ms.e, v_samp = ms.v;
         bool ahead = false;
         uint64_t lo = 0, H = 0;
         if ((g->ahead == 2 || (g->ahead == 1 && g->sharded_rank)) && (grouped || (c->chain_only && n_draw == 1)) && g->est_ok && (uint64_t)n_d <= ((uint64_t)MAX_BINS << BIN_SHIFT) && 4.0 * (double)k <= n_d) {
@@ -1252,9 +1262,9 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         SnpDefer df{nullptr, 0, 0};
         if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr, grouped ? &df : nullptr))) return rc;
         if (g->est_ok) {                              // a uniform() = 2 words, a transversion's randbelow(2) = a geometric(1/2) loop
-            const double p_tv = 1.0 - std::min(1.0, (double)P.ti_lim / 9007199254740992.0);
-            g->est_e += (double)K * (2.0 + 2.0 * p_tv);
-            g->est_v += (double)K * (2.0 * p_tv + 4.0 * p_tv * (1.0 - p_tv));
+            const StreamMoments mv = snp_words_moments(K, P.ti_lim);
+            g->est_e += mv.e;
+            g->est_v += mv.v;
             g->est_lo += 2 * K;
             pos_hi = est_hi(pos_hi);
         }
