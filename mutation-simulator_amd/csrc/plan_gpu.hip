@@ -185,15 +185,15 @@ struct GpuPlan {
     uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
     // Measured (c2, 3 Gb, tools/compat_steps.py): a rank that owns every contig is bound by its emission + APPLY train either way
     // and the extra off-chain launches only slow that train (4.1 ms on the chain, 4.2-4.7 ahead); a rank of a sharded step, which
-    // walks the other ranks' contigs for their stream positions only, is bound by the chain: 2.9 -> 2.3 ms owning none of 24,
-    // 3.4 -> 2.75 owning three.  So: ahead on a context that has been asked for msim_plan_chain in this pass or the last one.
+    // walks the other ranks' contigs for their stream positions only, is bound by the chain: 2.63 -> 2.30 ms owning none of 24,
+    // 2.95 -> 2.48 owning three (profiles/r05_sharded_rank_steps.txt).  So: ahead on a context that has been asked for
+    // msim_plan_chain in this pass or the last one.
     int ahead = 1;                      //   0 never (MSIM_NO_AHEAD), 1 sharded ranks, 2 always (MSIM_AHEAD=2)
     uint32_t pass_chain_only = 0;       //   msim_plan_chain calls in this pass
     bool sharded_rank = false;          //   ... there were some in this pass or in the one before
     bool est_ok = false;
     double est_e = 0, est_v = 0;
     uint64_t est_lo = 0;
-    uint32_t ahead_contigs = 0;         //   contigs planned this way (tests)
 };
 
 static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
@@ -1002,7 +1002,6 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipEventRecord(S.chain_done, c->stream));
     out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
-    g->ahead_contigs++;
     c->t.snp_samples_ahead++;
     static const bool log_ahead = getenv("MSIM_DBG_AHEAD_LOG") != nullptr;
     if (log_ahead) fprintf(stderr, "msim: sample ahead of the chain: K %u, start in [%llu, %llu], core %u draws\n", K, (unsigned long long)lo, (unsigned long long)H, k_core);
