@@ -238,8 +238,7 @@ def cpu_baseline(sample_total: int, workload: str = "c2", n_contigs: int = 4, de
     import hashlib
 
     from oracle import oracle as orc
-    from test_gpu_parity import synth_host  # same generator as the device kernel
-    from test_host_settings import dump_sim
+    from oracle.support import dump_sim, synth_host      # (synth_host: the device generator's host twin)
     lengths = [sample_total // n_contigs] * n_contigs
     sim = build_settings(workload, lengths)
     dump = dump_sim(sim)
@@ -464,6 +463,64 @@ def fast_rng_sharded(lengths, owned, local_rank, barrier, max_over_ranks, mm, st
     return out
 
 
+def predict_scaling(measure, lengths, steps, dt_full_c2, sec, mm, n_list=(2, 4, 8)):
+    """Step time of the most loaded rank of an N-way LPT partition, on this GPU: c2 and c3 in the bit-compatible mode (the rank
+    walks every contig's stream positions, msim_plan_chain for what it does not own) and in `--rng fast` (it skips them)."""
+    from mutation_simulator_amd import _ffi
+    from mutation_simulator_amd.sharding import lpt_partition
+    out = {"what": "predicted strong scaling of ONE 3 Gb genome, from 1 GPU: full step / step of the most loaded rank of an N-way LPT "
+                   "partition of the 24 contigs (results left in HBM on the owning GPU; the RCCL gather to rank 0 is extra)",
+           "n_gpus": list(n_list)}
+    heavy = {}
+    for n in n_list:
+        parts = lpt_partition(lengths, n)
+        heavy[n] = max(parts, key=lambda part: sum(lengths[i] for i in part))
+    full = {"c2": dt_full_c2 / steps * 1e3, "c3": sec["c3"]["ms_per_step"] if "c3" in sec else None}
+    for w, k in (("c2", min(steps, 10)), ("c3", 3)):
+        if full[w] is None:
+            continue
+        row = {"full_step_ms": round(full[w], 3)}
+        for n in n_list:
+            dtn, _ = measure(w, k, 2, owned=heavy[n], step_seed=42)
+            ms = dtn / k * 1e3
+            row[str(n)] = {"rank_owns": f"{len(heavy[n])} of {len(lengths)} contigs, {sum(lengths[i] for i in heavy[n]) / 1e6:.0f} Mb",
+                           "rank_step_ms": round(ms, 3), "speedup": round(full[w] / ms, 3)}
+        out[w] = row
+    fr = sec.get("fast_rng") or {}
+    if "c2" in fr and "error" not in fr:
+        eng = _ffi.Engine(int(os.environ.get("MSIM_BENCH_DEVICE", 0)), _ffi.RNG_FAST)
+        try:
+            cids = [eng.add_contig_synthetic(L, 1000 + i) for i, L in enumerate(lengths)]
+            for w in ("c2", "c3"):
+                sim = build_settings(w, lengths)
+                tables = [mm.plan_table(ch) for ch in sim.chromosomes]
+                eng.set_params(mm.params_descriptor(sim))
+                row = {"full_step_ms": fr[w]["ms_per_step"]}
+                for n in n_list:
+                    mine = set(heavy[n])
+
+                    def step():
+                        eng.set_fast_key(42)
+                        for ch, t in zip(sim.chromosomes, tables):
+                            if ch.number in mine:
+                                eng.plan_contig(cids[ch.number], t)
+                                eng.apply_contig(cids[ch.number])
+                            else:
+                                eng.plan_chain(lengths[ch.number], t)
+                        eng.sync()
+                    for _ in range(2):
+                        step()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        step()
+                    ms = (time.perf_counter() - t0) / 5 * 1e3
+                    row[str(n)] = {"rank_step_ms": round(ms, 3), "speedup": round(fr[w]["ms_per_step"] / ms, 3)}
+                out[f"fast_rng_{w}"] = row
+        finally:
+            eng.close()
+    return out
+
+
 def _snp_only_params():
     from mutation_simulator_amd import _ffi
     p = _ffi.Params()
@@ -557,15 +614,50 @@ def step_roofline(st, dt):
             "what": "algorithmic bytes of all APPLY launches / wall time of the timed steps"}
 
 
+def spread_of(per_step_s):
+    """Spread of the timed steps' own wall times (each step ends in a synchronisation), beside the mean the headline is made of."""
+    v = sorted(x * 1e3 for x in per_step_s)
+    n = len(v)
+    if not n:
+        return None
+    med = v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+    return {"ms_per_step_min": round(v[0], 3), "ms_per_step_median": round(med, 3), "ms_per_step_max": round(v[-1], 3), "steps": n}
+
+
+def host_walk_of(st):
+    """The host-sequential stages apart from their surroundings (msim_timing, ABI 8): ns of one host core per walked item and the
+    time the walks waited for the device -- a slower host shows in the first, a slower link / device in the second."""
+    out = {}
+    run, wait = st.get("host_walk_run_ms", 0.0), st.get("host_walk_wait_ms", 0.0)
+    if st.get("host_walk_candidates"):
+        out["host_walk_ns_per_candidate"] = round(run * 1e6 / st["host_walk_candidates"], 3)
+        out["candidates_per_step"] = None                # (filled by the caller, which knows the step count)
+    elif st.get("host_cut_words"):
+        out["host_cut_ns_per_word"] = round(run * 1e6 / st["host_cut_words"], 3)
+    if out:
+        out["run_ms_total"] = round(run, 3)
+        out["wait_ms_total"] = round(wait, 3)
+    return out
+
+
 def engines_of(st, steps):
     """Which PLAN engine the contigs of a step went through (msim_timing.contigs_*)."""
     return {k[len("contigs_"):]: st[k] // steps for k in st if k.startswith("contigs_") and st[k]}
 
 
 def stages_of(st, steps):
-    return {"plan_host": round(st["plan_host_ms"] / steps, 3), "plan_gpu": round(st["plan_gpu_ms"] / steps, 3),
-            "record_upload": round(st["upload_ms"] / steps, 3), "apply_all_kernels": round(st["apply_ms"] / steps, 3),
-            "apply_rewrite_kernel": round(st["apply_kernel_ms"] / steps, 3)}
+    out = {"plan_host": round(st["plan_host_ms"] / steps, 3), "plan_gpu": round(st["plan_gpu_ms"] / steps, 3),
+           "record_upload": round(st["upload_ms"] / steps, 3), "apply_all_kernels": round(st["apply_ms"] / steps, 3),
+           "apply_rewrite_kernel": round(st["apply_kernel_ms"] / steps, 3)}
+    hw = host_walk_of(st)
+    if hw:                                              # engines with a host chain: the walk itself / its waits, per step
+        out["host_walk_run"] = round(hw.pop("run_ms_total") / steps, 3)
+        out["host_walk_wait"] = round(hw.pop("wait_ms_total") / steps, 3)
+        hw.pop("candidates_per_step", None)
+        if st.get("host_walk_candidates"):
+            hw["host_walk_candidates_per_step"] = st["host_walk_candidates"] // steps
+        out.update(hw)
+    return out
 
 
 def main():
@@ -651,6 +743,7 @@ def main():
         return float(t.item())
 
     marshal_ms = {}
+    spread = {}                                         # per workload: this rank's wall time of every timed step (last measure() of it)
 
     def measure(workload, steps, warmup, gather=False, owned=None, step_seed=None):
         owned = mine if owned is None else owned
@@ -679,12 +772,16 @@ def main():
         eng.reset_stats()
         barrier()
         marsh[0] = 0.0
+        per_step = []
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            ts = time.perf_counter()
+            step()                                      # (ends in the context's synchronisation: a step's own wall time)
+            per_step.append(time.perf_counter() - ts)
         barrier()
         dt = max_over_ranks(time.perf_counter() - t0)
         marshal_ms[workload] = round(marsh[0] / steps * 1e3, 3)
+        spread[workload] = spread_of(per_step)
         return dt, eng.stats()
 
     dt, st = measure(a.workload, a.steps, a.warmup)
@@ -696,7 +793,9 @@ def main():
         line = {
             "metric": W["metric"],
             "value": round(total * a.steps / dt / 1e6, 3), "unit": "Mbases/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            **{k: v for k, v in (spread.get(a.workload) or {}).items() if k != "steps"},      # rank 0's own steps: min / median / max
+            "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W['mode']} mode, 3 Gb 24-contig synthetic genome (GRCh38-proportioned), {W['what']}"
                                    ", CPython/NumPy-compatible MT19937 streams seeded 42/42",
@@ -793,7 +892,8 @@ def main():
         for w in ("c3", "c4", "c4sv"):
             dts, sts = measure(w, n_sec, w_sec)
             sec[w] = {"metric": WORKLOADS[w]["metric"], "value": round(sum(lengths) * n_sec / dts / 1e6, 3), "unit": "Mbases/s",
-                      "ms_per_step": round(dts / n_sec * 1e3, 3), "steps": n_sec, "warmup": w_sec,
+                      "ms_per_step": round(dts / n_sec * 1e3, 3), **{k: v for k, v in (spread.get(w) or {}).items() if k != "steps"},
+                      "steps": n_sec, "warmup": w_sec,
                       "stages_ms_per_step": stages_of(sts, n_sec), "descriptor_marshalling_ms": marshal_ms[w],
                       "plan_engines": engines_of(sts, n_sec),
                       "records_per_step": sts["records"] // n_sec,
@@ -808,6 +908,14 @@ def main():
             except Exception as e:  # noqa: BLE001  (no tmpfs / disk space: the kernels' numbers above still stand)
                 sec[key] = {"error": f"{type(e).__name__}: {e}"}
         line["secondary"] = sec
+        # What a SCALE run should show, from this one GPU: the step of the most loaded rank of an N-way LPT partition (it plans
+        # / applies what it owns and walks the others' contigs for their stream positions) against the full step -- the strong-
+        # scaling speed-up of ONE genome that 2 / 4 / 8 GPUs can reach before the gather, per mode.  A prediction to hold a
+        # measured curve against, not a measurement of N GPUs.
+        try:
+            line["predicted_one_genome_scaling"] = predict_scaling(measure, lengths, a.steps, dtf, sec, mm)
+        except Exception as e:  # noqa: BLE001
+            line["predicted_one_genome_scaling"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload, device=device)      # bounded sample: ~6-10 s of CPU work
     printed = [False]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MSIM_ABI_VERSION 7
+#define MSIM_ABI_VERSION 8
 
 /* ---- return codes ---------------------------------------------------------------------------- */
 #define MSIM_OK               0
@@ -141,6 +141,13 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
                                     and of contigs walked for their stream positions alike -- whose count / scatter / de-dup
                                     ran off the stream-position chain, on a window anchored at the host's bound of the start
                                                                                                      */
+    /* The host-sequential stages of the bit-compatible engines, apart from what surrounds them (round 6, ABI 8): a slower
+       host core shows in host_walk_run_ms per item, a slower link or device in host_walk_wait_ms -- so that "slower box" and
+       "slower code" can be told apart from one bench line.                                                              */
+    double host_walk_run_ms;     /* the host walking: boundary chains (SV mix, host chain), stream cuts (host cut)        */
+    double host_walk_wait_ms;    /* ... and waiting: for the mailbox, for the pieces of its word window / candidates      */
+    uint64_t host_walk_candidates;  /* candidates those chains walked (SV mix: the non-SNP ones; host chain: all)        */
+    uint64_t host_cut_words;     /* stream words the host-cut engine's cuts went through                                  */
 } msim_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

@@ -943,8 +943,8 @@ int dev_reserve(Ctx *c, void **p, size_t *cap, size_t want_bytes) {
 
 int ensure_scratch(Ctx *c, size_t bytes) {
     if (bytes <= c->scratch_bytes) return MSIM_OK;
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));          // the old block may still be in use
-    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    MSIM_HIP(c, wait_stream(c->stream));          // the old block may still be in use
+    MSIM_HIP(c, wait_stream(c->emit_stream));
     if (c->d_scratch) MSIM_HIP(c, hipFree(c->d_scratch));
     c->d_scratch = nullptr;
     c->scratch_bytes = 0;
@@ -976,7 +976,7 @@ int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum) {
     }
     unsigned long long h = 0;
     MSIM_HIP(c, hipMemcpyAsync(&h, d_sum, 8, hipMemcpyDeviceToHost, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     *sum = h + len * 0x9E3779B97F4A7C15ull;
     return MSIM_OK;
 }
@@ -1004,6 +1004,18 @@ int apply_finish(Ctx *c) {
         // KeyError words ride behind its lanes' work, under the same host wait.
         int state = 0;
         const bool ride = c->fast && !c->pending_apply.empty();
+        // The copies ride on the emit stream behind the lanes whose set is still pending (fast_plan_collect joins those).  An
+        // APPLY enqueued on a lane whose set was collected earlier (plan, sync, msim_apply_contig, plan more) is on none of them:
+        // the emit stream joins every such launch through the event behind it, so that no KeyError / length word is copied
+        // before the rewrite that writes it has run.  (A contig whose rewrite rode in another's batched launch -- timing_shared --
+        // is covered by that launch's event: the batch's contigs are all pending.)
+        if (ride)
+            for (int idx : c->pending_apply) {
+                if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
+                const Contig &g = c->contigs[(size_t)idx];
+                if (g.apply_pending && !g.timing_shared && g.ea2 && g.apply_stream && g.apply_stream != c->emit_stream)
+                    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, g.ea2, 0));
+            }
         const int rc = fast_plan_collect(c, ride ? enqueue_err_copies : nullptr, &state);
         if (rc) { c->pending_apply.clear(); for (auto &g : c->contigs) g.apply_pending = g.dyn_applied = false; return rc; }
         have_errs = state == 1;
@@ -1014,14 +1026,14 @@ int apply_finish(Ctx *c) {
         for (int idx : c->pending_apply) {
             if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
             hipStream_t s = c->contigs[(size_t)idx].apply_stream;
-            if (s && s != last && s != c->emit_stream) { MSIM_HIP(c, hipStreamSynchronize(s)); last = s; }
+            if (s && s != last && s != c->emit_stream) { MSIM_HIP(c, wait_stream(s)); last = s; }
         }
     }
     const size_t nc = c->contigs.size();
     if (!have_errs) {                                      // (two blocking hipMemcpy cost ~40 us each at every step boundary)
         const int rc = enqueue_err_copies(c);
         if (rc) return rc;
-        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        MSIM_HIP(c, wait_stream(c->emit_stream));
     }
     unsigned long long *errs = c->h_errs, *deltas = c->h_errs + nc;
     bool delta_mismatch = false;
@@ -1106,9 +1118,12 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         // (only what a device engine planned: a device-sized table, an SNP-only one, or one that came with its offsets and its
         //  length -- the host-chain engines' --, on the batch's stream, not in flight)
         if (!g.apply_stream || !n || !out_bound || g.apply_pending || (st && g.apply_stream != st)) continue;
+        // (a mutated contig of 4 GiB or more, or a negative length: left unmarked -- apply_contig_device takes it alone and
+        //  refuses it before anything is sized from the value)
+        if (!g.all_snp && !dyn && ((long long)g.len + g.known_delta < 0 || (long long)g.len + g.known_delta >= (1ll << 32))) continue;
         st = g.apply_stream;
         const uint32_t n_tiles = (uint32_t)((out_bound + TILE - 1) / TILE);
-        if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, hipStreamSynchronize(st));
+        if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, wait_stream(st));
         int rc = dev_reserve(c, (void **)&g.d_first, &g.cap_first, (size_t)(n_tiles + 1) * sizeof(int32_t));
         if (rc) return rc;
         if (!g.ea0) {
@@ -1225,7 +1240,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
             hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, st,
                                reinterpret_cast<const unsigned long long *>(d_sums + nb), c->h_mail);
             MSIM_HIP(c, hipGetLastError());
-            MSIM_HIP(c, hipStreamSynchronize(st));
+            MSIM_HIP(c, wait_stream(st));
             total_delta = (long long)*c->h_mail;
         }
         d_off = g.d_off;
@@ -1235,7 +1250,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
         return fail(c, MSIM_ERR_UNSUPPORTED, "mutated contig of 4 GiB or more");
     g.out_len = (uint64_t)out_len_ll;
     if (g.cap_out < g.out_len + PAD) {                     // replacing a buffer: nothing may be in flight on it
-        MSIM_HIP(c, hipStreamSynchronize(st));
+        MSIM_HIP(c, wait_stream(st));
         int rc = dev_reserve(c, (void **)&g.d_out, &g.cap_out, g.out_len + PAD);
         if (rc) return rc;
     }
@@ -1244,7 +1259,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
     int32_t *d_first = nullptr;
     if (n_tiles) {
         if (g.apply_stream) {
-            if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, hipStreamSynchronize(st));
+            if (g.cap_first < (size_t)(n_tiles + 1) * sizeof(int32_t)) MSIM_HIP(c, wait_stream(st));
             int rc = dev_reserve(c, (void **)&g.d_first, &g.cap_first, (size_t)(n_tiles + 1) * sizeof(int32_t));
             if (rc) return rc;
             d_first = g.d_first;

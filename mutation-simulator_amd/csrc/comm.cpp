@@ -219,7 +219,7 @@ int msim_gather_to_root(msim_ctx *p, int n, const int *contig_ids, const int *ow
     const int erc = g_rccl.GroupEnd();
     if (!nrc) nrc = erc;
     if (nrc) return fail(c, MSIM_ERR_HIP, std::string("RCCL gather: ") + g_rccl.GetErrorString(nrc));
-    MSIM_HIP(c, hipStreamSynchronize(st));
+    MSIM_HIP(c, wait_stream(st));
     return MSIM_OK;
 }
 
@@ -255,7 +255,7 @@ int msim_dbg_comm_loopback(msim_ctx *p, int contig, uint64_t *sum) {
     const int erc = g_rccl.GroupEnd();
     if (!nrc) nrc = erc;
     if (nrc) { (void)hipFree(buf); return fail(c, MSIM_ERR_HIP, std::string("RCCL loopback: ") + g_rccl.GetErrorString(nrc)); }
-    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    MSIM_HIP(c, wait_stream(c->emit_stream));
     rc = checksum_device(c, buf, g.out_len, sum);
     (void)hipFree(buf);
     return rc;

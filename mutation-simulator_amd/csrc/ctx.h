@@ -122,6 +122,17 @@ struct TraceRange {
 int fail(Ctx *c, int code, const std::string &msg);
 int hip_fail(Ctx *c, hipError_t e, const char *what);
 
+// Host waits for the device, with a deadline.  hipStreamSynchronize / hipEventSynchronize block for as long as the device
+// takes -- for ever when a signal is lost -- and a caller blocked inside them cannot even be interrupted (the reference cannot
+// hang: mutator.py:105-142 is a plain loop).  These poll instead (spinning for the first 2 ms: a poll also returns sooner than
+// the blocking calls' wake-up, then sleeping 50 us between queries) and give up after MSIM_WAIT_TIMEOUT_S seconds (default
+// 120, 0 = never; read when a wait leaves its spinning phase) with MSIM_WAIT_TIMED_OUT, which hip_fail words as
+// "<call>(<stream or event>): no completion within N s" -- MSIM_ERR_HIP for the caller, the device work stays queued.
+constexpr hipError_t MSIM_WAIT_TIMED_OUT = hipErrorLaunchTimeOut;
+hipError_t wait_stream(hipStream_t s);
+hipError_t wait_event(hipEvent_t ev);
+double wait_limit_seconds();
+
 #define MSIM_HIP(ctx, call)                                              \
     do {                                                                 \
         hipError_t e__ = (call);                                         \

@@ -125,7 +125,7 @@ void run_job(FileChannel &ch, const FileJob &job) {
         for (uint64_t k = 0; k < pieces && e == hipSuccess; k++) {
             const int slot = (int)(k % FILE_SLOTS);
             const auto ta = std::chrono::steady_clock::now();
-            e = hipEventSynchronize(ch.ev[slot]);
+            e = wait_event(ch.ev[slot]);
             if (e != hipSuccess) break;
             const auto tb = std::chrono::steady_clock::now();
             const uint64_t off = k * FILE_CHUNK, len = job.n - off < FILE_CHUNK ? job.n - off : FILE_CHUNK;
@@ -137,7 +137,7 @@ void run_job(FileChannel &ch, const FileJob &job) {
             }
             if (!ok) {
                 set_err(ch, MSIM_ERR_IO, why);
-                (void)hipStreamSynchronize(ch.st);
+                (void)wait_stream(ch.st);
                 break;
             }
             if (k + FILE_SLOTS < pieces) e = issue(k + FILE_SLOTS);
@@ -145,7 +145,7 @@ void run_job(FileChannel &ch, const FileJob &job) {
     }
     if (e != hipSuccess) {
         set_err(ch, MSIM_ERR_HIP, std::string("output channel: ") + hipGetErrorString(e));
-        if (ch.st) (void)hipStreamSynchronize(ch.st);
+        if (ch.st) (void)wait_stream(ch.st);
     }
     (void)close(job.fd);
     if (prof)
@@ -228,7 +228,7 @@ void channel_main(FileChannel *chp) {
         ch.cv_done.notify_all();
     }
     if (ch.st) {
-        (void)hipStreamSynchronize(ch.st);
+        (void)wait_stream(ch.st);
         for (auto &e : ch.ev) if (e) (void)hipEventDestroy(e);
         if (ch.pin) (void)hipHostFree(ch.pin);
         (void)hipStreamDestroy(ch.st);

@@ -47,8 +47,41 @@ int fail(Ctx *c, int code, const std::string &msg) {
     return code;
 }
 int hip_fail(Ctx *c, hipError_t e, const char *what) {
+    if (e == MSIM_WAIT_TIMED_OUT) {
+        char buf[160];
+        snprintf(buf, sizeof buf, ": no completion within %g s (MSIM_WAIT_TIMEOUT_S); the work it waits for is still queued or the device hangs",
+                 wait_limit_seconds());
+        return fail(c, MSIM_ERR_HIP, std::string(what) + buf);
+    }
     return fail(c, MSIM_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
+
+double wait_limit_seconds() {
+    const char *e = getenv("MSIM_WAIT_TIMEOUT_S");
+    if (!e || !*e) return 120.0;
+    const double v = atof(e);
+    return v > 0 ? v : 0.0;
+}
+
+template <class Q>
+static hipError_t wait_poll(Q &&query) {
+    hipError_t e = query();
+    if (e != hipErrorNotReady) return e;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {                                             // spinning: what nearly every wait of a step ends in
+        for (int i = 0; i < 16; i++) __builtin_ia32_pause();
+        if ((e = query()) != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    const double limit = wait_limit_seconds();
+    for (;;) {                                             // long waits (a file's last pieces, a first step's allocations): leave the core
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if ((e = query()) != hipErrorNotReady) return e;
+        if (limit > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) return MSIM_WAIT_TIMED_OUT;
+    }
+}
+hipError_t wait_stream(hipStream_t s) { return wait_poll([s]() { return hipStreamQuery(s); }); }
+hipError_t wait_event(hipEvent_t ev) { return wait_poll([ev]() { return hipEventQuery(ev); }); }
 
 struct Batch;
 static void batch_free(Ctx *c);
@@ -68,8 +101,8 @@ static int drain(Ctx *c) {
     int rc2 = apply_finish(c);                             // (collects the counter-based engine's flags and sizes too)
     if (rc) return rc;
     if (rc2) return rc2;
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    MSIM_HIP(c, wait_stream(c->stream));
+    MSIM_HIP(c, wait_stream(c->emit_stream));
     return MSIM_OK;
 }
 // The APPLYs msim_apply_contig deferred.  only_groups (the engines' flush point at the start of a host walk): an incomplete group
@@ -305,8 +338,8 @@ void msim_destroy(msim_ctx *p) {
     auto lap = [&](int i) { const auto n = std::chrono::steady_clock::now(); ph[i] += std::chrono::duration<double, std::milli>(n - tp).count(); tp = n; };
     (void)hipSetDevice(c->device);
     file_io_destroy(c);                                    // (finishes what is queued for the output files first)
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->emit_stream);
+    (void)wait_stream(c->stream);
+    (void)wait_stream(c->emit_stream);
     lap(0);
     for (auto &g : c->contigs) (void)free_contig(c, g, false);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -412,7 +445,7 @@ int msim_add_contig(msim_ctx *p, const uint8_t *bases, uint64_t len, int *contig
     if (rc) return rc;
     if (!c->host_only) {
         if (len) MSIM_HIP(c, hipMemcpyAsync(g->d_in + PAD, bases, len, hipMemcpyHostToDevice, c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        MSIM_HIP(c, wait_stream(c->stream));
     }
     *contig = (int)c->contigs.size() - 1;
     return MSIM_OK;
@@ -427,7 +460,7 @@ int msim_add_contig_synthetic(msim_ctx *p, uint64_t len, uint64_t seed, int *con
     if (rc) return rc;
     rc = synth_contig_device(c, g->d_in + PAD, len, seed);
     if (rc) return rc;
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     *contig = (int)c->contigs.size() - 1;
     return MSIM_OK;
 }
@@ -449,7 +482,7 @@ int msim_read_contig(msim_ctx *p, int contig, uint64_t offset, uint64_t n, uint8
     if (!g) return MSIM_ERR_ARG;
     if (offset > g->len || n > g->len - offset) return fail(c, MSIM_ERR_ARG, "read beyond contig end");
     if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_in + PAD + offset, n, hipMemcpyDeviceToHost, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     return MSIM_OK;
 }
 
@@ -545,6 +578,7 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
         static const int force_at = getenv("MSIM_DBG_FORCE_OVERFLOW") ? atoi(getenv("MSIM_DBG_FORCE_OVERFLOW")) : 0;
         static int device_plans = 0;
         if (!rc && force_at && ++device_plans == force_at) rc = gpu_plan_force_overflow(c, c->gpu);
+        if (rc == MSIM_ERR_HIP) gpu_plan_abandon(c->gpu);      // (a wait's deadline, a failed call: nothing of this session is known any more)
         const int frc = flush_deferred_apply(c, rc == MSIM_OK);   // (an engine that failed never reached its flush point; a single
                                                                    //  contig left waiting by design stays for its successor)
         g->defer_apply = !rc && host_chain && !c->chain_only;
@@ -589,7 +623,7 @@ static int plan_dispatch(Ctx *c, Contig *g, int contig, const msim_range *ranges
     if (rc) return rc;
     if (g->pool_len)
         MSIM_HIP(c, hipMemcpyAsync(g->d_pool + PAD, hp.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     c->t.upload_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     g->planned = true;
     return MSIM_OK;
@@ -714,7 +748,7 @@ int msim_fetch_sequence(msim_ctx *p, int contig, uint64_t offset, uint64_t n, ui
     }
     if (offset > g->out_len || n > g->out_len - offset) return fail(c, MSIM_ERR_ARG, "fetch beyond mutated contig end");
     if (n) MSIM_HIP(c, hipMemcpyAsync(dst, g->d_out + offset, n, hipMemcpyDeviceToHost, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     return MSIM_OK;
 }
 
@@ -737,7 +771,7 @@ int msim_fetch_records(msim_ctx *p, int contig, msim_record *dst, uint8_t *pool_
         MSIM_HIP(c, hipMemcpyAsync(dst, g->d_recs, g->n_rec * sizeof(msim_record), hipMemcpyDeviceToHost, c->stream));
     if (pool_dst && g->pool_len)
         MSIM_HIP(c, hipMemcpyAsync(pool_dst, g->d_pool + PAD, g->pool_len, hipMemcpyDeviceToHost, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     return MSIM_OK;
 }
 
@@ -802,7 +836,7 @@ static int text_copy_out(Ctx *c, uint8_t *out, uint64_t cap, uint64_t *needed) {
     if (!out) return MSIM_OK;
     if (cap < c->text_len) return fail(c, MSIM_ERR_ARG, "text buffer too small (see *needed)");
     if (c->text_len) MSIM_HIP(c, hipMemcpyAsync(out, c->d_text, c->text_len, hipMemcpyDeviceToHost, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     return MSIM_OK;
 }
 
@@ -1127,6 +1161,21 @@ int msim_dbg_stream_status(msim_ctx *p, int out[8]) {
     CTX_FLUSHED(c, p)
     if (!c || !out || c->host_only || !c->gpu) return MSIM_ERR_ARG;
     gpu_plan_stream_status(c, c->gpu, out);
+    return MSIM_OK;
+}
+
+// test support (tests/test_gpu_waits.py): `ms` milliseconds of a one-lane kernel that does nothing, on the plan stream
+// (which = 0) or the emit stream (1) -- bounded by the device's 100 MHz wall clock, so the queue always drains -- for the
+// deadline of the host waits (ctx.h: wait_stream / wait_event, MSIM_WAIT_TIMEOUT_S) to be met by a wait that is really kept waiting
+__global__ void k_dbg_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+int msim_dbg_stall(msim_ctx *p, int which, uint32_t ms) {
+    Ctx *c = C(p);
+    if (!c || c->host_only || which < 0 || which > 1 || ms > 10000) return MSIM_ERR_ARG;
+    hipLaunchKernelGGL(k_dbg_stall, dim3(1), dim3(1), 0, which ? c->emit_stream : c->stream, (unsigned long long)ms * 100000ull);
+    MSIM_HIP(c, hipGetLastError());
     return MSIM_OK;
 }
 
@@ -1508,7 +1557,7 @@ int msim_batch_run(msim_ctx *p, const msim_batch_contig *contigs, int n) {
     rc = dev_reserve(c, (void **)&g->d_pool, &g->cap_pool, g->pool_len + 2 * PAD);
     if (rc) return rc;
     if (g->pool_len) MSIM_HIP(c, hipMemcpyAsync(g->d_pool + PAD, B.pool.data(), g->pool_len, hipMemcpyHostToDevice, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));          // (the uploads read pageable vectors; APPLY runs on the emit stream)
+    MSIM_HIP(c, wait_stream(c->stream));          // (the uploads read pageable vectors; APPLY runs on the emit stream)
     g->planned = true;
     rc = apply_contig_device(c, *g);
     if (rc) return rc;

@@ -129,7 +129,7 @@ template <class T>
 int dev_grow(Ctx *c, FastPlan *f, DevBuf<T> &b, size_t want) {
     if (b.cap >= want) return MSIM_OK;
     // a buffer is replaced: nothing that may still use the old one can be in flight
-    for (auto st : f->lane) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+    for (auto st : f->lane) if (st) MSIM_HIP(c, wait_stream(st));
     if (b.p) MSIM_HIP(c, hipFree(b.p));
     b.p = nullptr; b.cap = 0;
     const size_t n = want + want / 4 + 1024;
@@ -297,7 +297,7 @@ int ensure_plan(Ctx *c) {
 void fast_plan_destroy(Ctx *c) {
     FastPlan *f = c->fast;
     if (!f) return;
-    for (auto st : f->lane) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto st : f->lane) if (st) { (void)wait_stream(st); (void)hipStreamDestroy(st); }
     for (auto &s : f->set) {
         void *bufs[] = {s.tab.p, s.leaves.p, s.sub_k.p, s.sub_c0.p, s.cand_pos.p, s.cand_stop.p, s.cand_bend.p, s.cand_end2.p, s.blk_out.p, s.off_dummy.p, s.kept.p,
                         s.cand_meta.p, s.blk_u32.p, s.blk_delta.p};
@@ -366,9 +366,9 @@ int fast_plan_collect(Ctx *c, int (*behind)(Ctx *), int *behind_state) {
             if (brc) return brc;
             if (behind_state) *behind_state = 1;
         }
-        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        MSIM_HIP(c, wait_stream(c->emit_stream));
         for (int i = 0; i < F_SETS; i++)                   // (done by now: the emit stream waited for them)
-            if (f->set[i].pending) MSIM_HIP(c, hipEventSynchronize(f->t1[i]));
+            if (f->set[i].pending) MSIM_HIP(c, wait_event(f->t1[i]));
         float ms = 0;
         for (int i = 0; i < F_SETS; i++) {                 // (first batch's start to the end of the lane that finished last)
             if (!f->set[i].pending) continue;
@@ -446,7 +446,7 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
     hipStream_t st = f->lane[li];
     c->fast->prof.start();
     if (S.pending) {                                       // its last user (a few batches ago) may still be in flight on this stream
-        MSIM_HIP(c, hipStreamSynchronize(st));
+        MSIM_HIP(c, wait_stream(st));
         S.pending = false;
     }
     c->fast->prof.lap(1);
@@ -515,9 +515,9 @@ static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only) {
                 const size_t want = (size_t)P.K * sizeof(msim_record);
                 const size_t want_pool = (size_t)P.pool_cap + 2 * PAD, want_off = P.all_sn ? 0 : (size_t)P.K * sizeof(uint32_t);
                 if (ct.cap_recs < want || ct.cap_pool < want_pool || ct.cap_off < want_off) {
-                    MSIM_HIP(c, hipStreamSynchronize(c->stream));
-                    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
-                    if (ct.apply_stream) MSIM_HIP(c, hipStreamSynchronize(ct.apply_stream));
+                    MSIM_HIP(c, wait_stream(c->stream));
+                    MSIM_HIP(c, wait_stream(c->emit_stream));
+                    if (ct.apply_stream) MSIM_HIP(c, wait_stream(ct.apply_stream));
                 } else if (ct.apply_pending && ct.ea2) {
                     MSIM_HIP(c, hipStreamWaitEvent(st, ct.ea2, 0));
                 }

@@ -37,6 +37,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
 int gpu_emit_flush(Ctx *c);
 bool gpu_emit_pending(Ctx *c, int contig, bool mark_apply);
 int gpu_plan_force_overflow(Ctx *c, GpuPlan *g);          // test support
+void gpu_plan_abandon(GpuPlan *g);                        // a device engine failed mid-contig: the session is over
 // before a contig goes to a device engine: room for its windows in the current session's jump-table span, re-basing the session
 // where there is not (*fits = false: no span holds it -- the host planner's)
 int gpu_plan_make_room(Ctx *c, GpuPlan *g, const msim_range *ranges, int n_ranges, bool *fits);

@@ -199,9 +199,9 @@ struct GpuPlan {
 static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
     if (*cap >= want_bytes) return MSIM_OK;
     if (!*grew) {                         // a buffer is about to be replaced: nothing may be in flight
-        if (c->gpu) for (auto st : c->gpu->prep_streams) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+        if (c->gpu) for (auto st : c->gpu->prep_streams) if (st) MSIM_HIP(c, wait_stream(st));
+        MSIM_HIP(c, wait_stream(c->stream));
+        MSIM_HIP(c, wait_stream(c->emit_stream));
         *grew = true;
     }
     if (*p) MSIM_HIP(c, hipFree(*p));
@@ -258,9 +258,9 @@ static void host_stage_free(void *p) {
 
 void gpu_plan_destroy(GpuPlan *g) {
     if (!g) return;
-    if (g->jump_stream) { (void)hipStreamSynchronize(g->jump_stream); (void)hipStreamDestroy(g->jump_stream); }
-    if (g->gen_stream) { (void)hipStreamSynchronize(g->gen_stream); (void)hipStreamDestroy(g->gen_stream); }
-    for (auto st : g->prep_streams) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    if (g->jump_stream) { (void)wait_stream(g->jump_stream); (void)hipStreamDestroy(g->jump_stream); }
+    if (g->gen_stream) { (void)wait_stream(g->gen_stream); (void)hipStreamDestroy(g->gen_stream); }
+    for (auto st : g->prep_streams) if (st) { (void)wait_stream(st); (void)hipStreamDestroy(st); }
     for (auto &s : g->s) {
         if (s.d_raw) (void)hipFree(s.d_raw);
         if (s.d_states) (void)hipFree(s.d_states);
@@ -323,6 +323,22 @@ void gpu_plan_invalidate(GpuPlan *g) {
     g->unit = g->snp_unit = g->mixed_unit = 0;            // a new pass: contig i meets scratch set i again (sizes fit)
     g->sharded_rank = g->pass_chain_only > 0;
     g->pass_chain_only = 0;
+    // The anchored windows' side streams live as long as the context is a rank of a sharded step.  They sit at the plan
+    // stream's priority, where the device offers two hardware queues: left behind by a pass that walked other ranks' contigs
+    // (bench.py's chain-only steps), they shared those queues with the plan stream of every later pass -- the SV-mix engine's
+    // plan spans 7.3 -> 10.3 ms per 3 Gb step, its host walks' waits with them (round 5's c3 84 instead of 94 Gbases/s in the
+    // driver's line, which measures c3 behind such steps; scratch A/B in NOTES section 10).  MSIM_KEEP_PREP_STREAMS: the old way.
+    static const bool keep_prep = getenv("MSIM_KEEP_PREP_STREAMS") != nullptr;
+    if (!g->sharded_rank && g->ahead != 2 && !keep_prep) {
+        for (auto &st : g->prep_streams) {
+            if (!st) continue;
+            (void)wait_stream(st);                         // (idle: every caller has drained the context)
+            (void)hipStreamDestroy(st);
+            st = nullptr;
+        }
+        g->prep_stream = nullptr;
+        for (auto &w : g->prep_waited) w = 0;
+    }
     for (auto &s : g->s) {
         if (s.live) s.last_session_words = std::max<uint64_t>(s.pos, s.max_upto);
         s.live = false;
@@ -470,11 +486,11 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
         }
         const uint64_t want_cap = MT_N + (uint64_t)need_chunks * MT_CHUNK_WORDS;
         if (want_states > s.states_cap || want_cap > s.cap) {      // grow (rare): quiesce every stream first
-            MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));
-            MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
-            for (auto st : g->prep_streams) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));     // record emission reads the word arrays too
+            MSIM_HIP(c, wait_stream(g->jump_stream));
+            MSIM_HIP(c, wait_stream(g->gen_stream));
+            for (auto st : g->prep_streams) if (st) MSIM_HIP(c, wait_stream(st));
+            MSIM_HIP(c, wait_stream(c->stream));
+            MSIM_HIP(c, wait_stream(c->emit_stream));     // record emission reads the word arrays too
             if (want_states > s.states_cap) {
                 uint32_t *ns = nullptr;
                 MSIM_HIP(c, hipMalloc(&ns, (size_t)want_states * MT_N * sizeof(uint32_t)));
@@ -601,8 +617,8 @@ static int ensure_words(Ctx *c, GpuPlan *g, int si, uint64_t upto, bool maps = t
                 if (!on_plan) { const int rcj = join_plan_cascade(); if (rcj) return rcj; }
                 if (s.z_lvl != (int)s.lvl) {               // extend this level's source states once
                     if (s.z_cap < s.n_src) {
-                        MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));   // the old buffer may still be read
-                        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+                        MSIM_HIP(c, wait_stream(g->jump_stream));   // the old buffer may still be read
+                        MSIM_HIP(c, wait_stream(c->stream));
                         if (s.d_z) MSIM_HIP(c, hipFree(s.d_z));
                         s.d_z = nullptr; s.z_cap = 0;
                         MSIM_HIP(c, hipMalloc(&s.d_z, (size_t)s.n_src * JUMP_ZP * sizeof(uint32_t)));
@@ -661,15 +677,15 @@ static int stream_to_device(Ctx *c, GpuPlan *g, int si) {
         int rc0 = ensure_side_streams(c, g);
         if (rc0) return rc0;
     }
-    MSIM_HIP(c, hipStreamSynchronize(g->jump_stream));     // nothing of the old session in flight
-    MSIM_HIP(c, hipStreamSynchronize(g->gen_stream));
-    for (auto st : g->prep_streams) if (st) MSIM_HIP(c, hipStreamSynchronize(st));
+    MSIM_HIP(c, wait_stream(g->jump_stream));     // nothing of the old session in flight
+    MSIM_HIP(c, wait_stream(g->gen_stream));
+    for (auto st : g->prep_streams) if (st) MSIM_HIP(c, wait_stream(st));
     // the state goes through a pinned staging slot (one per stream), so the copies need no host synchronisation:
     // h.mt may change right after; the slot is rewritten only once the copies that read it are known to be done,
     // and the side streams are ordered behind the copies by the same event
     if (!g->h_seed) MSIM_HIP(c, hipHostMalloc(&g->h_seed, 2 * sizeof h.mt, hipHostMallocDefault));
     if (!g->seed_ev[si]) MSIM_HIP(c, hipEventCreateWithFlags(&g->seed_ev[si], hipEventDisableTiming));
-    else MSIM_HIP(c, hipEventSynchronize(g->seed_ev[si]));
+    else MSIM_HIP(c, wait_event(g->seed_ev[si]));
     uint32_t *slot = g->h_seed + (size_t)si * MT_N;
     memcpy(slot, h.mt, sizeof h.mt);
     MSIM_HIP(c, hipMemcpyAsync(s.d_states, slot, sizeof h.mt, hipMemcpyHostToDevice, c->stream));
@@ -718,7 +734,7 @@ int gpu_plan_sync_to_host(Ctx *c, GpuPlan *g) {
             MSIM_HIP(c, hipMemcpyAsync(h.mt, s.d_raw, sizeof h.mt, hipMemcpyDeviceToHost, c->stream));
             h.idx = (int)consumed;
         }
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        MSIM_HIP(c, wait_stream(c->stream));
         h.state_changed();
         s.last_session_words = std::max<uint64_t>(s.pos, s.max_upto);
         s.live = false;
@@ -765,8 +781,8 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1), 0, c->stream, g->d_ps, g->h_mail);
     MSIM_HIP(c, hipGetLastError());
     MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
-    MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+    MSIM_HIP(c, wait_stream(c->stream));
+    MSIM_HIP(c, wait_stream(c->emit_stream));
     float ms = 0;
     MSIM_HIP(c, hipEventElapsedTime(&ms, g->t0, g->t1));
     c->t.plan_gpu_ms += ms;
@@ -787,6 +803,16 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
 }
 
 // test support (MSIM_DBG_FORCE_OVERFLOW): what a 16-sigma window overflow leaves behind
+// A device engine gave up in the middle of a contig (a host wait met its deadline, a HIP call failed): whatever the device
+// streams' session holds is no longer a position the host knows.  The session ends here -- the next plan starts from the host
+// generators, which the caller sets (msim_seed / msim_set_mt_state: mutator.py restores them before it re-plans).
+void gpu_plan_abandon(GpuPlan *g) {
+    g->s[0].live = g->s[1].live = false;
+    g->unverified = false;
+    g->ps_valid = false;
+    g->est_ok = false;
+}
+
 int gpu_plan_force_overflow(Ctx *c, GpuPlan *g) {
     if (!g->d_ps) return MSIM_OK;
     hipLaunchKernelGGL(k_raise_flag, dim3(1), dim3(1), 0, c->stream, g->d_ps, (uint32_t)FLAG_SAMPLE_OVERFLOW);
@@ -816,8 +842,11 @@ static int wait_if_pending(Ctx *c, bool &pending, hipEvent_t ev) {
 struct SampleLaunch { SampleSet *S; uint32_t W, bmw, bnb; };
 // raw_other / ps_other: a word buffer and a bookkeeping block of the caller's instead of the CPython stream's (the fast RNG
 // mode samples every contig from words of its own, position 0: nothing to generate, nothing chained).
+// e_limit: the host's (tighter) bound of where the sample ends -- the next stage's window is laid out from min(pos_hi + W,
+// e_limit), so a cut beyond that raises the overflow flag instead of letting the next stage read words nobody made.
 static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t d, uint64_t pos_hi, bool &grew,
-                                SampleLaunch &out, const uint32_t *raw_other = nullptr, PlanState *ps_other = nullptr) {
+                                SampleLaunch &out, const uint32_t *raw_other = nullptr, PlanState *ps_other = nullptr,
+                                uint64_t e_limit = ~0ull) {
     const uint32_t *raw = raw_other ? raw_other : g->s[0].d_raw;
     PlanState *ps = ps_other ? ps_other : g->d_ps;
     int rc;
@@ -847,6 +876,7 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
         if ((rc = ensure_words(c, g, 0, pos_hi + W + 1, false))) return rc;
         raw = g->s[0].d_raw;                               // (may have been reallocated)
     }
+    const uint64_t pos_limit = (raw_other || e_limit == ~0ull) ? ~0ull : std::min<uint64_t>(pos_hi + W, e_limit);
     // ---- chain (plan stream): where does this sample end?
     const uint32_t n_bins = (uint32_t)((n + BIN_VALUES - 1) >> BIN_SHIFT);
     const bool binned = n_bins <= (uint32_t)MAX_BINS;
@@ -880,14 +910,16 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
         hipLaunchKernelGGL(k_bin_dedupe, dim3(n_bins), dim3(512), 0, c->stream, S.bins, S.cursors, bin_cap, S.bitmap,
                            ps);
         hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, raw, S.acc, k, S.cnt, nb, W,
-                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, ps, raw_counts);
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, ps, raw_counts, (const PlanState *)nullptr,
+                           (const SpecHdr *)nullptr, (unsigned long long)pos_limit);
     } else {
         MSIM_HIP(c, hipMemsetAsync(S.bitmap, 0, bm_words64 * 8, c->stream));
         hipLaunchKernelGGL(k_accept_scatter, dim3(nb), dim3(ACC_THREADS), 0, c->stream, raw, ps, W,
                            (uint32_t)(32 - bits), (uint32_t)n, S.cnt, S.acc);
         hipLaunchKernelGGL(k_bitmap_insert, dim3((k + 1023) / 1024), dim3(256), 0, c->stream, S.acc, k, S.bitmap, ps);
         hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, raw, S.acc, 0u, S.cnt, nb, W,
-                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, ps);
+                           (uint32_t)(32 - bits), (uint32_t)n, k, S.bitmap, ps, 0u, (const PlanState *)nullptr,
+                           (const SpecHdr *)nullptr, (unsigned long long)pos_limit);
     }
     MSIM_HIP(c, hipGetLastError());
     out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
@@ -1015,7 +1047,7 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
 // caller launches the bitmap expansion behind this stage and hands it that array (*aux8_out).
 // defer (with aux8_out): the emit pass is not launched here at all -- the caller queues it for the contig's emission group.
 static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const uint32_t *sn_index, uint64_t &pos_hi, bool &grew,
-                             uint8_t **aux8_out = nullptr, SnpDefer *defer = nullptr) {
+                             uint8_t **aux8_out = nullptr, SnpDefer *defer = nullptr, uint64_t e_limit = ~0ull) {
     const msim_params &P = c->params;
     GpuStream &py = g->s[0];
     int rc;
@@ -1043,7 +1075,8 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
         py.maps_ti_lim = P.ti_lim;
     }
     hipLaunchKernelGGL(k_snp_scan_cut_abs, dim3(1), dim3(SNP_THREADS), 0, c->stream, py.d_lanes, g->d_ps, W2,
-                       py.d_maps, T.maps, nb2, (uint32_t)K, T.base);
+                       py.d_maps, T.maps, nb2, (uint32_t)K, T.base,
+                       (unsigned long long)(e_limit == ~0ull ? ~0ull : std::min<uint64_t>(pos_hi + W2, e_limit)));
     MSIM_HIP(c, hipGetLastError());
     if (defer) { defer->T = &T; defer->W2 = W2; defer->nb2 = nb2; }
     if (!c->chain_only && !defer) {                       // (chain only: where the draws END is all that is wanted)
@@ -1146,8 +1179,8 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     if (!c->chain_only) {   // the record table may still be read by an earlier apply of this contig
         const size_t want = std::max<uint64_t>(K, 1) * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+            MSIM_HIP(c, wait_stream(c->stream));
+            MSIM_HIP(c, wait_stream(c->emit_stream));
         }
         if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
         if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
@@ -1228,7 +1261,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
             if ((rc = enqueue_sample_ahead(c, g, r, d, lo, H, e_lim, grew, sl, ahead))) return rc;
             if (ahead) pos_hi = std::min<uint64_t>(H + sl.W, e_lim) - sl.W;      // (+ W below)
         }
-        if (!ahead && (rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl))) return rc;
+        if (!ahead && (rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl, nullptr, nullptr, est_hi(~0ull)))) return rc;
         SampleSet &S = *sl.S;
         const uint32_t W = sl.W, bmw = sl.bmw, bnb = sl.bnb;
         if (grouped) {
@@ -1259,14 +1292,15 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     if (K) {                                          // SNP draws in position order (chain: scan + cut; aux off the chain)
         uint8_t *aux8 = nullptr;
         SnpDefer df{nullptr, 0, 0};
-        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr, grouped ? &df : nullptr))) return rc;
         if (g->est_ok) {                              // a uniform() = 2 words, a transversion's randbelow(2) = a geometric(1/2) loop
             const StreamMoments mv = snp_words_moments(K, P.ti_lim);
             g->est_e += mv.e;
             g->est_v += mv.v;
             g->est_lo += 2 * K;
-            pos_hi = est_hi(pos_hi);
         }
+        // (est_hi(~0): the bound the position is tightened to behind this stage -- the kernel flags a cut beyond it)
+        if ((rc = enqueue_snp_stage(c, g, ct, K, nullptr, pos_hi, grew, late.S ? &aux8 : nullptr, grouped ? &df : nullptr, est_hi(~0ull)))) return rc;
+        pos_hi = est_hi(pos_hi);
         if (grouped) {
             g->emit_d = (uint32_t)d;
             g->emit_items.push_back(EmitItem{ct.index, late.S, df.T, late.bmw, late.bnb, late.start, (uint32_t)K, df.W2, df.nb2,
@@ -1365,8 +1399,11 @@ static inline void cpu_relax() {
 }
 
 // Wait for a word in pinned host memory that a kernel on `s` raises to `want`.  The stream is queried now and then so
-// that a failed launch or a device fault ends the wait with an error instead of a hang.
+// that a failed launch or a device fault ends the wait with an error instead of a hang; a stream that neither drains nor
+// raises the word ends it at the deadline of every host wait (ctx.h: MSIM_WAIT_TIMEOUT_S).
 static int spin_until(Ctx *c, const uint32_t *word, uint32_t want, hipStream_t s) {
+    std::chrono::steady_clock::time_point t0{};
+    double limit = -1;
     for (uint64_t it = 1;; it++) {
         if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return MSIM_OK;
         cpu_relax();
@@ -1377,16 +1414,26 @@ static int spin_until(Ctx *c, const uint32_t *word, uint32_t want, hipStream_t s
                 return fail(c, MSIM_ERR_HIP, "plan stream drained without raising its signal");
             }
             if (e != hipErrorNotReady) return hip_fail(c, e, "hipStreamQuery(plan stream)");
+            const auto now = std::chrono::steady_clock::now();
+            if (limit < 0) { t0 = now; limit = wait_limit_seconds(); }
+            else if (limit > 0 && std::chrono::duration<double>(now - t0).count() > limit)
+                return hip_fail(c, MSIM_WAIT_TIMED_OUT, "spin_until(mailbox signal of the plan stream)");
         }
     }
 }
 
-static int spin_event(Ctx *c, hipEvent_t ev) {
-    for (;;) {
+// (an event the host chain is about to need: polled without a pause -- it is microseconds away; `what` names it at the deadline)
+static int spin_event(Ctx *c, hipEvent_t ev, const char *what = "spin_event(copy piece of the host chain)") {
+    for (uint32_t it = 1;; it++) {
         const hipError_t e = hipEventQuery(ev);
         if (e == hipSuccess) return MSIM_OK;
         if (e != hipErrorNotReady) return hip_fail(c, e, "hipEventQuery");
         cpu_relax();
+        if ((it & 0xfff) == 0) {                           // ~ every few ms: hand over to the bounded wait
+            const hipError_t w = wait_event(ev);
+            if (w == hipSuccess) return MSIM_OK;
+            return hip_fail(c, w, what);
+        }
     }
 }
 
@@ -1421,7 +1468,7 @@ static int mixed_poll(Ctx *c, GpuPlan *g, PlanState &h, F &&behind_mailbox) {
     if ((rc = spin_until(c, g->h_sig, g->epoch, c->stream))) return rc;
     float ms = 0;
     hipError_t e = hipEventElapsedTime(&ms, g->t0, g->t1);
-    if (e == hipErrorNotReady) { MSIM_HIP(c, hipEventSynchronize(g->t1)); e = hipEventElapsedTime(&ms, g->t0, g->t1); }
+    if (e == hipErrorNotReady) { MSIM_HIP(c, wait_event(g->t1)); e = hipEventElapsedTime(&ms, g->t0, g->t1); }
     MSIM_HIP(c, e);
     c->t.plan_gpu_ms += ms;
     h = *g->h_mail;
@@ -1496,8 +1543,8 @@ static int mixed_emit(Ctx *c, GpuPlan *g, Contig &ct, MixedSet &M, uint32_t k, u
     if (!c->chain_only) {   // the record table / pool may still be read by an earlier apply of this contig
         const size_t want = std::max<uint64_t>(n_rec, 1) * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < pool_len + 2 * PAD) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+            MSIM_HIP(c, wait_stream(c->stream));
+            MSIM_HIP(c, wait_stream(c->emit_stream));
         }
         if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
         if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, pool_len + 2 * PAD))) return rc;
@@ -1560,7 +1607,7 @@ static int mixed_link_translocations(Ctx *c, GpuPlan *g, MixedSet &M, uint32_t n
                            M.words);
         MSIM_HIP(c, hipGetLastError());
         MSIM_HIP(c, hipMemcpyAsync(g->h_win, M.words, (size_t)Wl * 4, hipMemcpyDeviceToHost, c->stream));
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));
+        MSIM_HIP(c, wait_stream(c->stream));
     }
     size_t used = 0;
     if ((rc = link_translocations(c, g->h_win, Wl, g->h_npos, g->h_ntype, g->h_nstop, g->h_nextra, g->h_naux, n_nsn, &used))) return rc;
@@ -1601,8 +1648,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     if ((rc = grow(c, (void **)&M.nsn_pos, &M.cap_npos, (size_t)k * 4 + 64, &grew))) return rc;
     if ((rc = grow(c, (void **)&M.nsn_type, &M.cap_ntype, (size_t)k + 64, &grew))) return rc;
     if (g->cap_h_npos < (size_t)k * 4 + 64 || g->cap_h_ntype < (size_t)k + 64 || g->cap_h_nstop < (size_t)k * 4 + 64) {
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
-        if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+        MSIM_HIP(c, wait_stream(c->stream));     // an earlier contig's copies may still use the old blocks
+        if (g->copy_stream) MSIM_HIP(c, wait_stream(g->copy_stream));
         if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)k * 4 + 64))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_ntype, &g->cap_h_ntype, (size_t)k + 64))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_nstop, &g->cap_h_nstop, (size_t)k * 4 + 64))) return rc;
@@ -1618,8 +1665,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         if ((rc = grow(c, (void **)&M.nsn_extra, &M.cap_nextra, (size_t)k * 4 + 64, &grew))) return rc;
         if ((rc = grow(c, (void **)&M.nsn_aux, &M.cap_naux, (size_t)k + 64, &grew))) return rc;
         if (g->cap_h_nextra < (size_t)k * 4 + 64 || g->cap_h_naux < (size_t)k + 64) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+            MSIM_HIP(c, wait_stream(c->stream));
+            if (g->copy_stream) MSIM_HIP(c, wait_stream(g->copy_stream));
             if ((rc = grow_host(c, (void **)&g->h_nextra, &g->cap_h_nextra, (size_t)k * 4 + 64))) return rc;
             if ((rc = grow_host(c, (void **)&g->h_naux, &g->cap_h_naux, (size_t)k + 64))) return rc;
         }
@@ -1695,7 +1742,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     if (early) {
         const size_t bytes = ((size_t)(Wb_hi + 1) << lg) * 4;
         if (g->cap_h_words < bytes) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
+            MSIM_HIP(c, wait_stream(c->stream));
             if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, bytes))) return rc;
         }
         if ((rc = grow(c, (void **)&M.words, &M.cap_words, bytes, &grew))) return rc;
@@ -1730,7 +1777,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
     // ---- 2. the sequential chain over the non-SNP candidates, on the host
     size_t consumed = 0;
     const bool early_ok = early && n_nsn > 0 && n_nsn <= n_hi;    // (beyond 16 sigma: the window is built again, exactly, below)
-    if (early && !early_ok) MSIM_HIP(c, hipStreamSynchronize(c->stream));   // nobody reads that table: the blocks are free again
+    if (early && !early_ok) MSIM_HIP(c, wait_stream(c->stream));   // nobody reads that table: the blocks are free again
     if (n_nsn) {
         const double wb = window_of((double)n_nsn);
         if (wb >= 4.0e9) return fail(c, MSIM_ERR_UNSUPPORTED, "boundary window beyond 2^32 words");
@@ -1738,7 +1785,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
         const size_t words_bytes = tables ? ((size_t)(Wb + 1) << lg) * 4 : (size_t)Wb * 4;
         if (!early_ok) {
             if (g->cap_h_words < words_bytes) {
-                MSIM_HIP(c, hipStreamSynchronize(c->stream));
+                MSIM_HIP(c, wait_stream(c->stream));
                 if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, words_bytes))) return rc;
             }
             if ((rc = grow(c, (void **)&M.words, &M.cap_words, words_bytes, &grew))) return rc;
@@ -1781,8 +1828,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 if (!need_c && !need_w) break;             // (run stops for one of the two reasons only)
                 if (need_c) {
                     const size_t had = avail_c;
-                    if (ci < 3) { if ((rc = spin_event(c, g->ev_cpiece[ci]))) break; avail_c = std::min<size_t>(ccut[++ci], n_nsn); }
-                    else if (avail_c < n_nsn) { if ((rc = spin_event(c, g->ev_cand))) break; avail_c = n_nsn; }   // (beyond 16 sigma)
+                    if (ci < 3) { if ((rc = spin_event(c, g->ev_cpiece[ci], "spin_event(candidate piece, copy stream)"))) break; avail_c = std::min<size_t>(ccut[++ci], n_nsn); }
+                    else if (avail_c < n_nsn) { if ((rc = spin_event(c, g->ev_cand, "spin_event(candidates of the host chain, copy stream)"))) break; avail_c = n_nsn; }   // (beyond 16 sigma)
                     else break;
                     if (!ChainWalk::types_ok(g->h_ntype + had, avail_c - had, has_tl)) {
                         rc = fail(c, MSIM_ERR_HIP, "boundary chain: candidate type outside the range's draw");
@@ -1791,7 +1838,7 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 }
                 if (need_w) {
                     if (ti >= 3) break;                    // the window is used up: finish() reports it
-                    if ((rc = spin_event(c, g->ev_piece[ti]))) break;
+                    if ((rc = spin_event(c, g->ev_piece[ti], "spin_event(accept-table piece, plan stream)"))) break;
                     avail_w = cut[++ti];
                 }
                 lap(t_wait);
@@ -1799,13 +1846,16 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
                 else cw.run(g->h_npos, g->h_ntype, avail_c, g->h_words, avail_w, g->h_nstop);
                 lap(t_run);
             }
-            if (!rc) rc = spin_event(c, g->ev_cand);       // (every copy into the pinned blocks has landed before they are reused)
+            if (!rc) rc = spin_event(c, g->ev_cand, "spin_event(candidates of the host chain, copy stream)");       // (every copy into the pinned blocks has landed before they are reused)
             if (prof) fprintf(stderr, "chain: n_nsn %u Wb %u wait %.0f us run %.0f us (%.2f ns/cand) w %zu | poll %.0f us, enqueue %.0f us\n", n_nsn, Wb, t_wait, t_run, t_run * 1e3 / n_nsn, cw.ws >> cw.lg_rows,
                               std::chrono::duration<double, std::micro>(tq1 - tq0).count(), std::chrono::duration<double, std::micro>(w0 - tq1).count());
             if (!rc) rc = cw.finish(c, n_nsn, &consumed);
+            c->t.host_walk_run_ms += t_run * 1e-3;
+            c->t.host_walk_wait_ms += t_wait * 1e-3 + std::chrono::duration<double, std::milli>(tq1 - tq0).count();
+            c->t.host_walk_candidates += n_nsn;
             c->t.plan_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
             if (!rc) {
-                MSIM_HIP(c, hipEventSynchronize(g->t1));   // long complete
+                MSIM_HIP(c, wait_event(g->t1));   // long complete
                 rc = span_close(c, g);
             }
         } else {
@@ -1815,8 +1865,8 @@ int plan_contig_gpu_mixed(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *rang
             MSIM_HIP(c, hipMemcpyAsync(g->h_words, M.words, words_bytes, hipMemcpyDeviceToHost, c->stream));
             MSIM_HIP(c, hipEventRecord(g->t1, c->stream));
             if ((rc = flush_deferred_apply(c, true))) return rc;
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+            MSIM_HIP(c, wait_stream(c->stream));
+            MSIM_HIP(c, wait_stream(g->copy_stream));
             if ((rc = span_close(c, g))) return rc;
             size_t kept_host = 0;
             long long delta_host = 0;                      // both are summed on the device, where the stops end up
@@ -1926,7 +1976,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
     if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;
     if (M.pending) {                                       // the pinned range table of this set may still be in flight
-        MSIM_HIP(c, hipEventSynchronize(M.emit_done));
+        MSIM_HIP(c, wait_event(M.emit_done));
         M.pending = false;
     }
     if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
@@ -1937,7 +1987,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     if ((rc = grow(c, (void **)&M.walk_d, &M.cap_walk_d, (size_t)n_draw * sizeof(WalkRange) + 64, &grew))) return rc;
     if ((rc = grow_host(c, (void **)&M.walk_h, &M.cap_walk_h, (size_t)n_draw * sizeof(WalkRange) + 64))) return rc;
     if (g->cap_h_words < (size_t)W * 4 || g->cap_h_npos < n_back * 4 + 64) {
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
+        MSIM_HIP(c, wait_stream(c->stream));     // an earlier contig's copies may still use the old blocks
         if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, (size_t)W * 4))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, n_back * 4 + 64))) return rc;
     }
@@ -1960,8 +2010,8 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     if (!c->chain_only) {   // the record table may still be read by an earlier apply of this contig
         const size_t want = (size_t)K * sizeof(msim_record);
         if (ct.cap_recs < want || ct.cap_pool < 2 * PAD) {
-            MSIM_HIP(c, hipStreamSynchronize(c->stream));
-            MSIM_HIP(c, hipStreamSynchronize(c->emit_stream));
+            MSIM_HIP(c, wait_stream(c->stream));
+            MSIM_HIP(c, wait_stream(c->emit_stream));
         }
         if ((rc = dev_reserve(c, (void **)&ct.d_recs, &ct.cap_recs, want))) return rc;
         if ((rc = dev_reserve(c, (void **)&ct.d_pool, &ct.cap_pool, 2 * PAD))) return rc;
@@ -1984,7 +2034,7 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     MSIM_HIP(c, hipGetLastError());
     // the window comes over in three pieces (1/8, 3/8, 1/2); the host starts on the first while the others are in flight
     if ((rc = ensure_signals(c, g))) return rc;
-    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0};
+    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; double wait_us; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0, 0.0};
     for (int q = 0; q < 3; q++) {
         if (fd.cut[q + 1] > fd.cut[q])
             MSIM_HIP(c, hipMemcpyAsync(g->h_words + fd.cut[q], M.words + fd.cut[q], (fd.cut[q + 1] - fd.cut[q]) * 4,
@@ -2003,14 +2053,23 @@ int plan_contig_gpu_hostsample(Ctx *c, GpuPlan *g, Contig &ct, const msim_range 
     feed.more = [](void *u, size_t *avail) -> int {
         Feed &f = *static_cast<Feed *>(u);
         if (f.next >= 3) return MSIM_OK;
-        const int rc = spin_event(f.c, f.g->ev_piece[f.next]);
+        const auto w0 = std::chrono::steady_clock::now();
+        const int rc = spin_event(f.c, f.g->ev_piece[f.next], "spin_event(word-window piece, plan stream)");
+        f.wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         if (!rc) *avail = f.cut[++f.next];
         return rc;
     };
     if ((rc = flush_deferred_apply_behind(c, g->ev_piece[2]))) return rc;   // the previous contig's APPLY
-    rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed, &feed);
+    {
+        const auto cw0 = std::chrono::steady_clock::now();
+        rc = cut_ranges_host(c, ranges, n_ranges, d, g->h_words, W, h_cut, h_pool, &n_pool_pos, &consumed, &feed);
+        const double all_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - cw0).count();
+        c->t.host_walk_wait_ms += fd.wait_us * 1e-3;
+        c->t.host_walk_run_ms += std::max(0.0, all_ms - fd.wait_us * 1e-3);
+        c->t.host_cut_words += consumed;
+    }
     if (!rc) {
-        MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned window is free again
+        MSIM_HIP(c, wait_event(g->t1));           // all pieces landed (usually long ago): the pinned window is free again
         rc = span_close(c, g);
     }
     if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; M.wbits_dirty = true; return rc; }
@@ -2154,7 +2213,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     MixedSet &M = g->mixed[g->mixed_unit++ % N_SETS];
     if ((rc = wait_if_pending(c, M.pending, M.emit_done))) return rc;
     if (M.pending) {                                       // the pinned tables of this set may still be in flight
-        MSIM_HIP(c, hipEventSynchronize(M.emit_done));
+        MSIM_HIP(c, wait_event(M.emit_done));
         M.pending = false;
     }
     if (!M.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&M.emit_done, hipEventDisableTiming));
@@ -2185,8 +2244,8 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     if (g->cap_h_words < n_slots * 4 || g->cap_h_win < (size_t)W * 4 || g->cap_h_npos < (size_t)K * 4 + 64 ||
         g->cap_h_ntype < (size_t)K + 64 || g->cap_h_nstop < (size_t)K * 4 + 64 || g->cap_h_nrank < (size_t)K * 4 + 64 ||
         (ms.has_tl && (g->cap_h_nextra < (size_t)K * 4 + 64 || g->cap_h_naux < (size_t)K + 64))) {
-        MSIM_HIP(c, hipStreamSynchronize(c->stream));     // an earlier contig's copies may still use the old blocks
-        if (g->copy_stream) MSIM_HIP(c, hipStreamSynchronize(g->copy_stream));
+        MSIM_HIP(c, wait_stream(c->stream));     // an earlier contig's copies may still use the old blocks
+        if (g->copy_stream) MSIM_HIP(c, wait_stream(g->copy_stream));
         if ((rc = grow_host(c, (void **)&g->h_words, &g->cap_h_words, n_slots * 4))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_win, &g->cap_h_win, (size_t)W * 4))) return rc;
         if ((rc = grow_host(c, (void **)&g->h_npos, &g->cap_h_npos, (size_t)K * 4 + 64))) return rc;
@@ -2248,7 +2307,7 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     MSIM_HIP(c, hipGetLastError());
     // window and tables come over in three pieces (1/8, 3/8, 1/2); the host starts on the first while the others are in flight.
     // Their copies go out behind the mailbox kernel, before the host polls: nothing of them depends on what the poll tells.
-    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0};
+    struct Feed { Ctx *c; GpuPlan *g; size_t cut[4]; int next; double wait_us; } fd{c, g, {0, (size_t)W / 8, (size_t)W / 2, (size_t)W}, 0, 0.0};
     PlanState h;
     rc = mixed_poll(c, g, h, [&]() -> int {                // exact stream position + the chain's length
         for (int q = 0; q < 3; q++) {
@@ -2280,16 +2339,26 @@ int plan_contig_gpu_multimix(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *r
     feed.more = [](void *u, size_t *avail) -> int {
         Feed &f = *static_cast<Feed *>(u);
         if (f.next >= 3) return MSIM_OK;
-        const int rc = spin_event(f.c, f.g->ev_piece[f.next]);
+        const auto w0 = std::chrono::steady_clock::now();
+        const int rc = spin_event(f.c, f.g->ev_piece[f.next], "spin_event(word-window piece, plan stream)");
+        f.wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count();
         if (!rc) *avail = f.cut[++f.next];
         return rc;
     };
-    rc = spin_event(c, g->ev_cand);
+    rc = spin_event(c, g->ev_cand, "spin_event(candidates of the host chain, copy stream)");
+    const auto mw0 = std::chrono::steady_clock::now();
+    c->t.host_walk_wait_ms += std::chrono::duration<double, std::milli>(mw0 - tp1).count();
     if (!rc) rc = multimix_walk_host(c, ct.len, ranges, n_ranges, d, ms, g->h_win, g->h_words, W, g->h_nrank, g->h_ntype, n_ch,
                                      g->h_npos, g->h_nstop, visit_h, &consumed, &feed, ms.has_tl ? g->h_nextra : nullptr,
                                      ms.has_tl ? g->h_naux : nullptr);
+    {
+        const double all_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - mw0).count();
+        c->t.host_walk_wait_ms += fd.wait_us * 1e-3;
+        c->t.host_walk_run_ms += std::max(0.0, all_ms - fd.wait_us * 1e-3);
+        c->t.host_walk_candidates += K;
+    }
     if (!rc) {
-        MSIM_HIP(c, hipEventSynchronize(g->t1));           // all pieces landed (usually long ago): the pinned blocks are free again
+        MSIM_HIP(c, wait_event(g->t1));           // all pieces landed (usually long ago): the pinned blocks are free again
         rc = span_close(c, g);
     }
     if (rc) { g->s[0].live = g->s[1].live = false; g->unverified = false; return rc; }

@@ -1043,7 +1043,8 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const SnpLane 
                                                                   uint32_t W,
                                                                   const SnpMap *__restrict__ abs_maps,
                                                                   SnpMap *__restrict__ win_maps, uint32_t nb_max, uint32_t K,
-                                                                  unsigned long long *__restrict__ base_out) {
+                                                                  unsigned long long *__restrict__ base_out,
+                                                                  unsigned long long pos_limit = ~0ull) {
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     __shared__ SnpMap s_first;
     __shared__ uint32_t s_blk, s_bs, s_bc;
@@ -1124,7 +1125,11 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_scan_cut_abs(const SnpLane 
         uint32_t e = emits;
         for (uint32_t q = idx + 1; q < K; q++) e &= e - 1; // drop the first K - idx - 1 emits
         const unsigned long long w0 = (unsigned long long)wbase + (unsigned long long)threadIdx.x * SNP_ITEMS2;
-        ps->pos = w0 + (unsigned long long)__builtin_ctz(e) + 1;
+        const unsigned long long cut = w0 + (unsigned long long)__builtin_ctz(e) + 1;
+        ps->pos = cut;
+        // pos_limit: the host's bound of where these draws end -- what it lays the next stage's window out from (and makes sure
+        // exists).  Beyond it the next stage would read words nobody generated: an overflow, never a silent short read.
+        if (cut > pos_limit) atomicOr(&ps->flags, FLAG_SNP_OVERFLOW);
     }
 }
 

@@ -909,7 +909,7 @@ int vcf_render_device(Ctx *c, Contig &g, const char *seq_name, uint64_t *bytes, 
     hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, st, d_sums, nb, c->h_mail);
     hipLaunchKernelGGL(k_len_offsets, dim3(nb), dim3(TX_THREADS), 0, st, d_len, n, d_sums, d_off);
     MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipStreamSynchronize(st));
+    MSIM_HIP(c, wait_stream(st));
     const uint64_t total = *c->h_mail;
     rc = dev_reserve(c, (void **)buf, cap, total + 64);
     if (rc) return rc;
@@ -958,7 +958,7 @@ int fasta_gather_device(Ctx *c, const uint8_t *body, uint64_t body_bytes, uint64
     hipLaunchKernelGGL(k_gather, dim3((uint32_t)((groups + TX_THREADS - 1) / TX_THREADS)), dim3(TX_THREADS), 0, c->stream,
                        c->d_text, (unsigned long long)n_bases, lenc, lenb, d_dst);
     MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipStreamSynchronize(c->stream));
+    MSIM_HIP(c, wait_stream(c->stream));
     c->text_len = 0;
     return MSIM_OK;
 }
@@ -984,7 +984,7 @@ int splice_device(Ctx *c, const Contig &a, const Contig *b, const uint32_t *seg_
                            (unsigned long long)out_len, dst.d_out);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = wait_stream(c->stream);
     (void)hipFree(d_tab);
     if (e != hipSuccess) return hip_fail(c, e, "splice");
     return MSIM_OK;

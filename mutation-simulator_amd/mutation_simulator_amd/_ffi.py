@@ -75,7 +75,9 @@ class Timing(C.Structure):           # msim_timing
                 ("contigs_snp", C.c_uint64), ("contigs_svmix", C.c_uint64), ("contigs_hostcut", C.c_uint64),
                 ("contigs_hostchain", C.c_uint64), ("contigs_host", C.c_uint64), ("contigs_batch", C.c_uint64),
                 ("contigs_fast", C.c_uint64), ("stream_rebases", C.c_uint64),
-                ("snp_samples_ahead", C.c_uint64)]
+                ("snp_samples_ahead", C.c_uint64),
+                ("host_walk_run_ms", C.c_double), ("host_walk_wait_ms", C.c_double),
+                ("host_walk_candidates", C.c_uint64), ("host_cut_words", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -171,7 +173,7 @@ def load():
             fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.msim_abi_version() != 7:
+        if lib.msim_abi_version() != 8:
             raise MsimError("libmsim ABI version mismatch")
         _lib = lib
     return _lib

@@ -152,6 +152,12 @@ static uint32_t py32(orc_t *o) { o->py_words++; return mt_next(&o->py); }
 static uint32_t np32(orc_t *o) { o->np_words++; return mt_next(&o->np); }
 uint32_t orc_py_next32(orc_t *o) { return py32(o); }
 uint32_t orc_np_next32(orc_t *o) { return np32(o); }
+/* n words of a stream consumed and dropped: the sequential generation a jump-ahead table is checked against
+   (tests/test_jump_table.py); the same genrand_int32 steps as every draw of the reference (_randommodule.c) */
+void orc_skip_words(orc_t *o, int stream, uint64_t n) {
+    if (stream) for (uint64_t i = 0; i < n; i++) (void)np32(o);
+    else for (uint64_t i = 0; i < n; i++) (void)py32(o);
+}
 
 /* ------------------------------------------------------------------ CPython random layer */
 /* _randommodule.c getrandbits: k<=32 -> one word >> (32-k); else little-endian limbs, the top

@@ -64,6 +64,8 @@ def lib():
         L.orc_py_next32.restype = C.c_uint32
         L.orc_np_next32.argtypes = [C.c_void_p]
         L.orc_np_next32.restype = C.c_uint32
+        L.orc_skip_words.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        L.orc_skip_words.restype = None
         L.orc_randbelow.argtypes = [C.c_void_p, C.c_uint64]
         L.orc_randbelow.restype = C.c_uint64
         L.orc_randint.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
@@ -172,6 +174,10 @@ class Oracle:
 
     def np_words32(self, n):
         return [self.L.orc_np_next32(self.h) for _ in range(n)]
+
+    def skip_words(self, stream: int, n: int):
+        """n words of the stream drawn and dropped (sequential generation, in C)."""
+        self.L.orc_skip_words(self.h, stream, n)
 
     def randbelow(self, n):
         return self.L.orc_randbelow(self.h, n)

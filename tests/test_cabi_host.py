@@ -24,14 +24,14 @@ def test_header_symbols_exported_and_bound():
     assert declared == bound, declared ^ bound
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.msim_abi_version() == 7
+    assert lib.msim_abi_version() == 8
 
 
 def test_struct_layouts_match_header():
     assert _ffi.C.sizeof(_ffi.Record) == 16 and _ffi.RECORD_DTYPE.itemsize == 16
     assert _ffi.C.sizeof(_ffi.Range) == 8 * 4 + 4 + 4 * 8 + 4 + 8 * 8 * 3
     assert _ffi.C.sizeof(_ffi.Params) == 72
-    assert _ffi.C.sizeof(_ffi.Timing) == 5 * 8 + 15 * 8
+    assert _ffi.C.sizeof(_ffi.Timing) == 5 * 8 + 15 * 8 + 4 * 8
 
 
 def test_no_silent_cpu_fallback():

@@ -212,39 +212,7 @@ def test_rmt_many_ranges_vs_oracle(tmp_path):
 
 
 # ------------------------------------------------------------------ device helpers
-def mix64(z):
-    z = (z + np.uint64(0x9E3779B97F4A7C15)).astype(np.uint64)
-    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)).astype(np.uint64)
-    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)).astype(np.uint64)
-    return z ^ (z >> np.uint64(31))
-
-
-def synth_host(length: int, seed: int) -> np.ndarray:
-    """Host twin of msim::k_synth: base(i) = "ACGT"[(mix64(seed + (i >> 5)) >> (2 * (i & 31))) & 3]."""
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    out = np.empty(length, dtype=np.uint8)
-    lanes = (length + 31) // 32
-    sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
-    step = 1 << 20
-    with np.errstate(over="ignore"):
-        for g0 in range(0, lanes, step):
-            g = np.arange(g0, min(lanes, g0 + step), dtype=np.uint64)
-            bits = mix64(np.uint64(seed) + g)
-            codes = ((bits[:, None] >> sh) & np.uint64(3)).astype(np.uint8).reshape(-1)
-            lo = g0 * 32
-            hi = min(length, lo + codes.shape[0])
-            out[lo:hi] = acgt[codes[:hi - lo]]
-    return out
-
-
-def checksum_host(b: np.ndarray) -> int:
-    n = len(b)
-    pad = (-n) % 8
-    w = np.concatenate([b, np.zeros(pad, np.uint8)]).view("<u8")
-    with np.errstate(over="ignore"):
-        k = np.arange(len(w), dtype=np.uint64)
-        s = int(mix64(w + k * np.uint64(0x9E3779B97F4A7C15)).sum(dtype=np.uint64))
-        return (s + n * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+from oracle.support import checksum_host, mix64, synth_host  # noqa: E402,F401  (host twins of k_synth / k_checksum)
 
 
 @pytest.mark.parametrize("length", [1, 31, 32, 33, 1000, 1 << 20, (1 << 20) + 17])

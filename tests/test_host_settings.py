@@ -15,28 +15,7 @@ from pipeline import build_settings, prepare
 SETTINGS = load_json("settings.json")
 
 
-def dump_sim(sim) -> dict:
-    """Same neutral form as tests/golden/make_goldens.py:dump_sim, from OUR settings classes."""
-    def ms(m):
-        if m.mut_rates is None:
-            return None
-        return {"rates": [[t.name, r] for t, r in m.mut_rates.items()],
-                "rates_hex": [[t.name, float(r).hex()] for t, r in m.mut_rates.items()],
-                "chances_hex": [[t.name, float(c).hex()] for t, c in m.mut_chances.items()],
-                "rate_sum_hex": float(sum(m.mut_rates.values())).hex(),
-                "min": {t.name: v for t, v in m.mut_lengs["min"].items()} if m.mut_lengs else None,
-                "max": {t.name: v for t, v in m.mut_lengs["max"].items()} if m.mut_lengs else None,
-                "has_mutations": m.has_mutations}
-    return {
-        "mut_block": [[t.name, v] for t, v in sim.mut_block.items()],
-        "titv": sim.titv, "fasta": sim.fasta if sim.fasta is None else str(sim.fasta),
-        "md5": sim.md5, "species_name": sim.species_name, "assembly_name": sim.assembly_name,
-        "sample_name": sim.sample_name, "has_mutations": sim.has_mutations, "has_it": sim.has_it,
-        "chromosomes": [{"number": c.number, "it_rate": c.it_rate,
-                         "ranges": [{"start": r.start, "stop": r.stop,
-                                     "settings": ms(r.mutation_settings)}
-                                    for r in c.range_definitions]} for c in sim.chromosomes],
-    }
+from oracle.support import dump_sim  # noqa: E402,F401  (the neutral form the oracle consumes)
 
 
 def _norm_blocks(d):
