@@ -902,12 +902,6 @@ def main():
             sec["fast_rng"] = fast_rng_steps(lengths, mm)
         except Exception as e:  # noqa: BLE001
             sec["fast_rng"] = {"error": f"{type(e).__name__}: {e}"}
-        for key, where in (("e2e", "tmpfs"), ("e2e_tmpdir", "tmpdir")):
-            try:
-                sec[key] = e2e_cli(eng, where=where)
-            except Exception as e:  # noqa: BLE001  (no tmpfs / disk space: the kernels' numbers above still stand)
-                sec[key] = {"error": f"{type(e).__name__}: {e}"}
-        line["secondary"] = sec
         # What a SCALE run should show, from this one GPU: the step of the most loaded rank of an N-way LPT partition (it plans
         # / applies what it owns and walks the others' contigs for their stream positions) against the full step -- the strong-
         # scaling speed-up of ONE genome that 2 / 4 / 8 GPUs can reach before the gather, per mode.  A prediction to hold a
@@ -916,6 +910,13 @@ def main():
             line["predicted_one_genome_scaling"] = predict_scaling(measure, lengths, a.steps, dtf, sec, mm)
         except Exception as e:  # noqa: BLE001
             line["predicted_one_genome_scaling"] = {"error": f"{type(e).__name__}: {e}"}
+        # (in front of the CLI runs: e2e_cli clears this context's contigs)
+        for key, where in (("e2e", "tmpfs"), ("e2e_tmpdir", "tmpdir")):
+            try:
+                sec[key] = e2e_cli(eng, where=where)
+            except Exception as e:  # noqa: BLE001  (no tmpfs / disk space: the kernels' numbers above still stand)
+                sec[key] = {"error": f"{type(e).__name__}: {e}"}
+        line["secondary"] = sec
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(a.cpu_sample, a.workload, device=device)      # bounded sample: ~6-10 s of CPU work
     printed = [False]

@@ -1009,13 +1009,19 @@ int apply_finish(Ctx *c) {
         // the emit stream joins every such launch through the event behind it, so that no KeyError / length word is copied
         // before the rewrite that writes it has run.  (A contig whose rewrite rode in another's batched launch -- timing_shared --
         // is covered by that launch's event: the batch's contigs are all pending.)
-        if (ride)
-            for (int idx : c->pending_apply) {
-                if (idx < 0 || (size_t)idx >= c->contigs.size()) continue;
-                const Contig &g = c->contigs[(size_t)idx];
-                if (g.apply_pending && !g.timing_shared && g.ea2 && g.apply_stream && g.apply_stream != c->emit_stream)
-                    MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, g.ea2, 0));
+        if (ride) {                                        // (the last launch of every such stream is enough: a stream runs in order)
+            std::vector<hipStream_t> seen;
+            for (auto it = c->pending_apply.rbegin(); it != c->pending_apply.rend(); ++it) {
+                if (*it < 0 || (size_t)*it >= c->contigs.size()) continue;
+                const Contig &g = c->contigs[(size_t)*it];
+                hipStream_t s = g.apply_stream;
+                if (!g.apply_pending || g.timing_shared || !g.ea2 || !s || s == c->emit_stream) continue;
+                if (std::find(seen.begin(), seen.end(), s) != seen.end()) continue;
+                seen.push_back(s);
+                if (fast_lane_joined_at_collect(c, s)) continue;       // fast_plan_collect joins this lane itself
+                MSIM_HIP(c, hipStreamWaitEvent(c->emit_stream, g.ea2, 0));
             }
+        }
         const int rc = fast_plan_collect(c, ride ? enqueue_err_copies : nullptr, &state);
         if (rc) { c->pending_apply.clear(); for (auto &g : c->contigs) g.apply_pending = g.dyn_applied = false; return rc; }
         have_errs = state == 1;
@@ -1066,9 +1072,10 @@ int apply_finish(Ctx *c) {
             // Launches of the counter-based engine's batches run on lanes of their own and can overlap: the stage times are
             // the time during which at least one launch was in flight (the union of the spans), not the sum of the spans --
             // two rewrites side by side would otherwise be booked twice (1.27 ms of rewriting read 2.4 ms).
-            if (!origin) origin = g.ea0;
+            hipEvent_t e0 = g.ea0_is_ea1 ? g.ea1 : g.ea0;
+            if (!origin) origin = e0;
             float t0 = 0, t1 = 0, t2 = 0;
-            MSIM_HIP(c, hipEventElapsedTime(&t0, origin, g.ea0));
+            MSIM_HIP(c, hipEventElapsedTime(&t0, origin, e0));
             MSIM_HIP(c, hipEventElapsedTime(&t1, origin, g.ea1));
             MSIM_HIP(c, hipEventElapsedTime(&t2, origin, g.ea2));
             spans_all.push_back({t0, t2});
@@ -1099,6 +1106,21 @@ int apply_finish(Ctx *c) {
 // (the collector hangs on the context -- Ctx::rw_collect -- so that two contexts driven from two threads never see each other's)
 struct RwPending { RwJob job; int variant; int contig; };
 
+static_assert((TILE & (TILE - 1)) == 0, "the expansion's tile index shifts by log2(TILE)");
+int apply_prepare_tile_index(Ctx *c, Contig &g, hipStream_t st, int32_t **first, uint32_t *n_tiles, uint32_t *tile_shift,
+                             unsigned long long **err) {
+    const uint32_t nt = (uint32_t)((g.len + TILE - 1) / TILE);      // (SNP-only: the mutated contig is as long as the contig)
+    if (g.cap_first < (size_t)(nt + 1) * sizeof(int32_t)) MSIM_HIP(c, wait_stream(st));
+    const int rc = dev_reserve(c, (void **)&g.d_first, &g.cap_first, (size_t)(nt + 1) * sizeof(int32_t));
+    if (rc) return rc;
+    *first = g.d_first;
+    *n_tiles = nt;
+    *tile_shift = (uint32_t)__builtin_ctz((unsigned)TILE);
+    *err = c->d_errs + g.index;
+    g.tile_index_by_plan = nt != 0;
+    return MSIM_OK;
+}
+
 int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites) {
     TileJobs J;
     J.n_jobs = 0; J.total = 0;
@@ -1109,6 +1131,11 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
     };
     std::vector<int> marked;
     int batch_first = -1;
+    bool any_tile_job = false;                             // (none: every contig's tile index comes with its records -- no start event)
+    for (int id : ids) {
+        const Contig &g = c->contigs[(size_t)id];
+        if (!(g.tile_index_by_plan && g.all_snp && !g.d_dyn)) any_tile_job = true;
+    }
     for (int id : ids) {
         Contig &g = c->contigs[(size_t)id];
         const uint32_t *dyn = g.d_dyn;
@@ -1133,7 +1160,18 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         }
         // ONE start event for the batch (on its first contig, in front of the tile index): an event per contig is a packet per
         // contig on the queue -- twelve of them stood between a batch's tile index and its rewrite launch, 50 us of an idle device
-        if (marked.empty()) { MSIM_HIP(c, hipEventRecord(g.ea0, st)); batch_first = id; }
+        g.ea0_is_ea1 = false;
+        if (marked.empty()) {
+            if (any_tile_job) MSIM_HIP(c, hipEventRecord(g.ea0, st));
+            else g.ea0_is_ea1 = true;
+            batch_first = id;
+        }
+        if (g.tile_index_by_plan && g.all_snp && !dyn) {   // its tile index is already on its way (k_bitmap_expand_tiles_b)
+            g.tile_index_by_plan = false;
+            g.tile_index_done = true;
+            marked.push_back(id);
+            continue;
+        }
         TileJob &T = J.j[J.n_jobs++];
         T.off = g.all_snp ? nullptr : g.d_off; T.recs = g.d_recs; T.dyn = dyn; T.first = g.d_first; T.err = c->d_errs + g.index;
         T.n = n; T.n_entries = n_tiles + 1; T.entry_base = J.total; T.rsv = 0;
@@ -1164,7 +1202,10 @@ int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites)
         auto go = [&]() -> int {
             if (!R.n) return MSIM_OK;
             Contig &L = c->contigs[(size_t)leader];
-            if (leader != batch_first) MSIM_HIP(c, hipEventRecord(L.ea0, st));   // (a second kernel variant's launch: its own span)
+            if (leader != batch_first) {                    // (a second kernel variant's launch: its own span)
+                if (any_tile_job) MSIM_HIP(c, hipEventRecord(L.ea0, st));
+                else L.ea0_is_ea1 = true;
+            }
             MSIM_HIP(c, hipEventRecord(L.ea1, st));
             if (variant == 0) hipLaunchKernelGGL(k_rewrite_snp_b, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
             else if (variant == 1) hipLaunchKernelGGL(k_rewrite_b<REC_CAP_SMALL>, dim3(R.total), dim3(THREADS), 0, st, R, ctx_lut(c));
@@ -1207,7 +1248,7 @@ int apply_contig_device(Ctx *c, Contig &g) {
         if (rc) return rc;
     }
     unsigned long long *d_err = c->d_errs + g.index;
-    if (!(c->rw_collect && g.tile_index_done)) MSIM_HIP(c, hipEventRecord(g.ea0, st));   // (batched: apply_batch_device recorded the batch's)
+    if (!(c->rw_collect && g.tile_index_done)) { MSIM_HIP(c, hipEventRecord(g.ea0, st)); g.ea0_is_ea1 = false; }   // (batched: apply_batch_device recorded the batch's)
     // ---- 1. output offsets (skipped for an SNP-only table: no length change, offset == position)
     long long total_delta = 0;
     const uint32_t nb = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;

@@ -33,6 +33,8 @@ struct Contig {
     int32_t *d_first = nullptr;       // tile index of its own (contigs on different streams cannot share the context's scratch)
     size_t cap_first = 0;
     bool tile_index_done = false;     // (transient) apply_batch_device has already launched this contig's tile index
+    bool tile_index_by_plan = false;  // (one shot) the SNP sampler's expansion is writing d_first on the contig's stream
+                                      // (apply_prepare_tile_index): apply_batch_device launches no tile-index job for it
     bool timing_shared = false;       // its rewrite ran inside another contig's batched launch: that contig's events time it
     uint64_t n_rec = 0, pool_len = 0;
     msim_record *d_recs = nullptr;    // sorted, visited-only records
@@ -51,6 +53,8 @@ struct Contig {
     bool apply_pending = false;       // APPLY enqueued, result not yet collected
     bool defer_apply = false;         // planned by an engine with a host chain: its APPLY may wait for the next plan's chain
     hipEvent_t ea0 = nullptr, ea1 = nullptr, ea2 = nullptr;   // APPLY timing (emit stream)
+    bool ea0_is_ea1 = false;          // nothing ran between the APPLY's start and its rewrite launch (tile index made by PLAN): ea0 was
+                                      // not recorded -- one packet less on the queue -- and ea1 stands for it
     // host-only context (device_id -1): the record table stays here
     std::vector<msim_record> h_recs;
     std::vector<uint8_t> h_pool;
@@ -274,6 +278,8 @@ bool fast_plan_queued(Ctx *c, int contig, bool mark_apply);
 // *behind_state: 0 it did not run (nothing was pending), 1 it ran and what it copied is complete, 2 it ran, but a plan was
 // replayed (and applied again) afterwards -- stale
 int fast_plan_collect(Ctx *c, int (*behind)(Ctx *) = nullptr, int *behind_state = nullptr);
+// is `s` a lane whose set is pending -- one the next fast_plan_collect makes the emit stream wait for?
+bool fast_lane_joined_at_collect(const Ctx *c, hipStream_t s);
 // test support (msim_dbg_fast_plan): the engine restated sequentially on the host over the same arithmetic (fast_math.h)
 int fast_plan_emulated(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges, uint64_t key, uint32_t seq, HostPlan &out);
 
@@ -311,6 +317,10 @@ int apply_contig_device(Ctx *c, Contig &g);
 // and the three-contig rewrite kernel runs at 0.76 of the HBM peak inside the pipeline instead of 0.67 -- fewer ramps and tails)
 int apply_batch_device(Ctx *c, const std::vector<int> &ids, bool batch_rewrites);
 int apply_finish(Ctx *c);             // collect results of asynchronous APPLYs (timing, KeyError words)
+// SNP sampler (plan_gpu.hip: gpu_emit_flush): the expansion kernel writes an SNP-only contig's tile index itself -- room for it,
+// its geometry (tile = 1 << *tile_shift output bytes, *n_tiles of them; n_tiles + 1 entries) and the contig's KeyError word
+int apply_prepare_tile_index(Ctx *c, Contig &g, hipStream_t st, int32_t **first, uint32_t *n_tiles, uint32_t *tile_shift,
+                             unsigned long long **err);
 constexpr int MAX_CONTIGS = 1 << 16;
 int synth_contig_device(Ctx *c, uint8_t *d_dst, uint64_t len, uint64_t seed);
 int checksum_device(Ctx *c, const uint8_t *d_src, uint64_t len, uint64_t *sum);

@@ -176,6 +176,7 @@ static void build_lut(uint8_t *lut) {
 static void reset_contig(Contig &g) {   // (callers also drop the context's text cache: see text_kind)
     g.planned = g.applied = false;
     g.defer_apply = false;
+    g.tile_index_by_plan = false;
     g.delta_known = false;
     g.off_ready = false;
     g.known_delta = 0;

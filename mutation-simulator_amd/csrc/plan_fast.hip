@@ -322,6 +322,13 @@ int fast_plan_check(Ctx *c, uint64_t L, const msim_range *ranges, int n_ranges) 
 
 static int enqueue_batch(Ctx *c, std::vector<Pending> &items, bool orbit_only);
 
+bool fast_lane_joined_at_collect(const Ctx *c, hipStream_t s) {
+    const FastPlan *f = c->fast;
+    if (!f || !f->pending) return false;
+    for (int i = 0; i < F_SETS; i++) if (f->lane[i] == s) return f->set[i].pending;
+    return false;
+}
+
 int fast_plan_collect(Ctx *c, int (*behind)(Ctx *), int *behind_state) {
     FastPlan *f = c->fast;
     if (behind_state) *behind_state = 0;

@@ -87,6 +87,7 @@ struct SampleSet {                       // scratch of one sampled range
     hipEvent_t chain_done = nullptr;                      // behind the set's last kernel on the plan stream (anchored windows)
     uint8_t last_user = 0;                                // since the last finish: 1 a sample on the chain, 2 an anchored window
     hipEvent_t emit_done = nullptr;
+    hipEvent_t wait_ev = nullptr;                         // what marks its last emit: its own emit_done or its group's event
     bool pending = false;
 };
 struct SnpSet {                          // scratch of one contig's SNP draws
@@ -94,6 +95,7 @@ struct SnpSet {                          // scratch of one contig's SNP draws
     uint8_t *aux8 = nullptr; size_t aux_cap = 0;          // one-range contigs: the outcomes by rank (folded into the records by k_bitmap_expand)
     unsigned long long *base = nullptr;                   // device word: stream position the draws start at
     hipEvent_t emit_done = nullptr;
+    hipEvent_t wait_ev = nullptr;                         // (as SampleSet::wait_ev)
     bool pending = false;
 };
 
@@ -161,6 +163,11 @@ struct GpuPlan {
     uint32_t unit = 0, snp_unit = 0;    // rotation counters
     hipEvent_t chain_ev[2 * N_SETS] = {};
     uint32_t chain_i = 0;
+    // ONE event per emission group, behind its rewrite launch, instead of two per contig between the expansion and the rewrite:
+    // an event record is a packet on the queue (~6-10 us of it each) -- four of them and the APPLY's two stood between a pair's
+    // expansion and its rewrite (70 us in the trace of a step whose emission train is the bound)
+    hipEvent_t grp_ev[2 * N_SETS] = {};
+    uint32_t grp_i = 0;
     hipEvent_t t0 = nullptr, t1 = nullptr;   // chain-time span since the last finish
     bool ps_valid = false;              // device PlanState carries the current session's position
     bool unverified = false;            // work enqueued since the last finish (flags / exact position unknown)
@@ -170,17 +177,22 @@ struct GpuPlan {
     uint64_t reserve_words[2] = {0, 0};
     // per context, read when it is created (tests run several group sizes / stream spans in one process):
     int emit_group = 2;                 //   contigs per emission group (MSIM_EMIT_GROUP; see plan_contig_gpu)
+    int emit_train = 0;                 //   launches of an emission group's train: 3, 6, or 0 = by the context's role (gpu_emit_flush; MSIM_EMIT_TRAIN)
     uint32_t max_chunks = MT_JUMP_MAX_CHUNKS;   //   chunks one (re)seeded session may span (MSIM_DBG_JUMP_MAX_CHUNKS lowers it)
     uint32_t rebases = 0;               //   sessions ended because the next contig would not fit into the span
     // anchored windows: the CPython stream's position as the host knows it between two exact readings -- mean and variance of
     // the words consumed since (the sampler's rejections and duplicates, the SNP draws' transversion loops), a hard lower bound
     hipStream_t prep_stream = nullptr;  //   the off-chain part of the samples: the stream of the sample being enqueued,
     hipStream_t prep_streams[8] = {};   //   one of these in turn (contigs' off-chain parts are independent of each other)
-    // (at the chain's priority.  A rank that owns 3 of 24 contigs: 2.8 ms per step against 3.1-3.2 with these streams at normal
-    //  priority, where the off-chain kernels fall behind beside the rank's own emission + APPLY; a rank that owns nothing would
-    //  do 2.3 instead of 2.6 at normal priority, but a second set of streams for that case left some of them sharing hardware
-    //  queues with other streams of the context: 3.9 ms -- one set, one priority)
-    int n_prep = 4, prep_i = 0, prep_prio = -1;
+    // THREE streams at NORMAL priority (round 6; four at the chain's priority in round 5).  Measured on one box, c2 3 Gb, ms per
+    // step of a rank that owns 0 / 3 / 12 of 24 contigs (tools/compat_steps.py, profiles/r06_prep_streams.txt):
+    //   4 at the chain's priority 2.27 / 2.46 / 3.45   3 there 2.24 / 2.46 / 3.62   2 there 2.11 / 2.93 / 4.03   1 there 2.00 / 4.35 / 5.3
+    //   4 normal 2.13 / 2.77 / 3.52   **3 normal 2.10 / 2.29 / 3.30**   2 normal 2.08 / 2.61 / 3.59   1 normal 1.98 / 3.8 / 4.6
+    // and three or more streams CREATED at the chain's priority slow every later pass of the context that has a host chain,
+    // for as long as the process lives (the SV-mix engine's plan spans 7.0 -> 10.0 ms per 3 Gb step, c3 30.8 -> 35.4 ms; the
+    // streams may be idle or destroyed, the hardware queues stay): bench.py measures c3 behind chain-only steps -- round 5's
+    // "regression" of c3 from 94 to 84 Gbases/s in the driver's line was this (NOTES section 10 has the bisect).
+    int n_prep = 3, prep_i = 0, prep_prio = 0;
     double ahead_sigma = 8.0;
     uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
     // Measured (c2, 3 Gb, tools/compat_steps.py): a rank that owns every contig is bound by its emission + APPLY train either way
@@ -217,6 +229,7 @@ GpuPlan *gpu_plan_create() {
     if (const char *e = getenv("MSIM_EMIT_GROUP")) g->emit_group = std::min(EMIT_G, std::max(1, atoi(e)));
     if (const char *e = getenv("MSIM_DBG_JUMP_MAX_CHUNKS"))
         g->max_chunks = (uint32_t)std::min<long>(MT_JUMP_MAX_CHUNKS, std::max<long>(2, atol(e)));
+    if (const char *e = getenv("MSIM_EMIT_TRAIN")) g->emit_train = atoi(e) == 3 ? 3 : atoi(e) == 6 ? 6 : 0;
     if (getenv("MSIM_NO_AHEAD")) g->ahead = 0;
     else if (const char *e = getenv("MSIM_AHEAD")) g->ahead = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("MSIM_PREP_STREAMS")) g->n_prep = std::min(8, std::max(1, atoi(e)));
@@ -304,6 +317,7 @@ void gpu_plan_destroy(GpuPlan *g) {
     void *hb[] = {g->h_words, g->h_npos, g->h_ntype, g->h_nstop, g->h_win, g->h_nrank, g->h_nextra, g->h_naux};
     for (void *b : hb) host_stage_free(b);
     for (auto e : g->chain_ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : g->grp_ev) if (e) (void)hipEventDestroy(e);
     if (g->t0) (void)hipEventDestroy(g->t0);
     if (g->t1) (void)hipEventDestroy(g->t1);
     if (g->h_seed) (void)hipHostFree(g->h_seed);
@@ -323,22 +337,6 @@ void gpu_plan_invalidate(GpuPlan *g) {
     g->unit = g->snp_unit = g->mixed_unit = 0;            // a new pass: contig i meets scratch set i again (sizes fit)
     g->sharded_rank = g->pass_chain_only > 0;
     g->pass_chain_only = 0;
-    // The anchored windows' side streams live as long as the context is a rank of a sharded step.  They sit at the plan
-    // stream's priority, where the device offers two hardware queues: left behind by a pass that walked other ranks' contigs
-    // (bench.py's chain-only steps), they shared those queues with the plan stream of every later pass -- the SV-mix engine's
-    // plan spans 7.3 -> 10.3 ms per 3 Gb step, its host walks' waits with them (round 5's c3 84 instead of 94 Gbases/s in the
-    // driver's line, which measures c3 behind such steps; scratch A/B in NOTES section 10).  MSIM_KEEP_PREP_STREAMS: the old way.
-    static const bool keep_prep = getenv("MSIM_KEEP_PREP_STREAMS") != nullptr;
-    if (!g->sharded_rank && g->ahead != 2 && !keep_prep) {
-        for (auto &st : g->prep_streams) {
-            if (!st) continue;
-            (void)wait_stream(st);                         // (idle: every caller has drained the context)
-            (void)hipStreamDestroy(st);
-            st = nullptr;
-        }
-        g->prep_stream = nullptr;
-        for (auto &w : g->prep_waited) w = 0;
-    }
     for (auto &s : g->s) {
         if (s.live) s.last_session_words = std::max<uint64_t>(s.pos, s.max_upto);
         s.live = false;
@@ -862,13 +860,13 @@ static int enqueue_sample_chain(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     const uint32_t W = (uint32_t)wd;
     SampleSet &S = g->sample[g->unit++ % N_SETS];
     S.last_user = 1;
-    if ((rc = wait_if_pending(c, S.pending, S.emit_done))) return rc;          // its last emit may still read it
+    if ((rc = wait_if_pending(c, S.pending, S.wait_ev))) return rc;            // its last emit may still read it
     const uint32_t nb = (W + ACC_BLOCK - 1) / ACC_BLOCK;
     const size_t bm_words64 = (size_t)((n + 63) / 64);
     const uint32_t bmw = (uint32_t)bm_words64;
     const uint32_t bnb = (bmw + BM_THREADS - 1) / BM_THREADS;
     if ((rc = grow(c, (void **)&S.cnt, &S.cnt_cap, (size_t)(nb + 2) * sizeof(uint32_t), &grew))) return rc;
-    if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + EMIT_SUPER + bnb / EMIT_SUPER + 4) * sizeof(uint32_t), &grew))) return rc;   // (+ whole super-blocks and their totals: k_snp_emit_count_b)
     if ((rc = grow(c, (void **)&S.acc, &S.acc_cap, (size_t)W * sizeof(uint32_t), &grew))) return rc;
     if ((rc = grow(c, (void **)&S.bitmap, &S.bm_cap, bm_words64 * 8, &grew))) return rc;
     if (!S.emit_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.emit_done, hipEventDisableTiming));
@@ -985,7 +983,7 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     const double mean = (double)((nbk + BIN_SUBS - 1) / BIN_SUBS) * SPL_BLOCK * p_acc * std::min(1.0, (double)BIN_VALUES / (double)n);
     const uint32_t bin_cap = (uint32_t)std::min<double>((double)K + 16.0, 1.25 * mean + 16.0 * std::sqrt(mean) + 512.0);
     if ((rc = grow(c, (void **)&S.cnt, &S.cnt_cap, (size_t)(nb + 2) * sizeof(uint32_t), &grew))) return rc;
-    if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + 2) * sizeof(uint32_t), &grew))) return rc;
+    if ((rc = grow(c, (void **)&S.cnt2, &S.cnt2_cap, (size_t)(bnb + EMIT_SUPER + bnb / EMIT_SUPER + 4) * sizeof(uint32_t), &grew))) return rc;   // (+ whole super-blocks and their totals: k_snp_emit_count_b)
     if ((rc = grow(c, (void **)&S.acc, &S.acc_cap, (size_t)W * sizeof(uint32_t), &grew))) return rc;
     if ((rc = grow(c, (void **)&S.bins, &S.bins_cap, (size_t)n_bins * BIN_SUBS * bin_cap * sizeof(uint32_t), &grew))) return rc;
     if ((rc = grow(c, (void **)&S.cursors, &S.cursors_cap, (size_t)MAX_BINS * BIN_SUBS * sizeof(uint32_t), &grew))) return rc;
@@ -1001,8 +999,8 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     const uint32_t *raw = g->s[0].d_raw;
     if ((rc = prep_wait_words(c, g, H + W + 1))) return rc;
     if (S.pending) {                                       // the set's last emission may still read it
-        if (hipEventQuery(S.emit_done) == hipSuccess) S.pending = false;
-        else { (void)hipGetLastError(); MSIM_HIP(c, hipStreamWaitEvent(ps_, S.emit_done, 0)); }
+        if (hipEventQuery(S.wait_ev) == hipSuccess) S.pending = false;
+        else { (void)hipGetLastError(); MSIM_HIP(c, hipStreamWaitEvent(ps_, S.wait_ev, 0)); }
     }
     // ... and so may the chain of the contig that had the set N_SETS contigs ago (the host may be that far ahead of the device):
     // an anchored window left an event behind its last chain kernel; behind a sample on the chain, whatever the plan stream holds
@@ -1057,7 +1055,7 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
     const uint32_t W2 = (uint32_t)w2;
     const uint32_t nb2 = W2 / SNP_BLOCK2 + 2;              // window blocks incl. the partial first one
     SnpSet &T = g->snp[g->snp_unit++ % N_SETS];
-    if ((rc = wait_if_pending(c, T.pending, T.emit_done))) return rc;
+    if ((rc = wait_if_pending(c, T.pending, T.wait_ev))) return rc;
     if ((rc = grow(c, (void **)&T.maps, &T.cap, (size_t)(nb2 + 1) * sizeof(SnpMap), &grew))) return rc;
     if (aux8_out) {
         if ((rc = grow(c, (void **)&T.aux8, &T.aux_cap, (size_t)K + 64, &grew))) return rc;
@@ -1088,6 +1086,7 @@ static int enqueue_snp_stage(Ctx *c, GpuPlan *g, Contig &ct, uint64_t K, const u
         MSIM_HIP(c, hipGetLastError());
         if (!aux8_out) {                                  // (else: the caller records it behind the expansion that reads aux8)
             MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+            T.wait_ev = T.emit_done;
             T.pending = true;
         }
     }
@@ -1118,26 +1117,68 @@ int gpu_emit_flush(Ctx *c) {
     }
     J.total_blk = blk; J.total_eblk = eblk;
     hipStream_t es = c->emit_stream;
+    // The train in three launches (MSIM_EMIT_TRAIN=6: the six of rounds 4-5: count, scan, outcomes, expansion, tile index,
+    // rewrite): outcomes + popcounts in one grid; the expansion makes its rank base from two levels of counts and writes the
+    // APPLY tile index of the contigs that are applied with their group; the rewrite.
+    // Which one: measured on one box, c2 3 Gb, ms per step (profiles/r06_emission_train.txt).  A rank that owns everything and
+    // samples on the chain is bound by that chain, and the denser train slows the chain's kernels more than the six small
+    // launches with their gaps did: 3.88 (six) against 4.07-4.14 (three).  Where the samples' heavy kernels run off the chain
+    // (anchored windows: ranks of a sharded step, MSIM_AHEAD=2) the train is the bound: a rank owning 12 of 24 contigs 3.35-3.47
+    // (six) -> 3.18-3.21 (three); owning 3: 2.38-2.40 / 2.34-2.41.
+    const bool ahead_in_use = g->ahead == 2 || (g->ahead == 1 && g->sharded_rank);
+    const bool train3 = g->emit_train == 3 || (g->emit_train == 0 && ahead_in_use);
+    std::vector<int> applies;
+    if (train3) {
+        uint32_t cblk = 0;
+        for (uint32_t i = 0; i < J.n; i++) {
+            const EmitItem &it = items[i];
+            EmitJob &T = J.j[i];
+            T.cblk0 = cblk;
+            cblk += (it.bnb + EMIT_SUPER - 1) / EMIT_SUPER;
+            T.first = nullptr; T.err = nullptr; T.n_tiles = 0;
+            if (it.apply && (size_t)it.contig < c->contigs.size()) {
+                Contig &ct = c->contigs[(size_t)it.contig];
+                ct.apply_stream = es;                      // (apply_batch_device takes contigs with a stream of their own)
+                uint32_t shift = 0;
+                const int rc = apply_prepare_tile_index(c, ct, es, &T.first, &T.n_tiles, &shift, &T.err);
+                if (rc) return rc;
+                J.tile_shift = shift;
+                if (!T.n_tiles) T.first = nullptr;
+                applies.push_back(it.contig);
+            }
+        }
+        J.total_cblk = cblk;
+    }
     hipEvent_t ce = next_chain_event(g);
     MSIM_HIP(c, hipEventRecord(ce, c->stream));
     MSIM_HIP(c, hipStreamWaitEvent(es, ce, 0));
-    hipLaunchKernelGGL(k_bitmap_count_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
-    hipLaunchKernelGGL(k_scan_u32_b, dim3(J.n), dim3(256), 0, es, J);
-    hipLaunchKernelGGL(k_snp_emit_abs_b, dim3(eblk), dim3(SNP_THREADS), 0, es, g->s[0].d_lanes, J);
-    hipLaunchKernelGGL(k_bitmap_expand_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
+    if (train3) {
+        hipLaunchKernelGGL(k_snp_emit_count_b, dim3(eblk + J.total_cblk), dim3(SNP_THREADS), 0, es, g->s[0].d_lanes, J);
+        hipLaunchKernelGGL(k_bitmap_expand_tiles_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
+    } else {
+        hipLaunchKernelGGL(k_bitmap_count_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
+        hipLaunchKernelGGL(k_scan_u32_b, dim3(J.n), dim3(256), 0, es, J);
+        hipLaunchKernelGGL(k_snp_emit_abs_b, dim3(eblk), dim3(SNP_THREADS), 0, es, g->s[0].d_lanes, J);
+        hipLaunchKernelGGL(k_bitmap_expand_b, dim3(blk), dim3(BM_THREADS), 0, es, J);
+    }
     MSIM_HIP(c, hipGetLastError());
-    std::vector<int> applies;
     for (const EmitItem &it : items) {
-        MSIM_HIP(c, hipEventRecord(it.S->emit_done, es));
-        it.S->pending = true;
-        MSIM_HIP(c, hipEventRecord(it.T->emit_done, es));
-        it.T->pending = true;
-        if (it.apply && (size_t)it.contig < c->contigs.size()) {
+        if (!train3 && it.apply && (size_t)it.contig < c->contigs.size()) {
             c->contigs[(size_t)it.contig].apply_stream = es;      // (apply_batch_device takes contigs with a stream of their own)
             applies.push_back(it.contig);
         }
     }
-    return applies.empty() ? MSIM_OK : apply_batch_device(c, applies, true);
+    const int arc = applies.empty() ? MSIM_OK : apply_batch_device(c, applies, true);
+    // the group's event: behind the rewrite (a scratch set meets its next user a step later -- what it waits for may as well
+    // include the APPLY)
+    hipEvent_t &ge = g->grp_ev[g->grp_i++ % (2 * N_SETS)];
+    if (!ge) MSIM_HIP(c, hipEventCreateWithFlags(&ge, hipEventDisableTiming));
+    MSIM_HIP(c, hipEventRecord(ge, es));
+    for (const EmitItem &it : items) {
+        it.S->wait_ev = ge; it.S->pending = true;
+        it.T->wait_ev = ge; it.T->pending = true;
+    }
+    return arc;
 }
 
 bool gpu_emit_pending(Ctx *c, int contig, bool mark_apply) {
@@ -1282,6 +1323,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
                                    ct.d_recs + rec_base, (const uint8_t *)nullptr);
                 MSIM_HIP(c, hipGetLastError());
                 MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
+                S.wait_ev = S.emit_done;
                 S.pending = true;
             }
         }
@@ -1314,8 +1356,10 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
                                ct.d_recs, (const uint8_t *)aux8);
             MSIM_HIP(c, hipGetLastError());
             MSIM_HIP(c, hipEventRecord(S.emit_done, c->emit_stream));
+            S.wait_ev = S.emit_done;
             S.pending = true;
             MSIM_HIP(c, hipEventRecord(T.emit_done, c->emit_stream));
+            T.wait_ev = T.emit_done;
             T.pending = true;
         }
     }

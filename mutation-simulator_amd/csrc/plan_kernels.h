@@ -779,8 +779,13 @@ struct EmitJob {
     const uint64_t *bm; uint32_t *cnt2; msim_record *recs; uint8_t *aux8;
     const unsigned long long *base; const SnpMap *win_maps;
     uint32_t bmw, bnb, start, K, W2, nb2, blk0, eblk0;       // blk0 / eblk0: the job's first block in the bitmap / the emit grids
+    // the three-launch train (k_snp_emit_count_b, k_bitmap_expand_tiles_b): cblk0 = the job's first SUPER-block in the count
+    // grid; first / n_tiles / err: the contig's APPLY tile index and KeyError word, written by the expansion (first == nullptr:
+    // the contig is not applied with its group)
+    int32_t *first; unsigned long long *err;
+    uint32_t cblk0, n_tiles;
 };
-struct EmitJobs { EmitJob j[EMIT_G]; uint32_t n, d, total_blk, total_eblk; };
+struct EmitJobs { EmitJob j[EMIT_G]; uint32_t n, d, total_blk, total_eblk, total_cblk, tile_shift; };   // (tile = 1 << tile_shift bytes)
 __device__ __forceinline__ uint32_t emit_job_of(const EmitJobs &J, uint32_t blk, bool emit_grid) {
     uint32_t k = 0;
     for (uint32_t q = 1; q < J.n; q++) if ((emit_grid ? J.j[q].eblk0 : J.j[q].blk0) <= blk) k = q;
@@ -838,6 +843,104 @@ __global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand_b(EmitJobs J) {
     __shared__ uint32_t wsum[BM_THREADS / 64];
     const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, false)];
     bitmap_expand_body(T.bm, T.bmw, T.cnt2, T.start, J.d, T.recs, T.aux8, blockIdx.x - T.blk0, wsum);
+}
+
+// ---- the emission train in THREE launches (round 6; count, scan, outcomes, expansion, tile index, rewrite before):
+//   k_snp_emit_count_b      the SNP outcomes by rank (snp_emit_body) and, in the same grid, the bitmap's popcounts: a workgroup per
+//                           SUPER-block of 16 expansion blocks writes their 16 counts and the super-block's total -- exclusive
+//                           owners, no atomics, nothing to zero
+//   k_bitmap_expand_tiles_b the expansion; a workgroup makes its own rank base from the two levels (the totals of the super-blocks in
+//                           front of its own + the counts of the blocks in front of it inside: <= 16 loads per lane for n = 2^30 --
+//                           the scan launch is gone) and writes the APPLY tile index while it is there (below)
+//   k_rewrite_snp_b         (apply.hip)
+constexpr int EMIT_SUPER = 16;                            // expansion blocks per super-block (4096 bitmap words)
+__device__ __forceinline__ void bitmap_count_super_body(const uint64_t *__restrict__ bm, uint32_t n_words,
+                                                        uint32_t *__restrict__ block_cnt, uint32_t *__restrict__ super_cnt,
+                                                        uint32_t sb, uint32_t *red) {
+    // wave w takes blocks 4q + w of the super-block (q = 0 .. 3): four 64-word loads per lane and block, a wave reduction each
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int q = 0; q < EMIT_SUPER / 4; q++) {
+        const uint32_t blk = sb * EMIT_SUPER + q * 4 + wave;
+        uint32_t c = 0;
+#pragma unroll
+        for (int r = 0; r < BM_THREADS / 64; r++) {
+            const uint32_t i = blk * BM_THREADS + r * 64 + lane;
+            c += i < n_words ? (uint32_t)__popcll(bm[i]) : 0u;
+        }
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) { block_cnt[blk] = c; tot += c; }    // (the count array holds whole super-blocks: plan_gpu.hip sizes it so)
+    }
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) super_cnt[sb] = red[0] + red[1] + red[2] + red[3];
+}
+
+// first[t] = (number of records at or in front of position t * tile) - 1 for t = 0 .. n_tiles -- what k_tile_index finds by a binary
+// search per tile over the finished table (apply.hip), here from the expansion's own registers: the positions a bitmap word's bits
+// can take are the interval [start + 64 i + d rank_before(i), start + 64 (i + 1) + d rank_before(i + 1)), the intervals of
+// consecutive words tile the axis, so every tile border lies in exactly one lane's interval (the first word's reaches down to 0, the
+// last word's up to the last border), and that lane counts how many of its own bits lie at or in front of the border.
+__device__ __forceinline__ void expand_tile_borders(uint64_t w, uint32_t i, uint32_t n_words, uint32_t start, uint32_t d,
+                                                    uint32_t rank, uint32_t c, uint32_t tile_shift, uint32_t n_tiles,
+                                                    int32_t *__restrict__ first) {
+    const unsigned long long p_lo = i == 0 ? 0ull : (unsigned long long)start + 64ull * i + (unsigned long long)d * rank;
+    const unsigned long long p_hi = i + 1 == n_words ? ~0ull
+                                                     : (unsigned long long)start + 64ull * (i + 1) + (unsigned long long)d * (rank + c);
+    unsigned long long t = (p_lo + ((1ull << tile_shift) - 1)) >> tile_shift;
+    for (; t <= n_tiles && (t << tile_shift) < p_hi; t++) {
+        const unsigned long long B = t << tile_shift;
+        uint32_t below = 0, r = rank;
+        uint64_t x = w;
+        while (x) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(x);
+            if ((unsigned long long)start + 64ull * i + bit + (unsigned long long)d * r > B) break;
+            x &= x - 1;
+            below++; r++;
+        }
+        first[t] = (int32_t)(rank + below) - 1;
+    }
+}
+__global__ __launch_bounds__(BM_THREADS) void k_bitmap_expand_tiles_b(EmitJobs J) {
+    __shared__ uint32_t wsum[BM_THREADS / 64];
+    __shared__ uint32_t bsum[BM_THREADS / 64];
+    const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, false)];
+    const uint32_t blk = blockIdx.x - T.blk0;
+    const uint32_t sb = blk / EMIT_SUPER, n_super = (T.bnb + EMIT_SUPER - 1) / EMIT_SUPER;
+    const uint32_t *super_cnt = T.cnt2 + (size_t)n_super * EMIT_SUPER;
+    // the block's rank base: super-block totals in front of its super-block + block counts in front of it inside
+    uint32_t v = 0;
+    for (uint32_t j = threadIdx.x; j < sb; j += BM_THREADS) v += super_cnt[j];
+    if (threadIdx.x < blk % EMIT_SUPER) v += T.cnt2[sb * EMIT_SUPER + threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) bsum[threadIdx.x >> 6] = v;
+    const uint32_t i = blk * BM_THREADS + threadIdx.x;
+    uint64_t w = i < T.bmw ? T.bm[i] : 0;
+    const uint32_t c = (uint32_t)__popcll(w);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o, 64);
+        if ((threadIdx.x & 63) >= (unsigned)o) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    for (uint32_t q = 0; q < (threadIdx.x >> 6); q++) incl += wsum[q];
+    uint32_t rank = bsum[0] + bsum[1] + bsum[2] + bsum[3] + incl - c;
+    if (T.first) {
+        if (blk == 0 && threadIdx.x == 0) *T.err = ~0ull;  // the contig's KeyError word: none so far (the rewrite kernel follows)
+        if (i < T.bmw) expand_tile_borders(w, i, T.bmw, T.start, J.d, rank, c, J.tile_shift, T.n_tiles, T.first);
+    }
+    while (w) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(w);
+        w &= w - 1;
+        const uint32_t pos = T.start + (i * 64 + bit) + J.d * rank;
+        msim_record r;
+        r.pos = pos; r.stop = pos; r.extra = 0; r.type = MSIM_SN; r.aux = T.aux8[rank]; r.rsv = 0;
+        T.recs[rank] = r;
+        rank++;
+    }
 }
 
 // ------------------------------------------------------------------ 5. SNP ti/tv transducer
@@ -1175,6 +1278,24 @@ __global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_abs_b(const SnpLane *_
     __shared__ SnpMap wave_tot[SNP_THREADS / 64];
     const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, true)];
     snp_emit_body(lanes, T.base, T.W2, T.win_maps, T.nb2, T.recs, T.K, nullptr, T.aux8, blockIdx.x - T.eblk0, wave_tot);
+}
+// ... and with the bitmap's popcounts in the same grid: blocks [0, total_eblk) are k_snp_emit_abs_b's, blocks behind them count one
+// super-block each (two independent jobs of the emission train in ONE launch; SNP_THREADS == BM_THREADS)
+static_assert(SNP_THREADS == BM_THREADS, "k_snp_emit_count_b runs both bodies with one block size");
+__global__ __launch_bounds__(SNP_THREADS) void k_snp_emit_count_b(const SnpLane *__restrict__ lanes, EmitJobs J) {
+    __shared__ SnpMap wave_tot[SNP_THREADS / 64];
+    __shared__ uint32_t red[BM_THREADS / 64];
+    if (blockIdx.x < J.total_eblk) {
+        const EmitJob &T = J.j[emit_job_of(J, blockIdx.x, true)];
+        snp_emit_body(lanes, T.base, T.W2, T.win_maps, T.nb2, T.recs, T.K, nullptr, T.aux8, blockIdx.x - T.eblk0, wave_tot);
+        return;
+    }
+    const uint32_t cb = blockIdx.x - J.total_eblk;
+    uint32_t k = 0;
+    for (uint32_t q = 1; q < J.n; q++) if (J.j[q].cblk0 <= cb) k = q;
+    const EmitJob &T = J.j[k];
+    const uint32_t n_super = (T.bnb + EMIT_SUPER - 1) / EMIT_SUPER;
+    bitmap_count_super_body(T.bm, T.bmw, T.cnt2, T.cnt2 + (size_t)n_super * EMIT_SUPER, cb - T.cblk0, red);
 }
 
 // ------------------------------------------------------------------ 6. SV mixes: candidates, types, filter

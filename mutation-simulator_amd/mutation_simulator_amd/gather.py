@@ -29,7 +29,10 @@ def owners_of(parts, n_contigs: int):
 
 
 class Communicator:
-    """One per rank.  ``dist`` = an initialised ``torch.distributed`` module (any backend) or None for world 1."""
+    """One per rank.  ``dist`` = an initialised ``torch.distributed`` module or None for world 1.  The control plane moves CPU
+    objects and CPU tensors (the ``ncclUniqueId``, the sizes exchange): its process group needs a CPU-capable backend -- ``gloo``,
+    what ``bench.py`` and ``multi_gpu.py`` initialise.  Under a device-only group (``nccl``) the sizes go by ``all_gather_object``
+    instead of the packed ``all_reduce`` (slower, pickles; correct)."""
 
     def __init__(self, engine, rank: int, world: int, dist=None):
         self.eng, self.rank, self.world, self.dist = engine, rank, world, dist
@@ -70,8 +73,13 @@ class Communicator:
                 if owner[i] == self.rank:
                     a, b, c = self.eng.result_sizes(cid)
                     t[i], t[n + i], t[2 * n + i] = int(a), int(b), int(c)
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
-            v = t.tolist()
+            if "gloo" in str(self.dist.get_backend()):
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+                v = t.tolist()
+            else:                                          # a device-only backend cannot reduce a CPU tensor
+                rows = [None] * self.world
+                self.dist.all_gather_object(rows, t.tolist())
+                v = [sum(col) for col in zip(*rows)]
             return owner, v[:n], v[n:2 * n], v[2 * n:]
         lens, nrec, pool = [0] * n, [0] * n, [0] * n
         for i, cid in enumerate(contig_ids):

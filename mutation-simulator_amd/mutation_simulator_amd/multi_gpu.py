@@ -196,6 +196,18 @@ def _copy_range(src, offset: int, nbytes: int, write):
         left -= len(chunk)
 
 
+def die_with_parent():
+    """``preexec_fn`` of a worker: SIGKILL when the parent goes away (PR_SET_PDEATHSIG) -- a parent that is killed from outside
+    (a watchdog's ``os._exit``, a lease's limit) never reaches the ``finally`` that ends its workers, and an orphan would go on
+    holding its GPU."""
+    try:
+        import ctypes
+        import signal
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGKILL), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+    except Exception:  # noqa: BLE001  (not Linux: the worker simply lives as before)
+        pass
+
+
 def mutate_sharded(m: Mutator):
     """``Mutator.mutate()`` for ``--gpus N`` (the parent side; see the module docstring)."""
     import pickle
@@ -215,7 +227,7 @@ def mutate_sharded(m: Mutator):
     try:
         for r in range(world):
             procs.append(subprocess.Popen([sys.executable, "-m", "mutation_simulator_amd.multi_gpu", str(job), str(r)],
-                                          env=env, stdout=subprocess.DEVNULL))
+                                          env=env, stdout=subprocess.DEVNULL, preexec_fn=die_with_parent))
         # All workers are watched together: the first one that dies without a result or reports a fatal error (no device,
         # a bad MSIM_SHARD_DEVICES) ends the run at once -- the others are killed (finally:) instead of being left to finish
         # their whole share -- and a worker that hangs (a stuck GPU) is bounded by MSIM_SHARD_TIMEOUT seconds (0 = none).

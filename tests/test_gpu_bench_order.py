@@ -179,3 +179,29 @@ def test_bench_cpu_baseline_carries_matches_gpu():
     assert out["matches_gpu_detail"]["apply_launches"] == 2
     out = bench.cpu_baseline(24_000_000, "c3", n_contigs=3, device=0)
     assert out["matches_gpu"] is True, out
+
+
+@pytest.mark.parametrize("train", ["3", "6"])
+@pytest.mark.parametrize("sn_block", [1, 300])
+def test_emission_train_tile_index_with_ranges_inside_the_contig_vs_oracle(train, sn_block, monkeypatch):
+    """The three-launch emission train (outcomes + popcounts, expansion with its own rank base and the APPLY tile index, rewrite)
+    where the tile index has edges to get right: RMT contigs whose ONE drawing range starts and ends inside the contig (tile
+    borders in front of the first and behind the last bitmap word), a range of one base short of the contig, contigs shorter
+    than a tile and of exactly whole tiles, and a sampling distance of 300 (every `*_block` = 300: a bitmap word's positions span several
+    16 KiB tiles) -- all in the bench's order (groups of two, applied with their group) against the ORACLE; the six-launch
+    train of rounds 4-5 (MSIM_EMIT_TRAIN=6) through the same cases."""
+    monkeypatch.setenv("MSIM_EMIT_TRAIN", train)
+    lengths = [5_000_000, 3_000_000, 4_000_000, 16_384 * 40, 2_000_003, 1_000_000]
+    head = "".join(f"{t}_block = {sn_block}\n" for t in ("sn", "in", "de", "iv", "du", "tl")) if sn_block != 1 else ""
+    rate = "0.0016" if sn_block != 1 else "0.01"             # (k >= 4096 on the Mb-sized contigs: the SNP sampler)
+    text = (
+            head + "std\nit None\nNone\n\n"
+            f"chr 1\n1000001-4000000 sn {rate}\n"
+            f"chr 2\n20001-2999000 sn {rate}\n"
+            f"chr 3\n1-3999999 sn {rate}\n"
+            f"chr 4\n1-{16_384 * 40} sn {rate}\n"
+            f"chr 5\n500001-2000003 sn {rate}\n"
+            f"chr 6\n1-900000 sn {rate}\n")
+    sim = bench.workload_settings_rmt(lengths, text)
+    st = _bench_order_vs_oracle("c2", lengths, sim=sim)
+    assert st["contigs_snp"] >= 3, {k: v for k, v in st.items() if k.startswith("contigs_")}

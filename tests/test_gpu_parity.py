@@ -421,6 +421,8 @@ def _run_sharded(tmp_path, transport, one_device):
     import subprocess
     import sys
     from pathlib import Path
+
+    from mutation_simulator_amd.multi_gpu import die_with_parent
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -430,8 +432,14 @@ def _run_sharded(tmp_path, transport, one_device):
             "_sharded_worker({rank}, 2, {port}, {out!r}, {transport!r}, {one!r})\n")
     procs = [subprocess.Popen([sys.executable, "-c", code.format(here=here, rank=r, port=port, out=str(tmp_path), transport=transport,
                                                                   one=one_device)],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=540)[0] for p in procs]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, preexec_fn=die_with_parent)
+             for r in range(2)]
+    try:
+        outs = [p.communicate(timeout=540)[0] for p in procs]
+    finally:                                               # (a worker that outlives its test would keep the GPU)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
     res = json.loads((tmp_path / "sharded.json").read_text())
     bad = [c for c in res["checked"] if not c[3]]
