@@ -176,7 +176,7 @@ struct GpuPlan {
     uint64_t verified_pos = 0;          // exact position at the last finish
     uint64_t reserve_words[2] = {0, 0};
     // per context, read when it is created (tests run several group sizes / stream spans in one process):
-    int emit_group = 2;                 //   contigs per emission group (MSIM_EMIT_GROUP; see plan_contig_gpu)
+    int emit_group = 0;                 //   contigs per emission group (MSIM_EMIT_GROUP; 0 = by the context's role: see plan_contig_gpu)
     int emit_train = 0;                 //   launches of an emission group's train: 3, 6, or 0 = by the context's role (gpu_emit_flush; MSIM_EMIT_TRAIN)
     uint32_t max_chunks = MT_JUMP_MAX_CHUNKS;   //   chunks one (re)seeded session may span (MSIM_DBG_JUMP_MAX_CHUNKS lowers it)
     uint32_t rebases = 0;               //   sessions ended because the next contig would not fit into the span
@@ -200,7 +200,7 @@ struct GpuPlan {
     // walks the other ranks' contigs for their stream positions only, is bound by the chain: 2.63 -> 2.30 ms owning none of 24,
     // 2.95 -> 2.48 owning three (profiles/r05_sharded_rank_steps.txt).  So: ahead on a context that has been asked for
     // msim_plan_chain in this pass or the last one.
-    int ahead = 1;                      //   0 never (MSIM_NO_AHEAD), 1 sharded ranks, 2 always (MSIM_AHEAD=2)
+    int ahead = 2;                      //   0 never (MSIM_NO_AHEAD), 1 sharded ranks only (round 5's default), 2 always
     uint32_t pass_chain_only = 0;       //   msim_plan_chain calls in this pass
     bool sharded_rank = false;          //   ... there were some in this pass or in the one before
     bool est_ok = false;
@@ -226,7 +226,7 @@ static int grow(Ctx *c, void **p, size_t *cap, size_t want_bytes, bool *grew) {
 
 GpuPlan *gpu_plan_create() {
     GpuPlan *g = new GpuPlan();
-    if (const char *e = getenv("MSIM_EMIT_GROUP")) g->emit_group = std::min(EMIT_G, std::max(1, atoi(e)));
+    if (const char *e = getenv("MSIM_EMIT_GROUP")) g->emit_group = std::min(EMIT_G, std::max(0, atoi(e)));
     if (const char *e = getenv("MSIM_DBG_JUMP_MAX_CHUNKS"))
         g->max_chunks = (uint32_t)std::min<long>(MT_JUMP_MAX_CHUNKS, std::max<long>(2, atol(e)));
     if (const char *e = getenv("MSIM_EMIT_TRAIN")) g->emit_train = atoi(e) == 3 ? 3 : atoi(e) == 6 ? 6 : 0;
@@ -945,8 +945,11 @@ static int prep_wait_words(Ctx *c, GpuPlan *g, uint64_t upto) {
     return MSIM_OK;
 }
 
+// grouped: the contig's emission goes out with a group (gpu_emit_flush) -- the group's event, behind its rewrite launch, then also
+// covers the chain kernels enqueued here (the emit stream waited for the plan stream's position at the flush), so no event of the
+// set's own is recorded behind them: one packet less per contig on the chain's queue
 static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t d, uint64_t lo, uint64_t H, uint64_t e_limit,
-                                bool &grew, SampleLaunch &out, bool &took) {
+                                bool &grew, SampleLaunch &out, bool &took, bool grouped) {
     int rc;
     const uint32_t K = (uint32_t)r.k;
     const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
@@ -1006,11 +1009,11 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     // an anchored window left an event behind its last chain kernel; behind a sample on the chain, whatever the plan stream holds
     if (!S.chain_done) MSIM_HIP(c, hipEventCreateWithFlags(&S.chain_done, hipEventDisableTiming));
     if (S.last_user == 1) MSIM_HIP(c, hipEventRecord(S.chain_done, c->stream));
-    if (S.last_user && hipEventQuery(S.chain_done) != hipSuccess) {
+    if ((S.last_user == 1 || S.last_user == 2) && hipEventQuery(S.chain_done) != hipSuccess) {
         (void)hipGetLastError();
         MSIM_HIP(c, hipStreamWaitEvent(ps_, S.chain_done, 0));
     }
-    S.last_user = 2;
+    S.last_user = grouped ? 3 : 2;                         // (3: its group's event -- S.wait_ev, checked above -- stands for chain_done)
     // ---- off the chain
     const uint32_t shift = (uint32_t)(32 - bits);
     hipLaunchKernelGGL(k_ahead_count, dim3(nb + nbh), dim3(ACC_THREADS), 0, ps_, raw, ps_core, ps_head, hdr, (unsigned long long)H,
@@ -1030,7 +1033,7 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, raw, S.acc, k_core, S.cnt, nb, W, shift, (uint32_t)n,
                        k_core, S.bitmap, g->d_ps, 1u, ps_core, hdr, (unsigned long long)e_limit);
     MSIM_HIP(c, hipGetLastError());
-    MSIM_HIP(c, hipEventRecord(S.chain_done, c->stream));
+    if (!grouped) MSIM_HIP(c, hipEventRecord(S.chain_done, c->stream));
     out.S = &S; out.W = W; out.bmw = bmw; out.bnb = bnb;
     c->t.snp_samples_ahead++;
     static const bool log_ahead = getenv("MSIM_DBG_AHEAD_LOG") != nullptr;
@@ -1268,7 +1271,11 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
     //  sixes 4.36-4.38 at 0.79 -- a larger group is a better rewrite launch and a longer stretch in which the chain's kernels
     //  crawl beside it, plus more left to do behind the last chain; groups cut by their bases instead of their count, 250-400 Mb
     //  with at most 4-6 contigs, were no better than threes; one per group = the ungrouped 4.6-5.1)
-    const int group = g->emit_group;
+    // (round 6: with the samples' heavy kernels off the chain -- anchored windows, now every context's default -- the train is the
+    //  bound and larger groups pay: fours 3.67-3.70 ms, threes 3.69-3.82, pairs 3.76-3.81 on a box where pairs with every sample
+    //  on the chain take 3.90-4.00; profiles/r06_emission_train.txt)
+    const bool ahead_role = g->ahead == 2 || (g->ahead == 1 && g->sharded_rank);
+    const int group = g->emit_group ? g->emit_group : (ahead_role ? 4 : 2);
     if (!g->emit_items.empty() && (!grouped || g->emit_d != (uint32_t)d || g->emit_items.size() >= (size_t)group))
         if ((rc = gpu_emit_flush(c))) return rc;
     struct { SampleSet *S; uint32_t bmw, bnb, start; } late = {nullptr, 0, 0, 0};
@@ -1299,7 +1306,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if (ahead) {
             // the sample ends at or in front of e_lim (and inside its window): what the SNP stage's windows are laid out from
             const uint64_t e_lim = est_hi(~0ull);
-            if ((rc = enqueue_sample_ahead(c, g, r, d, lo, H, e_lim, grew, sl, ahead))) return rc;
+            if ((rc = enqueue_sample_ahead(c, g, r, d, lo, H, e_lim, grew, sl, ahead, grouped))) return rc;
             if (ahead) pos_hi = std::min<uint64_t>(H + sl.W, e_lim) - sl.W;      // (+ W below)
         }
         if (!ahead && (rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl, nullptr, nullptr, est_hi(~0ull)))) return rc;

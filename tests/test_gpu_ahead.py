@@ -5,7 +5,8 @@ starts, the accepted draws in front of the anchor joined in once the exact start
 What has to hold: the same records and both streams at the same positions as the sequential host planner (which restates
 ``mutator.py:144-265`` and ``util.py:104-109``), whatever the uncertainty of the start, the accept ratio, the duplicate rate,
 the number of contigs in flight -- and a start outside the interval the host planned for is an error, never a wrong result.
-``MSIM_AHEAD=2`` plans every eligible sample this way (the default: only on a rank of a sharded step, where it pays)."""
+``MSIM_AHEAD=2`` plans every eligible sample this way (the default since round 6; ``MSIM_AHEAD=1``: only on a rank of a sharded
+step -- round 5's default; ``MSIM_NO_AHEAD``: never)."""
 from __future__ import annotations
 
 import numpy as np
@@ -115,12 +116,22 @@ def test_more_contigs_in_flight_than_scratch_sets(monkeypatch):
     assert gst["snp_samples_ahead"] >= 45          # (more than the 32 sets)
 
 
-def test_sharded_rank_takes_it_by_itself():
-    """Default policy: a context that walks other ranks' contigs (msim_plan_chain) plans ahead, one that owns everything does not."""
+def test_sharded_rank_takes_it_by_itself(monkeypatch):
+    """Policies: by default (round 6) every context plans ahead; MSIM_AHEAD=1 is round 5's -- a context that walks other ranks'
+    contigs (msim_plan_chain) plans ahead, one that owns everything does not; MSIM_NO_AHEAD: nobody."""
     rs = np.random.RandomState(21)
     contigs = _genome(rs, 10, lo=1_000_000, hi=4_000_000)
     params = _params(titv=2.0)
     host, hs, hst = _run_then_fetch(_ffi.PLAN_HOST, contigs, params, (8, 9))
+    full, fs, fst = _run_then_fetch(_ffi.PLAN_GPU, contigs, params, (8, 9))
+    _same(host, full, hs, fs, hst, fst)
+    assert fst["snp_samples_ahead"] >= len(contigs) // 2
+    monkeypatch.setenv("MSIM_NO_AHEAD", "1")
+    none, ns, nst = _run_then_fetch(_ffi.PLAN_GPU, contigs, params, (8, 9))
+    _same(host, none, hs, ns, hst, nst)
+    assert nst["snp_samples_ahead"] == 0
+    monkeypatch.delenv("MSIM_NO_AHEAD")
+    monkeypatch.setenv("MSIM_AHEAD", "1")
     full, fs, fst = _run_then_fetch(_ffi.PLAN_GPU, contigs, params, (8, 9))
     _same(host, full, hs, fs, hst, fst)
     assert fst["snp_samples_ahead"] == 0

@@ -98,8 +98,17 @@ def _bench_order_vs_oracle(workload, lengths, engines=None, launches=None, sim=N
 
 def test_config2_bench_order_full_genome_vs_oracle():
     """BASELINE configs[1] exactly as ``bench.py`` runs it: 24 contigs planned + applied, one synchronisation, then the
-    reads.  12 rewrite launches = the emission pairs went through ``k_rewrite_snp_b``."""
-    _bench_order_vs_oracle("c2", bench.contig_lengths(3_000_000_000), {"contigs_snp": 24}, launches=12)
+    reads.  6 rewrite launches = the emission groups (fours since round 6: anchored windows are every context's default)
+    went through ``k_rewrite_snp_b``; 23 of the 24 samples ran off the chain (the first starts at an exact position)."""
+    st = _bench_order_vs_oracle("c2", bench.contig_lengths(3_000_000_000), {"contigs_snp": 24}, launches=6)
+    assert st["snp_samples_ahead"] == 23
+
+
+def test_config2_bench_order_round5_schedule_vs_oracle(monkeypatch):
+    """The same with round 5's schedule (every sample on the chain, emission pairs, six-launch train): MSIM_NO_AHEAD."""
+    monkeypatch.setenv("MSIM_NO_AHEAD", "1")
+    st = _bench_order_vs_oracle("c2", bench.contig_lengths(3_000_000_000), {"contigs_snp": 24}, launches=12)
+    assert st["snp_samples_ahead"] == 0
 
 
 @pytest.mark.parametrize("workload,engines", [("c3", {"contigs_svmix": 24}), ("c4", {"contigs_hostcut": 24}),
@@ -176,7 +185,7 @@ def test_bench_cpu_baseline_carries_matches_gpu():
     (here on a reduced sample; the driver's run uses 4 x 250 Mb)."""
     out = bench.cpu_baseline(40_000_000, "c2", n_contigs=4, device=0)
     assert out["matches_gpu"] is True, out
-    assert out["matches_gpu_detail"]["apply_launches"] == 2
+    assert out["matches_gpu_detail"]["apply_launches"] == 1          # (one emission group of four: k_rewrite_snp_b)
     out = bench.cpu_baseline(24_000_000, "c3", n_contigs=3, device=0)
     assert out["matches_gpu"] is True, out
 
