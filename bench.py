@@ -579,7 +579,7 @@ def roofline_of(st, workload, steps):
         source = ("measured during this run: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` of "
                   f"`bench.py --workload {workload} --steps 1`, per launch of the kernel; FETCH_SIZE x 2 (gfx950) = {live['fetch_bytes_x2']} "
                   f"+ WRITE_SIZE {live['write_bytes']} bytes")
-    for name in (() if live is not None else ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
+    for name in (() if live is not None else ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")):
         tf = ROOT / "profiles" / name
         if tf.exists():
             try:
