@@ -861,6 +861,11 @@ def main():
             "records_per_step": st["records"] // a.steps,
             "roofline": roofline_of(st, a.workload, a.steps),
         }
+        if st.get("snp_samples_ahead"):
+            # (anchored windows: samples whose heavy kernels ran off the stream-position chain, and how close the worst exact
+            #  start came to an edge of the +-(8 sigma + 256 words) interval the host planned for: 1000 = the edge = an error)
+            line["plan_ahead"] = {"samples_ahead_per_step": st["snp_samples_ahead"] // a.steps,
+                                  "margin_used_permille_worst": st.get("snp_ahead_margin_permille")}
         if world == 1:
             line["step_roofline"] = step_roofline(st, dt)
     LIVE_PMC[0] = False                                 # (the secondary workloads: profiles/r05_traffic.json)

@@ -148,6 +148,10 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     double host_walk_wait_ms;    /* ... and waiting: for the mailbox, for the pieces of its word window / candidates      */
     uint64_t host_walk_candidates;  /* candidates those chains walked (SV mix: the non-SNP ones; host chain: all)        */
     uint64_t host_cut_words;     /* stream words the host-cut engine's cuts went through                                  */
+    uint64_t snp_ahead_margin_permille;  /* anchored windows: the largest |exact start - expected start| of a sample planned
+                                    ahead of the chain, in permille of the deviation the host allowed for (8 sigma + 256 words:
+                                    1000 = the soft edge; beyond: MSIM_ERR_HIP, the caller re-plans) -- the maximum since
+                                    msim_reset_stats / the session's start.  Telemetry of the moment model behind the windows */
 } msim_timing;
 
 /* ---- lifetime -------------------------------------------------------------------------------- */

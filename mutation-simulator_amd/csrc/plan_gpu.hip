@@ -795,6 +795,7 @@ int gpu_plan_finish(Ctx *c, GpuPlan *g) {
         return fail(c, MSIM_ERR_HIP, "GPU sampler: a stream window overflowed its margin (16 sigma; 8 for the start of a sample planned ahead of the chain; results discarded)");
     }
     c->t.py_words += h.pos - g->verified_pos;
+    c->t.snp_ahead_margin_permille = std::max<uint64_t>(c->t.snp_ahead_margin_permille, h.ahead_margin_used);
     g->verified_pos = h.pos;
     g->s[0].pos = h.pos;
     return MSIM_OK;
@@ -949,7 +950,7 @@ static int prep_wait_words(Ctx *c, GpuPlan *g, uint64_t upto) {
 // covers the chain kernels enqueued here (the emit stream waited for the plan stream's position at the flush), so no event of the
 // set's own is recorded behind them: one packet less per contig on the chain's queue
 static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t d, uint64_t lo, uint64_t H, uint64_t e_limit,
-                                bool &grew, SampleLaunch &out, bool &took, bool grouped) {
+                                bool &grew, SampleLaunch &out, bool &took, bool grouped, uint64_t expect, uint32_t soft_half) {
     int rc;
     const uint32_t K = (uint32_t)r.k;
     const uint64_t n = (uint64_t)((r.stop - (r.k - 1) * d) - r.start);
@@ -1029,7 +1030,8 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     const uint32_t items_est = a_max + (uint32_t)(dups_est + 16.0 * std::sqrt(dups_est) + 64.0);
     const uint32_t G = std::max(1u, std::min(256u, (items_est + ACC_THREADS * FRINGE_ITEMS - 1) / (ACC_THREADS * FRINGE_ITEMS)));
     hipLaunchKernelGGL(k_ahead_fringe, dim3(G), dim3(ACC_THREADS), 0, c->stream, raw, g->d_ps, ps_core, ps_head, hdr,
-                       (unsigned long long)lo, F, S.hcnt, nbh, S.hacc, S.acc, K, k_core, shift, (uint32_t)n, S.bitmap);
+                       (unsigned long long)lo, F, S.hcnt, nbh, S.hacc, S.acc, K, k_core, shift, (uint32_t)n, S.bitmap,
+                       (unsigned long long)expect, soft_half);
     hipLaunchKernelGGL(k_sample_tail, dim3(1), dim3(1024), 0, c->stream, raw, S.acc, k_core, S.cnt, nb, W, shift, (uint32_t)n,
                        k_core, S.bitmap, g->d_ps, 1u, ps_core, hdr, (unsigned long long)e_limit);
     MSIM_HIP(c, hipGetLastError());
@@ -1290,11 +1292,14 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         const StreamMoments ms = sample_words_moments((uint64_t)n_d, (uint64_t)k);
         const double e_samp = ms.e, v_samp = ms.v;
         bool ahead = false;
-        uint64_t lo = 0, H = 0;
+        uint64_t lo = 0, H = 0, expect = 0;
+        uint32_t soft_half = 0;
         if ((g->ahead == 2 || (g->ahead == 1 && g->sharded_rank)) && (grouped || (c->chain_only && n_draw == 1)) && g->est_ok && (uint64_t)n_d <= ((uint64_t)MAX_BINS << BIN_SHIFT) && 4.0 * (double)k <= n_d) {
             // the interval costs what it holds (its accepted draws go through the fringe pass on the chain): g->ahead_sigma
             // (8) standard deviations instead of the windows' 16 -- a start outside it is reported like an overflowed window
             const double m = g->est_v > 0.0 ? g->ahead_sigma * std::sqrt(1.1 * g->est_v) + 256.0 : 0.0;
+            expect = (uint64_t)std::max(0.0, g->est_e);
+            soft_half = (uint32_t)std::min(4.0e9, m);
             lo = std::max<uint64_t>(g->est_lo, (uint64_t)std::max(0.0, std::floor(g->est_e - m)));
             H = std::max<uint64_t>(lo, std::min<uint64_t>(pos_hi, (uint64_t)std::ceil(g->est_e + m)));
             // (a sample smaller than the uncertainty of its start stays on the chain; so does one whose start is known exactly --
@@ -1306,7 +1311,7 @@ int plan_contig_gpu(Ctx *c, GpuPlan *g, Contig &ct, const msim_range *ranges, in
         if (ahead) {
             // the sample ends at or in front of e_lim (and inside its window): what the SNP stage's windows are laid out from
             const uint64_t e_lim = est_hi(~0ull);
-            if ((rc = enqueue_sample_ahead(c, g, r, d, lo, H, e_lim, grew, sl, ahead, grouped))) return rc;
+            if ((rc = enqueue_sample_ahead(c, g, r, d, lo, H, e_lim, grew, sl, ahead, grouped, expect, soft_half))) return rc;
             if (ahead) pos_hi = std::min<uint64_t>(H + sl.W, e_lim) - sl.W;      // (+ W below)
         }
         if (!ahead && (rc = enqueue_sample_chain(c, g, r, d, pos_hi, grew, sl, nullptr, nullptr, est_hi(~0ull)))) return rc;

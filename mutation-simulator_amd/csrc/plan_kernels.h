@@ -41,6 +41,8 @@ struct PlanState {
     uint32_t n_rec, n_sn;          // SV mixes: kept mutations / kept SNPs of the current contig
     uint32_t pool_len;             // SV mixes: insert bases of the current contig
     long long len_delta;           // SV mixes: output length - input length of the current contig (kept IN/DU +len, DE -len)
+    uint32_t ahead_margin_used;    // anchored windows: the largest |exact start - expected start| of a sample planned ahead, in permille
+    uint32_t rsv;                  //   of the deviation the host allowed for (8 sigma + 256 words; k_ahead_fringe)
 };
 
 // ------------------------------------------------------------------ 1. MT19937 in bulk
@@ -547,7 +549,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ahead_fringe(const uint32_t *__
                                                               const uint32_t *__restrict__ hcnt, uint32_t nbh,
                                                               const uint32_t *__restrict__ hacc, const uint32_t *__restrict__ tail,
                                                               uint32_t K, uint32_t k_core, uint32_t shift, uint32_t n,
-                                                              uint32_t *__restrict__ bitmap) {
+                                                              uint32_t *__restrict__ bitmap, unsigned long long expect,
+                                                              uint32_t soft_half) {
+    // expect / soft_half: the start the host expected and the half-width 8 sigma + 256 it allowed around it BEFORE the hard
+    // bounds clipped the interval to [lo, lo + F] (a start at a hard bound is certain, not lucky): telemetry only
     __shared__ uint32_t red[ACC_THREADS / 64];
     __shared__ uint32_t hoff[AHEAD_MAX_HEAD_BLOCKS + 1];   // accepted draws of [s, H) in front of head block b
     __shared__ uint32_t wsum[ACC_THREADS / 64];
@@ -557,6 +562,10 @@ __global__ __launch_bounds__(ACC_THREADS) void k_ahead_fringe(const uint32_t *__
         return;
     }
     const uint32_t rel = (uint32_t)(s - lo);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && soft_half) {   // telemetry: how much of the allowed deviation this start used
+        const unsigned long long dev = s > expect ? s - expect : expect - s;
+        atomicMax(&ps->ahead_margin_used, (uint32_t)min(1000000ull, 1000ull * dev / soft_half));
+    }
     const uint32_t blk = min(rel / ACC_BLOCK, nbh);         // head block that holds s (nbh: s == H on a block border)
     uint32_t h_acc = 0, skip = 0;
     if (nbh) {
@@ -1963,6 +1972,7 @@ __global__ void k_state_init(PlanState *ps, unsigned long long pos) {
     ps->pos = pos; ps->snp_base = pos; ps->flags = 0; ps->dups = 0; ps->accepted_used = 0;
     ps->n_nsn = ps->n_rec = ps->n_sn = ps->pool_len = 0;
     ps->len_delta = 0;
+    ps->ahead_margin_used = 0; ps->rsv = 0;
 }
 
 }  // namespace

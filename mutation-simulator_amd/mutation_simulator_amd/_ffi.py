@@ -77,7 +77,8 @@ class Timing(C.Structure):           # msim_timing
                 ("contigs_fast", C.c_uint64), ("stream_rebases", C.c_uint64),
                 ("snp_samples_ahead", C.c_uint64),
                 ("host_walk_run_ms", C.c_double), ("host_walk_wait_ms", C.c_double),
-                ("host_walk_candidates", C.c_uint64), ("host_cut_words", C.c_uint64)]
+                ("host_walk_candidates", C.c_uint64), ("host_cut_words", C.c_uint64),
+                ("snp_ahead_margin_permille", C.c_uint64)]
 
     def as_dict(self) -> dict:
         return {name: getattr(self, name) for name, _ in self._fields_}

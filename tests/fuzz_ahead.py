@@ -32,6 +32,7 @@ def main():
     always_big = len(sys.argv) > 3 and sys.argv[3] == "big"
     rs = np.random.RandomState(seed)
     ahead_total = 0
+    worst = 0
     for it in range(iters):
         d = int(rs.choice([1, 1, 2, 3]))
         titv = float(rs.choice([0.0, 0.5, 1.0, 2.0, 7.5, 1e9]))
@@ -73,8 +74,10 @@ def main():
             print("FAILED", what)
             raise
         ahead_total += gst["snp_samples_ahead"]
+        worst = max(worst, gst.get("snp_ahead_margin_permille", 0))
         print(f"it {it} ok  {n_contigs} contigs, {gst['snp_samples_ahead']} samples ahead, {len(chain_only)} walked", flush=True)
-    print(f"fuzz: {iters} iterations identical to the host planner, {ahead_total} samples ahead of the chain")
+    print(f"fuzz: {iters} iterations identical to the host planner, {ahead_total} samples ahead of the chain; the worst start used "
+          f"{worst / 10:.1f} % of the deviation the host allowed for (8 sigma + 256 words; 100 % = the soft edge = an error)")
 
 
 if __name__ == "__main__":

@@ -31,7 +31,7 @@ def test_struct_layouts_match_header():
     assert _ffi.C.sizeof(_ffi.Record) == 16 and _ffi.RECORD_DTYPE.itemsize == 16
     assert _ffi.C.sizeof(_ffi.Range) == 8 * 4 + 4 + 4 * 8 + 4 + 8 * 8 * 3
     assert _ffi.C.sizeof(_ffi.Params) == 72
-    assert _ffi.C.sizeof(_ffi.Timing) == 5 * 8 + 15 * 8 + 4 * 8
+    assert _ffi.C.sizeof(_ffi.Timing) == 5 * 8 + 15 * 8 + 5 * 8
 
 
 def test_no_silent_cpu_fallback():

@@ -198,3 +198,6 @@ def test_full_size_genome_ahead_vs_oracle(monkeypatch, owned):
     st = _bench_order_vs_oracle("c2", lengths, owned=owned)
     assert st["snp_samples_ahead"] >= 20, st["snp_samples_ahead"]
     assert st["contigs_snp"] == (24 if owned is None else len(owned))
+    # the moment model behind the intervals, observed: the worst of the 23 exact starts used this much of the allowed
+    # deviation (8 sigma + 256 words = 1000); 5 sigma of 8 would be ~600
+    assert 0 < st["snp_ahead_margin_permille"] < 650, st["snp_ahead_margin_permille"]
