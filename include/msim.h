@@ -137,10 +137,10 @@ typedef struct msim_timing {  /* milliseconds; device stages are HIP-event times
     uint64_t stream_rebases;     /* device MT19937 sessions re-based: the jump tables span 8192 chunks (1.31 G words) from a
                                     session's origin; before a contig that would not fit, the state at the streams' exact
                                     positions becomes the next session's origin (no limit on a run's stream length)     */
-    uint64_t snp_samples_ahead;  /* SNP sampler, on a rank of a sharded step (msim_plan_chain in use): samples -- of owned contigs
-                                    and of contigs walked for their stream positions alike -- whose count / scatter / de-dup
-                                    ran off the stream-position chain, on a window anchored at the host's bound of the start
-                                                                                                     */
+    uint64_t snp_samples_ahead;  /* SNP sampler: samples -- of owned contigs and of contigs walked for their stream positions
+                                    (msim_plan_chain) alike -- whose count / scatter / de-dup ran off the stream-position chain,
+                                    on a window anchored at the host's bound of the start (every
+                                    context's default since round 6, MSIM_AHEAD=1: sharded ranks only, MSIM_NO_AHEAD: never) */
     /* The host-sequential stages of the bit-compatible engines, apart from what surrounds them (round 6, ABI 8): a slower
        host core shows in host_walk_run_ms per item, a slower link or device in host_walk_wait_ms -- so that "slower box" and
        "slower code" can be told apart from one bench line.                                                              */
@@ -248,7 +248,7 @@ int msim_build_ranges(const msim_settings_desc *sets, int n_sets, const int64_t 
  * internal window overflow) are reported by the next call that synchronises: msim_sync,
  * msim_result_sizes(out_len), msim_fetch_*, msim_result_checksum, msim_get_mt_state, msim_stats, the text calls.
  * Enqueued does not mean launched at once: contigs the SNP sampler planned from ONE drawing range (ARGS mode) gather in groups
- * (pairs by default) whose emission stages, tile index and rewrite go to the device as one launch each; the APPLYs of contigs
+ * (fours by default) whose emission stages and rewrite go to the device as one launch each; the APPLYs of contigs
  * planned by an engine with a host chain wait for the walks of the contigs behind them and go out three at a time --
  * when the next msim_plan_contig arrives or at any other entry point, whichever comes first (plan + apply a whole genome,
  * then ask: that is the fast order; asking after every contig is as correct and launches per contig).                  */

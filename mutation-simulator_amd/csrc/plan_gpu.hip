@@ -195,11 +195,10 @@ struct GpuPlan {
     int n_prep = 3, prep_i = 0, prep_prio = 0;
     double ahead_sigma = 8.0;
     uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
-    // Measured (c2, 3 Gb, tools/compat_steps.py): a rank that owns every contig is bound by its emission + APPLY train either way
-    // and the extra off-chain launches only slow that train (4.1 ms on the chain, 4.2-4.7 ahead); a rank of a sharded step, which
-    // walks the other ranks' contigs for their stream positions only, is bound by the chain: 2.63 -> 2.30 ms owning none of 24,
-    // 2.95 -> 2.48 owning three (profiles/r05_sharded_rank_steps.txt).  So: ahead on a context that has been asked for
-    // msim_plan_chain in this pass or the last one.
+    // Who plans ahead.  Round 5: only a context that has been asked for msim_plan_chain in this pass or the last one (a rank that
+    // owns every contig was bound by its emission + APPLY train either way: 4.1 ms on the chain, 4.2-4.7 ahead).  Round 6: with the
+    // train in three launches, one event per group and groups of four (gpu_emit_flush) everybody: 3.66 ms against 4.03-4.12
+    // (profiles/r06_emission_train.txt).
     int ahead = 2;                      //   0 never (MSIM_NO_AHEAD), 1 sharded ranks only (round 5's default), 2 always
     uint32_t pass_chain_only = 0;       //   msim_plan_chain calls in this pass
     bool sharded_rank = false;          //   ... there were some in this pass or in the one before
