@@ -186,10 +186,10 @@ C3_FLAGS = ["-in", "0.001", "-inmin", "1", "-inmax", "50", "-de", "0.001", "-dem
 README_FLAGS = ["-in", "0.01", "-de", "0.01", "-du", "0.01", "-iv", "0.01", "-tl", "0.01"]     # + -sn 0.01: README.md:430-446
 
 WORKLOADS = {
-    "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp_b",   # (two contigs per launch)
+    "c2": {"mode": "ARGS", "what": "-sn 0.01 -titv 2.0 (BASELINE configs[1])", "kernel": "msim::k_rewrite_snp_b",   # (an emission group per launch: four contigs)
            "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS SNP rate 0.01"},
     "c3": {"mode": "ARGS", "what": "full SV mix (BASELINE configs[2]): -sn 0.005 -in/-de 0.001 len 1-50, -du/-iv 0.0005 len 50-500",
-           "kernel": "msim::k_rewrite_b<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},   # (pairs)
+           "kernel": "msim::k_rewrite_b<140>", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, ARGS full SV mix"},   # (threes)
     "c4": {"mode": "RMT", "what": "RMT mode, gene-blocking file with hot/cold spots (BASELINE configs[3])",
            "kernel": "msim::k_rewrite_snp_b", "metric": "Mbases mutated/sec on 3 Gb synthetic genome, RMT hot/cold/blocked ranges"},
     "c4sv": {"mode": "RMT", "what": "RMT mode, the configs[3] gene-blocking file with the configs[2] SV mix as its std line "
