@@ -1498,7 +1498,17 @@ static int ensure_signals(Ctx *c, GpuPlan *g) {
         memset(g->h_sig, 0, 4096);
     }
     if (!g->copy_stream) {
-        MSIM_HIP(c, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
+        {   // The candidates' copy stream lives in the LOW-priority pool of hardware queues (with the generation and the jump stream:
+            // three of that pool's four).  The runtime gives a process four queues per priority; at normal priority the context
+            // already has the emission stream and the three side streams of the anchored windows, and a fifth stream there shares
+            // a queue: behind c2 passes the SV-mix engine's step took 30.4-30.6 ms with this stream at normal priority, 29.7-30.0
+            // here (profiles/r06_copy_stream_priority.txt).  MSIM_COPY_PRIO=0 / -1: normal / the plan stream's priority.
+            int lo = 0, hi = 0;
+            MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char *e = getenv("MSIM_COPY_PRIO");
+            const int prio = !e ? lo : atoi(e) > 0 ? lo : atoi(e) < 0 ? hi : 0;
+            MSIM_HIP(c, hipStreamCreateWithPriority(&g->copy_stream, hipStreamNonBlocking, prio));
+        }
         MSIM_HIP(c, hipEventCreateWithFlags(&g->ev_cand, hipEventDisableTiming));
         for (auto &e : g->ev_piece) MSIM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : g->ev_cpiece) MSIM_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
