@@ -184,15 +184,20 @@ struct GpuPlan {
     // the words consumed since (the sampler's rejections and duplicates, the SNP draws' transversion loops), a hard lower bound
     hipStream_t prep_stream = nullptr;  //   the off-chain part of the samples: the stream of the sample being enqueued,
     hipStream_t prep_streams[8] = {};   //   one of these in turn (contigs' off-chain parts are independent of each other)
-    // THREE streams at NORMAL priority (round 6; four at the chain's priority in round 5).  Measured on one box, c2 3 Gb, ms per
-    // step of a rank that owns 0 / 3 / 12 of 24 contigs (tools/compat_steps.py, profiles/r06_prep_streams.txt):
+    // THREE streams at NORMAL priority + ONE in the low-priority pool (round 6; four at the chain's priority in round 5).  Measured
+    // on one box, c2 3 Gb, ms per step of a rank that owns 0 / 3 / 12 of 24 contigs (tools/compat_steps.py,
+    // profiles/r06_prep_streams.txt):
     //   4 at the chain's priority 2.27 / 2.46 / 3.45   3 there 2.24 / 2.46 / 3.62   2 there 2.11 / 2.93 / 4.03   1 there 2.00 / 4.35 / 5.3
-    //   4 normal 2.13 / 2.77 / 3.52   **3 normal 2.10 / 2.29 / 3.30**   2 normal 2.08 / 2.61 / 3.59   1 normal 1.98 / 3.8 / 4.6
-    // and three or more streams CREATED at the chain's priority slow every later pass of the context that has a host chain,
-    // for as long as the process lives (the SV-mix engine's plan spans 7.0 -> 10.0 ms per 3 Gb step, c3 30.8 -> 35.4 ms; the
-    // streams may be idle or destroyed, the hardware queues stay): bench.py measures c3 behind chain-only steps -- round 5's
-    // "regression" of c3 from 94 to 84 Gbases/s in the driver's line was this (NOTES section 10 has the bisect).
-    int n_prep = 3, prep_i = 0, prep_prio = 0;
+    //   4 normal 2.13 / 2.77 / 3.52   3 normal 2.10 / 2.29 / 3.30   2 normal 2.08 / 2.61 / 3.59   1 normal 1.98 / 3.8 / 4.6
+    // and for a rank that owns everything (profiles/r06_prep_stream_pools.txt): 3 normal 3.60-3.70, **3 normal + 1 low 3.43-3.62**,
+    // 2 normal + 1 low 3.77-3.82, 3 normal + 1 at the chain's priority 3.67-3.69, 3 normal + 2 low 4.0.
+    // What decides is the NUMBER of hardware queues the process holds (the runtime hands out up to four per priority, and they
+    // outlive the streams that asked for them): up to eight, fine; with the ninth every kernel launch of a later host-chain pass
+    // is ~6 us slower (the SV-mix engine's plan spans 7.0 -> 10.0 ms per 3 Gb step, c3 30 -> 35 ms) -- round 5's "regression" of
+    // c3 from 94 to 84 Gbases/s in the driver's line (bench.py measures c3 behind chain-only c2 steps) was this; NOTES section 10 has
+    // the bisect.  This context: plan (high) | emission, three side streams, [the SV-mix engine's copy stream shares] (normal) |
+    // generation, jump cascade, the fourth side stream (low) = eight.
+    int n_prep = 4, n_prep_low = 1, prep_i = 0, prep_prio = 0;
     double ahead_sigma = 8.0;
     uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
     // Who plans ahead.  Round 5: only a context that has been asked for msim_plan_chain in this pass or the last one (a rank that
@@ -231,7 +236,8 @@ GpuPlan *gpu_plan_create() {
     if (const char *e = getenv("MSIM_EMIT_TRAIN")) g->emit_train = atoi(e) == 3 ? 3 : atoi(e) == 6 ? 6 : 0;
     if (getenv("MSIM_NO_AHEAD")) g->ahead = 0;
     else if (const char *e = getenv("MSIM_AHEAD")) g->ahead = std::min(2, std::max(0, atoi(e)));
-    if (const char *e = getenv("MSIM_PREP_STREAMS")) g->n_prep = std::min(8, std::max(1, atoi(e)));
+    if (const char *e = getenv("MSIM_PREP_STREAMS")) { g->n_prep = std::min(8, std::max(1, atoi(e))); g->n_prep_low = 0; }
+    if (const char *e = getenv("MSIM_PREP_LOW")) g->n_prep_low = std::min(g->n_prep, std::max(0, atoi(e)));
     if (const char *e = getenv("MSIM_PREP_PRIO")) g->prep_prio = atoi(e);
     if (const char *e = getenv("MSIM_AHEAD_SIGMA")) g->ahead_sigma = std::min(16.0, std::max(0.0, atof(e)));
     return g;
@@ -969,7 +975,7 @@ static int enqueue_sample_ahead(Ctx *c, GpuPlan *g, const msim_range &r, int64_t
     if (!g->prep_streams[g->prep_i]) {
         int plo = 0, phi = 0;
         MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&plo, &phi));
-        const int prio = g->prep_prio > 0 ? plo : g->prep_prio < 0 ? phi : 0;
+        const int prio = g->prep_i >= g->n_prep - g->n_prep_low ? plo : g->prep_prio > 0 ? plo : g->prep_prio < 0 ? phi : 0;
         MSIM_HIP(c, hipStreamCreateWithPriority(&g->prep_streams[g->prep_i], hipStreamNonBlocking, prio));
         if (g->seed_ev[0]) MSIM_HIP(c, hipStreamWaitEvent(g->prep_streams[g->prep_i], g->seed_ev[0], 0));   // (the session's first 624 words are a copy)
     }
@@ -1498,15 +1504,15 @@ static int ensure_signals(Ctx *c, GpuPlan *g) {
         memset(g->h_sig, 0, 4096);
     }
     if (!g->copy_stream) {
-        {   // The candidates' copy stream lives in the LOW-priority pool of hardware queues (with the generation and the jump stream:
-            // three of that pool's four).  The runtime gives a process four queues per priority; at normal priority the context
-            // already has the emission stream and the three side streams of the anchored windows, and a fifth stream there shares
-            // a queue: behind c2 passes the SV-mix engine's step took 30.4-30.6 ms with this stream at normal priority, 29.7-30.0
-            // here (profiles/r06_copy_stream_priority.txt).  MSIM_COPY_PRIO=0 / -1: normal / the plan stream's priority.
+        {   // The candidates' copy stream: normal priority (MSIM_COPY_PRIO=1 / -1: the low-priority pool / the plan stream's).  The
+            // runtime gives a process four hardware queues per priority, and what matters more than a shared queue is how MANY the
+            // process has: with nine, every launch of a host-chain pass is ~6 us slower (GpuPlan::n_prep has the numbers).  At
+            // normal priority this stream shares one of the four queues there (behind c2 passes: 30.5-31.6 ms per c3 step against
+            // 29.7-30.0 with a queue of its own in the low pool -- which the fourth side stream now has).
             int lo = 0, hi = 0;
             MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
             const char *e = getenv("MSIM_COPY_PRIO");
-            const int prio = !e ? lo : atoi(e) > 0 ? lo : atoi(e) < 0 ? hi : 0;
+            const int prio = !e ? 0 : atoi(e) > 0 ? lo : atoi(e) < 0 ? hi : 0;
             MSIM_HIP(c, hipStreamCreateWithPriority(&g->copy_stream, hipStreamNonBlocking, prio));
         }
         MSIM_HIP(c, hipEventCreateWithFlags(&g->ev_cand, hipEventDisableTiming));
