@@ -1180,6 +1180,45 @@ int msim_dbg_stall(msim_ctx *p, int which, uint32_t ms) {
     return MSIM_OK;
 }
 
+// test support (tools/hw_queue_probe.py): n more streams at a priority (-1 the plan stream's, 0 normal, 1 the lowest), each used
+// once so that the runtime really gives it a hardware queue, kept until the process ends -- and the time of `launches` dependent
+// one-lane launches on the context's plan stream (ns per launch).  What it shows: how a process's NUMBER of hardware queues
+// changes the latency of every launch.
+int msim_dbg_queue_probe(msim_ctx *p, int n_more, int prio, int launches, int idle_us, double *ns_per_launch) {
+    Ctx *c = C(p);
+    if (!c || c->host_only || n_more < 0 || n_more > 64 || launches < 1 || !ns_per_launch) return MSIM_ERR_ARG;
+    int lo = 0, hi = 0;
+    MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    for (int i = 0; i < n_more; i++) {
+        hipStream_t s = nullptr;                               // (deliberately never destroyed)
+        MSIM_HIP(c, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio < 0 ? hi : prio > 0 ? lo : 0));
+        hipLaunchKernelGGL(k_dbg_stall, dim3(1), dim3(1), 0, s, 0ull);
+        MSIM_HIP(c, wait_stream(s));
+    }
+    for (int w = 0; w < 64; w++) hipLaunchKernelGGL(k_dbg_stall, dim3(1), dim3(1), 0, c->stream, 0ull);
+    MSIM_HIP(c, wait_stream(c->stream));
+    if (idle_us > 0) {
+        // a BURST of four dependent launches after the queue has idled for idle_us (what a host-chain engine does between two
+        // walks): launch -> completion of the burst, averaged over `launches` bursts
+        double sum = 0;
+        for (int i = 0; i < launches; i++) {
+            std::this_thread::sleep_for(std::chrono::microseconds(idle_us));
+            const auto b0 = std::chrono::steady_clock::now();
+            for (int q = 0; q < 4; q++) hipLaunchKernelGGL(k_dbg_stall, dim3(1), dim3(1), 0, c->stream, 0ull);
+            MSIM_HIP(c, wait_stream(c->stream));
+            sum += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - b0).count();
+        }
+        *ns_per_launch = sum / launches;
+        return MSIM_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < launches; i++) hipLaunchKernelGGL(k_dbg_stall, dim3(1), dim3(1), 0, c->stream, 0ull);
+    MSIM_HIP(c, hipGetLastError());
+    MSIM_HIP(c, wait_stream(c->stream));
+    *ns_per_launch = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / launches;
+    return MSIM_OK;
+}
+
 int msim_stats(msim_ctx *p, msim_timing *out) {
     CTX_FLUSHED(c, p)
     if (!c || !out) return MSIM_ERR_ARG;

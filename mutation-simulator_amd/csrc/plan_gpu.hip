@@ -191,12 +191,15 @@ struct GpuPlan {
     //   4 normal 2.13 / 2.77 / 3.52   3 normal 2.10 / 2.29 / 3.30   2 normal 2.08 / 2.61 / 3.59   1 normal 1.98 / 3.8 / 4.6
     // and for a rank that owns everything (profiles/r06_prep_stream_pools.txt): 3 normal 3.60-3.70, **3 normal + 1 low 3.43-3.62**,
     // 2 normal + 1 low 3.77-3.82, 3 normal + 1 at the chain's priority 3.67-3.69, 3 normal + 2 low 4.0.
-    // What decides is the NUMBER of hardware queues the process holds (the runtime hands out up to four per priority, and they
-    // outlive the streams that asked for them): up to eight, fine; with the ninth every kernel launch of a later host-chain pass
-    // is ~6 us slower (the SV-mix engine's plan spans 7.0 -> 10.0 ms per 3 Gb step, c3 30 -> 35 ms) -- round 5's "regression" of
-    // c3 from 94 to 84 Gbases/s in the driver's line (bench.py measures c3 behind chain-only c2 steps) was this; NOTES section 10 has
-    // the bisect.  This context: plan (high) | emission, three side streams, [the SV-mix engine's copy stream shares] (normal) |
-    // generation, jump cascade, the fourth side stream (low) = eight.
+    // Stream layouts are an EMPIRICAL matter on this runtime (up to four hardware queues per priority, which outlive the streams
+    // that asked for them), and a layout can slow every LATER pass of the process that has a host chain by ~6 us per kernel launch
+    // (the SV-mix engine's plan spans 7.0 -> 10.0 ms per 3 Gb step, c3 30 -> 35 ms): round 5's four streams at the chain's priority
+    // did (its "regression" of c3 from 94 to 84 Gbases/s in the driver's line, which measures c3 behind chain-only c2 steps), so do
+    // three there, a fourth stream in the low-priority pool beside this one's three (copy stream), GPU_MAX_HW_QUEUES >= 6.  Most
+    // of it reads as "nine queues in the process is one too many" (this context: plan | emission, three side streams, the SV-mix
+    // engine's copy stream sharing one of them | generation, jump cascade, the fourth side stream = eight) -- round 5's layout
+    // does not fit a pure count, and an isolated probe of launch latency against the number of streams shows nothing
+    // (tools/hw_queue_probe.py, profiles/r06_hw_queue_probe.txt): the effect needs the real kernels.  NOTES section 10 has every A/B.
     int n_prep = 4, n_prep_low = 1, prep_i = 0, prep_prio = 0;
     double ahead_sigma = 8.0;
     uint32_t prep_waited[8] = {};       //   ... already waited for the words of chunks below this (per stream)
@@ -1504,11 +1507,10 @@ static int ensure_signals(Ctx *c, GpuPlan *g) {
         memset(g->h_sig, 0, 4096);
     }
     if (!g->copy_stream) {
-        {   // The candidates' copy stream: normal priority (MSIM_COPY_PRIO=1 / -1: the low-priority pool / the plan stream's).  The
-            // runtime gives a process four hardware queues per priority, and what matters more than a shared queue is how MANY the
-            // process has: with nine, every launch of a host-chain pass is ~6 us slower (GpuPlan::n_prep has the numbers).  At
-            // normal priority this stream shares one of the four queues there (behind c2 passes: 30.5-31.6 ms per c3 step against
-            // 29.7-30.0 with a queue of its own in the low pool -- which the fourth side stream now has).
+        {   // The candidates' copy stream: normal priority (MSIM_COPY_PRIO=1 / -1: the low-priority pool / the plan stream's), where
+            // it shares a hardware queue with an (idle) side stream.  In the low pool it had a queue of its own and c3 behind c2
+            // passes gained 2 % (30.5 -> 29.8 ms) -- until the fourth side stream went there: both in the low pool cost c3 5 ms per
+            // step (GpuPlan::n_prep has the story).
             int lo = 0, hi = 0;
             MSIM_HIP(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
             const char *e = getenv("MSIM_COPY_PRIO");
