@@ -231,3 +231,48 @@ def test_config3_full_genome_length_identity():
         assert np.all(recs["pos"][1:].astype(np.int64) > span_end[:-1]) and span_end.max() < L
         eng.clear()
     eng.close()
+
+
+def test_contig_beyond_the_binned_sampler_vs_oracle():
+    """A 1.25 Gb contig, `-sn 0.01 -titv 2.0`: n = 1.2375e9 > 2^30, the reach of the binned sampler (1024 bins of 2^20 values) and of
+    the anchored windows -- its sample goes through the global-atomic path on the chain (k_accept_scatter / k_bitmap_insert), its
+    12.5 M records through the emission train (76 k tiles, 4.7 k super-blocks of counts) -- between two ordinary contigs, in the
+    bench's order, against the ORACLE (Fasta body, VCF text, both stream positions)."""
+    from test_gpu_bench_order import _bench_order_vs_oracle
+    lengths = [30_000_000, 1_250_000_000, 20_000_003]
+    st = _bench_order_vs_oracle("c2", lengths, {"contigs_snp": 3})
+    assert st["records"] == sum(int(L * 0.01) for L in lengths)
+    # (the first contig starts exact and the second is out of the anchored windows' reach: both sample on the chain; so does the
+    #  third -- 200 k draws are fewer than the uncertainty of a start behind 13 M draws and 12.5 M SNPs)
+    assert st["snp_samples_ahead"] == 0
+
+
+def test_contig_of_4_gib_is_refused_not_truncated():
+    """a contig of 2^32 bases or more would take CPython's multi-word getrandbits in random.sample (util.py:104) and
+    32-bit positions end there: MSIM_ERR_UNSUPPORTED at the door (the host package falls back to nothing -- it says so), never a
+    truncated length.  One base less is taken."""
+    with _ffi.Engine(0) as eng:
+        with pytest.raises(_ffi.MsimUnsupported, match="4 GiB"):
+            eng.add_contig_synthetic(1 << 32, 1)
+        cid = eng.add_contig_synthetic((1 << 32) - 1, 1)
+        assert cid == 0
+        sim = bench.workload_settings([(1 << 32) - 1], snp=0.0001)
+        eng.seed(3, 3)
+        eng.set_params(mm.params_descriptor(sim))
+        eng.plan_contig(cid, mm.plan_table(sim.chromosomes[0]))
+        eng.apply_contig(cid)
+        out_len, n_rec, _ = eng.result_sizes(cid)
+        assert out_len == (1 << 32) - 1 and n_rec == int(((1 << 32) - 1) * 0.0001)
+        recs, _ = eng.fetch_records(cid)
+        assert np.all(np.diff(recs["pos"].astype(np.int64)) >= 2) and int(recs["pos"][-1]) < (1 << 32) - 1
+
+
+@pytest.mark.parametrize("workload,engine", [("c3", "contigs_svmix"), ("c4", "contigs_hostcut"), ("c4sv", "contigs_hostchain")])
+def test_one_1250_mb_contig_through_the_host_chain_engines_vs_oracle(workload, engine):
+    """The engines with a host chain on ONE contig five times the largest human chromosome (10 M candidates of the SV mix and a
+    mutated length of 1.38 Gb; 14 k RMT ranges on one contig): word windows, accept tables, candidate and offset arrays at sizes
+    the 3 Gb genome never reaches per contig -- against the ORACLE, a small contig behind it (the streams must continue exactly)."""
+    from test_gpu_bench_order import _bench_order_vs_oracle
+    lengths = [1_250_000_000, 10_000_000]
+    st = _bench_order_vs_oracle(workload, lengths)
+    assert st[engine] >= 1, {k: v for k, v in st.items() if k.startswith("contigs_") and v}
